@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — rays/sec of the NeRF coarse+fine render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): one 800x800 view per GPU, 64 coarse +
+128 fine samples per ray, white background, perturb off, synthetic glorot weights (opaque
+variant), rays from the reference's pin-hole generator.  A "step" = one full pass of the hot path
+over one view's 640 000 rays per GPU: normalise -> gen_z -> coarse MLP -> composite ->
+hierarchical resample -> fine MLP -> composite.  Inputs are resident in HBM before the timed
+region.  N > 1: one process per GPU (torchrun), each rank renders its own view (rays are
+independent; no data-path collective) => weak scaling; value = all rays of all ranks / max time.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused NeRF MLP, MFMA-bound,
+algorithmic FLOPs / HIP-event kernel time) and, at N == 1, `cpu_baseline` (torch-CPU fp32 port of
+the reference op sequence on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+N_COARSE, N_FINE = 64, 128
+FLOP_PER_POINT = 2 * 593408          # 593 408 MAC per sample point
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_inputs(rank):
+    from tests import common
+    nets = common.nerf_nets(seed=0)
+    ang = 0.7 * rank
+    cam = (4 * np.cos(ang) * 0.8, 4 * np.sin(ang) * 0.8 - 0.1, 4 * 0.6)
+    rayo, rayd = common.camera_rays(H, W, cam_loc=cam)
+    return nets, rayo, rayd
+
+
+def render_step(ops, o, d_raw, blobs, ev=None):
+    d = ops.l2_normalize3(d_raw, 1e-12)
+    z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
+    if ev is not None:
+        ev[0].record()
+    raw = ops.nerf_mlp_fwd(o, d, z, blobs[0])
+    if ev is not None:
+        ev[1].record()
+    _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
+    z_all = ops.sample_fine(z, w, N_FINE)
+    if ev is not None:
+        ev[2].record()
+    raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1])
+    if ev is not None:
+        ev[3].record()
+    rgb, occu, depth, disp, _ = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)
+    return rgb
+
+
+def cpu_baseline(nets, rayo, rayd, budget_s=20.):
+    """torch-CPU fp32 port of the reference op sequence (oracle/torch_ref.py), all host cores."""
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tn = [torch_ref.to_torch_net(n) for n in nets]
+    idx = np.random.default_rng(0).permutation(rayo.shape[0])
+    with torch.no_grad():
+        n0 = 1024
+        o, d = torch.from_numpy(rayo[idx[:n0]]), torch.from_numpy(rayd[idx[:n0]])
+        t0 = time.perf_counter()
+        torch_ref.render_rays(o, d, tn[0], tn[1])
+        t_probe = time.perf_counter() - t0
+        n = int(min(65536, max(1024, n0 * budget_s / max(t_probe, 1e-3))))
+        n = (n // 1024) * 1024
+        o, d = torch.from_numpy(rayo[idx[:n]]), torch.from_numpy(rayd[idx[:n]])
+        t0 = time.perf_counter()
+        torch_ref.render_rays(o, d, tn[0], tn[1])
+        dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+        "sample": "%d rays of the same 800x800 view, 64+128 samples, torch-CPU fp32 "
+                  "(oracle/torch_ref.py, mlp_chunk=65536), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (
+            args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from nerfactor_amd import build
+    build.build()
+    from nerfactor_amd import ops
+
+    nets, rayo, rayd = synth_inputs(rank)
+    from tests import common
+    blobs = [ops.pack_nerf_weights(*common.nerf_layers(n)).to(dev) for n in nets]
+    o = torch.from_numpy(rayo).to(dev)
+    d = torch.from_numpy(rayd).to(dev)
+    n_rays = o.shape[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        render_step(ops, o, d, blobs)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        rgb = render_step(ops, o, d, blobs, evs[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(rgb).all()
+
+    # dominant kernel: the fused NeRF MLP (two launches per step: coarse + fine)
+    mlp_ms = [e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs]
+    fine_ms = [e[2].elapsed_time(e[3]) for e in evs]
+    pts_per_step = n_rays * (N_COARSE + N_COARSE + N_FINE)
+    mlp_avg_s = float(np.mean(mlp_ms)) * 1e-3
+    achieved = pts_per_step * FLOP_PER_POINT / mlp_avg_s / 1e12
+    fine_tf = n_rays * (N_COARSE + N_FINE) * FLOP_PER_POINT / (float(np.mean(fine_ms)) * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)",
+            "value": world * n_rays * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": "lego_3072-shaped NeRF coarse+fine MLP render, 800x800 rays per GPU, "
+                            "64+128 samples (BASELINE.json configs[1])",
+                "rays_per_step_per_gpu": n_rays, "n_samples_coarse": N_COARSE,
+                "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
+                "kernel_variant": os.environ.get("NFX_NERF_VARIANT", "1")},
+            "roofline": {
+                "bound": "mfma", "kernel": "nerf_mlp_bf16_kernel (coarse + fine launches)",
+                "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "flop_per_launch_pair": pts_per_step * FLOP_PER_POINT,
+                "avg_launch_pair_ms": mlp_avg_s * 1e3, "fine_launch_tflops": fine_tf,
+                "mlp_share_of_step": mlp_avg_s / (elapsed / args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nets, rayo, rayd)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

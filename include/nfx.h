@@ -1,0 +1,194 @@
+/*
+ * nfx.h — C-ABI of libnfx.so: the MI355X (gfx950) implementation of NeRFactor's
+ * per-ray rendering hot path.
+ *
+ * Every entry point replaces a cluster of TensorFlow ops in google/nerfactor; the
+ * reference site is cited per function as `file:line` relative to the reference
+ * tree.  Conventions (all entry points):
+ *
+ *   - plain pointers and sizes only; every pointer marked `dev` is DEVICE memory
+ *     owned by the caller (the host framework's allocator).  The library never
+ *     allocates, frees or synchronises device memory and enqueues work only on
+ *     the `stream` argument (a hipStream_t passed as void*; NULL = default stream).
+ *   - return value: NFX_OK (0) or a negative NFX_E* code; nfx_last_error() gives a
+ *     thread-local human-readable message for the last failure.
+ *   - all floating-point tensors are fp32, C-contiguous, ray-major, exactly the
+ *     layouts of the reference's flattened batch tuples
+ *     (nerfactor/datasets/nerf.py:96-104, nerfactor/datasets/nerf_shape.py:72-82).
+ *   - `prec`: NFX_PREC_BF16 = bf16 operands / fp32 accumulate on the MFMA path,
+ *     NFX_PREC_FP32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   - re-entrant: no global mutable state; concurrent calls on different streams
+ *     are legal.
+ */
+#ifndef NFX_H_
+#define NFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFX_OK 0
+#define NFX_EINVAL (-1)   /* bad shape / null pointer / unsupported dimension */
+#define NFX_EALIGN (-2)   /* pointer not aligned as required                  */
+#define NFX_EHIP (-3)     /* a HIP runtime call failed (see nfx_last_error)    */
+#define NFX_ENOSUP (-4)   /* configuration not supported by this build         */
+
+#define NFX_PREC_BF16 0
+#define NFX_PREC_FP32 1
+
+#define NFX_ACT_NONE 0
+#define NFX_ACT_RELU 1
+#define NFX_ACT_SIGMOID 2
+#define NFX_ACT_SOFTPLUS 3
+
+int nfx_version(void);
+/* Copies the calling thread's last error message (NUL-terminated) into buf. */
+int nfx_last_error(char *buf, size_t len);
+
+/* ------------------------------------------------------------------------ */
+/* Weight packing (host side, no GPU needed).                                */
+/* Keras Dense layout in: kernel [in, out] row-major fp32, bias [out]        */
+/* (nerfactor/networks/mlp.py:32-36).  Out: an opaque blob of MFMA A-operand  */
+/* fragments in consumption order + permuted biases, to be copied to the      */
+/* device verbatim.                                                           */
+/* ------------------------------------------------------------------------ */
+
+/* NeRF net of nerfactor/models/nerf.py:53-71 at the shipped configuration
+ * (config/nerf.ini:55-70): enc = 8x Dense(256, relu) with the input re-concatenated
+ * after layer 4 (mlp.py:47-48 puts y first: [y, x]); sigma_out Dense(1);
+ * bottleneck Dense(256); rgb_out Dense(128, relu) -> Dense(3).
+ * kernels[i]/biases[i], i = 0..7 enc layers, 8 sigma_out, 9 bottleneck,
+ * 10 rgb_out[0], 11 rgb_out[1].  n_freqs_xyz = 10, n_freqs_view = 4.        */
+size_t nfx_nerf_packed_bytes(int prec);
+int nfx_nerf_pack_weights(const float *const kernels[12], const float *const biases[12],
+                          int prec, void *blob, size_t blob_bytes);
+
+/* Width-128 surface MLP of nerfactor/models/shape.py:79-94 and
+ * nerfactor/models/nerfactor.py:128-143, models/brdf.py:57-66:
+ * `mlp` = 4x Dense(128, relu), input re-concatenated after layer 2 ([y, x]),
+ * followed by `out` = Dense(out_dim, act).
+ * in_kind selects the input encoding the kernel computes on the fly:
+ *   NFX_IN_XYZ        posenc10(xyz)                       63 dims (normal/albedo/brdf_z)
+ *   NFX_IN_XYZ_LDIR   [posenc10(xyz), posenc4(ldir)]      90 dims (light visibility)
+ *   NFX_IN_Z_RUSINK   [z(z_dim), posenc2(rusink)]         z_dim+15 dims (learned BRDF)
+ * kernels[0..3] the mlp layers, kernels[4] the out layer.                    */
+#define NFX_IN_XYZ 0
+#define NFX_IN_XYZ_LDIR 1
+#define NFX_IN_Z_RUSINK 2
+size_t nfx_mlp128_packed_bytes(int in_kind, int z_dim, int out_dim, int prec);
+int nfx_mlp128_pack_weights(const float *const kernels[5], const float *const biases[5],
+                            int in_kind, int z_dim, int out_dim, int prec, void *blob,
+                            size_t blob_bytes);
+
+/* ------------------------------------------------------------------------ */
+/* NeRF ray marching (nerfactor/models/nerf.py).                              */
+/* ------------------------------------------------------------------------ */
+
+/* rayd <- rayd * rsqrt(max(sum(rayd^2), eps))   (nerf.py:157, tf.linalg.l2_normalize,
+ * eps = 1e-12; shape.py:131,140 use eps = 1e-6 via util/math.py:63-64).      */
+int nfx_l2_normalize3(const float *dev_in, float *dev_out, int64_t n, float eps, void *stream);
+
+/* Stratified depths, Model.gen_z (nerf.py:120-136).  z [n_rays, n_samples].
+ * dev_u: NULL (no perturbation) or uniform [0,1) randoms [n_rays, n_samples]
+ * drawn by the caller (the reference draws them with tf.random.uniform).     */
+int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp,
+              const float *dev_u, float *dev_z, void *stream);
+
+/* Fused point generation + positional encoding + NeRF MLP,
+ * Model._eval_nerf_at (nerf.py:256-290) with pts = rayo + rayd * z (nerf.py:162-164)
+ * and views = rayd never materialised.  rayd must already be normalised.
+ * out: rgbs [n_rays, n_samples, 4] = (raw rgb, raw sigma) exactly as nerf.py:282. */
+int nfx_nerf_mlp_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z,
+                     int64_t n_rays, int n_samples, const void *dev_blob, int prec,
+                     float *dev_rgbs, void *stream);
+
+/* Volumetric compositing, Model.accumulate_sigma + Model._accumulate
+ * (nerf.py:184-254; util/math.py:67-68 safe_cumprod; util/img.py:76-95 alpha_blend).
+ * dev_noise: NULL or N(0,1)*noise_std already scaled, [n_rays, n_samples].
+ * Outputs (any may be NULL): rgb [n,3] (already blended onto bg = white_bg ? 1 : 0),
+ * occu [n], depth [n], disp [n], weights [n, n_samples].                     */
+int nfx_composite_fwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
+                      const float *dev_noise, int64_t n_rays, int n_samples, int white_bg,
+                      float *dev_rgb, float *dev_occu, float *dev_depth, float *dev_disp,
+                      float *dev_weights, void *stream);
+
+/* Hierarchical re-sampling, Model.gen_z_fine + inv_transform_sample
+ * (nerf.py:138-147; util/math.py:71-94): pdf over weights[:,1:-1], cdf,
+ * searchsorted(side='right'), lerp, then sort(concat(z_coarse, z_fine)).
+ * dev_u: NULL => deterministic u = linspace(0,1,n_fine); else [n_rays, n_fine].
+ * out: z_all [n_rays, n_coarse + n_fine] ascending.                          */
+int nfx_sample_fine(const float *dev_z, const float *dev_weights, int64_t n_rays, int n_coarse,
+                    int n_fine, const float *dev_u, float *dev_z_all, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* NeRFactor surface shading (nerfactor/models/{shape,nerfactor,*_microfacet}.py). */
+/* ------------------------------------------------------------------------ */
+
+/* Width-128 MLP on posenc10(xyz_scale * xyz): _pred_normal_at (shape.py:196-211),
+ * _pred_albedo_at (nerfactor.py:377-396), _pred_brdf_at (nerfactor.py:398-411).
+ * out [n, out_dim] = post_scale * act(out(mlp(pe))) + post_bias.             */
+int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const void *dev_blob,
+                       int out_dim, int out_act, float post_scale, float post_bias, int prec,
+                       float *dev_out, void *stream);
+
+/* Light-visibility MLP over the light sphere, _pred_lvis_at (shape.py:213-237) with the
+ * light directions of _calc_ldir (shape.py:128-135) recomputed in registers:
+ * lvis[n, l] = sigmoid(out(mlp([pe10(xyz_scale*xyz_n), pe4(normalize(lxyz_l - xyz_n))]))).
+ * dev_lxyz [n_lights, 3].  out [n, n_lights].                                */
+int nfx_lvis_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const float *dev_lxyz,
+                 int n_lights, const void *dev_blob, int prec, float *dev_lvis, void *stream);
+
+/* Fused shading integral, Model._render.integrate (nerfactor.py:315-365) with the
+ * analytic microfacet BRDF of brdf/microfacet/microfacet.py:30-111 evaluated in
+ * registers (nerfactor_microfacet.py:116-124), directions per shape.py:128-144:
+ *   rgb[n,p,c] = tonemap( sum_l brdf[n,l,c] * lvis[n,l]*[cos>0] * cos[n,l] * area[l] * light[p,l,c] )
+ * tonemap = clip(0,1) then optional linear2srgb (util/img.py:140-163).
+ * dev_spec: NULL => GGX microfacet with roughness dev_rough [n] and Fresnel f0;
+ *           else achromatic specular term [n, n_lights] (learned BRDF,
+ *           nerfactor.py:453-460) scaled by spec_scale; brdf = albedo/pi + spec.
+ * dev_lights [n_probes, n_lights, 3]: probe 0 is usually the trained light; the
+ * relighting loops of nerfactor.py:348-364 become the n_probes axis.
+ * out rgb [n, n_probes, 3].                                                  */
+int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                  const float *dev_albedo, const float *dev_rough, const float *dev_spec,
+                  float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
+                  const float *dev_lareas, const float *dev_lights, int64_t n, int n_lights,
+                  int n_probes, int linear2srgb, float *dev_rgb, void *stream);
+
+/* One-light-at-a-time relighting (nerfactor.py:79-84,348-354): light_l = inten*onehot(l)+ambient.
+ * out rgb_olat [n, n_lights, 3].                                             */
+int nfx_shade_olat_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                       const float *dev_albedo, const float *dev_rough, const float *dev_spec,
+                       float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
+                       const float *dev_lareas, float olat_inten, float ambient, int64_t n,
+                       int n_lights, int linear2srgb, float *dev_rgb_olat, void *stream);
+
+/* Learned-BRDF specular term, Model._eval_brdf_at (nerfactor.py:413-458):
+ * gen_world2local (util/geom.py:119-149), dir2rusink (util/geom.py:152-192),
+ * frozen BRDF MLP (models/brdf.py:57-66) on [z, pe2(rusink)], softplus;
+ * 0 for back-lit (local l.z <= 0) directions.  out spec [n, n_lights].       */
+int nfx_brdf_spec_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                      const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
+                      const void *dev_blob, int prec, int64_t n, float *dev_spec, void *stream);
+
+/* Rusinkiewicz coordinates (phi_d, theta_h, theta_d), util/geom.py:152-192. a,b [n,3]. */
+int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev_rusink,
+                   void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Diagnostics.                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* D[32,32] = A[32,16] * B[16,32] through one v_mfma_f32_32x32x16_bf16 with the operand
+ * lane maps documented in DESIGN.md; used by the GPU tests to pin the fragment layout. */
+int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
+/* out[i] = (which ? cos : sin)(in[i]) with the kernel's own range reduction.  */
+int nfx_selftest_sincos(const float *dev_in, int64_t n, int which, float *dev_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFX_H_ */

@@ -1,0 +1,70 @@
+"""ctypes binding of libnfx.so (include/nfx.h).  The library is mandatory: there is no Python or
+torch fallback for any hot-path op — a missing or stale .so raises at import of this module."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnfx.so')
+
+PREC_BF16, PREC_FP32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3
+IN_XYZ, IN_XYZ_LDIR, IN_Z_RUSINK = 0, 1, 2
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "%s not found: build it with `python -m nerfactor_amd.build` (or __graft_entry__.build()); "
+        "nerfactor_amd has no fallback path." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); every symbol declared in include/nfx.h
+SIGNATURES = {
+    'nfx_version': (_i, []),
+    'nfx_last_error': (_i, [ctypes.c_char_p, _sz]),
+    'nfx_nerf_packed_bytes': (_sz, [_i]),
+    'nfx_nerf_pack_weights': (_i, [_pp, _pp, _i, _p, _sz]),
+    'nfx_mlp128_packed_bytes': (_sz, [_i, _i, _i, _i]),
+    'nfx_mlp128_pack_weights': (_i, [_pp, _pp, _i, _i, _i, _i, _p, _sz]),
+    'nfx_l2_normalize3': (_i, [_p, _p, _i64, _f, _p]),
+    'nfx_gen_z': (_i, [_f, _f, _i, _i64, _i, _p, _p, _p]),
+    'nfx_nerf_mlp_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_composite_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'nfx_sample_fine': (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
+    'nfx_mlp128_xyz_fwd': (_i, [_p, _i64, _f, _p, _i, _i, _f, _f, _i, _p, _p]),
+    'nfx_lvis_fwd': (_i, [_p, _i64, _f, _p, _i, _p, _i, _p, _p]),
+    'nfx_shade_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
+    'nfx_shade_olat_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _f, _f, _i64, _i, _i, _p,
+                                _p]),
+    'nfx_brdf_spec_fwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p]),
+    'nfx_dir2rusink': (_i, [_p, _p, _i64, _p, _p]),
+    'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
+    'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class NfxError(RuntimeError):
+    """Raised for any non-zero return of the C-ABI; mirrors how the reference surfaces failures as
+    Python exceptions (tf.errors.InvalidArgumentError from tf.debugging.*)."""
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib.nfx_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NfxError("%s failed (%d): %s" % (what, rc, last_error()))

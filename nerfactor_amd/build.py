@@ -1,0 +1,71 @@
+"""Builds nerfactor_amd/libnfx.so (gfx950 only) with hipcc.  No torch involved: the library is a
+plain HIP shared object behind the C-ABI of include/nfx.h.
+
+    python -m nerfactor_amd.build [--force] [--verbose]
+
+Objects are cached under build/ (git-ignored) keyed on source + header mtimes; the .so stays
+in-tree so it travels to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OBJDIR = os.path.join(ROOT, 'build', 'obj')
+LIB = os.path.join(HERE, 'libnfx.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -ffp-contract=off: the fp32 stages follow the reference's op order (mul then add), fused
+# multiply-adds appear only where written as fmaf().
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+         '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include')]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
+    hs.append(os.path.join(ROOT, 'include', 'nfx.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force, verbose):
+    obj = os.path.join(OBJDIR, src + '.o')
+    spath = os.path.join(CSRC, src)
+    newest = max(os.path.getmtime(spath), _headers_mtime())
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ['-x', 'hip', '-c', spath, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError('hipcc failed on %s:\n%s' % (src, res.stdout))
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('link failed:\n' + res.stdout)
+    return LIB
+
+
+if __name__ == '__main__':
+    path = build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv)
+    print(path)

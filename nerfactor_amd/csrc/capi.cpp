@@ -1,0 +1,179 @@
+// capi.cpp — the C-ABI of libnfx.so (include/nfx.h): argument validation, error reporting and
+// dispatch to the kernel launchers.  No device allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nfx.h"
+#include "nerf_layout.hpp"
+#include "pack.hpp"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int hip_result(int e, const char* what) {
+    if (e == 0) return NFX_OK;
+    return fail(NFX_EHIP, "%s: HIP error %d (%s)", what, e, hipGetErrorString((hipError_t)e));
+}
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return fail(NFX_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
+
+extern "C" {
+// launchers (defined in the .hip files)
+int nfx_launch_nerf_mlp_bf16(const float*, const float*, const float*, long long, int, const void*,
+                             float*, int, int, hipStream_t);
+int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
+int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
+int nfx_launch_composite(const float*, const float*, const float*, const float*, long long, int, int,
+                         float*, float*, float*, float*, float*, hipStream_t);
+int nfx_launch_sample_fine(const float*, const float*, long long, int, int, const float*, float*,
+                           hipStream_t);
+int nfx_launch_selftest_mfma(const float*, const float*, float*, hipStream_t);
+int nfx_launch_selftest_sincos(const float*, long long, int, float*, hipStream_t);
+
+int nfx_version(void) { return 100; }
+
+int nfx_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return NFX_EINVAL;
+    strncpy(buf, g_err, len - 1);
+    buf[len - 1] = 0;
+    return NFX_OK;
+}
+
+// Tuning knobs (process-wide, read-only after first use): kernel variant and persistent grid size.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// --------------------------------------------------------------------------- packing
+size_t nfx_nerf_packed_bytes(int prec) {
+    if (prec == NFX_PREC_BF16) return nfx::nerf::kBlobBytes;
+    return 0;
+}
+
+int nfx_nerf_pack_weights(const float* const kernels[12], const float* const biases[12], int prec,
+                          void* blob, size_t blob_bytes) {
+    using namespace nfx;
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_weights: null argument");
+    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_weights: layer %d null", i);
+    if (prec == NFX_PREC_FP32) return fail(NFX_ENOSUP, "nfx_nerf_pack_weights: fp32 path not built yet");
+    REQUIRE(prec == NFX_PREC_BF16, "nfx_nerf_pack_weights: bad prec %d", prec);
+    REQUIRE(blob_bytes >= nfx_nerf_packed_bytes(prec), "nfx_nerf_pack_weights: blob too small (%zu < %zu)",
+            blob_bytes, nfx_nerf_packed_bytes(prec));
+    uint8_t* w = static_cast<uint8_t*>(blob);
+    float* b = reinterpret_cast<float*>(w + nerf::kWeightBytes);
+    const Seg pe_xyz{kPosEnc, 10, 0, nullptr};
+    const Seg hid256{kHidden, 256, 0, nullptr};
+    // enc[0]: posenc(xyz) 63 -> 256
+    w += pack_layer_bf16({pe_xyz}, {{kernels[0], biases[0], 256}}, 8, 4, w, b + nerf::kBiasL0);
+    for (int l = 1; l <= 7; ++l) {
+        float* bl = b + nerf::kBiasL0 + 256 * l;
+        if (l == 5) {  // input = concat(y[256], posenc(xyz)[63])   (mlp.py:47-48)
+            const Seg pe_skip{kPosEnc, 10, 256, nullptr};
+            w += pack_layer_bf16({hid256, pe_skip}, {{kernels[5], biases[5], 256}}, 8, 20, w, bl);
+        } else {
+            w += pack_layer_bf16({hid256}, {{kernels[l], biases[l], 256}}, 8, 16, w, bl);
+        }
+    }
+    // fused [bottleneck (256 cols) | sigma_out (1 col)] on the encoder output
+    w += pack_layer_bf16({hid256}, {{kernels[9], biases[9], 256}, {kernels[8], biases[8], 1}}, 9, 16, w,
+                         b + nerf::kBiasBott);
+    // rgb_out[0]: concat(bottleneck[256], posenc(view)[27]) -> 128
+    const Seg pe_view{kPosEnc, 4, 256, nullptr};
+    w += pack_layer_bf16({hid256, pe_view}, {{kernels[10], biases[10], 128}}, 4, 20, w, b + nerf::kBiasRgb0);
+    // rgb_out[1]: 128 -> 3
+    const Seg hid128{kHidden, 128, 0, nullptr};
+    w += pack_layer_bf16({hid128}, {{kernels[11], biases[11], 3}}, 1, 8, w, b + nerf::kBiasRgb1);
+    if (w != static_cast<uint8_t*>(blob) + nerf::kWeightBytes)
+        return fail(NFX_EINVAL, "nfx_nerf_pack_weights: internal layout mismatch");
+    return NFX_OK;
+}
+
+// ------------------------------------------------------------------------ NeRF path
+int nfx_l2_normalize3(const float* in, float* out, int64_t n, float eps, void* stream) {
+    REQUIRE(n >= 0, "nfx_l2_normalize3: n < 0");
+    REQUIRE(n == 0 || (in && out), "nfx_l2_normalize3: null pointer");
+    return hip_result(nfx_launch_l2_normalize3(in, out, n, eps, (hipStream_t)stream), "l2_normalize3");
+}
+
+int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp, const float* u,
+              float* z, void* stream) {
+    REQUIRE(n_samples >= 2, "nfx_gen_z: n_samples must be >= 2 (got %d)", n_samples);
+    REQUIRE(n_rays >= 0, "nfx_gen_z: n_rays < 0");
+    REQUIRE(n_rays == 0 || z, "nfx_gen_z: null output");
+    return hip_result(nfx_launch_gen_z(near, far, n_samples, n_rays, lin_in_disp, u, z, (hipStream_t)stream),
+                      "gen_z");
+}
+
+int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                     const void* blob, int prec, float* rgbs, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_mlp_fwd: bad shape (%lld rays, %d samples)",
+            (long long)n_rays, n_samples);
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && blob && rgbs, "nfx_nerf_mlp_fwd: null pointer");
+    if (!ALIGNED(blob, 16) || !ALIGNED(rgbs, 16))
+        return fail(NFX_EALIGN, "nfx_nerf_mlp_fwd: blob and rgbs must be 16-byte aligned");
+    const long long n_pts = (long long)n_rays * n_samples;
+    const int blocks = env_int("NFX_NERF_BLOCKS", 256);
+    if (prec == NFX_PREC_BF16) {
+        const int variant = env_int("NFX_NERF_VARIANT", 1);
+        return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
+                                                   blocks, (hipStream_t)stream),
+                          "nerf_mlp_fwd(bf16)");
+    }
+    if (prec == NFX_PREC_FP32) return fail(NFX_ENOSUP, "nfx_nerf_mlp_fwd: fp32 path not built yet");
+    return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: bad prec %d", prec);
+}
+
+int nfx_composite_fwd(const float* rgbs, const float* z, const float* rayd, const float* noise,
+                      int64_t n_rays, int n_samples, int white_bg, float* rgb, float* occu, float* depth,
+                      float* disp, float* weights, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_composite_fwd: bad shape");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rgbs && z && rayd, "nfx_composite_fwd: null input");
+    if (!ALIGNED(rgbs, 16)) return fail(NFX_EALIGN, "nfx_composite_fwd: rgbs must be 16-byte aligned");
+    return hip_result(nfx_launch_composite(rgbs, z, rayd, noise, n_rays, n_samples, white_bg, rgb, occu,
+                                           depth, disp, weights, (hipStream_t)stream),
+                      "composite_fwd");
+}
+
+int nfx_sample_fine(const float* z, const float* weights, int64_t n_rays, int n_coarse, int n_fine,
+                    const float* u, float* z_all, void* stream) {
+    REQUIRE(n_rays >= 0, "nfx_sample_fine: n_rays < 0");
+    REQUIRE(n_coarse >= 3 && n_fine >= 2, "nfx_sample_fine: need n_coarse >= 3 and n_fine >= 2 (got %d, %d)",
+            n_coarse, n_fine);
+    REQUIRE((size_t)4 * (2 * (n_coarse - 1) + n_coarse + n_fine) * 4 <= 64 * 1024,
+            "nfx_sample_fine: n_coarse + n_fine too large for one workgroup's LDS");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(z && weights && z_all, "nfx_sample_fine: null pointer");
+    return hip_result(
+        nfx_launch_sample_fine(z, weights, n_rays, n_coarse, n_fine, u, z_all, (hipStream_t)stream),
+        "sample_fine");
+}
+
+// --------------------------------------------------------------------- diagnostics
+int nfx_selftest_mfma_bf16(const float* a, const float* b, float* d, void* stream) {
+    REQUIRE(a && b && d, "nfx_selftest_mfma_bf16: null pointer");
+    return hip_result(nfx_launch_selftest_mfma(a, b, d, (hipStream_t)stream), "selftest_mfma");
+}
+int nfx_selftest_sincos(const float* in, int64_t n, int which, float* out, void* stream) {
+    REQUIRE(n >= 0 && (n == 0 || (in && out)), "nfx_selftest_sincos: bad arguments");
+    return hip_result(nfx_launch_selftest_sincos(in, n, which, out, (hipStream_t)stream), "selftest_sincos");
+}
+
+}  // extern "C"

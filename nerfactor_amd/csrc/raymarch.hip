@@ -1,0 +1,219 @@
+// raymarch.hip — the non-MLP stages of vanilla-NeRF ray marching (all HBM-bound, fp32):
+//   l2_normalize3   tf.linalg.l2_normalize                        nerf.py:157, util/math.py:63-64
+//   gen_z           Model.gen_z                                   nerf.py:120-136
+//   composite       Model.accumulate_sigma + Model._accumulate    nerf.py:184-254, util/math.py:67-68,
+//                                                                 util/img.py:76-95
+//   sample_fine     inv_transform_sample + Model.gen_z_fine       util/math.py:71-94, nerf.py:138-147
+// One wave (64 lanes) per ray for composite / sample_fine: the samples of a ray sit on the lanes,
+// loads are one contiguous 256-B / 1-KiB segment per wave, scans and reductions are wave shuffles.
+#include "nfx_common.hpp"
+
+namespace nfx {
+
+__global__ void l2_normalize3_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                     long long n, float eps) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    const float sq = x * x + y * y + z * z;
+    const float inv = 1.0f / sqrtf(fmaxf(sq, eps));
+    out[3 * i] = x * inv;
+    out[3 * i + 1] = y * inv;
+    out[3 * i + 2] = z * inv;
+}
+
+// tf.linspace(0,1,n)[i] = i * (1/(n-1)) in fp32 (TF 2.2 LinSpace CPU kernel: start + step*i).
+__device__ __forceinline__ float linspace01(int i, int n) { return (float)i * (1.0f / (float)(n - 1)); }
+
+__device__ __forceinline__ float z_of_t(float t, float near, float far, int lin_in_disp) {
+    if (lin_in_disp) return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+    return near * (1.0f - t) + far * t;
+}
+
+__global__ void gen_z_kernel(float near, float far, int n_samples, long long n_rays,
+                             int lin_in_disp, const float* __restrict__ u, float* __restrict__ z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n_samples) return;
+    const int s = (int)(i % n_samples);
+    const float zc = z_of_t(linspace01(s, n_samples), near, far, lin_in_disp);
+    if (u == nullptr) {
+        z[i] = zc;
+        return;
+    }
+    // nerf.py:130-135: jitter inside [lower, upper] = midpoints to the neighbours
+    const float zl = s > 0 ? z_of_t(linspace01(s - 1, n_samples), near, far, lin_in_disp) : zc;
+    const float zu = s < n_samples - 1 ? z_of_t(linspace01(s + 1, n_samples), near, far, lin_in_disp) : zc;
+    const float lower = s > 0 ? 0.5f * (zc + zl) : zc;
+    const float upper = s < n_samples - 1 ? 0.5f * (zu + zc) : zc;
+    z[i] = lower + (upper - lower) * u[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// composite: block = 256 threads = 4 rays (one wave each).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_kernel(
+    const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rayd,
+    const float* __restrict__ noise, long long n_rays, int S, float bg, float* __restrict__ rgb_out,
+    float* __restrict__ occu_out, float* __restrict__ depth_out, float* __restrict__ disp_out,
+    float* __restrict__ w_out) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;  // wave-uniform
+    const float dx = rayd[3 * ray], dy = rayd[3 * ray + 1], dz = rayd[3 * ray + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);  // nerf.py:192-193
+    const long long base = ray * S;
+    float carry = 1.0f;  // running exclusive product of (1 - alpha + 1e-6)
+    float s_w = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_d = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const float4 raw = rgbs[base + sc];
+        const float zc = z[base + sc];
+        const float zn = (sc < S - 1) ? z[base + sc + 1] : 0.f;
+        float dist = (sc < S - 1) ? (zn - zc) : 1e10f;  // nerf.py:188-191
+        dist = dist * dnorm;
+        float sg = raw.w;
+        if (noise) sg = sg + noise[base + sc];
+        const float alpha = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);  // nerf.py:199-200
+        float t = valid ? (1.0f - alpha + 1e-6f) : 1.0f;            // util/math.py:67-68
+        // inclusive product scan across the wave
+        float incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float w = valid ? alpha * (carry * excl) : 0.0f;
+        carry = carry * __shfl(incl, 63, 64);
+        if (w_out && valid) w_out[base + s] = w;
+        s_w += w;
+        s_r += w * sigmoidf(raw.x);  // nerf.py:223,234-235
+        s_g += w * sigmoidf(raw.y);
+        s_b += w * sigmoidf(raw.z);
+        s_d += w * zc;               // nerf.py:237-238
+    }
+    s_w = wave_sum(s_w);
+    s_r = wave_sum(s_r);
+    s_g = wave_sum(s_g);
+    s_b = wave_sum(s_b);
+    s_d = wave_sum(s_d);
+    if (lane == 0) {
+        if (rgb_out) {  // nerf.py:252-253 + util/img.py:95: rgb*occu + bg*(1-occu)
+            const float k = 1.0f - s_w;
+            rgb_out[3 * ray] = s_r * s_w + bg * k;
+            rgb_out[3 * ray + 1] = s_g * s_w + bg * k;
+            rgb_out[3 * ray + 2] = s_b * s_w + bg * k;
+        }
+        if (occu_out) occu_out[ray] = s_w;
+        if (depth_out) depth_out[ray] = s_d;
+        if (disp_out) disp_out[ray] = 1.0f / fmaxf(s_d, 1e-10f);  // nerf.py:240-241
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sample_fine: block = 256 threads = 4 rays.  Dynamic LDS per wave:
+//   cdf[nc-1], mid[nc-1], zall[nc+nf]   (floats)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_fine_kernel(
+    const float* __restrict__ z, const float* __restrict__ weights, long long n_rays, int nc, int nf,
+    const float* __restrict__ u, float* __restrict__ z_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = nc - 2;          // pdf bins = weights[:, 1:-1]        (nerf.py:142)
+    const int ncdf = nc - 1;        // cdf entries = mids                 (util/math.py:76)
+    const int ntot = nc + nf;
+    const int per_wave = 2 * ncdf + ntot;
+    float* cdf = smem + wave * per_wave;
+    float* mid = cdf + ncdf;
+    float* zall = mid + ncdf;
+    const long long ray = (long long)blockIdx.x * 4 + wave;
+    const bool active = ray < n_rays;
+    const long long rc = active ? ray : n_rays - 1;
+    const float* zr = z + rc * nc;
+    const float* wr = weights + rc * nc;
+
+    for (int i = lane; i < nc; i += 64) zall[i] = zr[i];
+    for (int i = lane; i < ncdf; i += 64) mid[i] = 0.5f * (zr[i + 1] + zr[i]);  // nerf.py:140
+    if (lane == 0) {
+        // util/math.py:72-76, sequential left-to-right sums (matches the oracle's order)
+        float denom = 0.f;
+        for (int i = 0; i < nb; ++i) denom += wr[1 + i];
+        denom += 1e-5f;
+        float acc = 0.f;
+        cdf[0] = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            acc += wr[1 + i] / denom;
+            cdf[1 + i] = acc;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nf; i += 64) {
+        const float uu = u ? u[rc * nf + i] : linspace01(i, nf);
+        // searchsorted(side='right') = #(cdf <= u); cdf is non-decreasing
+        int lo = 0, hi = ncdf;
+        while (lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if (cdf[m] <= uu) lo = m + 1; else hi = m;
+        }
+        const int ind = lo;
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < ncdf - 1 ? ind : ncdf - 1;
+        const float cb = cdf[below], ca = cdf[above];
+        float den = ca - cb;
+        den = den < 1e-5f ? 1.0f : den;
+        const float t = (uu - cb) / den;
+        const float vb = mid[below], va = mid[above];
+        zall[nc + i] = vb + t * (va - vb);
+    }
+    __syncthreads();
+    // tf.sort(concat(z_coarse, z_fine)) by ranking: exact for any input order, ties by index.
+    for (int i = lane; i < ntot; i += 64) {
+        const float v = zall[i];
+        int rank = 0;
+        for (int j = 0; j < ntot; ++j) {
+            const float o = zall[j];
+            rank += (o < v) || (o == v && j < i);
+        }
+        if (active) z_all[ray * ntot + rank] = v;
+    }
+}
+
+}  // namespace nfx
+
+extern "C" {
+int nfx_launch_l2_normalize3(const float* in, float* out, long long n, float eps, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(nfx::l2_normalize3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       in, out, n, eps);
+    return (int)hipGetLastError();
+}
+int nfx_launch_gen_z(float near, float far, int n_samples, long long n_rays, int lin_in_disp,
+                     const float* u, float* z, hipStream_t st) {
+    const long long tot = n_rays * n_samples;
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(nfx::gen_z_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, near,
+                       far, n_samples, n_rays, lin_in_disp, u, z);
+    return (int)hipGetLastError();
+}
+int nfx_launch_composite(const float* rgbs, const float* z, const float* rayd, const float* noise,
+                         long long n_rays, int S, int white_bg, float* rgb, float* occu, float* depth,
+                         float* disp, float* w, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(nfx::composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st,
+                       (const float4*)rgbs, z, rayd, noise, n_rays, S, white_bg ? 1.0f : 0.0f, rgb,
+                       occu, depth, disp, w);
+    return (int)hipGetLastError();
+}
+int nfx_launch_sample_fine(const float* z, const float* w, long long n_rays, int nc, int nf,
+                           const float* u, float* z_all, hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    const size_t lds = (size_t)4 * (2 * (nc - 1) + nc + nf) * sizeof(float);
+    hipLaunchKernelGGL(nfx::sample_fine_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, st,
+                       z, w, n_rays, nc, nf, u, z_all);
+    return (int)hipGetLastError();
+}
+}

@@ -1,0 +1,31 @@
+"""Shared synthetic-input generators for tests, smoke() and bench.py."""
+import numpy as np
+
+from oracle import nerf_ref
+
+
+def nerf_nets(seed=0, opaque=True, random_bias=True):
+    """Coarse + fine NeRF nets, glorot-uniform; 'opaque' scales sigma_out so rays terminate."""
+    rng = np.random.default_rng(seed)
+    nets = []
+    for _ in range(2):
+        net = nerf_ref.init_nerf_net(rng, sigma_bias=0.5 if opaque else 0.,
+                                     sigma_gain=8. if opaque else 1.)
+        if random_bias:
+            sb = net['sigma_out'][0][1].copy()
+            nerf_ref.randomize_biases(net, rng)
+            net['sigma_out'][0] = (net['sigma_out'][0][0], sb + net['sigma_out'][0][1])
+        nets.append(net)
+    return nets
+
+
+def nerf_layers(net):
+    """The 12 (kernel, bias) pairs in the order of nfx_nerf_pack_weights."""
+    layers = list(net['enc']) + [net['sigma_out'][0], net['bottleneck'][0]] + list(net['rgb_out'])
+    return [k for k, _ in layers], [b for _, b in layers]
+
+
+def camera_rays(imh, imw, cam_loc=(2.4, -2.6, 1.8), angle_x=0.6911):
+    c2w = nerf_ref.lookat_cam_to_world(np.asarray(cam_loc) * 4. / np.linalg.norm(cam_loc))
+    rayo, rayd = nerf_ref.gen_rays(c2w, angle_x, imh, imw)
+    return rayo.reshape(-1, 3).astype(np.float32), rayd.reshape(-1, 3).astype(np.float32)

@@ -1,0 +1,215 @@
+"""GPU parity suite, NeRF stage: libnfx (through the C-ABI) vs the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.md §4 / SURVEY.md §8d):
+  * fp32 stages (sampling, compositing): reassociation only -> 1e-5 absolute.
+  * bf16-MFMA MLP vs the oracle run with the SAME bf16 operand rounding: 4e-3 (fp32 accumulation
+    order + rare 1-ulp bf16 flips of activations) — this pins the kernel's logic.
+  * bf16-MFMA end-to-end vs the fp32 oracle: PSNR >= 40 dB (uint8 luma) and max-abs <= 3e-2 on rgb.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_ref
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+
+
+def test_mfma_fragment_layout(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(0)
+    a = nerf_ref.bf16_round(rng.normal(size=(32, 16)).astype(np.float32))
+    b = nerf_ref.bf16_round(rng.normal(size=(16, 32)).astype(np.float32))  # asymmetric
+    d = ops.selftest_mfma_bf16(dev(a, cuda), dev(b, cuda)).cpu().numpy()
+    np.testing.assert_allclose(d, a.astype(np.float64) @ b.astype(np.float64), atol=1e-5)
+
+
+def test_sincos_range_reduction(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-3100, 3100, 200000), rng.uniform(-4, 4, 50000),
+                        np.array([0., np.pi / 4, np.pi / 2, np.pi, 1e-8, -1e-8, 3071.9])])
+    x = x.astype(np.float32)
+    for which, fn in ((0, np.sin), (1, np.cos)):
+        got = ops.selftest_sincos(dev(x, cuda), which).cpu().numpy()
+        err = np.abs(got - fn(x.astype(np.float64)))
+        assert err.max() < 4e-7, (which, err.max())
+
+
+def test_normalize_and_gen_z(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(1000, 3)).astype(np.float32)
+    d[0] = 0  # zero direction: eps guards the rsqrt
+    got = ops.l2_normalize3(dev(d, cuda), 1e-12).cpu().numpy()
+    np.testing.assert_allclose(got, nerf_ref.l2_normalize(d, 1, 1e-12), atol=2e-7)
+    for lin in (False, True):
+        z = ops.gen_z(2., 6., 64, 37, lin_in_disp=lin, device=cuda).cpu().numpy()
+        np.testing.assert_allclose(z, nerf_ref.gen_z(2., 6., 64, 37, lin), atol=1e-6)
+        u = rng.uniform(size=(37, 64)).astype(np.float32)
+        z = ops.gen_z(2., 6., 64, 37, lin_in_disp=lin, u=dev(u, cuda), device=cuda).cpu().numpy()
+        np.testing.assert_allclose(z, nerf_ref.gen_z(2., 6., 64, 37, lin, u=u), atol=1e-6)
+    assert ops.gen_z(2., 6., 64, 0, device=cuda).shape == (0, 64)  # empty batch
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("n_rays,n_samples", [(1, 64), (300, 64), (77, 192), (4, 5)])
+def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monkeypatch):
+    from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_NERF_VARIANT", variant)
+    rng = np.random.default_rng(10 + n_rays)
+    net = common.nerf_nets(seed=7)[0]
+    ks, bs = common.nerf_layers(net)
+    blob = ops.pack_nerf_weights(ks, bs).to(cuda)
+    rayo = rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32) * 3
+    rayd = nerf_ref.l2_normalize(rng.normal(size=(n_rays, 3)).astype(np.float32), 1, 1e-12)
+    z = np.sort(rng.uniform(2, 6, size=(n_rays, n_samples)).astype(np.float32), -1)
+    got = ops.nerf_mlp_fwd(dev(rayo, cuda), dev(rayd, cuda), dev(z, cuda), blob).cpu().numpy()
+    pts = rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]
+    views = np.broadcast_to(rayd[:, None, :], pts.shape)
+    want_q = nerf_ref.eval_nerf_at(pts, views, net, quant=nerf_ref.bf16_round)
+    want = nerf_ref.eval_nerf_at(pts, views, net)
+    assert got.shape == (n_rays, n_samples, 4) and np.all(np.isfinite(got))
+    assert np.max(np.abs(got - want_q)) < 4e-3 * max(1., np.abs(want_q).max())
+    assert np.max(np.abs(got - want)) < 0.2  # raw logits / 8x-scaled sigma, pre-activation
+
+
+def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch):
+    """More tiles than workgroups (persistent loop, wrapped weight stream) must equal tile-by-tile."""
+    from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_NERF_BLOCKS", "3")
+    rng = np.random.default_rng(3)
+    net = common.nerf_nets(seed=8)[1]
+    blob = ops.pack_nerf_weights(*common.nerf_layers(net)).to(cuda)
+    n = 200
+    rayo = dev(rng.uniform(-2, 2, size=(n, 3)), cuda)
+    rayd = dev(nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12), cuda)
+    z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
+    full = ops.nerf_mlp_fwd(rayo, rayd, z, blob)
+    monkeypatch.setenv("NFX_NERF_BLOCKS", "256")
+    part = torch.cat([ops.nerf_mlp_fwd(rayo[i:i + 50], rayd[i:i + 50], z[i:i + 50], blob)
+                      for i in range(0, n, 50)])
+    assert torch.equal(full, part)
+
+
+@pytest.mark.parametrize("n_samples", [64, 192, 7])
+def test_composite_vs_oracle(nfx_lib, cuda, n_samples):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(4)
+    n = 129
+    rgbs = rng.normal(size=(n, n_samples, 4)).astype(np.float32) * 2
+    rgbs[:10, :, 3] = -1.  # empty rays
+    rgbs[10:20, :, 3] = 50.  # opaque at the first sample
+    z = np.sort(rng.uniform(2, 6, size=(n, n_samples)).astype(np.float32), -1)
+    rayd = nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12)
+    noise = rng.normal(size=(n, n_samples)).astype(np.float32)
+    for white_bg, nz in ((True, None), (False, noise)):
+        got = ops.composite_fwd(dev(rgbs, cuda), dev(z, cuda), dev(rayd, cuda), white_bg=white_bg,
+                                noise=None if nz is None else dev(nz, cuda))
+        want = nerf_ref.accumulate(rgbs, z, rayd, white_bg=white_bg, noise=nz)
+        for name, g, w in zip(('rgb', 'occu', 'depth', 'disp', 'weights'), got, want):
+            g = g.cpu().numpy()
+            if name == 'disp':  # 1/max(depth, 1e-10): compare relatively
+                np.testing.assert_allclose(g, w, rtol=2e-4)
+            else:
+                np.testing.assert_allclose(g, w, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("nc,nf", [(64, 128), (16, 8), (128, 320)])
+def test_sample_fine_vs_oracle(nfx_lib, cuda, nc, nf):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(5)
+    n = 67
+    z = nerf_ref.gen_z(2., 6., nc, n, u=rng.uniform(size=(n, nc)).astype(np.float32))
+    w = (rng.uniform(size=(n, nc)).astype(np.float32) ** 6)
+    w[0] = 0  # empty ray
+    w[1] = 0
+    w[1, nc // 2] = 1  # delta
+    for u in (None, rng.uniform(size=(n, nf)).astype(np.float32)):
+        got = ops.sample_fine(dev(z, cuda), dev(w, cuda), nf,
+                              u=None if u is None else dev(u, cuda)).cpu().numpy()
+        want = nerf_ref.gen_z_fine(z, w, nf, u=u)
+        assert got.shape == (n, nc + nf)
+        assert np.all(np.diff(got, axis=1) >= 0)
+        np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+def _render_device(rayo, rayd, nets, cuda, n_fine=128):
+    from nerfactor_amd import ops
+    blobs = [ops.pack_nerf_weights(*common.nerf_layers(n)).to(cuda) for n in nets]
+    o, d = dev(rayo, cuda), ops.l2_normalize3(dev(rayd, cuda), 1e-12)
+    z = ops.gen_z(2., 6., 64, o.shape[0], device=cuda)
+    raw = ops.nerf_mlp_fwd(o, d, z, blobs[0])
+    rgb_c, occu_c, depth_c, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
+    z_all = ops.sample_fine(z, w, n_fine)
+    raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1])
+    rgb_f, occu_f, depth_f, _, _ = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)
+    return dict(rgb_c=rgb_c, occu_c=occu_c, depth_c=depth_c, z_all=z_all, rgb_f=rgb_f,
+                occu_f=occu_f, depth_f=depth_f)
+
+
+def test_full_render_vs_fp32_oracle(nfx_lib, cuda):
+    """48x48 view, 64+128 samples, opaque-variant weights: the stated end-to-end tolerance."""
+    nets = common.nerf_nets(seed=0)
+    rayo, rayd = common.camera_rays(48, 48)
+    got = {k: v.cpu().numpy() for k, v in _render_device(rayo, rayd, nets, cuda).items()}
+    coarse, fine, aux = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1])
+    assert float(np.mean(coarse['occu'])) > 0.05
+    for tag, ref in (('c', coarse), ('f', fine)):
+        err = np.abs(got['rgb_' + tag] - ref['rgb'])
+        psnr = nerf_ref.psnr_uint8_luma(got['rgb_' + tag].reshape(48, 48, 3), ref['rgb'].reshape(48, 48, 3))
+        assert err.max() <= 3e-2, (tag, err.max())
+        assert psnr >= 40., (tag, psnr)
+        assert np.max(np.abs(got['occu_' + tag] - ref['occu'])) <= 3e-2
+    assert np.max(np.abs(got['z_all'] - aux['z_all'])) <= 1e-3 * 4 + 0.05  # resampled from bf16 weights
+
+
+def test_model_plugin_matches_ops(nfx_lib, cuda):
+    """The reference-shaped plugin (models.nerf.Model.call) drives the same kernels."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    nets = common.nerf_nets(seed=11)
+    model = get_model_class('nerf')(make_config('nerf')).to(cuda)
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for name in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            for layer, (k, b) in zip(model.net[pref + name].layers, net[name]):
+                layer.kernel.data.copy_(torch.from_numpy(k))
+                layer.bias.data.copy_(torch.from_numpy(b))
+    rayo, rayd = common.camera_rays(16, 16)
+    n = rayo.shape[0]
+    batch = (['v'] * n, torch.tensor([[16, 16]] * n), dev(rayo, cuda), dev(rayd, cuda),
+             torch.rand(n, 3, device=cuda))
+    pred, gt, loss_kwargs, to_vis = model(batch, mode='test')
+    ref = _render_device(rayo, rayd, nets, cuda)
+    assert torch.equal(pred['coarse'], ref['rgb_c']) and torch.equal(pred['fine'], ref['rgb_f'])
+    assert set(to_vis) >= {'id', 'hw', 'gt_rgb', 'coarse_rgb', 'coarse_occu', 'coarse_depth',
+                           'coarse_disp', 'fine_rgb', 'fine_occu', 'fine_depth', 'fine_disp'}
+    loss = model.compute_loss(pred, gt, keep_batch=True, **loss_kwargs)
+    want = nerf_ref.nerf_loss(gt.cpu().numpy(), pred['coarse'].cpu().numpy(), pred['fine'].cpu().numpy())
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=1e-5, atol=1e-7)
+
+
+def test_full_frame_properties(nfx_lib, cuda):
+    """800x800x(64+128) — BASELINE.json configs[1] size: size-independent invariants + a random
+    subset of rays re-rendered stand-alone must be bit-identical (batch independence)."""
+    nets = common.nerf_nets(seed=0)
+    rayo, rayd = common.camera_rays(800, 800)
+    out = _render_device(rayo, rayd, nets, cuda)
+    assert all(torch.isfinite(v).all() for v in out.values())
+    assert (out['z_all'][:, 1:] >= out['z_all'][:, :-1]).all()
+    assert out['z_all'].min() >= 2. - 1e-5 and out['z_all'].max() <= 6. + 1e-5
+    for tag in 'cf':
+        assert out['occu_' + tag].min() >= 0 and out['occu_' + tag].max() <= 1 + 1e-3
+        assert out['rgb_' + tag].min() >= -1e-5 and out['rgb_' + tag].max() <= 1 + 1e-3
+    idx = np.random.default_rng(6).choice(rayo.shape[0], 4096, replace=False)
+    sub = _render_device(rayo[idx], rayd[idx], nets, cuda)
+    sel = torch.from_numpy(idx).to(cuda)
+    for k in ('rgb_c', 'rgb_f', 'z_all'):
+        assert torch.equal(out[k][sel], sub[k]), k
