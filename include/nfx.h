@@ -138,8 +138,12 @@ int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const v
  * light directions of _calc_ldir (shape.py:128-135) recomputed in registers:
  * lvis[n, l] = sigmoid(out(mlp([pe10(xyz_scale*xyz_n), pe4(normalize(lxyz_l - xyz_n))]))).
  * dev_lxyz [n_lights, 3].  out [n, n_lights].                                */
+/* The posenc(xyz) rows of layers 0 and 3 are evaluated once per point into a caller-provided
+ * workspace of nfx_lvis_workspace_bytes(n) bytes (16-byte aligned); n_lights % 32 == 0.      */
+size_t nfx_lvis_workspace_bytes(int64_t n);
 int nfx_lvis_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const float *dev_lxyz,
-                 int n_lights, const void *dev_blob, int prec, float *dev_lvis, void *stream);
+                 int n_lights, const void *dev_blob, int prec, void *dev_workspace,
+                 size_t workspace_bytes, float *dev_lvis, void *stream);
 
 /* Fused shading integral, Model._render.integrate (nerfactor.py:315-365) with the
  * analytic microfacet BRDF of brdf/microfacet/microfacet.py:30-111 evaluated in
@@ -152,6 +156,8 @@ int nfx_lvis_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const float *
  * dev_lights [n_probes, n_lights, 3]: probe 0 is usually the trained light; the
  * relighting loops of nerfactor.py:348-364 become the n_probes axis.
  * out rgb [n, n_probes, 3].                                                  */
+/* Dynamic LDS the shading kernels need for a given sphere / probe count (must be <= 160 KiB). */
+size_t nfx_shade_lds_bytes(int n_lights, int n_probes);
 int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,

@@ -3,6 +3,11 @@ torch fallback for any hot-path op — a missing or stale .so raises at import o
 import ctypes
 import os
 
+# torch first: it brings its own HIP runtime (torch/lib/libamdhip64.so); libnfx.so must bind to
+# that copy, not to a second runtime from /opt/rocm loaded earlier (two runtimes in one process
+# cannot both own the device: "no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnfx.so')
 
@@ -38,7 +43,9 @@ SIGNATURES = {
     'nfx_composite_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p]),
     'nfx_sample_fine': (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     'nfx_mlp128_xyz_fwd': (_i, [_p, _i64, _f, _p, _i, _i, _f, _f, _i, _p, _p]),
-    'nfx_lvis_fwd': (_i, [_p, _i64, _f, _p, _i, _p, _i, _p, _p]),
+    'nfx_lvis_workspace_bytes': (_sz, [_i64]),
+    'nfx_lvis_fwd': (_i, [_p, _i64, _f, _p, _i, _p, _i, _p, _sz, _p, _p]),
+    'nfx_shade_lds_bytes': (_sz, [_i, _i]),
     'nfx_shade_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
     'nfx_shade_olat_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _f, _f, _i64, _i, _i, _p,
                                 _p]),

@@ -14,14 +14,17 @@
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+int nfx_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-static int hip_result(int e, const char* what) {
+#define fail nfx_fail
+int nfx_hip_result(int e, const char* what);
+#define hip_result nfx_hip_result
+int nfx_hip_result(int e, const char* what) {
     if (e == 0) return NFX_OK;
     return fail(NFX_EHIP, "%s: HIP error %d (%s)", what, e, hipGetErrorString((hipError_t)e));
 }
@@ -54,7 +57,9 @@ int nfx_last_error(char* buf, size_t len) {
 }
 
 // Tuning knobs (process-wide, read-only after first use): kernel variant and persistent grid size.
-static int env_int(const char* name, int dflt) {
+int nfx_env_int(const char* name, int dflt);
+#define env_int nfx_env_int
+int nfx_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }

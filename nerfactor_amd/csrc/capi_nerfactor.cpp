@@ -1,0 +1,233 @@
+// capi_nerfactor.cpp — C-ABI entry points of the NeRFactor surface-shading stage (include/nfx.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nfx.h"
+#include "mlp128_layout.hpp"
+#include "pack.hpp"
+
+int nfx_fail(int code, const char* fmt, ...);       // capi.cpp
+int nfx_hip_result(int e, const char* what);        // capi.cpp
+extern "C" int nfx_env_int(const char* name, int dflt);  // capi.cpp
+
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return nfx_fail(NFX_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
+
+extern "C" {
+int nfx_launch_mlp128_xyz(const float*, long long, float, const void*, int, int, float, float, float*, int,
+                          hipStream_t);
+int nfx_launch_lvis_pre(const float*, long long, float, const void*, float*, int, hipStream_t);
+int nfx_launch_lvis(const float*, long long, const float*, int, const float*, const void*, float*, int,
+                    hipStream_t);
+int nfx_launch_brdf_spec(const float*, const float*, const float*, const float*, int, const float*, int,
+                         const void*, long long, float*, int, hipStream_t);
+int nfx_launch_shade(const float*, const float*, const float*, const float*, const float*, const float*, float,
+                     float, const float*, const float*, const float*, const float*, long long, int, int, int,
+                     float*, hipStream_t);
+int nfx_launch_shade_olat(const float*, const float*, const float*, const float*, const float*, const float*,
+                          float, float, const float*, const float*, const float*, float, float, long long, int,
+                          int, float*, hipStream_t);
+int nfx_launch_dir2rusink(const float*, const float*, long long, float*, hipStream_t);
+size_t nfx_shade_olat_lds_bytes(int n_lights);
+
+// ------------------------------------------------------------------------------ packing
+static int in_dims_of(int in_kind, int z_dim) {
+    switch (in_kind) {
+        case NFX_IN_XYZ: return 63;
+        case NFX_IN_XYZ_LDIR: return 90;
+        case NFX_IN_Z_RUSINK: return z_dim + 15;
+        default: return -1;
+    }
+}
+
+size_t nfx_mlp128_packed_bytes(int in_kind, int z_dim, int out_dim, int prec) {
+    using namespace nfx::m128;
+    if (prec != NFX_PREC_BF16 || out_dim < 1 || out_dim > 8) return 0;
+    if (in_kind == NFX_IN_XYZ) return kMainBytes;
+    if (in_kind == NFX_IN_XYZ_LDIR) return (size_t)kPreBytes + kMainBytes;
+    if (in_kind == NFX_IN_Z_RUSINK && z_dim >= 1 && z_dim <= kMaxZDim) return kMainBytes;
+    return 0;
+}
+
+// B-operand slot table of the learned-BRDF input [z(z_dim) | posenc2(rusink)(15)], see
+// brdf_spec_kernel in mlp128.hip: [k-step][half][element] -> input row, -1 = zero.
+static void brdf_input_slots(int zd, int* slots /*[2][2][8]*/) {
+    for (int i = 0; i < 32; ++i) slots[i] = -1;
+    for (int h = 0; h < 2; ++h) {
+        int* s0 = slots + h * 8;
+        for (int j = 0; j < 6; ++j) s0[j] = zd + 3 + 6 * (j / 3) + (j % 3) + (h ? 3 : 0);
+        s0[6] = zd + (h ? 2 : 0);
+        s0[7] = h ? 0 : zd + 1;
+        int* s1 = slots + 16 + h * 8;
+        for (int j = 0; j < 8; ++j) {
+            const int i = 1 + 2 * j + h;
+            s1[j] = i < zd ? i : -1;
+        }
+    }
+}
+
+int nfx_mlp128_pack_weights(const float* const kernels[5], const float* const biases[5], int in_kind,
+                            int z_dim, int out_dim, int prec, void* blob, size_t blob_bytes) {
+    using namespace nfx::m128;
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_mlp128_pack_weights: null argument");
+    for (int i = 0; i < 5; ++i) REQUIRE(kernels[i] && biases[i], "nfx_mlp128_pack_weights: layer %d null", i);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_pack_weights: only bf16 is built");
+    const size_t need = nfx_mlp128_packed_bytes(in_kind, z_dim, out_dim, prec);
+    REQUIRE(need != 0, "nfx_mlp128_pack_weights: unsupported configuration (in_kind %d, z_dim %d, out_dim %d)",
+            in_kind, z_dim, out_dim);
+    REQUIRE(blob_bytes >= need, "nfx_mlp128_pack_weights: blob too small (%zu < %zu)", blob_bytes, need);
+    const int in_dims = in_dims_of(in_kind, z_dim);
+    uint8_t* w = static_cast<uint8_t*>(blob);
+    const Seg hid{kHidden, 128, 0, nullptr};
+    int slots[32];
+    brdf_input_slots(z_dim, slots);
+    if (in_kind == NFX_IN_XYZ_LDIR) {
+        float* pb = reinterpret_cast<float*>(w + kPreWeightBytes);
+        w += pack_layer_bf16({Seg{kPosEnc, 10, 0, nullptr}}, {{kernels[0], biases[0], 128}}, 4, 4, w, pb);
+        w += pack_layer_bf16({Seg{kPosEnc, 10, 128, nullptr}}, {{kernels[3], biases[3], 128}}, 4, 4, w,
+                             pb + 128);
+        w += kPreBiasFloats * 4;
+    }
+    uint8_t* main0 = w;
+    float* b = reinterpret_cast<float*>(main0 + kMainWeightBytes);
+    Seg in0, in3;
+    const float *bias0 = biases[0], *bias3 = biases[3];
+    if (in_kind == NFX_IN_XYZ) {
+        in0 = Seg{kPosEnc, 10, 0, nullptr};
+        in3 = Seg{kPosEnc, 10, 128, nullptr};
+    } else if (in_kind == NFX_IN_XYZ_LDIR) {
+        in0 = Seg{kPosEnc, 4, 63, nullptr};      // rows 63..89 = posenc4(ldir)
+        in3 = Seg{kPosEnc, 4, 128 + 63, nullptr};
+        bias0 = bias3 = nullptr;                 // folded into the per-point pre-activation
+    } else {
+        in0 = Seg{kRaw, 2, 0, slots};
+        in3 = Seg{kRaw, 2, 128, slots};
+    }
+    (void)in_dims;
+    w += pack_layer_bf16({in0}, {{kernels[0], bias0, 128}}, 4, 4, w, b);
+    w += pack_layer_bf16({hid}, {{kernels[1], biases[1], 128}}, 4, 8, w, b + 128);
+    w += pack_layer_bf16({hid}, {{kernels[2], biases[2], 128}}, 4, 8, w, b + 256);
+    w += pack_layer_bf16({hid, in3}, {{kernels[3], bias3, 128}}, 4, 12, w, b + 384);
+    w += pack_layer_bf16({hid}, {{kernels[4], biases[4], out_dim}}, 1, 8, w, b + 512);
+    if (w != main0 + kMainWeightBytes) return nfx_fail(NFX_EINVAL, "nfx_mlp128_pack_weights: layout mismatch");
+    return NFX_OK;
+}
+
+// -------------------------------------------------------------------------------- MLPs
+int nfx_mlp128_xyz_fwd(const float* xyz, int64_t n, float xyz_scale, const void* blob, int out_dim,
+                       int out_act, float post_scale, float post_bias, int prec, float* out, void* stream) {
+    REQUIRE(n >= 0, "nfx_mlp128_xyz_fwd: n < 0");
+    REQUIRE(out_dim >= 1 && out_dim <= 8, "nfx_mlp128_xyz_fwd: out_dim %d not in [1, 8]", out_dim);
+    REQUIRE(out_act >= 0 && out_act <= 3, "nfx_mlp128_xyz_fwd: bad activation %d", out_act);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_xyz_fwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && blob && out, "nfx_mlp128_xyz_fwd: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_mlp128_xyz_fwd: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_mlp128_xyz(xyz, n, xyz_scale, blob, out_dim, out_act, post_scale, post_bias,
+                                                out, nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                          "mlp128_xyz_fwd");
+}
+
+size_t nfx_lvis_workspace_bytes(int64_t n) { return n > 0 ? (size_t)n * 256 * sizeof(float) : 0; }
+
+int nfx_lvis_fwd(const float* xyz, int64_t n, float xyz_scale, const float* lxyz, int n_lights,
+                 const void* blob, int prec, void* workspace, size_t workspace_bytes, float* lvis,
+                 void* stream) {
+    using namespace nfx::m128;
+    REQUIRE(n >= 0, "nfx_lvis_fwd: n < 0");
+    REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_lvis_fwd: n_lights (%d) must be a positive multiple of 32",
+            n_lights);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_lvis_fwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && lxyz && blob && lvis && workspace, "nfx_lvis_fwd: null pointer");
+    REQUIRE(workspace_bytes >= nfx_lvis_workspace_bytes(n), "nfx_lvis_fwd: workspace too small (%zu < %zu)",
+            workspace_bytes, nfx_lvis_workspace_bytes(n));
+    if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_lvis_fwd: blob and workspace must be 16-byte aligned");
+    const int blocks = nfx_env_int("NFX_M128_BLOCKS", 256);
+    const char* b = static_cast<const char*>(blob);
+    float* pre = static_cast<float*>(workspace);
+    int rc = nfx_hip_result(nfx_launch_lvis_pre(xyz, n, xyz_scale, b, pre, blocks, (hipStream_t)stream), "lvis_pre");
+    if (rc) return rc;
+    return nfx_hip_result(
+        nfx_launch_lvis(xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis, blocks, (hipStream_t)stream), "lvis_fwd");
+}
+
+int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
+                      const float* lxyz, int n_lights, const void* blob, int prec, int64_t n, float* spec,
+                      void* stream) {
+    REQUIRE(n >= 0, "nfx_brdf_spec_fwd: n < 0");
+    REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_spec_fwd: z_dim %d not in [1, %d]", z_dim,
+            nfx::m128::kMaxZDim);
+    REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_brdf_spec_fwd: n_lights (%d) must be a multiple of 32",
+            n_lights);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_spec_fwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && z && lxyz && blob && spec, "nfx_brdf_spec_fwd: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_fwd: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_brdf_spec(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
+                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                          "brdf_spec_fwd");
+}
+
+// ------------------------------------------------------------------------------ shading
+static int check_shade(const char* who, const float* xyz, const float* cam, const float* normal,
+                       const float* albedo, const float* rough, const float* spec, const float* lvis,
+                       const float* lxyz, const float* lareas, int64_t n, int n_lights) {
+    REQUIRE(n >= 0 && n_lights > 0, "%s: bad shape", who);
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && albedo && lvis && lxyz && lareas, "%s: null pointer", who);
+    REQUIRE(rough || spec, "%s: need either roughness (microfacet) or a specular term (learned BRDF)", who);
+    return NFX_OK;
+}
+
+int nfx_shade_fwd(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                  const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
+                  const float* lxyz, const float* lareas, const float* lights, int64_t n, int n_lights,
+                  int n_probes, int linear2srgb, float* rgb, void* stream) {
+    int rc = check_shade("nfx_shade_fwd", xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, n_lights);
+    if (rc) return rc;
+    REQUIRE(n_probes >= 1, "nfx_shade_fwd: n_probes must be >= 1");
+    REQUIRE(nfx_shade_lds_bytes(n_lights, n_probes) <= 160 * 1024,
+            "nfx_shade_fwd: %d probes x %d lights do not fit the 160 KiB LDS; split the probes", n_probes,
+            n_lights);
+    if (n == 0) return NFX_OK;
+    REQUIRE(lights && rgb, "nfx_shade_fwd: null pointer");
+    return nfx_hip_result(nfx_launch_shade(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
+                                           lareas, lights, n, n_lights, n_probes, linear2srgb, rgb,
+                                           (hipStream_t)stream),
+                          "shade_fwd");
+}
+
+int nfx_shade_olat_fwd(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                       const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
+                       const float* lxyz, const float* lareas, float olat_inten, float ambient, int64_t n,
+                       int n_lights, int linear2srgb, float* rgb_olat, void* stream) {
+    int rc =
+        check_shade("nfx_shade_olat_fwd", xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, n_lights);
+    if (rc) return rc;
+    REQUIRE(nfx_shade_olat_lds_bytes(n_lights) <= 160 * 1024, "nfx_shade_olat_fwd: too many lights (%d)",
+            n_lights);
+    if (n == 0) return NFX_OK;
+    REQUIRE(rgb_olat, "nfx_shade_olat_fwd: null output");
+    return nfx_hip_result(nfx_launch_shade_olat(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
+                                                lareas, olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat,
+                                                (hipStream_t)stream),
+                          "shade_olat_fwd");
+}
+
+int nfx_dir2rusink(const float* a, const float* b, int64_t n, float* rusink, void* stream) {
+    REQUIRE(n >= 0 && (n == 0 || (a && b && rusink)), "nfx_dir2rusink: bad arguments");
+    return nfx_hip_result(nfx_launch_dir2rusink(a, b, n, rusink, (hipStream_t)stream), "dir2rusink");
+}
+
+}  // extern "C"

@@ -127,18 +127,46 @@ __device__ __forceinline__ void mma_k(const char* lane_frag0, const bf16x8 (&b)[
     }
 }
 
-// One 32-row output tile: acc = bias + W_tile^T [b1 ; b2].  Consumes one chunk.
-template <int KS1, int KS2, int NL_NEXT, int NW, int KS1A, int KS2A, int CT>
-__device__ __forceinline__ void tile_raw(WStream& ws, int tid, const float* bias_tile,
-                                         const bf16x8 (&b1)[KS1A][CT],
-                                         const bf16x8 (&b2)[KS2A][CT], f32x16 (&acc)[CT]) {
+// One 32-row output tile: acc = init + W_tile^T [b1 ; b2].  Consumes one chunk.
+// `init(acc)` fills the accumulators (bias from LDS, or a per-point pre-activation vector).
+template <int KS1, int KS2, int NL_NEXT, int NW, int KS1A, int KS2A, int CT, typename Init>
+__device__ __forceinline__ void tile_init(WStream& ws, int tid, Init&& init,
+                                          const bf16x8 (&b1)[KS1A][CT],
+                                          const bf16x8 (&b2)[KS2A][CT], f32x16 (&acc)[CT]) {
     const int lane = tid & 63;
-    bias_init<CT>(bias_tile, lane >> 5, acc);
+    init(acc);
     with_chunk<NL_NEXT, NW>(ws, tid, [&](const char* chunk) {
         const char* f0 = chunk + lane * 16;
         mma_k<KS1>(f0, b1, acc);
         if constexpr (KS2 > 0) mma_k<KS2>(f0 + KS1 * kFragBytes, b2, acc);
     });
+}
+
+template <int KS1, int KS2, int NL_NEXT, int NW, int KS1A, int KS2A, int CT>
+__device__ __forceinline__ void tile_raw(WStream& ws, int tid, const float* bias_tile,
+                                         const bf16x8 (&b1)[KS1A][CT],
+                                         const bf16x8 (&b2)[KS2A][CT], f32x16 (&acc)[CT]) {
+    const int h = (tid & 63) >> 5;
+    tile_init<KS1, KS2, NL_NEXT, NW>(
+        ws, tid, [&](f32x16(&a)[CT]) { bias_init<CT>(bias_tile, h, a); }, b1, b2, acc);
+}
+
+// acc[c][r] <- vec[(r&3) + 8(r>>2) + 4h] from a GLOBAL fp32 vector of 32 values per tile (all lanes
+// of a half read the same 16 B: one broadcast transaction each).
+template <int CT>
+__device__ __forceinline__ void vec_init(const float* __restrict__ vec_tile, int h,
+                                         f32x16 (&acc)[CT]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(vec_tile + 8 * g + 4 * h);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            acc[c][4 * g + 0] = v[0];
+            acc[c][4 * g + 1] = v[1];
+            acc[c][4 * g + 2] = v[2];
+            acc[c][4 * g + 3] = v[3];
+        }
+    }
 }
 
 template <bool RELU, int CT>
@@ -173,6 +201,24 @@ __device__ __forceinline__ void layer(WStream& ws, int tid, const float* bias,
         f32x16 acc[CT];
         tile_raw<KS1, KS2, (t == NT - 1 ? NL_NEXT : NL_SELF), NW>(ws, tid, bias + 32 * t, b1, b2,
                                                                  acc);
+        acc_to_b<RELU, CT>(acc, bout[2 * t], bout[2 * t + 1]);
+    });
+}
+
+// Same, but the accumulators start from a per-point pre-activation vector in global memory
+// (`pre` points at this layer's first value for this wave's point) instead of the bias.
+template <int KS1, int KS2, int NT, int NL_SELF, int NL_NEXT, bool RELU, int NW, int KS1A,
+          int KS2A, int NTA, int CT>
+__device__ __forceinline__ void layer_pre(WStream& ws, int tid, const float* __restrict__ pre,
+                                          const bf16x8 (&b1)[KS1A][CT],
+                                          const bf16x8 (&b2)[KS2A][CT], bf16x8 (&bout)[NTA][CT]) {
+    static_assert(2 * NT <= NTA, "output array too small");
+    const int h = (tid & 63) >> 5;
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[CT];
+        tile_init<KS1, KS2, (t == NT - 1 ? NL_NEXT : NL_SELF), NW>(
+            ws, tid, [&](f32x16(&a)[CT]) { vec_init<CT>(pre + 32 * t, h, a); }, b1, b2, acc);
         acc_to_b<RELU, CT>(acc, bout[2 * t], bout[2 * t + 1]);
     });
 }

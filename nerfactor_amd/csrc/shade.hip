@@ -1,0 +1,224 @@
+// shade.hip — the rendering integral of NeRFactor, fused per surface point (HBM-bound, fp32):
+//   directions (shape.py:128-144) -> BRDF (microfacet.py:30-111, or albedo/pi + learned spec,
+//   nerfactor.py:459-461) -> cos / front-lit mask / visibility / solid angle / light products
+//   -> sum over the light sphere -> clip -> linear2srgb       (nerfactor.py:315-365)
+// One wave per surface point, the lights of the sphere on the lanes (l = lane, lane+64, ...);
+// light positions, solid angles and all probes are staged once per workgroup in LDS.  Nothing of
+// size N x L x 3 is materialised; lvis[n, :] is read once (one coalesced row per point).
+#include "geom.hpp"
+
+namespace nfx {
+
+struct ShadeArgs {
+    const float *xyz, *cam, *normal, *albedo, *rough, *spec, *lvis, *lxyz, *lareas, *lights;
+    float spec_scale, f0;
+    long long n;
+    int n_lights, n_probes, to_srgb;
+    float olat_inten, ambient;
+    float* out;
+};
+
+struct PointCtx {
+    float x[3], nrm[3], alb_pi[3];
+    MicrofacetPoint mp;
+};
+
+__device__ __forceinline__ void load_point(const ShadeArgs& a, long long pt, PointCtx& pc) {
+    float cam[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pc.x[k] = a.xyz[3 * pt + k];
+        cam[k] = a.cam[3 * pt + k];
+        pc.nrm[k] = a.normal[3 * pt + k];
+        pc.alb_pi[k] = a.albedo[3 * pt + k] / 3.14159265358979323846f;  // microfacet.py:64
+    }
+    dir_to(cam, pc.x, v);  // shape.py:137-140
+    if (a.spec == nullptr) microfacet_point(v, pc.nrm, a.rough[pt], pc.mp);
+}
+
+// T[c] = brdf[n,l,c] * lvis[n,l]*[cos>0] * cos[n,l] * area[l]     (nerfactor.py:325-336)
+__device__ __forceinline__ void light_transport(const ShadeArgs& a, const PointCtx& pc, long long pt, int l,
+                                                const float* lxyz_s, const float* area_s, float (&T)[3]) {
+    const float lp[3] = {lxyz_s[3 * l], lxyz_s[3 * l + 1], lxyz_s[3 * l + 2]};
+    float ldir[3];
+    dir_to(lp, pc.x, ldir);  // shape.py:128-131
+    const float cosv = dot3(ldir, pc.nrm);
+    const float lv = cosv > 0.0f ? a.lvis[pt * a.n_lights + l] : 0.0f;
+    const float s = a.spec ? a.spec[pt * a.n_lights + l] * a.spec_scale : microfacet_spec(pc.mp, ldir, a.f0);
+    const float k = lv * cosv * area_s[l];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[c] = (s + pc.alb_pi[c]) * k;
+}
+
+__device__ __forceinline__ float tonemap(float v, int to_srgb) {
+    v = fminf(fmaxf(v, 0.0f), 1.0f);  // nerfactor.py:338
+    return to_srgb ? linear2srgb1(v) : v;
+}
+
+constexpr int kShadeWaves = 4;
+constexpr int kLightsPerPass = 8;  // per lane -> 512 lights per pass
+
+// LDS: lxyz[L*3] | area[L] | lights[P*L*3] | part[kShadeWaves][P*3]
+__global__ __launch_bounds__(kShadeWaves * 64) void shade_kernel(ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int L = a.n_lights, P = a.n_probes;
+    float* lxyz_s = sm;
+    float* area_s = lxyz_s + 3 * L;
+    float* light_s = area_s + L;
+    float* part_s = light_s + (size_t)P * L * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * L; i += blockDim.x) lxyz_s[i] = a.lxyz[i];
+    for (int i = tid; i < L; i += blockDim.x) area_s[i] = a.lareas[i];
+    for (int i = tid; i < P * L * 3; i += blockDim.x) light_s[i] = a.lights[i];
+    __syncthreads();
+    float* part = part_s + wave * P * 3;
+    for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < a.n;
+         pt += (long long)gridDim.x * kShadeWaves) {
+        PointCtx pc;
+        load_point(a, pt, pc);
+        for (int i = lane; i < P * 3; i += 64) part[i] = 0.0f;
+        for (int l0 = 0; l0 < L; l0 += 64 * kLightsPerPass) {
+            float T[kLightsPerPass][3];
+#pragma unroll
+            for (int k = 0; k < kLightsPerPass; ++k) {
+                const int l = l0 + k * 64 + lane;
+                if (l < L) light_transport(a, pc, pt, l, lxyz_s, area_s, T[k]);
+                else T[k][0] = T[k][1] = T[k][2] = 0.0f;
+            }
+            for (int p = 0; p < P; ++p) {
+                float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < kLightsPerPass; ++k) {
+                    const int l = l0 + k * 64 + lane;
+                    if (l < L) {
+                        const float* lg = light_s + ((size_t)p * L + l) * 3;
+                        s[0] += T[k][0] * lg[0];
+                        s[1] += T[k][1] * lg[1];
+                        s[2] += T[k][2] * lg[2];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s[c] = wave_sum(s[c]);
+                if (lane == 0) {
+                    part[3 * p] += s[0];
+                    part[3 * p + 1] += s[1];
+                    part[3 * p + 2] += s[2];
+                }
+            }
+        }
+        // part[] was written by lane 0 only; same-wave LDS ops are ordered
+        for (int i = lane; i < P * 3; i += 64) a.out[pt * P * 3 + i] = tonemap(part[i], a.to_srgb);
+    }
+}
+
+// OLAT: rgb[n, l, c] = tonemap(inten * T[l][c] + ambient * sum_l' T[l'][c])   (nerfactor.py:79-84,348-354)
+// LDS: lxyz[L*3] | area[L] | T[kShadeWaves][L*3]
+__global__ __launch_bounds__(kShadeWaves * 64) void shade_olat_kernel(ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int L = a.n_lights;
+    float* lxyz_s = sm;
+    float* area_s = lxyz_s + 3 * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* T_s = area_s + L + (size_t)wave * L * 3;
+    for (int i = tid; i < 3 * L; i += blockDim.x) lxyz_s[i] = a.lxyz[i];
+    for (int i = tid; i < L; i += blockDim.x) area_s[i] = a.lareas[i];
+    __syncthreads();
+    for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < a.n;
+         pt += (long long)gridDim.x * kShadeWaves) {
+        PointCtx pc;
+        load_point(a, pt, pc);
+        float tot[3] = {0.f, 0.f, 0.f};
+        for (int l = lane; l < L; l += 64) {
+            float T[3];
+            light_transport(a, pc, pt, l, lxyz_s, area_s, T);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T_s[3 * l + c] = T[c];
+                tot[c] += T[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tot[c] = wave_sum(tot[c]) * a.ambient;
+        float* o = a.out + pt * L * 3;
+        for (int i = lane; i < 3 * L; i += 64) {
+            const int c = i % 3;
+            const float amb = c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]);
+            o[i] = tonemap(a.olat_inten * T_s[i] + amb, a.to_srgb);
+        }
+    }
+}
+
+__global__ void dir2rusink_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                  float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float av[3] = {a[3 * i], a[3 * i + 1], a[3 * i + 2]};
+    const float bv[3] = {b[3 * i], b[3 * i + 1], b[3 * i + 2]};
+    float r[3];
+    dir2rusink(av, bv, r);
+    out[3 * i] = r[0];
+    out[3 * i + 1] = r[1];
+    out[3 * i + 2] = r[2];
+}
+
+}  // namespace nfx
+
+extern "C" {
+static nfx::ShadeArgs make_args(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                                const float* rough, const float* spec, float spec_scale, float f0,
+                                const float* lvis, const float* lxyz, const float* lareas,
+                                const float* lights, long long n, int n_lights, int n_probes, int to_srgb,
+                                float olat_inten, float ambient, float* out) {
+    nfx::ShadeArgs a;
+    a.xyz = xyz; a.cam = cam; a.normal = normal; a.albedo = albedo; a.rough = rough; a.spec = spec;
+    a.lvis = lvis; a.lxyz = lxyz; a.lareas = lareas; a.lights = lights;
+    a.spec_scale = spec_scale; a.f0 = f0; a.n = n; a.n_lights = n_lights; a.n_probes = n_probes;
+    a.to_srgb = to_srgb; a.olat_inten = olat_inten; a.ambient = ambient; a.out = out;
+    return a;
+}
+size_t nfx_shade_lds_bytes(int n_lights, int n_probes) {
+    return sizeof(float) * ((size_t)4 * n_lights + (size_t)n_probes * n_lights * 3 +
+                            (size_t)nfx::kShadeWaves * n_probes * 3);
+}
+size_t nfx_shade_olat_lds_bytes(int n_lights) {
+    return sizeof(float) * ((size_t)4 * n_lights + (size_t)nfx::kShadeWaves * n_lights * 3);
+}
+int nfx_launch_shade(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                     const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
+                     const float* lxyz, const float* lareas, const float* lights, long long n, int n_lights,
+                     int n_probes, int to_srgb, float* out, hipStream_t st) {
+    if (n <= 0) return 0;
+    const size_t lds = nfx_shade_lds_bytes(n_lights, n_probes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (n + nfx::kShadeWaves - 1) / nfx::kShadeWaves;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(nfx::shade_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
+                       make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
+                                 lights, n, n_lights, n_probes, to_srgb, 0.f, 0.f, out));
+    return (int)hipGetLastError();
+}
+int nfx_launch_shade_olat(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                          const float* rough, const float* spec, float spec_scale, float f0,
+                          const float* lvis, const float* lxyz, const float* lareas, float olat_inten,
+                          float ambient, long long n, int n_lights, int to_srgb, float* out, hipStream_t st) {
+    if (n <= 0) return 0;
+    const size_t lds = nfx_shade_olat_lds_bytes(n_lights);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_olat_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (n + nfx::kShadeWaves - 1) / nfx::kShadeWaves;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(nfx::shade_olat_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
+                       make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
+                                 nullptr, n, n_lights, 0, to_srgb, olat_inten, ambient, out));
+    return (int)hipGetLastError();
+}
+int nfx_launch_dir2rusink(const float* a, const float* b, long long n, float* out, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(nfx::dir2rusink_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n,
+                       out);
+    return (int)hipGetLastError();
+}
+}

@@ -158,3 +158,100 @@ def selftest_sincos(x, which):
     check(lib.nfx_selftest_sincos(_ptr(x), x.numel(), int(which), _ptr(out), _stream()),
           'nfx_selftest_sincos')
     return out
+
+
+# ------------------------------------------------------------------------- NeRFactor ops
+def mlp128_xyz_fwd(xyz, blob, out_dim, out_act=None, xyz_scale=1., post_scale=1., post_bias=0.,
+                   prec='bf16'):
+    """out[n, out_dim] = post_scale * act(out(mlp(posenc10(xyz_scale * xyz)))) + post_bias."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    out = torch.empty((n, out_dim), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_mlp128_xyz_fwd(_ptr(xyz), n, xyz_scale, _ptr(blob), out_dim, _ACT[out_act],
+                                 post_scale, post_bias, _PREC[prec], _ptr(out), _stream()),
+          'nfx_mlp128_xyz_fwd')
+    return out
+
+
+def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., prec='bf16'):
+    """lvis[n, L]: the light-visibility MLP for every (surface point, light) pair."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    n, nl = xyz.shape[0], lxyz.shape[0]
+    out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
+    ws_bytes = lib.nfx_lvis_workspace_bytes(n)
+    ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_lvis_fwd(_ptr(xyz), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
+                           ws.numel() * 4, _ptr(out), _stream()), 'nfx_lvis_fwd')
+    return out
+
+
+def brdf_spec_fwd(xyz, cam, normal, z, lxyz, blob, prec='bf16'):
+    """spec[n, L]: learned-BRDF specular term (0 for back-lit directions)."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    cam = _dev(cam, 'cam', (n, 3))
+    normal = _dev(normal, 'normal', (n, 3))
+    z = _dev(z, 'z', (n, None))
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    nl = lxyz.shape[0]
+    out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_brdf_spec_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(z), z.shape[1], _ptr(lxyz), nl,
+                                _ptr(blob), _PREC[prec], n, _ptr(out), _stream()), 'nfx_brdf_spec_fwd')
+    return out
+
+
+def _shade_common(xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas):
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    nl = lxyz.shape[0]
+    if rough is not None and rough.dim() == 2:
+        rough = rough.reshape(-1)
+    return (xyz, _dev(cam, 'cam', (n, 3)), _dev(normal, 'normal', (n, 3)),
+            _dev(albedo, 'albedo', (n, 3)), _dev(rough, 'rough', (n,)), _dev(spec, 'spec', (n, nl)),
+            _dev(lvis, 'lvis', (n, nl)), lxyz, _dev(lareas.reshape(-1), 'lareas', (nl,)), n, nl)
+
+
+def shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, lights, rough=None, spec=None,
+              spec_scale=1., f0=0.04, linear2srgb=True):
+    """rgb[n, P, 3] for P lights [P, L, 3] (microfacet BRDF if `rough`, else albedo/pi + spec)."""
+    xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
+        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
+    lights = _dev(lights, 'lights', (None, nl, 3))
+    p_total = lights.shape[0]
+    out = torch.empty((n, p_total, 3), dtype=torch.float32, device=xyz.device)
+    # all probes of one call must fit the LDS together; split if they do not
+    p_max = p_total
+    while p_max > 1 and lib.nfx_shade_lds_bytes(nl, p_max) > 160 * 1024:
+        p_max -= 1
+    for p0 in range(0, p_total, p_max):
+        chunk = lights[p0:p0 + p_max].contiguous()
+        dst = out if p_max == p_total else torch.empty((n, chunk.shape[0], 3), dtype=torch.float32,
+                                                      device=xyz.device)
+        check(lib.nfx_shade_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
+                                spec_scale, f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), _ptr(chunk), n, nl,
+                                chunk.shape[0], int(linear2srgb), _ptr(dst), _stream()), 'nfx_shade_fwd')
+        if dst is not out:
+            out[:, p0:p0 + chunk.shape[0]] = dst
+    return out
+
+
+def shade_olat_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, olat_inten, ambient, rough=None,
+                   spec=None, spec_scale=1., f0=0.04, linear2srgb=True):
+    """rgb_olat[n, L, 3]: one-light-at-a-time relighting."""
+    xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
+        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
+    out = torch.empty((n, nl, 3), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_shade_olat_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
+                                 spec_scale, f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
+                                 n, nl, int(linear2srgb), _ptr(out), _stream()), 'nfx_shade_olat_fwd')
+    return out
+
+
+def dir2rusink(a, b):
+    a = _dev(a, 'a', (None, 3))
+    b = _dev(b, 'b', (a.shape[0], 3))
+    out = torch.empty_like(a)
+    check(lib.nfx_dir2rusink(_ptr(a), _ptr(b), a.shape[0], _ptr(out), _stream()), 'nfx_dir2rusink')
+    return out

@@ -21,9 +21,9 @@ import numpy as np
 def bf16_round(x):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 (what v_cvt_pk_bf16_f32 does)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
-    return u.astype(np.uint32).view(np.float32).reshape(x.shape)
+    u = x.view(np.uint32)
+    u = (u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32).reshape(x.shape)
 
 
 def l2_normalize(x, axis, eps):
@@ -57,7 +57,7 @@ def _act(y, name):
     if name is None:
         return y
     if name == 'relu':
-        return np.maximum(y, 0)
+        return np.maximum(y, 0, out=y)  # y is always a fresh matmul result here
     if name == 'sigmoid':
         return 1. / (1. + np.exp(-y))
     if name == 'softplus':

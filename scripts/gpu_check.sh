@@ -18,8 +18,9 @@ for v in ${VARIANTS:-1 0}; do
 done
 if [ "${PROFILE:-1}" = "1" ]; then
   echo "=== rocprofv3 kernel stats"
-  (cd /tmp && NFX_NERF_VARIANT=${PROF_VARIANT:-1} timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o nerf -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+  (cd /tmp && NFX_NERF_VARIANT=${PROF_VARIANT:-1} timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o nerf -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
   ls -R $OUT/prof | head -20
   find $OUT/prof -name "*kernel_stats*" | head -2 | xargs -r head -20
+  cat /sys/fs/cgroup/cpu.max 2>/dev/null >> $OUT/gpu.txt
 fi
 echo done

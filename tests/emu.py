@@ -105,3 +105,91 @@ def nerf_tile(blob, pts, views):
     acc = tile(rd, 8, bias, 2048 + 288 + 128, r0)
     assert rd.pos == 1192
     return np.stack([acc[:32, 0], acc[:32, 1], acc[:32, 2], sigma], -1)
+
+
+# ----------------------------------------------------------------------------- width-128 nets
+M128_MAIN_W = 136 * 1024
+M128_PRE_W = 32 * 1024
+
+
+def _m128_mid_and_out(rd, bias, h, skip_ops, pre3=None):
+    h = layer(rd, 8, bias, 128, h, 4, True)
+    h = layer(rd, 8, bias, 256, h, 4, True)
+    if pre3 is None:
+        h = layer(rd, 12, bias, 384, h + skip_ops, 4, True)
+    else:
+        h = layer_pre(rd, 12, pre3, h + skip_ops, 4)
+    return tile(rd, 8, bias, 512, h)
+
+
+def layer_pre(reader, chunk_frags, pre_vec, b_ops, n_tiles):
+    """Like layer() but the accumulators start from a per-point vector pre_vec [32 pts, 128]
+    (relu, bf16 out).  All 32 lanes&31 share ONE point in the lvis kernel; here we allow a
+    per-lane point for generality."""
+    out = []
+    for t in range(n_tiles):
+        frags = reader.chunk(chunk_frags)
+        acc = np.zeros((64, 16), np.float32)
+        for r in range(16):
+            acc[:, r] = pre_vec[P, 32 * t + (r & 3) + 8 * (r >> 2) + 4 * H]
+        for s, b in enumerate(b_ops):
+            acc = mfma_32x32x16(frags[s], b, acc)
+        acc = bf16_round(np.maximum(acc, 0))
+        out += [acc[:, :8], acc[:, 8:]]
+    return out
+
+
+def mlp128_xyz_tile(blob, pts, out_dim):
+    """pts [32,3] (already scaled) -> raw out [32, out_dim] (pre-activation)."""
+    rd = BlobReader(np.asarray(blob), M128_MAIN_W)
+    pe = posenc_slots(pts.astype(np.float32), 10)
+    h = layer(rd, 4, rd.b, 0, pe, 4, True)
+    acc = _m128_mid_and_out(rd, rd.b, h, pe)
+    assert rd.pos == 136
+    rows = np.zeros((32, out_dim), np.float32)
+    for row in range(out_dim):
+        rows[:, row] = acc[:32, row] if row < 4 else acc[32:, row - 4]
+    return rows
+
+
+def lvis_tile(blob, pt, ldirs):
+    """One surface point pt [3] (scaled), 32 light directions [32,3] -> raw logits [32]."""
+    blob = np.asarray(blob)
+    pre_blob = blob[:M128_PRE_W + 1024]
+    rd = BlobReader(pre_blob, M128_PRE_W)
+    pe = posenc_slots(np.broadcast_to(pt.astype(np.float32), (32, 3)), 10)
+    pre = np.zeros((32, 256), np.float32)
+    for t in range(8):
+        acc = tile(rd, 4, rd.b, 32 * t, pe)
+        for r in range(16):
+            pre[P, 32 * t + (r & 3) + 8 * (r >> 2) + 4 * H] = acc[:, r]
+    rd = BlobReader(blob[M128_PRE_W + 1024:], M128_MAIN_W)
+    pl = posenc_slots(ldirs.astype(np.float32), 4)
+    h = layer_pre(rd, 4, pre[:, :128], pl, 4)
+    acc = _m128_mid_and_out(rd, rd.b, h, pl, pre3=pre[:, 128:])
+    assert rd.pos == 136
+    return acc[:32, 0]
+
+
+def brdf_tile(blob, z, rusink):
+    """z [32, zd], rusink [32, 3] -> raw logits [32] of the learned-BRDF MLP."""
+    zd = z.shape[1]
+    zl, rl = z[P].astype(np.float32), rusink[P].astype(np.float32)
+    v = np.zeros((64, 16), np.float32)
+    for q in range(6):
+        arg = rl[:, q % 3] * np.float32(2 ** (q // 3))
+        v[:, q] = np.where(H == 1, np.cos(arg), np.sin(arg))
+    v[:, 6] = np.where(H == 1, rl[:, 2], rl[:, 0])
+    v[:, 7] = np.where(H == 1, zl[:, 0], rl[:, 1])
+    for j in range(8):
+        for hh in range(2):
+            i = 1 + 2 * j + hh
+            if i < zd:
+                v[H == hh, 8 + j] = zl[H == hh, i]
+    v = bf16_round(v)
+    ops_in = [v[:, :8], v[:, 8:]]
+    rd = BlobReader(np.asarray(blob), M128_MAIN_W)
+    h = layer(rd, 4, rd.b, 0, ops_in, 4, True)
+    acc = _m128_mid_and_out(rd, rd.b, h, ops_in)
+    assert rd.pos == 136
+    return acc[:32, 0]

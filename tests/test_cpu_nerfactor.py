@@ -1,0 +1,149 @@
+"""CPU suite, NeRFactor stage: oracle vs the importable reference pieces (golden anchors), oracle
+self-consistency, and the width-128 packers through the lane-level kernel emulation."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nerf_ref, nerfactor_ref as R
+from tests import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_anchors.npz'))
+
+
+# ---------------------------------------------------------------- golden anchors (real reference)
+@pytest.mark.parametrize("h", [16, 4])
+def test_gen_light_xyz_matches_reference(h):
+    xyz, areas = R.gen_light_xyz(h, 2 * h)
+    np.testing.assert_allclose(xyz, GOLD['lxyz_%d' % h], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(areas, GOLD['lareas_%d' % h], rtol=1e-13)
+    assert abs(areas.sum() - 4 * np.pi) < 1e-12
+
+
+def test_sph2cart_convention_matches_reference():
+    sph = GOLD['sph_in']
+    r, lat, lng = sph[:, 0], sph[:, 1], sph[:, 2]
+    cart = np.stack((r * np.cos(lat) * np.cos(lng), r * np.cos(lat) * np.sin(lng), r * np.sin(lat)), -1)
+    np.testing.assert_allclose(cart, GOLD['sph_cart'], atol=1e-12)
+
+
+def test_dir2rusink_matches_nielsen2015on():
+    got = R.dir2rusink(GOLD['rusink_a'], GOLD['rusink_b'])
+    np.testing.assert_allclose(got, GOLD['rusink_out'], atol=5e-6)  # eps=1e-6 in safe_l2_normalize
+    got32 = R.dir2rusink(GOLD['rusink_a'].astype(np.float32), GOLD['rusink_b'].astype(np.float32))
+    d = np.abs(got32 - GOLD['rusink_out'])
+    d[:, 0] = np.minimum(d[:, 0], np.pi - d[:, 0])  # phi_d wraps at pi
+    assert d.max() < 2e-3
+
+
+def test_linear2srgb_and_luma_match_xiuminglib():
+    np.testing.assert_allclose(R.linear2srgb(GOLD['srgb_in']), GOLD['srgb_out'], atol=1e-12)
+    lum = GOLD['psnr_im1'] @ np.array([0.2126, 0.7152, 0.0722])
+    np.testing.assert_allclose(lum, GOLD['lum'], atol=1e-12)
+
+
+# -------------------------------------------------------------------------------- oracle props
+def test_world2local_is_orthonormal_and_maps_normal_to_z():
+    rng = np.random.default_rng(0)
+    n = rng.normal(size=(100, 3))
+    rot = R.gen_world2local(n)
+    eye = np.einsum('nij,nkj->nik', rot, rot)
+    np.testing.assert_allclose(eye, np.broadcast_to(np.eye(3), eye.shape), atol=1e-5)
+    nz = np.einsum('nij,nj->ni', rot, nerf_ref.l2_normalize(n, 1, 1e-6))
+    np.testing.assert_allclose(nz, np.broadcast_to([0, 0, 1.], nz.shape), atol=1e-5)
+
+
+def test_microfacet_properties():
+    rng = np.random.default_rng(1)
+    n_pts, n_l = 50, 64
+    normal = nerf_ref.l2_normalize(rng.normal(size=(n_pts, 3)), 1, 1e-6)
+    l = nerf_ref.l2_normalize(rng.normal(size=(n_pts, n_l, 3)), 2, 1e-6)
+    v = nerf_ref.l2_normalize(rng.normal(size=(n_pts, 3)), 1, 1e-6)
+    albedo = rng.uniform(.03, .8, size=(n_pts, 3))
+    rough = rng.uniform(.05, 1., size=(n_pts, 1))
+    brdf = R.microfacet(l, v, normal, albedo, rough)
+    assert brdf.shape == (n_pts, n_l, 3) and np.all(np.isfinite(brdf))
+    assert np.all(brdf >= albedo[:, None, :] / np.pi - 1e-12)  # glossy term is non-negative
+    lam = R.microfacet(l, v, normal, albedo, rough, lambert_only=True)
+    np.testing.assert_allclose(lam, np.broadcast_to((albedo / np.pi)[:, None], lam.shape))
+    # half vector below the surface -> D = 0
+    hv = nerf_ref.l2_normalize(l + v[:, None, :], 2, 1e-6)
+    below = np.einsum('ijk,ik->ij', hv, normal) <= 0
+    assert np.allclose((brdf - lam)[below], 0)
+
+
+def test_render_matches_manual_sum_and_masks_back_lit():
+    rng = np.random.default_rng(2)
+    lxyz, areas = R.gen_light_xyz(4, 8)
+    lxyz = lxyz.reshape(-1, 3)
+    pts = rng.uniform(-1, 1, size=(6, 3))
+    surf2l = R.calc_ldir(pts, lxyz)
+    normal = nerf_ref.l2_normalize(rng.normal(size=(6, 3)), 1, 1e-6)
+    brdf = rng.uniform(0, .3, size=(6, 32, 3))
+    lvis = rng.uniform(size=(6, 32))
+    light = rng.uniform(0, 1, size=(4, 8, 3))
+    rgb = R.integrate(brdf, lvis, surf2l, normal, light, areas, to_srgb=False)
+    cos = np.einsum('ijk,ik->ij', surf2l, normal)
+    manual = np.zeros((6, 3))
+    for l in range(32):
+        if True:
+            manual += (brdf[:, l] * (lvis[:, l] * (cos[:, l] > 0))[:, None] * light.reshape(-1, 3)[l] *
+                       cos[:, l, None] * areas.reshape(-1)[l])
+    np.testing.assert_allclose(rgb, np.clip(manual, 0, 1), atol=1e-12)
+
+
+# ------------------------------------------------------------------ packers via lane emulation
+def _net128(seed, in_dims, out_dims):
+    rng = np.random.default_rng(seed)
+    layers, out = R.init_mlp128(rng, in_dims, out_dims)
+    for lst in (layers, out):
+        for i, (k, b) in enumerate(lst):
+            lst[i] = (k, rng.uniform(-.2, .2, size=b.shape).astype(np.float32))
+    return layers, out
+
+
+def _pack(nfx_lib, layers, out, in_kind, out_dim, z_dim=0):
+    from nerfactor_amd import ops
+    ks = [k for k, _ in layers] + [out[0][0]]
+    bs = [b for _, b in layers] + [out[0][1]]
+    return ops.pack_mlp128_weights(ks, bs, in_kind, out_dim, z_dim=z_dim).numpy()
+
+
+def test_mlp128_xyz_pack_through_emulation(nfx_lib):
+    layers, out = _net128(3, 63, 3)
+    blob = _pack(nfx_lib, layers, out, nfx_lib.IN_XYZ, 3)
+    assert blob.nbytes == 136 * 1024 + 544 * 4
+    pts = np.random.default_rng(4).uniform(-1.5, 1.5, size=(32, 3)).astype(np.float32)
+    got = emu.mlp128_xyz_tile(blob, pts, 3)
+    want = R.mlp128(nerf_ref.embed(pts, 10), layers, out, None, quant=nerf_ref.bf16_round)
+    np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-3)
+
+
+def test_lvis_pack_through_emulation(nfx_lib):
+    layers, out = _net128(5, 90, 1)
+    blob = _pack(nfx_lib, layers, out, nfx_lib.IN_XYZ_LDIR, 1)
+    assert blob.nbytes == (32 * 1024 + 1024) + (136 * 1024 + 544 * 4)
+    rng = np.random.default_rng(6)
+    pt = rng.uniform(-1, 1, size=3).astype(np.float32)
+    ldirs = nerf_ref.l2_normalize(rng.normal(size=(32, 3)).astype(np.float32), 1, 1e-6)
+    got = emu.lvis_tile(blob, pt, ldirs)
+    x = np.concatenate((nerf_ref.embed(np.broadcast_to(pt, (32, 3)), 10), nerf_ref.embed(ldirs, 4)), -1)
+    want = R.mlp128(x, layers, out, None, quant=nerf_ref.bf16_round)[:, 0]
+    # the per-point fold keeps the posenc(xyz) partial sums in fp32 (more accurate than rounding
+    # the concatenated input): compare against both the rounded and the fp32 evaluation
+    want32 = R.mlp128(x, layers, out, None)[:, 0]
+    assert np.max(np.abs(got - want)) < 1.5e-2 and np.max(np.abs(got - want32)) < 3e-2
+
+
+@pytest.mark.parametrize("zd", [3, 1, 6])
+def test_brdf_pack_through_emulation(nfx_lib, zd):
+    layers, out = _net128(7, zd + 15, 1)
+    blob = _pack(nfx_lib, layers, out, nfx_lib.IN_Z_RUSINK, 1, z_dim=zd)
+    rng = np.random.default_rng(8)
+    z = rng.normal(size=(32, zd)).astype(np.float32)
+    rus = rng.uniform(0, np.pi / 2, size=(32, 3)).astype(np.float32)
+    got = emu.brdf_tile(blob, z, rus)
+    x = np.concatenate((z, nerf_ref.embed(rus, 2)), -1)
+    want = R.mlp128(x, layers, out, None, quant=nerf_ref.bf16_round)[:, 0]
+    np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-3)
