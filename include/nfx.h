@@ -136,14 +136,16 @@ int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const v
 
 /* Light-visibility MLP over the light sphere, _pred_lvis_at (shape.py:213-237) with the
  * light directions of _calc_ldir (shape.py:128-135) recomputed in registers:
- * lvis[n, l] = sigmoid(out(mlp([pe10(xyz_scale*xyz_n), pe4(normalize(lxyz_l - xyz_n))]))).
- * dev_lxyz [n_lights, 3].  out [n, n_lights].                                */
+ * lvis[n, l] = sigmoid(out(mlp([pe10(xyz_scale*xyz_n), pe4(normalize(lxyz_l - xyz_dir_n))]))).
+ * dev_xyz_dir: the points the DIRECTIONS are taken from; NULL = dev_xyz.  (The reference's
+ * smoothness term evaluates the MLP at jittered points but keeps the directions of the
+ * un-jittered ones: nerfactor.py:195,226.)  dev_lxyz [n_lights, 3].  out [n, n_lights].   */
 /* The posenc(xyz) rows of layers 0 and 3 are evaluated once per point into a caller-provided
  * workspace of nfx_lvis_workspace_bytes(n) bytes (16-byte aligned); n_lights % 32 == 0.      */
 size_t nfx_lvis_workspace_bytes(int64_t n);
-int nfx_lvis_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const float *dev_lxyz,
-                 int n_lights, const void *dev_blob, int prec, void *dev_workspace,
-                 size_t workspace_bytes, float *dev_lvis, void *stream);
+int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
+                 const float *dev_lxyz, int n_lights, const void *dev_blob, int prec,
+                 void *dev_workspace, size_t workspace_bytes, float *dev_lvis, void *stream);
 
 /* Fused shading integral, Model._render.integrate (nerfactor.py:315-365) with the
  * analytic microfacet BRDF of brdf/microfacet/microfacet.py:30-111 evaluated in

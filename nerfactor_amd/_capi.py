@@ -44,7 +44,7 @@ SIGNATURES = {
     'nfx_sample_fine': (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     'nfx_mlp128_xyz_fwd': (_i, [_p, _i64, _f, _p, _i, _i, _f, _f, _i, _p, _p]),
     'nfx_lvis_workspace_bytes': (_sz, [_i64]),
-    'nfx_lvis_fwd': (_i, [_p, _i64, _f, _p, _i, _p, _i, _p, _sz, _p, _p]),
+    'nfx_lvis_fwd': (_i, [_p, _p, _i64, _f, _p, _i, _p, _i, _p, _sz, _p, _p]),
     'nfx_shade_lds_bytes': (_sz, [_i, _i]),
     'nfx_shade_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
     'nfx_shade_olat_fwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _f, _f, _i64, _i, _i, _p,

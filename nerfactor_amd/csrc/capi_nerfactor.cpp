@@ -139,9 +139,9 @@ int nfx_mlp128_xyz_fwd(const float* xyz, int64_t n, float xyz_scale, const void*
 
 size_t nfx_lvis_workspace_bytes(int64_t n) { return n > 0 ? (size_t)n * 256 * sizeof(float) : 0; }
 
-int nfx_lvis_fwd(const float* xyz, int64_t n, float xyz_scale, const float* lxyz, int n_lights,
-                 const void* blob, int prec, void* workspace, size_t workspace_bytes, float* lvis,
-                 void* stream) {
+int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale, const float* lxyz,
+                 int n_lights, const void* blob, int prec, void* workspace, size_t workspace_bytes,
+                 float* lvis, void* stream) {
     using namespace nfx::m128;
     REQUIRE(n >= 0, "nfx_lvis_fwd: n < 0");
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_lvis_fwd: n_lights (%d) must be a positive multiple of 32",
@@ -159,7 +159,9 @@ int nfx_lvis_fwd(const float* xyz, int64_t n, float xyz_scale, const float* lxyz
     int rc = nfx_hip_result(nfx_launch_lvis_pre(xyz, n, xyz_scale, b, pre, blocks, (hipStream_t)stream), "lvis_pre");
     if (rc) return rc;
     return nfx_hip_result(
-        nfx_launch_lvis(xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis, blocks, (hipStream_t)stream), "lvis_fwd");
+        nfx_launch_lvis(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis, blocks,
+                        (hipStream_t)stream),
+        "lvis_fwd");
 }
 
 int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,

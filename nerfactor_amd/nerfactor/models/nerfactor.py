@@ -1,0 +1,319 @@
+"""models.nerfactor.Model — the NeRFactor factorisation forward (reference:
+nerfactor/models/nerfactor.py:33-541): surface points -> normals, light visibility, albedo, BRDF
+latent -> learned-BRDF evaluation -> rendering integral (+ relighting) -> losses.
+
+Per-ray work runs in libnfx:
+    normals / albedo / z      nfx_mlp128_xyz_fwd
+    light visibility          nfx_lvis_fwd            (N x L rows, posenc(xyz) folded per point)
+    learned BRDF (specular)   nfx_brdf_spec_fwd       (world->local, Rusinkiewicz, frozen MLP)
+    render + light probes     nfx_shade_fwd           (all probes in one pass over the sphere)
+    OLAT relighting           nfx_shade_olat_fwd
+Masking / compaction / scatter of the alpha > 0 rays is torch indexing (plumbing).
+"""
+from collections import OrderedDict
+import glob
+from os.path import basename, join
+
+import numpy as np
+import torch
+
+from nerfactor_amd import _capi, ops
+
+from .. import config as default_configs
+from ..util import config as configutil, img as imgutil, math as mathutil
+from .brdf import Model as BRDFModel
+from .shape import Model as ShapeModel, _mae, _mse
+
+
+class Model(ShapeModel):
+    def __init__(self, config, debug=False):
+        # --- BRDF prior (frozen): its own config sits next to its checkpoint
+        brdf_ckpt = config.get('DEFAULT', 'brdf_model_ckpt', fallback='none')
+        self.config_brdf = self._load_sub_config(brdf_ckpt, 'brdf')
+        self.pred_brdf = config.getboolean('DEFAULT', 'pred_brdf')
+        self.z_dim = self.config_brdf.getint('DEFAULT', 'z_dim')
+        self.normalize_brdf_z = self.config_brdf.getboolean('DEFAULT', 'normalize_z')
+        # --- shape
+        self.shape_mode = config.get('DEFAULT', 'shape_mode')
+        self.shape_model_ckpt = config.get('DEFAULT', 'shape_model_ckpt', fallback='none')
+        self.config_shape = None
+        if self.shape_mode not in ('nerf', 'scratch'):
+            self.config_shape = self._load_sub_config(self.shape_model_ckpt, 'shape')
+        self._brdf_ckpt = brdf_ckpt
+        super().__init__(config, debug=debug)
+        self.albedo_smooth_weight = config.getfloat('DEFAULT', 'albedo_smooth_weight')
+        self.brdf_smooth_weight = config.getfloat('DEFAULT', 'brdf_smooth_weight')
+        self._init_brdf_model()
+        self._init_lighting()
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _load_sub_config(ckpt, default_name):
+        if configutil.ckpt_available(ckpt):
+            return configutil.read_config(configutil.get_config_ini(ckpt))
+        return default_configs.make_config(default_name)
+
+    def _init_brdf_model(self):
+        self.brdf_model = BRDFModel(self.config_brdf)
+        if configutil.ckpt_available(self._brdf_ckpt):
+            configutil.restore_model(self.brdf_model, self._brdf_ckpt)
+        for p in self.brdf_model.parameters():
+            p.requires_grad_(False)  # the prior stays frozen (nerfactor.py:60)
+
+    def _init_lighting(self):
+        cfg = self.config
+        light_h = cfg.getint('DEFAULT', 'light_h')
+        self.light_res = (light_h, 2 * light_h)
+        maxv = cfg.getfloat('DEFAULT', 'light_init_max')
+        self._light = torch.nn.Parameter(torch.rand(self.light_res + (3,)) * maxv)
+        olat_inten = cfg.getfloat('DEFAULT', 'olat_inten', fallback=200)
+        ambi_inten = cfg.getfloat('DEFAULT', 'ambient_inten', fallback=0)
+        self.olat_inten = olat_inten
+        self.olat_ambient = ambi_inten if self.white_bg else 0.
+        # (1) OLAT conditions: names only — the kernel never materialises the one-hot maps
+        n_i = 2 if self.debug else self.light_res[0]
+        n_j = 2 if self.debug else self.light_res[1]
+        self.novel_olat = OrderedDict(
+            ('%04d-%04d' % (i, j), (i, j)) for i in range(n_i) for j in range(n_j))
+        # (2) light probes, [h, w, 3] float tensors (resized to light_res by the loader)
+        self.novel_probes = OrderedDict()
+        envmap_dir = cfg.get('DEFAULT', 'test_envmap_dir', fallback='')
+        for path in sorted(glob.glob(join(envmap_dir, '*.npy'))) if envmap_dir else []:
+            self.add_probe(basename(path)[:-len('.npy')], np.load(path))
+        self.embed_light_h = cfg.getint('DEFAULT', 'embed_light_h', fallback=32)
+
+    def add_probe(self, name, envmap):
+        env = torch.as_tensor(np.asarray(envmap), dtype=torch.float32)
+        if tuple(env.shape) != self.light_res + (3,):
+            raise ValueError("probe %s has shape %s, expected %s" % (
+                name, tuple(env.shape), self.light_res + (3,)))
+        self.novel_probes[name] = env
+
+    def olat_envmap(self, name):
+        """The [h, w, 3] environment map of one OLAT condition (what the reference stores)."""
+        i, j = self.novel_olat[name]
+        env = torch.full(self.light_res + (3,), float(self.olat_ambient))
+        env[i, j, :] += self.olat_inten
+        return env
+
+    def _init_embedder(self):
+        from ..networks.embedder import Embedder
+        embedder = super()._init_embedder()
+        n = self.config_brdf.getint('DEFAULT', 'n_freqs')  # the level the BRDF MLP was trained with
+        embedder['rusink'] = Embedder(incl_input=True, in_dims=3, log2_max_freq=n - 1, n_freqs=n)
+        return embedder
+
+    def _init_net(self):
+        dx = self.embedder['xyz'].out_dims
+        net = {}
+        net['albedo_mlp'], net['albedo_out'] = self._mlp128(dx, 3, 'sigmoid')
+        if self.pred_brdf:
+            net['brdf_z_mlp'], net['brdf_z_out'] = self._mlp128(dx, self.z_dim, self._brdf_z_act())
+        if self.shape_mode == 'scratch':
+            net.update(super()._init_net())
+        elif self.shape_mode in ('frozen', 'finetune'):
+            shape_model = ShapeModel(self.config_shape)
+            if configutil.ckpt_available(self.shape_model_ckpt):
+                configutil.restore_model(shape_model, self.shape_model_ckpt)
+            for p in shape_model.parameters():
+                p.requires_grad_(self.shape_mode == 'finetune')
+            for k in ('normal_mlp', 'normal_out', 'lvis_mlp', 'lvis_out'):
+                net[k] = shape_model.net[k]
+        elif self.shape_mode != 'nerf':
+            raise ValueError(self.shape_mode)
+        return net
+
+    @staticmethod
+    def _brdf_z_act():
+        return None  # linear latent code; the microfacet variant squashes roughness to [0, 1]
+
+    # ------------------------------------------------------------------ lighting
+    @property
+    def light(self):
+        return torch.clamp(self._light, min=0.)  # no negative light
+
+    # ------------------------------------------------------------------ forward
+    def call(self, batch, mode='train', relight_olat=False, relight_probes=False,
+             albedo_scales=None, albedo_override=None, brdf_z_override=None):
+        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
+        self._validate_mode(mode)
+        id_, hw, rayo, _, rgb, alpha, xyz, normal, lvis = batch
+        n_all = alpha.shape[0]
+        idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped
+        rayo, rgb, xyz, normal, lvis = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal, lvis))
+        # The reference also evaluates the jittered copies in vali/test mode (nerfactor.py:198-232)
+        # although only the training loss reads them; they are skipped here outside training.
+        jitter = xyz_jitter_std > 0 and mode == 'train'
+        xyz_j = xyz + torch.randn_like(xyz) * xyz_jitter_std if jitter else None
+        # ------ normals
+        if self.shape_mode == 'nerf':
+            normal_pred, normal_jitter = normal, None
+        else:
+            normal_pred = self._pred_normal_at(xyz)
+            normal_jitter = self._pred_normal_at(xyz_j) if jitter else None
+        normal_pred = ops.l2_normalize3(normal_pred, 1e-6)
+        if normal_jitter is not None:
+            normal_jitter = ops.l2_normalize3(normal_jitter, 1e-6)
+        # ------ light visibility
+        if self.shape_mode == 'nerf':
+            lvis_pred, lvis_jitter = torch.clamp(lvis, 1e-8, 1.), None
+        else:
+            lvis_pred = self._pred_lvis_at(xyz)
+            lvis_jitter = self._pred_lvis_at(xyz_j, dir_pts=xyz) if jitter else None
+        # ------ albedo
+        albedo = self._pred_albedo_at(xyz)
+        albedo_jitter = self._pred_albedo_at(xyz_j) if jitter else None
+        if albedo_scales is not None:
+            albedo = torch.as_tensor(albedo_scales, device=albedo.device).reshape(1, 3) * albedo
+        if albedo_override is not None:
+            ao = torch.as_tensor(albedo_override, dtype=torch.float32, device=albedo.device)
+            albedo = ao[None, :].expand(albedo.shape[0], -1).contiguous() if ao.dim() == 1 else ao[idx]
+        # ------ BRDF latent
+        if not self.pred_brdf:
+            raise NotImplementedError("pred_brdf=False: the reference calls an undefined "
+                                      "_get_default_brdf_at (nerfactor.py:256)")
+        brdf_prop = self._pred_brdf_at(xyz)
+        brdf_prop_jitter = self._pred_brdf_at(xyz_j) if jitter else None
+        if self.normalize_brdf_z:
+            brdf_prop = mathutil.safe_l2_normalize(brdf_prop, axis=1)
+            if brdf_prop_jitter is not None:
+                brdf_prop_jitter = mathutil.safe_l2_normalize(brdf_prop_jitter, axis=1)
+        if brdf_z_override is not None:
+            zo = torch.as_tensor(brdf_z_override, dtype=torch.float32, device=xyz.device)
+            brdf_prop = zo.reshape(1, self.z_dim).expand(brdf_prop.shape[0], -1).contiguous()
+        # ------ rendering equation
+        rgb_pred, rgb_olat, rgb_probes = self._render(
+            xyz, rayo, normal_pred, albedo, brdf_prop, lvis_pred, relight_olat=relight_olat,
+            relight_probes=relight_probes)
+
+        def full(v):  # zero-filled scatter back to all rays (tf.scatter_nd)
+            if v is None:
+                return None
+            out = torch.zeros((n_all,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            out[idx] = v
+            return out
+
+        pred = {'rgb': full(rgb_pred), 'normal': full(normal_pred), 'lvis': full(lvis_pred),
+                'albedo': full(albedo), 'brdf': full(brdf_prop)}
+        if rgb_olat is not None:
+            pred['rgb_olat'] = full(rgb_olat)
+        if rgb_probes is not None:
+            pred['rgb_probes'] = full(rgb_probes)
+        gt = {'rgb': full(rgb), 'normal': full(normal), 'lvis': full(lvis), 'alpha': alpha}
+        loss_kwargs = {
+            'mode': mode, 'normal_jitter': full(normal_jitter), 'lvis_jitter': full(lvis_jitter),
+            'brdf_prop_jitter': full(brdf_prop_jitter), 'albedo_jitter': full(albedo_jitter)}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, loss_kwargs, to_vis
+
+    # ------------------------------------------------------------------ heads
+    def _pred_albedo_at(self, pts):
+        scale = self.config.getfloat('DEFAULT', 'albedo_slope', fallback=0.7)
+        bias = self.config.getfloat('DEFAULT', 'albedo_bias', fallback=0.1)
+        blob = self._blob128('albedo_mlp', 'albedo_out', _capi.IN_XYZ, 3)
+        albedo = ops.mlp128_xyz_fwd(pts, blob, 3, out_act='sigmoid', xyz_scale=self.xyz_scale,
+                                    post_scale=scale, post_bias=bias, prec=self.precision)
+        if not torch.isfinite(albedo).all():
+            raise FloatingPointError("Albedo")
+        return albedo
+
+    def _pred_brdf_at(self, pts):
+        blob = self._blob128('brdf_z_mlp', 'brdf_z_out', _capi.IN_XYZ, self.z_dim)
+        return ops.mlp128_xyz_fwd(pts, blob, self.z_dim, out_act=self._brdf_z_act(),
+                                  xyz_scale=self.xyz_scale, prec=self.precision)
+
+    # ------------------------------------------------------------------ BRDF + rendering
+    def _brdf_terms(self, xyz, cam, normal, brdf_prop):
+        """kwargs for the shading kernels describing the BRDF: learned specular term [N, L]."""
+        blob = self._blob128('brdf_mlp', 'brdf_out', _capi.IN_Z_RUSINK, 1, z_dim=self.z_dim,
+                             nets=self.brdf_model.net)
+        spec = ops.brdf_spec_fwd(xyz, cam, normal, brdf_prop, self.lxyz.reshape(-1, 3), blob,
+                                 prec=self.precision)
+        return {'spec': spec, 'spec_scale': self.config.getfloat('DEFAULT', 'learned_brdf_scale')}
+
+    def _eval_brdf_at(self, pts2l, pts2c, normal, albedo, brdf_prop, xyz=None, cam=None):
+        """[N, L, 3] BRDF values (explicit tensor, reference signature).  The renderer does not
+        use this — it hands the terms of `_brdf_terms` to the fused kernels."""
+        if xyz is None or cam is None:
+            raise ValueError("pass xyz= and cam=: directions are recomputed from points in libnfx")
+        t = self._brdf_terms(xyz, cam, normal, brdf_prop)
+        return albedo[:, None, :] / np.pi + t['spec'][:, :, None] * t['spec_scale']
+
+    def _render(self, xyz, cam, normal, albedo, brdf_prop, light_vis, relight_olat=False,
+                relight_probes=False, white_light_override=False, white_lvis_override=False):
+        to_srgb = self.config.getboolean('DEFAULT', 'linear2srgb')
+        light = torch.ones_like(self.light) if white_light_override else self.light
+        if white_lvis_override:
+            light_vis = torch.ones_like(light_vis)
+        terms = self._brdf_terms(xyz, cam, normal, brdf_prop)
+        lights = [light.reshape(-1, 3)]
+        if relight_probes:
+            lights += [p.to(light.device).reshape(-1, 3) for p in self.novel_probes.values()]
+        common = (xyz, cam, normal, albedo, light_vis, self.lxyz.reshape(-1, 3), self.lareas)
+        out = ops.shade_fwd(*common, torch.stack(lights).detach(), linear2srgb=to_srgb, **terms)
+        rgb = out[:, 0]
+        rgb_probes = out[:, 1:] if relight_probes else None
+        rgb_olat = None
+        if relight_olat:
+            rgb_olat = ops.shade_olat_fwd(*common, self.olat_inten, self.olat_ambient,
+                                          linear2srgb=to_srgb, **terms)
+            if len(self.novel_olat) != rgb_olat.shape[1]:  # debug mode keeps the 2x2 corner only
+                keep = [i * self.light_res[1] + j for (i, j) in self.novel_olat.values()]
+                rgb_olat = rgb_olat[:, keep]
+        for name, v in (("OLAT Renders", rgb_olat), ("Light Probe Renders", rgb_probes)):
+            if v is not None and not torch.isfinite(v).all():
+                raise FloatingPointError(name)
+        return rgb, rgb_olat, rgb_probes
+
+    # ------------------------------------------------------------------ loss
+    def compute_loss(self, pred, gt, **kwargs):
+        cfg = self.config
+        normal_loss_weight = cfg.getfloat('DEFAULT', 'normal_loss_weight')
+        lvis_loss_weight = cfg.getfloat('DEFAULT', 'lvis_loss_weight')
+        smooth = _mae if cfg.getboolean('DEFAULT', 'smooth_use_l1') else _mse
+        light_tv_weight = cfg.getfloat('DEFAULT', 'light_tv_weight')
+        light_achro_weight = cfg.getfloat('DEFAULT', 'light_achro_weight')
+        mode = kwargs.pop('mode')
+        normal_jitter = kwargs.pop('normal_jitter')
+        lvis_jitter = kwargs.pop('lvis_jitter')
+        albedo_jitter = kwargs.pop('albedo_jitter')
+        brdf_prop_jitter = kwargs.pop('brdf_prop_jitter')
+        alpha = gt['alpha']
+        bg = 1. if self.white_bg else 0.
+
+        def on_bg(x):
+            return imgutil.alpha_blend(x, alpha, torch.full_like(x, bg))
+
+        rgb_pred, rgb_gt = on_bg(pred['rgb']), on_bg(gt['rgb'])
+        normal_pred, normal_gt = on_bg(pred['normal']), on_bg(gt['normal'])
+        lvis_pred, lvis_gt = on_bg(pred['lvis']), on_bg(gt['lvis'])
+        loss = _mse(rgb_gt, rgb_pred)
+        if mode == 'vali':
+            return loss
+        if self.shape_mode in ('scratch', 'finetune'):
+            loss = loss + normal_loss_weight * _mse(normal_gt, normal_pred)
+            loss = loss + lvis_loss_weight * _mse(lvis_gt, lvis_pred)
+            if normal_jitter is not None:
+                loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
+            if lvis_jitter is not None:
+                loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
+        if albedo_jitter is not None:
+            loss = loss + self.albedo_smooth_weight * smooth(pred['albedo'], albedo_jitter)
+        if brdf_prop_jitter is not None:
+            loss = loss + self.brdf_smooth_weight * smooth(pred['brdf'], brdf_prop_jitter)
+        if mode == 'train':
+            light = self.light
+            if light_tv_weight > 0:
+                dx = light - torch.roll(light, 1, 1)
+                dy = light - torch.roll(light, 1, 0)
+                loss = loss + light_tv_weight * (dx ** 2 + dy ** 2).sum()
+            if light_achro_weight > 0:
+                dc = light - torch.roll(light, 1, 2)
+                loss = loss + light_achro_weight * (dc ** 2).sum()
+        if not torch.isfinite(loss).all():
+            raise FloatingPointError("Loss")
+        return loss

@@ -1,0 +1,198 @@
+"""models.shape.Model — surface normals + light visibility MLPs (reference:
+nerfactor/models/shape.py:33-277), evaluated by libnfx: nfx_mlp128_xyz_fwd for the normals,
+nfx_lvis_fwd for the visibility of all (point, light) pairs."""
+from os.path import join
+
+import numpy as np
+import torch
+
+from nerfactor_amd import _capi, ops
+from nerfactor_amd.brdf.renderer import gen_light_xyz
+
+from ..networks import mlp
+from ..networks.embedder import Embedder
+from ..util import img as imgutil, math as mathutil
+from .base import Model as BaseModel
+
+
+class Model(BaseModel):
+    def __init__(self, config, debug=False):
+        super().__init__(config, debug=debug)
+        cfg = self.config
+        self.white_bg = cfg.getboolean('DEFAULT', 'white_bg')
+        self.mlp_chunk = cfg.getint('DEFAULT', 'mlp_chunk')
+        self.normal_smooth_weight = cfg.getfloat('DEFAULT', 'normal_smooth_weight', fallback=0.)
+        self.lvis_smooth_weight = cfg.getfloat('DEFAULT', 'lvis_smooth_weight', fallback=0.)
+        self.embedder = self._init_embedder()
+        self.net = self._init_net()
+        # big world-space coordinates (e.g. MVS reconstructions) are scaled before the MLPs
+        self.xyz_scale = cfg.getfloat('DEFAULT', 'xyz_scale', fallback=1.)
+        lxyz, lareas = self._gen_lights()
+        self.register_buffer('lxyz', lxyz)
+        self.register_buffer('lareas', lareas)
+        self.register_trainable()
+
+    # ------------------------------------------------------------------ construction
+    def _gen_lights(self):
+        mvs_root = self.config.get('DEFAULT', 'mvs_root', fallback=None)
+        if mvs_root is None:
+            light_h = self.config.getint('DEFAULT', 'light_h')
+            lxyz, lareas = gen_light_xyz(light_h, 2 * light_h)
+        else:  # MVS initialisation ships its own light locations
+            with open(join(mvs_root, 'lights.npz'), 'rb') as h:
+                data = dict(np.load(h))
+            lxyz, lareas = data['lxyzs'], data['lareas']
+        return (torch.as_tensor(np.asarray(lxyz), dtype=torch.float32),
+                torch.as_tensor(np.asarray(lareas), dtype=torch.float32))
+
+    def _mlp128(self, in_dims, out_dims, out_act):
+        cfg = self.config
+        width = cfg.getint('DEFAULT', 'mlp_width')
+        depth = cfg.getint('DEFAULT', 'mlp_depth')
+        skip_at = cfg.getint('DEFAULT', 'mlp_skip_at')
+        if (width, depth, skip_at) != (128, 4, 2):
+            raise NotImplementedError(
+                "libnfx implements the shipped surface MLP (mlp_width=128, mlp_depth=4, mlp_skip_at=2)")
+        body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
+        body.build(in_dims)
+        head = mlp.Network([out_dims], act=[out_act])
+        head.build(width)
+        return body, head
+
+    def _init_net(self):
+        dx = self.embedder['xyz'].out_dims
+        dl = self.embedder['ldir'].out_dims
+        net = {}
+        net['normal_mlp'], net['normal_out'] = self._mlp128(dx, 3, None)  # normalised elsewhere
+        net['lvis_mlp'], net['lvis_out'] = self._mlp128(dx + dl, 1, 'sigmoid')
+        return net
+
+    def _init_embedder(self):
+        cfg = self.config
+        if not cfg.getboolean('DEFAULT', 'pos_enc'):
+            raise NotImplementedError("pos_enc=False is not supported by the fused kernels")
+        lx = cfg.getint('DEFAULT', 'n_freqs_xyz')
+        ll = cfg.getint('DEFAULT', 'n_freqs_ldir')
+        lv = cfg.getint('DEFAULT', 'n_freqs_vdir')
+        if (lx, ll) != (10, 4):
+            raise NotImplementedError("libnfx implements n_freqs_xyz=10, n_freqs_ldir=4")
+        return {name: Embedder(incl_input=True, in_dims=3, log2_max_freq=L - 1, n_freqs=L)
+                for name, L in (('xyz', lx), ('ldir', ll), ('vdir', lv))}
+
+    # ------------------------------------------------------------------ packed weights
+    def _blob128(self, body_name, head_name, in_kind, out_dim, z_dim=0, nets=None):
+        nets = self.net if nets is None else nets
+        ks, bs = nets[body_name].kernels_and_biases()
+        ko, bo = nets[head_name].kernels_and_biases()
+        ks, bs = ks + ko, bs + bo
+        return self._packed(
+            body_name + self.precision, ks + bs,
+            lambda: ops.pack_mlp128_weights(ks, bs, in_kind, out_dim, z_dim=z_dim, prec=self.precision))
+
+    # ------------------------------------------------------------------ geometry helpers
+    def _calc_ldir(self, pts):
+        """[N,L,3] unit directions surface -> light.  Off-path helper: the kernels recompute these
+        in registers from `self.lxyz`."""
+        d = self.lxyz.reshape(1, -1, 3) - pts[:, None, :]
+        return mathutil.safe_l2_normalize(d, axis=2)
+
+    @staticmethod
+    def _calc_vdir(cam_loc, pts):
+        return mathutil.safe_l2_normalize(cam_loc - pts, axis=1)
+
+    @staticmethod
+    def chunk_apply(func, x, dim, chunk_size):
+        y = torch.zeros((x.shape[0], dim), dtype=torch.float32, device=x.device)
+        for i in range(0, x.shape[0], chunk_size):
+            y[i:i + chunk_size] = func(x[i:i + chunk_size])
+        return y
+
+    # ------------------------------------------------------------------ forward
+    def call(self, batch, mode='train'):
+        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
+        self._validate_mode(mode)
+        id_, hw, _, _, _, alpha, xyz, normal, lvis = batch
+        xyz_noise = torch.randn_like(xyz) * xyz_jitter_std if xyz_jitter_std > 0 else None
+        normal_pred = mathutil.safe_l2_normalize(self._pred_normal_at(xyz), axis=1)
+        normal_jitter = None
+        if xyz_noise is not None and self.normal_smooth_weight > 0:
+            normal_jitter = mathutil.safe_l2_normalize(self._pred_normal_at(xyz + xyz_noise), axis=1)
+        lvis_pred = self._pred_lvis_at(xyz)
+        lvis_jitter = None
+        if xyz_noise is not None and self.lvis_smooth_weight > 0:
+            lvis_jitter = self._pred_lvis_at(xyz + xyz_noise, dir_pts=xyz)
+        pred = {'normal': normal_pred, 'lvis': lvis_pred}
+        gt = {'normal': normal, 'lvis': lvis, 'alpha': alpha}
+        loss_kwargs = {'normal_jitter': normal_jitter, 'lvis_jitter': lvis_jitter}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, loss_kwargs, to_vis
+
+    def _pred_normal_at(self, pts, eps=1e-6):
+        """Raw (un-normalised) normals, +eps so an all-zero prediction cannot break the tangents."""
+        blob = self._blob128('normal_mlp', 'normal_out', _capi.IN_XYZ, 3)
+        return ops.mlp128_xyz_fwd(pts, blob, 3, out_act=None, xyz_scale=self.xyz_scale, post_bias=eps,
+                                  prec=self.precision)
+
+    def _pred_lvis_at(self, pts, surf2l=None, dir_pts=None):
+        """[N,L] visibility of every light from every point.  Directions are recomputed in the
+        kernel from `self.lxyz` and `dir_pts` (default `pts`); an explicit `surf2l` tensor is
+        accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
+        blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
+        lvis = ops.lvis_fwd(pts, self.lxyz.reshape(-1, 3), blob, xyz_scale=self.xyz_scale,
+                            xyz_dir=dir_pts, prec=self.precision)
+        if not torch.isfinite(lvis).all():
+            raise FloatingPointError("Light visibility")
+        return lvis
+
+    # ------------------------------------------------------------------ loss
+    def compute_loss(self, pred, gt, **kwargs):
+        cfg = self.config
+        normal_loss_weight = cfg.getfloat('DEFAULT', 'normal_loss_weight')
+        lvis_loss_weight = cfg.getfloat('DEFAULT', 'lvis_loss_weight')
+        smooth = _mae if cfg.getboolean('DEFAULT', 'smooth_use_l1') else _mse
+        normal_jitter = kwargs.pop('normal_jitter')
+        lvis_jitter = kwargs.pop('lvis_jitter')
+        alpha = gt['alpha']
+        bg = 1. if self.white_bg else 0.
+        normal_pred = imgutil.alpha_blend(pred['normal'], alpha, torch.full_like(gt['normal'], bg))
+        normal_gt = imgutil.alpha_blend(gt['normal'], alpha, torch.full_like(gt['normal'], bg))
+        lvis_pred = imgutil.alpha_blend(pred['lvis'], alpha, torch.full_like(gt['lvis'], bg))
+        lvis_gt = imgutil.alpha_blend(gt['lvis'], alpha, torch.full_like(gt['lvis'], bg))
+        loss = normal_loss_weight * _mse(normal_gt, normal_pred) + \
+            lvis_loss_weight * _mse(lvis_gt, lvis_pred)
+        if normal_jitter is not None:
+            loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
+        if lvis_jitter is not None:
+            loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
+        if not torch.isfinite(loss).all():
+            raise FloatingPointError("Loss")
+        return loss
+
+    # ------------------------------------------------------------------ vis (raw dumps only)
+    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None):
+        """The reference renders PNG/HTML collages here (shape.py:279-360) — out of scope of this
+        hot-path implementation; the tensors are dumped raw so a viewer can be pointed at them."""
+        self._validate_mode(mode)
+        if mode == 'train':
+            return
+        import os
+        os.makedirs(outdir, exist_ok=True)
+        arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                  for k, v in data_dict.items()}
+        np.savez(join(outdir if dump_raw_to is None else os.path.dirname(dump_raw_to) or outdir,
+                      'batch_raw.npz'), **arrays)
+
+    def compile_batch_vis(self, batch_vis_dirs, outpref, mode='train'):
+        return outpref + '.txt'
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean(-1)   # keras.losses.MSE: mean over the last axis
+
+
+def _mae(a, b):
+    return (a - b).abs().mean(-1)

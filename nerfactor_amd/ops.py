@@ -173,15 +173,17 @@ def mlp128_xyz_fwd(xyz, blob, out_dim, out_act=None, xyz_scale=1., post_scale=1.
     return out
 
 
-def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., prec='bf16'):
-    """lvis[n, L]: the light-visibility MLP for every (surface point, light) pair."""
+def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., xyz_dir=None, prec='bf16'):
+    """lvis[n, L]: the light-visibility MLP for every (surface point, light) pair.  `xyz_dir`
+    (default xyz) are the points the light directions are taken from."""
     xyz = _dev(xyz, 'xyz', (None, 3))
+    xyz_dir = _dev(xyz_dir, 'xyz_dir', (xyz.shape[0], 3))
     lxyz = _dev(lxyz, 'lxyz', (None, 3))
     n, nl = xyz.shape[0], lxyz.shape[0]
     out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
     ws_bytes = lib.nfx_lvis_workspace_bytes(n)
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=xyz.device)
-    check(lib.nfx_lvis_fwd(_ptr(xyz), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
+    check(lib.nfx_lvis_fwd(_ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
                            ws.numel() * 4, _ptr(out), _stream()), 'nfx_lvis_fwd')
     return out
 

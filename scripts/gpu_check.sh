@@ -9,7 +9,7 @@ mkdir -p $OUT
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $OUT/gpu.txt
 echo "=== pytest -m gpu" | tee $OUT/pytest_gpu.log
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 | tee -a $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -60 | tee -a $OUT/pytest_gpu.log
 echo "=== smoke" | tee $OUT/smoke.log
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5 | tee -a $OUT/smoke.log
 for v in ${VARIANTS:-1 0}; do
