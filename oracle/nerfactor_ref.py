@@ -39,7 +39,7 @@ def gen_light_xyz(envmap_h, envmap_w, envmap_radius=1e2):
 def one_hot_light(h, w, i, j, inten, ambient, dtype=np.float32):
     """novel_olat entries (nerfactor.py:79-83; util/tensor.py:57-64)."""
     env = np.full((h, w, 3), ambient, dtype)
-    env[i, j, :] += dtype(inten)
+    env[i, j, :] += np.dtype(dtype).type(inten)
     return env
 
 

@@ -9,10 +9,12 @@ mkdir -p $OUT
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $OUT/gpu.txt
 echo "=== pytest -m gpu" | tee $OUT/pytest_gpu.log
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -60 | tee -a $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q -k "${PYTEST_K:-test}" > $OUT/pytest_gpu_full.log 2>&1; tail -15 $OUT/pytest_gpu_full.log | tee -a $OUT/pytest_gpu.log
+if [ "${SMOKE:-1}" = "1" ]; then
 echo "=== smoke" | tee $OUT/smoke.log
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5 | tee -a $OUT/smoke.log
-for v in ${VARIANTS:-1 0}; do
+fi
+for v in ${VARIANTS-1 0}; do
   echo "=== bench variant $v" | tee $OUT/bench_v$v.log
   NFX_NERF_VARIANT=$v timeout 900 python bench.py --steps 5 --warmup 2 $( [ "$v" != "1" ] && echo --no-cpu-baseline ) 2>&1 | tail -3 | tee -a $OUT/bench_v$v.log
 done
