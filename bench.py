@@ -127,10 +127,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    import torch.distributed as dist
+    from nerfactor_amd import dist as nfx_dist
+    nfx_dist.init_from_env(backend='nccl', device=dev)
 
     from nerfactor_amd import build
     build.build()
@@ -157,10 +156,7 @@ def main():
         rgb = render_step(ops, o, d, blobs, evs[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = nfx_dist.max_over_ranks(elapsed, device=dev)
     assert torch.isfinite(rgb).all()
 
     # dominant kernel: the fused NeRF MLP (two launches per step: coarse + fine)

@@ -1,0 +1,87 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).
+
+The reference's only parallelism is data parallelism over rays (tf.distribute.MirroredStrategy,
+trainvali.py:259-330).  Here:
+  * rendering shards rays (or views) across ranks, each rank writes its own slice — no data-path
+    collective;
+  * a training step issues ONE all-reduce on a flat fp32 bucket = [all gradients | scalar loss]
+    (replaces the per-variable NCCL all-reduce of optimizer.apply_gradients, trainvali.py:285, and
+    strategy.reduce(SUM, loss), trainvali.py:322).  1.09-4.77 MB: latency-bound, so one call.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise the default process group from torchrun's environment; returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kwargs = {}
+        if backend == 'nccl' and device is not None:
+            kwargs['device_id'] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
+def shard_range(n, rank=None, world_size=None):
+    """Contiguous slice [lo, hi) of n rays owned by `rank` (sizes differ by at most one)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard(tensor, rank=None, world_size=None):
+    lo, hi = shard_range(tensor.shape[0], rank, world_size)
+    return tensor[lo:hi]
+
+
+def max_over_ranks(value, device='cpu'):
+    """Max of a Python float over all ranks (used for the wall-clock of a timed region)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class FlatBucket:
+    """One flat fp32 buffer holding every gradient plus one trailing scalar slot."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        self.sizes = [p.numel() for p in self.params]
+        n = sum(self.sizes)
+        dev = self.params[0].device if self.params else 'cpu'
+        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p, s in zip(self.params, self.sizes):
+            self.views.append(self.flat[off:off + s].view_as(p))
+            off += s
+
+    def pack(self, grads, scalar):
+        for v, g in zip(self.views, grads):
+            if g is None:
+                v.zero_()
+            else:
+                v.copy_(g)
+        self.flat[-1] = scalar
+
+    def all_reduce(self, stream=None):
+        """Sum over ranks: ONE collective for all gradients and the loss."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        return self.views, self.flat[-1]
