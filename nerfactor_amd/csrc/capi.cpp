@@ -38,6 +38,8 @@ extern "C" {
 // launchers (defined in the .hip files)
 int nfx_launch_nerf_mlp_bf16(const float*, const float*, const float*, long long, int, const void*,
                              float*, int, int, hipStream_t);
+int nfx_launch_nerf_mlp_bf16_v2(const float*, const float*, const float*, long long, int, const void*,
+                                float*, int, hipStream_t);
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
 int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
 int nfx_launch_composite(const float*, const float*, const float*, const float*, long long, int, int,
@@ -85,12 +87,12 @@ int nfx_nerf_pack_weights(const float* const kernels[12], const float* const bia
     const Seg pe_xyz{kPosEnc, 10, 0, nullptr};
     const Seg hid256{kHidden, 256, 0, nullptr};
     // enc[0]: posenc(xyz) 63 -> 256
-    w += pack_layer_bf16({pe_xyz}, {{kernels[0], biases[0], 256}}, 8, 4, w, b + nerf::kBiasL0);
+    w += pack_layer_bf16({pe_xyz}, {{kernels[0], biases[0], 256}}, 8, 8, w, b + nerf::kBiasL0);
     for (int l = 1; l <= 7; ++l) {
         float* bl = b + nerf::kBiasL0 + 256 * l;
         if (l == 5) {  // input = concat(y[256], posenc(xyz)[63])   (mlp.py:47-48)
             const Seg pe_skip{kPosEnc, 10, 256, nullptr};
-            w += pack_layer_bf16({hid256, pe_skip}, {{kernels[5], biases[5], 256}}, 8, 20, w, bl);
+            w += pack_layer_bf16({hid256, pe_skip}, {{kernels[5], biases[5], 256}}, 8, 24, w, bl);
         } else {
             w += pack_layer_bf16({hid256}, {{kernels[l], biases[l], 256}}, 8, 16, w, bl);
         }
@@ -100,7 +102,7 @@ int nfx_nerf_pack_weights(const float* const kernels[12], const float* const bia
                          b + nerf::kBiasBott);
     // rgb_out[0]: concat(bottleneck[256], posenc(view)[27]) -> 128
     const Seg pe_view{kPosEnc, 4, 256, nullptr};
-    w += pack_layer_bf16({hid256, pe_view}, {{kernels[10], biases[10], 128}}, 4, 20, w, b + nerf::kBiasRgb0);
+    w += pack_layer_bf16({hid256, pe_view}, {{kernels[10], biases[10], 128}}, 4, 24, w, b + nerf::kBiasRgb0);
     // rgb_out[1]: 128 -> 3
     const Seg hid128{kHidden, 128, 0, nullptr};
     w += pack_layer_bf16({hid128}, {{kernels[11], biases[11], 3}}, 1, 8, w, b + nerf::kBiasRgb1);
@@ -136,7 +138,13 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
     const long long n_pts = (long long)n_rays * n_samples;
     const int blocks = env_int("NFX_NERF_BLOCKS", 256);
     if (prec == NFX_PREC_BF16) {
+        // 0: 4 waves x 64 points, register-staged weights; 1: 8 waves x 32 points, register-staged;
+        // 2: 8 waves x 32 points, LDS-DMA ring + half-tile phase offset between the wave groups
         const int variant = env_int("NFX_NERF_VARIANT", 1);
+        if (variant == 2)
+            return hip_result(nfx_launch_nerf_mlp_bf16_v2(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
+                                                          (hipStream_t)stream),
+                              "nerf_mlp_fwd(bf16, v2)");
         return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
                                                    blocks, (hipStream_t)stream),
                           "nerf_mlp_fwd(bf16)");

@@ -27,7 +27,7 @@
 namespace nfx {
 
 constexpr int kFragBytes = 1024;                  // 64 lanes x 16 B
-constexpr int kSlotFrags = 20;                    // largest chunk: K = 320 -> 20 k-steps
+constexpr int kSlotFrags = 24;                    // largest chunk: K = 320 -> 20 k-steps, padded to 24
 constexpr int kSlotBytes = kSlotFrags * kFragBytes;
 constexpr int kPieceThreads = 256;                // a "piece" = 256 lanes x 16 B = 4 KiB
 

@@ -87,23 +87,23 @@ def layer(reader, chunk_frags, bias, bias_off, b_ops, n_tiles, relu):
 
 def nerf_tile(blob, pts, views):
     """pts, views [32,3] -> raw [32,4] (rgb, sigma), emulating nerf_mlp_bf16_kernel."""
-    WEIGHT_BYTES = 1192 * 1024
+    WEIGHT_BYTES = 1272 * 1024
     rd = BlobReader(np.asarray(blob), WEIGHT_BYTES)
     bias = rd.b
     pe = posenc_slots(pts.astype(np.float32), 10)
     pv = posenc_slots(views.astype(np.float32), 4)
-    h = layer(rd, 4, bias, 0, pe, 8, True)
+    h = layer(rd, 8, bias, 0, pe, 8, True)
     for l in range(1, 8):
         if l == 5:
-            h = layer(rd, 20, bias, 256 * l, h + pe, 8, True)
+            h = layer(rd, 24, bias, 256 * l, h + pe, 8, True)
         else:
             h = layer(rd, 16, bias, 256 * l, h, 8, True)
     feat = layer(rd, 16, bias, 2048, h, 8, False)
     acc = tile(rd, 16, bias, 2048 + 256, h)
     sigma = acc[:32, 0]
-    r0 = layer(rd, 20, bias, 2048 + 288, feat + pv, 4, True)
+    r0 = layer(rd, 24, bias, 2048 + 288, feat + pv, 4, True)
     acc = tile(rd, 8, bias, 2048 + 288 + 128, r0)
-    assert rd.pos == 1192
+    assert rd.pos == 1272
     return np.stack([acc[:32, 0], acc[:32, 1], acc[:32, 2], sigma], -1)
 
 

@@ -152,7 +152,7 @@ def test_packed_blob_through_lane_emulation_matches_oracle(nfx_lib):
     net = common.nerf_nets(seed=4)[0]
     ks, bs = common.nerf_layers(net)
     blob = ops.pack_nerf_weights(ks, bs, 'bf16').numpy()
-    assert blob.nbytes == nfx_lib.lib.nfx_nerf_packed_bytes(0) == 1192 * 1024 + 2496 * 4
+    assert blob.nbytes == nfx_lib.lib.nfx_nerf_packed_bytes(0) == 1272 * 1024 + 2496 * 4
     pts = rng.uniform(-3, 3, size=(32, 3)).astype(np.float32)
     views = nerf_ref.l2_normalize(rng.normal(size=(32, 3)).astype(np.float32), 1, 1e-12)
     got = emu.nerf_tile(blob, pts, views)

@@ -59,7 +59,7 @@ def test_normalize_and_gen_z(nfx_lib, cuda):
     assert ops.gen_z(2., 6., 64, 0, device=cuda).shape == (0, 64)  # empty batch
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 @pytest.mark.parametrize("n_rays,n_samples", [(1, 64), (300, 64), (77, 192), (4, 5)])
 def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monkeypatch):
     from nerfactor_amd import ops
@@ -81,21 +81,23 @@ def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monk
     assert np.max(np.abs(got - want)) < 0.2  # raw logits / 8x-scaled sigma, pre-activation
 
 
-def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch):
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch, variant):
     """More tiles than workgroups (persistent loop, wrapped weight stream) must equal tile-by-tile."""
     from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_NERF_VARIANT", variant)
     monkeypatch.setenv("NFX_NERF_BLOCKS", "3")
     rng = np.random.default_rng(3)
     net = common.nerf_nets(seed=8)[1]
     blob = ops.pack_nerf_weights(*common.nerf_layers(net)).to(cuda)
-    n = 200
+    n = 2000
     rayo = dev(rng.uniform(-2, 2, size=(n, 3)), cuda)
     rayd = dev(nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12), cuda)
     z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
     full = ops.nerf_mlp_fwd(rayo, rayd, z, blob)
     monkeypatch.setenv("NFX_NERF_BLOCKS", "256")
-    part = torch.cat([ops.nerf_mlp_fwd(rayo[i:i + 50], rayd[i:i + 50], z[i:i + 50], blob)
-                      for i in range(0, n, 50)])
+    part = torch.cat([ops.nerf_mlp_fwd(rayo[i:i + 500], rayd[i:i + 500], z[i:i + 500], blob)
+                      for i in range(0, n, 500)])
     assert torch.equal(full, part)
 
 
@@ -229,3 +231,21 @@ def test_full_frame_properties(nfx_lib, cuda):
     sel = torch.from_numpy(idx).to(cuda)
     for k in ('rgb_c', 'rgb_f', 'z_all'):
         assert torch.equal(out[k][sel], sub[k]), k
+
+
+def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
+    """Variants 1 and 2 differ in weight pipeline and wave schedule only — same MFMA order, so the
+    outputs must be bit-identical (a DMA/LDS race in variant 2 would show up here)."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(9)
+    blob = ops.pack_nerf_weights(*common.nerf_layers(common.nerf_nets(seed=12)[0])).to(cuda)
+    n = 20000
+    rayo = dev(rng.uniform(-2, 2, size=(n, 3)), cuda)
+    rayd = dev(nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12), cuda)
+    z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
+    outs = {}
+    for v in ("1", "2"):
+        monkeypatch.setenv("NFX_NERF_VARIANT", v)
+        outs[v] = [ops.nerf_mlp_fwd(rayo, rayd, z, blob) for _ in range(3)]
+    for t in outs["1"][1:] + outs["2"]:
+        assert torch.equal(outs["1"][0], t)
