@@ -167,6 +167,17 @@ def main():
     achieved = pts_per_step * FLOP_PER_POINT / mlp_avg_s / 1e12
     fine_tf = n_rays * (N_COARSE + N_FINE) * FLOP_PER_POINT / (float(np.mean(fine_ms)) * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so
+    # the figure comes from the committed digest of the same workload (scripts/gpu_pmc.sh ->
+    # scripts/pmc_digest.py): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch pair.
+    traffic = None
+    variant = os.environ.get("NFX_NERF_VARIANT", "1")
+    dig = os.path.join(ROOT, 'profiles', 'r01', 'pmc_variant%s_digest.json' % variant)
+    if os.path.exists(dig):
+        for k, v in json.load(open(dig)).items():
+            if 'nerf_mlp' in k and 'hbm_write_bytes' in v:
+                # digest = average over the coarse and the fine dispatch; a launch pair = both
+                traffic = 2 * (v.get('hbm_read_bytes_corrected', 0) + v['hbm_write_bytes']) / 1e9
     if rank == 0:
         out = {
             "metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)",
@@ -181,11 +192,12 @@ def main():
                             "64+128 samples (BASELINE.json configs[1])",
                 "rays_per_step_per_gpu": n_rays, "n_samples_coarse": N_COARSE,
                 "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
-                "kernel_variant": os.environ.get("NFX_NERF_VARIANT", "1")},
+                "kernel_variant": variant},
             "roofline": {
                 "bound": "mfma", "kernel": "nerf_mlp_bf16_kernel (coarse + fine launches)",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch pair",
+                "algorithmic_hbm_gb": pts_per_step * 20 / 1e9,
                 "flop_per_launch_pair": pts_per_step * FLOP_PER_POINT,
                 "avg_launch_pair_ms": mlp_avg_s * 1e3, "fine_launch_tflops": fine_tf,
                 "mlp_share_of_step": mlp_avg_s / (elapsed / args.steps)},

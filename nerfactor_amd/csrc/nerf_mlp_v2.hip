@@ -80,20 +80,42 @@ __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
     for (int i = 0; i < n; ++i) dma_piece(cx.lane_off, g + i * 1024, l + i * 1024);
 }
 
-template <int S0, int S1, int KS1, int KS1A, int KS2A, int CT>
+// acc += sum over k-steps [S0, S1) with the A fragments software-pipelined kDepth deep: measured on
+// variant 1 (rocprofv3 PMC, profiles/r01): waves spent 57 % of their cycles in s_waitcnt/barrier and
+// the MFMA pipe was 53 % busy because only two ds_read_b128 were in flight per wave — every second
+// MFMA waited a full LDS round trip.
+constexpr int kDepth = 4;
+template <int S0, int S1, int KS1, int PRE, int KS1A, int KS2A, int CT>
 __device__ __forceinline__ void mma_range(const char* lane_frag0, const bf16x8 (&b1)[KS1A][CT],
                                           const bf16x8 (&b2)[KS2A][CT], f32x16 (&acc)[CT]) {
-    static_for<S0, S1>([&](auto S) {
-        constexpr int s = decltype(S)::value;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lane_frag0 + s * kFragBytes);
+    constexpr int N = S1 - S0;
+    bf16x8 a[N];
+    static_for<0, (kDepth < N ? kDepth : N)>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        a[i] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (S0 + i) * kFragBytes);
+    });
+    static_for<0, N>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int s = S0 + i;
+        if constexpr (i + kDepth < N)
+            a[i + kDepth] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (s + kDepth) * kFragBytes);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if constexpr (s < KS1)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1[s][c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b1[s][c], acc[c], 0, 0, 0);
             else
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2[s - KS1][c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b2[s - KS1][c], acc[c], 0, 0, 0);
         }
     });
+    // Pin the schedule (the machine scheduler otherwise re-sinks the reads to 2 in flight):
+    // [PRE + kDepth ds_reads] then (1 MFMA, 1 ds_read) ... then the last kDepth MFMAs.
+    constexpr int D = kDepth < N ? kDepth : N;
+    __builtin_amdgcn_sched_group_barrier(0x100, PRE + D, 0);
+    static_for<0, N - D>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+    __builtin_amdgcn_sched_group_barrier(0x008, D * CT, 0);
 }
 
 // One 32-row output tile = chunk K of the pass.
@@ -107,15 +129,15 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* bias_tile,
     constexpr int KS = KS1 + KS2, H1 = KS / 2;
     static_assert(KS <= nerf::chunk_frags(K), "chunk too small");
     const char* f0 = cx.ring + (K % kRing) * kSlot + cx.lane * 16;
-    bias_init<1>(bias_tile, cx.lane >> 5, acc);
     if (!cx.grp_b) wait_vm<N1>();      // A: my share of chunk K has landed
     wg_barrier();                      // even barrier for A (chunk K readable), odd for B
     if (cx.grp_b) dma_chunk<(K + 2) % kN>(cx);
-    mma_range<0, H1, KS1>(f0, b1, b2, acc);
+    bias_init<1>(bias_tile, cx.lane >> 5, acc);   // 4 ds_read_b128, scheduled with the first fragments
+    mma_range<0, H1, KS1, 4>(f0, b1, b2, acc);
     if (cx.grp_b) wait_vm<N2>();       // B: my share of chunk K+1 has landed
     wg_barrier();                      // odd barrier for A, even for B
     if (!cx.grp_b) dma_chunk<(K + 2) % kN>(cx);
-    mma_range<H1, KS, KS1>(f0, b1, b2, acc);
+    mma_range<H1, KS, KS1, 0>(f0, b1, b2, acc);
 }
 
 template <int K0, int KS1, int KS2, int NT, bool RELU, int KS1A, int KS2A, int NTA>

@@ -186,7 +186,8 @@ def test_full_render_vs_fp32_oracle(nfx_lib, cuda):
         assert np.quantile(err, 0.9) <= 5e-3  # the bulk is far inside the bound
     # resampled depths: same discontinuity (weights of the last bin), compare the stable rays
     dz = np.abs(got['z_all'] - aux['z_all'])[ok_c]
-    assert np.quantile(dz, 0.99) <= 0.05 and dz.mean() <= 5e-3  # a sample may hop one coarse bin
+    # a sample may hop one coarse bin (bin width (far-near)/63 = 0.0635)
+    assert np.quantile(dz, 0.99) <= 0.07 and dz.mean() <= 5e-3
 
 
 def test_model_plugin_matches_ops(nfx_lib, cuda):
