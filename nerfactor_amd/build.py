@@ -22,6 +22,8 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # multiply-adds appear only where written as fmaf().
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
          '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include')]
+if os.environ.get('NFX_ABLATION_BUILD'):  # diagnostic instantiations of the v2 kernel
+    FLAGS.append('-DNFX_ABLATION_BUILD')
 
 
 def _sources():

@@ -39,6 +39,8 @@ extern "C" {
 int nfx_launch_nerf_mlp_bf16(const float*, const float*, const float*, long long, int, const void*,
                              float*, int, int, hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v2(const float*, const float*, const float*, long long, int, const void*,
+                                float*, int, int, hipStream_t);
+int nfx_launch_nerf_mlp_bf16_v3(const float*, const float*, const float*, long long, int, const void*,
                                 float*, int, hipStream_t);
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
 int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
@@ -141,9 +143,13 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
         // 0: 4 waves x 64 points, register-staged weights; 1: 8 waves x 32 points, register-staged;
         // 2: 8 waves x 32 points, LDS-DMA ring + half-tile phase offset between the wave groups
         const int variant = env_int("NFX_NERF_VARIANT", 1);
+        if (variant == 3)  // segment-level LOAD/COMP anti-phase between the two waves of a SIMD, 6-slot DMA ring
+            return hip_result(nfx_launch_nerf_mlp_bf16_v3(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
+                                                          (hipStream_t)stream),
+                              "nerf_mlp_fwd(bf16, v3)");
         if (variant == 2)
             return hip_result(nfx_launch_nerf_mlp_bf16_v2(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          (hipStream_t)stream),
+                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v2)");
         return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
                                                    blocks, (hipStream_t)stream),

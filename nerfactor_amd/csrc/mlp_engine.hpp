@@ -113,35 +113,21 @@ __device__ __forceinline__ void bias_init(const float* bias_tile, int h, f32x16 
     }
 }
 
-// acc += A(frag 0 .. KS-1 from lane_frag0) x b[s], with the A-fragment ds_reads software-pipelined
-// kMmaDepth deep and the schedule pinned (the machine scheduler otherwise re-sinks the reads to two
-// in flight, and every second MFMA then waits a full LDS round trip: rocprofv3 PMC on r01 showed
-// 57 % of wave cycles in s_waitcnt/barrier and the MFMA pipe 53 % busy).
-constexpr int kMmaDepth = 4;
+// acc += A(frag 0 .. KS-1 from lane_frag0) x b[s].
+// (A depth-4 software pipeline of the ds_reads pinned with sched_group_barrier was measured on r01:
+//  no throughput change on any variant and 10-100x longer compiles — the LDS round trip is not
+//  what limits these kernels; left to the compiler's own schedule.)
 template <int KS, int KSA, int CT>
 __device__ __forceinline__ void mma_k(const char* lane_frag0, const bf16x8 (&b)[KSA][CT],
                                       f32x16 (&acc)[CT]) {
     static_assert(KS <= KSA, "operand array too small");
-    constexpr int D = kMmaDepth < KS ? kMmaDepth : KS;
-    bf16x8 a[KS];
-    static_for<0, D>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        a[i] = *reinterpret_cast<const bf16x8*>(lane_frag0 + i * kFragBytes);
-    });
-    static_for<0, KS>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (i + D < KS)
-            a[i + D] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (i + D) * kFragBytes);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lane_frag0 + s * kFragBytes);
 #pragma unroll
         for (int c = 0; c < CT; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i][c], acc[c], 0, 0, 0);
-    });
-    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);  // DS read
-    static_for<0, KS - D>([&](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    });
-    __builtin_amdgcn_sched_group_barrier(0x008, D * CT, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][c], acc[c], 0, 0, 0);
+    }
 }
 
 // One 32-row output tile: acc = init + W_tile^T [b1 ; b2].  Consumes one chunk.

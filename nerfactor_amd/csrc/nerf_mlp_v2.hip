@@ -27,6 +27,9 @@ constexpr int kLds = kBiasBytes + kRing * kSlot;
 static_assert(nerf::kBiasFloats * 4 <= kBiasBytes, "bias region");
 typedef __attribute__((address_space(3))) char lds_char;
 
+// Ablation mask (diagnostic, NFX_ABLATE): 1 no weight DMA / vmcnt waits, 2 no workgroup barriers, 4 no MFMA,
+// 8 no A-fragment ds_reads, 16 no epilogue (ReLU/convert), 32 no positional encoding.  Results are wrong by
+// construction for any non-zero mask; only the timing is meaningful.
 struct Ctx {
     const char* blob;
     char* ring;         // generic pointer to the ring (for ds_read)
@@ -36,13 +39,15 @@ struct Ctx {
     bool grp_b;
 };
 
-template <int N>
+template <int N, int AB = 0>
 __device__ __forceinline__ void wait_vm() {
+    if constexpr (AB & 1) return;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int AB = 0>
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(AB & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
@@ -63,8 +68,9 @@ __device__ __forceinline__ void dma_piece(unsigned lane_off, const char* gbase, 
 }
 
 // This wave's share of chunk J: pieces [wave*n, wave*n + n), n = frags(J) / 8.
-template <int J>
+template <int J, int AB = 0>
 __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
+    if constexpr (AB & 1) return;
     constexpr int n = nerf::chunk_frags(J) / 8;
     constexpr int goff = nerf::chunk_frag_offset(J) * 1024;
     // Opaque copies: without them LICM hoists the ~160 loop-invariant piece addresses of a pass out
@@ -85,20 +91,28 @@ __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
 // the MFMA pipe was 53 % busy because only two ds_read_b128 were in flight per wave — every second
 // MFMA waited a full LDS round trip.
 constexpr int kDepth = 4;
-template <int S0, int S1, int KS1, int PRE, int KS1A, int KS2A, int CT>
+constexpr bool kPinSchedule = false;  // sched_group_barrier pinning: no gain measured, slow compiles
+template <int S0, int S1, int KS1, int PRE, int AB, int KS1A, int KS2A, int CT>
 __device__ __forceinline__ void mma_range(const char* lane_frag0, const bf16x8 (&b1)[KS1A][CT],
                                           const bf16x8 (&b2)[KS2A][CT], f32x16 (&acc)[CT]) {
     constexpr int N = S1 - S0;
     bf16x8 a[N];
+    if constexpr (AB & 8) {
+        static_for<0, N>([&](auto I) { a[decltype(I)::value] = b1[0][0]; });
+    }
     static_for<0, (kDepth < N ? kDepth : N)>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        a[i] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (S0 + i) * kFragBytes);
+        if constexpr (!(AB & 8)) a[i] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (S0 + i) * kFragBytes);
     });
     static_for<0, N>([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int s = S0 + i;
-        if constexpr (i + kDepth < N)
+        if constexpr (i + kDepth < N && !(AB & 8))
             a[i + kDepth] = *reinterpret_cast<const bf16x8*>(lane_frag0 + (s + kDepth) * kFragBytes);
+        if constexpr (AB & 4) {
+            asm volatile("" ::"v"(a[i]));
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if constexpr (s < KS1)
@@ -109,6 +123,7 @@ __device__ __forceinline__ void mma_range(const char* lane_frag0, const bf16x8 (
     });
     // Pin the schedule (the machine scheduler otherwise re-sinks the reads to 2 in flight):
     // [PRE + kDepth ds_reads] then (1 MFMA, 1 ds_read) ... then the last kDepth MFMAs.
+    if constexpr ((AB & (4 | 8)) || !kPinSchedule) return;
     constexpr int D = kDepth < N ? kDepth : N;
     __builtin_amdgcn_sched_group_barrier(0x100, PRE + D, 0);
     static_for<0, N - D>([&](auto) {
@@ -119,7 +134,7 @@ __device__ __forceinline__ void mma_range(const char* lane_frag0, const bf16x8 (
 }
 
 // One 32-row output tile = chunk K of the pass.
-template <int K, int KS1, int KS2, int KS1A, int KS2A>
+template <int K, int KS1, int KS2, int AB, int KS1A, int KS2A>
 __device__ __forceinline__ void tile(const Ctx& cx, const float* bias_tile,
                                      const bf16x8 (&b1)[KS1A][1], const bf16x8 (&b2)[KS2A][1],
                                      f32x16 (&acc)[1]) {
@@ -129,29 +144,36 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* bias_tile,
     constexpr int KS = KS1 + KS2, H1 = KS / 2;
     static_assert(KS <= nerf::chunk_frags(K), "chunk too small");
     const char* f0 = cx.ring + (K % kRing) * kSlot + cx.lane * 16;
-    if (!cx.grp_b) wait_vm<N1>();      // A: my share of chunk K has landed
-    wg_barrier();                      // even barrier for A (chunk K readable), odd for B
-    if (cx.grp_b) dma_chunk<(K + 2) % kN>(cx);
+    if (!cx.grp_b) wait_vm<N1, AB>();      // A: my share of chunk K has landed
+    wg_barrier<AB>();                      // even barrier for A (chunk K readable), odd for B
+    if (cx.grp_b) dma_chunk<(K + 2) % kN, AB>(cx);
     bias_init<1>(bias_tile, cx.lane >> 5, acc);   // 4 ds_read_b128, scheduled with the first fragments
-    mma_range<0, H1, KS1, 4>(f0, b1, b2, acc);
-    if (cx.grp_b) wait_vm<N2>();       // B: my share of chunk K+1 has landed
-    wg_barrier();                      // odd barrier for A, even for B
-    if (!cx.grp_b) dma_chunk<(K + 2) % kN>(cx);
-    mma_range<H1, KS, KS1, 0>(f0, b1, b2, acc);
+    mma_range<0, H1, KS1, 4, AB>(f0, b1, b2, acc);
+    if (cx.grp_b) wait_vm<N2, AB>();       // B: my share of chunk K+1 has landed
+    wg_barrier<AB>();                      // odd barrier for A, even for B
+    if (!cx.grp_b) dma_chunk<(K + 2) % kN, AB>(cx);
+    mma_range<H1, KS, KS1, 0, AB>(f0, b1, b2, acc);
 }
 
-template <int K0, int KS1, int KS2, int NT, bool RELU, int KS1A, int KS2A, int NTA>
+template <int K0, int KS1, int KS2, int NT, bool RELU, int AB, int KS1A, int KS2A, int NTA>
 __device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const bf16x8 (&b1)[KS1A][1],
                                       const bf16x8 (&b2)[KS2A][1], bf16x8 (&bout)[NTA][1]) {
     static_assert(2 * NT <= NTA, "output array too small");
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
         f32x16 acc[1];
-        tile<K0 + t, KS1, KS2>(cx, bias + 32 * t, b1, b2, acc);
-        acc_to_b<RELU, 1>(acc, bout[2 * t], bout[2 * t + 1]);
+        tile<K0 + t, KS1, KS2, AB>(cx, bias + 32 * t, b1, b2, acc);
+        if constexpr (AB & 16) {
+            asm volatile("" ::"v"(acc[0]));
+            bout[2 * t][0] = b1[0][0];
+            bout[2 * t + 1][0] = b1[0][0];
+        } else {
+            acc_to_b<RELU, 1>(acc, bout[2 * t], bout[2 * t + 1]);
+        }
     });
 }
 
+template <int AB>
 __global__ __launch_bounds__(512, 2) void nerf_mlp_bf16_v2_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf,
     long long n_pts, int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
@@ -173,12 +195,12 @@ __global__ __launch_bounds__(512, 2) void nerf_mlp_bf16_v2_kernel(
         const float* bsrc = reinterpret_cast<const float*>(blob + nerf::kWeightBytes);
         for (int i = tid; i < nerf::kBiasFloats; i += 512) bias_lds[i] = bsrc[i];
     }
-    dma_chunk<0>(cx);
-    dma_chunk<1>(cx);
+    dma_chunk<0, AB>(cx);
+    dma_chunk<1, AB>(cx);
     __syncthreads();  // biases visible to every wave
     if (cx.grp_b) {   // half-a-tile phase offset: B's first tile starts at barrier 1
-        wait_vm<nerf::chunk_frags(1) / 8>();
-        wg_barrier();
+        wait_vm<nerf::chunk_frags(1) / 8, AB>();
+        wg_barrier<AB>();
     }
 
     const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
@@ -195,52 +217,74 @@ __global__ __launch_bounds__(512, 2) void nerf_mlp_bf16_v2_kernel(
                 d[k] = rayd[ray * 3 + k];
                 x[k] = rayo[ray * 3 + k] + d[k] * zz;  // nerf.py:162-163
             }
-            posenc<10, 1>(x, h, 0, pe);
-            posenc<4, 1>(d, h, 0, pv);
+            if constexpr (AB & 32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pe[q][0] = pack8(x[0], x[1], x[2], d[0], d[1], d[2], zz, zz);
+                pv[0][0] = pe[0][0];
+                pv[1][0] = pe[1][0];
+            } else {
+                posenc<10, 1>(x, h, 0, pe);
+                posenc<4, 1>(d, h, 0, pv);
+            }
         }
         bf16x8 ha[16][1], hb[16][1];
         using namespace nerf;
-        layer<0, 4, 0, 8, true>(cx, bias_lds + kBiasL0, pe, pe, ha);
-        layer<8, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 1, ha, pe, hb);
-        layer<16, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 2, hb, pe, ha);
-        layer<24, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 3, ha, pe, hb);
-        layer<32, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 4, hb, pe, ha);
-        layer<40, 16, 4, 8, true>(cx, bias_lds + kBiasL0 + 256 * 5, ha, pe, hb);
-        layer<48, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 6, hb, pe, ha);
-        layer<56, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 7, ha, pe, hb);
-        layer<64, 16, 0, 8, false>(cx, bias_lds + kBiasBott, hb, pe, ha);  // bottleneck
+        layer<0, 4, 0, 8, true, AB>(cx, bias_lds + kBiasL0, pe, pe, ha);
+        layer<8, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 1, ha, pe, hb);
+        layer<16, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 2, hb, pe, ha);
+        layer<24, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 3, ha, pe, hb);
+        layer<32, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 4, hb, pe, ha);
+        layer<40, 16, 4, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 5, ha, pe, hb);
+        layer<48, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 6, hb, pe, ha);
+        layer<56, 16, 0, 8, true, AB>(cx, bias_lds + kBiasL0 + 256 * 7, ha, pe, hb);
+        layer<64, 16, 0, 8, false, AB>(cx, bias_lds + kBiasBott, hb, pe, ha);  // bottleneck
         float sigma;
         {
             f32x16 acc[1];
-            tile<72, 16, 0>(cx, bias_lds + kBiasBott + 256, hb, pe, acc);   // sigma_out row
+            tile<72, 16, 0, AB>(cx, bias_lds + kBiasBott + 256, hb, pe, acc);   // sigma_out row
             sigma = acc[0][0];
         }
         bf16x8 r0[8][1];
-        layer<73, 16, 2, 4, true>(cx, bias_lds + kBiasRgb0, ha, pv, r0);
+        layer<73, 16, 2, 4, true, AB>(cx, bias_lds + kBiasRgb0, ha, pv, r0);
         {
             f32x16 acc[1];
-            tile<77, 8, 0>(cx, bias_lds + kBiasRgb1, r0, pe, acc);
+            tile<77, 8, 0, AB>(cx, bias_lds + kBiasRgb1, r0, pe, acc);
             if (h == 0 && m < n_pts) out[m] = make_float4(acc[0][0], acc[0][1], acc[0][2], sigma);
         }
     }
-    if (!cx.grp_b) wg_barrier();  // matches B's extra initial barrier
+    if (!cx.grp_b) wg_barrier<AB>();  // matches B's extra initial barrier
     wait_vm<0>();                 // the two chunks prefetched for a pass that never comes
 }
 
 }  // namespace v2
 }  // namespace nfx
 
-extern "C" int nfx_launch_nerf_mlp_bf16_v2(const float* rayo, const float* rayd, const float* z,
-                                           long long n_pts, int n_samples, const void* blob, float* out,
-                                           int max_blocks, hipStream_t stream) {
+template <int AB>
+static int launch_v2(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
+                     const void* blob, float* out, int max_blocks, hipStream_t stream) {
     using namespace nfx;
-    if (n_pts <= 0) return 0;
     const long long n_tiles = (n_pts + 255) / 256;
     const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::nerf_mlp_bf16_v2_kernel),
+    auto kern = v2::nerf_mlp_bf16_v2_kernel<AB>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, v2::kLds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(v2::nerf_mlp_bf16_v2_kernel, dim3(grid), dim3(512), v2::kLds, stream, rayo, rayd, z,
-                       n_pts, n_samples, (const char*)blob, (float4*)out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), v2::kLds, stream, rayo, rayd, z, n_pts, n_samples,
+                       (const char*)blob, (float4*)out);
     return (int)hipGetLastError();
+}
+
+extern "C" int nfx_launch_nerf_mlp_bf16_v2(const float* rayo, const float* rayd, const float* z,
+                                           long long n_pts, int n_samples, const void* blob, float* out,
+                                           int max_blocks, int ablate, hipStream_t stream) {
+    if (n_pts <= 0) return 0;
+#define NFX_AB(m) case m: return launch_v2<m>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream)
+    switch (ablate) {
+        NFX_AB(0);
+#ifdef NFX_ABLATION_BUILD
+        NFX_AB(1); NFX_AB(2); NFX_AB(3); NFX_AB(4); NFX_AB(8); NFX_AB(12); NFX_AB(16); NFX_AB(32); NFX_AB(28); NFX_AB(31);
+#endif
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef NFX_AB
 }
