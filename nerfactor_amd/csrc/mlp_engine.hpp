@@ -97,6 +97,32 @@ __device__ __forceinline__ void with_chunk(WStream& ws, int tid, F&& compute) {
     __syncthreads();
 }
 
+// Same as with_chunk, but the size of the NEXT chunk is a run-time (wave-uniform) piece count
+// n_next <= NLMAX: lets identical layers share one rolled loop body (smaller instruction footprint).
+template <int NLMAX, int NW, typename F>
+__device__ __forceinline__ void with_chunk_rt(WStream& ws, int tid, int n_next, F&& compute) {
+    constexpr int G = NW / 4;
+    constexpr int N = (NLMAX + G - 1) / G;
+    u32x4 r[N];
+    const int grp = tid >> 8, t = tid & 255;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = k * G + grp;
+        if (i < n_next) r[k] = ws.gnext[i * kPieceThreads + t];
+    }
+    compute(ws.ring + ws.cur * kSlotBytes);
+    u32x4* dst = reinterpret_cast<u32x4*>(ws.ring + (ws.cur ^ 1) * kSlotBytes);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = k * G + grp;
+        if (i < n_next) dst[i * kPieceThreads + t] = r[k];
+    }
+    ws.gnext += n_next * kPieceThreads;
+    if (ws.gnext == ws.gend) ws.gnext = ws.gbase;
+    ws.cur ^= 1;
+    __syncthreads();
+}
+
 // acc[c][r] <- bias of output row (r&3) + 8(r>>2) + 4h of this tile (bias_tile: 32 floats in LDS).
 template <int CT>
 __device__ __forceinline__ void bias_init(const float* bias_tile, int h, f32x16 (&acc)[CT]) {
@@ -204,6 +230,27 @@ __device__ __forceinline__ void layer(WStream& ws, int tid, const float* bias,
         f32x16 acc[CT];
         tile_raw<KS1, KS2, (t == NT - 1 ? NL_NEXT : NL_SELF), NW>(ws, tid, bias + 32 * t, b1, b2,
                                                                  acc);
+        acc_to_b<RELU, CT>(acc, bout[2 * t], bout[2 * t + 1]);
+    });
+}
+
+// layer() with run-time chunk sizes: nl_self pieces per chunk of this layer, nl_next for the chunk
+// after the layer's last tile (both wave-uniform, <= NLMAX).
+template <int KS1, int KS2, int NT, int NLMAX, bool RELU, int NW, int KS1A, int KS2A, int NTA, int CT>
+__device__ __forceinline__ void layer_rt(WStream& ws, int tid, const float* bias, int nl_self, int nl_next,
+                                         const bf16x8 (&b1)[KS1A][CT], const bf16x8 (&b2)[KS2A][CT],
+                                         bf16x8 (&bout)[NTA][CT]) {
+    static_assert(2 * NT <= NTA, "output array too small");
+    const int lane = tid & 63;
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[CT];
+        bias_init<CT>(bias + 32 * t, lane >> 5, acc);
+        with_chunk_rt<NLMAX, NW>(ws, tid, t == NT - 1 ? nl_next : nl_self, [&](const char* chunk) {
+            const char* f0 = chunk + lane * 16;
+            mma_k<KS1>(f0, b1, acc);
+            if constexpr (KS2 > 0) mma_k<KS2>(f0 + KS1 * kFragBytes, b2, acc);
+        });
         acc_to_b<RELU, CT>(acc, bout[2 * t], bout[2 * t + 1]);
     });
 }

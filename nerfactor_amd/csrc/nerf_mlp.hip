@@ -91,6 +91,84 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void nerf_mlp_bf16_kernel(
     }
 }
 
+
+// Variant 4: variant 1 (8 waves x 32 points, register-staged weights) with the six identical
+// 256->256 ReLU layers (enc[1..4], enc[6..7]) executed by ONE rolled two-layer loop body, to test
+// whether the ~55-110 KiB of straight-line code of the other variants (vs a 64 KiB instruction
+// cache shared by two CUs) is what holds them near 48 % of MFMA peak.  enc[5] sits inside the loop
+// (third trip) followed by a register copy hb -> ha so the body's buffer roles repeat.
+__global__ __launch_bounds__(512, 2) void nerf_mlp_bf16_rolled_kernel(
+    const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf,
+    long long n_pts, int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8, CT = 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, p = lane & 31;
+    constexpr int kTilePts = NW * 32;
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + nerf::kWeightBytes);
+        for (int i = tid; i < nerf::kBiasFloats; i += NW * 64) bias_lds[i] = bsrc[i];
+    }
+    WStream ws;
+    ws.gbase = reinterpret_cast<const u32x4*>(blob);
+    ws.gend = reinterpret_cast<const u32x4*>(blob + nerf::kWeightBytes);
+    ws.gnext = ws.gbase;
+    ws.ring = smem;
+    stream_prologue<nerf::kNL0, NW>(ws, tid);
+    const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bf16x8 pe[4][CT], pv[2][CT];
+        const long long m = tile * kTilePts + wave * 32 + p;
+        {
+            const long long mm = m < n_pts ? m : n_pts - 1;
+            const long long ray = mm / n_samples;
+            const float zz = zbuf[mm];
+            float x[3], d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = rayd[ray * 3 + k];
+                x[k] = rayo[ray * 3 + k] + d[k] * zz;
+            }
+            posenc<10, CT>(x, h, 0, pe);
+            posenc<4, CT>(d, h, 0, pv);
+        }
+        bf16x8 ha[16][CT], hb[16][CT];
+        using namespace nerf;
+        layer<4, 0, 8, kNL0, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0, pe, pe, ha);
+        const float* bias = bias_lds + kBiasL0 + 256;
+#pragma unroll 1
+        for (int it = 0; it < 3; ++it) {
+            if (it == 2) {  // enc[5]: [y, posenc(x)] -> hb, then hb -> ha so the roles below repeat
+                layer<16, 4, 8, kNL5, kNLH, true, NW>(ws, tid, bias, ha, pe, hb);
+                bias += 256;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) ha[s][0] = hb[s][0];
+            }
+            // (it, layer): (0: enc1, enc2) (1: enc3, enc4 -> next chunk is enc5's) (2: enc6, enc7)
+            layer_rt<16, 0, 8, kNL5, true, NW>(ws, tid, bias, kNLH, kNLH, ha, pe, hb);
+            layer_rt<16, 0, 8, kNL5, true, NW>(ws, tid, bias + 256, kNLH, it == 1 ? kNL5 : kNLH, hb, pe, ha);
+            bias += 512;
+        }
+        // after the loop the encoder output is in ha
+        layer<16, 0, 8, kNLH, kNLH, false, NW>(ws, tid, bias_lds + kBiasBott, ha, pe, hb);  // bottleneck -> hb
+        float sigma;
+        {
+            f32x16 acc[CT];
+            tile_raw<16, 0, kNLR0, NW>(ws, tid, bias_lds + kBiasBott + 256, ha, pe, acc);
+            sigma = acc[0][0];
+        }
+        bf16x8 r0[8][CT];
+        layer<16, 2, 4, kNLR0, kNLR1, true, NW>(ws, tid, bias_lds + kBiasRgb0, hb, pv, r0);
+        {
+            f32x16 acc[CT];
+            tile_raw<8, 0, kNL0, NW>(ws, tid, bias_lds + kBiasRgb1, r0, pe, acc);
+            if (h == 0 && m < n_pts) out[m] = make_float4(acc[0][0], acc[0][1], acc[0][2], sigma);
+        }
+    }
+}
+
 }  // namespace nfx
 
 template <int CT, int NW>
@@ -117,6 +195,17 @@ extern "C" int nfx_launch_nerf_mlp_bf16(const float* rayo, const float* rayd, co
                                         float* out, int variant, int max_blocks,
                                         hipStream_t stream) {
     if (n_pts <= 0) return 0;
+    if (variant == 4) {
+        using namespace nfx;
+        const long long n_tiles = (n_pts + 255) / 256;
+        const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bf16_rolled_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kNerfLdsBytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nerf_mlp_bf16_rolled_kernel, dim3(grid), dim3(512), kNerfLdsBytes, stream, rayo,
+                           rayd, z, n_pts, n_samples, (const char*)blob, (float4*)out);
+        return (int)hipGetLastError();
+    }
     if (variant == 0)
         return launch_variant<2, 4>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
     return launch_variant<1, 8>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
