@@ -187,6 +187,34 @@ int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev
                    void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Training (replaces tape.gradient / optimizer.apply_gradients,             */
+/* nerfactor/trainvali.py:278-285, for the pieces built so far).             */
+/* ------------------------------------------------------------------------ */
+
+/* Backward of a width-128 surface MLP call (NFX_IN_XYZ or NFX_IN_XYZ_LDIR): given
+ * dout [rows, out_dim] = dLoss / d(post_scale * act(out) + post_bias), ACCUMULATES the gradients of
+ * the 5 Keras kernels / biases into dev_dkernels[i] ([in, out] fp32) / dev_dbiases[i] ([out] fp32).
+ * rows = n (NFX_IN_XYZ) or n * n_lights (NFX_IN_XYZ_LDIR, row = point * n_lights + light).
+ * The forward is re-computed inside; `blob` is the TRAIN blob (forward + dgrad fragments).
+ * Workspace: nfx_mlp128_bwd_workspace_bytes() bytes, 16-byte aligned.  No input gradients.    */
+size_t nfx_mlp128_train_packed_bytes(int in_kind);
+int nfx_mlp128_pack_train_weights(const float *const kernels[5], const float *const biases[5],
+                                  int in_kind, int out_dim, int prec, void *blob, size_t blob_bytes);
+size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights);
+int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, int64_t n,
+                   float xyz_scale, const float *dev_lxyz, int n_lights, const void *dev_blob,
+                   int out_dim, int out_act, float post_scale, const float *dev_dout,
+                   void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
+                   float *const dev_dbiases[5], int prec, void *stream);
+
+/* tf.keras.optimizers.Adam(amsgrad=True) dense update on flat fp32 buffers (trainvali.py:116-127):
+ * lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step); m, v, vhat updated in place;
+ * p -= lr_t * m / (sqrt(vhat) + eps).  `step` is 1-based.                                      */
+int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
+                     int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                     void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Diagnostics.                                                              */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,156 @@
+// capi_train.cpp — C-ABI entry points of the training-side kernels (include/nfx.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nfx.h"
+#include "mlp128_layout.hpp"
+#include "pack.hpp"
+
+int nfx_fail(int code, const char* fmt, ...);
+int nfx_hip_result(int e, const char* what);
+extern "C" int nfx_env_int(const char* name, int dflt);
+
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return nfx_fail(NFX_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
+
+extern "C" {
+int nfx_launch_mlp128_bwd(int, const float*, const float*, long long, float, const float*, int, const void*, int,
+                          int, float, const float*, void*, long long, int, hipStream_t);
+int nfx_mlp128_train_feats(int in_kind);
+int nfx_mlp128_train_blob_bytes(int in_kind);
+int nfx_launch_wgrad(const void*, const void*, long long, int, int, long long, float*, float*, hipStream_t);
+int nfx_launch_amsgrad(float*, const float*, float*, float*, float*, long long, float, float, float, float,
+                       hipStream_t);
+
+static bool kind_ok(int k) { return k == NFX_IN_XYZ || k == NFX_IN_XYZ_LDIR; }
+static int in_dims(int k) { return k == NFX_IN_XYZ ? 63 : 90; }
+
+size_t nfx_mlp128_train_packed_bytes(int in_kind) {
+    return kind_ok(in_kind) ? (size_t)nfx_mlp128_train_blob_bytes(in_kind) : 0;
+}
+
+int nfx_mlp128_pack_train_weights(const float* const kernels[5], const float* const biases[5], int in_kind,
+                                  int out_dim, int prec, void* blob, size_t blob_bytes) {
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_mlp128_pack_train_weights: null argument");
+    for (int i = 0; i < 5; ++i) REQUIRE(kernels[i] && biases[i], "nfx_mlp128_pack_train_weights: layer %d null", i);
+    REQUIRE(kind_ok(in_kind), "nfx_mlp128_pack_train_weights: in_kind %d has no backward", in_kind);
+    REQUIRE(out_dim >= 1 && out_dim <= 8, "nfx_mlp128_pack_train_weights: out_dim %d not in [1, 8]", out_dim);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_pack_train_weights: only bf16 is built");
+    const size_t need = nfx_mlp128_train_packed_bytes(in_kind);
+    REQUIRE(blob_bytes >= need, "nfx_mlp128_pack_train_weights: blob too small (%zu < %zu)", blob_bytes, need);
+    const int ind = in_dims(in_kind);
+    const bool lv = in_kind == NFX_IN_XYZ_LDIR;
+    const int p0 = lv ? 8 : 4, p3 = lv ? 16 : 12;
+    uint8_t* w = static_cast<uint8_t*>(blob);
+    float* b = reinterpret_cast<float*>(w + need - nfx::m128::kMainBiasFloats * 4);
+    const Seg hid{kHidden, 128, 0, nullptr};
+    std::vector<Seg> in0{Seg{kPosEnc, 10, 0, nullptr}}, in3{hid, Seg{kPosEnc, 10, 128, nullptr}};
+    if (lv) {
+        in0.push_back(Seg{kPosEnc, 4, 63, nullptr});
+        in3.push_back(Seg{kPosEnc, 4, 128 + 63, nullptr});
+    }
+    // ---- forward fragments (same dataflow as the inference kernels, un-folded input)
+    w += pack_layer_bf16(in0, {{kernels[0], biases[0], 128}}, 4, p0, w, b);
+    w += pack_layer_bf16({hid}, {{kernels[1], biases[1], 128}}, 4, 8, w, b + 128);
+    w += pack_layer_bf16({hid}, {{kernels[2], biases[2], 128}}, 4, 8, w, b + 256);
+    w += pack_layer_bf16(in3, {{kernels[3], biases[3], 128}}, 4, p3, w, b + 384);
+    w += pack_layer_bf16({hid}, {{kernels[4], biases[4], out_dim}}, 1, 8, w, b + 512);
+    // ---- dgrad fragments: layer l backward = a Dense whose Keras kernel is W_l^T ([out, in])
+    std::vector<float> scratch_bias(128, 0.f), bias_sink(128 * 4);
+    auto transposed = [&](const float* k, int rows_used, int cols, int pad_rows) {
+        std::vector<float> t((size_t)pad_rows * rows_used, 0.f);  // [cols(pad) , rows_used]
+        for (int r = 0; r < rows_used; ++r)
+            for (int c = 0; c < cols; ++c) t[(size_t)c * rows_used + r] = k[(size_t)r * cols + c];
+        return t;
+    };
+    {   // through the out layer: dH3[128] = Wo[128, out] dZo[out]; 16 padded gradient slots
+        std::vector<float> t = transposed(kernels[4], 128, out_dim, 16);
+        w += pack_layer_bf16({Seg{kHidden, 16, 0, nullptr}}, {{t.data(), nullptr, 128}}, 4, 4, w, bias_sink.data());
+    }
+    {   // through L3: only the h2 rows (first 128) carry a gradient that is needed
+        std::vector<float> t = transposed(kernels[3], 128, 128, 128);
+        w += pack_layer_bf16({hid}, {{t.data(), nullptr, 128}}, 4, 8, w, bias_sink.data());
+    }
+    for (int l = 2; l >= 1; --l) {
+        std::vector<float> t = transposed(kernels[l], 128, 128, 128);
+        w += pack_layer_bf16({hid}, {{t.data(), nullptr, 128}}, 4, 8, w, bias_sink.data());
+    }
+    (void)ind;
+    if (w != reinterpret_cast<uint8_t*>(b)) return nfx_fail(NFX_EINVAL, "nfx_mlp128_pack_train_weights: layout mismatch");
+    return NFX_OK;
+}
+
+static long long ld_for(int in_kind, int64_t n, int n_lights) {
+    const long long rows = in_kind == NFX_IN_XYZ ? n : n * (long long)n_lights;
+    return (rows + 127) / 128 * 128;
+}
+
+size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights) {
+    if (!kind_ok(in_kind) || n <= 0) return 0;
+    return (size_t)nfx_mlp128_train_feats(in_kind) * ld_for(in_kind, n, n_lights) * 2;
+}
+
+int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale,
+                   const float* lxyz, int n_lights, const void* blob, int out_dim, int out_act,
+                   float post_scale, const float* dout, void* workspace, size_t workspace_bytes,
+                   float* const dkernels[5], float* const dbiases[5], int prec, void* stream) {
+    REQUIRE(kind_ok(in_kind), "nfx_mlp128_bwd: in_kind %d has no backward", in_kind);
+    REQUIRE(n >= 0, "nfx_mlp128_bwd: n < 0");
+    REQUIRE(out_dim >= 1 && out_dim <= 8 && out_act >= 0 && out_act <= 3, "nfx_mlp128_bwd: bad out_dim/act");
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_bwd: only bf16 is built");
+    if (in_kind == NFX_IN_XYZ_LDIR)
+        REQUIRE(n_lights > 0 && lxyz, "nfx_mlp128_bwd: light positions required for NFX_IN_XYZ_LDIR");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && blob && dout && workspace && dkernels && dbiases, "nfx_mlp128_bwd: null pointer");
+    for (int i = 0; i < 5; ++i) REQUIRE(dkernels[i] && dbiases[i], "nfx_mlp128_bwd: gradient buffer %d null", i);
+    REQUIRE(workspace_bytes >= nfx_mlp128_bwd_workspace_bytes(in_kind, n, n_lights),
+            "nfx_mlp128_bwd: workspace too small");
+    if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_mlp128_bwd: blob and workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long long ld = ld_for(in_kind, n, n_lights);
+    const long long rows = in_kind == NFX_IN_XYZ ? n : n * (long long)n_lights;
+    const long long rows16 = (rows + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in dZ
+    int rc = nfx_hip_result(nfx_launch_mlp128_bwd(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights,
+                                                  blob, out_dim, out_act, post_scale, dout, workspace, ld,
+                                                  nfx_env_int("NFX_M128_BLOCKS", 256), st),
+                            "mlp128_bwd");
+    if (rc) return rc;
+    const int ind = in_dims(in_kind), kx = in_kind == NFX_IN_XYZ ? 64 : 96;
+    const char* ws = static_cast<const char*>(workspace);
+    auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
+    const int oH = kx, oDZ = kx + 512, oDZo = kx + 1024;
+    struct Call { const void* xt; const void* zt; int k_in; int n_out; float* dw; float* db; };
+    const Call calls[] = {
+        {feat(0), feat(oDZ + 0), ind, 128, dkernels[0], dbiases[0]},
+        {feat(oH + 0), feat(oDZ + 128), 128, 128, dkernels[1], dbiases[1]},
+        {feat(oH + 128), feat(oDZ + 256), 128, 128, dkernels[2], dbiases[2]},
+        {feat(oH + 256), feat(oDZ + 384), 128, 128, dkernels[3], dbiases[3]},
+        {feat(0), feat(oDZ + 384), ind, 128, dkernels[3] + 128 * 128, nullptr},
+        {feat(oH + 384), feat(oDZo), 128, out_dim, dkernels[4], dbiases[4]},
+    };
+    for (const Call& c : calls) {
+        rc = nfx_hip_result(nfx_launch_wgrad(c.xt, c.zt, ld, c.k_in, c.n_out, rows16, c.dw, c.db, st), "wgrad");
+        if (rc) return rc;
+    }
+    return NFX_OK;
+}
+
+int nfx_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, int64_t n, float lr, float beta1,
+                     float beta2, float eps, int64_t step, void* stream) {
+    REQUIRE(n >= 0 && step >= 1, "nfx_amsgrad_step: bad n/step");
+    if (n == 0) return NFX_OK;
+    REQUIRE(p && g && m && v && vhat, "nfx_amsgrad_step: null pointer");
+    const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);
+    const float lr_t = (float)((double)lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+    return nfx_hip_result(nfx_launch_amsgrad(p, g, m, v, vhat, n, lr_t, beta1, beta2, eps, (hipStream_t)stream),
+                          "amsgrad_step");
+}
+}  // extern "C"

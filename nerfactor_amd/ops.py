@@ -257,3 +257,46 @@ def dir2rusink(a, b):
     out = torch.empty_like(a)
     check(lib.nfx_dir2rusink(_ptr(a), _ptr(b), a.shape[0], _ptr(out), _stream()), 'nfx_dir2rusink')
     return out
+
+
+# ---------------------------------------------------------------------------- training ops
+def pack_mlp128_train_weights(kernels, biases, in_kind, out_dim, prec='bf16'):
+    """Train blob (forward + dgrad fragments) of a width-128 surface MLP, for mlp128_bwd."""
+    if len(kernels) != 5 or len(biases) != 5:
+        raise _capi.NfxError("pack_mlp128_train_weights: need 5 kernels and 5 biases")
+    return _pack(lambda k, o, p: lib.nfx_mlp128_train_packed_bytes(k), lib.nfx_mlp128_pack_train_weights,
+                 kernels, biases, (in_kind, out_dim, _PREC[prec]))
+
+
+def mlp128_bwd(in_kind, xyz, dout, blob, dkernels, dbiases, out_act=None, xyz_scale=1., post_scale=1.,
+               lxyz=None, xyz_dir=None, prec='bf16'):
+    """Accumulate the weight gradients of one width-128 MLP call into `dkernels` / `dbiases`
+    (lists of 5 fp32 CUDA tensors, Keras layout) given dout = dLoss/d(output)."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    nl = 0
+    if in_kind == _capi.IN_XYZ_LDIR:
+        lxyz = _dev(lxyz, 'lxyz', (None, 3))
+        nl = lxyz.shape[0]
+    rows = n if in_kind == _capi.IN_XYZ else n * nl
+    dout = _dev(dout.reshape(rows, -1), 'dout', (rows, None))
+    out_dim = dout.shape[1]
+    xyz_dir = _dev(xyz_dir, 'xyz_dir', (n, 3))
+    for t in list(dkernels) + list(dbiases):
+        _dev(t, 'gradient buffer')
+    ws_bytes = lib.nfx_mlp128_bwd_workspace_bytes(in_kind, n, nl)
+    ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=xyz.device)
+    karr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dkernels])
+    barr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dbiases])
+    check(lib.nfx_mlp128_bwd(in_kind, _ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob),
+                             out_dim, _ACT[out_act], post_scale, _ptr(dout), _ptr(ws), ws.numel() * 2, karr,
+                             barr, _PREC[prec], _stream()), 'nfx_mlp128_bwd')
+    return ws
+
+
+def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
+    """In-place Keras Adam(amsgrad=True) update of the flat fp32 buffer `p` (step is 1-based)."""
+    for t in (p, g, m, v, vhat):
+        _dev(t, 'optimizer buffer')
+    check(lib.nfx_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), lr, beta1, beta2,
+                               eps, step, _stream()), 'nfx_amsgrad_step')
