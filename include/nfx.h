@@ -207,6 +207,19 @@ int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, 
                    void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
                    float *const dev_dbiases[5], int prec, void *stream);
 
+/* Backward of nfx_shade_fwd for ONE light (n_probes = 1, the trained light): given dev_drgb [n,3] =
+ * dLoss/d rgb, writes d_albedo [n,3], d_normal [n,3], d_lvis [n,L] and either d_rough [n]
+ * (microfacet, dev_spec == NULL) or d_spec [n,L] (given specular term); ACCUMULATES d_light [L,3]
+ * (atomics; zero it before the first call of a step).  Gradients flow to the normal both through
+ * cos = l.n and through the BRDF; none to positions, camera or light geometry.  */
+int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                  const float *dev_albedo, const float *dev_rough, const float *dev_spec,
+                  float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
+                  const float *dev_lareas, const float *dev_light, int64_t n, int n_lights,
+                  int linear2srgb, const float *dev_drgb, float *dev_d_albedo, float *dev_d_rough,
+                  float *dev_d_spec, float *dev_d_normal, float *dev_d_lvis, float *dev_d_light,
+                  void *stream);
+
 /* tf.keras.optimizers.Adam(amsgrad=True) dense update on flat fp32 buffers (trainvali.py:116-127):
  * lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step); m, v, vhat updated in place;
  * p -= lr_t * m / (sqrt(vhat) + eps).  `step` is 1-based.                                      */

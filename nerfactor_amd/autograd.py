@@ -1,0 +1,75 @@
+"""torch.autograd glue: every differentiable hot-path op = one libnfx forward kernel + one libnfx
+backward kernel.  Gradients exist for what the reference trains (trainvali.py:278-285): the MLP
+kernels/biases, the light, and — between kernels — normals, albedo, roughness and visibility.
+Points, cameras and light geometry are data (no gradient)."""
+import torch
+
+from . import _capi, ops
+
+
+def _grads_for(params):
+    return [torch.zeros_like(p) for p in params]
+
+
+class Mlp128Xyz(torch.autograd.Function):
+    """out = post_scale * act(out(mlp(posenc10(xyz_scale * xyz)))) + post_bias."""
+
+    @staticmethod
+    def forward(ctx, xyz, fwd_blob, train_blob_fn, out_dim, out_act, xyz_scale, post_scale, post_bias,
+                *params):
+        ctx.save_for_backward(xyz)
+        ctx.cfg = (train_blob_fn, out_dim, out_act, xyz_scale, post_scale, len(params), params)
+        return ops.mlp128_xyz_fwd(xyz, fwd_blob, out_dim, out_act=out_act, xyz_scale=xyz_scale,
+                                  post_scale=post_scale, post_bias=post_bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xyz,) = ctx.saved_tensors
+        train_blob_fn, out_dim, out_act, xyz_scale, post_scale, n_params, params = ctx.cfg
+        ks, bs = list(params[:5]), list(params[5:])
+        dks, dbs = _grads_for(ks), _grads_for(bs)
+        ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
+                       xyz_scale=xyz_scale, post_scale=post_scale)
+        return (None,) * 8 + tuple(dks) + tuple(dbs)
+
+
+class Lvis(torch.autograd.Function):
+    """lvis[n, L] = sigmoid(out(mlp([posenc10(xyz_scale*xyz), posenc4(dir(lxyz - xyz_dir))])))."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_dir, lxyz, fwd_blob, train_blob_fn, xyz_scale, *params):
+        ctx.save_for_backward(xyz, xyz_dir, lxyz)
+        ctx.cfg = (train_blob_fn, xyz_scale, params)
+        return ops.lvis_fwd(xyz, lxyz, fwd_blob, xyz_scale=xyz_scale, xyz_dir=xyz_dir)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, xyz_dir, lxyz = ctx.saved_tensors
+        train_blob_fn, xyz_scale, params = ctx.cfg
+        ks, bs = list(params[:5]), list(params[5:])
+        dks, dbs = _grads_for(ks), _grads_for(bs)
+        ops.mlp128_bwd(_capi.IN_XYZ_LDIR, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act='sigmoid',
+                       xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir)
+        return (None,) * 6 + tuple(dks) + tuple(dbs)
+
+
+class ShadeMicrofacet(torch.autograd.Function):
+    """rgb[n,3] under the trained light with the GGX microfacet BRDF (nerfactor.py:315-342)."""
+
+    @staticmethod
+    def forward(ctx, xyz, cam, lxyz, lareas, f0, to_srgb, normal, albedo, rough, lvis, light):
+        ctx.save_for_backward(xyz, cam, lxyz, lareas, normal, albedo, rough, lvis, light)
+        ctx.cfg = (f0, to_srgb)
+        out = ops.shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(1, -1, 3).contiguous(),
+                            rough=rough, f0=f0, linear2srgb=to_srgb)
+        return out[:, 0]
+
+    @staticmethod
+    def backward(ctx, drgb):
+        xyz, cam, lxyz, lareas, normal, albedo, rough, lvis, light = ctx.saved_tensors
+        f0, to_srgb = ctx.cfg
+        d_light = torch.zeros_like(light.reshape(-1, 3))
+        d_albedo, d_normal, d_lvis, d_rough = ops.shade_bwd(
+            xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(-1, 3).contiguous(), drgb.contiguous(),
+            d_light, rough=rough, f0=f0, linear2srgb=to_srgb)
+        return (None,) * 6 + (d_normal, d_albedo, d_rough.reshape(rough.shape), d_lvis, d_light.reshape(light.shape))

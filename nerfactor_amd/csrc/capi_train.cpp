@@ -143,6 +143,28 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     return NFX_OK;
 }
 
+int nfx_launch_shade_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float,
+                         float, const float*, const float*, const float*, const float*, long long, int, int,
+                         const float*, float*, float*, float*, float*, float*, float*, hipStream_t);
+
+int nfx_shade_bwd(const float* xyz, const float* cam, const float* normal, const float* albedo, const float* rough,
+                  const float* spec, float spec_scale, float f0, const float* lvis, const float* lxyz,
+                  const float* lareas, const float* light, int64_t n, int n_lights, int linear2srgb,
+                  const float* drgb, float* d_albedo, float* d_rough, float* d_spec, float* d_normal, float* d_lvis,
+                  float* d_light, void* stream) {
+    REQUIRE(n >= 0 && n_lights > 0, "nfx_shade_bwd: bad shape");
+    REQUIRE((size_t)7 * n_lights * sizeof(float) <= 160 * 1024, "nfx_shade_bwd: too many lights (%d)", n_lights);
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && albedo && lvis && lxyz && lareas && light && drgb, "nfx_shade_bwd: null input");
+    REQUIRE(rough || spec, "nfx_shade_bwd: need roughness (microfacet) or a specular term");
+    REQUIRE(d_albedo && d_normal, "nfx_shade_bwd: d_albedo and d_normal are required outputs");
+    REQUIRE(spec ? d_spec != nullptr : d_rough != nullptr, "nfx_shade_bwd: missing BRDF-parameter gradient output");
+    return nfx_hip_result(nfx_launch_shade_bwd(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
+                                               lareas, light, n, n_lights, linear2srgb, drgb, d_albedo, d_rough,
+                                               d_spec, d_normal, d_lvis, d_light, (hipStream_t)stream),
+                          "shade_bwd");
+}
+
 int nfx_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, int64_t n, float lr, float beta1,
                      float beta2, float eps, int64_t step, void* stream) {
     REQUIRE(n >= 0 && step >= 1, "nfx_amsgrad_step: bad n/step");

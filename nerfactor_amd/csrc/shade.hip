@@ -222,3 +222,190 @@ int nfx_launch_dir2rusink(const float* a, const float* b, long long n, float* ou
     return (int)hipGetLastError();
 }
 }
+
+// =========================================================================================
+// Backward of the rendering integral for ONE light (the trained one), microfacet or given specular:
+// d(loss)/d(rgb) -> d albedo, d rough | d spec, d normal, d lvis, d light   (tape.gradient through
+// nerfactor.py:315-342 and microfacet.py:30-111).  One wave per point, two passes over the sphere.
+// =========================================================================================
+namespace nfx {
+
+struct ShadeBwdArgs {
+    ShadeArgs f;          // forward inputs; f.lights = the trained light [L,3]; f.out unused
+    const float* drgb;    // [n,3]
+    float *d_albedo, *d_rough, *d_spec, *d_normal, *d_lvis, *d_light;  // d_light [L,3] is ACCUMULATED
+};
+
+__device__ __forceinline__ float tonemap_grad(float s, int to_srgb) {
+    if (s < 0.0f || s > 1.0f) return 0.0f;                 // clip_by_value passes gradient inside [0,1]
+    if (!to_srgb) return 1.0f;
+    return s <= 0.0031308f ? 12.92f : (1.055f / 2.4f) * powf(s, 1.0f / 2.4f - 1.0f);
+}
+
+// spec and its partial derivatives w.r.t. the (re-normalised) normal n^ and a2 = rough^4.
+__device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp, const float (&l_in)[3], float f0,
+                                                      float (&dn)[3], float& da2) {
+    float l[3] = {l_in[0], l_in[1], l_in[2]};
+    normalize3(l, 1e-6f);
+    float hv[3] = {l[0] + mp.v[0], l[1] + mp.v[1], l[2] + mp.v[2]};
+    normalize3(hv, 1e-6f);
+    const float om = 1.0f - dot3(l, hv), om2 = om * om;
+    const float F = f0 + (1.0f - f0) * (om2 * om2 * om);
+    const float a2 = mp.alpha * mp.alpha;
+    const float cm = dot3(hv, mp.n), q = cm * cm;
+    const float chi = cm > 0.0f ? 1.0f : 0.0f;
+    const float tm = div_no_nan(1.0f - q, q), E = a2 + tm;
+    const float pi = 3.14159265358979323846f;
+    const float D = div_no_nan(a2 * chi, pi * (q * q) * (E * E));
+    float dD_dq = 0.f, dD_da2 = 0.f;
+    if (chi > 0.f && q > 0.f && E != 0.f) {
+        dD_dq = a2 / pi * (-2.0f / (q * q * q * E * E) + 2.0f / (q * q * q * q * E * E * E));
+        dD_da2 = (1.0f / (q * q * E * E) - 2.0f * a2 / (q * q * E * E * E)) / pi;
+    }
+    const float cv = mp.cos_v, ct = dot3(hv, mp.v);
+    const float chig = div_no_nan(ct, cv) > 0.0f ? 1.0f : 0.0f;
+    const float cv2 = cv * cv, p = fminf(fmaxf(cv2, 0.0f), 1.0f);
+    const float tv_raw = div_no_nan(1.0f - p, p), tv = fmaxf(tv_raw, 0.0f);
+    const float s = sqrtf(1.0f + a2 * tv);
+    const float G = div_no_nan(chig * 2.0f, 1.0f + s);
+    const float dG_ds = -2.0f * chig / ((1.0f + s) * (1.0f + s));
+    float dG_dcv = 0.f;
+    if (tv_raw > 0.0f && p > 0.0f && cv2 < 1.0f) dG_dcv = dG_ds * (a2 / (2.0f * s)) * (-1.0f / (p * p)) * (2.0f * cv);
+    const float dG_da2 = dG_ds * tv / (2.0f * s);
+    const float cl = dot3(l, mp.n);
+    const float den = 4.0f * fabsf(cl) * fabsf(cv);
+    if (den == 0.0f) {
+        dn[0] = dn[1] = dn[2] = 0.f;
+        da2 = 0.f;
+        return 0.f;
+    }
+    const float spec = F * G * D / den;
+    const float sgl = cl > 0.f ? 1.f : (cl < 0.f ? -1.f : 0.f), sgv = cv > 0.f ? 1.f : (cv < 0.f ? -1.f : 0.f);
+    const float kq = F / den * G * dD_dq * 2.0f * cm;   // along h
+    const float kv = F / den * D * dG_dcv;               // along v
+    const float kd = spec / den * 4.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        dn[k] = kq * hv[k] + kv * mp.v[k] - kd * (sgl * fabsf(cv) * l[k] + fabsf(cl) * sgv * mp.v[k]);
+    da2 = F / den * (G * dD_da2 + D * dG_da2);
+    return spec;
+}
+
+__global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const ShadeArgs& f = a.f;
+    const int L = f.n_lights;
+    float* lxyz_s = sm;
+    float* area_s = lxyz_s + 3 * L;
+    float* light_s = area_s + L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * L; i += blockDim.x) lxyz_s[i] = f.lxyz[i];
+    for (int i = tid; i < L; i += blockDim.x) area_s[i] = f.lareas[i];
+    for (int i = tid; i < 3 * L; i += blockDim.x) light_s[i] = f.lights[i];
+    __syncthreads();
+    const float pi = 3.14159265358979323846f;
+    for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < f.n;
+         pt += (long long)gridDim.x * kShadeWaves) {
+        PointCtx pc;
+        load_point(f, pt, pc);
+        // ---- pass 1: the pre-tonemap sums S[c]
+        float S[3] = {0.f, 0.f, 0.f};
+        for (int l = lane; l < L; l += 64) {
+            float T[3];
+            light_transport(f, pc, pt, l, lxyz_s, area_s, T);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[c] += T[c] * light_s[3 * l + c];
+        }
+        float dS[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            S[c] = wave_sum(S[c]);
+            dS[c] = a.drgb[3 * pt + c] * tonemap_grad(S[c], f.to_srgb);
+        }
+        // ---- pass 2: gradients
+        float d_alb[3] = {0.f, 0.f, 0.f};
+        float d_nhat[3] = {0.f, 0.f, 0.f};  // w.r.t. the normal re-normalised inside the microfacet BRDF
+        float d_dir[3] = {0.f, 0.f, 0.f};   // w.r.t. the normal as used in cos = l . n
+        float d_a2 = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            const float lp[3] = {lxyz_s[3 * l], lxyz_s[3 * l + 1], lxyz_s[3 * l + 2]};
+            float ldir[3];
+            dir_to(lp, pc.x, ldir);
+            const float cosv = dot3(ldir, pc.nrm);
+            const bool front = cosv > 0.0f;
+            const float lvis = f.lvis[pt * L + l];
+            const float area = area_s[l];
+            const float k = front ? lvis * cosv * area : 0.0f;
+            float dsn[3] = {0.f, 0.f, 0.f}, dsa2 = 0.f, s;
+            if (f.spec) s = f.spec[pt * L + l] * f.spec_scale;
+            else s = microfacet_spec_grad(pc.mp, ldir, f.f0, dsn, dsa2);
+            float T = 0.f, U = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float lg = light_s[3 * l + c];
+                const float b = s + pc.alb_pi[c];
+                T += dS[c] * b * lg;
+                U += dS[c] * lg;
+                d_alb[c] += dS[c] * k * lg / pi;
+                if (a.d_light) atomicAdd(a.d_light + 3 * l + c, dS[c] * b * k);
+            }
+            if (a.d_lvis) a.d_lvis[pt * L + l] = front ? cosv * area * T : 0.0f;
+            const float d_cos = front ? lvis * area * T : 0.0f;
+            const float d_s = k * U;
+            if (f.spec) {
+                if (a.d_spec) a.d_spec[pt * L + l] = d_s * f.spec_scale;
+            } else {
+                d_a2 += d_s * dsa2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d_nhat[c] += d_s * dsn[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_dir[c] += d_cos * ldir[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            d_alb[c] = wave_sum(d_alb[c]);
+            d_nhat[c] = wave_sum(d_nhat[c]);
+            d_dir[c] = wave_sum(d_dir[c]);
+        }
+        d_a2 = wave_sum(d_a2);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.d_albedo[3 * pt + c] = d_alb[c];
+            // n^ = n / max(|n|, ..): d n = (d n^ - n^ (n^ . d n^)) / |n|
+            float nn = sqrtf(fmaxf(dot3(pc.nrm, pc.nrm), 1e-6f));
+            float nh[3] = {pc.nrm[0] / nn, pc.nrm[1] / nn, pc.nrm[2] / nn};
+            const float proj = dot3(nh, d_nhat);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.d_normal[3 * pt + c] = d_dir[c] + (d_nhat[c] - nh[c] * proj) / nn;
+            if (a.d_rough && !f.spec) {
+                const float r = f.rough[pt];
+                a.d_rough[pt] = d_a2 * 4.0f * r * r * r;  // a2 = rough^4
+            }
+        }
+    }
+}
+
+}  // namespace nfx
+
+extern "C" int nfx_launch_shade_bwd(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                                    const float* rough, const float* spec, float spec_scale, float f0,
+                                    const float* lvis, const float* lxyz, const float* lareas, const float* light,
+                                    long long n, int n_lights, int to_srgb, const float* drgb, float* d_albedo,
+                                    float* d_rough, float* d_spec, float* d_normal, float* d_lvis, float* d_light,
+                                    hipStream_t st) {
+    if (n <= 0) return 0;
+    nfx::ShadeBwdArgs a;
+    a.f = make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas, light, n, n_lights, 1,
+                    to_srgb, 0.f, 0.f, nullptr);
+    a.drgb = drgb; a.d_albedo = d_albedo; a.d_rough = d_rough; a.d_spec = d_spec; a.d_normal = d_normal;
+    a.d_lvis = d_lvis; a.d_light = d_light;
+    const size_t lds = sizeof(float) * (size_t)7 * n_lights;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (n + nfx::kShadeWaves - 1) / nfx::kShadeWaves;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(nfx::shade_bwd_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st, a);
+    return (int)hipGetLastError();
+}

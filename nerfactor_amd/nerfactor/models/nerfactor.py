@@ -134,7 +134,9 @@ class Model(ShapeModel):
 
     # ------------------------------------------------------------------ forward
     def call(self, batch, mode='train', relight_olat=False, relight_probes=False,
-             albedo_scales=None, albedo_override=None, brdf_z_override=None):
+             albedo_scales=None, albedo_override=None, brdf_z_override=None, xyz_noise=None):
+        """`xyz_noise` (extra to the reference signature): the [n_masked, 3] jitter to use instead of
+        drawing tf.random.normal-style noise internally — lets a test feed an oracle the same noise."""
         xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         self._validate_mode(mode)
         id_, hw, rayo, _, rgb, alpha, xyz, normal, lvis = batch
@@ -144,16 +146,19 @@ class Model(ShapeModel):
         # The reference also evaluates the jittered copies in vali/test mode (nerfactor.py:198-232)
         # although only the training loss reads them; they are skipped here outside training.
         jitter = xyz_jitter_std > 0 and mode == 'train'
-        xyz_j = xyz + torch.randn_like(xyz) * xyz_jitter_std if jitter else None
+        if jitter:
+            xyz_j = xyz + (torch.randn_like(xyz) * xyz_jitter_std if xyz_noise is None else xyz_noise)
+        else:
+            xyz_j = None
         # ------ normals
         if self.shape_mode == 'nerf':
             normal_pred, normal_jitter = normal, None
         else:
             normal_pred = self._pred_normal_at(xyz)
             normal_jitter = self._pred_normal_at(xyz_j) if jitter else None
-        normal_pred = ops.l2_normalize3(normal_pred, 1e-6)
+        normal_pred = self._normalize(normal_pred)
         if normal_jitter is not None:
-            normal_jitter = ops.l2_normalize3(normal_jitter, 1e-6)
+            normal_jitter = self._normalize(normal_jitter)
         # ------ light visibility
         if self.shape_mode == 'nerf':
             lvis_pred, lvis_jitter = torch.clamp(lvis, 1e-8, 1.), None
@@ -210,21 +215,26 @@ class Model(ShapeModel):
             to_vis['gt_' + k] = v
         return pred, gt, loss_kwargs, to_vis
 
+    @staticmethod
+    def _normalize(v):
+        """safe_l2_normalize(v, axis=1): the HIP kernel, or the (differentiable) torch formula while
+        autograd is recording — 3 floats per ray, not a hot spot."""
+        if torch.is_grad_enabled() and v.requires_grad:
+            return mathutil.safe_l2_normalize(v, axis=1)
+        return ops.l2_normalize3(v, 1e-6)
+
     # ------------------------------------------------------------------ heads
     def _pred_albedo_at(self, pts):
         scale = self.config.getfloat('DEFAULT', 'albedo_slope', fallback=0.7)
         bias = self.config.getfloat('DEFAULT', 'albedo_bias', fallback=0.1)
-        blob = self._blob128('albedo_mlp', 'albedo_out', _capi.IN_XYZ, 3)
-        albedo = ops.mlp128_xyz_fwd(pts, blob, 3, out_act='sigmoid', xyz_scale=self.xyz_scale,
-                                    post_scale=scale, post_bias=bias, prec=self.precision)
+        albedo = self._mlp128_xyz(pts, 'albedo_mlp', 'albedo_out', 3, out_act='sigmoid', post_scale=scale,
+                                  post_bias=bias)
         if not torch.isfinite(albedo).all():
             raise FloatingPointError("Albedo")
         return albedo
 
     def _pred_brdf_at(self, pts):
-        blob = self._blob128('brdf_z_mlp', 'brdf_z_out', _capi.IN_XYZ, self.z_dim)
-        return ops.mlp128_xyz_fwd(pts, blob, self.z_dim, out_act=self._brdf_z_act(),
-                                  xyz_scale=self.xyz_scale, prec=self.precision)
+        return self._mlp128_xyz(pts, 'brdf_z_mlp', 'brdf_z_out', self.z_dim, out_act=self._brdf_z_act())
 
     # ------------------------------------------------------------------ BRDF + rendering
     def _brdf_terms(self, xyz, cam, normal, brdf_prop):
@@ -249,6 +259,11 @@ class Model(ShapeModel):
         light = torch.ones_like(self.light) if white_light_override else self.light
         if white_lvis_override:
             light_vis = torch.ones_like(light_vis)
+        if torch.is_grad_enabled() and any(
+                t.requires_grad for t in (normal, albedo, brdf_prop, light_vis, light)):
+            if relight_olat or relight_probes:
+                raise NotImplementedError("relighting is inference-only; run it under torch.no_grad()")
+            return self._render_train(xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb), None, None
         terms = self._brdf_terms(xyz, cam, normal, brdf_prop)
         lights = [light.reshape(-1, 3)]
         if relight_probes:
@@ -269,6 +284,14 @@ class Model(ShapeModel):
                 raise FloatingPointError(name)
         return rgb, rgb_olat, rgb_probes
 
+    def _render_train(self, xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb):
+        """Differentiable render under the trained light.  Only the analytic (microfacet) BRDF has a
+        backward kernel so far; the learned BRDF needs the dgrad of the frozen prior MLP through the
+        Rusinkiewicz geometry (not built)."""
+        raise NotImplementedError(
+            "training the learned-BRDF NeRFactor needs nfx_brdf_spec backward (not built); "
+            "model = nerfactor_microfacet trains")
+
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):
         cfg = self.config
@@ -277,6 +300,7 @@ class Model(ShapeModel):
         smooth = _mae if cfg.getboolean('DEFAULT', 'smooth_use_l1') else _mse
         light_tv_weight = cfg.getfloat('DEFAULT', 'light_tv_weight')
         light_achro_weight = cfg.getfloat('DEFAULT', 'light_achro_weight')
+        kwargs.pop('keep_batch', None)  # the driver always asks for per-ray losses; that is what this returns
         mode = kwargs.pop('mode')
         normal_jitter = kwargs.pop('normal_jitter')
         lvis_jitter = kwargs.pop('lvis_jitter')

@@ -4,6 +4,7 @@ nerfactor/models/nerfactor_microfacet.py:34-132).  The BRDF is evaluated inside 
 kernels (nerfactor_amd/csrc/geom.hpp)."""
 import torch
 
+from nerfactor_amd import autograd as nfx_grad
 from nerfactor_amd.brdf.microfacet.microfacet import Microfacet
 
 from .. import config as default_configs
@@ -37,6 +38,11 @@ class Model(NeRFactorModel):
 
     def _brdf_terms(self, xyz, cam, normal, brdf_prop):
         return {'rough': brdf_prop, 'f0': self.config.getfloat('DEFAULT', 'fresnel_f0')}
+
+    def _render_train(self, xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb):
+        return nfx_grad.ShadeMicrofacet.apply(
+            xyz, cam, self.lxyz.reshape(-1, 3), self.lareas, self.config.getfloat('DEFAULT', 'fresnel_f0'),
+            to_srgb, normal, albedo, brdf_prop, light_vis, light)
 
     def _eval_brdf_at(self, pts2l, pts2c, normal, albedo, brdf_prop, xyz=None, cam=None):
         """Explicit [N, L, 3] tensor via the torch Microfacet (off the hot path)."""

@@ -6,7 +6,7 @@ from os.path import join
 import numpy as np
 import torch
 
-from nerfactor_amd import _capi, ops
+from nerfactor_amd import _capi, autograd as nfx_grad, ops
 from nerfactor_amd.brdf.renderer import gen_light_xyz
 
 from ..networks import mlp
@@ -89,6 +89,37 @@ class Model(BaseModel):
             body_name + self.precision, ks + bs,
             lambda: ops.pack_mlp128_weights(ks, bs, in_kind, out_dim, z_dim=z_dim, prec=self.precision))
 
+    def _train_blob128(self, body_name, head_name, in_kind, out_dim, nets=None):
+        """Forward + dgrad fragments for the fused backward kernel (packed lazily, cached like _blob128)."""
+        nets = self.net if nets is None else nets
+        ks, bs = nets[body_name].kernels_and_biases()
+        ko, bo = nets[head_name].kernels_and_biases()
+        ks, bs = ks + ko, bs + bo
+        return self._packed(
+            body_name + '_train' + self.precision, ks + bs,
+            lambda: ops.pack_mlp128_train_weights(ks, bs, in_kind, out_dim, prec=self.precision))
+
+    def _params128(self, body_name, head_name, nets=None):
+        nets = self.net if nets is None else nets
+        ks, bs = nets[body_name].kernels_and_biases()
+        ko, bo = nets[head_name].kernels_and_biases()
+        return tuple(ks + ko) + tuple(bs + bo)
+
+    @staticmethod
+    def _wants_grad(params):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+    def _mlp128_xyz(self, pts, body, head, out_dim, out_act=None, post_scale=1., post_bias=0.):
+        """One xyz-conditioned head; differentiable w.r.t. its weights when autograd is recording."""
+        blob = self._blob128(body, head, _capi.IN_XYZ, out_dim)
+        params = self._params128(body, head)
+        if self._wants_grad(params):
+            return nfx_grad.Mlp128Xyz.apply(
+                pts, blob, lambda: self._train_blob128(body, head, _capi.IN_XYZ, out_dim), out_dim, out_act,
+                self.xyz_scale, post_scale, post_bias, *params)
+        return ops.mlp128_xyz_fwd(pts, blob, out_dim, out_act=out_act, xyz_scale=self.xyz_scale,
+                                  post_scale=post_scale, post_bias=post_bias, prec=self.precision)
+
     # ------------------------------------------------------------------ geometry helpers
     def _calc_ldir(self, pts):
         """[N,L,3] unit directions surface -> light.  Off-path helper: the kernels recompute these
@@ -133,17 +164,23 @@ class Model(BaseModel):
 
     def _pred_normal_at(self, pts, eps=1e-6):
         """Raw (un-normalised) normals, +eps so an all-zero prediction cannot break the tangents."""
-        blob = self._blob128('normal_mlp', 'normal_out', _capi.IN_XYZ, 3)
-        return ops.mlp128_xyz_fwd(pts, blob, 3, out_act=None, xyz_scale=self.xyz_scale, post_bias=eps,
-                                  prec=self.precision)
+        return self._mlp128_xyz(pts, 'normal_mlp', 'normal_out', 3, out_act=None, post_bias=eps)
 
     def _pred_lvis_at(self, pts, surf2l=None, dir_pts=None):
         """[N,L] visibility of every light from every point.  Directions are recomputed in the
         kernel from `self.lxyz` and `dir_pts` (default `pts`); an explicit `surf2l` tensor is
         accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
         blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
-        lvis = ops.lvis_fwd(pts, self.lxyz.reshape(-1, 3), blob, xyz_scale=self.xyz_scale,
-                            xyz_dir=dir_pts, prec=self.precision)
+        params = self._params128('lvis_mlp', 'lvis_out')
+        lxyz = self.lxyz.reshape(-1, 3)
+        if self._wants_grad(params):
+            lvis = nfx_grad.Lvis.apply(
+                pts, pts if dir_pts is None else dir_pts, lxyz, blob,
+                lambda: self._train_blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1), self.xyz_scale,
+                *params)
+        else:
+            lvis = ops.lvis_fwd(pts, lxyz, blob, xyz_scale=self.xyz_scale, xyz_dir=dir_pts,
+                                prec=self.precision)
         if not torch.isfinite(lvis).all():
             raise FloatingPointError("Light visibility")
         return lvis
@@ -154,6 +191,7 @@ class Model(BaseModel):
         normal_loss_weight = cfg.getfloat('DEFAULT', 'normal_loss_weight')
         lvis_loss_weight = cfg.getfloat('DEFAULT', 'lvis_loss_weight')
         smooth = _mae if cfg.getboolean('DEFAULT', 'smooth_use_l1') else _mse
+        kwargs.pop('keep_batch', None)
         normal_jitter = kwargs.pop('normal_jitter')
         lvis_jitter = kwargs.pop('lvis_jitter')
         alpha = gt['alpha']

@@ -300,3 +300,25 @@ def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
         _dev(t, 'optimizer buffer')
     check(lib.nfx_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), lr, beta1, beta2,
                                eps, step, _stream()), 'nfx_amsgrad_step')
+
+
+def shade_bwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light, drgb, d_light, rough=None, spec=None,
+              spec_scale=1., f0=0.04, linear2srgb=True):
+    """Backward of shade_fwd for one light [L,3].  Returns (d_albedo, d_normal, d_lvis, d_rough|d_spec);
+    accumulates into d_light [L,3]."""
+    xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
+        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
+    light = _dev(light, 'light', (nl, 3))
+    drgb = _dev(drgb, 'drgb', (n, 3))
+    d_light = _dev(d_light, 'd_light', (nl, 3))
+    dev_ = xyz.device
+    d_albedo = torch.empty((n, 3), dtype=torch.float32, device=dev_)
+    d_normal = torch.empty((n, 3), dtype=torch.float32, device=dev_)
+    d_lvis = torch.empty((n, nl), dtype=torch.float32, device=dev_)
+    d_rough = torch.empty((n,), dtype=torch.float32, device=dev_) if spec is None else None
+    d_spec = torch.empty((n, nl), dtype=torch.float32, device=dev_) if spec is not None else None
+    check(lib.nfx_shade_bwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec), spec_scale,
+                            f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), _ptr(light), n, nl, int(linear2srgb),
+                            _ptr(drgb), _ptr(d_albedo), _ptr(d_rough), _ptr(d_spec), _ptr(d_normal), _ptr(d_lvis),
+                            _ptr(d_light), _stream()), 'nfx_shade_bwd')
+    return d_albedo, d_normal, d_lvis, (d_rough if spec is None else d_spec)

@@ -1,0 +1,96 @@
+"""Optimizer and training step (reference: nerfactor/trainvali.py:110-127, 273-295).
+
+  * all trainable parameters live in ONE flat fp32 buffer (the tensors the model sees are views into
+    it), so do their gradients: a step is ONE all-reduce over [gradients | loss] (RCCL over xGMI; one
+    process per GPU) followed by ONE fused AMSGrad kernel (nfx_amsgrad_step);
+  * semantics of tf.keras.optimizers.Adam(amsgrad=True): epsilon = 1e-7 added to sqrt(vhat), bias
+    correction folded into the step size, optional ExponentialDecay schedule
+    lr * decay_rate ** (step / decay_steps).
+"""
+import torch
+
+from . import dist as nfx_dist, ops
+
+
+class AMSGrad:
+    def __init__(self, params, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, lr_decay_steps=-1,
+                 lr_decay_rate=1., clipnorm=-1., clipvalue=-1.):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        if clipnorm > 0 and clipvalue > 0:
+            raise ValueError("Both `clipnorm` and `clipvalue` are active -- turn one off")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.bucket = nfx_dist.FlatBucket(self.params)  # [grads | loss]
+        off = 0
+        for p, gview in zip(self.params, self.bucket.views):
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)   # parameters become views of the flat buffer
+            p.grad = gview                                # and their gradients views of the bucket
+            off += k
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.vhat = torch.zeros_like(self.flat)
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+        self.lr_decay_steps, self.lr_decay_rate = lr_decay_steps, lr_decay_rate
+        self.clipnorm, self.clipvalue = clipnorm, clipvalue
+        self.iterations = 0
+
+    def current_lr(self):
+        if self.lr_decay_steps > 0:
+            return self.lr * self.lr_decay_rate ** (self.iterations / self.lr_decay_steps)
+        return self.lr
+
+    def zero_grad(self):
+        self.bucket.flat.zero_()
+
+    def step(self, loss=0.):
+        """All-reduce [grads | loss] (sum over ranks), apply the update; returns the summed loss."""
+        self.bucket.flat[-1] = loss
+        _, total = self.bucket.all_reduce()
+        g = self.bucket.flat[:-1]
+        if self.clipvalue > 0:
+            g.clamp_(-self.clipvalue, self.clipvalue)
+        if self.clipnorm > 0:  # keras clips per variable
+            for gv in self.bucket.views:
+                nrm = gv.norm()
+                gv.mul_(torch.clamp(self.clipnorm / (nrm + 1e-12), max=1.))
+        lr = self.current_lr()
+        self.iterations += 1
+        ops.amsgrad_step(self.flat, g, self.m, self.v, self.vhat, lr, self.iterations, self.beta_1,
+                         self.beta_2, self.epsilon)
+        return total
+
+    def state_dict(self):
+        return {'m': self.m, 'v': self.v, 'vhat': self.vhat, 'iterations': self.iterations}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.vhat.copy_(sd['vhat'])
+        self.iterations = int(sd['iterations'])
+
+
+def make_optimizer(model, config):
+    """Adam(amsgrad) from the ini keys the reference reads (trainvali.py:110-127)."""
+    get = lambda k, fb: config.getfloat('DEFAULT', k, fallback=fb)
+    return AMSGrad(
+        model.trainable_variables, lr=config.getfloat('DEFAULT', 'lr'),
+        lr_decay_steps=config.getint('DEFAULT', 'lr_decay_steps', fallback=-1),
+        lr_decay_rate=get('lr_decay_rate', 1.), clipnorm=get('clipnorm', -1.), clipvalue=get('clipvalue', -1.))
+
+
+def train_step(model, batch, optimizer, global_bs):
+    """distributed_train_step (trainvali.py:273-295): per-example loss summed / global batch size,
+    backward through the libnfx kernels, one collective, one fused optimizer kernel."""
+    optimizer.zero_grad()
+    pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
+    loss_kwargs['keep_batch'] = True
+    per_example = model.compute_loss(pred, gt, **loss_kwargs)
+    weighted = per_example.sum() / global_bs   # tf.nn.compute_average_loss
+    weighted.backward()
+    total = optimizer.step(loss=weighted.detach())
+    return total, to_vis

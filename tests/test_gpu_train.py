@@ -130,3 +130,170 @@ def test_amsgrad_matches_keras_semantics(nfx_lib, cuda):
         p = p - f(lr_t) * m / (np.sqrt(vh) + f(eps))
     np.testing.assert_allclose(tp.cpu().numpy(), p, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(tvh.cpu().numpy(), vh, rtol=1e-5)
+
+
+def _torch_render(xyz, cam, normal, albedo, rough, lvis, lxyz, lareas, light, to_srgb):
+    """Differentiable float64 restatement of nerfactor.py:315-342 + microfacet.py (torch autograd)."""
+    from nerfactor_amd.brdf.microfacet.microfacet import Microfacet
+    from nerfactor_amd.nerfactor.util import img as imgutil
+
+    def nz(x, dim):
+        return x * torch.rsqrt(torch.clamp((x * x).sum(dim, keepdim=True), min=1e-6))
+    surf2l = nz(lxyz[None] - xyz[:, None], 2)
+    surf2c = nz(cam - xyz, 1)
+    brdf = Microfacet(f0=0.04)(surf2l, surf2c, normal, albedo=albedo, rough=rough)
+    cos = torch.einsum('ijk,ik->ij', surf2l, normal)
+    lv = (cos > 0).double() * lvis
+    rgb = (brdf * (lv[:, :, None] * light[None]) * cos[:, :, None] * lareas[None, :, None]).sum(1)
+    rgb = torch.clamp(rgb, 0., 1.)
+    return imgutil.linear2srgb(rgb) if to_srgb else rgb
+
+
+@pytest.mark.parametrize("to_srgb", [True, False])
+def test_shade_backward_vs_autograd(nfx_lib, cuda, to_srgb):
+    from nerfactor_amd import ops
+    from tests.test_gpu_nerfactor import _shade_inputs
+    n = 64
+    rng, lxyz, lareas, xyz, cam, normal, albedo, rough, lvis, lights = _shade_inputs(n, 95)
+    rough = np.clip(rough, 0.25, 1.)  # keep GGX away from its fp32-ill-conditioned corner
+    light = (lights[0].reshape(512, 3) * 0.5).astype(np.float32)
+    drgb = rng.normal(size=(n, 3)).astype(np.float32)
+    d_light = torch.zeros(512, 3, device=cuda)
+    got = ops.shade_bwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(albedo, cuda), dev(lvis, cuda),
+                        dev(lxyz, cuda), dev(lareas, cuda), dev(light, cuda), dev(drgb, cuda), d_light,
+                        rough=dev(rough, cuda), f0=0.04, linear2srgb=to_srgb)
+    t = lambda a, g=False: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    tn, ta, tr, tv, tl = t(normal, True), t(albedo, True), t(rough, True), t(lvis, True), t(light, True)
+    rgb = _torch_render(t(xyz), t(cam), tn, ta, tr, tv, t(lxyz), t(lareas.reshape(-1)), tl, to_srgb)
+    rgb.backward(t(drgb))
+    inside = ((rgb.detach() > 1e-4) & (rgb.detach() < 1 - 1e-4)).all(1).numpy()  # away from the clip kinks
+    assert inside.mean() > 0.5
+
+    def rel(g, w):
+        g, w = g.double().cpu().numpy()[inside], w.numpy()[inside]
+        return np.linalg.norm(g - w) / (np.linalg.norm(w) + 1e-30)
+    assert rel(got[0], ta.grad) < 1e-3, rel(got[0], ta.grad)             # d albedo
+    assert rel(got[2], tv.grad) < 1e-3, rel(got[2], tv.grad)             # d lvis
+    assert rel(got[3][:, None], tr.grad) < 2e-2, rel(got[3][:, None], tr.grad)   # d rough
+    assert rel(got[1], tn.grad) < 2e-2, rel(got[1], tn.grad)             # d normal
+    # d light: sum over the points that are inside the clip range only -> recompute with those points
+    d_light2 = torch.zeros(512, 3, device=cuda)
+    sel = torch.from_numpy(np.nonzero(inside)[0]).to(cuda)
+    pick = lambda a: dev(a, cuda)[sel].contiguous()
+    ops.shade_bwd(pick(xyz), pick(cam), pick(normal), pick(albedo), pick(lvis), dev(lxyz, cuda), dev(lareas, cuda),
+                  dev(light, cuda), pick(drgb), d_light2, rough=pick(rough), f0=0.04, linear2srgb=to_srgb)
+    tl2 = t(light, True)
+    idx = np.nonzero(inside)[0]
+    rgb2 = _torch_render(t(xyz[idx]), t(cam[idx]), t(normal[idx]), t(albedo[idx]), t(rough[idx]), t(lvis[idx]),
+                         t(lxyz), t(lareas.reshape(-1)), tl2, to_srgb)
+    rgb2.backward(t(drgb[idx]))
+    e = np.linalg.norm(d_light2.double().cpu().numpy() - tl2.grad.numpy()) / np.linalg.norm(tl2.grad.numpy())
+    assert e < 1e-3, e
+
+
+# ------------------------------------------------------------------------ full training step
+def _torch_reference_grads(model, np_batch, xyz_noise, global_bs):
+    """float64 torch autograd of the nerfactor_microfacet training loss with the model's weights:
+    the reference semantics of nerfactor.py:181-541 restated with differentiable torch ops."""
+    cam, rgb, alpha, xyz, normal, lvis = [torch.tensor(a, dtype=torch.float64) for a in np_batch]
+    cfg = model.config
+    mask = alpha[:, 0] > 0
+    P = {n: p.detach().double().cpu().requires_grad_(True) for n, p in model.named_parameters() if p.requires_grad}
+
+    def net(name, x, act):
+        ks = [P['net_%s_mlp_layer%d.kernel' % (name, i)] for i in range(4)] + [P['net_%s_out_layer0.kernel' % name]]
+        bs = [P['net_%s_mlp_layer%d.bias' % (name, i)] for i in range(4)] + [P['net_%s_out_layer0.bias' % name]]
+        return torch_mlp128(x, ks, bs, act)
+
+    lxyz = model.lxyz.double().cpu().reshape(-1, 3)
+    lareas = model.lareas.double().cpu().reshape(-1)
+    xm, cm = xyz[mask], cam[mask]
+    surf2l = R_t_normalize(lxyz[None] - xm[:, None], 2)
+
+    def heads(p):
+        pe = torch_embed(p, 10)
+        nrm = R_t_normalize(net('normal', pe, None) + 1e-6, 1)
+        x = torch.cat((torch_embed(p[:, None, :].expand(-1, 512, -1).reshape(-1, 3), 10),
+                       torch_embed(surf2l.reshape(-1, 3), 4)), -1)
+        lv = net('lvis', x, 'sigmoid').reshape(-1, 512)
+        alb = 0.77 * net('albedo', pe, 'sigmoid') + 0.03
+        z = net('brdf_z', pe, 'sigmoid')
+        return nrm, lv, alb, z
+
+    nrm, lv, alb, z = heads(xm)
+    nrm_j, lv_j, alb_j, z_j = heads(xm + torch.tensor(xyz_noise, dtype=torch.float64))
+    light = torch.clamp(P['_light'], min=0.)
+    rgb_pred = _torch_render(xm, cm, nrm, alb, z, lv, lxyz, lareas, light.reshape(-1, 3), True)
+    n_all = alpha.shape[0]
+
+    def full(v):
+        out = torch.zeros((n_all,) + tuple(v.shape[1:]), dtype=torch.float64)
+        out[mask] = v
+        return out
+
+    def on_bg(x):
+        return x * alpha + 1. * (1. - alpha)
+    mse = lambda a, b: ((a - b) ** 2).mean(-1)
+    mae = lambda a, b: (a - b).abs().mean(-1)
+    rgb_p, rgb_g = on_bg(full(rgb_pred)), on_bg(full(rgb[mask]))
+    n_p, n_g = on_bg(full(nrm)), on_bg(full(normal[mask]))
+    v_p, v_g = on_bg(full(lv)), on_bg(full(lvis[mask]))
+    loss = mse(rgb_g, rgb_p) + 0.1 * mse(n_g, n_p) + 0.1 * mse(v_g, v_p)
+    loss = loss + 0.05 * mae(n_p, full(nrm_j)) + 0.05 * mae(v_p, full(lv_j))
+    loss = loss + 0.05 * mae(full(alb), full(alb_j)) + 0. * mae(full(z), full(z_j))
+    dx = light - torch.roll(light, 1, 1)
+    dy = light - torch.roll(light, 1, 0)
+    loss = loss + 5e-6 * (dx ** 2 + dy ** 2).sum()
+    weighted = loss.sum() / global_bs
+    weighted.backward()
+    return float(weighted), {n: p.grad for n, p in P.items()}
+
+
+def R_t_normalize(x, dim):
+    return x * torch.rsqrt(torch.clamp((x * x).sum(dim, keepdim=True), min=1e-6))
+
+
+def test_nerfactor_microfacet_train_step_vs_autograd(nfx_lib, cuda):
+    """One full training step through the plugin (forward kernels -> loss -> backward kernels -> one
+    bucket -> fused AMSGrad) vs float64 torch autograd of the same loss: gradient direction / norm per
+    parameter tensor, the loss value, and the parameters after the update."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from tests.test_gpu_nerfactor import _nerfactor_batch
+    cfg = make_config('nerfactor_microfacet', shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='')
+    torch.manual_seed(3)
+    model = get_model_class('nerfactor_microfacet')(cfg).to(cuda)
+    with torch.no_grad():  # non-zero biases, moderate roughness
+        for n_, p in model.named_parameters():
+            if n_.endswith('bias'):
+                p.uniform_(-0.2, 0.2)
+    n = 160
+    np_batch, t_batch, lxyz, lareas = _nerfactor_batch(n, 97, cuda)
+    n_fg = int((np_batch[2][:, 0] > 0).sum())
+    noise = np.random.default_rng(98).normal(size=(n_fg, 3)).astype(np.float32) * 0.01
+    global_bs = n
+    want_loss, want = _torch_reference_grads(model, np_batch, noise, global_bs)
+    opt = optim.make_optimizer(model, cfg)
+    before = opt.flat.clone()
+    opt.zero_grad()
+    pred, gt, loss_kwargs, _ = model(t_batch, mode='train', xyz_noise=dev(noise, cuda))
+    loss_kwargs['keep_batch'] = True
+    weighted = model.compute_loss(pred, gt, **loss_kwargs).sum() / global_bs
+    weighted.backward()
+    assert abs(float(weighted) - want_loss) < 2e-2 * abs(want_loss)
+    report = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g, w = p.grad.double().cpu().reshape(-1), want[name].reshape(-1)
+        cos = float((g @ w) / (g.norm() * w.norm() + 1e-30))
+        report[name] = (round(cos, 4), round(float(g.norm() / (w.norm() + 1e-30)), 3))
+    bad = {k: v for k, v in report.items() if v[0] < 0.97 or not 0.85 < v[1] < 1.15}
+    assert not bad, bad
+    total = opt.step(loss=weighted.detach())
+    assert abs(float(total) - float(weighted)) < 1e-6
+    moved = (opt.flat - before).abs()
+    lr_t = 5e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert float(moved.max()) <= lr_t * 1.001 and float(moved.max()) > 0.5 * lr_t  # |m/sqrt(v)| = 1 at step 1
+    assert opt.iterations == 1
