@@ -137,8 +137,12 @@ class Model(ShapeModel):
              albedo_scales=None, albedo_override=None, brdf_z_override=None, xyz_noise=None):
         """`xyz_noise` (extra to the reference signature): the [n_masked, 3] jitter to use instead of
         drawing tf.random.normal-style noise internally — lets a test feed an oracle the same noise."""
-        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         self._validate_mode(mode)
+        if mode != 'train' and torch.is_grad_enabled():
+            with torch.no_grad():  # vali / test never differentiate (trainvali.py:301-308, test.py:189)
+                return self.call(batch, mode, relight_olat, relight_probes, albedo_scales, albedo_override,
+                                 brdf_z_override, xyz_noise)
+        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         id_, hw, rayo, _, rgb, alpha, xyz, normal, lvis = batch
         n_all = alpha.shape[0]
         idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped

@@ -140,8 +140,11 @@ class Model(BaseModel):
 
     # ------------------------------------------------------------------ forward
     def call(self, batch, mode='train'):
-        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         self._validate_mode(mode)
+        if mode != 'train' and torch.is_grad_enabled():
+            with torch.no_grad():
+                return self.call(batch, mode)
+        xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         id_, hw, _, _, _, alpha, xyz, normal, lvis = batch
         xyz_noise = torch.randn_like(xyz) * xyz_jitter_std if xyz_jitter_std > 0 else None
         normal_pred = mathutil.safe_l2_normalize(self._pred_normal_at(xyz), axis=1)

@@ -294,6 +294,6 @@ def test_nerfactor_microfacet_train_step_vs_autograd(nfx_lib, cuda):
     total = opt.step(loss=weighted.detach())
     assert abs(float(total) - float(weighted)) < 1e-6
     moved = (opt.flat - before).abs()
-    lr_t = 5e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
-    assert float(moved.max()) <= lr_t * 1.001 and float(moved.max()) > 0.5 * lr_t  # |m/sqrt(v)| = 1 at step 1
+    # first Adam step: lr_t * m / sqrt(vhat) = lr * sign(g) wherever |g| >> eps
+    assert 0.9 * 5e-3 < float(moved.max()) <= 5e-3 * 1.001
     assert opt.iterations == 1
