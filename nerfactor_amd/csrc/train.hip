@@ -1,7 +1,7 @@
 // train.hip — training-side kernels that are not part of an MLP chain:
 //   amsgrad_step   tf.keras.optimizers.Adam(amsgrad=True) dense update          trainvali.py:110-127
 //   wgrad_bf16     dW[K,N] += X[rows,K]^T dZ[rows,N] from feature-major bf16    (tape.gradient, trainvali.py:284)
-//   rowsum_bf16    db[N]   += sum_rows dZ[rows,N]
+//                  (+ db[N] += sum_rows dZ[rows,N], folded into the same pass)
 // Activations / pre-activation gradients arrive FEATURE-MAJOR ([feature][row], bf16) from the fused
 // backward kernels, so an MFMA operand fragment (one feature x 8 consecutive rows) is one 16-byte
 // global load — no LDS transposition anywhere.
@@ -34,7 +34,8 @@ constexpr int kWgTiles = 4;  // 4 x 4 tiles of 32 x 32
 __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__ xt,
                                                       const __bf16* __restrict__ zt, long long ld,
                                                       int k_in, int n_out, long long rows,
-                                                      long long slab, float* __restrict__ dw) {
+                                                      long long slab, float* __restrict__ dw,
+                                                      float* __restrict__ db) {
     const int lane = threadIdx.x, h = lane >> 5, q = lane & 31;
     const int kb = blockIdx.y * (32 * kWgTiles);  // first input feature of this block
     const long long r0 = (long long)blockIdx.x * slab;
@@ -48,6 +49,8 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool do_bias = db != nullptr && blockIdx.y == 0;  // db[f] += sum_rows dZ[f][row], once per slab
+    float bsum[kWgTiles] = {0.f, 0.f, 0.f, 0.f};
     for (long long k0 = r0; k0 < r1; k0 += 16) {
         bf16x8 a[kWgTiles], b[kWgTiles];
 #pragma unroll
@@ -60,11 +63,25 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
             const int f = 32 * j + q;
             b[j] = f < n_out ? *reinterpret_cast<const bf16x8*>(zt + (long long)f * ld + k0 + 8 * h) : zero;
         }
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < kWgTiles; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[j] += (float)b[j][e];
+        }
 #pragma unroll
         for (int i = 0; i < kWgTiles; ++i)
 #pragma unroll
             for (int j = 0; j < kWgTiles; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < kWgTiles; ++j) {
+            const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);  // the two row halves of a k-step
+            const int col = 32 * j + q;
+            if (h == 0 && col < n_out) atomicAdd(db + col, s);
+        }
     }
 #pragma unroll
     for (int i = 0; i < kWgTiles; ++i)
@@ -76,21 +93,6 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
                 const int col = 32 * j + q;
                 if (row < k_in && col < n_out) atomicAdd(dw + (long long)row * n_out + col, acc[i][j][r]);
             }
-}
-
-// db[f] += sum over rows of zt[f][:]   (one wave per feature)
-__global__ __launch_bounds__(64) void rowsum_kernel(const __bf16* __restrict__ zt, long long ld,
-                                                    long long rows, int n_out, float* __restrict__ db) {
-    const int f = blockIdx.x;
-    if (f >= n_out) return;
-    float s = 0.f;
-    for (long long r = threadIdx.x * 8; r < rows; r += 64 * 8) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(zt + (long long)f * ld + r);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)v[j];
-    }
-    s = wave_sum(s);
-    if (threadIdx.x == 0) atomicAdd(db + f, s);
 }
 
 }  // namespace nfx
@@ -106,14 +108,11 @@ int nfx_launch_amsgrad(float* p, const float* g, float* m, float* v, float* vhat
 int nfx_launch_wgrad(const void* xt, const void* zt, long long ld, int k_in, int n_out, long long rows,
                      float* dw, float* db, hipStream_t st) {
     if (rows <= 0) return 0;
-    long long slab = 2048;
+    long long slab = 1024;
     const unsigned gx = (unsigned)((rows + slab - 1) / slab);
     const unsigned gy = (unsigned)((k_in + 127) / 128);
     hipLaunchKernelGGL(nfx::wgrad_kernel, dim3(gx, gy), dim3(64), 0, st, (const __bf16*)xt, (const __bf16*)zt, ld,
-                       k_in, n_out, rows, slab, dw);
-    if (db)
-        hipLaunchKernelGGL(nfx::rowsum_kernel, dim3(n_out), dim3(64), 0, st, (const __bf16*)zt, ld, rows, n_out,
-                           db);
+                       k_in, n_out, rows, slab, dw, db);
     return (int)hipGetLastError();
 }
 }

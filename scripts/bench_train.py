@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Secondary benchmark (BASELINE.json configs[3], SURVEY.md §8d "C4"): NeRFactor-microfacet training
+steps — 1024 foreground rays per GPU per step (weak scaling; n_rays_per_step of config/nerfactor.ini),
+xyz_jitter_std = 0.01, 512 lights, one flat-bucket all-reduce + one fused AMSGrad kernel per step.
+
+    python scripts/bench_train.py [--steps K]            (torchrun for N > 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rays', type=int, default=1024)
+    args = ap.parse_args()
+    from nerfactor_amd import build
+    build.build()
+    from nerfactor_amd import dist as nfx_dist, optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    rank, world = nfx_dist.init_from_env(backend='nccl', device=dev)
+    torch.manual_seed(5)  # identical initial weights on every rank (MirroredStrategy semantics)
+    cfg = make_config('nerfactor_microfacet', shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='')
+    model = get_model_class('nerfactor_microfacet')(cfg).to(dev)
+    opt = optim.make_optimizer(model, cfg)
+    rng = np.random.default_rng(100 + rank)
+    n = args.rays
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+    nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))), torch.ones(n, 1, device=dev), xyz,
+             nrm, t(rng.uniform(size=(n, 512))))
+    global_bs = n * world
+    for _ in range(args.warmup):
+        optim.train_step(model, batch, opt, global_bs)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = optim.train_step(model, batch, opt, global_bs)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = nfx_dist.max_over_ranks(time.perf_counter() - t0, device=dev) / args.steps
+    if rank == 0:
+        rows = n * 512 * 2  # clean + jittered visibility rows
+        print(json.dumps({
+            "workload": "nerfactor_microfacet train step, %d rays/GPU (weak), 512 lights, jitter on" % n,
+            "n_gpus": world, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
+            "lvis_rows_per_step_per_gpu": rows,
+            "mlp_flops_per_step_per_gpu": 3 * 2 * (rows * 72320 + 2 * 3 * n * 65664),
+            "final_loss": float(loss)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
