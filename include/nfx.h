@@ -207,6 +207,18 @@ int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, 
                    void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
                    float *const dev_dbiases[5], int prec, void *stream);
 
+/* Backward of nfx_brdf_spec_fwd (frozen prior, so no weight gradients): given dev_dspec [n, L] =
+ * dLoss/d spec, ACCUMULATES dLoss/d z into dev_d_z [n, z_dim] and dLoss/d normal into dev_d_normal
+ * [n, 3] (atomics; zero or pre-fill them).  `blob` is the BRDF train blob
+ * (nfx_brdf_train_packed_bytes / nfx_brdf_pack_train_weights).                                  */
+size_t nfx_brdf_train_packed_bytes(void);
+int nfx_brdf_pack_train_weights(const float *const kernels[5], const float *const biases[5],
+                                int z_dim, int prec, void *blob, size_t blob_bytes);
+int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                      const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
+                      const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
+                      float *dev_d_z, float *dev_d_normal, void *stream);
+
 /* Backward of nfx_shade_fwd for ONE light (n_probes = 1, the trained light): given dev_drgb [n,3] =
  * dLoss/d rgb, writes d_albedo [n,3], d_normal [n,3], d_lvis [n,L] and either d_rough [n]
  * (microfacet, dev_spec == NULL) or d_spec [n,L] (given specular term); ACCUMULATES d_light [L,3]

@@ -73,3 +73,41 @@ class ShadeMicrofacet(torch.autograd.Function):
             xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(-1, 3).contiguous(), drgb.contiguous(),
             d_light, rough=rough, f0=f0, linear2srgb=to_srgb)
         return (None,) * 6 + (d_normal, d_albedo, d_rough.reshape(rough.shape), d_lvis, d_light.reshape(light.shape))
+
+
+class BrdfSpec(torch.autograd.Function):
+    """spec[n, L] of the frozen learned BRDF; differentiable w.r.t. the normal and the latent z."""
+
+    @staticmethod
+    def forward(ctx, xyz, cam, lxyz, fwd_blob, train_blob_fn, normal, z):
+        ctx.save_for_backward(xyz, cam, lxyz, normal, z)
+        ctx.train_blob_fn = train_blob_fn
+        return ops.brdf_spec_fwd(xyz, cam, normal, z, lxyz, fwd_blob)
+
+    @staticmethod
+    def backward(ctx, dspec):
+        xyz, cam, lxyz, normal, z = ctx.saved_tensors
+        d_z, d_normal = ops.brdf_spec_bwd(xyz, cam, normal, z, lxyz, ctx.train_blob_fn(), dspec.contiguous())
+        return (None,) * 5 + (d_normal, d_z)
+
+
+class ShadeSpec(torch.autograd.Function):
+    """rgb[n,3] under the trained light with brdf = albedo/pi + spec_scale * spec (nerfactor.py:459-461)."""
+
+    @staticmethod
+    def forward(ctx, xyz, cam, lxyz, lareas, spec_scale, to_srgb, normal, albedo, spec, lvis, light):
+        ctx.save_for_backward(xyz, cam, lxyz, lareas, normal, albedo, spec, lvis, light)
+        ctx.cfg = (spec_scale, to_srgb)
+        out = ops.shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(1, -1, 3).contiguous(),
+                            spec=spec, spec_scale=spec_scale, linear2srgb=to_srgb)
+        return out[:, 0]
+
+    @staticmethod
+    def backward(ctx, drgb):
+        xyz, cam, lxyz, lareas, normal, albedo, spec, lvis, light = ctx.saved_tensors
+        spec_scale, to_srgb = ctx.cfg
+        d_light = torch.zeros_like(light.reshape(-1, 3))
+        d_albedo, d_normal, d_lvis, d_spec = ops.shade_bwd(
+            xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(-1, 3).contiguous(), drgb.contiguous(),
+            d_light, spec=spec, spec_scale=spec_scale, linear2srgb=to_srgb)
+        return (None,) * 6 + (d_normal, d_albedo, d_spec, d_lvis, d_light.reshape(light.shape))

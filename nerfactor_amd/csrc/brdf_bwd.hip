@@ -1,0 +1,215 @@
+// brdf_bwd.hip — backward of the learned-BRDF specular term (tape.gradient through
+// nerfactor.py:413-458 with the FROZEN prior MLP of models/brdf.py:57-66):
+//   d spec[n, l]  ->  d z[n, z_dim]  and  d normal[n, 3]
+// per (point, light) row:  d logit = d spec * softplus'(logit) for front-lit rows;  dgrad chain through
+// the four ReLU layers (weights frozen: no wgrad, nothing stored) INCLUDING the two input-gradient
+// products  dx = W0 dZ0 + W3[128:, :] dZ3  (the input re-enters at layer 3);  dx lands, by construction of
+// the packed fragments, in the same (k-step, half, element) slots the lane filled in the forward, so
+//   d z_i      = dx[z slots]                                                  (summed over the lights)
+//   d rusink_k = dx[r_k] + sum_b 2^b ( cos(2^b r_k) dx[sin] - sin(2^b r_k) dx[cos] )
+//   d normal   = J^T d rusink,  J = d rusink / d normal by forward-mode duals (geom_ad.hpp)
+#include "geom.hpp"
+#include "geom_ad.hpp"
+#include "mlp128_layout.hpp"
+#include "mlp_engine.hpp"
+
+namespace nfx {
+namespace brdfbwd {
+
+constexpr int kNW = 4;
+constexpr int kRows = kNW * 32;
+// chunks: fwd L0 4x4, L1 4x8, L2 4x8, L3 4x12, out 1x8 | bwd dOut 4x4, dL3x 1x8, dL3 4x8, dL2 4x8, dL1 4x8, dL0x 1x8
+constexpr int kFwdFrags = 16 + 32 + 32 + 48 + 8;
+constexpr int kBwdFrags = 16 + 8 + 32 + 32 + 32 + 8;
+constexpr int kWeightBytes = (kFwdFrags + kBwdFrags) * 1024;
+constexpr int kBiasFloats = m128::kMainBiasFloats;
+constexpr int kBlobBytes = kWeightBytes + kBiasFloats * 4;
+
+template <int CT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT]) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+}
+
+template <int KS, int NL_SELF, int NL_NEXT>
+__device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (&dz)[8][1],
+                                            const bf16x8 (&hact)[8][1], bf16x8 (&dout)[8][1]) {
+    static_for<0, 4>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[1];
+        tile_init<KS, 0, (t == 3 ? NL_NEXT : NL_SELF), kNW>(
+            ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dz, dz, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float hv = (float)hact[2 * t + (r >> 3)][0][r & 7];
+            dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
+        }
+    });
+}
+
+__global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ cam, const float* __restrict__ normal,
+    const float* __restrict__ z, int z_dim, const float* __restrict__ lxyz, int n_lights,
+    const char* __restrict__ blob, long long n, const float* __restrict__ dspec, float* __restrict__ d_z,
+    float* __restrict__ d_normal) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace m128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + kWeightBytes);
+        for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
+    }
+    WStream ws;
+    ws.gbase = reinterpret_cast<const u32x4*>(blob);
+    ws.gend = reinterpret_cast<const u32x4*>(blob + kWeightBytes);
+    ws.gnext = ws.gbase;
+    ws.ring = smem;
+    stream_prologue<1, kNW>(ws, tid);
+    const long long n_rows = n * n_lights;
+    const long long n_tiles = (n_rows + kRows - 1) / kRows;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long m0 = tile * kRows + wave * 32;  // wave-uniform: 32 lights of one point
+        const bool valid = m0 < n_rows;
+        const long long mc = valid ? m0 : 0;
+        const long long pt = mc / n_lights;
+        const int l = (int)(mc % n_lights) + p;
+        float x[3], c[3], nr[3], lp[3], ldir[3], vdir[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x[k] = xyz[pt * 3 + k];
+            c[k] = cam[pt * 3 + k];
+            nr[k] = normal[pt * 3 + k];
+            lp[k] = lxyz[l * 3 + k];
+        }
+        dir_to(lp, x, ldir);
+        dir_to(c, x, vdir);
+        Dual3 rus[3];
+        float lz;
+        rusink_dual(nr, ldir, vdir, rus, lz);
+        const bool front = lz > 0.0f;
+        // ---- forward input (same slots as brdf_spec_kernel)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = sin_shifted(rus[q % 3].v * (float)(1 << (q / 3)), h);
+        v[6] = h ? rus[2].v : rus[0].v;
+        v[7] = h ? z[pt * z_dim] : rus[1].v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = 1 + 2 * j + h;
+            v[8 + j] = i < z_dim ? z[pt * z_dim + i] : 0.0f;
+        }
+        bf16x8 bin[2][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bin[s][0][j] = (__bf16)v[8 * s + j];
+        // ---- forward (re-computed)
+        bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
+        layer<2, 0, 4, 1, 2, true, kNW>(ws, tid, bias_lds, bin, bin, h0);
+        layer<8, 0, 4, 2, 2, true, kNW>(ws, tid, bias_lds + 128, h0, bin, h1);
+        layer<8, 0, 4, 2, 3, true, kNW>(ws, tid, bias_lds + 256, h1, bin, h2);
+        layer<8, 2, 4, 3, 2, true, kNW>(ws, tid, bias_lds + 384, h2, bin, h3);
+        f32x16 logit[1];
+        tile_raw<8, 0, 1, kNW>(ws, tid, bias_lds + 512, h3, bin, logit);
+        // ---- d logit (row 0 of the out tile lives in reg 0 of the half-0 lanes)
+        float g = 0.f;
+        if (valid && front && h == 0) g = dspec[m0 + p] * sigmoidf(logit[0][0]);  // softplus' = sigmoid
+        bf16x8 dzo[1][1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dzo[0][0][j] = (__bf16)0.f;
+        dzo[0][0][0] = (__bf16)g;
+        // ---- dgrad chain
+        bf16x8 dz3[8][1], dz2[8][1], dz1[8][1], dz0[8][1];
+        static_for<0, 4>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            f32x16 acc[1];
+            tile_init<1, 0, (t == 3 ? 2 : 1), kNW>(
+                ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dzo, dzo, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float hv = (float)h3[2 * t + (r >> 3)][0][r & 7];
+                dz3[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
+            }
+        });
+        f32x16 dx[1];  // gradient w.r.t. the 32 input slots of this lane's half: reg r <-> (s = r>>3, j = r&7)
+        tile_init<8, 0, 2, kNW>(ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dz3, dz3, dx);   // W3[128:, :] dZ3
+        dgrad_layer<8, 2, 2>(ws, tid, dz3, h2, dz2);
+        dgrad_layer<8, 2, 2>(ws, tid, dz2, h1, dz1);
+        dgrad_layer<8, 2, 2>(ws, tid, dz1, h0, dz0);
+        tile_init<8, 0, 1, kNW>(ws, tid, [&](f32x16(&a)[1]) {}, dz0, dz0, dx);                     // += W0 dZ0
+        // ---- input slots -> d rusink, d z
+        float dr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int k = q % 3;
+            const float f = (float)(1 << (q / 3));
+            const float arg = rus[k].v * f;
+            // half 0 holds sin(f r): d/dr = f cos(f r); half 1 holds cos(f r): d/dr = -f sin(f r)
+            dr[k] += dx[0][q] * f * (h ? -sin_shifted(arg, 0) : sin_shifted(arg, 1));
+        }
+        if (h == 0) {
+            dr[0] += dx[0][6];
+            dr[1] += dx[0][7];
+        } else {
+            dr[2] += dx[0][6];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dr[k] += __shfl_xor(dr[k], 32, 64);  // the two halves of the same row
+        // d normal = J^T d rusink, summed over this wave's 32 lights
+        float dn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dn[a] = rus[0].d[a] * dr[0] + rus[1].d[a] * dr[1] + rus[2].d[a] * dr[2];
+        float dzv[m128::kMaxZDim];
+#pragma unroll
+        for (int i = 0; i < m128::kMaxZDim; ++i) dzv[i] = 0.f;
+        if (h == 1) dzv[0] = dx[0][7];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // k-step 1: element j of half hh holds z_i, i = 1 + 2j + hh  (compile-time split by half)
+            if (1 + 2 * j < m128::kMaxZDim && h == 0) dzv[1 + 2 * j] = dx[0][8 + j];
+            if (2 + 2 * j < m128::kMaxZDim && h == 1) dzv[2 + 2 * j] = dx[0][8 + j];
+        }
+        // reduce over the 32 rows (lanes of one half), halves hold disjoint z indices / identical dn
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dn[a] += __shfl_xor(dn[a], o, 64);
+#pragma unroll
+            for (int i = 0; i < m128::kMaxZDim; ++i) dzv[i] += __shfl_xor(dzv[i], o, 64);
+        }
+        if (valid && p == 0) {
+            if (h == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) atomicAdd(d_normal + pt * 3 + a, dn[a]);
+            }
+#pragma unroll
+            for (int i = 0; i < m128::kMaxZDim; ++i)
+                if (i < z_dim && ((i == 0) ? h == 1 : ((i - 1) & 1) == h)) atomicAdd(d_z + pt * z_dim + i, dzv[i]);
+        }
+    }
+}
+
+}  // namespace brdfbwd
+}  // namespace nfx
+
+extern "C" {
+int nfx_brdf_train_blob_bytes(void) { return nfx::brdfbwd::kBlobBytes; }
+int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
+                             const float* lxyz, int n_lights, const void* blob, long long n, const float* dspec,
+                             float* d_z, float* d_normal, int max_blocks, hipStream_t st) {
+    using namespace nfx;
+    if (n <= 0) return 0;
+    const long long tiles = (n * n_lights + brdfbwd::kRows - 1) / brdfbwd::kRows;
+    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
+    const int lds = 2 * kSlotBytes + m128::kMainBiasFloats * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(brdfbwd::brdf_spec_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
+                       z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, d_z, d_normal);
+    return (int)hipGetLastError();
+}
+}

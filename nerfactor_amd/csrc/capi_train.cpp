@@ -143,6 +143,103 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     return NFX_OK;
 }
 
+int nfx_brdf_train_blob_bytes(void);
+int nfx_launch_brdf_spec_bwd(const float*, const float*, const float*, const float*, int, const float*, int,
+                             const void*, long long, const float*, float*, float*, int, hipStream_t);
+
+size_t nfx_brdf_train_packed_bytes(void) { return (size_t)nfx_brdf_train_blob_bytes(); }
+
+// same slot table as brdf_input_slots() in capi_nerfactor.cpp / brdf_spec_kernel
+static void brdf_slots(int zd, int* slots) {
+    for (int i = 0; i < 32; ++i) slots[i] = -1;
+    for (int h = 0; h < 2; ++h) {
+        int* s0 = slots + h * 8;
+        for (int j = 0; j < 6; ++j) s0[j] = zd + 3 + 6 * (j / 3) + (j % 3) + (h ? 3 : 0);
+        s0[6] = zd + (h ? 2 : 0);
+        s0[7] = h ? 0 : zd + 1;
+        int* s1 = slots + 16 + h * 8;
+        for (int j = 0; j < 8; ++j) {
+            const int i = 1 + 2 * j + h;
+            s1[j] = i < zd ? i : -1;
+        }
+    }
+}
+
+int nfx_brdf_pack_train_weights(const float* const kernels[5], const float* const biases[5], int z_dim, int prec,
+                                void* blob, size_t blob_bytes) {
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_brdf_pack_train_weights: null argument");
+    for (int i = 0; i < 5; ++i) REQUIRE(kernels[i] && biases[i], "nfx_brdf_pack_train_weights: layer %d null", i);
+    REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_pack_train_weights: z_dim %d unsupported", z_dim);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_pack_train_weights: only bf16 is built");
+    const size_t need = nfx_brdf_train_packed_bytes();
+    REQUIRE(blob_bytes >= need, "nfx_brdf_pack_train_weights: blob too small (%zu < %zu)", blob_bytes, need);
+    int slots[32];
+    brdf_slots(z_dim, slots);
+    uint8_t* w = static_cast<uint8_t*>(blob);
+    float* b = reinterpret_cast<float*>(w + need - nfx::m128::kMainBiasFloats * 4);
+    const Seg hid{kHidden, 128, 0, nullptr};
+    const Seg in0{kRaw, 2, 0, slots}, in3{kRaw, 2, 128, slots};
+    w += pack_layer_bf16({in0}, {{kernels[0], biases[0], 128}}, 4, 4, w, b);
+    w += pack_layer_bf16({hid}, {{kernels[1], biases[1], 128}}, 4, 8, w, b + 128);
+    w += pack_layer_bf16({hid}, {{kernels[2], biases[2], 128}}, 4, 8, w, b + 256);
+    w += pack_layer_bf16({hid, in3}, {{kernels[3], biases[3], 128}}, 4, 12, w, b + 384);
+    w += pack_layer_bf16({hid}, {{kernels[4], biases[4], 1}}, 1, 8, w, b + 512);
+    std::vector<float> sink(128 * 4);
+    auto hidden_t = [&](const float* k, int cols, int pad_rows) {  // W[:128, :cols]^T as [pad_rows, 128]
+        std::vector<float> t((size_t)pad_rows * 128, 0.f);
+        for (int r = 0; r < 128; ++r)
+            for (int c = 0; c < cols; ++c) t[(size_t)c * 128 + r] = k[(size_t)r * cols + c];
+        return t;
+    };
+    // input-gradient products: kernel'[k][f'] = W[row0 + input_row(slot f')][k], f' = F(s,h,j) of the slot
+    auto input_t = [&](const float* k, int row0) {
+        std::vector<float> t((size_t)128 * 32, 0.f);
+        for (int s = 0; s < 2; ++s)
+            for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < 8; ++j) {
+                    const int src = slots[(s * 2 + h) * 8 + j];
+                    if (src < 0) continue;
+                    const int fp = 16 * s + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    for (int kk = 0; kk < 128; ++kk) t[(size_t)kk * 32 + fp] = k[(size_t)(row0 + src) * 128 + kk];
+                }
+        return t;
+    };
+    {
+        std::vector<float> t = hidden_t(kernels[4], 1, 16);           // through the out layer
+        w += pack_layer_bf16({Seg{kHidden, 16, 0, nullptr}}, {{t.data(), nullptr, 128}}, 4, 4, w, sink.data());
+    }
+    {
+        std::vector<float> t = input_t(kernels[3], 128);              // W3[128:, :] dZ3 -> input slots
+        w += pack_layer_bf16({hid}, {{t.data(), nullptr, 32}}, 1, 8, w, sink.data());
+    }
+    for (int l = 3; l >= 1; --l) {                                    // hidden-to-hidden dgrads
+        std::vector<float> t = hidden_t(kernels[l], 128, 128);
+        w += pack_layer_bf16({hid}, {{t.data(), nullptr, 128}}, 4, 8, w, sink.data());
+    }
+    {
+        std::vector<float> t = input_t(kernels[0], 0);                // W0 dZ0 -> input slots
+        w += pack_layer_bf16({hid}, {{t.data(), nullptr, 32}}, 1, 8, w, sink.data());
+    }
+    if (w != reinterpret_cast<uint8_t*>(b)) return nfx_fail(NFX_EINVAL, "nfx_brdf_pack_train_weights: layout mismatch");
+    return NFX_OK;
+}
+
+int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
+                      const float* lxyz, int n_lights, const void* blob, int prec, int64_t n, const float* dspec,
+                      float* d_z, float* d_normal, void* stream) {
+    REQUIRE(n >= 0, "nfx_brdf_spec_bwd: n < 0");
+    REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_spec_bwd: z_dim %d unsupported", z_dim);
+    REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_brdf_spec_bwd: n_lights (%d) must be a multiple of 32", n_lights);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_spec_bwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && z && lxyz && blob && dspec && d_z && d_normal, "nfx_brdf_spec_bwd: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_brdf_spec_bwd(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, dspec, d_z,
+                                                   d_normal, nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                          "brdf_spec_bwd");
+}
+
 int nfx_launch_shade_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float,
                          float, const float*, const float*, const float*, const float*, long long, int, int,
                          const float*, float*, float*, float*, float*, float*, float*, hipStream_t);

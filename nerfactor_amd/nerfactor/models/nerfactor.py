@@ -289,12 +289,23 @@ class Model(ShapeModel):
         return rgb, rgb_olat, rgb_probes
 
     def _render_train(self, xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb):
-        """Differentiable render under the trained light.  Only the analytic (microfacet) BRDF has a
-        backward kernel so far; the learned BRDF needs the dgrad of the frozen prior MLP through the
-        Rusinkiewicz geometry (not built)."""
-        raise NotImplementedError(
-            "training the learned-BRDF NeRFactor needs nfx_brdf_spec backward (not built); "
-            "model = nerfactor_microfacet trains")
+        """Differentiable render under the trained light: frozen learned BRDF (gradients reach the
+        latent z and the normal through nfx_brdf_spec_bwd) + the shading integral."""
+        from nerfactor_amd import autograd as nfx_grad
+        nets = self.brdf_model.net
+        fwd_blob = self._blob128('brdf_mlp', 'brdf_out', _capi.IN_Z_RUSINK, 1, z_dim=self.z_dim, nets=nets)
+
+        def train_blob():
+            ks, bs = nets['brdf_mlp'].kernels_and_biases()
+            ko, bo = nets['brdf_out'].kernels_and_biases()
+            ks, bs = ks + ko, bs + bo
+            return self._packed('brdf_mlp_train' + self.precision, ks + bs,
+                                lambda: ops.pack_brdf_train_weights(ks, bs, self.z_dim, prec=self.precision))
+        lxyz = self.lxyz.reshape(-1, 3)
+        spec = nfx_grad.BrdfSpec.apply(xyz, cam, lxyz, fwd_blob, train_blob, normal, brdf_prop)
+        return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,
+                                        self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
+                                        albedo, spec, light_vis, light)
 
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):

@@ -322,3 +322,25 @@ def shade_bwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light, drgb, d_light
                             _ptr(drgb), _ptr(d_albedo), _ptr(d_rough), _ptr(d_spec), _ptr(d_normal), _ptr(d_lvis),
                             _ptr(d_light), _stream()), 'nfx_shade_bwd')
     return d_albedo, d_normal, d_lvis, (d_rough if spec is None else d_spec)
+
+
+def pack_brdf_train_weights(kernels, biases, z_dim, prec='bf16'):
+    """Train blob of the (frozen) learned-BRDF MLP: forward + dgrad + input-gradient fragments."""
+    return _pack(lambda zd, p: lib.nfx_brdf_train_packed_bytes(), lib.nfx_brdf_pack_train_weights, kernels,
+                 biases, (z_dim, _PREC[prec]))
+
+
+def brdf_spec_bwd(xyz, cam, normal, z, lxyz, blob, dspec, prec='bf16'):
+    """(d_z [n, z_dim], d_normal [n, 3]) from dspec [n, L] through the frozen BRDF prior."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    z = _dev(z, 'z', (n, None))
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    nl = lxyz.shape[0]
+    dspec = _dev(dspec, 'dspec', (n, nl))
+    d_z = torch.zeros_like(z)
+    d_normal = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_brdf_spec_bwd(_ptr(xyz), _ptr(_dev(cam, 'cam', (n, 3))), _ptr(_dev(normal, 'normal', (n, 3))),
+                                _ptr(z), z.shape[1], _ptr(lxyz), nl, _ptr(blob), _PREC[prec], n, _ptr(dspec),
+                                _ptr(d_z), _ptr(d_normal), _stream()), 'nfx_brdf_spec_bwd')
+    return d_z, d_normal
