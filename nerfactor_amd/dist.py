@@ -85,3 +85,52 @@ class FlatBucket:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.views, self.flat[-1]
+
+
+def local_device():
+    """cuda:<LOCAL_RANK> (one process per GPU), made current."""
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def sum_over_ranks(tensor):
+    """Sum of a (device) scalar tensor over ranks, returned as a Python float."""
+    t = tensor.detach().clone().reshape(1)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_cat(tensor, dst=0):
+    """Ragged concatenation along dim 0 of every rank's tensor on `dst` (ranks hold contiguous ray
+    shards of sizes differing by at most one: pad to the maximum, all_gather, trim).  Other ranks
+    get their own shard back.  Off the hot path: validation / visualisation only."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return tensor
+    ws = dist.get_world_size()
+    n = torch.tensor([tensor.shape[0]], dtype=torch.int64, device=tensor.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    pad = torch.zeros((max(sizes),) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    pad[:tensor.shape[0]] = tensor
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad)
+    if dist.get_rank() != dst:
+        return tensor
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
+
+
+def gather_objects(obj):
+    """List of every rank's picklable `obj` (ids of the rays of a view)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

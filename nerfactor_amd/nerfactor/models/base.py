@@ -3,6 +3,7 @@ torch.nn.Module: `config` (ConfigParser), `net` dict of networks, `register_trai
 `call(batch, mode)` -> (pred, gt, loss_kwargs, to_vis), `compute_loss`, `vis_batch`,
 `compile_batch_vis`, `trainable_variables`.
 """
+import numpy as np
 import torch
 
 from .. import losses
@@ -95,8 +96,60 @@ class Model(torch.nn.Module):
     def compute_loss(self, pred, gt, **kwargs):
         raise NotImplementedError
 
-    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None):
-        raise NotImplementedError
+    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None, **kwargs):
+        """Writes every per-ray buffer of one full view as <key>.png (linear values clipped to [0,1]; normals
+        mapped from [-1,1]; light visibility averaged over lights) plus metadata.json {"id": view}.  The
+        reference's collages / videos / HTML (nerf.py:343-420, shape.py:279-360, nerfactor.py:460-640) are
+        viewer tooling outside the hot path; `dump_raw_to` gets the raw tensors (np.savez instead of pickle)."""
+        import json
+        import os
+        self._validate_mode(mode)
+        arrays = {}
+        for k, v in data_dict.items():
+            if isinstance(v, torch.Tensor):
+                arrays[k] = v.detach().float().cpu().numpy()
+            elif isinstance(v, (list, tuple)) and v and isinstance(v[0], str):
+                arrays[k] = np.array(v)
+            elif v is not None:
+                arrays[k] = np.asarray(v)
+        if dump_raw_to is not None:
+            os.makedirs(os.path.dirname(dump_raw_to) or '.', exist_ok=True)
+            with open(dump_raw_to, 'wb') as h:
+                np.savez(h, **arrays)
+        if mode == 'train':
+            return  # random rays of one view: nothing to lay out as an image
+        os.makedirs(outdir, exist_ok=True)
+        hw = arrays['hw'][0]
+        h, w = int(hw[0]), int(hw[1])
+        with open(os.path.join(outdir, 'metadata.json'), 'w') as fh:
+            json.dump({'id': str(arrays['id'][0])}, fh)
+        from PIL import Image
+        for k, a in arrays.items():
+            if k in ('id', 'hw') or a.dtype.kind not in 'fiu' or a.ndim < 1 or a.shape[0] != h * w:
+                continue
+            if a.ndim == 3 and a.shape[2] == 3:  # [rays, lights or probes, 3]: one image per light / probe
+                os.makedirs(os.path.join(outdir, k), exist_ok=True)
+                for i in range(a.shape[1]):
+                    img = (np.clip(a[:, i], 0, 1) * 255 + 0.5).astype(np.uint8).reshape(h, w, 3)
+                    Image.fromarray(img).save(os.path.join(outdir, k, '%04d.png' % i))
+                continue
+            a = a.reshape(h * w, -1).astype(np.float32)
+            if a.shape[1] not in (1, 3):
+                a = a.mean(1, keepdims=True)  # e.g. per-light visibility
+            if 'normal' in k:
+                a = a / 2 + 0.5
+            elif 'albedo' in k:
+                a = np.clip(a, 0, 1) ** (1 / 2.2)  # display gamma, undone by test.py's compute_rgb_scales
+            img = (np.clip(a, 0, 1) * 255 + 0.5).astype(np.uint8).reshape(h, w, -1)
+            Image.fromarray(img[:, :, 0] if img.shape[2] == 1 else img).save(os.path.join(outdir, k + '.png'))
 
-    def compile_batch_vis(self, batch_vis_dirs, outpref, mode='train'):
-        raise NotImplementedError
+    def compile_batch_vis(self, batch_vis_dirs, outpref, mode='train', **kwargs):
+        """Index of the per-batch directories (the reference emits HTML / MP4 here)."""
+        import os
+        if not batch_vis_dirs:
+            return None
+        path = outpref + '.txt'
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        with open(path, 'w') as h:
+            h.write('\n'.join(batch_vis_dirs) + '\n')
+        return path

@@ -214,21 +214,6 @@ class Model(BaseModel):
         return loss
 
     # ------------------------------------------------------------------ vis (raw dumps only)
-    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None):
-        """The reference renders PNG/HTML collages here (shape.py:279-360) — out of scope of this
-        hot-path implementation; the tensors are dumped raw so a viewer can be pointed at them."""
-        self._validate_mode(mode)
-        if mode == 'train':
-            return
-        import os
-        os.makedirs(outdir, exist_ok=True)
-        arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-                  for k, v in data_dict.items()}
-        np.savez(join(outdir if dump_raw_to is None else os.path.dirname(dump_raw_to) or outdir,
-                      'batch_raw.npz'), **arrays)
-
-    def compile_batch_vis(self, batch_vis_dirs, outpref, mode='train'):
-        return outpref + '.txt'
 
 
 def _mse(a, b):

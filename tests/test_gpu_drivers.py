@@ -1,0 +1,124 @@
+"""End-to-end driver tests on the GPU: the reference's three-stage NeRFactor workflow on a tiny synthetic scene
+(shape pre-training -> joint optimisation -> test/relight/edit) through trainvali.py / test.py / nerf_test.py,
+checking the output layout of nerfactor/trainvali.py:64-256 and nerfactor/test.py:143-199."""
+import csv
+import glob
+import os
+from os.path import exists, join
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def scene(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp('scene'))
+    data_root, nerf_root = synth_scene.write_scene(root, imh=24, imw=24, n_train=3, n_val=1, n_test=3)
+    return root, data_root, nerf_root
+
+
+def _override(scene, **kw):
+    root, data_root, nerf_root = scene
+    kv = dict(data_root=data_root, data_nerf_root=nerf_root, imh=24, n_rays_per_step=128, vali_batches=1,
+              vis_train_batches=1)
+    kv.update(kw)
+    return ','.join('%s=%s' % item for item in kv.items())
+
+
+def _scalars(path):
+    with open(path) as h:
+        return [(int(r['step']), r['tag'], float(r['value'])) for r in csv.DictReader(h)]
+
+
+@pytest.fixture(scope='module')
+def shape_run(nfx_lib, cuda, scene):
+    from nerfactor_amd.nerfactor import trainvali
+    ov = _override(scene, outroot=join(scene[0], 'out_shape'), epochs=6, ckpt_period=3, vali_period=3,
+                   use_nerf_alpha=False)
+    outdir = trainvali.main(['--config=shape.ini', '--config_override=' + ov])
+    return outdir, ov
+
+
+def test_shape_trainvali_layout_and_descent(shape_run):
+    outdir, _ = shape_run
+    assert outdir.endswith('out_shape/lr1e-2') and exists(outdir + '.ini')
+    assert sorted(os.listdir(join(outdir, 'checkpoints'))) == ['ckpt-1', 'ckpt-2']
+    tr = _scalars(join(outdir, 'summary_train', 'scalars.csv'))
+    assert [s for s, t, _ in tr if t == 'loss_train'] == [3, 6]
+    losses = [v for _, t, v in tr if t == 'loss_train']
+    assert np.isfinite(losses).all() and losses[1] < losses[0]
+    va = _scalars(join(outdir, 'summary_vali', 'scalars.csv'))
+    assert [s for s, t, _ in va] == [3, 6] and all(np.isfinite(v) for _, _, v in va)
+    bdir = join(outdir, 'vis_vali', 'epoch000000006', 'batch000000000')
+    for f in ('pred_normal.png', 'pred_lvis.png', 'gt_normal.png', 'metadata.json'):
+        assert exists(join(bdir, f)), f
+    assert exists(join(outdir, 'vis_train', 'epoch000000003', 'batch000000000_raw.npz'))
+
+
+def test_shape_trainvali_resumes(shape_run, scene):
+    from nerfactor_amd.nerfactor import trainvali
+    outdir, ov = shape_run
+    state = torch.load(join(outdir, 'checkpoints', 'ckpt-2'), map_location='cpu')
+    assert state['step'] == 6 and int(state['optimizer']['iterations']) == 18      # 3 views x 6 epochs
+    trainvali.main(['--config=shape.ini', '--config_override=' + ov.replace('epochs=6', 'epochs=9')])
+    assert sorted(os.listdir(join(outdir, 'checkpoints'))) == ['ckpt-1', 'ckpt-2', 'ckpt-3']
+    state = torch.load(join(outdir, 'checkpoints', 'ckpt-3'), map_location='cpu')
+    assert state['step'] == 9 and int(state['optimizer']['iterations']) == 27
+    steps = [s for s, t, _ in _scalars(join(outdir, 'summary_train', 'scalars.csv')) if t == 'loss_train']
+    assert steps == [3, 6, 9]
+
+
+@pytest.mark.parametrize('model', ['nerfactor_microfacet', 'nerfactor'])
+def test_joint_optimisation_then_test_driver(shape_run, scene, model):
+    from nerfactor_amd.nerfactor import test as test_driver, trainvali
+    shape_ckpt = join(shape_run[0], 'checkpoints', 'ckpt-2')
+    ov = _override(scene, outroot=join(scene[0], 'out_' + model), epochs=4, ckpt_period=2, vali_period=2,
+                   shape_model_ckpt=shape_ckpt, brdf_model_ckpt='none', test_envmap_dir='', shape_mode='finetune')
+    outdir = trainvali.main(['--config=%s.ini' % model, '--config_override=' + ov])
+    ckpt = join(outdir, 'checkpoints', 'ckpt-2')
+    assert exists(ckpt)
+    losses = [v for _, t, v in _scalars(join(outdir, 'summary_train', 'scalars.csv')) if t == 'loss_train']
+    assert len(losses) == 2 and np.isfinite(losses).all()
+    vdir = join(outdir, 'vis_vali', 'epoch000000004', 'batch000000000')
+    for f in ('pred_rgb.png', 'pred_albedo.png', 'pred_normal.png', 'gt_rgb.png'):
+        assert exists(join(vdir, f)), f
+
+    out = test_driver.main(['--ckpt=' + ckpt, '--color_correct_albedo'])
+    assert out == join(outdir, 'vis_test', 'ckpt-2')
+    bdirs = sorted(glob.glob(join(out, 'batch?????????')))
+    assert len(bdirs) == 3
+    assert exists(join(bdirs[0], 'pred_rgb.png')) and not exists(join(bdirs[0], 'pred_rgb_olat'))
+    assert len(os.listdir(join(bdirs[2], 'pred_rgb_olat'))) == 512      # OLAT only for the final view
+    assert exists(out + '.txt')
+    # --debug: only view test_002 (the reference's debug glob), one batch
+    out2 = test_driver.main(['--ckpt=' + ckpt, '--tgt_albedo=rainbow', '--sv_axis_i=2', '--sv_axis_min=-1',
+                             '--sv_axis_max=1', '--debug'])
+    assert out2 == out + '_rainbow' and exists(join(out2, 'batch000000000', 'pred_albedo.png'))
+    from PIL import Image
+    alb = np.asarray(Image.open(join(out2, 'batch000000000', 'pred_albedo.png')))
+    assert len(np.unique(alb.reshape(-1, 3), axis=0)) <= 8 + 1           # 7 bands + background
+
+
+def test_nerf_test_driver(nfx_lib, cuda, scene, tmp_path):
+    """A (random-weight) NeRF checkpoint in the trainvali layout renders through nerf_test.py."""
+    from nerfactor_amd.nerfactor import nerf_test
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    outdir = str(tmp_path / 'out_nerf' / 'lr1e-4')
+    cfg = make_config('nerf', data_root=scene[1], imh=24, outroot=str(tmp_path / 'out_nerf'), n_samples_coarse=16,
+                      n_samples_fine=32)
+    os.makedirs(join(outdir, 'checkpoints'))
+    with open(outdir + '.ini', 'w') as h:
+        cfg.write(h)
+    torch.manual_seed(0)
+    model = get_model_class('nerf')(cfg)
+    model.register_trainable()
+    torch.save({'net': model.state_dict(), 'step': 0}, join(outdir, 'checkpoints', 'ckpt-1'))
+    out = nerf_test.main(['--ckpt=' + join(outdir, 'checkpoints', 'ckpt-1')])
+    bdirs = sorted(glob.glob(join(out, 'batch?????????')))
+    assert len(bdirs) == 3 and exists(join(bdirs[0], 'fine_rgb.png')) and exists(join(bdirs[1], 'coarse_rgb.png'))
