@@ -207,6 +207,28 @@ int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, 
                    void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
                    float *const dev_dbiases[5], int prec, void *stream);
 
+/* Backward of nfx_composite_fwd w.r.t. the raw network outputs (nerf.py:184-254): given dev_d_rgb [n_rays, 3] =
+ * dLoss/d rgb (the composited, background-blended colour), writes dev_d_rgbs [n_rays, S, 4] = dLoss/d rgbs
+ * (sigmoid and relu derivatives applied).  Same rgbs / z / rayd / noise / white_bg as the forward call.  Sample
+ * positions carry no gradient (nerf.py:145).  16-byte aligned rgbs / d_rgbs.                                  */
+int nfx_composite_bwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
+                      const float *dev_noise, int64_t n_rays, int n_samples, int white_bg,
+                      const float *dev_d_rgb, float *dev_d_rgbs, void *stream);
+
+/* Backward of nfx_nerf_mlp_fwd (trainvali.py:284 through nerf.py:256-290): given dev_d_rgbs [n_rays, S, 4],
+ * ACCUMULATES the gradients of the 12 Keras kernels / biases (order of nfx_nerf_pack_weights) into
+ * dev_dkernels[i] ([in, out] fp32) / dev_dbiases[i].  The forward is re-computed inside; `blob` is the TRAIN
+ * blob (forward + dgrad fragments).  Workspace: nfx_nerf_bwd_workspace_bytes() bytes (feature-major bf16
+ * activations and pre-activation gradients, ~10 KB per sample point), 16-byte aligned.  No input gradients. */
+size_t nfx_nerf_train_packed_bytes(int prec);
+int nfx_nerf_pack_train_weights(const float *const kernels[12], const float *const biases[12],
+                                int prec, void *blob, size_t blob_bytes);
+size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples);
+int nfx_nerf_mlp_bwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+                     int n_samples, const void *dev_blob, int prec, const float *dev_d_rgbs,
+                     void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[12],
+                     float *const dev_dbiases[12], void *stream);
+
 /* Backward of nfx_brdf_spec_fwd (frozen prior, so no weight gradients): given dev_dspec [n, L] =
  * dLoss/d spec, ACCUMULATES dLoss/d z into dev_d_z [n, z_dim] and dLoss/d normal into dev_d_normal
  * [n, 3] (atomics; zero or pre-fill them).  `blob` is the BRDF train blob
@@ -231,6 +253,13 @@ int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_n
                   int linear2srgb, const float *dev_drgb, float *dev_d_albedo, float *dev_d_rough,
                   float *dev_d_spec, float *dev_d_normal, float *dev_d_lvis, float *dev_d_light,
                   void *stream);
+
+/* Device-side re-packing of any blob produced by the nfx_*_pack_*weights functions (all of them are pure gathers of
+ * the parameters).  One map entry (two int32) per 32-bit word of the blob: (a, -2) = the fp32 value src[a];
+ * (a, b) = the bf16 pair {src[a], src[b]}, low half first; a negative index gives 0.  `src` is the concatenation
+ * of the network's fp32 parameters on the device, the map a device int32 array built once from the host packer
+ * (nerfactor_amd/ops.py:DevicePacker).  Lets a training step refresh its blobs without a device->host round trip. */
+int nfx_pack_gather(const float *dev_src, const int32_t *dev_map, int64_t n_words, void *dev_blob, void *stream);
 
 /* tf.keras.optimizers.Adam(amsgrad=True) dense update on flat fp32 buffers (trainvali.py:116-127):
  * lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step); m, v, vhat updated in place;

@@ -55,11 +55,17 @@ SIGNATURES = {
     'nfx_mlp128_pack_train_weights': (_i, [_pp, _pp, _i, _i, _i, _p, _sz]),
     'nfx_mlp128_bwd_workspace_bytes': (_sz, [_i, _i64, _i]),
     'nfx_mlp128_bwd': (_i, [_i, _p, _p, _i64, _f, _p, _i, _p, _i, _i, _f, _p, _p, _sz, _pp, _pp, _i, _p]),
+    'nfx_composite_bwd': (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p]),
+    'nfx_nerf_train_packed_bytes': (_sz, [_i]),
+    'nfx_nerf_pack_train_weights': (_i, [_pp, _pp, _i, _p, _sz]),
+    'nfx_nerf_bwd_workspace_bytes': (_sz, [_i64, _i]),
+    'nfx_nerf_mlp_bwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p, _sz, _pp, _pp, _p]),
     'nfx_brdf_train_packed_bytes': (_sz, []),
     'nfx_brdf_pack_train_weights': (_i, [_pp, _pp, _i, _i, _p, _sz]),
     'nfx_brdf_spec_bwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p]),
     'nfx_shade_bwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p,
                            _p, _p]),
+    'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),
     'nfx_amsgrad_step': (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _i64, _p]),
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),

@@ -111,3 +111,45 @@ class ShadeSpec(torch.autograd.Function):
             xyz, cam, normal, albedo, lvis, lxyz, lareas, light.reshape(-1, 3).contiguous(), drgb.contiguous(),
             d_light, spec=spec, spec_scale=spec_scale, linear2srgb=to_srgb)
         return (None,) * 6 + (d_normal, d_albedo, d_spec, d_lvis, d_light.reshape(light.shape))
+
+
+class NerfMlp(torch.autograd.Function):
+    """rgbs[N,S,4] = NeRF MLP at rayo + rayd z (nerf.py:256-290); gradients for the 12 kernels / biases only."""
+
+    @staticmethod
+    def forward(ctx, rayo, rayd, z, fwd_blob, train_blob_fn, prec, *params):
+        ctx.save_for_backward(rayo, rayd, z)
+        ctx.cfg = (train_blob_fn, prec, params)
+        return ops.nerf_mlp_fwd(rayo, rayd, z, fwd_blob, prec)
+
+    @staticmethod
+    def backward(ctx, d_rgbs):
+        rayo, rayd, z = ctx.saved_tensors
+        train_blob_fn, prec, params = ctx.cfg
+        ks, bs = list(params[:12]), list(params[12:])
+        dks, dbs = _grads_for(ks), _grads_for(bs)
+        ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs.contiguous(), train_blob_fn(), dks, dbs, prec)
+        return (None,) * 6 + tuple(dks) + tuple(dbs)
+
+
+class Composite(torch.autograd.Function):
+    """(rgb, occu, depth, disp, weights) of nerf.py:184-254; the loss reaches the networks through rgb only, so
+    that is the one differentiable output (occu / depth / disp / weights are returned detached)."""
+
+    @staticmethod
+    def forward(ctx, rgbs, z, rayd, noise, white_bg, want_weights):
+        ctx.save_for_backward(rgbs, z, rayd, noise)
+        ctx.white_bg = white_bg
+        rgb, occu, depth, disp, w = ops.composite_fwd(rgbs, z, rayd, white_bg=white_bg, noise=noise,
+                                                      want_weights=want_weights)
+        ctx.mark_non_differentiable(occu, depth, disp)
+        if w is None:
+            w = rgb.new_empty(0)
+        ctx.mark_non_differentiable(w)
+        return rgb, occu, depth, disp, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, *unused):
+        rgbs, z, rayd, noise = ctx.saved_tensors
+        d_rgbs = ops.composite_bwd(rgbs, z, rayd, d_rgb.contiguous(), white_bg=ctx.white_bg, noise=noise)
+        return d_rgbs, None, None, None, None, None

@@ -7,6 +7,7 @@
 
 #include "../../include/nfx.h"
 #include "mlp128_layout.hpp"
+#include "nerf_train_layout.hpp"
 #include "pack.hpp"
 
 int nfx_fail(int code, const char* fmt, ...);
@@ -141,6 +142,137 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
         if (rc) return rc;
     }
     return NFX_OK;
+}
+
+// ------------------------------------------------------------------------------------ NeRF MLP backward
+int nfx_launch_nerf_bwd(const float*, const float*, const float*, long long, int, const void*, const float*, void*,
+                        long long, int, hipStream_t);
+int nfx_launch_composite_bwd(const float*, const float*, const float*, const float*, long long, int, int,
+                             const float*, float*, hipStream_t);
+
+size_t nfx_nerf_train_packed_bytes(int prec) { return prec == NFX_PREC_BF16 ? (size_t)nfx::nerf::kTrainBlobBytes : 0; }
+
+int nfx_nerf_pack_train_weights(const float* const kernels[12], const float* const biases[12], int prec, void* blob,
+                                size_t blob_bytes) {
+    using namespace nfx;
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_train_weights: null argument");
+    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_train_weights: layer %d null", i);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_pack_train_weights: only bf16 is built");
+    REQUIRE(blob_bytes >= (size_t)nerf::kTrainBlobBytes, "nfx_nerf_pack_train_weights: blob too small (%zu < %d)",
+            blob_bytes, nerf::kTrainBlobBytes);
+    uint8_t* w0 = static_cast<uint8_t*>(blob);
+    // forward fragments + biases: the inference packer's layout, biases moved behind the dgrad fragments
+    std::vector<uint8_t> fwd(nfx_nerf_packed_bytes(prec));
+    int rc = nfx_nerf_pack_weights(kernels, biases, prec, fwd.data(), fwd.size());
+    if (rc) return rc;
+    memcpy(w0, fwd.data(), nerf::kWeightBytes);
+    memcpy(w0 + nerf::kTrainWeightBytes, fwd.data() + nerf::kWeightBytes, (size_t)nerf::kBiasFloats * 4);
+    uint8_t* w = w0 + nerf::kWeightBytes;
+    std::vector<float> sink(256);
+    // W[r0 : r0 + n_in_used, :cols]^T as a Keras kernel [pad_in' = cols padded, out' = n_rows]
+    auto transposed = [](const float* k, int row0, int n_rows, int cols, int pad_cols) {
+        std::vector<float> t((size_t)pad_cols * n_rows, 0.f);
+        for (int r = 0; r < n_rows; ++r)
+            for (int c = 0; c < cols; ++c) t[(size_t)c * n_rows + r] = k[(size_t)(row0 + r) * cols + c];
+        return t;
+    };
+    const Seg hid256{kHidden, 256, 0, nullptr}, hid128{kHidden, 128, 0, nullptr}, hid16{kHidden, 16, 0, nullptr};
+    {   // D1: dR0[128] = Wrgb1[128, 3] dZrgb[3]
+        std::vector<float> t = transposed(kernels[11], 0, 128, 3, 16);
+        w += pack_layer_bf16({hid16}, {{t.data(), nullptr, 128}}, 4, 4, w, sink.data());
+    }
+    {   // D2: dBott[256] = Wrgb0[:256, 128] dZr0[128]
+        std::vector<float> t = transposed(kernels[10], 0, 256, 128, 128);
+        w += pack_layer_bf16({hid128}, {{t.data(), nullptr, 256}}, 8, 8, w, sink.data());
+    }
+    {   // D3: dA7[256] = Wbott[256, 256] dZbott[256] + Wsigma[256, 1] dZsigma  (input rows: 256 + 16 slots)
+        std::vector<float> t((size_t)(256 + 16) * 256, 0.f);
+        for (int r = 0; r < 256; ++r) {
+            for (int c = 0; c < 256; ++c) t[(size_t)c * 256 + r] = kernels[9][(size_t)r * 256 + c];
+            t[(size_t)256 * 256 + r] = kernels[8][r];
+        }
+        const Seg sig{kHidden, 16, 256, nullptr};
+        w += pack_layer_bf16({hid256, sig}, {{t.data(), nullptr, 256}}, 8, 20, w, sink.data());
+    }
+    for (int l = 7; l >= 1; --l) {  // dA_{l-1}[256] = W_l[:256, 256] dZ_l[256]   (enc[5]: the y rows of [y, posenc])
+        std::vector<float> t = transposed(kernels[l], 0, 256, 256, 256);
+        w += pack_layer_bf16({hid256}, {{t.data(), nullptr, 256}}, 8, 16, w, sink.data());
+    }
+    if (w != w0 + nerf::kTrainWeightBytes) return nfx_fail(NFX_EINVAL, "nfx_nerf_pack_train_weights: layout mismatch");
+    return NFX_OK;
+}
+
+static long long nerf_ld(long long n_pts) { return (n_pts + 127) / 128 * 128; }
+
+size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return (size_t)nfx::nerf::kTrainFeats * nerf_ld((long long)n_rays * n_samples) * 2;
+}
+
+int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                     const void* blob, int prec, const float* d_rgbs, void* workspace, size_t workspace_bytes,
+                     float* const dkernels[12], float* const dbiases[12], void* stream) {
+    using namespace nfx::nerf;
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_mlp_bwd: bad shape");
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_mlp_bwd: only bf16 is built");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && blob && d_rgbs && workspace && dkernels && dbiases, "nfx_nerf_mlp_bwd: null pointer");
+    for (int i = 0; i < 12; ++i) REQUIRE(dkernels[i] && dbiases[i], "nfx_nerf_mlp_bwd: gradient buffer %d null", i);
+    REQUIRE(workspace_bytes >= nfx_nerf_bwd_workspace_bytes(n_rays, n_samples), "nfx_nerf_mlp_bwd: workspace too small");
+    if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16) || !ALIGNED(d_rgbs, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_nerf_mlp_bwd: blob, workspace and d_rgbs must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_pts = (long long)n_rays * n_samples, ld = nerf_ld(n_pts);
+    REQUIRE(ld * 2 * 4 < (1ll << 32), "nfx_nerf_mlp_bwd: at most 2^28 points per call (got %lld)", n_pts);
+    int rc = nfx_hip_result(nfx_launch_nerf_bwd(rayo, rayd, z, n_pts, n_samples, blob, d_rgbs, workspace, ld,
+                                                nfx_env_int("NFX_NERF_BLOCKS", 256), st),
+                            "nerf_bwd");
+    if (rc) return rc;
+    const long long rows16 = (n_pts + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in every dZ
+    const char* ws = static_cast<const char*>(workspace);
+    auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
+    struct Call { const void* xt; const void* zt; int k_in; int n_out; float* dw; float* db; };
+    std::vector<Call> calls;
+    calls.push_back({feat(kOffPe), feat(kOffDZ), 63, 256, dkernels[0], dbiases[0]});
+    for (int l = 1; l <= 7; ++l)
+        calls.push_back({feat(kOffA + 256 * (l - 1)), feat(kOffDZ + 256 * l), 256, 256, dkernels[l], dbiases[l]});
+    calls.push_back({feat(kOffPe), feat(kOffDZ + 256 * 5), 63, 256, dkernels[5] + 256 * 256, nullptr});  // skip rows
+    calls.push_back({feat(kOffA + 256 * 7), feat(kOffDSig), 256, 1, dkernels[8], dbiases[8]});            // sigma_out
+    calls.push_back({feat(kOffA + 256 * 7), feat(kOffDBott), 256, 256, dkernels[9], dbiases[9]});         // bottleneck
+    calls.push_back({feat(kOffBott), feat(kOffDR0), 256, 128, dkernels[10], dbiases[10]});                // rgb_out[0]
+    calls.push_back({feat(kOffPv), feat(kOffDR0), 27, 128, dkernels[10] + 256 * 128, nullptr});
+    calls.push_back({feat(kOffR0), feat(kOffDRgb), 128, 3, dkernels[11], dbiases[11]});                   // rgb_out[1]
+    for (const Call& c : calls) {
+        rc = nfx_hip_result(nfx_launch_wgrad(c.xt, c.zt, ld, c.k_in, c.n_out, rows16, c.dw, c.db, st), "wgrad");
+        if (rc) return rc;
+    }
+    return NFX_OK;
+}
+
+int nfx_composite_bwd(const float* rgbs, const float* z, const float* rayd, const float* noise, int64_t n_rays,
+                      int n_samples, int white_bg, const float* d_rgb, float* d_rgbs, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_composite_bwd: bad shape");
+    REQUIRE(n_samples <= 4096, "nfx_composite_bwd: at most 4096 samples per ray (got %d)", n_samples);
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rgbs && z && rayd && d_rgb && d_rgbs, "nfx_composite_bwd: null pointer");
+    if (!ALIGNED(rgbs, 16) || !ALIGNED(d_rgbs, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_composite_bwd: rgbs and d_rgbs must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_composite_bwd(rgbs, z, rayd, noise, n_rays, n_samples, white_bg, d_rgb, d_rgbs,
+                                                   (hipStream_t)stream),
+                          "composite_bwd");
+}
+
+// ------------------------------------------------------------------------------------ device-side re-packing
+int nfx_launch_pack_gather(const float*, const int*, long long, void*, hipStream_t);
+
+int nfx_pack_gather(const float* src, const int32_t* map, int64_t n_words, void* blob, void* stream) {
+    REQUIRE(n_words >= 0, "nfx_pack_gather: negative size");
+    if (n_words == 0) return NFX_OK;
+    REQUIRE(src && map && blob, "nfx_pack_gather: null pointer");
+    if (!ALIGNED(blob, 16) || !ALIGNED(map, 8))
+        return nfx_fail(NFX_EALIGN, "nfx_pack_gather: blob must be 16-byte and map 8-byte aligned");
+    return nfx_hip_result(nfx_launch_pack_gather(src, map, n_words, blob, (hipStream_t)stream), "pack_gather");
 }
 
 int nfx_brdf_train_blob_bytes(void);

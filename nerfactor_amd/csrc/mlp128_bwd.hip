@@ -12,6 +12,7 @@
 #include "geom.hpp"
 #include "mlp128_layout.hpp"
 #include "mlp_engine.hpp"
+#include "feat_store.hpp"
 
 namespace nfx {
 namespace bwd {
@@ -38,43 +39,6 @@ struct Geo {
     static constexpr int kFeats = kXFeats + 1032;
 };
 
-// Feature-major store: wave-uniform base (SGPR pair, global_store saddr form) + 32-bit lane offset.
-// `ld2` = bytes per feature row; it is laundered through an empty asm once per tile so the ~1100
-// per-feature bases are computed next to their stores instead of being hoisted and spilled.
-struct FeatStore {
-    char* base;
-    unsigned long long ld2;
-    unsigned roff;  // row * 2
-};
-__device__ __forceinline__ void st16(const FeatStore& fs, int feat, __bf16 v) {
-    *reinterpret_cast<__bf16*>(fs.base + (unsigned long long)feat * fs.ld2 + fs.roff) = v;
-}
-// B-operand registers of a hidden activation (k-step s, element j <-> feature F(s,h,j)) -> feature-major
-template <int KS>
-__device__ __forceinline__ void store_hidden(const FeatStore& fs, int feat0, int h, const bf16x8 (&b)[KS][1]) {
-    // the lane half selects between two uniform bases instead of entering the per-store address
-    FeatStore f2 = fs;
-    f2.roff = fs.roff + (h ? (unsigned)(4 * fs.ld2) : 0u);  // + 4 features for half 1 (needs 4*ld2 < 4 GiB)
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            st16(f2, feat0 + 32 * (s >> 1) + 16 * (s & 1) + (j & 3) + 8 * (j >> 2), b[s][0][j]);
-}
-// posenc slots (mlp_engine.hpp:posenc) -> logical Embedder order [x, sin f0, cos f0, ...] starting at e0
-template <int L, int KS>
-__device__ __forceinline__ void store_posenc(const FeatStore& fs, int e0, int h, const bf16x8 (&b)[KS][1]) {
-    FeatStore f3 = fs, f2 = fs;
-    f3.roff = fs.roff + (h ? (unsigned)(3 * fs.ld2) : 0u);  // cosines sit 3 features after the sines
-    f2.roff = fs.roff + (h ? (unsigned)(2 * fs.ld2) : 0u);  // x[2] sits 2 features after x[0]
-#pragma unroll
-    for (int q = 0; q < KS * 8; ++q) {
-        if (q < 3 * L) st16(f3, e0 + 3 + 6 * (q / 3) + (q % 3), b[q >> 3][0][q & 7]);
-        else if (q == 3 * L) st16(f2, e0, b[q >> 3][0][q & 7]);
-        else if (q == 3 * L + 1) { if (h == 0) st16(fs, e0 + 1, b[q >> 3][0][q & 7]); }
-    }
-}
-
 __device__ __forceinline__ float act_grad(float logit, int act) {
     switch (act) {
         case 1: return logit > 0.f ? 1.f : 0.f;
@@ -82,14 +46,6 @@ __device__ __forceinline__ float act_grad(float logit, int act) {
         case 3: return sigmoidf(logit);  // d softplus
         default: return 1.f;
     }
-}
-
-template <int CT>
-__device__ __forceinline__ void zero_init(f32x16 (&acc)[CT]) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 }
 
 // dgrad layer: dH^T = W dZ^T (NT tiles of 32 input features), ReLU-masked by the activation `hact`

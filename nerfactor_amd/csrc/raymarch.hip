@@ -114,6 +114,102 @@ __global__ __launch_bounds__(256) void composite_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// composite_bwd: gradient of the composited colour (nerf.py:184-254) w.r.t. the raw network outputs.
+// One wave per ray.  Pass 1 re-runs the forward scan (weights w_i and transmittances T_i parked in LDS, sums R_c, O);
+// pass 2 walks the samples backwards with a suffix sum:
+//   out_c = R_c O + bg (1 - O);  dR_c = g_c O;  dO = sum_c g_c (R_c - bg);  G_i = sum_c dR_c c_ic + dO
+//   d raw_ic = dR_c w_i c_ic (1 - c_ic);  d alpha_i = G_i T_i - (sum_{k>i} G_k w_k) / t_i
+//   d sigma_i = [sigma_i + noise_i > 0] dist_i exp(-relu(.) dist_i) d alpha_i
+// z carries no gradient (nerf.py:145 stop_gradient; coarse z are constants).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rayd,
+    const float* __restrict__ noise, long long n_rays, int S, float bg, const float* __restrict__ d_rgb,
+    float4* __restrict__ d_rgbs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;  // wave-uniform
+    float* w_s = reinterpret_cast<float*>(smem_raw) + (size_t)wv * 2 * S;
+    float* T_s = w_s + S;
+    const float dx = rayd[3 * ray], dy = rayd[3 * ray + 1], dz = rayd[3 * ray + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const long long base = ray * S;
+    float carry = 1.0f, s_w = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const float4 raw = rgbs[base + sc];
+        const float zc = z[base + sc];
+        const float zn = (sc < S - 1) ? z[base + sc + 1] : 0.f;
+        const float dist = ((sc < S - 1) ? (zn - zc) : 1e10f) * dnorm;
+        float sg = raw.w;
+        if (noise) sg = sg + noise[base + sc];
+        const float alpha = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);
+        const float t = valid ? (1.0f - alpha + 1e-6f) : 1.0f;
+        float incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = carry * excl;
+        const float w = valid ? alpha * T : 0.0f;
+        carry = carry * __shfl(incl, 63, 64);
+        if (valid) {
+            w_s[s] = w;
+            T_s[s] = T;
+        }
+        s_w += w;
+        s_r += w * sigmoidf(raw.x);
+        s_g += w * sigmoidf(raw.y);
+        s_b += w * sigmoidf(raw.z);
+    }
+    s_w = wave_sum(s_w);
+    s_r = wave_sum(s_r);
+    s_g = wave_sum(s_g);
+    s_b = wave_sum(s_b);
+    const float g0 = d_rgb[3 * ray], g1 = d_rgb[3 * ray + 1], g2 = d_rgb[3 * ray + 2];
+    const float dR0 = g0 * s_w, dR1 = g1 * s_w, dR2 = g2 * s_w;
+    const float dO = g0 * (s_r - bg) + g1 * (s_g - bg) + g2 * (s_b - bg);
+    float tail = 0.f;  // sum of G_k w_k over the chunks behind the current one
+    const int n_chunks = (S + 63) / 64;
+    for (int c = n_chunks - 1; c >= 0; --c) {
+        const int s = c * 64 + lane;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const float4 raw = rgbs[base + sc];
+        const float zc = z[base + sc];
+        const float zn = (sc < S - 1) ? z[base + sc + 1] : 0.f;
+        const float dist = ((sc < S - 1) ? (zn - zc) : 1e10f) * dnorm;
+        float sg = raw.w;
+        if (noise) sg = sg + noise[base + sc];
+        const float e = expf(-fmaxf(sg, 0.0f) * dist);
+        const float t = 1.0f - (1.0f - e) + 1e-6f;
+        const float w = valid ? w_s[sc] : 0.f, T = valid ? T_s[sc] : 0.f;
+        const float c0 = sigmoidf(raw.x), c1 = sigmoidf(raw.y), c2 = sigmoidf(raw.z);
+        const float G = dR0 * c0 + dR1 * c1 + dR2 * c2 + dO;
+        const float v = valid ? G * w : 0.f;
+        float incl = v;  // inclusive suffix sum inside the chunk
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float dn = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += dn;
+        }
+        const float suffix = incl - v + tail;  // strictly behind this sample
+        tail += __shfl(incl, 0, 64);
+        const float d_alpha = G * T - suffix / t;
+        const float d_sg = sg > 0.f ? dist * e * d_alpha : 0.f;
+        if (valid)
+            d_rgbs[base + s] = make_float4(dR0 * w * c0 * (1.f - c0), dR1 * w * c1 * (1.f - c1),
+                                           dR2 * w * c2 * (1.f - c2), d_sg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // sample_fine: block = 256 threads = 4 rays.  Dynamic LDS per wave:
 //   cdf[nc-1], mid[nc-1], zall[nc+nf]   (floats)
 // ---------------------------------------------------------------------------------------
@@ -214,6 +310,21 @@ int nfx_launch_sample_fine(const float* z, const float* w, long long n_rays, int
     const size_t lds = (size_t)4 * (2 * (nc - 1) + nc + nf) * sizeof(float);
     hipLaunchKernelGGL(nfx::sample_fine_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, st,
                        z, w, n_rays, nc, nf, u, z_all);
+    return (int)hipGetLastError();
+}
+int nfx_launch_composite_bwd(const float* rgbs, const float* z, const float* rayd, const float* noise,
+                             long long n_rays, int n_samples, int white_bg, const float* d_rgb, float* d_rgbs,
+                             hipStream_t st) {
+    if (n_rays <= 0) return 0;
+    const size_t lds = (size_t)4 * 2 * n_samples * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::composite_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(nfx::composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds, st,
+                       (const float4*)rgbs, z, rayd, noise, n_rays, n_samples, white_bg ? 1.0f : 0.0f, d_rgb,
+                       (float4*)d_rgbs);
     return (int)hipGetLastError();
 }
 }

@@ -27,7 +27,7 @@ __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ 
     p[i] = p[i] - lr_t * mi / (sqrtf(vh) + eps);
 }
 
-// One wave owns a [<=128 x <=128] block of dW and a slab of rows.
+// One wave owns a [<=128 x <=128] block of dW (grid y, z) and a slab of rows (grid x).
 //   xt: [k_in][ld] bf16 (feature-major), zt: [n_out][ld] bf16; rows in [row0, row1), multiple of 16.
 //   dW: [k_in][n_out] fp32 (Keras layout), accumulated with atomics.
 constexpr int kWgTiles = 4;  // 4 x 4 tiles of 32 x 32
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
                                                       float* __restrict__ db) {
     const int lane = threadIdx.x, h = lane >> 5, q = lane & 31;
     const int kb = blockIdx.y * (32 * kWgTiles);  // first input feature of this block
+    const int nb = blockIdx.z * (32 * kWgTiles);  // first output feature of this block
     const long long r0 = (long long)blockIdx.x * slab;
     long long r1 = r0 + slab;
     if (r1 > rows) r1 = rows;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
         }
 #pragma unroll
         for (int j = 0; j < kWgTiles; ++j) {
-            const int f = 32 * j + q;
+            const int f = nb + 32 * j + q;
             b[j] = f < n_out ? *reinterpret_cast<const bf16x8*>(zt + (long long)f * ld + k0 + 8 * h) : zero;
         }
         if (do_bias) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < kWgTiles; ++j) {
             const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);  // the two row halves of a k-step
-            const int col = 32 * j + q;
+            const int col = nb + 32 * j + q;
             if (h == 0 && col < n_out) atomicAdd(db + col, s);
         }
     }
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = kb + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = 32 * j + q;
+                const int col = nb + 32 * j + q;
                 if (row < k_in && col < n_out) atomicAdd(dw + (long long)row * n_out + col, acc[i][j][r]);
             }
 }
@@ -111,7 +112,8 @@ int nfx_launch_wgrad(const void* xt, const void* zt, long long ld, int k_in, int
     long long slab = 1024;
     const unsigned gx = (unsigned)((rows + slab - 1) / slab);
     const unsigned gy = (unsigned)((k_in + 127) / 128);
-    hipLaunchKernelGGL(nfx::wgrad_kernel, dim3(gx, gy), dim3(64), 0, st, (const __bf16*)xt, (const __bf16*)zt, ld,
+    const unsigned gz = (unsigned)((n_out + 127) / 128);
+    hipLaunchKernelGGL(nfx::wgrad_kernel, dim3(gx, gy, gz), dim3(64), 0, st, (const __bf16*)xt, (const __bf16*)zt, ld,
                        k_in, n_out, rows, slab, dw, db);
     return (int)hipGetLastError();
 }

@@ -6,6 +6,8 @@ torch.nn.Module: `config` (ConfigParser), `net` dict of networks, `register_trai
 import numpy as np
 import torch
 
+from nerfactor_amd import ops
+
 from .. import losses
 from ..networks import base as basenet
 
@@ -20,6 +22,7 @@ class Model(torch.nn.Module):
         self.wloss = self._init_loss()
         self.precision = config.get('DEFAULT', 'precision', fallback='bf16')  # MFMA operand type
         self._blobs = {}  # packed-weight cache: key -> (versions, device blob)
+        self._packers = {}  # key -> ops.DevicePacker
 
     # ------------------------------------------------------------------ loss string parsing
     def _init_loss(self):
@@ -75,16 +78,25 @@ class Model(torch.nn.Module):
 
     # ------------------------------------------------------------------ packed-weight cache
     def _packed(self, key, tensors, pack_fn):
-        """Device blob for `tensors` (Keras-layout parameters), re-packed only when one of them
-        was modified in place (optimizer step, checkpoint restore)."""
+        """Device blob for `tensors` (Keras-layout parameters: kernels then biases, as many of each), re-packed only
+        when one of them changed (in-place edit, checkpoint restore, optimizer step — optim.AMSGrad bumps the version
+        counters, its kernel writes through raw pointers).  `pack_fn(kernels, biases)` is the host packer; after the
+        first call the re-pack runs on the device (ops.DevicePacker), so a training step never leaves the GPU."""
         versions = tuple((t.data_ptr(), t._version) for t in tensors)
         hit = self._blobs.get(key)
         dev = tensors[0].device
-        if hit is None or hit[0] != versions or hit[1].device != dev:
-            blob = pack_fn().to(dev)
-            self._blobs[key] = (versions, blob)
-            return blob
-        return hit[1]
+        if hit is not None and hit[0] == versions and hit[1].device == dev:
+            return hit[1]
+        if dev.type != 'cuda':
+            raise RuntimeError("libnfx blobs live on the GPU: move the model with .to('cuda') first")
+        packer = self._packers.get(key)
+        if packer is None:
+            nk = len(tensors) // 2
+            packer = ops.DevicePacker(pack_fn, [t.shape for t in tensors[:nk]], [t.shape for t in tensors[nk:]])
+            self._packers[key] = packer
+        blob = packer.pack(list(tensors))
+        self._blobs[key] = (versions, blob)
+        return blob
 
     # ------------------------------------------------------------------ contract
     def forward(self, batch, mode='train', **kwargs):

@@ -8,7 +8,7 @@ nerfactor/models/nerf.py:33-300), ray marching on libnfx:
 """
 import torch
 
-from nerfactor_amd import ops
+from nerfactor_amd import autograd, ops
 
 from ..networks import mlp
 from ..networks.embedder import Embedder
@@ -79,18 +79,16 @@ class Model(BaseModel):
 
     # ------------------------------------------------------------------ weights -> device blob
     def _nerf_blob(self, pref):
-        nets = [self.net[pref + k] for k in ('enc', 'sigma_out', 'bottleneck', 'rgb_out')]
-        ks, bs = [], []
-        for n in nets:
-            k, b = n.kernels_and_biases()
-            ks += k
-            bs += b
+        ks, bs = self._nerf_params(pref)
         return self._packed(pref + self.precision, ks + bs,
-                            lambda: ops.pack_nerf_weights(ks, bs, self.precision))
+                            lambda k, b: ops.pack_nerf_weights(k, b, self.precision))
 
     # ------------------------------------------------------------------ forward
     def call(self, batch, mode='train'):
         self._validate_mode(mode)
+        if mode != 'train' and torch.is_grad_enabled():
+            with torch.no_grad():
+                return self.call(batch, mode=mode)
         id_, hw, rayo, rayd, rgb = batch
         pred_coarse, pred_fine = self._render_rays(rayo, rayd, mode=mode)
         pred = {'coarse': pred_coarse['rgb'], 'fine': pred_fine.get('rgb', None)}
@@ -125,6 +123,28 @@ class Model(BaseModel):
         noise = torch.randn_like(sigma) * noise_std if noise_std > 0 else None
         return ops.composite_fwd(rgbs, z, rayd, white_bg=False, noise=noise)[4]
 
+    def _nerf_params(self, pref):
+        nets = [self.net[pref + k] for k in ('enc', 'sigma_out', 'bottleneck', 'rgb_out')]
+        ks, bs = [], []
+        for n in nets:
+            k, b = n.kernels_and_biases()
+            ks += k
+            bs += b
+        return ks, bs
+
+    def _nerf_train_blob(self, pref):
+        ks, bs = self._nerf_params(pref)
+        return self._packed(pref + 'train' + self.precision, ks + bs,
+                            lambda k, b: ops.pack_nerf_train_weights(k, b, self.precision))
+
+    def _eval_rays(self, rayo, rayd, z, pref):
+        """rgbs[N,S,4]; differentiable w.r.t. the network weights while autograd is recording."""
+        if torch.is_grad_enabled():
+            ks, bs = self._nerf_params(pref)
+            return autograd.NerfMlp.apply(rayo, rayd, z, self._nerf_blob(pref),
+                                          lambda: self._nerf_train_blob(pref), self.precision, *(ks + bs))
+        return ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision)
+
     def _render_rays(self, rayo, rayd, mode='train'):
         cfg = self.config
         n_coarse = cfg.getint('DEFAULT', 'n_samples_coarse')
@@ -133,19 +153,21 @@ class Model(BaseModel):
         rayd = ops.l2_normalize3(rayd, 1e-12)
         z = self.gen_z(self.near, self.far, n_coarse, rayo.shape[0], lin_in_disp=lin_in_disp,
                        perturb=perturb, device=rayo.device)
-        rgbs = ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob('coarse_'), self.precision)
+        rgbs = self._eval_rays(rayo, rayd, z, 'coarse_')
         rgb, occu, depth, disp, weights = self._accumulate(rgbs, z, rayd)
         pred_coarse = {'rgb': rgb, 'occu': occu, 'depth': depth, 'disp': disp}
         if self.n_samples_fine <= 0:
             return pred_coarse, {}
         z = self.gen_z_fine(z, weights, self.n_samples_fine, perturb=perturb)
-        rgbs = ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob('fine_'), self.precision)
+        rgbs = self._eval_rays(rayo, rayd, z, 'fine_')
         rgb, occu, depth, disp, _ = self._accumulate(rgbs, z, rayd, want_weights=False)
         return pred_coarse, {'rgb': rgb, 'occu': occu, 'depth': depth, 'disp': disp}
 
     def _accumulate(self, rgbs, z, rayd, want_weights=True):
         noise_std = self.config.getfloat('DEFAULT', 'noise_std')
         noise = torch.randn_like(z) * noise_std if noise_std > 0 else None
+        if torch.is_grad_enabled() and rgbs.requires_grad:
+            return autograd.Composite.apply(rgbs, z, rayd, noise, self.white_bg, want_weights)
         return ops.composite_fwd(rgbs, z, rayd, white_bg=self.white_bg, noise=noise,
                                  want_weights=want_weights)
 

@@ -300,7 +300,7 @@ class Model(ShapeModel):
             ko, bo = nets['brdf_out'].kernels_and_biases()
             ks, bs = ks + ko, bs + bo
             return self._packed('brdf_mlp_train' + self.precision, ks + bs,
-                                lambda: ops.pack_brdf_train_weights(ks, bs, self.z_dim, prec=self.precision))
+                                lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=self.precision))
         lxyz = self.lxyz.reshape(-1, 3)
         spec = nfx_grad.BrdfSpec.apply(xyz, cam, lxyz, fwd_blob, train_blob, normal, brdf_prop)
         return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,

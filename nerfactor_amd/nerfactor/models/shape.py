@@ -87,7 +87,7 @@ class Model(BaseModel):
         ks, bs = ks + ko, bs + bo
         return self._packed(
             body_name + self.precision, ks + bs,
-            lambda: ops.pack_mlp128_weights(ks, bs, in_kind, out_dim, z_dim=z_dim, prec=self.precision))
+            lambda k, b: ops.pack_mlp128_weights(k, b, in_kind, out_dim, z_dim=z_dim, prec=self.precision))
 
     def _train_blob128(self, body_name, head_name, in_kind, out_dim, nets=None):
         """Forward + dgrad fragments for the fused backward kernel (packed lazily, cached like _blob128)."""
@@ -97,7 +97,7 @@ class Model(BaseModel):
         ks, bs = ks + ko, bs + bo
         return self._packed(
             body_name + '_train' + self.precision, ks + bs,
-            lambda: ops.pack_mlp128_train_weights(ks, bs, in_kind, out_dim, prec=self.precision))
+            lambda k, b: ops.pack_mlp128_train_weights(k, b, in_kind, out_dim, prec=self.precision))
 
     def _params128(self, body_name, head_name, nets=None):
         nets = self.net if nets is None else nets

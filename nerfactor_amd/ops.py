@@ -57,6 +57,74 @@ def _pack(fn_bytes, fn_pack, kernels, biases, extra):
     return torch.from_numpy(blob)
 
 
+
+class DevicePacker:
+    """Re-packs one network's blob ON THE DEVICE (nfx_pack_gather) from an index map derived once from the host
+    packer `pack_fn(kernels, biases) -> uint8 blob`: the packer is run on arrays holding the base-256 digits (+1)
+    of each parameter's flat index — exactly representable in bf16 — so the blobs it returns ARE the gather map
+    (0 = padding).  Two probes (unit biases / unit kernels) tell fp32 bias words from bf16 weight pairs."""
+
+    def __init__(self, pack_fn, shapes_k, shapes_b):
+        self.pack_fn = pack_fn
+        self.shapes = [tuple(s) for s in list(shapes_k) + list(shapes_b)]
+        self.nk = len(shapes_k)
+        sizes = [int(np.prod(s)) for s in self.shapes]
+        if sum(sizes) >= 1 << 24:
+            raise _capi.NfxError("DevicePacker: network too large for the 3-digit index map")
+        offs = np.cumsum([0] + sizes)
+
+        def run(arrays):
+            return pack_fn(arrays[:self.nk], arrays[self.nk:]).numpy()
+
+        def const(vk, vb):
+            return [np.full(s, vk if i < self.nk else vb, np.float32) for i, s in enumerate(self.shapes)]
+        is_bias = run(const(0., 1.)).view(np.uint32) != 0
+        is_weight = run(const(1., 0.)).view(np.uint32) != 0
+        if (is_bias & is_weight).any() or not is_bias.any():
+            raise _capi.NfxError("DevicePacker: cannot separate the fp32 and bf16 regions of the blob")
+        self.n_words = int(is_bias.size)
+        self.nbytes = self.n_words * 4
+        lo = np.zeros(self.n_words, np.int64)
+        hi = np.zeros(self.n_words, np.int64)
+        fb = np.zeros(self.n_words, np.int64)
+        pad_lo = pad_hi = pad_b = None
+        for d in range(3):
+            arrays = [(((np.arange(offs[i], offs[i + 1]) >> (8 * d)) & 255) + 1).astype(np.float32).reshape(s)
+                      for i, s in enumerate(self.shapes)]
+            words = run(arrays).view(np.uint32)
+            vlo = (words << 16).view(np.float32).astype(np.int64)              # low bf16 of every word
+            vhi = (words & np.uint32(0xffff0000)).view(np.float32).astype(np.int64)
+            vb = np.where(is_bias, words.view(np.float32), 0.).astype(np.int64)
+            if d == 0:
+                pad_lo, pad_hi, pad_b = vlo == 0, vhi == 0, vb == 0
+            lo += np.maximum(vlo - 1, 0) << (8 * d)
+            hi += np.maximum(vhi - 1, 0) << (8 * d)
+            fb += np.maximum(vb - 1, 0) << (8 * d)
+        lo[pad_lo], hi[pad_hi], fb[pad_b] = -1, -1, -1
+        m = np.empty((self.n_words, 2), np.int32)
+        m[:, 0] = np.where(is_bias, fb, lo)
+        m[:, 1] = np.where(is_bias, -2, hi)
+        self.map_host = m
+        self._dev = {}
+        self._checked = False
+
+    def pack(self, tensors):
+        """tensors: the network's parameters (CUDA fp32, kernels then biases) -> uint8 CUDA blob."""
+        dev = tensors[0].device
+        if dev not in self._dev:
+            self._dev[dev] = torch.from_numpy(self.map_host).to(dev)
+        src = torch.cat([t.detach().reshape(-1) for t in tensors])
+        blob = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        check(lib.nfx_pack_gather(_ptr(src), _ptr(self._dev[dev]), self.n_words, _ptr(blob), _stream()),
+              'nfx_pack_gather')
+        if not self._checked:   # once per network: the device gather must reproduce the host packer bit for bit
+            want = self.pack_fn(list(tensors[:self.nk]), list(tensors[self.nk:]))
+            if not torch.equal(blob.cpu(), want):
+                raise _capi.NfxError("DevicePacker: device re-pack differs from the host packer")
+            self._checked = True
+        return blob
+
+
 NERF_LAYER_SHAPES = [(63, 256)] + [(256, 256)] * 4 + [(319, 256)] + [(256, 256)] * 2 + \
     [(256, 1), (256, 256), (283, 128), (128, 3)]
 
@@ -293,6 +361,57 @@ def mlp128_bwd(in_kind, xyz, dout, blob, dkernels, dbiases, out_act=None, xyz_sc
                              barr, _PREC[prec], _stream()), 'nfx_mlp128_bwd')
     return ws
 
+
+
+# ------------------------------------------------------------------------------ NeRF training ops
+def pack_nerf_train_weights(kernels, biases, prec='bf16'):
+    """Train blob (forward + dgrad fragments) of one NeRF network, for nerf_mlp_bwd."""
+    if len(kernels) != 12 or len(biases) != 12:
+        raise _capi.NfxError("pack_nerf_train_weights: need 12 kernels and 12 biases")
+    return _pack(lib.nfx_nerf_train_packed_bytes, lib.nfx_nerf_pack_train_weights, kernels, biases, (_PREC[prec],))
+
+
+def composite_bwd(rgbs, z, rayd, d_rgb, white_bg=True, noise=None):
+    """d_rgbs[N,S,4] = dLoss/d rgbs given d_rgb[N,3] = dLoss/d (composited rgb)."""
+    rgbs = _dev(rgbs, 'rgbs', (None, None, 4))
+    n, s = rgbs.shape[:2]
+    z = _dev(z, 'z', (n, s))
+    rayd = _dev(rayd, 'rayd', (n, 3))
+    noise = _dev(noise, 'noise', (n, s))
+    d_rgb = _dev(d_rgb, 'd_rgb', (n, 3))
+    out = torch.empty_like(rgbs)
+    check(lib.nfx_composite_bwd(_ptr(rgbs), _ptr(z), _ptr(rayd), _ptr(noise), n, s, int(white_bg), _ptr(d_rgb),
+                                _ptr(out), _stream()), 'nfx_composite_bwd')
+    return out
+
+
+NERF_BWD_MAX_POINTS = 1 << 19   # ~5 GB of feature-major workspace per call; more rays are processed in slices
+
+
+def nerf_mlp_bwd(rayo, rayd, z, d_rgbs, blob, dkernels, dbiases, prec='bf16'):
+    """Accumulate the weight gradients of one nerf_mlp_fwd call into `dkernels` / `dbiases` (lists of 12 fp32
+    CUDA tensors, Keras layout) given d_rgbs[N,S,4]."""
+    rayo = _dev(rayo, 'rayo', (None, 3))
+    n = rayo.shape[0]
+    rayd = _dev(rayd, 'rayd', (n, 3))
+    z = _dev(z, 'z', (n, None))
+    s = z.shape[1]
+    d_rgbs = _dev(d_rgbs, 'd_rgbs', (n, s, 4))
+    for t in list(dkernels) + list(dbiases):
+        _dev(t, 'gradient buffer')
+    karr = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in dkernels])
+    barr = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in dbiases])
+    rays_per_call = max(1, NERF_BWD_MAX_POINTS // s)
+    ws = None
+    for lo in range(0, n, rays_per_call):
+        hi = min(n, lo + rays_per_call)
+        ws_bytes = lib.nfx_nerf_bwd_workspace_bytes(hi - lo, s)
+        if ws is None or ws.numel() * 2 < ws_bytes:
+            ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=z.device)
+        check(lib.nfx_nerf_mlp_bwd(_ptr(rayo[lo:hi]), _ptr(rayd[lo:hi]), _ptr(z[lo:hi]), hi - lo, s, _ptr(blob),
+                                   _PREC[prec], _ptr(d_rgbs[lo:hi]), _ptr(ws), ws.numel() * 2, karr, barr,
+                                   _stream()), 'nfx_nerf_mlp_bwd')
+    return ws
 
 def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
     """In-place Keras Adam(amsgrad=True) update of the flat fp32 buffer `p` (step is 1-based)."""

@@ -62,6 +62,8 @@ class AMSGrad:
         self.iterations += 1
         ops.amsgrad_step(self.flat, g, self.m, self.v, self.vhat, lr, self.iterations, self.beta_1,
                          self.beta_2, self.epsilon)
+        # the kernel wrote through raw pointers: tell torch (and the models' packed-blob caches) the parameters changed
+        torch.autograd.graph.increment_version(self.params)
         return total
 
     def state_dict(self):

@@ -1,0 +1,56 @@
+"""The device re-pack maps (ops.DevicePacker) against the host packers, on the CPU: gathering random parameters
+through the maps (NumPy stand-in for nfx_pack_gather) must reproduce every host-packed blob bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+
+def _bf16_bits(x):
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def _emulate_gather(packer, arrays):
+    src = np.concatenate([a.reshape(-1) for a in arrays]).astype(np.float32)
+    m = packer.map_host.astype(np.int64)
+    take = lambda idx: np.where(idx >= 0, src[np.maximum(idx, 0)], 0.).astype(np.float32)
+    fp32 = m[:, 1] == -2
+    pair = _bf16_bits(take(m[:, 0])).astype(np.uint32) | (_bf16_bits(take(np.where(fp32, -1, m[:, 1]))).astype(np.uint32) << 16)
+    return np.where(fp32, take(m[:, 0]).view(np.uint32), pair).astype(np.uint32).view(np.uint8)
+
+
+def _cases(nfx):
+    from nerfactor_amd import ops
+    nerf_k = list(ops.NERF_LAYER_SHAPES)
+
+    def m128(ind, out):
+        return [(ind, 128), (128, 128), (128, 128), (128 + ind, 128), (128, out)]
+    return {
+        'nerf': (lambda k, b: ops.pack_nerf_weights(k, b), nerf_k),
+        'nerf_train': (lambda k, b: ops.pack_nerf_train_weights(k, b), nerf_k),
+        'normal': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ, 3), m128(63, 3)),
+        'lvis': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ_LDIR, 1), m128(90, 1)),
+        'brdf': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_Z_RUSINK, 1, z_dim=3), m128(18, 1)),
+        'normal_train': (lambda k, b: ops.pack_mlp128_train_weights(k, b, nfx.IN_XYZ, 3), m128(63, 3)),
+        'lvis_train': (lambda k, b: ops.pack_mlp128_train_weights(k, b, nfx.IN_XYZ_LDIR, 1), m128(90, 1)),
+        'brdf_train': (lambda k, b: ops.pack_brdf_train_weights(k, b, 3), m128(18, 1)),
+    }
+
+
+@pytest.mark.parametrize('name', ['nerf', 'nerf_train', 'normal', 'lvis', 'brdf', 'normal_train', 'lvis_train',
+                                  'brdf_train'])
+def test_gather_map_reproduces_host_packer(nfx_lib, name):
+    from nerfactor_amd import ops
+    pack_fn, shapes_k = _cases(nfx_lib)[name]
+    shapes_b = [(s[1],) for s in shapes_k]
+    packer = ops.DevicePacker(pack_fn, shapes_k, shapes_b)
+    rng = np.random.default_rng(len(name))
+    arrays = [rng.normal(size=s).astype(np.float32) for s in shapes_k + shapes_b]
+    want = pack_fn(arrays[:len(shapes_k)], arrays[len(shapes_k):]).numpy()
+    got = _emulate_gather(packer, arrays)
+    assert got.shape == want.shape and packer.nbytes == want.size
+    assert np.array_equal(got, want)
+    n_kernel = sum(int(np.prod(s)) for s in shapes_k)
+    m = packer.map_host
+    fp32 = m[:, 1] == -2
+    assert (m[fp32, 0][m[fp32, 0] >= 0] >= n_kernel).all()             # fp32 words gather biases only
+    assert m[~fp32].max() < n_kernel                                   # bf16 pairs gather kernels only

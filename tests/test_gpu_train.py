@@ -414,3 +414,158 @@ def test_nerfactor_learned_brdf_train_step_runs_and_descends(nfx_lib, cuda):
                     assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert not any(p.requires_grad for p in model.brdf_model.parameters())
+
+
+# ---------------------------------------------------------------------------------------- NeRF training path
+def torch_nerf(pe_x, pe_v, ks, bs, quant):
+    """rgbs[M,4] of nerf.py:256-290 (enc 8x256 with the skip after layer 4, sigma_out, bottleneck, rgb_out)."""
+    q = q16 if quant else (lambda t: t)
+    h = pe_x
+    for i in range(8):
+        h = torch.relu(q(h) @ q(ks[i]) + bs[i])
+        if i == 4:
+            h = torch.cat((h, pe_x), -1)
+    sigma = q(h) @ q(ks[8]) + bs[8]
+    bott = q(h) @ q(ks[9]) + bs[9]
+    r = torch.relu(q(torch.cat((bott, pe_v), -1)) @ q(ks[10]) + bs[10])
+    return torch.cat((q(r) @ q(ks[11]) + bs[11], sigma), -1)
+
+
+def torch_composite(rgbs, z, rayd, white_bg, noise=None):
+    """nerf.py:184-254 in torch (any dtype), for autograd."""
+    dist = torch.cat((z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)), 1) * rayd.norm(dim=1, keepdim=True)
+    sg = rgbs[..., 3] if noise is None else rgbs[..., 3] + noise
+    alpha = 1. - torch.exp(-torch.relu(sg) * dist)
+    t = 1. - alpha + 1e-6
+    T = torch.cat((torch.ones_like(t[:, :1]), torch.cumprod(t, 1)[:, :-1]), 1)
+    w = alpha * T
+    occu = w.sum(1, keepdim=True)
+    rgb = (w[..., None] * torch.sigmoid(rgbs[..., :3])).sum(1)
+    return rgb * occu + (1. if white_bg else 0.) * (1. - occu)
+
+
+@pytest.mark.parametrize("n,s,white_bg,use_noise", [(37, 64, True, False), (9, 192, False, True), (5, 7, True, False)])
+def test_composite_backward_vs_autograd(nfx_lib, cuda, n, s, white_bg, use_noise):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(300 + s)
+    rgbs = rng.normal(size=(n, s, 4)).astype(np.float32)
+    rgbs[..., 3] = rgbs[..., 3] * 3. + 0.5
+    z = np.sort(rng.uniform(2., 6., size=(n, s)).astype(np.float32), 1)
+    rayd = rng.normal(size=(n, 3)).astype(np.float32)
+    noise = rng.normal(size=(n, s)).astype(np.float32) if use_noise else None
+    g = rng.normal(size=(n, 3)).astype(np.float32)
+    got = ops.composite_bwd(dev(rgbs, cuda), dev(z, cuda), dev(rayd, cuda), dev(g, cuda), white_bg=white_bg,
+                            noise=None if noise is None else dev(noise, cuda)).cpu().numpy()
+    t = torch.tensor(rgbs, dtype=torch.float64, requires_grad=True)
+    out = torch_composite(t, torch.tensor(z, dtype=torch.float64), torch.tensor(rayd, dtype=torch.float64), white_bg,
+                          None if noise is None else torch.tensor(noise, dtype=torch.float64))
+    out.backward(torch.tensor(g, dtype=torch.float64))
+    want = t.grad.numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-5 * np.abs(want).max())
+    # and the forward the backward re-computes is the forward kernel's
+    rgb = ops.composite_fwd(dev(rgbs, cuda), dev(z, cuda), dev(rayd, cuda), white_bg=white_bg,
+                            noise=None if noise is None else dev(noise, cuda))[0].cpu().numpy()
+    np.testing.assert_allclose(rgb, out.detach().numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("n_rays,s", [(40, 7), (3, 192)])
+def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s):
+    from nerfactor_amd import ops
+    from tests import common
+    net = common.nerf_nets(seed=5, opaque=False)[0]
+    ks_np, bs_np = common.nerf_layers(net)
+    rng = np.random.default_rng(310 + s)
+    rayo = rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32)
+    rayd = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    rayd /= np.linalg.norm(rayd, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(0.5, 3., size=(n_rays, s)).astype(np.float32), 1)
+    d_rgbs = rng.normal(size=(n_rays, s, 4)).astype(np.float32)
+    blob = ops.pack_nerf_train_weights(ks_np, bs_np).to(cuda)
+    dks = [torch.zeros(k.shape, device=cuda) for k in ks_np]
+    dbs = [torch.zeros(b.shape, device=cuda) for b in bs_np]
+    ops.nerf_mlp_bwd(dev(rayo, cuda), dev(rayd, cuda), dev(z, cuda), dev(d_rgbs, cuda), blob, dks, dbs)
+    pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3)      # fp32, as the kernel forms them
+    views = np.broadcast_to(rayd[:, None, :], (n_rays, s, 3)).reshape(-1, 3)
+    pe_x = torch_embed(torch.tensor(pts).double(), 10)
+    pe_v = torch_embed(torch.tensor(views).double(), 4)
+    for quant, tol in ((True, 3e-2), (False, 0.3)):
+        ks = [torch.tensor(k, dtype=torch.float64, requires_grad=True) for k in ks_np]
+        bs = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs_np]
+        y = torch_nerf(pe_x, pe_v, ks, bs, quant)
+        y.backward(torch.tensor(d_rgbs.reshape(-1, 4), dtype=torch.float64))
+        _check_grads(dks, [k.grad for k in ks], 'dkernel(quant=%s)' % quant, tol)
+        _check_grads(dbs, [b.grad for b in bs], 'dbias(quant=%s)' % quant, tol)
+    # the train blob's forward half is the inference blob
+    inf = ops.pack_nerf_weights(ks_np, bs_np)
+    nfrag = 1272 * 1024
+    assert torch.equal(inf[:nfrag], blob[:nfrag].cpu()) and torch.equal(inf[nfrag:], blob[-(inf.numel() - nfrag):].cpu())
+
+
+def test_nerf_train_step_descends(nfx_lib, cuda):
+    """models.nerf through optim.train_step: every one of the 48 parameter tensors gets a finite gradient and the
+    coarse + fine L2 loss (nerf.py:292-300) goes down on a fixed batch."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from tests import common
+    torch.manual_seed(0)
+    cfg = make_config('nerf', n_samples_coarse=16, n_samples_fine=32, perturb=False, lr='5e-4')
+    model = get_model_class('nerf')(cfg).to(cuda)
+    with torch.no_grad():   # some opacity so that the compositing gradient is not vanishing
+        for pref in ('coarse_', 'fine_'):
+            layer = model.net[pref + 'sigma_out'].layers[0]
+            layer.kernel.mul_(8.)
+            layer.bias.add_(0.5)
+    rayo, rayd = common.camera_rays(16, 16)
+    n = rayo.shape[0]
+    rng = np.random.default_rng(3)
+    rgb = rng.uniform(size=(n, 3)).astype(np.float32)
+    batch = (['v'] * n, torch.tensor([[16, 16]] * n, dtype=torch.int32, device=cuda), dev(rayo, cuda),
+             dev(rayd, cuda), dev(rgb, cuda))
+    pred, gt, kw, _ = model(batch, mode='train')
+    loss = model.compute_loss(pred, gt, keep_batch=True).sum() / n
+    loss.backward()
+    got = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert len(got) == 48 and all(torch.isfinite(g).all() for g in got.values())
+    opt = optim.make_optimizer(model, cfg)
+    first = None
+    for it in range(25):
+        total, _ = optim.train_step(model, batch, opt, n)
+        first = float(total) if first is None else first
+    assert np.isfinite(float(total)) and float(total) < 0.9 * first, (first, float(total))
+    assert abs(first - float(loss)) < 1e-5 * max(1., abs(first))
+    # the cached device blobs follow the optimizer (its kernel writes the parameters through raw pointers)
+    from nerfactor_amd import ops
+    for pref in ('coarse_', 'fine_'):
+        ks, bs = model._nerf_params(pref)
+        assert torch.equal(model._nerf_blob(pref).cpu(), ops.pack_nerf_weights(ks, bs))
+        assert torch.equal(model._nerf_train_blob(pref).cpu(), ops.pack_nerf_train_weights(ks, bs))
+
+
+def test_packed_blobs_follow_optimizer_steps(nfx_lib, cuda):
+    """Regression: after AMSGrad steps the width-128 blobs used by the kernels are the CURRENT weights
+    (device re-pack through nfx_pack_gather, invalidated by the optimizer's version bump)."""
+    from nerfactor_amd import ops, optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(1)
+    cfg = make_config('shape', lr='1e-2')
+    model = get_model_class('shape')(cfg).to(cuda)
+    rng, lxyz, _, xyz, cam, normal = scene(256, 17)
+    lvis = rng.uniform(size=(256, 512)).astype(np.float32)
+    batch = (['v'] * 256, torch.tensor([[16, 16]] * 256, dtype=torch.int32, device=cuda), dev(cam, cuda),
+             dev(xyz - cam, cuda), dev(xyz * 0 + .5, cuda), torch.ones((256, 1), device=cuda), dev(xyz, cuda),
+             dev(normal, cuda), dev(lvis, cuda))
+    opt = optim.make_optimizer(model, cfg)
+    before = model._blob128('normal_mlp', 'normal_out', nfx_lib.IN_XYZ, 3).clone()
+    losses = [float(optim.train_step(model, batch, opt, 256)[0]) for _ in range(12)]
+    assert losses[-1] < losses[0], losses
+    for body, head, kind, od in (('normal_mlp', 'normal_out', nfx_lib.IN_XYZ, 3),
+                                 ('lvis_mlp', 'lvis_out', nfx_lib.IN_XYZ_LDIR, 1)):
+        params = model._params128(body, head)
+        ks, bs = list(params[:5]), list(params[5:])
+        assert torch.equal(model._blob128(body, head, kind, od).cpu(), ops.pack_mlp128_weights(ks, bs, kind, od))
+        assert torch.equal(model._train_blob128(body, head, kind, od).cpu(),
+                           ops.pack_mlp128_train_weights(ks, bs, kind, od))
+    assert not torch.equal(before, model._blob128('normal_mlp', 'normal_out', nfx_lib.IN_XYZ, 3))
