@@ -257,10 +257,14 @@ __device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp,
     const float tm = div_no_nan(1.0f - q, q), E = a2 + tm;
     const float pi = 3.14159265358979323846f;
     const float D = div_no_nan(a2 * chi, pi * (q * q) * (E * E));
+    // Derivatives in overflow-free closed form (the literal chain rule through q^2 E^2 and tan^2 produces inf - inf
+    // for grazing half vectors, |h.n| < ~1e-6, which 512 lights x 1024 rays hit every few steps):
+    //   q^2 E^2 = W^2 with W = q E = 1 + (a2 - 1) q  in [min(1,a2), max(1,a2)]   =>  D = a2 chi / (pi W^2)
     float dD_dq = 0.f, dD_da2 = 0.f;
-    if (chi > 0.f && q > 0.f && E != 0.f) {
-        dD_dq = a2 / pi * (-2.0f / (q * q * q * E * E) + 2.0f / (q * q * q * q * E * E * E));
-        dD_da2 = (1.0f / (q * q * E * E) - 2.0f * a2 / (q * q * E * E * E)) / pi;
+    if (chi > 0.f && q > 0.f) {
+        const float W = 1.0f + (a2 - 1.0f) * q, W3 = W * W * W;
+        dD_dq = -2.0f * a2 * (a2 - 1.0f) / (pi * W3);
+        dD_da2 = (W - 2.0f * a2 * q) / (pi * W3);
     }
     const float cv = mp.cos_v, ct = dot3(hv, mp.v);
     const float chig = div_no_nan(ct, cv) > 0.0f ? 1.0f : 0.0f;
@@ -268,10 +272,14 @@ __device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp,
     const float tv_raw = div_no_nan(1.0f - p, p), tv = fmaxf(tv_raw, 0.0f);
     const float s = sqrtf(1.0f + a2 * tv);
     const float G = div_no_nan(chig * 2.0f, 1.0f + s);
-    const float dG_ds = -2.0f * chig / ((1.0f + s) * (1.0f + s));
-    float dG_dcv = 0.f;
-    if (tv_raw > 0.0f && p > 0.0f && cv2 < 1.0f) dG_dcv = dG_ds * (a2 / (2.0f * s)) * (-1.0f / (p * p)) * (2.0f * cv);
-    const float dG_da2 = dG_ds * tv / (2.0f * s);
+    //   with c = |n.v|, r = sqrt(a2 + (1 - a2) c^2) (= c s):  G = 2 chi_g c / (c + r)
+    //   dG/dc = 2 a2 / (r (c + r)^2),   dG/da2 = -(1 - c^2) c / (r (c + r)^2)
+    float dG_dcv = 0.f, dG_da2 = 0.f;
+    if (chig > 0.f && cv2 > 0.0f && cv2 < 1.0f) {
+        const float c = fabsf(cv), r = sqrtf(a2 + (1.0f - a2) * p), cr2 = (c + r) * (c + r);
+        dG_dcv = (cv > 0.f ? 1.f : -1.f) * 2.0f * a2 / (r * cr2);
+        dG_da2 = -(1.0f - p) * c / (r * cr2);
+    }
     const float cl = dot3(l, mp.n);
     const float den = 4.0f * fabsf(cl) * fabsf(cv);
     if (den == 0.0f) {

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Secondary benchmark (BASELINE.json configs[3], SURVEY.md §8d "C4"): NeRFactor-microfacet training
-steps — 1024 foreground rays per GPU per step (weak scaling; n_rays_per_step of config/nerfactor.ini),
-xyz_jitter_std = 0.01, 512 lights, one flat-bucket all-reduce + one fused AMSGrad kernel per step.
+"""Secondary benchmark (BASELINE.json configs[3], SURVEY.md §8d "C4"): training steps — 1024 rays per GPU per
+step (weak scaling; n_rays_per_step of config/*.ini), one flat-bucket all-reduce + one fused AMSGrad kernel per
+step, blobs re-packed on the device.  --model nerfactor_microfacet | nerfactor (xyz_jitter_std = 0.01, 512 lights)
+| shape | nerf (64 + 128 samples, perturb on).
 
-    python scripts/bench_train.py [--steps K]            (torchrun for N > 1)
+    python scripts/bench_train.py [--model M] [--steps K]            (torchrun for N > 1)
 """
 import argparse
 import json
@@ -23,6 +24,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rays', type=int, default=1024)
+    ap.add_argument('--model', default='nerfactor_microfacet',
+                    choices=['nerfactor_microfacet', 'nerfactor', 'shape', 'nerf'])
     args = ap.parse_args()
     from nerfactor_amd import build
     build.build()
@@ -34,8 +37,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     rank, world = nfx_dist.init_from_env(backend='nccl', device=dev)
     torch.manual_seed(5)  # identical initial weights on every rank (MirroredStrategy semantics)
-    cfg = make_config('nerfactor_microfacet', shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='')
-    model = get_model_class('nerfactor_microfacet')(cfg).to(dev)
+    extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if 'nerfactor' in args.model else {}
+    cfg = make_config(args.model, **extra)
+    model = get_model_class(args.model)(cfg).to(dev)
     opt = optim.make_optimizer(model, cfg)
     rng = np.random.default_rng(100 + rank)
     n = args.rays
@@ -45,6 +49,8 @@ def main():
     cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
     batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))), torch.ones(n, 1, device=dev), xyz,
              nrm, t(rng.uniform(size=(n, 512))))
+    if args.model == 'nerf':   # rays from the camera towards the unit cube
+        batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
     global_bs = n * world
     for _ in range(args.warmup):
         optim.train_step(model, batch, opt, global_bs)
@@ -60,11 +66,14 @@ def main():
     dt = nfx_dist.max_over_ranks(time.perf_counter() - t0, device=dev) / args.steps
     if rank == 0:
         rows = n * 512 * 2  # clean + jittered visibility rows
+        if args.model == 'nerf':   # forward + recomputed forward + dgrad + wgrad of (64 + 192) points per ray
+            flops, what = 4 * n * 256 * 1186816, "64+128 samples, perturb on"
+        else:
+            flops, what = 3 * 2 * (rows * 72320 + 2 * 3 * n * 65664), "512 lights, jitter on"
         print(json.dumps({
-            "workload": "nerfactor_microfacet train step, %d rays/GPU (weak), 512 lights, jitter on" % n,
+            "workload": "%s train step, %d rays/GPU (weak), %s" % (args.model, n, what),
             "n_gpus": world, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
-            "lvis_rows_per_step_per_gpu": rows,
-            "mlp_flops_per_step_per_gpu": 3 * 2 * (rows * 72320 + 2 * 3 * n * 65664),
+            "mlp_flops_per_step_per_gpu": flops, "mlp_tflops": flops / dt / 1e12,
             "final_loss": float(loss)}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -569,3 +569,33 @@ def test_packed_blobs_follow_optimizer_steps(nfx_lib, cuda):
         assert torch.equal(model._train_blob128(body, head, kind, od).cpu(),
                            ops.pack_mlp128_train_weights(ks, bs, kind, od))
     assert not torch.equal(before, model._blob128('normal_mlp', 'normal_out', nfx_lib.IN_XYZ, 3))
+
+
+def test_shade_backward_finite_for_grazing_half_vectors(nfx_lib, cuda):
+    """Regression: normals orthogonal (to ~1e-7) to the half vector of some light used to give inf - inf in the
+    literal chain rule through cos^4 (a2 + tan^2)^2; the closed-form GGX derivatives stay finite."""
+    from nerfactor_amd import ops
+    n = 2048
+    rng, lxyz, lareas, xyz, cam, normal = scene(n, 123)
+    # make every point graze the half vector of light (i mod 512): n = unit vector orthogonal to h, + 1e-7 h
+    v = cam - xyz
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    l = lxyz[np.arange(n) % 512] - xyz
+    l /= np.linalg.norm(l, axis=1, keepdims=True)
+    h = (l + v) / np.linalg.norm(l + v, axis=1, keepdims=True)
+    t = np.cross(h, v)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    normal = (np.cos(0.3) * np.cross(t, h) + np.sin(0.3) * t + rng.choice([1e-7, 3e-8, 0., 1e-6], size=(n, 1)) * h)
+    normal = normal.astype(np.float32)
+    albedo = rng.uniform(.1, .8, size=(n, 3)).astype(np.float32)
+    rough = rng.uniform(.1, .9, size=(n,)).astype(np.float32)
+    lvis = rng.uniform(size=(n, 512)).astype(np.float32)
+    light = rng.uniform(size=(512, 3)).astype(np.float32)
+    drgb = rng.normal(size=(n, 3)).astype(np.float32)
+    d_light = torch.zeros((512, 3), device=cuda)
+    outs = ops.shade_bwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(albedo, cuda), dev(lvis, cuda),
+                         dev(lxyz, cuda), dev(lareas, cuda), dev(light, cuda), dev(drgb, cuda), d_light,
+                         rough=dev(rough, cuda))
+    for name, o in zip(('d_albedo', 'd_normal', 'd_lvis', 'd_rough'), outs):
+        assert torch.isfinite(o).all(), name
+    assert torch.isfinite(d_light).all()
