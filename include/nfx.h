@@ -269,6 +269,25 @@ int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_
                      void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Geometry extraction from a trained NeRF (geometry_from_nerf.py:177-350).   */
+/* ------------------------------------------------------------------------ */
+
+/* sigma[n_rays, S] = sigma_out(enc(posenc(rayo + rayd z))) BEFORE the relu (eval_sigma_mlp, :322-350), from the
+ * inference blob of nfx_nerf_pack_weights: the bottleneck / rgb head is not evaluated.                        */
+int nfx_nerf_sigma_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+                       int n_samples, const void *dev_blob, int prec, float *dev_sigma, void *stream);
+
+/* out[n_rays, S, 4] = (n_x, n_y, n_z, sigma_raw) with n = -l2_normalize(d relu(sigma_raw)/dx, eps 1e-12): the
+ * per-sample normal of compute_depth_and_normal (:280-297, GradientTape.batch_jacobian there).  `geom_blob` =
+ * nfx_nerf_pack_geom_weights (encoder + sigma tile, transposed encoder, input-gradient tiles).  16-byte aligned out. */
+size_t nfx_nerf_geom_packed_bytes(int prec);
+int nfx_nerf_pack_geom_weights(const float *const kernels[12], const float *const biases[12], int prec,
+                               void *blob, size_t blob_bytes);
+int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+                        int n_samples, const void *dev_geom_blob, int prec, float *dev_normal_sigma,
+                        void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Diagnostics.                                                              */
 /* ------------------------------------------------------------------------ */
 

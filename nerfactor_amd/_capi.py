@@ -67,6 +67,10 @@ SIGNATURES = {
                            _p, _p]),
     'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),
     'nfx_amsgrad_step': (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _i64, _p]),
+    'nfx_nerf_sigma_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_nerf_geom_packed_bytes': (_sz, [_i]),
+    'nfx_nerf_pack_geom_weights': (_i, [_pp, _pp, _i, _p, _sz]),
+    'nfx_nerf_sigma_grad': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
 }

@@ -1,0 +1,119 @@
+// capi_geom.cpp — C-ABI entry points of the geometry-extraction kernels (include/nfx.h): density only, and density
+// with its spatial gradient (geometry_from_nerf.py:249-350).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nfx.h"
+#include "nerf_geom_layout.hpp"
+#include "pack.hpp"
+
+int nfx_fail(int code, const char* fmt, ...);
+int nfx_hip_result(int e, const char* what);
+extern "C" int nfx_env_int(const char* name, int dflt);
+
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return nfx_fail(NFX_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
+
+extern "C" {
+int nfx_launch_nerf_sigma_bf16(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                               hipStream_t);
+int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                               hipStream_t);
+
+size_t nfx_nerf_geom_packed_bytes(int prec) { return prec == NFX_PREC_BF16 ? (size_t)nfx::nerf::kGeoBlobBytes : 0; }
+
+int nfx_nerf_pack_geom_weights(const float* const kernels[12], const float* const biases[12], int prec, void* blob,
+                               size_t blob_bytes) {
+    using namespace nfx;
+    using namespace nfx::pack;
+    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_geom_weights: null argument");
+    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_geom_weights: layer %d null", i);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_pack_geom_weights: only bf16 is built");
+    REQUIRE(blob_bytes >= (size_t)nerf::kGeoBlobBytes, "nfx_nerf_pack_geom_weights: blob too small (%zu < %d)",
+            blob_bytes, nerf::kGeoBlobBytes);
+    uint8_t* w0 = static_cast<uint8_t*>(blob);
+    std::vector<uint8_t> fwd(nfx_nerf_packed_bytes(prec));
+    int rc = nfx_nerf_pack_weights(kernels, biases, prec, fwd.data(), fwd.size());
+    if (rc) return rc;
+    // forward: encoder chunks 0..63 and the sigma tile (chunk 72 = 9th tile of the fused [bottleneck | sigma_out])
+    const size_t enc_bytes = (size_t)nerf::chunk_frag_offset(64) * 1024;
+    memcpy(w0, fwd.data(), enc_bytes);
+    memcpy(w0 + enc_bytes, fwd.data() + (size_t)nerf::chunk_frag_offset(72) * 1024, 16 * 1024);
+    uint8_t* w = w0 + enc_bytes + 16 * 1024;
+    std::vector<float> sink(256);
+    const Seg hid256{kHidden, 256, 0, nullptr};
+    auto hidden_t = [](const float* k) {  // W[:256, :256]^T
+        std::vector<float> t((size_t)256 * 256);
+        for (int r = 0; r < 256; ++r)
+            for (int c = 0; c < 256; ++c) t[(size_t)c * 256 + r] = k[(size_t)r * 256 + c];
+        return t;
+    };
+    // input-gradient product: kernel'[k][f'] = W[row0 + posenc_row(slot f')][k], f' = F(s,h,j) of the slot, so the
+    // C/D lane map of the output tile IS the posenc slot layout of mlp_engine.hpp:posenc<10>
+    auto input_t = [](const float* k, int row0) {
+        std::vector<float> t((size_t)256 * 64, 0.f);
+        const Seg pe{kPosEnc, 10, 0, nullptr};
+        for (int s = 0; s < 4; ++s)
+            for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < 8; ++j) {
+                    const int src = seg_row(pe, s, h, j);
+                    if (src < 0) continue;
+                    const int fp = 32 * (s >> 1) + 16 * (s & 1) + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    for (int kk = 0; kk < 256; ++kk) t[(size_t)kk * 64 + fp] = k[(size_t)(row0 + src) * 256 + kk];
+                }
+        return t;
+    };
+    auto dgrad = [&](int l) {
+        std::vector<float> t = hidden_t(kernels[l]);
+        w += pack_layer_bf16({hid256}, {{t.data(), nullptr, 256}}, 8, 16, w, sink.data());
+    };
+    auto igrad = [&](int l, int row0) {
+        std::vector<float> t = input_t(kernels[l], row0);
+        w += pack_layer_bf16({hid256}, {{t.data(), nullptr, 64}}, 2, 16, w, sink.data());
+    };
+    dgrad(7);
+    dgrad(6);
+    igrad(5, 256);
+    for (int l = 5; l >= 1; --l) dgrad(l);
+    igrad(0, 0);
+    if (w != w0 + nerf::kGeoWeightBytes) return nfx_fail(NFX_EINVAL, "nfx_nerf_pack_geom_weights: layout mismatch");
+    float* fl = reinterpret_cast<float*>(w0 + nerf::kGeoWeightBytes);
+    const float* fb = reinterpret_cast<const float*>(fwd.data() + nerf::kWeightBytes);
+    memcpy(fl, fb + nerf::kBiasL0, 8 * 256 * 4);
+    memcpy(fl + nerf::kGeoBiasSig, fb + nerf::kBiasBott + 256, 32 * 4);
+    // sigma_out kernel in fp32: the kernel rounds it to bf16 when it forms dZ7, as the forward's packed copy is
+    memcpy(fl + nerf::kGeoWSig, kernels[8], 256 * 4);
+    return NFX_OK;
+}
+
+int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                       const void* blob, int prec, float* sigma, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_fwd: bad shape");
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_sigma_fwd: only bf16 is built");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && blob && sigma, "nfx_nerf_sigma_fwd: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_fwd: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_nerf_sigma_bf16(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
+                                                     sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                          "nerf_sigma_fwd");
+}
+
+int nfx_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                        const void* geom_blob, int prec, float* normal_sigma, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_grad: bad shape");
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_sigma_grad: only bf16 is built");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && geom_blob && normal_sigma, "nfx_nerf_sigma_grad: null pointer");
+    if (!ALIGNED(geom_blob, 16) || !ALIGNED(normal_sigma, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_grad: blob and output must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_nerf_sigma_grad(rayo, rayd, z, (long long)n_rays * n_samples, n_samples,
+                                                     geom_blob, normal_sigma, nfx_env_int("NFX_NERF_BLOCKS", 256),
+                                                     (hipStream_t)stream),
+                          "nerf_sigma_grad");
+}
+}  // extern "C"

@@ -181,6 +181,37 @@ class Model(BaseModel):
         pref = 'fine_' if use_fine else 'coarse_'
         return ops.nerf_mlp_fwd(o, d, z, self._nerf_blob(pref), self.precision).reshape(n, s, 4)
 
+    # ------------------------------------------------------------------ geometry extraction (geometry_from_nerf.py)
+    def _nerf_geom_blob(self, pref):
+        ks, bs = self._nerf_params(pref)
+        return self._packed(pref + 'geom' + self.precision, ks + bs,
+                            lambda k, b: ops.pack_nerf_geom_weights(k, b, self.precision))
+
+    @staticmethod
+    def _in_bounds(rayo, rayd, z, bbox):
+        pts = rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]
+        lo = pts.new_tensor(bbox[0::2])
+        hi = pts.new_tensor(bbox[1::2])
+        return ((pts >= lo) & (pts <= hi)).all(-1)
+
+    def eval_sigma(self, rayo, rayd, z, use_fine=False, bbox=None):
+        """relu(sigma)[N,S] at rayo + rayd z (eval_sigma_mlp, geometry_from_nerf.py:322-350); outside the optional
+        bounding box (x_min, x_max, y_min, y_max, z_min, z_max) the density is 0."""
+        pref = 'fine_' if use_fine else 'coarse_'
+        sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision))
+        if bbox is not None:
+            sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)
+        return sigma
+
+    def eval_sigma_normal(self, rayo, rayd, z, bbox=None):
+        """(relu(sigma)[N,S], normal[N,S,3]) of the FINE network, normal = -l2_normalize(d sigma / dx)
+        (geometry_from_nerf.py:280-306: the bounding box zeroes sigma, not the normal)."""
+        normal, sigma = ops.nerf_sigma_grad(rayo, rayd, z, self._nerf_geom_blob('fine_'), self.precision)
+        sigma = torch.relu(sigma)
+        if bbox is not None:
+            sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)
+        return sigma, normal
+
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):
         coarse, fine = pred['coarse'], pred['fine']

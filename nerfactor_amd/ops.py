@@ -62,7 +62,7 @@ class DevicePacker:
     """Re-packs one network's blob ON THE DEVICE (nfx_pack_gather) from an index map derived once from the host
     packer `pack_fn(kernels, biases) -> uint8 blob`: the packer is run on arrays holding the base-256 digits (+1)
     of each parameter's flat index — exactly representable in bf16 — so the blobs it returns ARE the gather map
-    (0 = padding).  Two probes (unit biases / unit kernels) tell fp32 bias words from bf16 weight pairs."""
+    (0 = padding).  A probe with every parameter = 1 + 2^-20 tells fp32 words from bf16 pairs."""
 
     def __init__(self, pack_fn, shapes_k, shapes_b):
         self.pack_fn = pack_fn
@@ -76,11 +76,11 @@ class DevicePacker:
         def run(arrays):
             return pack_fn(arrays[:self.nk], arrays[self.nk:]).numpy()
 
-        def const(vk, vb):
-            return [np.full(s, vk if i < self.nk else vb, np.float32) for i, s in enumerate(self.shapes)]
-        is_bias = run(const(0., 1.)).view(np.uint32) != 0
-        is_weight = run(const(1., 0.)).view(np.uint32) != 0
-        if (is_bias & is_weight).any() or not is_bias.any():
+        # probe: every parameter = 1 + 2^-20 -> an fp32 word reads 0x3f800008, a bf16 half 0x3f80 (or 0 = padding)
+        probe = run([np.full(s, 1. + 2. ** -20, np.float32) for s in self.shapes]).view(np.uint32)
+        is_bias = probe == np.uint32(0x3f800008)                  # "bias" = any parameter stored as fp32
+        halves_ok = np.isin(probe & np.uint32(0xffff), (0, 0x3f80)) & np.isin(probe >> np.uint32(16), (0, 0x3f80))
+        if not (is_bias | halves_ok).all() or not is_bias.any():
             raise _capi.NfxError("DevicePacker: cannot separate the fp32 and bf16 regions of the blob")
         self.n_words = int(is_bias.size)
         self.nbytes = self.n_words * 4
@@ -412,6 +412,42 @@ def nerf_mlp_bwd(rayo, rayd, z, d_rgbs, blob, dkernels, dbiases, prec='bf16'):
                                    _PREC[prec], _ptr(d_rgbs[lo:hi]), _ptr(ws), ws.numel() * 2, karr, barr,
                                    _stream()), 'nfx_nerf_mlp_bwd')
     return ws
+
+
+# ------------------------------------------------------------------------------ geometry extraction ops
+def pack_nerf_geom_weights(kernels, biases, prec='bf16'):
+    """Blob of nerf_sigma_grad: encoder + sigma tile, transposed encoder, input-gradient tiles."""
+    if len(kernels) != 12 or len(biases) != 12:
+        raise _capi.NfxError("pack_nerf_geom_weights: need 12 kernels and 12 biases")
+    return _pack(lib.nfx_nerf_geom_packed_bytes, lib.nfx_nerf_pack_geom_weights, kernels, biases, (_PREC[prec],))
+
+
+def _ray_args(rayo, rayd, z, blob):
+    rayo = _dev(rayo, 'rayo', (None, 3))
+    n = rayo.shape[0]
+    rayd = _dev(rayd, 'rayd', (n, 3))
+    z = _dev(z, 'z', (n, None))
+    if not blob.is_cuda or blob.dtype != torch.uint8:
+        raise _capi.NfxError("blob must be a CUDA uint8 tensor")
+    return rayo, rayd, z, n, z.shape[1]
+
+
+def nerf_sigma_fwd(rayo, rayd, z, blob, prec='bf16'):
+    """sigma_raw[N,S] (no relu) at rayo + rayd*z from the inference blob; the rgb head is skipped."""
+    rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, blob)
+    out = torch.empty((n, s), dtype=torch.float32, device=z.device)
+    check(lib.nfx_nerf_sigma_fwd(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(blob), _PREC[prec], _ptr(out),
+                                 _stream()), 'nfx_nerf_sigma_fwd')
+    return out
+
+
+def nerf_sigma_grad(rayo, rayd, z, geom_blob, prec='bf16'):
+    """(normal[N,S,3], sigma_raw[N,S]) with normal = -l2_normalize(d relu(sigma)/dx)."""
+    rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, geom_blob)
+    out = torch.empty((n, s, 4), dtype=torch.float32, device=z.device)
+    check(lib.nfx_nerf_sigma_grad(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(geom_blob), _PREC[prec], _ptr(out),
+                                  _stream()), 'nfx_nerf_sigma_grad')
+    return out[..., :3], out[..., 3]
 
 def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
     """In-place Keras Adam(amsgrad=True) update of the flat fp32 buffer `p` (step is 1-based)."""

@@ -27,6 +27,7 @@ def _cases(nfx):
     return {
         'nerf': (lambda k, b: ops.pack_nerf_weights(k, b), nerf_k),
         'nerf_train': (lambda k, b: ops.pack_nerf_train_weights(k, b), nerf_k),
+        'nerf_geom': (lambda k, b: ops.pack_nerf_geom_weights(k, b), nerf_k),
         'normal': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ, 3), m128(63, 3)),
         'lvis': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ_LDIR, 1), m128(90, 1)),
         'brdf': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_Z_RUSINK, 1, z_dim=3), m128(18, 1)),
@@ -36,7 +37,7 @@ def _cases(nfx):
     }
 
 
-@pytest.mark.parametrize('name', ['nerf', 'nerf_train', 'normal', 'lvis', 'brdf', 'normal_train', 'lvis_train',
+@pytest.mark.parametrize('name', ['nerf', 'nerf_train', 'nerf_geom', 'normal', 'lvis', 'brdf', 'normal_train', 'lvis_train',
                                   'brdf_train'])
 def test_gather_map_reproduces_host_packer(nfx_lib, name):
     from nerfactor_amd import ops
@@ -52,5 +53,6 @@ def test_gather_map_reproduces_host_packer(nfx_lib, name):
     n_kernel = sum(int(np.prod(s)) for s in shapes_k)
     m = packer.map_host
     fp32 = m[:, 1] == -2
-    assert (m[fp32, 0][m[fp32, 0] >= 0] >= n_kernel).all()             # fp32 words gather biases only
+    if name != 'nerf_geom':   # (its fp32 region also carries the sigma_out kernel)
+        assert (m[fp32, 0][m[fp32, 0] >= 0] >= n_kernel).all()         # fp32 words gather biases only
     assert m[~fp32].max() < n_kernel                                   # bf16 pairs gather kernels only

@@ -115,6 +115,25 @@ def test_nerf_trainvali_then_nerf_test(nfx_lib, cuda, scene):
     assert exists(join(outdir, 'vis_vali', 'epoch000000004', 'batch000000000', 'fine_rgb.png'))
     out = nerf_test.main(['--ckpt=' + join(outdir, 'checkpoints', 'ckpt-2')])
     assert len(glob.glob(join(out, 'batch?????????', 'fine_rgb.png'))) == 3
+    # ---- stage 2: geometry_from_nerf writes what datasets/nerf_shape.py reads
+    from nerfactor_amd.nerfactor import geometry_from_nerf
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets import get_dataset_class
+    surf_root = join(scene[0], 'surf')
+    done = geometry_from_nerf.main(['--trained_nerf=' + outdir, '--out_root=' + surf_root, '--lvis_far=1',
+                                    '--scene_bbox=-1.5,1.5,-1.5,1.5,-1.5,1.5'])
+    assert len(done) == 3 + 1 + 3
+    vdir = join(surf_root, 'train_000')
+    xyz, normal, lvis = (np.load(join(vdir, f + '.npy')) for f in ('xyz', 'normal', 'lvis'))
+    assert xyz.shape == (24, 24, 3) and normal.shape == (24, 24, 3) and lvis.shape == (24, 24, 512)
+    assert np.isfinite(xyz).all() and np.isfinite(lvis).all() and lvis.min() >= 0 and lvis.max() <= 1
+    np.testing.assert_allclose(np.linalg.norm(normal, axis=2), 1., atol=1e-4)
+    for f in ('alpha.png', 'xyz.png', 'normal.png', 'lvis.png'):
+        assert exists(join(vdir, f)), f
+    assert geometry_from_nerf.main(['--trained_nerf=' + outdir, '--out_root=' + surf_root]) == done   # resumable: skips
+    cfg = make_config('shape', data_root=scene[1], data_nerf_root=surf_root, imh=24, n_rays_per_step=16)
+    batch = next(iter(get_dataset_class('nerf_shape')(cfg, 'vali', device='cpu').build_pipeline(no_batch=True)))
+    assert batch[8].shape == (576, 512)
 
 
 def test_nerf_test_driver(nfx_lib, cuda, scene, tmp_path):

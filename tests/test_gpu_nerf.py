@@ -250,3 +250,71 @@ def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
         outs[v] = [ops.nerf_mlp_fwd(rayo, rayd, z, blob) for _ in range(3)]
     for t in outs["1"][1:] + outs["2"] + outs["3"] + outs["4"]:
         assert torch.equal(outs["1"][0], t)
+
+
+# ---------------------------------------------------------------------------------------- geometry extraction
+def _geom_inputs(n_rays, s, seed):
+    rng = np.random.default_rng(seed)
+    rayo = rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32)
+    rayd = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    rayd /= np.linalg.norm(rayd, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(0.1, 2.5, size=(n_rays, s)).astype(np.float32), 1)
+    return rayo, rayd, z
+
+
+def test_sigma_only_kernel_is_the_full_kernel_s_density(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    net = common.nerf_nets(seed=7)[1]
+    ks, bs = common.nerf_layers(net)
+    blob = ops.pack_nerf_weights(ks, bs).to(cuda)
+    rayo, rayd, z = _geom_inputs(301, 5, 0)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    full = ops.nerf_mlp_fwd(t(rayo), t(rayd), t(z), blob)
+    sig = ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), blob)
+    assert torch.equal(sig, full[..., 3])
+
+
+def test_sigma_gradient_normals_vs_autograd(nfx_lib, cuda):
+    """n = -normalize(d relu(sigma)/dx) (geometry_from_nerf.py:289-297) against torch autograd through the network
+    evaluated with the kernel's bf16 operand rounding (straight-through), and loosely against plain fp64."""
+    from nerfactor_amd import ops
+    net = common.nerf_nets(seed=8)[1]
+    ks_np, bs_np = common.nerf_layers(net)
+    blob = ops.pack_nerf_weights(ks_np, bs_np).to(cuda)
+    gblob = ops.pack_nerf_geom_weights(ks_np, bs_np).to(cuda)
+    rayo, rayd, z = _geom_inputs(50, 9, 1)     # 450 points: exercises the padded last tile
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    normal, sigma = ops.nerf_sigma_grad(t(rayo), t(rayd), t(z), gblob)
+    assert torch.equal(sigma, ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), blob))
+    normal, sigma = normal.cpu().numpy().reshape(-1, 3), sigma.cpu().numpy().reshape(-1)
+    pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3)
+
+    def q16(v):
+        return v + (v.detach().float().to(torch.bfloat16).to(v.dtype) - v.detach())
+
+    def reference(quant):
+        q = q16 if quant else (lambda v: v)
+        x = torch.tensor(pts, dtype=torch.float64, requires_grad=True)
+        parts = [x]
+        for k in range(10):
+            parts += [torch.sin(x * 2. ** k), torch.cos(x * 2. ** k)]
+        pe = torch.cat(parts, -1)
+        h = pe
+        for i in range(8):
+            h = torch.relu(q(h) @ q(torch.tensor(ks_np[i], dtype=torch.float64)) + torch.tensor(bs_np[i], dtype=torch.float64))
+            if i == 4:
+                h = torch.cat((h, pe), -1)
+        raw = q(h) @ q(torch.tensor(ks_np[8], dtype=torch.float64)) + torch.tensor(bs_np[8], dtype=torch.float64)
+        (g,) = torch.autograd.grad(torch.relu(raw).sum(), x)
+        return raw.detach().numpy()[:, 0], g.numpy()
+    raw_q, g_q = reference(True)
+    assert np.abs(raw_q - sigma).max() < 2e-2 * max(1., np.abs(raw_q).max())
+    on = sigma > 0
+    assert 0.2 < on.mean() < 1.0
+    assert np.abs(normal[~on]).max() == 0.                       # l2_normalize(0) = 0
+    np.testing.assert_allclose(np.linalg.norm(normal[on], axis=1), 1., atol=1e-5)
+    for (raw, g), (p50, p10) in ((reference(True), (0.999, 0.98)), (reference(False), (0.99, 0.8))):
+        want = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+        both = on & (raw > 0)
+        cos = (want[both] * normal[both]).sum(1)
+        assert np.median(cos) > p50 and np.quantile(cos, 0.1) > p10, (np.median(cos), np.quantile(cos, 0.1))
