@@ -7,7 +7,8 @@ outputs (nerfactor/geometry_from_nerf.py:30-391):
 
 For every view of every split writes <out_root>/<view id>/{alpha.png, xyz.npy, xyz.png, normal.npy, normal.png,
 lvis.npy, lvis.png} — what datasets/nerf_shape.py reads.  All marching runs on libnfx:
-  * camera rays: (64 + n_samples_coarse) coarse density samples -> inverse-CDF -> + (64 + n_samples_fine) samples;
+  * camera rays: 64 + n_samples_coarse (= 128) coarse density samples -> inverse-CDF -> + 64 + n_samples_fine (= 192)
+    samples, all 320 evaluated by the fine network;
     density AND its spatial gradient from ONE fused kernel (nfx_nerf_sigma_grad; the reference differentiates through
     the network with GradientTape.batch_jacobian); expected depth / normal from the compositing weights;
   * shadow rays: every (surface point, front-lit light) pair is a ray from lvis_near = 0.1 to lvis_far marched with the
