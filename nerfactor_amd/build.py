@@ -24,6 +24,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
          '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include')]
 if os.environ.get('NFX_ABLATION_BUILD'):  # diagnostic instantiations of the v2 kernel
     FLAGS.append('-DNFX_ABLATION_BUILD')
+if os.environ.get('NFX_EXTRA_DEFS'):  # experiment switches, e.g. NFX_EXTRA_DEFS='-DNFX_V5_BIAS_COPY'
+    FLAGS += os.environ['NFX_EXTRA_DEFS'].split()
 
 
 def _sources():

@@ -40,6 +40,10 @@ int nfx_launch_nerf_mlp_bf16(const float*, const float*, const float*, long long
                              float*, int, int, hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v2(const float*, const float*, const float*, long long, int, const void*,
                                 float*, int, int, hipStream_t);
+int nfx_launch_nerf_mlp_bf16_v5(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                                int, hipStream_t);
+int nfx_launch_nerf_mlp_bf16_v6(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                                int, hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v3(const float*, const float*, const float*, long long, int, const void*,
                                 float*, int, hipStream_t);
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
@@ -142,7 +146,15 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
     if (prec == NFX_PREC_BF16) {
         // 0: 4 waves x 64 points, register-staged weights; 1: 8 waves x 32 points, register-staged;
         // 2: 8 waves x 32 points, LDS-DMA ring + half-tile phase offset between the wave groups
-        const int variant = env_int("NFX_NERF_VARIANT", 1);
+        const int variant = env_int("NFX_NERF_VARIANT", 5);
+        if (variant == 6)  // variant 5 + 3-slot ring, mid-tile weight store, next tile's operands read before the barrier
+            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
+                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
+                              "nerf_mlp_fwd(bf16, v6)");
+        if (variant == 5)  // one wave per SIMD, 64 points per wave, epilogue software-pipelined under the next tile's MFMAs
+            return hip_result(nfx_launch_nerf_mlp_bf16_v5(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
+                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
+                              "nerf_mlp_fwd(bf16, v5)");
         if (variant == 3)  // segment-level LOAD/COMP anti-phase between the two waves of a SIMD, 6-slot DMA ring
             return hip_result(nfx_launch_nerf_mlp_bf16_v3(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
                                                           (hipStream_t)stream),

@@ -1,0 +1,297 @@
+// nerf_mlp_v6.hip — variant 6 of the fused NeRF MLP: variant 5 (one wave per SIMD, 64 points per wave, epilogue of
+// tile i-1 in the shadow of tile i's MFMAs) with the serialisation at the tile boundary removed.  The r01 ablation of
+// variant 5 (profiles/r01/ablation_variant5.log) showed its non-MFMA stream alone takes longer than the MFMAs:
+// ds_write -> s_waitcnt lgkmcnt(0) -> s_barrier -> bias/A ds_read -> first MFMA is ~300 dead cycles per tile.  Here:
+//   * 3-slot LDS ring, chunk k lives in slot k % 3 (78 = 3 x 26 chunks): chunk k+2 is fetched global -> VGPR at the
+//     start of tile k and written to its slot at the END of the tile; nobody waits for those writes (they are a full
+//     tile old when first read),
+//   * the first three A fragments and the bias of tile k+1 are read BEFORE the end-of-tile barrier (chunk k+1 has been
+//     in LDS for a whole tile), so their latency overlaps the tail MFMAs and the barrier,
+//   * the barrier is a bare s_barrier (no lgkmcnt(0) drain).
+// Same blob, bit-identical results to variants 0-5.
+#include "mlp_engine.hpp"
+#include "nerf_layout.hpp"
+
+namespace nfx {
+namespace v6 {
+
+constexpr int kNW = 4, kCT = 2;
+constexpr int kLds = 3 * kSlotBytes + nerf::kBiasFloats * 4;
+constexpr int kNChunks = nerf::kNChunks;  // 78
+
+struct Acc {
+    f32x16 v[kCT];
+};
+struct Pre {
+    bf16x8 a[3];  // first three A fragments of the next tile
+};
+
+template <bool RELU>
+__device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 vv = {v0, v1};
+    b2 pr = __builtin_convertvector(vv, b2);  // one v_cvt_pk_bf16_f32
+    if (RELU) {                               // a negative bf16 is a negative int16: ReLU = one v_pk_max_i16
+        s2 w = __builtin_bit_cast(s2, pr);
+        const s2 z = {0, 0};
+        w = __builtin_elementwise_max(w, z);
+        pr = __builtin_bit_cast(b2, w);
+    }
+    dst[j] = pr[0];
+    dst[j + 1] = pr[1];
+}
+
+template <bool RELU>
+struct EpiB {
+    const Acc& acc;
+    bf16x8 (&lo)[kCT];
+    bf16x8 (&hi)[kCT];
+    template <int R0, int R1>
+    __device__ __forceinline__ void run() {
+#pragma unroll
+        for (int r = R0; r < R1; r += 2)
+#pragma unroll
+            for (int c = 0; c < kCT; ++c) {
+                if (r < 8) cvt_pair<RELU>(acc.v[c][r], acc.v[c][r + 1], lo[c], r);
+                else cvt_pair<RELU>(acc.v[c][r], acc.v[c][r + 1], hi[c], r - 8);
+            }
+    }
+};
+struct EpiNone {
+    template <int R0, int R1>
+    __device__ __forceinline__ void run() {}
+};
+struct EpiSigma {
+    const Acc& acc;
+    float (&sigma)[kCT];
+    template <int R0, int R1>
+    __device__ __forceinline__ void run() {
+        if constexpr (R0 == 0) {
+#pragma unroll
+            for (int c = 0; c < kCT; ++c) sigma[c] = acc.v[c][0];
+        }
+    }
+};
+
+__device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
+#pragma unroll
+    for (int c = 0; c < kCT; ++c) {
+        int hoff = 4 * (lane >> 5);
+        asm volatile("" : "+v"(hoff));  // a second read group per column tile instead of 16 register copies
+        const float* bt = bias_tile + hoff;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+            acc.v[c][4 * g + 0] = v[0];
+            acc.v[c][4 * g + 1] = v[1];
+            acc.v[c][4 * g + 2] = v[2];
+            acc.v[c][4 * g + 3] = v[3];
+        }
+    }
+}
+
+struct Ctx {
+    char* smem;
+    const char* blob;
+    int tid;
+};
+
+// Tile K (global chunk index).  On entry `acc` holds the tile's bias and `pre` its first three A fragments; on exit
+// `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
+// (1 no weight staging, 2 no barrier, 4 no MFMA, 8 no A reads, 64 no bias reads).
+template <int K, int KS1, int KS2, int AB, int KS1A, int KS2A, typename Epi>
+__device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, const bf16x8 (&b1)[KS1A][kCT],
+                                     const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
+    constexpr int KS = KS1 + KS2;
+    constexpr int PIECES = KS >= 16 ? 8 : 4;
+    constexpr int SP = PIECES < KS ? PIECES : KS - 1;  // k-step after which the previous tile's epilogue is complete
+    constexpr int K1 = (K + 1) % kNChunks, K2 = (K + 2) % kNChunks;
+    constexpr int NL2 = nerf::chunk_frags(K2) / 4;
+    const int lane = cx.tid & 63;
+    const char* f0 = cx.smem + (K % 3) * kSlotBytes + lane * 16;
+    Stage<NL2, kNW> st;
+    if constexpr (!(AB & 1)) {
+        // opaque per tile: otherwise the ~300 loop-invariant chunk addresses are hoisted out of the point-tile loop
+        // and spilled (same cure as variant 2)
+        const char* gb = cx.blob;
+        asm volatile("" : "+s"(gb));
+        st.load(reinterpret_cast<const u32x4*>(gb + (size_t)nerf::chunk_frag_offset(K2) * kFragBytes), cx.tid);
+    }
+    bf16x8 abuf[4];
+    abuf[0] = pre.a[0];
+    abuf[1] = pre.a[1];
+    abuf[2] = pre.a[2];
+    static_for<0, KS>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s + 3 < KS && !(AB & 8))
+            abuf[(s + 3) % 4] = *reinterpret_cast<const bf16x8*>(f0 + (s + 3) * kFragBytes);
+        const bf16x8 a = abuf[s % 4];
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
+            if constexpr (AB & 4) {
+                asm volatile("" ::"v"(a), "v"(b));
+            } else {
+                acc.v[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc.v[c], 0, 0, 0);
+            }
+        }
+        if constexpr (s < PIECES) prev.template run<16 * s / PIECES, 16 * (s + 1) / PIECES>();
+        if constexpr (s == SP) {
+            // the other accumulator set is free now: tile K+1's bias goes to its accumulators
+            if constexpr (!(AB & 64)) bias_to_acc(next_bias, lane, acc_next);
+        }
+    });
+    // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
+    // mid-tile stalls on vmcnt, L2 latency under this load exceeds half a tile)
+    if constexpr (!(AB & 1)) st.store(reinterpret_cast<u32x4*>(cx.smem + (K2 % 3) * kSlotBytes), cx.tid);
+    if constexpr (!(AB & 8)) {
+        const char* f1 = cx.smem + (K1 % 3) * kSlotBytes + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(f1 + i * kFragBytes);
+    }
+    if constexpr (!(AB & 2)) asm volatile("s_barrier" ::: "memory");
+    // the whole network is one basic block: without this the scheduler hoists the (invariant) weight loads of later
+    // tiles to the top of the kernel and spills them
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// A Dense layer of NT tiles starting at chunk K0, outputs to bout.  `prev0` = pending epilogue of tile K0-1;
+// `next_bias` = bias of the tile after this layer's last one.  On return the last tile's epilogue is pending.
+template <int K0, int KS1, int KS2, int NT, bool RELU, int AB, int KS1A, int KS2A, int NTA, typename Epi0>
+__device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const float* next_bias,
+                                      const bf16x8 (&b1)[KS1A][kCT], const bf16x8 (&b2)[KS2A][kCT],
+                                      bf16x8 (&bout)[NTA][kCT], Acc (&accs)[2], Pre& pre, Epi0&& prev0) {
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        constexpr int K = K0 + t;
+        const float* nb = t == NT - 1 ? next_bias : bias + 32 * (t + 1);
+        if constexpr (t == 0) {
+            tile<K, KS1, KS2, AB>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
+        } else {
+            EpiB<RELU> e{accs[(K - 1) & 1], bout[2 * (t - 1)], bout[2 * (t - 1) + 1]};
+            tile<K, KS1, KS2, AB>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
+        }
+    });
+}
+
+template <int AB>
+__global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
+    const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
+    int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace nerf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    constexpr int kTilePts = kNW * 32 * kCT;
+    float* bias_lds = reinterpret_cast<float*>(smem + 3 * kSlotBytes);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + kWeightBytes);
+        for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
+    }
+    Ctx cx{smem, blob, tid};
+    Acc accs[2];
+    Pre pre;
+    {   // chunks 0 and 1 -> slots 0 and 1
+        Stage<chunk_frags(0) / 4, kNW> s0;
+        Stage<chunk_frags(1) / 4, kNW> s1;
+        s0.load(reinterpret_cast<const u32x4*>(blob), tid);
+        s1.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(1) * kFragBytes), tid);
+        s0.store(reinterpret_cast<u32x4*>(smem), tid);
+        s1.store(reinterpret_cast<u32x4*>(smem + kSlotBytes), tid);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + i * kFragBytes);
+        bias_to_acc(bias_lds + kBiasL0, lane, accs[0]);
+    }
+    const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
+    for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        bf16x8 pe[4][kCT], pv[2][kCT];
+        long long m[kCT];
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            m[c] = tl * kTilePts + wave * (32 * kCT) + c * 32 + p;
+            const long long mm = m[c] < n_pts ? m[c] : n_pts - 1;
+            const long long ray = mm / n_samples;
+            const float zz = zbuf[mm];
+            float x[3], d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = rayd[ray * 3 + k];
+                x[k] = rayo[ray * 3 + k] + d[k] * zz;
+            }
+            posenc<10, kCT>(x, h, c, pe);
+            posenc<4, kCT>(d, h, c, pv);
+        }
+        bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
+        float sigma[kCT];
+        const float* bl = bias_lds + kBiasL0;
+        auto pend = [&](auto relu_tag, const Acc& a, bf16x8(&lo)[kCT], bf16x8(&hi)[kCT]) {
+            return EpiB<decltype(relu_tag)::value>{a, lo, hi};
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        // chunk index K: L0 0-7, L1-4 8-39, L5 40-47, L6-7 48-63, bottleneck 64-71, sigma 72, rgb0 73-76, rgb1 77;
+        // tile K accumulates in accs[K & 1]
+        layer<0, 4, 0, 8, true, AB>(cx, bl, bl + 256 * 1, pe, pe, ha, accs, pre, EpiNone{});
+        layer<8, 16, 0, 8, true, AB>(cx, bl + 256 * 1, bl + 256 * 2, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<16, 16, 0, 8, true, AB>(cx, bl + 256 * 2, bl + 256 * 3, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<24, 16, 0, 8, true, AB>(cx, bl + 256 * 3, bl + 256 * 4, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<32, 16, 0, 8, true, AB>(cx, bl + 256 * 4, bl + 256 * 5, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<40, 16, 4, 8, true, AB>(cx, bl + 256 * 5, bl + 256 * 6, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<48, 16, 0, 8, true, AB>(cx, bl + 256 * 6, bl + 256 * 7, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<56, 16, 0, 8, true, AB>(cx, bl + 256 * 7, bias_lds + kBiasBott, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        // bottleneck (no activation) hb -> ha; next tile = sigma (bias row 256 of the fused matrix)
+        layer<64, 16, 0, 8, false, AB>(cx, bias_lds + kBiasBott, bias_lds + kBiasBott + 256, hb, pe, ha, accs, pre,
+                                       pend(T{}, accs[1], hb[14], hb[15]));
+        // sigma tile (K = 72 -> accs[0]); pending: last bottleneck tile (accs[1]); next: rgb_out[0] tile 0
+        tile<72, 16, 0, AB>(cx, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
+        {
+            EpiSigma es{accs[0], sigma};
+            layer<73, 16, 2, 4, true, AB>(cx, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
+        }
+        // rgb_out[1] (K = 77 -> accs[1]); pending: last rgb_out[0] tile (K = 76 -> accs[0]); next: L0 tile 0
+        tile<77, 8, 0, AB>(cx, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < kCT; ++c)
+                if (m[c] < n_pts) out[m[c]] = make_float4(accs[1].v[c][0], accs[1].v[c][1], accs[1].v[c][2], sigma[c]);
+        }
+    }
+}
+
+}  // namespace v6
+}  // namespace nfx
+
+template <int AB>
+static int launch_v6(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
+                     const void* blob, float* out, int max_blocks, hipStream_t stream) {
+    using namespace nfx;
+    const int tile_pts = v6::kNW * 32 * v6::kCT;
+    const long long n_tiles = (n_pts + tile_pts - 1) / tile_pts;
+    const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
+    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       v6::kLds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::kLds, stream, rayo, rayd, z, n_pts, n_samples,
+                       (const char*)blob, (float4*)out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                           int n_samples, const void* blob, float* out, int max_blocks, int ablate,
+                                           hipStream_t stream) {
+    if (n_pts <= 0) return 0;
+#ifdef NFX_ABLATION_BUILD
+    switch (ablate) {
+#define NFX_V6_CASE(m) case m: return launch_v6<m>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+        NFX_V6_CASE(1) NFX_V6_CASE(2) NFX_V6_CASE(3) NFX_V6_CASE(4) NFX_V6_CASE(8) NFX_V6_CASE(64) NFX_V6_CASE(7)
+        NFX_V6_CASE(12) NFX_V6_CASE(75)
+#undef NFX_V6_CASE
+        default: break;
+    }
+#endif
+    (void)ablate;
+    return launch_v6<0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+}

@@ -1,5 +1,7 @@
-"""Timing-only ablation of the variant-2 NeRF MLP kernel (needs a build with NFX_ABLATION_BUILD=1).
-Masks: 1 no weight DMA, 2 no barriers, 4 no MFMA, 8 no A ds_reads, 16 no epilogue, 32 no posenc."""
+"""Timing-only ablation of a NeRF MLP kernel variant (needs a build with NFX_ABLATION_BUILD=1).
+Variant 2 masks: 1 no weight DMA, 2 no barriers, 4 no MFMA, 8 no A ds_reads, 16 no epilogue, 32 no posenc.
+Variant 5 masks (ABLATE_VARIANT=5): 1 no weight staging, 2 no barrier, 4 no MFMA, 8 no A ds_reads, 16 no epilogue,
+64 no bias init."""
 import json
 import os
 import sys
@@ -18,9 +20,11 @@ n, s = 640000, 192
 o = torch.randn(n, 3, device=dev)
 d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=1)
 z = torch.sort(torch.rand(n, s, device=dev) * 4 + 2, dim=1)[0]
-os.environ['NFX_NERF_VARIANT'] = '2'
+VARIANT = os.environ.get('ABLATE_VARIANT', '2')
+os.environ['NFX_NERF_VARIANT'] = VARIANT
 res = {}
-for mask in [0, 1, 2, 3, 4, 8, 12, 16, 32, 28, 31]:
+MASKS = [0, 1, 2, 3, 4, 8, 12, 16, 32, 28, 31] if VARIANT == '2' else [0, 1, 2, 3, 4, 8, 16, 64, 80, 83, 7, 12]
+for mask in MASKS:
     os.environ['NFX_ABLATE'] = str(mask)
     ops.nerf_mlp_fwd(o, d, z, blob)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
