@@ -47,7 +47,7 @@ class Dataset:
 
         class _Pipe:
             def __iter__(self_inner):
-                files = sorted(ds.files)
+                files = list(ds.files) if getattr(ds, 'keep_order', False) else sorted(ds.files)
                 if filter_predicate is not None:
                     files = [f for f in files if filter_predicate(f)]
                 if ds.mode == 'train' and not no_shuffle:

@@ -63,3 +63,72 @@ class Model(BaseModel):
         reci = torch.cat((rusink[:, :1] + torch.pi, rusink[:, 1:]), 1)  # reciprocity: phi_d + pi
         brdf_reci = head(body(torch.cat((z, emb(reci)), 1)))
         return brdf, brdf_reci
+
+    # ------------------------------------------------------------------ training of the prior (brdf.py:87-136)
+    def call(self, batch, mode='train'):
+        """batch = (id_, i, envmap_h, ims, spp, rusink[N,3], refl[N,1]) of datasets/brdf_merl.py.  The prior is a
+        128-wide MLP on 18 inputs trained once on the MERL tables, off the per-ray hot path: it runs in torch
+        (autograd) under the same driver / optimizer kernel; NeRFactor evaluates and differentiates the frozen
+        prior through libnfx (nfx_brdf_spec_fwd / nfx_brdf_spec_bwd)."""
+        self._validate_mode(mode)
+        if mode != 'train' and torch.is_grad_enabled():
+            with torch.no_grad():
+                return self.call(batch, mode=mode)
+        id_, i, envmap_h, ims, spp, rusink, refl = batch
+        if mode == 'test' and int(i[0]) == -1:   # novel identity: "<n>_<w1>_<mat1>_<w2>_<mat2>" (merl names may
+            _, w1, rest = id_[0].split('_', 2)    # contain '-', never '_' followed by a float: split from both ends)
+            mat1, w2, mat2 = self._split_interp_id(rest)
+            z = self.latent_code.interp(float(w1), self.brdf_names.index(mat1), float(w2),
+                                        self.brdf_names.index(mat2))
+            z = z.reshape(1, -1).expand(rusink.shape[0], -1)
+        else:
+            z = self.latent_code(i)
+        chunks = [self._eval_brdf_at(z[lo:lo + self.mlp_chunk], rusink[lo:lo + self.mlp_chunk])
+                  for lo in range(0, rusink.shape[0], self.mlp_chunk)]
+        brdf = torch.cat([c[0] for c in chunks], 0)
+        brdf_reci = torch.cat([c[1] for c in chunks], 0)
+        pred = {'brdf': brdf, 'brdf_reci': brdf_reci}
+        gt = {'brdf': refl}
+        to_vis = {'id': id_, 'i': i, 'z': z, 'gt_brdf': refl, 'envmap_h': envmap_h, 'ims': ims, 'spp': spp}
+        to_vis.update(pred)
+        return pred, gt, {}, to_vis
+
+    def _split_interp_id(self, rest):
+        """'<mat1>_<w2>_<mat2>' -> (mat1, w2, mat2) with material names that may themselves contain '_'."""
+        for name in sorted(self.brdf_names, key=len, reverse=True):
+            if rest.startswith(name + '_'):
+                w2, mat2 = rest[len(name) + 1:].split('_', 1)
+                return name, w2, mat2
+        raise ValueError("cannot parse interpolation id %r" % rest)
+
+    def compute_loss(self, pred, gt, **kwargs):
+        transform = self.config.get('DEFAULT', 'loss_transform')
+        if transform.lower() == 'none':
+            f = lambda x: x
+        elif transform == 'log':
+            f = torch.log
+        elif transform == 'divide':
+            f = lambda x: x / (x + 1.)
+        else:
+            raise NotImplementedError(transform)
+        loss = 0
+        for weight, fn in self.wloss:   # the reciprocal Rusinkiewicz coordinates share the ground truth
+            loss = loss + weight * fn(f(gt['brdf']), f(pred['brdf']), **kwargs)
+            loss = loss + weight * fn(f(gt['brdf']), f(pred['brdf_reci']), **kwargs)
+        return loss
+
+    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None, **kwargs):
+        """Raw dump only (the reference renders the BRDF on spheres here, brdf.py:138-220: viewer tooling)."""
+        import os
+        import numpy as np
+        self._validate_mode(mode)
+        if dump_raw_to is None and mode == 'train':
+            return
+        path = dump_raw_to if dump_raw_to is not None else os.path.join(outdir, 'raw.npz')
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        arrays = {k: (v.detach().float().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                  for k, v in data_dict.items() if v is not None}
+        with open(path, 'wb') as h:
+            np.savez(h, **arrays)
+        if mode != 'train':
+            os.makedirs(outdir, exist_ok=True)

@@ -63,3 +63,23 @@ def write_scene(root, imh=16, imw=16, n_train=3, n_val=1, n_test=2, light_h=16, 
             np.save(join(nerf_root, id_, 'normal.npy'), normal.astype(np.float32))
             np.save(join(nerf_root, id_, 'lvis.npy'), lvis.astype(np.float32))
     return data_root, nerf_root
+
+
+def write_merl(root, names=('alum-bronze', 'blue_rubber', 'gold-metallic-paint'), n_rows=4096, seed=0):
+    """Tiny stand-in for the pre-processed MERL tables (datasets/brdf_merl.py layout): <root>/{train,vali}_<name>.npz
+    and one test.npz; reflectance = a smooth positive lobe of the Rusinkiewicz angles, different per material."""
+    rng = np.random.default_rng(seed)
+    os.makedirs(root, exist_ok=True)
+
+    def coords(n):
+        return np.stack((rng.uniform(0, np.pi, n), rng.uniform(0, np.pi / 2, n), rng.uniform(0, np.pi / 2, n)),
+                        1).astype(np.float32)
+    for i, name in enumerate(names):
+        for split, n in (('train', n_rows), ('vali', n_rows // 4)):
+            rus = coords(n)
+            refl = (0.05 + 0.1 * i + (1. + i) * np.exp(-(4. + 2 * i) * rus[:, 1:2] ** 2)
+                    + 0.02 * np.cos(rus[:, 2:3])).astype(np.float32)
+            np.savez(join(root, '%s_%s.npz' % (split, name)), name=name, i=np.int32(i), envmap_h=np.int32(16),
+                     ims=np.int32(128), spp=np.int32(1), rusink=rus, refl=refl)
+    np.savez(join(root, 'test.npz'), envmap_h=np.int32(16), ims=np.int32(128), spp=np.int32(1), rusink=coords(512))
+    return list(names)

@@ -168,3 +168,42 @@ def _gather_worker(rank, world):
 
 def test_shard_and_ragged_gather_two_ranks():
     run_workers(_gather_worker, 2)
+
+
+def test_brdf_merl_dataset_and_prior_model_on_cpu(tmp_path):
+    """datasets/brdf_merl.py + models/brdf.py call / compute_loss (plain torch: the prior is off the hot path)."""
+    from nerfactor_amd.nerfactor.models import get_model_class
+    root = str(tmp_path / 'merl')
+    names = synth_scene.write_merl(root)
+    cfg = make_config('brdf', data_root=root, n_rays_per_step=64)
+    Dataset = get_dataset_class('brdf_merl')
+    tr = Dataset(cfg, 'train', device='cpu')
+    assert tr.brdf_names == sorted(names) and tr.get_n_brdfs() == 3 and tr.bs == 64
+    batches = list(tr.build_pipeline(no_batch=True, seed=0))
+    assert len(batches) == 3 and all(b[5].shape == (64, 3) and b[6].shape == (64, 1) for b in batches)
+    assert sorted(int(b[1][0]) for b in batches) == [0, 1, 2] and batches[0][1].dtype == torch.int32
+    va = next(iter(Dataset(cfg, 'vali', device='cpu').build_pipeline(no_batch=True)))
+    assert va[5].shape == (1024, 3) and va[0][0] == 'alum-bronze'
+    te = Dataset(cfg, 'test', device='cpu', n_iden=3, n_between=3)
+    ids = [b[0][0] for b in te.build_pipeline(no_batch=True, no_shuffle=True)]
+    assert ids[:3] == sorted(names) and len(ids) == 3 + 2 * 3 and ids[3].startswith('000000_1.000000_')
+    torch.manual_seed(0)
+    model = get_model_class('brdf')(cfg)
+    assert model.brdf_names == sorted(names) and model.latent_code.z.shape == (3, 3)
+    pred, gt, kw, to_vis = model(batches[0], mode='train')
+    loss = model.compute_loss(pred, gt, keep_batch=True, **kw)
+    assert loss.shape == (64,) and torch.isfinite(loss).all() and (pred['brdf'] > 0).all()
+    loss.sum().backward()
+    assert model.latent_code._z.grad is not None and float(model.latent_code._z.grad.abs().sum()) > 0
+    # reciprocity branch: phi_d + pi
+    b2, _ = model._eval_brdf_at(model.latent_code(batches[0][1]),
+                                torch.cat((batches[0][5][:, :1] + torch.pi, batches[0][5][:, 1:]), 1))
+    assert torch.allclose(b2, pred['brdf_reci'], atol=1e-6)
+    # interpolated identity at test time: z = w1 z1 + w2 z2
+    tb = [b for b in te.build_pipeline(no_batch=True, no_shuffle=True)][4]
+    assert int(tb[1][0]) == -1
+    _, w1, rest = tb[0][0].split('_', 2)
+    m1, w2, m2 = model._split_interp_id(rest)
+    p2, _, _, vis = model(tb, mode='test')
+    want = float(w1) * model.latent_code.z[model.brdf_names.index(m1)] + float(w2) * model.latent_code.z[model.brdf_names.index(m2)]
+    assert torch.allclose(vis['z'][0], want, atol=1e-6) and p2['brdf'].shape == (512, 1)

@@ -73,12 +73,33 @@ def test_shape_trainvali_resumes(shape_run, scene):
     assert steps == [3, 6, 9]
 
 
+@pytest.fixture(scope='module')
+def brdf_run(nfx_lib, cuda, scene):
+    """The BRDF prior trained by the same driver on a tiny MERL-like table set (stage 0 of the workflow)."""
+    from nerfactor_amd.nerfactor import trainvali
+    merl = join(scene[0], 'merl')
+    synth_scene.write_merl(merl)
+    ov = 'data_root=%s,outroot=%s,epochs=6,ckpt_period=3,vali_period=3,vali_batches=2,n_rays_per_step=512' % (
+        merl, join(scene[0], 'out_brdf'))
+    outdir = trainvali.main(['--config=brdf.ini', '--config_override=' + ov])
+    return outdir
+
+
+def test_brdf_prior_trainvali(brdf_run):
+    losses = [v for _, t, v in _scalars(join(brdf_run, 'summary_train', 'scalars.csv')) if t == 'loss_train']
+    assert len(losses) == 2 and np.isfinite(losses).all() and losses[1] < losses[0]
+    state = torch.load(join(brdf_run, 'checkpoints', 'ckpt-2'), map_location='cpu')
+    assert state['net']['latent_code._z'].shape == (3, 3)
+    assert exists(join(brdf_run, 'vis_vali', 'epoch000000006', 'batch000000001_raw.npz'))
+
+
 @pytest.mark.parametrize('model', ['nerfactor_microfacet', 'nerfactor'])
-def test_joint_optimisation_then_test_driver(shape_run, scene, model):
+def test_joint_optimisation_then_test_driver(shape_run, brdf_run, scene, model):
     from nerfactor_amd.nerfactor import test as test_driver, trainvali
     shape_ckpt = join(shape_run[0], 'checkpoints', 'ckpt-2')
     ov = _override(scene, outroot=join(scene[0], 'out_' + model), epochs=4, ckpt_period=2, vali_period=2,
-                   shape_model_ckpt=shape_ckpt, brdf_model_ckpt='none', test_envmap_dir='', shape_mode='finetune')
+                   shape_model_ckpt=shape_ckpt, brdf_model_ckpt=join(brdf_run, 'checkpoints', 'ckpt-2'),
+                   test_envmap_dir='', shape_mode='finetune')
     outdir = trainvali.main(['--config=%s.ini' % model, '--config_override=' + ov])
     ckpt = join(outdir, 'checkpoints', 'ckpt-2')
     assert exists(ckpt)
@@ -102,6 +123,9 @@ def test_joint_optimisation_then_test_driver(shape_run, scene, model):
     from PIL import Image
     alb = np.asarray(Image.open(join(out2, 'batch000000000', 'pred_albedo.png')))
     assert len(np.unique(alb.reshape(-1, 3), axis=0)) <= 8 + 1           # 7 bands + background
+    if model == 'nerfactor':   # material editing with a latent code of the trained prior
+        out3 = test_driver.main(['--ckpt=' + ckpt, '--tgt_brdf=blue_rubber', '--debug'])
+        assert out3 == out + '_blue_rubber' and exists(join(out3, 'batch000000000', 'pred_rgb.png'))
 
 
 def test_nerf_trainvali_then_nerf_test(nfx_lib, cuda, scene):
