@@ -5,6 +5,8 @@
 // Activations / pre-activation gradients arrive FEATURE-MAJOR ([feature][row], bf16) from the fused
 // backward kernels, so an MFMA operand fragment (one feature x 8 consecutive rows) is one 16-byte
 // global load — no LDS transposition anywhere.
+#include <stdlib.h>
+
 #include "nfx_common.hpp"
 
 namespace nfx {
@@ -96,6 +98,117 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-staged variant for large row counts: one workgroup (4 waves, one per SIMD) owns a [<=256 x <=256] block of dW
+// and a slab of rows; per 64-row chunk the X^T and Z^T tiles (256 features x 128 B each, COALESCED: 8 lanes per
+// feature row) are staged global -> VGPR -> LDS (row pitch 144 B: conflict-free ds_read_b128 across 16 features),
+// double buffered; each wave multiplies its 128 x 128 quadrant (4 x 4 MFMA tiles, 256 accumulator registers) straight
+// from LDS — the feature-major layout already is the A / B fragment layout (one feature x 8 consecutive rows = 16 B).
+// Every operand byte is read from HBM once per 256-wide block instead of twice per 128-wide block through strided
+// 16-byte loads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWlRows = 64;                  // rows per chunk
+constexpr int kWlPitch = 2 * kWlRows + 16;   // bytes per feature row in LDS
+constexpr int kWlTile = 256 * kWlPitch;      // one operand tile
+constexpr int kWlLds = 4 * kWlTile;          // 2 operands x 2 stages = 147456 B
+
+__global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const __bf16* __restrict__ xt, const __bf16* __restrict__ zt,
+                                                           long long ld, int k_in, int n_out, long long rows,
+                                                           long long slab, float* __restrict__ dw,
+                                                           float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const int kb = blockIdx.y * 256, nb = blockIdx.z * 256;
+    const int wk = wave >> 1, wn = wave & 1;
+    const long long r0 = (long long)blockIdx.x * slab;
+    long long r1 = r0 + slab;
+    if (r1 > rows) r1 = rows;
+    const int n_chunks = (int)((r1 - r0 + kWlRows - 1) / kWlRows);
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // staging: piece p = i * 256 + tid -> feature p >> 3, 16-byte part p & 7
+    u32x4 sx[8], sz[8];
+    auto load_chunk = [&](long long row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 256 + tid, f = pp >> 3, part = pp & 7;
+            const long long row = row0 + part * 8;  // rows beyond r1 inside the last chunk: zero (ld is padded, but
+            const bool rok = row < r1;              // another slab's rows must not be counted twice)
+            sx[i] = (kb + f < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + (long long)(kb + f) * ld + row) : zero4;
+            sz[i] = (nb + f < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + (long long)(nb + f) * ld + row) : zero4;
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        char* bx = smem + stage * 2 * kWlTile;
+        char* bz = bx + kWlTile;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 256 + tid, f = pp >> 3, part = pp & 7;
+            *reinterpret_cast<u32x4*>(bx + f * kWlPitch + part * 16) = sx[i];
+            *reinterpret_cast<u32x4*>(bz + f * kWlPitch + part * 16) = sz[i];
+        }
+    };
+    const bool active = kb + 128 * wk < k_in && nb + 128 * wn < n_out;  // wave-uniform: quadrant has real features
+    const bool do_bias = db != nullptr && blockIdx.y == 0 && wk == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    load_chunk(r0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) load_chunk(r0 + (long long)(c + 1) * kWlRows);
+        const char* bx = smem + (c & 1) * 2 * kWlTile + (128 * wk + q) * kWlPitch + h * 16;
+        const char* bz = smem + (c & 1) * 2 * kWlTile + kWlTile + (128 * wn + q) * kWlPitch + h * 16;
+        if (active) {
+#pragma unroll 1
+            for (int s = 0; s < kWlRows / 16; ++s) {   // rolled: 32 fragment registers live, not 128
+                bf16x8 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(bx + 32 * i * kWlPitch + s * 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bz + 32 * j * kWlPitch + s * 32);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bsum[j] += (float)b[j][e];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < n_chunks) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sm = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            const int col = nb + 128 * wn + 32 * j + q;
+            if (h == 0 && col < n_out) atomicAdd(db + col, sm);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = kb + 128 * wk + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = nb + 128 * wn + 32 * j + q;
+                if (row < k_in && col < n_out) atomicAdd(dw + (long long)row * n_out + col, acc[i][j][r]);
+            }
+}
+
 }  // namespace nfx
 
 extern "C" {
@@ -109,6 +222,33 @@ int nfx_launch_amsgrad(float* p, const float* g, float* m, float* v, float* vhat
 int nfx_launch_wgrad(const void* xt, const void* zt, long long ld, int k_in, int n_out, long long rows,
                      float* dw, float* db, hipStream_t st) {
     if (rows <= 0) return 0;
+    const char* env = getenv("NFX_WGRAD_LDS");
+    const bool use_lds = env ? atoi(env) != 0 : rows >= 16384;
+    if (use_lds) {
+        // slab: a multiple of 64 rows.  Every slab ends with 64 K fp32 atomics per 256 x 256 block (L2 atomic rate
+        // ~200 G/s measured), so fewer, longer slabs beat more parallelism: r01 sweep on the NeRF step 64/128/256/512
+        // slabs -> 4.88/4.22/4.47/4.95 ms, on the microfacet step 128/256 -> 7.89/7.24 ms  =>  >= 2048 rows per slab
+        // but at least 64 slabs, at most one per CU (NFX_WGRAD_SLABS overrides the slab count)
+        const char* es = getenv("NFX_WGRAD_SLABS");
+        long long slab;
+        if (es && atoi(es) > 0) {
+            slab = rows / atoi(es);
+        } else {
+            slab = rows / 256 > 2048 ? rows / 256 : 2048;
+            const long long cap = rows / 64 > 256 ? rows / 64 : 256;
+            if (slab > cap) slab = cap;
+        }
+        slab = (slab + 63) / 64 * 64;
+        if (slab < 256) slab = 256;
+        const unsigned gx = (unsigned)((rows + slab - 1) / slab);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::wgrad_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, nfx::kWlLds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nfx::wgrad_lds_kernel, dim3(gx, (unsigned)((k_in + 255) / 256), (unsigned)((n_out + 255) / 256)),
+                           dim3(256), nfx::kWlLds, st, (const __bf16*)xt, (const __bf16*)zt, ld, k_in, n_out, rows, slab,
+                           dw, db);
+        return (int)hipGetLastError();
+    }
     long long slab = 1024;
     const unsigned gx = (unsigned)((rows + slab - 1) / slab);
     const unsigned gy = (unsigned)((k_in + 127) / 128);

@@ -83,8 +83,10 @@ def test_mlp128_xyz_backward_vs_autograd(nfx_lib, cuda, out_dim, act, scale, n):
     _check_grads([d / 2 for d in dks], [k.grad for k in ks], 'dkernel x2', 0.2)
 
 
-def test_lvis_backward_vs_autograd(nfx_lib, cuda):
+@pytest.mark.parametrize("wgrad_lds", ["0", "1"])
+def test_lvis_backward_vs_autograd(nfx_lib, cuda, monkeypatch, wgrad_lds):
     from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)   # both weight-gradient GEMM kernels (train.hip)
     layers, out = net128(90, 90, 1)
     n = 21
     rng, lxyz, _, xyz, _, _ = scene(n, 91)
@@ -469,9 +471,11 @@ def test_composite_backward_vs_autograd(nfx_lib, cuda, n, s, white_bg, use_noise
     np.testing.assert_allclose(rgb, out.detach().numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("wgrad_lds", ["0", "1"])
 @pytest.mark.parametrize("n_rays,s", [(40, 7), (3, 192)])
-def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s):
+def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s, monkeypatch, wgrad_lds):
     from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)
     from tests import common
     net = common.nerf_nets(seed=5, opaque=False)[0]
     ks_np, bs_np = common.nerf_layers(net)
