@@ -50,10 +50,15 @@ def parse_args(argv=None):
 
 
 def latest_checkpoint(trained_nerf):
-    ckpts = [p for p in glob.glob(join(trained_nerf, 'checkpoints', 'ckpt-*')) if re.fullmatch(r'ckpt-\d+', basename(p))]
-    if not ckpts:
+    """Highest-numbered checkpoint prefix: a torch file `ckpt-N` of this framework or a TensorFlow `ckpt-N.index`."""
+    found = set()
+    for p in glob.glob(join(trained_nerf, 'checkpoints', 'ckpt-*')):
+        m = re.fullmatch(r'(ckpt-\d+)(\.index)?', basename(p))
+        if m:
+            found.add(join(trained_nerf, 'checkpoints', m.group(1)))
+    if not found:
         raise FileNotFoundError("no checkpoint under %s" % join(trained_nerf, 'checkpoints'))
-    return max(ckpts, key=lambda p: int(p.rsplit('-', 1)[1]))
+    return max(found, key=lambda p: int(p.rsplit('-', 1)[1]))
 
 
 def _march(model, rayo, rayd, near, far, n_coarse, n_fine, lin_in_disp, bbox, want_normal, rays_per_call):

@@ -3,6 +3,7 @@ nerfactor/util/io.py:36-45, 48-52)."""
 from configparser import ConfigParser
 from os.path import exists
 
+import numpy as np
 import torch
 
 
@@ -19,13 +20,25 @@ def read_config(path):
 
 
 def restore_model(model, ckpt_path, strict=False):
-    """Load a torch checkpoint written by this framework's trainvali ({'net': state_dict, ...})."""
+    """Load a checkpoint into `model`: a torch file written by this framework's trainvali ({'net': state_dict, ...}),
+    or — when `<ckpt_path>.index` exists — a TensorFlow checkpoint of the reference (util/tf_ckpt.py; Keras kernels are
+    already [in, out], the layout of networks.layers.Dense)."""
     model.register_trainable()
-    state = torch.load(ckpt_path, map_location='cpu')
-    state = state.get('net', state)
+    from . import tf_ckpt
+    if tf_ckpt.is_tf_checkpoint(ckpt_path):
+        state = {k: torch.from_numpy(np.ascontiguousarray(v))
+                 for k, v in tf_ckpt.to_state_dict(tf_ckpt.load_tensors(ckpt_path)).items()}
+        own = model.state_dict()
+        for k in list(state):          # scalars / shape mismatches are reported, not silently reshaped
+            if k in own and tuple(own[k].shape) != tuple(state[k].shape):
+                raise ValueError("checkpoint tensor %s has shape %s, the model expects %s" % (
+                    k, tuple(state[k].shape), tuple(own[k].shape)))
+    else:
+        state = torch.load(ckpt_path, map_location='cpu')
+        state = state.get('net', state)
     missing, unexpected = model.load_state_dict(state, strict=strict)
     return missing, unexpected
 
 
 def ckpt_available(path):
-    return bool(path) and path.lower() not in ('none', 'null', '') and exists(path)
+    return bool(path) and path.lower() not in ('none', 'null', '') and (exists(path) or exists(path + '.index'))
