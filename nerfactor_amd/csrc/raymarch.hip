@@ -234,15 +234,21 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(
 
     for (int i = lane; i < nc; i += 64) zall[i] = zr[i];
     for (int i = lane; i < ncdf; i += 64) mid[i] = 0.5f * (zr[i + 1] + zr[i]);  // nerf.py:140
+    // util/math.py:72-76 with the oracle's summation order (sequential, left to right); only the two running sums are
+    // serial — the nb divisions run across the wave
+    float denom = 0.f;
     if (lane == 0) {
-        // util/math.py:72-76, sequential left-to-right sums (matches the oracle's order)
-        float denom = 0.f;
         for (int i = 0; i < nb; ++i) denom += wr[1 + i];
         denom += 1e-5f;
+    }
+    denom = __shfl(denom, 0, 64);
+    for (int i = lane; i < nb; i += 64) cdf[1 + i] = wr[1 + i] / denom;   // pdf, turned into the cdf in place below
+    __syncthreads();
+    if (lane == 0) {
         float acc = 0.f;
         cdf[0] = 0.f;
         for (int i = 0; i < nb; ++i) {
-            acc += wr[1 + i] / denom;
+            acc += cdf[1 + i];
             cdf[1 + i] = acc;
         }
     }
@@ -266,7 +272,35 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(
         zall[nc + i] = vb + t * (va - vb);
     }
     __syncthreads();
-    // tf.sort(concat(z_coarse, z_fine)) by ranking: exact for any input order, ties by index.
+    // tf.sort(concat(z_coarse, z_fine)): rank of every element, ties by position in the concatenation.
+    if (u == nullptr) {
+        // deterministic sampling: both lists are already sorted (z_coarse always is; the inverse cdf is monotone in u),
+        // so a rank is an index plus one binary search in the other list — same permutation as the general path
+        const float* zc = zall;
+        const float* zf = zall + nc;
+        for (int i = lane; i < ntot; i += 64) {
+            const float v = zall[i];
+            int lo = 0, hi, rank;
+            if (i < nc) {           // coarse element: fine elements strictly below it come first
+                hi = nf;
+                while (lo < hi) {
+                    const int m = (lo + hi) >> 1;
+                    if (zf[m] < v) lo = m + 1; else hi = m;
+                }
+                rank = i + lo;
+            } else {                // fine element: coarse elements below or EQUAL come first (lower index wins ties)
+                hi = nc;
+                while (lo < hi) {
+                    const int m = (lo + hi) >> 1;
+                    if (zc[m] <= v) lo = m + 1; else hi = m;
+                }
+                rank = (i - nc) + lo;
+            }
+            if (active) z_all[ray * ntot + rank] = v;
+        }
+        return;
+    }
+    // random u: z_fine is unsorted -> all-pairs ranking, exact for any input order
     for (int i = lane; i < ntot; i += 64) {
         const float v = zall[i];
         int rank = 0;
