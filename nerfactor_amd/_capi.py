@@ -10,6 +10,8 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnfx.so')
+if os.environ.get('NFX_LIB_PATH'):   # experiment builds (python -m nerfactor_amd.build --out ...)
+    LIB_PATH = os.environ['NFX_LIB_PATH']
 
 PREC_BF16, PREC_FP32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3

@@ -53,7 +53,12 @@ def _compile(src, force, verbose):
     return obj, True
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None):
+    """out: alternative .so path (experiment builds with NFX_EXTRA_DEFS; objects go to build/obj_<name>)."""
+    global OBJDIR, LIB
+    if out:
+        LIB = os.path.abspath(out)
+        OBJDIR = os.path.join(ROOT, 'build', 'obj_' + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
@@ -71,5 +76,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    path = build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv)
+    out = sys.argv[sys.argv.index('--out') + 1] if '--out' in sys.argv else None
+    path = build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv, out=out)
     print(path)

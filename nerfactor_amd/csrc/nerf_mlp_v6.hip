@@ -151,10 +151,10 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
 #pragma unroll
         for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(f1 + i * kFragBytes);
     }
+    // (a __builtin_amdgcn_sched_barrier(0) here costs 4 %: it stops the scheduler from draining the tail MFMAs of this
+    //  tile behind the barrier; the per-tile laundering of the blob base above is what keeps the weight addresses
+    //  from being hoisted)
     if constexpr (!(AB & 2)) asm volatile("s_barrier" ::: "memory");
-    // the whole network is one basic block: without this the scheduler hoists the (invariant) weight loads of later
-    // tiles to the top of the kernel and spills them
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 // A Dense layer of NT tiles starting at chunk K0, outputs to bout.  `prev0` = pending epilogue of tile K0-1;
