@@ -15,8 +15,12 @@
  *   - all floating-point tensors are fp32, C-contiguous, ray-major, exactly the
  *     layouts of the reference's flattened batch tuples
  *     (nerfactor/datasets/nerf.py:96-104, nerfactor/datasets/nerf_shape.py:72-82).
- *   - `prec`: NFX_PREC_BF16 = bf16 operands / fp32 accumulate on the MFMA path,
- *     NFX_PREC_FP32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   - `prec`: NFX_PREC_BF16 = bf16 operands / fp32 accumulate on the MFMA path;
+ *     NFX_PREC_FP32 = fp32-class accuracy on the same pipe: every operand a bf16 hi/lo
+ *     pair (16 significant bits), three MFMAs per product, fp32 accumulate (stated
+ *     tolerance 2e-4 on rgb; ~5x the v_mfma_f32_32x32x2_f32 peak).  Built for the NeRF
+ *     MLP forward (nfx_nerf_pack_weights / nfx_nerf_mlp_fwd); every other entry point
+ *     returns NFX_ENOSUP for it.
  *   - re-entrant: no global mutable state; concurrent calls on different streams
  *     are legal.
  */

@@ -42,6 +42,8 @@ int nfx_launch_nerf_mlp_bf16_v2(const float*, const float*, const float*, long l
                                 float*, int, int, hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v5(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                 int, hipStream_t);
+int nfx_launch_nerf_mlp_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                           hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v6(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                 int, hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v3(const float*, const float*, const float*, long long, int, const void*,
@@ -75,21 +77,15 @@ int nfx_env_int(const char* name, int dflt) {
 // --------------------------------------------------------------------------- packing
 size_t nfx_nerf_packed_bytes(int prec) {
     if (prec == NFX_PREC_BF16) return nfx::nerf::kBlobBytes;
+    if (prec == NFX_PREC_FP32) return (size_t)nfx::nerf::kBlobBytes + nfx::nerf::kWeightBytes;  // hi | lo | biases
     return 0;
 }
 
-int nfx_nerf_pack_weights(const float* const kernels[12], const float* const biases[12], int prec,
-                          void* blob, size_t blob_bytes) {
+// bf16 fragments of the 12 layers into w (nerf::kWeightBytes), biases into b (nerf::kBiasFloats)
+static int pack_nerf_fragments(const float* const kernels[12], const float* const biases[12], uint8_t* w0, float* b) {
     using namespace nfx;
     using namespace nfx::pack;
-    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_weights: null argument");
-    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_weights: layer %d null", i);
-    if (prec == NFX_PREC_FP32) return fail(NFX_ENOSUP, "nfx_nerf_pack_weights: fp32 path not built yet");
-    REQUIRE(prec == NFX_PREC_BF16, "nfx_nerf_pack_weights: bad prec %d", prec);
-    REQUIRE(blob_bytes >= nfx_nerf_packed_bytes(prec), "nfx_nerf_pack_weights: blob too small (%zu < %zu)",
-            blob_bytes, nfx_nerf_packed_bytes(prec));
-    uint8_t* w = static_cast<uint8_t*>(blob);
-    float* b = reinterpret_cast<float*>(w + nerf::kWeightBytes);
+    uint8_t* w = w0;
     const Seg pe_xyz{kPosEnc, 10, 0, nullptr};
     const Seg hid256{kHidden, 256, 0, nullptr};
     // enc[0]: posenc(xyz) 63 -> 256
@@ -112,7 +108,43 @@ int nfx_nerf_pack_weights(const float* const kernels[12], const float* const bia
     // rgb_out[1]: 128 -> 3
     const Seg hid128{kHidden, 128, 0, nullptr};
     w += pack_layer_bf16({hid128}, {{kernels[11], biases[11], 3}}, 1, 8, w, b + nerf::kBiasRgb1);
-    if (w != static_cast<uint8_t*>(blob) + nerf::kWeightBytes)
+    return w == w0 + nerf::kWeightBytes ? NFX_OK : NFX_EINVAL;
+}
+
+int nfx_nerf_pack_weights(const float* const kernels[12], const float* const biases[12], int prec,
+                          void* blob, size_t blob_bytes) {
+    using namespace nfx;
+    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_weights: null argument");
+    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_weights: layer %d null", i);
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_nerf_pack_weights: bad prec %d", prec);
+    REQUIRE(blob_bytes >= nfx_nerf_packed_bytes(prec), "nfx_nerf_pack_weights: blob too small (%zu < %zu)",
+            blob_bytes, nfx_nerf_packed_bytes(prec));
+    uint8_t* w = static_cast<uint8_t*>(blob);
+    if (prec == NFX_PREC_BF16) {
+        if (pack_nerf_fragments(kernels, biases, w, reinterpret_cast<float*>(w + nerf::kWeightBytes)))
+            return fail(NFX_EINVAL, "nfx_nerf_pack_weights: internal layout mismatch");
+        return NFX_OK;
+    }
+    // NFX_PREC_FP32 (nerf_mlp_x3.hip): [fragments of hi = bf16(W) | fragments of lo = bf16(W - hi) | fp32 biases]
+    static const int rows[12] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
+    static const int cols[12] = {256, 256, 256, 256, 256, 256, 256, 256, 1, 256, 128, 3};
+    std::vector<std::vector<float>> lo(12);
+    const float* lo_ptr[12];
+    for (int i = 0; i < 12; ++i) {
+        const size_t n = (size_t)rows[i] * cols[i];
+        lo[i].resize(n);
+        for (size_t k = 0; k < n; ++k) {
+            const uint32_t bits = (uint32_t)pack::f32_to_bf16_rne(kernels[i][k]) << 16;
+            float hi;
+            memcpy(&hi, &bits, 4);
+            lo[i][k] = kernels[i][k] - hi;
+        }
+        lo_ptr[i] = lo[i].data();
+    }
+    float* b = reinterpret_cast<float*>(w + 2 * (size_t)nerf::kWeightBytes);
+    std::vector<float> sink(nerf::kBiasFloats);
+    if (pack_nerf_fragments(kernels, biases, w, b) ||
+        pack_nerf_fragments(lo_ptr, biases, w + nerf::kWeightBytes, sink.data()))
         return fail(NFX_EINVAL, "nfx_nerf_pack_weights: internal layout mismatch");
     return NFX_OK;
 }
@@ -167,7 +199,9 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
                                                    blocks, (hipStream_t)stream),
                           "nerf_mlp_fwd(bf16)");
     }
-    if (prec == NFX_PREC_FP32) return fail(NFX_ENOSUP, "nfx_nerf_mlp_fwd: fp32 path not built yet");
+    if (prec == NFX_PREC_FP32)  // split-bf16 operands, 3 MFMAs per product (nerf_mlp_x3.hip)
+        return hip_result(nfx_launch_nerf_mlp_x3(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, (hipStream_t)stream),
+                          "nerf_mlp_fwd(fp32 via 3 x bf16)");
     return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: bad prec %d", prec);
 }
 

@@ -89,12 +89,19 @@ class Model(torch.nn.Module):
             return hit[1]
         if dev.type != 'cuda':
             raise RuntimeError("libnfx blobs live on the GPU: move the model with .to('cuda') first")
-        packer = self._packers.get(key)
+        if key not in self._packers:
+            nk = len(tensors) // 2
+            try:
+                self._packers[key] = ops.DevicePacker(pack_fn, [t.shape for t in tensors[:nk]],
+                                                      [t.shape for t in tensors[nk:]])
+            except ops.NotAGather:
+                self._packers[key] = None   # e.g. the split hi/lo fragments of precision = fp32: packed on the host
+        packer = self._packers[key]
         if packer is None:
             nk = len(tensors) // 2
-            packer = ops.DevicePacker(pack_fn, [t.shape for t in tensors[:nk]], [t.shape for t in tensors[nk:]])
-            self._packers[key] = packer
-        blob = packer.pack(list(tensors))
+            blob = pack_fn(list(tensors[:nk]), list(tensors[nk:])).to(dev)
+        else:
+            blob = packer.pack(list(tensors))
         self._blobs[key] = (versions, blob)
         return blob
 

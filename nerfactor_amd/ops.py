@@ -58,6 +58,10 @@ def _pack(fn_bytes, fn_pack, kernels, biases, extra):
 
 
 
+class NotAGather(_capi.NfxError):
+    """The packer's output is not a pure gather of the parameters (no device re-pack map exists for it)."""
+
+
 class DevicePacker:
     """Re-packs one network's blob ON THE DEVICE (nfx_pack_gather) from an index map derived once from the host
     packer `pack_fn(kernels, biases) -> uint8 blob`: the packer is run on arrays holding the base-256 digits (+1)
@@ -81,7 +85,7 @@ class DevicePacker:
         is_bias = probe == np.uint32(0x3f800008)                  # "bias" = any parameter stored as fp32
         halves_ok = np.isin(probe & np.uint32(0xffff), (0, 0x3f80)) & np.isin(probe >> np.uint32(16), (0, 0x3f80))
         if not (is_bias | halves_ok).all() or not is_bias.any():
-            raise _capi.NfxError("DevicePacker: cannot separate the fp32 and bf16 regions of the blob")
+            raise NotAGather("DevicePacker: cannot separate the fp32 and bf16 regions of the blob")
         self.n_words = int(is_bias.size)
         self.nbytes = self.n_words * 4
         lo = np.zeros(self.n_words, np.int64)

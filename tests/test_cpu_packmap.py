@@ -56,3 +56,26 @@ def test_gather_map_reproduces_host_packer(nfx_lib, name):
     if name != 'nerf_geom':   # (its fp32 region also carries the sigma_out kernel)
         assert (m[fp32, 0][m[fp32, 0] >= 0] >= n_kernel).all()         # fp32 words gather biases only
     assert m[~fp32].max() < n_kernel                                   # bf16 pairs gather kernels only
+
+
+def test_fp32_split_blob_is_hi_lo_of_the_bf16_blob(nfx_lib):
+    """NFX_PREC_FP32 blob = [bf16(W) fragments | bf16(W - bf16(W)) fragments | fp32 biases]; not a gather."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(5)
+    ks = [rng.normal(size=s).astype(np.float32) for s in ops.NERF_LAYER_SHAPES]
+    bs = [rng.normal(size=(s[1],)).astype(np.float32) for s in ops.NERF_LAYER_SHAPES]
+    b16 = ops.pack_nerf_weights(ks, bs, 'bf16').numpy()
+    f32 = ops.pack_nerf_weights(ks, bs, 'fp32').numpy()
+    nw = 1272 * 1024
+    assert f32.size == b16.size + nw
+    assert np.array_equal(f32[:nw], b16[:nw]) and np.array_equal(f32[2 * nw:], b16[nw:])
+    hi = (b16[:nw].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    lo = (f32[nw:2 * nw].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    # every packed weight is reproduced to 2^-16 relative by hi + lo
+    ks_lo = [k - (_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).reshape(k.shape) for k in ks]
+    want_lo = ops.pack_nerf_weights(ks_lo, bs, 'bf16').numpy()[:nw]
+    assert np.array_equal(f32[nw:2 * nw], want_lo)
+    assert np.abs(lo).max() <= 2. ** -8 * np.abs(hi).max()
+    with pytest.raises(ops.NotAGather):
+        ops.DevicePacker(lambda k, b: ops.pack_nerf_weights(k, b, 'fp32'), ops.NERF_LAYER_SHAPES,
+                         [(s[1],) for s in ops.NERF_LAYER_SHAPES])
