@@ -360,3 +360,45 @@ def test_sigma_gradient_normals_vs_autograd(nfx_lib, cuda):
         both = on & (raw > 0)
         cos = (want[both] * normal[both]).sum(1)
         assert np.median(cos) > p50 and np.quantile(cos, 0.1) > p10, (np.median(cos), np.quantile(cos, 0.1))
+
+
+def test_geometry_extraction_vs_oracle(nfx_lib, cuda):
+    """geometry_from_nerf's two stages through models.nerf + libnfx against oracle/geometry_ref.py on a tiny view."""
+    from nerfactor_amd.nerfactor import geometry_from_nerf as G
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from oracle import geometry_ref, nerfactor_ref
+    nets = common.nerf_nets(seed=3)
+    cfg = make_config('nerf')
+    model = get_model_class('nerf')(cfg).to(cuda)
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for name in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            for layer, (k, b) in zip(model.net[pref + name].layers, net[name]):
+                layer.kernel.data.copy_(torch.from_numpy(k))
+                layer.bias.data.copy_(torch.from_numpy(b))
+    rayo, rayd = common.camera_rays(10, 10)
+    rayd = nerf_ref.l2_normalize(rayd, 1, 1e-12)
+    with torch.no_grad():
+        occu, depth, normal = (t.cpu().numpy() for t in G.compute_depth_and_normal(model, dev(rayo, cuda), dev(rayd, cuda), cfg))
+    w_occu, w_depth, w_normal = geometry_ref.compute_depth_and_normal(rayo, rayd, nets[0], nets[1])
+    assert occu.shape == (100,) and normal.shape == (100, 3)
+    stable = np.abs(w_occu - 0.5) > 0.0        # every ray; the last-sample discontinuity shows up as isolated outliers
+    assert np.quantile(np.abs(occu - w_occu)[stable], 0.9) <= 3e-2
+    assert np.quantile(np.abs(depth - w_depth), 0.9) <= 5e-2
+    hit = w_occu > 0.5
+    assert hit.sum() > 20
+    # expected normals of a random-weight NeRF are short (per-sample normals cancel along the ray), so the test is on
+    # the vector difference, not on a direction (per-sample directions: test_sigma_gradient_normals_vs_autograd)
+    dn = np.abs(normal - w_normal).max(1)
+    assert np.quantile(dn[hit], 0.9) <= 3e-2 and np.median(dn[hit]) <= 1e-2, (np.quantile(dn[hit], 0.9), np.median(dn[hit]))
+    # light visibility from the ORACLE's surface points / normals, 4 x 8 lights
+    lxyz, _ = nerfactor_ref.gen_light_xyz(4, 8)
+    lxyz = lxyz.reshape(-1, 3).astype(np.float32)
+    surf = (rayo + rayd * w_depth[:, None])[hit][:12].astype(np.float32)
+    nrm = w_normal[hit][:12].astype(np.float32)
+    with torch.no_grad():
+        lvis = G.compute_light_visibility(model, dev(surf, cuda), dev(nrm, cuda), cfg, lvis_far=1., light_h=4).cpu().numpy()
+    w_lvis = geometry_ref.compute_light_visibility(surf, nrm, lxyz, nets[0], nets[1])
+    assert lvis.shape == w_lvis.shape == (12, 32)
+    assert np.array_equal(lvis == 0, w_lvis == 0) or np.mean((lvis == 0) != (w_lvis == 0)) < 0.02   # same front-lit set
+    assert np.quantile(np.abs(lvis - w_lvis), 0.9) <= 4e-2 and np.abs(lvis - w_lvis).mean() <= 2e-2
