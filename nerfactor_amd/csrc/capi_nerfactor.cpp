@@ -25,6 +25,10 @@ extern "C" {
 int nfx_launch_mlp128_xyz(const float*, long long, float, const void*, int, int, float, float, float*, int,
                           hipStream_t);
 int nfx_launch_lvis_pre(const float*, long long, float, const void*, float*, int, hipStream_t);
+int nfx_launch_brdf_spec_v2(const float*, const float*, const float*, const float*, int, const float*, int,
+                            const void*, long long, float*, int, int, hipStream_t);
+int nfx_launch_lvis_v2(const float*, long long, const float*, int, const float*, const void*, float*, int, int,
+                       hipStream_t);
 int nfx_launch_lvis(const float*, long long, const float*, int, const float*, const void*, float*, int,
                     hipStream_t);
 int nfx_launch_brdf_spec(const float*, const float*, const float*, const float*, int, const float*, int,
@@ -158,6 +162,13 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
     float* pre = static_cast<float*>(workspace);
     int rc = nfx_hip_result(nfx_launch_lvis_pre(xyz, n, xyz_scale, b, pre, blocks, (hipStream_t)stream), "lvis_pre");
     if (rc) return rc;
+    // NFX_LVIS_VARIANT: 0 = 8 waves x 32 rows with streamed weights (mlp128.hip); 2 | 3 | 4 = network resident in LDS,
+    // one wave per SIMD with that many 32-row column tiles (lvis_v2.hip)
+    const int variant = nfx_env_int("NFX_LVIS_VARIANT", 4);
+    if (variant >= 2 && variant <= 4)
+        return nfx_hip_result(nfx_launch_lvis_v2(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis,
+                                                 variant, blocks, (hipStream_t)stream),
+                              "lvis_fwd(v2)");
     return nfx_hip_result(
         nfx_launch_lvis(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis, blocks,
                         (hipStream_t)stream),
@@ -176,6 +187,11 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
     if (n == 0) return NFX_OK;
     REQUIRE(xyz && cam && normal && z && lxyz && blob && spec, "nfx_brdf_spec_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_fwd: blob must be 16-byte aligned");
+    const int variant = nfx_env_int("NFX_BRDF_VARIANT", 3);   // as NFX_LVIS_VARIANT
+    if (variant >= 2 && variant <= 4)
+        return nfx_hip_result(nfx_launch_brdf_spec_v2(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, variant,
+                                                      nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                              "brdf_spec_fwd(v2)");
     return nfx_hip_result(nfx_launch_brdf_spec(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
                                                nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
                           "brdf_spec_fwd");

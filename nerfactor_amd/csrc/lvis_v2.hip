@@ -1,0 +1,330 @@
+// lvis_v2.hip — the two (point, light)-row MLPs of NeRFactor, light visibility (shape.py:213-237) and the learned-BRDF
+// specular term (nerfactor.py:413-458), with the whole network RESIDENT in LDS.
+// The width-128 net is 136 fragments = 136 KiB (+ 2 KiB of biases): it fits the 160 KiB of a CU, so unlike the NeRF
+// kernels there is no weight stream, no staging and — after the one-time load — no barrier at all.  One wave per
+// SIMD, CT column tiles of 32 (point, light) rows per wave: one A fragment read from LDS feeds CT MFMAs (CT = 4:
+// a quarter of the LDS traffic of the 8 x 32 kernel in mlp128.hip), the epilogue of tile i-1 (accvgpr_read +
+// v_cvt_pk_bf16_f32 + v_pk_max_i16 per pair) is issued in the shadow of tile i's MFMAs, the per-point
+// pre-activations of layers 0 and 3 (lvis_pre_kernel) are fetched into the free accumulator set one tile ahead.
+// MODE 0 = light visibility, MODE 1 = learned BRDF (same chunk geometry: 2 input k-steps, skip into layer 3; biases
+// instead of per-point pre-activations, softplus on front-lit rows).  Same blobs and arithmetic as lvis_kernel /
+// brdf_spec_kernel of mlp128.hip: bit-identical outputs.
+#include "geom.hpp"
+#include "mlp128_layout.hpp"
+#include "mlp_engine.hpp"
+
+namespace nfx {
+namespace lv2 {
+
+constexpr int kNW = 4;
+constexpr int kLds = m128::kMainWeightBytes + m128::kMainBiasFloats * 4;
+// fragment offset of chunk K: L0 0-3 (4 frags), L1 4-7, L2 8-11 (8 frags), L3 12-15 (12 frags), out 16
+constexpr int frag_off(int k) { return k < 4 ? 4 * k : k < 12 ? 16 + 8 * (k - 4) : k < 16 ? 80 + 12 * (k - 12) : 128; }
+
+template <int CT>
+struct Acc {
+    f32x16 v[CT];
+};
+struct Pre {
+    bf16x8 a[2];  // first two A fragments of the next tile (layer 0 has only two k-steps)
+};
+
+template <bool RELU>
+__device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 vv = {v0, v1};
+    b2 pr = __builtin_convertvector(vv, b2);
+    if (RELU) {
+        s2 w = __builtin_bit_cast(s2, pr);
+        const s2 z = {0, 0};
+        w = __builtin_elementwise_max(w, z);
+        pr = __builtin_bit_cast(b2, w);
+    }
+    dst[j] = pr[0];
+    dst[j + 1] = pr[1];
+}
+
+template <int CT>
+struct EpiB {   // ReLU layer output -> next B operand (k-steps lo / hi), in register-pair pieces
+    const Acc<CT>& acc;
+    bf16x8 (&lo)[CT];
+    bf16x8 (&hi)[CT];
+    template <int R0, int R1>
+    __device__ __forceinline__ void run() {
+#pragma unroll
+        for (int r = R0; r < R1; r += 2)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (r < 8) cvt_pair<true>(acc.v[c][r], acc.v[c][r + 1], lo[c], r);
+                else cvt_pair<true>(acc.v[c][r], acc.v[c][r + 1], hi[c], r - 8);
+            }
+    }
+};
+struct EpiNone {
+    template <int R0, int R1>
+    __device__ __forceinline__ void run() {}
+};
+
+// accumulator initialisers for the NEXT tile
+struct InitBias {   // broadcast LDS reads of the bias tile
+    const float* bias_tile;
+    template <int CT>
+    __device__ __forceinline__ void operator()(int lane, Acc<CT>& acc) const {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            int hoff = 4 * (lane >> 5);
+            asm volatile("" : "+v"(hoff));
+            const float* bt = bias_tile + hoff;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+                acc.v[c][4 * g + 0] = v[0];
+                acc.v[c][4 * g + 1] = v[1];
+                acc.v[c][4 * g + 2] = v[2];
+                acc.v[c][4 * g + 3] = v[3];
+            }
+        }
+    }
+};
+template <int CT>
+struct InitPre {    // per-point pre-activation rows from global memory (one point per column tile)
+    const float* const (&pre_pt)[CT];
+    int off;        // 32 t (+128 for layer 3)
+    __device__ __forceinline__ void operator()(int lane, Acc<CT>& acc) const {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float* bt = pre_pt[c] + off + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+                acc.v[c][4 * g + 0] = v[0];
+                acc.v[c][4 * g + 1] = v[1];
+                acc.v[c][4 * g + 2] = v[2];
+                acc.v[c][4 * g + 3] = v[3];
+            }
+        }
+    }
+};
+
+// Tile K: acc (already initialised) += W_K^T [b1 ; b2]; the previous tile's epilogue `prev` is spread over the
+// k-steps; once it is complete `init_next` fills acc_next for tile K+1; the first A fragments of chunk K1 are read
+// at the end.  No barrier: the weights never change.
+template <int K, int K1, int KS1, int KS2, int CT, int KS1A, int KS2A, typename Epi, typename Init>
+__device__ __forceinline__ void tile(const char* wlds, int lane, const bf16x8 (&b1)[KS1A][CT],
+                                     const bf16x8 (&b2)[KS2A][CT], Acc<CT>& acc, Acc<CT>& acc_next, Pre& pre,
+                                     Epi&& prev, Init&& init_next) {
+    constexpr int KS = KS1 + KS2;
+    // 16 accumulator registers of the previous tile in PIECES groups; at a layer boundary its outputs are this tile's
+    // LAST input k-steps, so the epilogue must be complete well before them: 4 pieces (done after k-step 3) for 8-10
+    // k-steps
+    constexpr int PIECES = KS >= 4 ? 4 : KS;
+    static_assert(16 % PIECES == 0 && (16 / PIECES) % 2 == 0, "pairs");
+    const char* f0 = wlds + frag_off(K) * kFragBytes + lane * 16;
+    bf16x8 abuf[4];
+    abuf[0] = pre.a[0];
+    abuf[1] = pre.a[1];
+    if constexpr (KS > 2) abuf[2] = *reinterpret_cast<const bf16x8*>(f0 + 2 * kFragBytes);
+    static_for<0, KS>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s + 3 < KS) abuf[(s + 3) % 4] = *reinterpret_cast<const bf16x8*>(f0 + (s + 3) * kFragBytes);
+        const bf16x8 a = abuf[s % 4];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
+            acc.v[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc.v[c], 0, 0, 0);
+        }
+        if constexpr (s < PIECES) prev.template run<16 * s / PIECES, 16 * (s + 1) / PIECES>();
+        if constexpr (s == PIECES - 1) {
+            // keep the next tile's initial loads BEHIND the epilogue that frees their destination registers (hoisted
+            // above it they need 16 CT temporaries and spill at CT = 4)
+            __builtin_amdgcn_sched_barrier(0);
+            init_next(lane, acc_next);
+        }
+    });
+    const char* f1 = wlds + frag_off(K1) * kFragBytes + lane * 16;
+    pre.a[0] = *reinterpret_cast<const bf16x8*>(f1);
+    pre.a[1] = *reinterpret_cast<const bf16x8*>(f1 + kFragBytes);
+}
+
+struct Args {
+    const float* xyz;      // [n,3] points (lvis: the points the directions are taken from)
+    const float* lxyz;     // [L,3]
+    const float* pre;      // MODE 0: [n,256] per-point pre-activations
+    const float* cam;      // MODE 1: [n,3]
+    const float* normal;   // MODE 1: [n,3]
+    const float* z;        // MODE 1: [n,z_dim]
+    int z_dim;
+    long long n;
+    int n_lights;
+    const char* blob;
+    float* out;            // [n,L]
+};
+
+template <int CT, int MODE>
+__global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace m128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    {   // the whole network, once
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.blob);
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        for (int i = tid; i < kLds / 16; i += kNW * 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    const char* wlds = smem;
+    const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
+    constexpr int kTileRows = kNW * CT * 32;
+    const int n_lights = a.n_lights;
+    const long long n_rows = a.n * n_lights;
+    const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        bf16x8 pl[2][CT];
+        const float* pre_pt[CT];
+        long long m0[CT];
+        bool front[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            m0[c] = tl * kTileRows + (wave * CT + c) * 32;   // 32 consecutive lights of one point (n_lights % 32 == 0)
+            const long long mc = m0[c] < n_rows ? m0[c] : 0;
+            const long long pt = mc / n_lights;
+            const int l = (int)(mc % n_lights) + p;
+            float x[3], lp[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                x[k] = a.xyz[pt * 3 + k];
+                lp[k] = a.lxyz[l * 3 + k];
+            }
+            if constexpr (MODE == 0) {
+                float d[3], sq = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    d[k] = lp[k] - x[k];   // _calc_ldir (shape.py:128-131): normalize(lxyz[l] - x), eps 1e-6
+                    sq += d[k] * d[k];
+                }
+                const float inv = 1.0f / sqrtf(fmaxf(sq, 1e-6f));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d[k] *= inv;
+                posenc<4, CT>(d, h, c, pl);
+                pre_pt[c] = a.pre + pt * 256;
+                front[c] = true;
+            } else {
+                float cm[3], nr[3], ldir[3], vdir[3], rot[9], ll[3], vl[3], rus[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    cm[k] = a.cam[pt * 3 + k];
+                    nr[k] = a.normal[pt * 3 + k];
+                }
+                dir_to(lp, x, ldir);          // shape.py:128-131
+                dir_to(cm, x, vdir);          // shape.py:137-140
+                world2local(nr, rot);         // util/geom.py:119-149
+                mat3_apply(rot, ldir, ll);    // nerfactor.py:418-419
+                mat3_apply(rot, vdir, vl);
+                dir2rusink(ll, vl, rus);      // util/geom.py:152-192 with a = light, b = view
+                front[c] = ll[2] > 0.0f;      // nerfactor.py:429-432
+                // B operand slots of brdf_input_slots() (capi_nerfactor.cpp)
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) v[q] = sin_shifted(rus[q % 3] * (float)(1 << (q / 3)), h);
+                v[6] = h ? rus[2] : rus[0];
+                v[7] = h ? a.z[pt * a.z_dim] : rus[1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 1 + 2 * j + h;
+                    v[8 + j] = i < a.z_dim ? a.z[pt * a.z_dim + i] : 0.0f;
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+                pre_pt[c] = nullptr;
+            }
+        }
+        bf16x8 ha[8][CT], hb[8][CT];
+        Acc<CT> accs[2];
+        Pre pre;
+        // initial accumulators of the layer-0 / layer-3 tiles: per-point pre-activations (MODE 0) or plain biases
+        auto init03 = [&](int off_pre, int off_bias) {
+            return [=, &pre_pt](int ln, Acc<CT>& ac) {
+                if constexpr (MODE == 0) InitPre<CT>{pre_pt, off_pre}(ln, ac);
+                else InitBias{bias_lds + off_bias}(ln, ac);
+            };
+        };
+        {   // tile 0's operands
+            const char* f0 = wlds + lane * 16;
+            pre.a[0] = *reinterpret_cast<const bf16x8*>(f0);
+            pre.a[1] = *reinterpret_cast<const bf16x8*>(f0 + kFragBytes);
+            init03(0, 0)(lane, accs[0]);
+        }
+        // chunk K accumulates in accs[K & 1]; layers: L0 K 0-3 (pl -> ha), L1 4-7 (ha -> hb), L2 8-11 (hb -> ha),
+        // L3 12-15 ([ha ; pl] -> hb), out 16 (hb -> activation)
+#define NFX_LV2_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
+        tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
+#define NFX_LV2_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
+        NFX_LV2_TILE(0, 2, 0, pl, pl, EpiNone{}, init03(32, 32));
+        NFX_LV2_TILE(1, 2, 0, pl, pl, NFX_LV2_EPI(0, ha, 0), init03(64, 64));
+        NFX_LV2_TILE(2, 2, 0, pl, pl, NFX_LV2_EPI(1, ha, 1), init03(96, 96));
+        NFX_LV2_TILE(3, 2, 0, pl, pl, NFX_LV2_EPI(2, ha, 2), (InitBias{bias_lds + 128}));
+        NFX_LV2_TILE(4, 8, 0, ha, pl, NFX_LV2_EPI(3, ha, 3), (InitBias{bias_lds + 128 + 32}));
+        NFX_LV2_TILE(5, 8, 0, ha, pl, NFX_LV2_EPI(4, hb, 0), (InitBias{bias_lds + 128 + 64}));
+        NFX_LV2_TILE(6, 8, 0, ha, pl, NFX_LV2_EPI(5, hb, 1), (InitBias{bias_lds + 128 + 96}));
+        NFX_LV2_TILE(7, 8, 0, ha, pl, NFX_LV2_EPI(6, hb, 2), (InitBias{bias_lds + 256}));
+        NFX_LV2_TILE(8, 8, 0, hb, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
+        NFX_LV2_TILE(9, 8, 0, hb, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
+        NFX_LV2_TILE(10, 8, 0, hb, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
+        NFX_LV2_TILE(11, 8, 0, hb, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));
+        NFX_LV2_TILE(12, 8, 2, ha, pl, NFX_LV2_EPI(11, ha, 3), init03(128 + 32, 384 + 32));
+        NFX_LV2_TILE(13, 8, 2, ha, pl, NFX_LV2_EPI(12, hb, 0), init03(128 + 64, 384 + 64));
+        NFX_LV2_TILE(14, 8, 2, ha, pl, NFX_LV2_EPI(13, hb, 1), init03(128 + 96, 384 + 96));
+        NFX_LV2_TILE(15, 8, 2, ha, pl, NFX_LV2_EPI(14, hb, 2), (InitBias{bias_lds + 512}));
+        NFX_LV2_TILE(16, 8, 0, hb, pl, NFX_LV2_EPI(15, hb, 3), [](int, Acc<CT>&) {});
+#undef NFX_LV2_TILE
+#undef NFX_LV2_EPI
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                if (m0[c] < n_rows) {
+                    const float o = accs[0].v[c][0];
+                    if constexpr (MODE == 0) a.out[m0[c] + p] = sigmoidf(o);             // shape.py:93 sigmoid out
+                    else a.out[m0[c] + p] = front[c] ? softplusf(o) : 0.0f;             // brdf.py:65, back-lit rows 0
+                }
+        }
+    }
+}
+
+}  // namespace lv2
+}  // namespace nfx
+
+template <int CT, int MODE>
+static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
+    using namespace nfx;
+    const long long rows = a.n * a.n_lights, tile_rows = lv2::kNW * CT * 32;
+    const long long tiles = (rows + tile_rows - 1) / tile_rows;
+    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
+    auto k = lv2::resident128_kernel<CT, MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lv2::kLds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(lv2::kNW * 64), lv2::kLds, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nfx_launch_lvis_v2(const float* xyz, long long n, const float* lxyz, int n_lights, const float* pre,
+                                  const void* blob_main, float* lvis, int ct, int max_blocks, hipStream_t st) {
+    if (n <= 0) return 0;
+    nfx::lv2::Args a{xyz, lxyz, pre, nullptr, nullptr, nullptr, 0, n, n_lights, (const char*)blob_main, lvis};
+    if (ct == 2) return launch_res<2, 0>(a, max_blocks, st);
+    if (ct == 3) return launch_res<3, 0>(a, max_blocks, st);
+    return launch_res<4, 0>(a, max_blocks, st);
+}
+
+extern "C" int nfx_launch_brdf_spec_v2(const float* xyz, const float* cam, const float* normal, const float* z,
+                                       int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
+                                       float* spec, int ct, int max_blocks, hipStream_t st) {
+    if (n <= 0) return 0;
+    nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
+    if (ct == 2) return launch_res<2, 1>(a, max_blocks, st);
+    if (ct == 3) return launch_res<3, 1>(a, max_blocks, st);
+    return launch_res<4, 1>(a, max_blocks, st);
+}
