@@ -28,6 +28,15 @@ if os.environ.get('NFX_EXTRA_DEFS'):  # experiment switches, e.g. NFX_EXTRA_DEFS
     FLAGS += os.environ['NFX_EXTRA_DEFS'].split()
 
 
+# Per-source extra flags.  -amdgpu-mfma-vgpr-form: MFMA accumulators in ArchVGPRs (the epilogue reads them without
+# v_accvgpr_read; activations move to AccVGPRs, which MFMA takes as B operands).  NFX_VGPR_FORM_FILES overrides the list.
+VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
+# r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554)
+PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v5.hip': VGPR_FORM}
+if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
+    PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
 
@@ -44,7 +53,7 @@ def _compile(src, force, verbose):
     newest = max(os.path.getmtime(spath), _headers_mtime())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-x', 'hip', '-c', spath, '-o', obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + ['-x', 'hip', '-c', spath, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
