@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
         // ---- forward input (same slots as brdf_spec_kernel)
         float v[16];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) v[q] = sin_shifted(rus[q % 3].v * (float)(1 << (q / 3)), h);
+        for (int q = 0; q < 6; ++q) v[q] = sin_shifted_small(rus[q % 3].v * (float)(1 << (q / 3)), h);
         v[6] = h ? rus[2].v : rus[0].v;
         v[7] = h ? z[pt * z_dim] : rus[1].v;
 #pragma unroll

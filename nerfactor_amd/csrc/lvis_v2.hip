@@ -13,11 +13,18 @@
 #include "mlp128_layout.hpp"
 #include "mlp_engine.hpp"
 
+#ifdef NFX_LV2_TIMING
+__device__ unsigned long long nfx_lv2_times[64];   // s_memtime before each tile of one wave (diagnostic build)
+#endif
+
 namespace nfx {
 namespace lv2 {
 
 constexpr int kNW = 4;
-constexpr int kLds = m128::kMainWeightBytes + m128::kMainBiasFloats * 4;
+constexpr int kLdsNet = m128::kMainWeightBytes + m128::kMainBiasFloats * 4;
+// MODE 0 additionally parks the per-point pre-activation rows of the wave's column tiles (CT x 1 KiB per wave), copied
+// one point tile ahead: the layer-0 / layer-3 accumulators then start from LDS like a bias, not from a global load
+constexpr int kLds = kLdsNet + kNW * 4 * 1024;
 // fragment offset of chunk K: L0 0-3 (4 frags), L1 4-7, L2 8-11 (8 frags), L3 12-15 (12 frags), out 16
 constexpr int frag_off(int k) { return k < 4 ? 4 * k : k < 12 ? 16 + 8 * (k - 4) : k < 16 ? 80 + 12 * (k - 12) : 128; }
 
@@ -89,13 +96,13 @@ struct InitBias {   // broadcast LDS reads of the bias tile
     }
 };
 template <int CT>
-struct InitPre {    // per-point pre-activation rows from global memory (one point per column tile)
-    const float* const (&pre_pt)[CT];
-    int off;        // 32 t (+128 for layer 3)
+struct InitPre {    // per-point pre-activation rows parked in the wave's LDS area (one point per column tile)
+    const float* rows;   // [CT][256] floats
+    int off;             // 32 t (+128 for layer 3)
     __device__ __forceinline__ void operator()(int lane, Acc<CT>& acc) const {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            const float* bt = pre_pt[c] + off + 4 * (lane >> 5);
+            const float* bt = rows + c * 256 + off + 4 * (lane >> 5);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
@@ -135,6 +142,11 @@ __device__ __forceinline__ void tile(const char* wlds, int lane, const bf16x8 (&
             const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
             acc.v[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc.v[c], 0, 0, 0);
         }
+#ifdef NFX_LV2_TIMING
+        if constexpr (K == 8 || K == 9) {
+            if (blockIdx.x == 7 && threadIdx.x == 0) nfx_lv2_times[(K == 8 ? 20 : 32) + s] = __builtin_readcyclecounter();
+        }
+#endif
         if constexpr (s < PIECES) prev.template run<16 * s / PIECES, 16 * (s + 1) / PIECES>();
         if constexpr (s == PIECES - 1) {
             // keep the next tile's initial loads BEHIND the epilogue that frees their destination registers (hoisted
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
     {   // the whole network, once
         const u32x4* src = reinterpret_cast<const u32x4*>(a.blob);
         u32x4* dst = reinterpret_cast<u32x4*>(smem);
-        for (int i = tid; i < kLds / 16; i += kNW * 64) dst[i] = src[i];
+        for (int i = tid; i < kLdsNet / 16; i += kNW * 64) dst[i] = src[i];
         __syncthreads();
     }
     const char* wlds = smem;
@@ -179,9 +191,35 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
     const int n_lights = a.n_lights;
     const long long n_rows = a.n * n_lights;
     const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    float* pre_rows = reinterpret_cast<float*>(smem + kLdsNet) + wave * 1024;   // this wave's [CT][256] floats
+    // point of column tile c in point tile t (clamped), and the copy of its pre row: one 16-byte piece per lane
+    auto point_of = [&](long long t, int c) {
+        const long long m = t * kTileRows + (wave * CT + c) * 32;
+        return (m < n_rows ? m : 0) / n_lights;
+    };
+    u32x4 stage[CT];
+    auto fetch_rows = [&](long long t) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                stage[c] = *reinterpret_cast<const u32x4*>(a.pre + point_of(t, c) * 256 + lane * 4);
+        }
+    };
+    auto park_rows = [&]() {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) *reinterpret_cast<u32x4*>(pre_rows + c * 256 + lane * 4) = stage[c];
+        }
+    };
+    fetch_rows(blockIdx.x);
+    park_rows();
     for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         bf16x8 pl[2][CT];
         const float* pre_pt[CT];
+        {   // next point tile's rows: in flight during this whole tile, parked after the last layer-3 initialiser
+            const long long tn = tl + gridDim.x;
+            fetch_rows(tn < n_tiles ? tn : tl);
+        }
         long long m0[CT];
         bool front[CT];
 #pragma unroll
@@ -226,7 +264,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
                 // B operand slots of brdf_input_slots() (capi_nerfactor.cpp)
                 float v[16];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) v[q] = sin_shifted(rus[q % 3] * (float)(1 << (q / 3)), h);
+                for (int q = 0; q < 6; ++q) v[q] = sin_shifted_small(rus[q % 3] * (float)(1 << (q / 3)), h);   // angles <= pi, 2 bands
                 v[6] = h ? rus[2] : rus[0];
                 v[7] = h ? a.z[pt * a.z_dim] : rus[1];
 #pragma unroll
@@ -246,8 +284,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
         Pre pre;
         // initial accumulators of the layer-0 / layer-3 tiles: per-point pre-activations (MODE 0) or plain biases
         auto init03 = [&](int off_pre, int off_bias) {
-            return [=, &pre_pt](int ln, Acc<CT>& ac) {
-                if constexpr (MODE == 0) InitPre<CT>{pre_pt, off_pre}(ln, ac);
+            return [=](int ln, Acc<CT>& ac) {
+                if constexpr (MODE == 0) InitPre<CT>{pre_rows, off_pre}(ln, ac);
                 else InitBias{bias_lds + off_bias}(ln, ac);
             };
         };
@@ -259,7 +297,13 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
         }
         // chunk K accumulates in accs[K & 1]; layers: L0 K 0-3 (pl -> ha), L1 4-7 (ha -> hb), L2 8-11 (hb -> ha),
         // L3 12-15 ([ha ; pl] -> hb), out 16 (hb -> activation)
+#ifdef NFX_LV2_TIMING
+#define NFX_LV2_STAMP(K) if (blockIdx.x == 7 && tid == 0 && tl == blockIdx.x + 4 * (long long)gridDim.x) nfx_lv2_times[K] = __builtin_readcyclecounter();
+#else
+#define NFX_LV2_STAMP(K)
+#endif
 #define NFX_LV2_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
+        NFX_LV2_STAMP(K) \
         tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
 #define NFX_LV2_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
         NFX_LV2_TILE(0, 2, 0, pl, pl, EpiNone{}, init03(32, 32));
@@ -278,9 +322,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
         NFX_LV2_TILE(13, 8, 2, ha, pl, NFX_LV2_EPI(12, hb, 0), init03(128 + 64, 384 + 64));
         NFX_LV2_TILE(14, 8, 2, ha, pl, NFX_LV2_EPI(13, hb, 1), init03(128 + 96, 384 + 96));
         NFX_LV2_TILE(15, 8, 2, ha, pl, NFX_LV2_EPI(14, hb, 2), (InitBias{bias_lds + 512}));
+        park_rows();   // the rows of THIS point tile were last read by tile 14's initialiser (LDS ops of a wave are in order)
         NFX_LV2_TILE(16, 8, 0, hb, pl, NFX_LV2_EPI(15, hb, 3), [](int, Acc<CT>&) {});
 #undef NFX_LV2_TILE
 #undef NFX_LV2_EPI
+        NFX_LV2_STAMP(17)
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
@@ -328,3 +374,9 @@ extern "C" int nfx_launch_brdf_spec_v2(const float* xyz, const float* cam, const
     if (ct == 3) return launch_res<3, 1>(a, max_blocks, st);
     return launch_res<4, 1>(a, max_blocks, st);
 }
+
+#ifdef NFX_LV2_TIMING
+extern "C" int nfx_debug_lv2_times(unsigned long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(nfx_lv2_times), sizeof(unsigned long long) * 64);
+}
+#endif

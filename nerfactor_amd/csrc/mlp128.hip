@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void brdf_spec_kernel(
         // B operand
         float v[16];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) v[q] = sin_shifted(rus[q % 3] * (float)(1 << (q / 3)), h);
+        for (int q = 0; q < 6; ++q) v[q] = sin_shifted_small(rus[q % 3] * (float)(1 << (q / 3)), h);   // angles <= pi, 2 bands
         v[6] = h ? rus[2] : rus[0];
         v[7] = h ? z[pt * z_dim] : rus[1];
 #pragma unroll

@@ -297,7 +297,9 @@ __device__ __forceinline__ void posenc(const float (&x)[3], int h, int c,
     for (int q = 0; q < NQ; ++q) {
         if (q < 3 * L) {
             const float freq = (float)(1 << (q / 3));
-            v[q] = sin_shifted(x[q % 3] * freq, h);
+            // L <= 4 encodes unit vectors (|arg| <= 8): v_sin_f32 / v_cos_f32, 7e-7 abs error measured on [-8.5, 8.5];
+            // the 10-band encoder of positions (|arg| up to ~3000) needs the Cody-Waite reduction
+            v[q] = L <= 4 ? sin_shifted_small(x[q % 3] * freq, h) : sin_shifted(x[q % 3] * freq, h);
         } else if (q == 3 * L) {
             v[q] = h ? x[2] : x[0];
         } else if (q == 3 * L + 1) {

@@ -23,7 +23,7 @@ __global__ void selftest_mfma_kernel(const float* A, const float* B, float* D) {
 }
 __global__ void selftest_sincos_kernel(const float* in, long long n, int which, float* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = sin_shifted(in[i], which);
+    if (i < n) out[i] = which < 2 ? sin_shifted(in[i], which) : sin_shifted_small(in[i], which - 2);   // 2, 3: v_sin / v_cos
 }
 }  // namespace nfx
 
