@@ -37,6 +37,24 @@ __device__ __forceinline__ float sin_shifted(float y, int shift) {
     return (q & 2) ? -v : v;
 }
 
+// Both sin(y) and cos(y) from one Cody-Waite reduction (same polynomials as sin_shifted).
+__device__ __forceinline__ void sincos_cw(float y, float& sn, float& cs) {
+    const float n = rintf(y * 0.6366197466850281f);
+    float r = fmaf(n, -1.5707963705062866f, y);
+    r = fmaf(n, 4.371138828673793e-08f, r);
+    const int q = (int)n;
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, r2, -1.6666654611e-1f);
+    ps = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, r2, 4.166664568298827e-2f);
+    pc = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // Hardware sine/cosine (v_sin_f32 / v_cos_f32 take revolutions) for SMALL arguments: the 4-band encoders of unit
 // vectors (|y| <= 8) and the 2-band encoder of Rusinkiewicz angles.  3 instructions instead of ~25.
 __device__ __forceinline__ float sin_shifted_small(float y, int shift) {
