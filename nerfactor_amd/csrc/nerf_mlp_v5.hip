@@ -11,6 +11,11 @@
 #include "mlp_engine.hpp"
 #include "nerf_layout.hpp"
 
+#ifdef NFX_V5_TIMING
+__device__ unsigned long long nfx_v5_times[128];   // cycle stamp before each tile of one wave (diagnostic build)
+__device__ int nfx_v5_idx = -1;
+#endif
+
 namespace nfx {
 namespace v5 {
 
@@ -104,6 +109,9 @@ __device__ __forceinline__ void tile_pipe(WStream& ws, int tid, const float* bia
     // k-steps are multiplied -> 8 pieces for 16+ k-steps, 4 pieces otherwise
     constexpr int PIECES = KS >= 16 ? 8 : 4;
     const int lane = tid & 63;
+#ifdef NFX_V5_TIMING
+    if (blockIdx.x == 7 && tid == 0 && nfx_v5_idx >= 0 && nfx_v5_idx < 128) nfx_v5_times[nfx_v5_idx++] = __builtin_readcyclecounter();
+#endif
     with_chunk_ab<AB, NL_NEXT, NW>(ws, tid, [&](const char* chunk) {
         const char* f0 = chunk + lane * 16;
         // accumulators start from the bias.  NFX_V5_BIAS_COPY: one broadcast read group + register copies for the
@@ -124,19 +132,27 @@ __device__ __forceinline__ void tile_pipe(WStream& ws, int tid, const float* bia
                 acc.v[c][4 * g + 3] = v[3];
             }
         }
-        // A fragments two k-steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
-        bf16x8 abuf[3];
+        // A fragments kADepth k-steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency; a
+        // k-step is only 64 MFMA cycles here, the LDS round trip under load several times that)
+#ifndef NFX_V5_ADEPTH
+#define NFX_V5_ADEPTH 2
+#endif
+        constexpr int kADepth = NFX_V5_ADEPTH, kABuf = kADepth + 1;
+        bf16x8 abuf[kABuf];
         if constexpr (AB & 8) {
-            abuf[0] = abuf[1] = abuf[2] = b1[0][0];
+#pragma unroll
+            for (int i = 0; i < kABuf; ++i) abuf[i] = b1[0][0];
         } else {
-            abuf[0] = *reinterpret_cast<const bf16x8*>(f0);
-            if constexpr (KS > 1) abuf[1] = *reinterpret_cast<const bf16x8*>(f0 + kFragBytes);
+            static_for<0, kADepth>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (i < KS) abuf[i] = *reinterpret_cast<const bf16x8*>(f0 + i * kFragBytes);
+            });
         }
         static_for<0, KS>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            if constexpr (s + 2 < KS && !(AB & 8))
-                abuf[(s + 2) % 3] = *reinterpret_cast<const bf16x8*>(f0 + (s + 2) * kFragBytes);
-            const bf16x8 a = abuf[s % 3];
+            if constexpr (s + kADepth < KS && !(AB & 8))
+                abuf[(s + kADepth) % kABuf] = *reinterpret_cast<const bf16x8*>(f0 + (s + kADepth) * kFragBytes);
+            const bf16x8 a = abuf[s % kABuf];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
@@ -208,6 +224,9 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_mlp_bf16_v5_kernel(
             posenc<10, CT>(x, h, c, pe);
             posenc<4, CT>(d, h, c, pv);
         }
+#ifdef NFX_V5_TIMING
+        if (blockIdx.x == 7 && tid == 0) nfx_v5_idx = (tile == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
+#endif
         bf16x8 ha[16][CT], hb[16][CT], r0[8][CT];
         Acc<CT> accs[2];
         float sigma[CT];
@@ -283,3 +302,9 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v5(const float* rayo, const float* rayd,
     (void)ablate;
     return launch_v5<2, 4, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }
+
+#ifdef NFX_V5_TIMING
+extern "C" int nfx_debug_v5_times(unsigned long long* host128) {
+    return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(nfx_v5_times), sizeof(unsigned long long) * 128);
+}
+#endif
