@@ -292,3 +292,29 @@ def test_nerfactor_train_mode_loss_vs_oracle(nfx_lib, cuda):
     # jittered predictions are close to, but not equal to, the clean ones
     d = (pred['albedo'] - loss_kwargs['albedo_jitter']).abs().max().item()
     assert 0 < d < 0.5
+
+
+def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
+    """Streamed 8 x 32 kernels (mlp128.hip) and the LDS-resident ones with 2 / 3 / 4 column tiles (lvis_v2.hip) compute
+    the same arithmetic in the same order: light visibility and the learned-BRDF specular term must agree bit for bit,
+    also on a row count that is not a multiple of any tile size."""
+    from nerfactor_amd import ops
+    n = 333
+    rng, lxyz, _, xyz, cam, normal = scene(n, 77)
+    layers, out = net128(31, 90, 1)
+    blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
+    outs = {}
+    for v in ("0", "2", "3", "4"):
+        monkeypatch.setenv("NFX_LVIS_VARIANT", v)
+        outs[v] = ops.lvis_fwd(dev(xyz, cuda), dev(lxyz, cuda), blob, xyz_scale=0.9)
+    for v in ("2", "3", "4"):
+        assert torch.equal(outs["0"], outs[v]), "lvis variant " + v
+    layers, out = net128(43, 18, 1)
+    blob = pack(layers, out, nfx_lib.IN_Z_RUSINK, 1, cuda, z_dim=3)
+    z = rng.normal(size=(n, 3)).astype(np.float32)
+    outs = {}
+    for v in ("0", "2", "3", "4"):
+        monkeypatch.setenv("NFX_BRDF_VARIANT", v)
+        outs[v] = ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda), dev(lxyz, cuda), blob)
+    for v in ("2", "3", "4"):
+        assert torch.equal(outs["0"], outs[v]), "brdf variant " + v
