@@ -16,7 +16,12 @@ namespace nfx {
 namespace v6 {
 
 constexpr int kNW = 4, kCT = 2;
-constexpr int kLds = 3 * kSlotBytes + nerf::kBiasFloats * 4;
+// ring size / fetch distance: register-staged 3 slots, chunk K+2 fetched during tile K; LDS-DMA 6 slots (78 = 6 x 13),
+// chunk K+3 issued during tile K and awaited at the end of tile K: when tile K+1 prefetches the head of chunk K+2
+// before ITS barrier, every wave's pieces of that chunk have been behind a barrier already
+template <int DMA> constexpr int ring_of = DMA ? 6 : 3;
+template <int DMA> constexpr int dist_of = DMA ? 3 : 2;
+template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
 constexpr int kNChunks = nerf::kNChunks;  // 78
 
 struct Acc {
@@ -96,23 +101,57 @@ struct Ctx {
     char* smem;
     const char* blob;
     int tid;
+    unsigned smem_lds;   // LDS byte address of smem (for M0)
+    int wave;            // wave-uniform
 };
+
+// DMA = 1: the weight stream goes global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
+// staging, no ds_write, no lgkmcnt drain); completion is tracked with counted s_waitcnt vmcnt (the pieces of chunk
+// K+2 must have landed before the barrier that ends tile K+1, those of chunk K+3 may still be in flight).
+__device__ __forceinline__ void dma_piece(unsigned lane_off, const char* gbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gbase), "s"(lds_dst)
+        : "memory");
+}
+template <int K>
+__device__ __forceinline__ void dma_chunk(const Ctx& cx) {
+    constexpr int n = nerf::chunk_frags(K) / kNW;   // 1-KiB pieces per wave
+    unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
+    unsigned lds = cx.smem_lds;
+    asm volatile("" : "+s"(base), "+s"(lds));       // per tile: keeps the piece addresses out of the loop preheader
+    const int piece0 = cx.wave * n;
+    const char* g = reinterpret_cast<const char*>(base) + (size_t)nerf::chunk_frag_offset(K) * kFragBytes + piece0 * 1024;
+    const unsigned l = lds + (K % 6) * kSlotBytes + piece0 * 1024;
+    const unsigned lane_off = (cx.tid & 63) * 16;
+#pragma unroll
+    for (int i = 0; i < n; ++i) dma_piece(lane_off, g + i * 1024, l + i * 1024);
+}
 
 // Tile K (global chunk index).  On entry `acc` holds the tile's bias and `pre` its first three A fragments; on exit
 // `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
 // (1 no weight staging, 2 no barrier, 4 no MFMA, 8 no A reads, 64 no bias reads).
-template <int K, int KS1, int KS2, int AB, int KS1A, int KS2A, typename Epi>
+template <int K, int KS1, int KS2, int AB, int DMA, int KS1A, int KS2A, typename Epi>
 __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, const bf16x8 (&b1)[KS1A][kCT],
                                      const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
     constexpr int KS = KS1 + KS2;
     constexpr int PIECES = KS >= 16 ? 8 : 4;
     constexpr int SP = PIECES < KS ? PIECES : KS - 1;  // k-step after which the previous tile's epilogue is complete
-    constexpr int K1 = (K + 1) % kNChunks, K2 = (K + 2) % kNChunks;
+    constexpr int R = ring_of<DMA>;
+    constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
     constexpr int NL2 = nerf::chunk_frags(K2) / 4;
     const int lane = cx.tid & 63;
-    const char* f0 = cx.smem + (K % 3) * kSlotBytes + lane * 16;
-    Stage<NL2, kNW> st;
-    if constexpr (!(AB & 1)) {
+    const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
+    Stage<DMA ? 1 : NL2, kNW> st;
+    if constexpr (DMA && !(AB & 1)) {
+        dma_chunk<K2>(cx);
+    } else if constexpr (!(AB & 1)) {
         // opaque per tile: otherwise the ~300 loop-invariant chunk addresses are hoisted out of the point-tile loop
         // and spilled (same cure as variant 2)
         const char* gb = cx.blob;
@@ -145,9 +184,15 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
     });
     // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
     // mid-tile stalls on vmcnt, L2 latency under this load exceeds half a tile)
-    if constexpr (!(AB & 1)) st.store(reinterpret_cast<u32x4*>(cx.smem + (K2 % 3) * kSlotBytes), cx.tid);
+    if constexpr (DMA && !(AB & 1)) {
+        // the chunk issued one tile ago must be complete before the barrier; this tile's pieces may stay in flight
+        constexpr int kInFlight = nerf::chunk_frags(K2) / kNW;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
+    } else if constexpr (!(AB & 1)) {
+        st.store(reinterpret_cast<u32x4*>(cx.smem + (K2 % R) * kSlotBytes), cx.tid);
+    }
     if constexpr (!(AB & 8)) {
-        const char* f1 = cx.smem + (K1 % 3) * kSlotBytes + lane * 16;
+        const char* f1 = cx.smem + (K1 % R) * kSlotBytes + lane * 16;
 #pragma unroll
         for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(f1 + i * kFragBytes);
     }
@@ -159,7 +204,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
 
 // A Dense layer of NT tiles starting at chunk K0, outputs to bout.  `prev0` = pending epilogue of tile K0-1;
 // `next_bias` = bias of the tile after this layer's last one.  On return the last tile's epilogue is pending.
-template <int K0, int KS1, int KS2, int NT, bool RELU, int AB, int KS1A, int KS2A, int NTA, typename Epi0>
+template <int K0, int KS1, int KS2, int NT, bool RELU, int AB, int DMA, int KS1A, int KS2A, int NTA, typename Epi0>
 __device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const float* next_bias,
                                       const bf16x8 (&b1)[KS1A][kCT], const bf16x8 (&b2)[KS2A][kCT],
                                       bf16x8 (&bout)[NTA][kCT], Acc (&accs)[2], Pre& pre, Epi0&& prev0) {
@@ -168,15 +213,15 @@ __device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const fl
         constexpr int K = K0 + t;
         const float* nb = t == NT - 1 ? next_bias : bias + 32 * (t + 1);
         if constexpr (t == 0) {
-            tile<K, KS1, KS2, AB>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
+            tile<K, KS1, KS2, AB, DMA>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
         } else {
             EpiB<RELU> e{accs[(K - 1) & 1], bout[2 * (t - 1)], bout[2 * (t - 1) + 1]};
-            tile<K, KS1, KS2, AB>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
+            tile<K, KS1, KS2, AB, DMA>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
         }
     });
 }
 
-template <int AB>
+template <int AB, int DMA>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
@@ -184,12 +229,14 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     using namespace nerf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
     constexpr int kTilePts = kNW * 32 * kCT;
-    float* bias_lds = reinterpret_cast<float*>(smem + 3 * kSlotBytes);
+    float* bias_lds = reinterpret_cast<float*>(smem + ring_of<DMA> * kSlotBytes);
     {
         const float* bsrc = reinterpret_cast<const float*>(blob + kWeightBytes);
         for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
     }
-    Ctx cx{smem, blob, tid};
+    typedef __attribute__((address_space(3))) char lds_char;
+    Ctx cx{smem, blob, tid, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem),
+           __builtin_amdgcn_readfirstlane(tid >> 6)};
     Acc accs[2];
     Pre pre;
     {   // chunks 0 and 1 -> slots 0 and 1
@@ -199,6 +246,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         s1.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(1) * kFragBytes), tid);
         s0.store(reinterpret_cast<u32x4*>(smem), tid);
         s1.store(reinterpret_cast<u32x4*>(smem + kSlotBytes), tid);
+        if constexpr (DMA) {   // fetch distance 3: chunk 2 must be resident before the first tile as well
+            Stage<chunk_frags(2) / 4, kNW> s2;
+            s2.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(2) * kFragBytes), tid);
+            s2.store(reinterpret_cast<u32x4*>(smem + 2 * kSlotBytes), tid);
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + i * kFragBytes);
@@ -233,25 +285,25 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         using F = std::false_type;
         // chunk index K: L0 0-7, L1-4 8-39, L5 40-47, L6-7 48-63, bottleneck 64-71, sigma 72, rgb0 73-76, rgb1 77;
         // tile K accumulates in accs[K & 1]
-        layer<0, 4, 0, 8, true, AB>(cx, bl, bl + 256 * 1, pe, pe, ha, accs, pre, EpiNone{});
-        layer<8, 16, 0, 8, true, AB>(cx, bl + 256 * 1, bl + 256 * 2, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<16, 16, 0, 8, true, AB>(cx, bl + 256 * 2, bl + 256 * 3, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<24, 16, 0, 8, true, AB>(cx, bl + 256 * 3, bl + 256 * 4, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<32, 16, 0, 8, true, AB>(cx, bl + 256 * 4, bl + 256 * 5, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<40, 16, 4, 8, true, AB>(cx, bl + 256 * 5, bl + 256 * 6, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<48, 16, 0, 8, true, AB>(cx, bl + 256 * 6, bl + 256 * 7, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<56, 16, 0, 8, true, AB>(cx, bl + 256 * 7, bias_lds + kBiasBott, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<0, 4, 0, 8, true, AB, DMA>(cx, bl, bl + 256 * 1, pe, pe, ha, accs, pre, EpiNone{});
+        layer<8, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 1, bl + 256 * 2, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<16, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 2, bl + 256 * 3, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<24, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 3, bl + 256 * 4, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<32, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 4, bl + 256 * 5, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<40, 16, 4, 8, true, AB, DMA>(cx, bl + 256 * 5, bl + 256 * 6, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<48, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 6, bl + 256 * 7, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<56, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 7, bias_lds + kBiasBott, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
         // bottleneck (no activation) hb -> ha; next tile = sigma (bias row 256 of the fused matrix)
-        layer<64, 16, 0, 8, false, AB>(cx, bias_lds + kBiasBott, bias_lds + kBiasBott + 256, hb, pe, ha, accs, pre,
+        layer<64, 16, 0, 8, false, AB, DMA>(cx, bias_lds + kBiasBott, bias_lds + kBiasBott + 256, hb, pe, ha, accs, pre,
                                        pend(T{}, accs[1], hb[14], hb[15]));
         // sigma tile (K = 72 -> accs[0]); pending: last bottleneck tile (accs[1]); next: rgb_out[0] tile 0
-        tile<72, 16, 0, AB>(cx, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
+        tile<72, 16, 0, AB, DMA>(cx, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
         {
             EpiSigma es{accs[0], sigma};
-            layer<73, 16, 2, 4, true, AB>(cx, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
+            layer<73, 16, 2, 4, true, AB, DMA>(cx, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
         }
         // rgb_out[1] (K = 77 -> accs[1]); pending: last rgb_out[0] tile (K = 76 -> accs[0]); next: L0 tile 0
-        tile<77, 8, 0, AB>(cx, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
+        tile<77, 8, 0, AB, DMA>(cx, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < kCT; ++c)
@@ -263,18 +315,18 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
 }  // namespace v6
 }  // namespace nfx
 
-template <int AB>
+template <int AB, int DMA>
 static int launch_v6(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                      const void* blob, float* out, int max_blocks, hipStream_t stream) {
     using namespace nfx;
     const int tile_pts = v6::kNW * 32 * v6::kCT;
     const long long n_tiles = (n_pts + tile_pts - 1) / tile_pts;
     const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB>;
+    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       v6::kLds);
+                                       v6::lds_of<DMA>);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::kLds, stream, rayo, rayd, z, n_pts, n_samples,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::lds_of<DMA>, stream, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (float4*)out);
     return (int)hipGetLastError();
 }
@@ -285,13 +337,13 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
     if (n_pts <= 0) return 0;
 #ifdef NFX_ABLATION_BUILD
     switch (ablate) {
-#define NFX_V6_CASE(m) case m: return launch_v6<m>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+#define NFX_V6_CASE(m) case m: return launch_v6<m, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
         NFX_V6_CASE(1) NFX_V6_CASE(2) NFX_V6_CASE(3) NFX_V6_CASE(4) NFX_V6_CASE(8) NFX_V6_CASE(64) NFX_V6_CASE(7)
         NFX_V6_CASE(12) NFX_V6_CASE(75)
 #undef NFX_V6_CASE
         default: break;
     }
 #endif
-    (void)ablate;
-    return launch_v6<0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+    if (ablate == -7) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }
