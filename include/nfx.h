@@ -277,9 +277,10 @@ int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_
 /* ------------------------------------------------------------------------ */
 
 /* sigma[n_rays, S] = sigma_out(enc(posenc(rayo + rayd z))) BEFORE the relu (eval_sigma_mlp, :322-350), from the
- * inference blob of nfx_nerf_pack_weights: the bottleneck / rgb head is not evaluated.                        */
+ * GEOM blob (nfx_nerf_pack_geom_weights, whose first 65 chunks are the encoder + the sigma tile): the bottleneck /
+ * rgb head is neither evaluated nor streamed.  Bit-identical to the sigma of nfx_nerf_mlp_fwd.                 */
 int nfx_nerf_sigma_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
-                       int n_samples, const void *dev_blob, int prec, float *dev_sigma, void *stream);
+                       int n_samples, const void *dev_geom_blob, int prec, float *dev_sigma, void *stream);
 
 /* out[n_rays, S, 4] = (n_x, n_y, n_z, sigma_raw) with n = -l2_normalize(d relu(sigma_raw)/dx, eps 1e-12): the
  * per-sample normal of compute_depth_and_normal (:280-297, GradientTape.batch_jacobian there).  `geom_blob` =

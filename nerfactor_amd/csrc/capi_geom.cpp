@@ -20,8 +20,8 @@ extern "C" int nfx_env_int(const char* name, int dflt);
 #define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
 
 extern "C" {
-int nfx_launch_nerf_sigma_bf16(const float*, const float*, const float*, long long, int, const void*, float*, int,
-                               hipStream_t);
+int nfx_launch_nerf_sigma_geo(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                              hipStream_t);
 int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                hipStream_t);
 
@@ -98,8 +98,8 @@ int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int
     if (n_rays == 0) return NFX_OK;
     REQUIRE(rayo && rayd && z && blob && sigma, "nfx_nerf_sigma_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_fwd: blob must be 16-byte aligned");
-    return nfx_hip_result(nfx_launch_nerf_sigma_bf16(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
-                                                     sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+    return nfx_hip_result(nfx_launch_nerf_sigma_geo(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
+                                                    sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
                           "nerf_sigma_fwd");
 }
 

@@ -150,6 +150,57 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_grad_kernel(
     }
 }
 
+// Density only, for the shadow-ray and coarse camera marches (eval_sigma_mlp, geometry_from_nerf.py:322-350, before its
+// relu): the encoder + sigma tile are the first 65 chunks of the GEOM blob, so the weight stream wraps right after the
+// sigma tile — none of the 13 bottleneck / rgb chunks of the inference blob is fetched, staged or synchronised on.
+// 8 waves x 32 points like nerf_mlp_bf16_kernel<1, 8>; same arithmetic: bit-identical sigma.
+__global__ __launch_bounds__(512, 2) void nerf_sigma_geo_kernel(
+    const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
+    int n_samples, const char* __restrict__ blob, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace nerf;
+    constexpr int NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    constexpr int kTilePts = NW * 32;
+    float* fl = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
+    {
+        const float* src = reinterpret_cast<const float*>(blob + kGeoWeightBytes);
+        for (int i = tid; i < kGeoWSig; i += NW * 64) fl[i] = src[i];   // encoder biases + the sigma bias tile
+    }
+    WStream ws;
+    ws.gbase = reinterpret_cast<const u32x4*>(blob);
+    ws.gend = reinterpret_cast<const u32x4*>(blob + (size_t)kGeoFwdFrags * kFragBytes);
+    ws.gnext = ws.gbase;
+    ws.ring = smem;
+    stream_prologue<kNL0, NW>(ws, tid);
+    const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bf16x8 pe[4][1];
+        const long long m = tile * kTilePts + wave * 32 + p;
+        {
+            const long long mm = m < n_pts ? m : n_pts - 1;
+            const long long ray = mm / n_samples;
+            const float zz = zbuf[mm];
+            float x[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = rayo[ray * 3 + k] + rayd[ray * 3 + k] * zz;
+            posenc<10, 1>(x, h, 0, pe);
+        }
+        bf16x8 ha[16][1], hb[16][1];
+        layer<4, 0, 8, kNL0, kNLH, true, NW>(ws, tid, fl + 256 * 0, pe, pe, ha);
+        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, fl + 256 * 1, ha, pe, hb);
+        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, fl + 256 * 2, hb, pe, ha);
+        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, fl + 256 * 3, ha, pe, hb);
+        layer<16, 0, 8, kNLH, kNL5, true, NW>(ws, tid, fl + 256 * 4, hb, pe, ha);
+        layer<16, 4, 8, kNL5, kNLH, true, NW>(ws, tid, fl + 256 * 5, ha, pe, hb);
+        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, fl + 256 * 6, hb, pe, ha);
+        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, fl + 256 * 7, ha, pe, hb);
+        f32x16 acc[1];
+        tile_raw<16, 0, kNL0, NW>(ws, tid, fl + kGeoBiasSig, hb, pe, acc);   // next chunk: enc[0] tile 0 again
+        if (h == 0 && m < n_pts) out[m] = acc[0][0];
+    }
+}
+
 }  // namespace geo
 }  // namespace nfx
 
@@ -165,5 +216,20 @@ extern "C" int nfx_launch_nerf_sigma_grad(const float* rayo, const float* rayd, 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(geo::kNW * 64), geo::kLds, st, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (float4*)out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nfx_launch_nerf_sigma_geo(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                         int n_samples, const void* blob, float* out, int max_blocks, hipStream_t st) {
+    using namespace nfx;
+    if (n_pts <= 0) return 0;
+    const long long tiles = (n_pts + 255) / 256;
+    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
+    constexpr int lds = 2 * kSlotBytes + nerf::kGeoWSig * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo::nerf_sigma_geo_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(geo::nerf_sigma_geo_kernel, dim3(grid), dim3(512), lds, st, rayo, rayd, z, n_pts, n_samples,
+                       (const char*)blob, out);
     return (int)hipGetLastError();
 }

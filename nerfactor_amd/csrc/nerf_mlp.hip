@@ -169,64 +169,6 @@ __global__ __launch_bounds__(512, 2) void nerf_mlp_bf16_rolled_kernel(
     }
 }
 
-// Density only (geometry_from_nerf.py:322-350 eval_sigma_mlp, before its relu): the encoder and the sigma_out tile
-// of the SAME inference blob; the bottleneck / rgb chunks stream through LDS without being multiplied
-// (208 of 1272 MFMAs per 32 points saved: shadow-ray marching needs 448 density samples per (point, light)).
-__global__ __launch_bounds__(512, 2) void nerf_sigma_bf16_kernel(
-    const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf,
-    long long n_pts, int n_samples, const char* __restrict__ blob, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NW = 8, CT = 1;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, p = lane & 31;
-    constexpr int kTilePts = NW * 32;
-    float* bias_lds = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
-    {
-        const float* bsrc = reinterpret_cast<const float*>(blob + nerf::kWeightBytes);
-        for (int i = tid; i < nerf::kBiasFloats; i += NW * 64) bias_lds[i] = bsrc[i];
-    }
-    WStream ws;
-    ws.gbase = reinterpret_cast<const u32x4*>(blob);
-    ws.gend = reinterpret_cast<const u32x4*>(blob + nerf::kWeightBytes);
-    ws.gnext = ws.gbase;
-    ws.ring = smem;
-    stream_prologue<nerf::kNL0, NW>(ws, tid);
-    const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        bf16x8 pe[4][CT];
-        const long long m = tile * kTilePts + wave * 32 + p;
-        {
-            const long long mm = m < n_pts ? m : n_pts - 1;
-            const long long ray = mm / n_samples;
-            const float zz = zbuf[mm];
-            float x[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) x[k] = rayo[ray * 3 + k] + rayd[ray * 3 + k] * zz;
-            posenc<10, CT>(x, h, 0, pe);
-        }
-        bf16x8 ha[16][CT], hb[16][CT];
-        using namespace nerf;
-        layer<4, 0, 8, kNL0, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0, pe, pe, ha);
-        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 1, ha, pe, hb);
-        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 2, hb, pe, ha);
-        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 3, ha, pe, hb);
-        layer<16, 0, 8, kNLH, kNL5, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 4, hb, pe, ha);
-        layer<16, 4, 8, kNL5, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 5, ha, pe, hb);
-        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 6, hb, pe, ha);
-        layer<16, 0, 8, kNLH, kNLH, true, NW>(ws, tid, bias_lds + kBiasL0 + 256 * 7, ha, pe, hb);
-        static_for<0, 8>([&](auto) { with_chunk<kNLH, NW>(ws, tid, [](const char*) {}); });  // bottleneck tiles
-        {
-            f32x16 acc[CT];
-            tile_raw<16, 0, kNLR0, NW>(ws, tid, bias_lds + kBiasBott + 256, hb, pe, acc);
-            if (h == 0 && m < n_pts) out[m] = acc[0][0];
-        }
-        static_for<0, 3>([&](auto) { with_chunk<kNLR0, NW>(ws, tid, [](const char*) {}); });  // rgb_out[0] tiles
-        with_chunk<kNLR1, NW>(ws, tid, [](const char*) {});
-        with_chunk<kNL0, NW>(ws, tid, [](const char*) {});                                    // rgb_out[1]
-    }
-}
-
 }  // namespace nfx
 
 template <int CT, int NW>
@@ -267,19 +209,4 @@ extern "C" int nfx_launch_nerf_mlp_bf16(const float* rayo, const float* rayd, co
     if (variant == 0)
         return launch_variant<2, 4>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
     return launch_variant<1, 8>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
-}
-
-extern "C" int nfx_launch_nerf_sigma_bf16(const float* rayo, const float* rayd, const float* z, long long n_pts,
-                                          int n_samples, const void* blob, float* out, int max_blocks,
-                                          hipStream_t stream) {
-    using namespace nfx;
-    if (n_pts <= 0) return 0;
-    const long long n_tiles = (n_pts + 255) / 256;
-    const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_sigma_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kNerfLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nerf_sigma_bf16_kernel, dim3(grid), dim3(512), kNerfLdsBytes, stream, rayo, rayd, z, n_pts,
-                       n_samples, (const char*)blob, out);
-    return (int)hipGetLastError();
 }

@@ -198,7 +198,7 @@ class Model(BaseModel):
         """relu(sigma)[N,S] at rayo + rayd z (eval_sigma_mlp, geometry_from_nerf.py:322-350); outside the optional
         bounding box (x_min, x_max, y_min, y_max, z_min, z_max) the density is 0."""
         pref = 'fine_' if use_fine else 'coarse_'
-        sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision))
+        sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_geom_blob(pref), self.precision))
         if bbox is not None:
             sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)
         return sigma

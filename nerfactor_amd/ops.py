@@ -437,7 +437,8 @@ def _ray_args(rayo, rayd, z, blob):
 
 
 def nerf_sigma_fwd(rayo, rayd, z, blob, prec='bf16'):
-    """sigma_raw[N,S] (no relu) at rayo + rayd*z from the inference blob; the rgb head is skipped."""
+    """sigma_raw[N,S] (no relu) at rayo + rayd*z from the GEOM blob (pack_nerf_geom_weights); the rgb head is neither
+    evaluated nor streamed."""
     rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, blob)
     out = torch.empty((n, s), dtype=torch.float32, device=z.device)
     check(lib.nfx_nerf_sigma_fwd(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(blob), _PREC[prec], _ptr(out),

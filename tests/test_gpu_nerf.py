@@ -312,7 +312,7 @@ def test_sigma_only_kernel_is_the_full_kernel_s_density(nfx_lib, cuda):
     rayo, rayd, z = _geom_inputs(301, 5, 0)
     t = lambda a: torch.from_numpy(a).to(cuda)
     full = ops.nerf_mlp_fwd(t(rayo), t(rayd), t(z), blob)
-    sig = ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), blob)
+    sig = ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), ops.pack_nerf_geom_weights(ks, bs).to(cuda))
     assert torch.equal(sig, full[..., 3])
 
 
@@ -327,7 +327,8 @@ def test_sigma_gradient_normals_vs_autograd(nfx_lib, cuda):
     rayo, rayd, z = _geom_inputs(50, 9, 1)     # 450 points: exercises the padded last tile
     t = lambda a: torch.from_numpy(a).to(cuda)
     normal, sigma = ops.nerf_sigma_grad(t(rayo), t(rayd), t(z), gblob)
-    assert torch.equal(sigma, ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), blob))
+    assert torch.equal(sigma, ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), gblob))
+    assert torch.equal(sigma, ops.nerf_mlp_fwd(t(rayo), t(rayd), t(z), blob)[..., 3])
     normal, sigma = normal.cpu().numpy().reshape(-1, 3), sigma.cpu().numpy().reshape(-1)
     pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3)
 
