@@ -7,8 +7,23 @@ import torch
 from . import _capi, ops
 
 
-def _grads_for(params):
-    return [torch.zeros_like(p) for p in params]
+def _targets(params):
+    """Where the backward kernels accumulate the gradient of each parameter.  The libnfx weight-gradient kernels ADD
+    into their output, so when a parameter already owns a gradient buffer (optim.AMSGrad makes every .grad a view of
+    its flat bucket, zeroed once per step) they add straight into it and autograd gets None for that input: no
+    zero-fill and no `grad += g` kernel per parameter and call (≈100 tiny launches per NeRF step).  Otherwise a fresh
+    zero buffer is returned to autograd as usual."""
+    bufs, rets = [], []
+    for p in params:
+        g = getattr(p, 'grad', None)
+        if g is not None and g.is_contiguous() and g.shape == p.shape:
+            bufs.append(g)
+            rets.append(None)
+        else:
+            z = torch.zeros_like(p)
+            bufs.append(z)
+            rets.append(z)
+    return bufs, rets
 
 
 class Mlp128Xyz(torch.autograd.Function):
@@ -27,10 +42,10 @@ class Mlp128Xyz(torch.autograd.Function):
         (xyz,) = ctx.saved_tensors
         train_blob_fn, out_dim, out_act, xyz_scale, post_scale, n_params, params = ctx.cfg
         ks, bs = list(params[:5]), list(params[5:])
-        dks, dbs = _grads_for(ks), _grads_for(bs)
+        (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
                        xyz_scale=xyz_scale, post_scale=post_scale)
-        return (None,) * 8 + tuple(dks) + tuple(dbs)
+        return (None,) * 8 + tuple(rks) + tuple(rbs)
 
 
 class Lvis(torch.autograd.Function):
@@ -47,10 +62,10 @@ class Lvis(torch.autograd.Function):
         xyz, xyz_dir, lxyz = ctx.saved_tensors
         train_blob_fn, xyz_scale, params = ctx.cfg
         ks, bs = list(params[:5]), list(params[5:])
-        dks, dbs = _grads_for(ks), _grads_for(bs)
+        (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ_LDIR, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act='sigmoid',
                        xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir)
-        return (None,) * 6 + tuple(dks) + tuple(dbs)
+        return (None,) * 6 + tuple(rks) + tuple(rbs)
 
 
 class ShadeMicrofacet(torch.autograd.Function):
@@ -127,9 +142,9 @@ class NerfMlp(torch.autograd.Function):
         rayo, rayd, z = ctx.saved_tensors
         train_blob_fn, prec, params = ctx.cfg
         ks, bs = list(params[:12]), list(params[12:])
-        dks, dbs = _grads_for(ks), _grads_for(bs)
+        (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs.contiguous(), train_blob_fn(), dks, dbs, prec)
-        return (None,) * 6 + tuple(dks) + tuple(dbs)
+        return (None,) * 6 + tuple(rks) + tuple(rbs)
 
 
 class Composite(torch.autograd.Function):
