@@ -213,26 +213,50 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
     };
     fetch_rows(blockIdx.x);
     park_rows();
+    // point position and light position of this lane's row in column tile c of point tile t, fetched one point tile
+    // ahead: the first touch of a point's xyz is an HBM miss (~2-3 k cycles) that the first MFMA of the tile waited for
+    float xq[CT][3], lq[CT][3];
+    auto fetch_inputs = [&](long long t) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const long long m = t * kTileRows + (wave * CT + c) * 32;
+            const long long mc = m < n_rows ? m : 0;
+            const long long pt = mc / n_lights;
+            const int l = (int)(mc % n_lights) + p;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xq[c][k] = a.xyz[pt * 3 + k];
+                lq[c][k] = a.lxyz[l * 3 + k];
+            }
+        }
+    };
+    fetch_inputs(blockIdx.x);
     for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         bf16x8 pl[2][CT];
         const float* pre_pt[CT];
-        {   // next point tile's rows: in flight during this whole tile, parked after the last layer-3 initialiser
-            const long long tn = tl + gridDim.x;
-            fetch_rows(tn < n_tiles ? tn : tl);
-        }
+        const long long tnext = tl + gridDim.x < n_tiles ? tl + gridDim.x : tl;
+        fetch_rows(tnext);   // next point tile's rows: in flight during this whole tile, parked after the last layer-3 initialiser
         long long m0[CT];
         bool front[CT];
+        float xc[CT][3], lc[CT][3];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xc[c][k] = xq[c][k];
+                lc[c][k] = lq[c][k];
+            }
+        fetch_inputs(tnext);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             m0[c] = tl * kTileRows + (wave * CT + c) * 32;   // 32 consecutive lights of one point (n_lights % 32 == 0)
             const long long mc = m0[c] < n_rows ? m0[c] : 0;
             const long long pt = mc / n_lights;
-            const int l = (int)(mc % n_lights) + p;
             float x[3], lp[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                x[k] = a.xyz[pt * 3 + k];
-                lp[k] = a.lxyz[l * 3 + k];
+                x[k] = xc[c][k];
+                lp[k] = lc[c][k];
             }
             if constexpr (MODE == 0) {
                 float d[3], sq = 0.f;
