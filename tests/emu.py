@@ -193,3 +193,40 @@ def brdf_tile(blob, z, rusink):
     acc = _m128_mid_and_out(rd, rd.b, h, ops_in)
     assert rd.pos == 136
     return acc[:32, 0]
+
+
+# ----------------------------------------------------------------------------- backward-side blobs
+def hidden_ops(x):
+    """Logical activations x [32, F] (F a multiple of 16) -> hidden-layout B operands: operand o holds features
+    16 o + (j & 3) + 8 (j >> 2) + 4 h in element j of lane (h, p) — what relu+cvt of a C/D tile leaves in registers."""
+    x = bf16_round(np.asarray(x, np.float32))
+    j = np.arange(8)
+    ops = []
+    for o in range(x.shape[1] // 16):
+        feat = 16 * o + (j & 3)[None, :] + 8 * (j >> 2)[None, :] + 4 * H[:, None]
+        ops.append(x[P[:, None], feat])
+    return ops
+
+
+def tile_features(acc, n_valid=32):
+    """C/D tile acc [64, 16] -> [32 points, 32 features] (feature = (r & 3) + 8 (r >> 2) + 4 h)."""
+    out = np.zeros((32, 32), np.float32)
+    for r in range(16):
+        out[P, (r & 3) + 8 * (r >> 2) + 4 * H] = acc[:, r]
+    return out[:, :n_valid]
+
+
+def dgrad_layer(reader, chunk_frags, b_ops, n_tiles):
+    """Transposed-layer product with zero-initialised accumulators: -> [32, 32 n_tiles] fp32."""
+    zero = np.zeros(32 * n_tiles + 64, np.float32)
+    return np.concatenate([tile_features(tile(reader, chunk_frags, zero, 0, b_ops)) for _ in range(n_tiles)], 1)
+
+
+def posenc10_slot_rows():
+    """Keras-kernel input row (of the 63-wide posenc(x) block) behind slot q of lane half h, or -1."""
+    rows = -np.ones((2, 32), np.int64)
+    for q in range(30):
+        rows[0, q] = 3 + 6 * (q // 3) + (q % 3)        # sin(2^b x_c)
+        rows[1, q] = 3 + 6 * (q // 3) + 3 + (q % 3)    # cos(2^b x_c)
+    rows[0, 30], rows[1, 30], rows[0, 31] = 0, 2, 1
+    return rows
