@@ -1,5 +1,6 @@
 """NumPy restatement of the vanilla-NeRF ray-marching stage (TEST INFRASTRUCTURE, see
-oracle/__init__.py; parity with TensorFlow itself is UNPINNED).
+oracle/__init__.py; pinned to the reference's own model code run on a NumPy TF shim,
+tests/golden/make_reference_golden.py; the TF kernels themselves stay unpinned).
 
 Follows, op for op:
   nerfactor/models/nerf.py:120-290   gen_z, gen_z_fine, _render_rays, accumulate_sigma,

@@ -1,5 +1,6 @@
 """NumPy restatement of the NeRFactor surface-shading stage (TEST INFRASTRUCTURE, see
-oracle/__init__.py; parity with TensorFlow itself is UNPINNED).
+oracle/__init__.py; pinned to the reference's own model code run on a NumPy TF shim,
+tests/golden/make_reference_golden.py; the TF kernels themselves stay unpinned).
 
 Follows, op for op:
   brdf/renderer.py:184-219 + xiuminglib/geometry/sph.py:185-190   gen_light_xyz
@@ -337,3 +338,69 @@ def nerfactor_loss(pred, gt, loss_kwargs, light, mode='train', white_bg=True, sh
             dc = light - np.roll(light, 1, 2)
             loss = loss + dt(light_achro_weight) * np.sum(dc ** 2)
     return loss
+
+
+# ------------------------------------------------------------------- shape pre-training model
+def shape_call(xyz, net, lxyz, xyz_scale=1., xyz_noise=None, quant=None):
+    """models/shape.py:146-182 (Model.call): unit normals and light visibility at the surface points, plus the
+    jittered second evaluation when xyz_noise (the tf.random.normal stand-in) is given."""
+    surf2l = calc_ldir(xyz, lxyz)
+
+    def heads(p):
+        return (l2_normalize(pred_normal_at(p, net, xyz_scale, quant=quant), 1, 1e-6),
+                pred_lvis_at(p, surf2l, net, xyz_scale, quant=quant))
+
+    normal, lvis = heads(xyz)
+    jit = heads(xyz + xyz_noise) if xyz_noise is not None else (None, None)
+    return {'normal': normal, 'lvis': lvis}, {'normal_jitter': jit[0], 'lvis_jitter': jit[1]}
+
+
+def shape_loss(pred, gt, loss_kwargs, white_bg=True, normal_loss_weight=1., lvis_loss_weight=1.,
+               normal_smooth_weight=0., lvis_smooth_weight=0., smooth_use_l1=True):
+    """models/shape.py:239-281 (Model.compute_loss): per-point loss on alpha-composited predictions."""
+    alpha = gt['alpha']
+    dt = alpha.dtype.type
+    bgv = dt(1.) if white_bg else dt(0.)
+
+    def blend(x):
+        return x * alpha + bgv * (dt(1.) - alpha)
+
+    def mse(a, b):
+        return np.mean((a - b) ** 2, -1)
+
+    def smooth(a, b):
+        return np.mean(np.abs(a - b), -1) if smooth_use_l1 else mse(a, b)
+
+    normal_pred, lvis_pred = blend(pred['normal']), blend(pred['lvis'])
+    loss = dt(normal_loss_weight) * mse(blend(gt['normal']), normal_pred)
+    loss = loss + dt(lvis_loss_weight) * mse(blend(gt['lvis']), lvis_pred)
+    if loss_kwargs.get('normal_jitter') is not None:
+        loss = loss + dt(normal_smooth_weight) * smooth(normal_pred, loss_kwargs['normal_jitter'])
+    if loss_kwargs.get('lvis_jitter') is not None:
+        loss = loss + dt(lvis_smooth_weight) * smooth(lvis_pred, loss_kwargs['lvis_jitter'])
+    return loss
+
+
+# ------------------------------------------------------------------------- BRDF prior model
+def brdf_prior_eval(z, rusink, brdf_net, n_freqs=2, quant=None):
+    """models/brdf.py:101-123 (Model._eval_brdf_at): softplus MLP on [z, posenc(rusink)] and on the reciprocal
+    configuration (phi_d + pi).  z [N, z_dim], rusink [N, 3] -> (brdf, brdf_reci), both [N, 1]."""
+    def run(r):
+        x = np.concatenate((z, embed(r, n_freqs)), 1)
+        y = mlp(x, brdf_net['brdf_mlp'], ['relu'] * 4, skip_at=[2], quant=quant)
+        return mlp(y, brdf_net['brdf_out'], ['softplus'], quant=quant)
+    reci = np.concatenate((rusink[:, :1] + rusink.dtype.type(np.pi), rusink[:, 1:]), 1)
+    return run(rusink), run(reci)
+
+
+def latent_interp(z_table, w1, i1, w2, i2):
+    """networks/layers.py:57-68 (LatentCode.interp), un-normalised codes: linear interpolation -> [1, z_dim]."""
+    dt = z_table.dtype.type
+    return dt(w1) * z_table[i1:i1 + 1] + dt(w2) * z_table[i2:i2 + 1]
+
+
+def brdf_prior_loss(refl, brdf, brdf_reci, transform='log'):
+    """models/brdf.py:125-141 (Model.compute_loss) with loss = l2 (losses.py:32-46, keep_batch=False): the scalar
+    mean squared error of f(prediction) against f(measurement), summed over the two reciprocal halves."""
+    f = {'log': np.log, 'none': lambda x: x, 'divide': lambda x: x / (x + 1)}[transform.lower()]
+    return np.mean((f(refl) - f(brdf)) ** 2) + np.mean((f(refl) - f(brdf_reci)) ** 2)

@@ -1,0 +1,115 @@
+"""Deterministic inputs and weights shared by make_reference_golden.py (which feeds them to the reference's model
+classes) and the parity tests (which feed them to oracle/ and to the HIP path).  NumPy only; no reference access."""
+import numpy as np
+
+from oracle import nerf_ref, nerfactor_ref
+from tests import common
+
+NERF_SEED = 21
+LIGHT_SCALE = {'nfl': 0.3, 'nfm': 2.}      # keeps most pixels of both variants below the clip at 1
+BRDF_NAMES = ['alum-bronze', 'blue-fabric', 'chrome', 'delrin', 'nylon']   # sorted, as xm.os.sortglob returns them
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, np.float32)
+
+
+def checksum(list_of_pairs):
+    return np.float32(sum(float(np.abs(k).sum()) + float(np.abs(b).sum()) for k, b in list_of_pairs))
+
+
+def checksum_nerf(nets):
+    return _f32([checksum([p for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out') for p in net[part]])
+                 for net in nets])
+
+
+def nerf_rays():
+    """64 rays of an 8 x 8 camera looking at the origin + random ground-truth colours."""
+    rayo, rayd = common.camera_rays(8, 8)
+    rng = np.random.default_rng(31)
+    return _f32(rayo), _f32(rayd * 1.7), _f32(rng.uniform(0, 1, (rayo.shape[0], 3)))
+
+
+def sampler_inputs():
+    """z [32,64] (perturbed strata), weights [32,64] (peaky; row 0 all-zero, row 1 one-hot), sigma, ray dirs."""
+    rng = np.random.default_rng(32)
+    z = nerf_ref.gen_z(2., 6., 64, 32, u=rng.uniform(0, 1, (32, 64)).astype(np.float32))
+    w = rng.uniform(0, 1, (32, 64)) ** 8
+    w[0] = 0
+    w[1] = 0
+    w[1, 17] = 1
+    sigma = rng.normal(0, 4, (32, 64))
+    rd = rng.normal(size=(32, 3))
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    return _f32(z), _f32(w), _f32(sigma), _f32(rd)
+
+
+def frame_inputs():
+    rng = np.random.default_rng(33)
+    nrm = rng.normal(size=(48, 3))
+    nrm[0] = (0, 0, 1)
+    nrm[1] = (0, 0, -1)
+    nrm[2] = (1, 0, 0)
+    nrm[3] *= 5
+    a = rng.normal(size=(96, 3))
+    b = rng.normal(size=(96, 3))
+    a[:, 2] = np.abs(a[:, 2]) + 1e-2
+    b[:, 2] = np.abs(b[:, 2]) + 1e-2
+    b[0] = a[0]                                     # identical directions: theta_d = 0
+    return _f32(nrm), _f32(a), _f32(b)
+
+
+def microfacet_inputs():
+    rng = np.random.default_rng(34)
+    n_pts, n_l = 12, 40
+    l = rng.normal(size=(n_pts, n_l, 3))
+    v = rng.normal(size=(n_pts, 3))
+    nrm = rng.normal(size=(n_pts, 3))
+    v += 2 * nrm / np.linalg.norm(nrm, axis=1, keepdims=True)      # mostly front-facing views
+    alb = rng.uniform(0, 1, (n_pts, 3))
+    rough = rng.uniform(0.05, 1, (n_pts, 1))
+    return _f32(l), _f32(v), _f32(nrm), _f32(alb), _f32(rough)
+
+
+def surface_batch(n_lights):
+    """(rayo, rgb, alpha, xyz, normal, lvis) of 24 surface points, 5 of them background (alpha = 0)."""
+    rng = np.random.default_rng(35)
+    n = 24
+    xyz = rng.uniform(-1, 1, (n, 3))
+    normal = rng.normal(size=(n, 3))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    rayo = np.tile(np.float32([[2.2, -2.4, 1.9]]), (n, 1))
+    rgb = rng.uniform(0, 1, (n, 3))
+    alpha = rng.uniform(0.3, 1, (n, 1))
+    alpha[[2, 7, 8, 15, 23]] = 0
+    lvis = rng.uniform(0, 1, (n, n_lights))
+    return _f32(rayo), _f32(rgb), _f32(alpha), _f32(xyz), _f32(normal), _f32(lvis)
+
+
+def _with_biases(net, seed):
+    return nerf_ref.randomize_biases(net, np.random.default_rng(seed))
+
+
+def nerfactor_net(z_dim):
+    return _with_biases(nerfactor_ref.init_nerfactor_net(np.random.default_rng(40 + z_dim), z_dim), 50 + z_dim)
+
+
+def brdf_net():
+    return _with_biases(nerfactor_ref.init_brdf_mlp(np.random.default_rng(44)), 54)
+
+
+def latent_codes():
+    return _f32(np.random.default_rng(45).normal(0, 0.5, (len(BRDF_NAMES), 3)))
+
+
+def brdf_batch():
+    rng = np.random.default_rng(46)
+    n = 192
+    i = rng.integers(0, len(BRDF_NAMES), n).astype(np.int32)
+    rusink = np.stack([rng.uniform(0, np.pi, n), rng.uniform(0, np.pi / 2, n), rng.uniform(0, np.pi / 2, n)], 1)
+    refl = np.exp(rng.normal(-2, 2, (n, 1)))
+    return i, _f32(rusink), _f32(refl)
+
+
+def light_probe(scale=2.):
+    return _f32(np.random.default_rng(47).uniform(0, 1, (16, 32, 3)) ** 2 * scale)

@@ -1,0 +1,247 @@
+"""Generates tests/golden/reference_models.npz by running the REAL google/nerfactor model classes.
+
+    python tests/golden/make_reference_golden.py        (build container only: needs /root/reference)
+
+TensorFlow is not installable here, so the reference's Python runs on tests/golden/tf_shim — a NumPy implementation
+of the TensorFlow calls it makes (see tf_shim/README.md).  The model code itself is imported from /root/reference
+unmodified and configured from the reference's own nerfactor/config/*.ini files (only paths are overridden):
+
+  nerfactor/models/nerf.py                 Model.call (coarse + fine render), gen_z_fine, accumulate_sigma, compute_loss
+  nerfactor/models/shape.py                Model.call (normal + light-visibility MLPs), compute_loss
+  nerfactor/models/brdf.py                 Model._eval_brdf_at (learned BRDF MLP, both reciprocal halves), compute_loss
+  nerfactor/models/nerfactor.py            Model.call (test, OLAT relight) / train-mode call with jitter + compute_loss
+  nerfactor/models/nerfactor_microfacet.py Model.call + compute_loss
+  nerfactor/util/geom.py                   gen_world2local, dir2rusink
+  brdf/microfacet/microfacet.py            Microfacet.__call__
+
+Weights are not stored: they come from the deterministic generators in oracle/ and tests/common.py (seeds below),
+which the parity tests call again; a checksum of every weight set is stored so generator drift is detected.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('NERFACTOR_REFERENCE', '/root/reference')
+sys.path[:0] = [os.path.join(HERE, 'tf_shim'), REF, os.path.join(REF, 'nerfactor'), REPO]
+
+import tensorflow as tf  # noqa: E402  (the shim)
+
+assert 'numpy-shim' in tf.__version__
+from nerfactor.util import io as ioutil  # noqa: E402
+from nerfactor.util import geom as geomutil  # noqa: E402
+from nerfactor.models.nerf import Model as NerfModel  # noqa: E402
+from nerfactor.models.shape import Model as ShapeModel  # noqa: E402
+from nerfactor.models.brdf import Model as BrdfModel  # noqa: E402
+from nerfactor.models.nerfactor import Model as NerfactorModel  # noqa: E402
+from nerfactor.models.nerfactor_microfacet import Model as MicrofacetModel  # noqa: E402
+from brdf.microfacet.microfacet import Microfacet  # noqa: E402
+
+from oracle import nerf_ref, nerfactor_ref  # noqa: E402  (weight generators only)
+from tests import common  # noqa: E402
+from tests.golden import golden_inputs as gi  # noqa: E402
+
+OUT = {}
+
+
+def put(key, value):
+    a = np.asarray(value)
+    assert a.dtype != np.float64, (key, 'float64 leaked out of the fp32 model code')
+    assert np.all(np.isfinite(a)) if a.dtype.kind == 'f' else True, key
+    OUT[key] = a
+
+
+def set_layers(network, pairs):
+    assert len(network.layers) == len(pairs), (len(network.layers), len(pairs))
+    for layer, (k, b) in zip(network.layers, pairs):
+        layer.set_weights([k, b])
+
+
+def ref_config(name, **override):
+    cfg = ioutil.read_config(os.path.join(REF, 'nerfactor', 'config', name))
+    for k, v in override.items():
+        cfg.set('DEFAULT', k, str(v))
+    return cfg
+
+
+def as_tensors(*arrays):
+    return tuple(tf.convert_to_tensor(a) for a in arrays)
+
+
+# ------------------------------------------------------------------------------------------------ NeRF
+def run_nerf():
+    cfg = ref_config('nerf.ini')
+    model = NerfModel(cfg)
+    nets = common.nerf_nets(seed=gi.NERF_SEED)
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            set_layers(model.net[pref + part], net[part])
+    put('nerf_weight_checksum', gi.checksum_nerf(nets))
+    rayo, rayd, gt = gi.nerf_rays()
+    n = rayo.shape[0]
+    batch = (np.array([b'x'] * n), np.tile(np.int32([[4, n // 4]]), (n, 1))) + as_tensors(rayo, rayd, gt)
+    pred, gt_t, loss_kwargs, to_vis = model.call(batch, mode='test')
+    for lvl in ('coarse', 'fine'):
+        for k in ('rgb', 'occu', 'depth', 'disp'):
+            put('nerf_%s_%s' % (lvl, k), to_vis['%s_%s' % (lvl, k)])
+    put('nerf_loss', model.compute_loss(pred, gt_t, **loss_kwargs))
+    # stage-level anchors: the fine sampler and the compositing weights on inputs that do not depend on an MLP
+    z, w, sigma, rd = gi.sampler_inputs()
+    put('nerf_z_fine', NerfModel.gen_z_fine(tf.convert_to_tensor(z), tf.convert_to_tensor(w), 128, perturb=False))
+    put('nerf_acc_weights', NerfModel.accumulate_sigma(*as_tensors(sigma, z, rd)))
+    put('nerf_gen_z_disp', NerfModel.gen_z(2., 6., 64, 3, lin_in_disp=True))
+    put('nerf_gen_z', NerfModel.gen_z(2., 6., 64, 3))
+
+
+# ------------------------------------------------------------------------------------------------ geometry helpers
+def run_geom():
+    nrm, a, b = gi.frame_inputs()
+    put('geom_world2local', geomutil.gen_world2local(tf.convert_to_tensor(nrm)))
+    put('geom_rusink', geomutil.dir2rusink(*as_tensors(a, b)))
+    l, v, n, alb, rough = gi.microfacet_inputs()
+    put('microfacet_brdf', Microfacet(f0=0.04)(*as_tensors(l, v, n), albedo=tf.convert_to_tensor(alb),
+                                               rough=tf.convert_to_tensor(rough)))
+    put('microfacet_default', Microfacet()(*as_tensors(l, v, n)))
+
+
+# ------------------------------------------------------------------------------------------------ shape
+def shape_batch(n_lights):
+    rayo, rgb, alpha, xyz, normal, lvis = gi.surface_batch(n_lights)
+    n = rayo.shape[0]
+    id_ = np.array([b'x'] * n)
+    hw = np.tile(np.int32([[4, n // 4]]), (n, 1))
+    rayd = np.zeros_like(rayo)
+    return (id_, hw) + as_tensors(rayo, rayd, rgb, alpha, xyz, normal, lvis)
+
+
+def run_shape():
+    cfg = ref_config('shape.ini', xyz_jitter_std=0)
+    model = ShapeModel(cfg)
+    net = gi.nerfactor_net(3)
+    for part in ('normal_mlp', 'normal_out', 'lvis_mlp', 'lvis_out'):
+        set_layers(model.net[part], net[part])
+    batch = shape_batch(512)
+    pred, gt, loss_kwargs, _ = model.call(batch, mode='test')
+    put('shape_normal', pred['normal'])
+    put('shape_lvis', pred['lvis'])
+    put('shape_loss', model.compute_loss(pred, gt, **loss_kwargs))
+    put('shape_lxyz', model.lxyz)
+
+
+# ------------------------------------------------------------------------------------------------ BRDF prior
+def brdf_workdir(tmp):
+    data_root = os.path.join(tmp, 'merl_npz')
+    os.makedirs(data_root)
+    for name in gi.BRDF_NAMES:
+        open(os.path.join(data_root, 'train_%s.npz' % name), 'wb').close()
+    return data_root
+
+
+def run_brdf(tmp):
+    cfg = ref_config('brdf.ini', data_root=brdf_workdir(tmp))
+    model = BrdfModel(cfg)
+    assert model.brdf_names == sorted(gi.BRDF_NAMES)
+    bnet = gi.brdf_net()
+    set_layers(model.net['brdf_mlp'], bnet['brdf_mlp'])
+    set_layers(model.net['brdf_out'], bnet['brdf_out'])
+    model.latent_code.z = gi.latent_codes()
+    i, rusink, refl = gi.brdf_batch()
+    n = rusink.shape[0]
+    batch = (np.array([b'x'] * n), tf.convert_to_tensor(i), None, None, None) + as_tensors(rusink, refl)
+    pred, gt, loss_kwargs, to_vis = model.call(batch, mode='vali')
+    put('brdf_pred', pred['brdf'])
+    put('brdf_pred_reci', pred['brdf_reci'])
+    put('brdf_z', to_vis['z'])
+    put('brdf_loss', model.compute_loss(pred, gt, **loss_kwargs))
+    put('brdf_interp', model.latent_code.interp(0.25, 0, 0.75, 2))
+    return model
+
+
+# ------------------------------------------------------------------------------------------------ NeRFactor
+def nerfactor_workdir(tmp, brdf_root):
+    """The directory layout get_config_ini() expects: <root>/<xname>.ini next to <root>/<xname>/checkpoints/ckpt-N."""
+    paths = {}
+    for name, ini, over in (('shape', 'shape.ini', {}), ('brdf', 'brdf.ini', {'data_root': brdf_root})):
+        root = os.path.join(tmp, name)
+        os.makedirs(os.path.join(root, 'lr1e-2', 'checkpoints'))
+        ioutil.write_config(ref_config(ini, **over), os.path.join(root, 'lr1e-2.ini'))
+        paths[name] = os.path.join(root, 'lr1e-2', 'checkpoints', 'ckpt-1')
+    envdir = os.path.join(tmp, 'envmaps')
+    os.makedirs(envdir)
+    return paths, envdir
+
+
+class RecordNormal:
+    """Wraps tf.random.normal so the jitter the reference draws can be replayed by the parity test."""
+    def __init__(self):
+        self.draws = []
+        self.orig = tf.random.normal
+
+    def __call__(self, shape, **kw):
+        x = self.orig(shape, **kw)
+        self.draws.append(np.asarray(x))
+        return x
+
+
+def run_nerfactor(tmp, brdf_root, learned):
+    paths, envdir = nerfactor_workdir(tmp, brdf_root)
+    tag = 'nfl' if learned else 'nfm'
+    ini = 'nerfactor.ini' if learned else 'nerfactor_microfacet.ini'
+    over = dict(shape_model_ckpt=paths['shape'], test_envmap_dir=envdir, embed_light_h=16, light_tv_weight=2e-4,
+                light_achro_weight=1e-4)
+    if learned:
+        over['brdf_model_ckpt'] = paths['brdf']
+    cls = NerfactorModel if learned else MicrofacetModel
+    model = cls(ref_config(ini, **over), debug=True)        # debug: 2 x 2 OLAT lights instead of 16 x 32
+    z_dim = 3 if learned else 1
+    net = gi.nerfactor_net(z_dim)
+    for part in net:
+        set_layers(model.net[part], net[part])
+    if learned:
+        bnet = gi.brdf_net()
+        set_layers(model.brdf_model.net['brdf_mlp'], bnet['brdf_mlp'])
+        set_layers(model.brdf_model.net['brdf_out'], bnet['brdf_out'])
+    model._light = tf.Variable(gi.light_probe(gi.LIGHT_SCALE[tag]))
+    batch = shape_batch(512)
+    # test mode with OLAT relighting
+    pred, gt, loss_kwargs, _ = model.call(batch, mode='test', relight_olat=True)
+    for k in ('rgb', 'normal', 'lvis', 'albedo', 'brdf', 'rgb_olat'):
+        put('%s_test_%s' % (tag, k), pred[k])
+    loss_kwargs['mode'] = 'vali'
+    put('%s_vali_loss' % tag, model.compute_loss(pred, gt, **loss_kwargs))
+    # train mode: jittered second evaluation + smoothness terms + light priors
+    rec = RecordNormal()
+    tf.random.normal = rec
+    try:
+        pred, gt, loss_kwargs, _ = model.call(batch, mode='train')
+    finally:
+        tf.random.normal = rec.orig
+    assert len(rec.draws) == 1
+    put('%s_train_jitter' % tag, rec.draws[0])
+    put('%s_train_rgb' % tag, pred['rgb'])
+    put('%s_train_loss' % tag, model.compute_loss(pred, gt, **loss_kwargs))
+    put('%s_olat_keys' % tag, np.array(list(model.novel_olat.keys())))
+
+
+def main():
+    tf.random.set_seed(7)
+    run_nerf()
+    run_geom()
+    run_shape()
+    with tempfile.TemporaryDirectory() as tmp:
+        run_brdf(tmp)
+        root = os.path.join(tmp, 'merl_npz')
+        run_nerfactor(os.path.join(tmp, 'a'), root, learned=True)
+        run_nerfactor(os.path.join(tmp, 'b'), root, learned=False)
+    path = os.path.join(HERE, 'reference_models.npz')
+    np.savez_compressed(path, **OUT)
+    print('wrote %s (%.1f KiB)' % (path, os.path.getsize(path) / 1024))
+    for k, v in OUT.items():
+        print('  %-24s %-16s %s' % (k, v.shape, v.dtype))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,155 @@
+"""The HIP path (through the reference-shaped plugin classes) against outputs of the REFERENCE'S OWN model classes:
+tests/golden/reference_models.npz, produced by tests/golden/make_reference_golden.py from google/nerfactor's
+unmodified Python (run on the NumPy TensorFlow shim in tests/golden/tf_shim).
+
+The reference computes in float32; the kernels multiply in bf16 on the MFMA units (fp32 accumulate), so the stated
+tolerance is the bf16 one of SURVEY.md §8d: max-abs <= 3e-2 on [0,1]-valued outputs, PSNR >= 40 dB on the render;
+the fp32-class NeRF path (precision = fp32) is held to 2e-4-class bounds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_ref
+from tests import common
+from tests.golden import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_models.npz'))
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+
+
+def fill(network, pairs):
+    assert len(network.layers) == len(pairs)
+    for layer, (k, b) in zip(network.layers, pairs):
+        layer.kernel.data.copy_(torch.from_numpy(k))
+        layer.bias.data.copy_(torch.from_numpy(b))
+
+
+def make(name, cuda, **over):
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(0)
+    return get_model_class(name)(make_config(name, **over)).to(cuda)
+
+
+# ---------------------------------------------------------------------------------------------- NeRF
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
+def test_nerf_plugin_render_vs_reference_outputs(nfx_lib, cuda, prec):
+    model = make('nerf', cuda, precision=prec)
+    nets = common.nerf_nets(seed=gi.NERF_SEED)
+    np.testing.assert_allclose(gi.checksum_nerf(nets), GOLD['nerf_weight_checksum'], rtol=1e-6)
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            fill(model.net[pref + part], net[part])
+    rayo, rayd, gt = gi.nerf_rays()
+    n = rayo.shape[0]
+    batch = (['x'] * n, torch.tensor([[8, 8]] * n), dev(rayo, cuda), dev(rayd, cuda), dev(gt, cuda))
+    pred, gt_t, loss_kwargs, to_vis = model(batch, mode='test')
+    # rays whose last-sample logit sits inside the rounding noise flip between "hit" and "background"
+    # (dist_last = 1e10, nerf.py:186-191): excluded from the max-abs bound only (see test_gpu_nerf.py)
+    _, _, aux = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1])
+    band = 0.06 if prec == 'bf16' else 1e-2
+    ok_c = np.abs(aux['rgbs_coarse'][:, -1, 3]) > band
+    ok_f = ok_c & (np.abs(aux['rgbs_fine'][:, -1, 3]) > band)
+    assert ok_f.mean() > 0.7
+    tol_rgb, tol_occu, tol_med = (3e-2, 8e-2, 5e-3) if prec == 'bf16' else (2e-3, 2e-3, 1e-4)
+    for lvl, ok in (('coarse', ok_c), ('fine', ok_f)):
+        rgb = to_vis[lvl + '_rgb'].cpu().numpy()
+        want = GOLD['nerf_%s_rgb' % lvl]
+        err = np.abs(rgb - want).max(-1)
+        assert err[ok].max() <= tol_rgb, (lvl, err[ok].max())
+        assert np.median(err) <= tol_med, (lvl, np.median(err))
+        occu = to_vis[lvl + '_occu'].cpu().numpy()
+        assert np.abs(occu - GOLD['nerf_%s_occu' % lvl])[ok].max() <= tol_occu
+        psnr = nerf_ref.psnr_uint8_luma(rgb.reshape(8, 8, 3), want.reshape(8, 8, 3))
+        assert psnr >= (40. if prec == 'bf16' else 55.), (lvl, psnr)
+    loss = float(model.compute_loss(pred, gt_t, **loss_kwargs))
+    assert abs(loss - float(GOLD['nerf_loss'])) <= (2e-3 if prec == 'bf16' else 1e-4) * float(GOLD['nerf_loss'])
+
+
+def test_sampler_and_compositing_kernels_vs_reference_outputs(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    z, w, sigma, rd = gi.sampler_inputs()
+    got = ops.sample_fine(dev(z, cuda), dev(w, cuda), 128).cpu().numpy()
+    bad = np.abs(got - GOLD['nerf_z_fine']) > 1e-5
+    assert bad.mean() < 2e-3 and np.all(np.diff(got, axis=1) >= 0)
+    np.testing.assert_allclose(ops.gen_z(2., 6., 64, 3, device=cuda).cpu().numpy(), GOLD['nerf_gen_z'], atol=1e-6)
+    raw = np.zeros((32, 64, 4), np.float32)
+    raw[..., 3] = sigma
+    weights = ops.composite_fwd(dev(raw, cuda), dev(z, cuda), dev(rd, cuda), white_bg=True)[4].cpu().numpy()
+    np.testing.assert_allclose(weights, GOLD['nerf_acc_weights'], rtol=1e-4, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- shape / BRDF prior
+def surface_batch(cuda):
+    rayo, rgb, alpha, xyz, normal, lvis = gi.surface_batch(512)
+    n = rayo.shape[0]
+    return (['x'] * n, torch.tensor([[4, n // 4]] * n), dev(rayo, cuda), dev(np.zeros_like(rayo), cuda),
+            dev(rgb, cuda), dev(alpha, cuda), dev(xyz, cuda), dev(normal, cuda), dev(lvis, cuda))
+
+
+def test_shape_plugin_vs_reference_outputs(nfx_lib, cuda):
+    model = make('shape', cuda, xyz_jitter_std='0')
+    net = gi.nerfactor_net(3)
+    for part in ('normal_mlp', 'normal_out', 'lvis_mlp', 'lvis_out'):
+        fill(model.net[part], net[part])
+    pred, gt, kw, _ = model(surface_batch(cuda), mode='test')
+    assert np.abs(pred['normal'].cpu().numpy() - GOLD['shape_normal']).max() < 3e-2
+    assert np.abs(pred['lvis'].cpu().numpy() - GOLD['shape_lvis']).max() < 3e-2
+    loss = model.compute_loss(pred, gt, **kw).cpu().numpy()
+    np.testing.assert_allclose(loss, GOLD['shape_loss'], rtol=5e-2, atol=2e-3)
+
+
+def test_brdf_prior_plugin_vs_reference_outputs(nfx_lib, cuda, tmp_path):
+    for name in gi.BRDF_NAMES:
+        (tmp_path / ('train_%s.npz' % name)).write_bytes(b'')
+    model = make('brdf', cuda, data_root=str(tmp_path))
+    assert model.brdf_names == gi.BRDF_NAMES
+    bnet = gi.brdf_net()
+    fill(model.net['brdf_mlp'], bnet['brdf_mlp'])
+    fill(model.net['brdf_out'], bnet['brdf_out'])
+    model.latent_code.z = gi.latent_codes()
+    model.to(cuda)
+    i, rusink, refl = gi.brdf_batch()
+    n = rusink.shape[0]
+    batch = (['x'] * n, torch.from_numpy(i).to(cuda), None, None, None, dev(rusink, cuda), dev(refl, cuda))
+    pred, gt, kw, to_vis = model(batch, mode='vali')
+    np.testing.assert_allclose(pred['brdf'].cpu().numpy(), GOLD['brdf_pred'], rtol=1e-4)
+    np.testing.assert_allclose(pred['brdf_reci'].cpu().numpy(), GOLD['brdf_pred_reci'], rtol=1e-4)
+    np.testing.assert_array_equal(to_vis['z'].cpu().numpy(), GOLD['brdf_z'])
+    np.testing.assert_allclose(float(model.compute_loss(pred, gt, **kw)), float(GOLD['brdf_loss']), rtol=1e-4)
+    np.testing.assert_allclose(model.latent_code.interp(0.25, 0, 0.75, 2).detach().cpu().numpy(),
+                               GOLD['brdf_interp'], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- NeRFactor
+@pytest.mark.parametrize('tag', ['nfl', 'nfm'])
+def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag):
+    learned = tag == 'nfl'
+    name = 'nerfactor' if learned else 'nerfactor_microfacet'
+    model = make(name, cuda, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
+                 test_envmap_dir='')
+    net = gi.nerfactor_net(3 if learned else 1)
+    for part in net:
+        fill(model.net[part], net[part])
+    if learned:
+        bnet = gi.brdf_net()
+        fill(model.brdf_model.net['brdf_mlp'], bnet['brdf_mlp'])
+        fill(model.brdf_model.net['brdf_out'], bnet['brdf_out'])
+    model._light.data.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE[tag])))
+    pred, gt, kw, _ = model(surface_batch(cuda), mode='test', relight_olat=True)
+    for k in ('normal', 'lvis', 'albedo', 'brdf', 'rgb'):
+        err = np.abs(pred[k].cpu().numpy() - GOLD['%s_test_%s' % (tag, k)]).max()
+        assert err < 3e-2, (k, err)
+    keys = [str(k) for k in GOLD['%s_olat_keys' % tag]]
+    idx = [int(k[:4]) * 32 + int(k[5:]) for k in keys]
+    olat = pred['rgb_olat'].cpu().numpy()
+    assert olat.shape == (24, 512, 3)
+    assert np.abs(olat[:, idx] - GOLD['%s_test_rgb_olat' % tag]).max() < 6e-2     # one light x 200: steep tonemap
+    loss = model.compute_loss(pred, gt, **dict(kw, mode='vali')).cpu().numpy()
+    np.testing.assert_allclose(loss, GOLD['%s_vali_loss' % tag], atol=5e-3)
