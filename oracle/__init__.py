@@ -11,8 +11,8 @@ float32 mirrors TF's compute type, float64 is the anchor) and in torch-CPU fp32
 (``torch_ref.py``, the timed CPU baseline).  How it is pinned:
 
 * **Against the reference's own model code, run here.**  ``tests/golden/make_reference_golden.py``
-  imports the unmodified ``nerfactor/models/{nerf,shape,brdf,nerfactor,nerfactor_microfacet}.py``
-  (+ ``networks/``, ``util/``, ``brdf/microfacet``) from the reference tree, configures them from the
+  imports the unmodified ``nerfactor/models/{nerf,shape,brdf,nerfactor,nerfactor_microfacet}.py`` and
+  ``nerfactor/geometry_from_nerf.py`` (+ ``networks/``, ``util/``, ``brdf/microfacet``) from the reference tree, configures them from the
   reference's own ``config/*.ini``, and executes ``Model.call`` / ``compute_loss`` on a NumPy stand-in
   for the TensorFlow API (``tests/golden/tf_shim``); the outputs are committed as
   ``tests/golden/reference_models.npz`` and ``tests/test_cpu_reference_golden.py`` holds every oracle
@@ -24,8 +24,8 @@ float32 mirrors TF's compute type, float64 is the anchor) and in torch-CPU fp32
   ``xiuminglib.metric.PSNR``, ``xiuminglib.img.rgb2lum`` / ``linear2srgb``.
 * **What stays UNPINNED**: the TensorFlow kernels themselves (the shim implements their documented
   semantics in NumPy, so a TF-internal rounding or an undocumented behaviour is not captured), the
-  autodiff paths (no ``tf.GradientTape`` in the shim: geometry_from_nerf's normals and all training
-  gradients are checked against torch autograd of the restatement instead), and the TF checkpoint
+  training gradients (the shim's ``tf.GradientTape`` is forward-mode and covers only geometry_from_nerf's
+  d sigma / dx, which IS pinned; weight gradients are checked against torch autograd of the restatement), and the TF checkpoint
   reader (no TF-written file available).
 
 Every function cites the reference ``file:line`` (relative to the reference tree) it follows.

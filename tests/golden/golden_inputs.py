@@ -7,6 +7,8 @@ from tests import common
 
 NERF_SEED = 21
 LIGHT_SCALE = {'nfl': 0.3, 'nfm': 2.}      # keeps most pixels of both variants below the clip at 1
+GEOM_RAYS, GEOM_LIGHT_H, GEOM_SURF_IDX = 16, 8, [3, 4, 5, 11, 13, 15]
+GEOM_BBOX = '-1.5,1.5,-1.5,1.5,-1.5,1.5'
 BRDF_NAMES = ['alum-bronze', 'blue-fabric', 'chrome', 'delrin', 'nylon']   # sorted, as xm.os.sortglob returns them
 
 
@@ -113,3 +115,11 @@ def brdf_batch():
 
 def light_probe(scale=2.):
     return _f32(np.random.default_rng(47).uniform(0, 1, (16, 32, 3)) ** 2 * scale)
+
+
+def geom_bbox_points():
+    """Surface points inside GEOM_BBOX whose shadow rays (length 1) partly leave it, and their unit normals."""
+    rng = np.random.default_rng(48)
+    pts = rng.uniform(-1.2, 1.2, (5, 3))
+    nrm = rng.normal(size=(5, 3))
+    return _f32(pts), _f32(nrm / np.linalg.norm(nrm, axis=1, keepdims=True))

@@ -11,6 +11,7 @@ unmodified and configured from the reference's own nerfactor/config/*.ini files 
   nerfactor/models/brdf.py                 Model._eval_brdf_at (learned BRDF MLP, both reciprocal halves), compute_loss
   nerfactor/models/nerfactor.py            Model.call (test, OLAT relight) / train-mode call with jitter + compute_loss
   nerfactor/models/nerfactor_microfacet.py Model.call + compute_loss
+  nerfactor/geometry_from_nerf.py          compute_depth_and_normal (GradientTape normals), compute_light_visibility
   nerfactor/util/geom.py                   gen_world2local, dir2rusink
   brdf/microfacet/microfacet.py            Microfacet.__call__
 
@@ -39,6 +40,7 @@ from nerfactor.models.brdf import Model as BrdfModel  # noqa: E402
 from nerfactor.models.nerfactor import Model as NerfactorModel  # noqa: E402
 from nerfactor.models.nerfactor_microfacet import Model as MicrofacetModel  # noqa: E402
 from brdf.microfacet.microfacet import Microfacet  # noqa: E402
+from nerfactor import geometry_from_nerf as gfn  # noqa: E402
 
 from oracle import nerf_ref, nerfactor_ref  # noqa: E402  (weight generators only)
 from tests import common  # noqa: E402
@@ -94,6 +96,34 @@ def run_nerf():
     put('nerf_acc_weights', NerfModel.accumulate_sigma(*as_tensors(sigma, z, rd)))
     put('nerf_gen_z_disp', NerfModel.gen_z(2., 6., 64, 3, lin_in_disp=True))
     put('nerf_gen_z', NerfModel.gen_z(2., 6., 64, 3))
+    return model, cfg
+
+
+# ------------------------------------------------------------------------------------------------ geometry_from_nerf
+def run_geometry(model, cfg):
+    """The reference's surface extraction on the same NeRF: 128 + 192 samples per ray, normals from the batch Jacobian
+    of the fine density (forward-mode tape of the shim), then shadow rays from 6 surface points to 8 x 16 lights."""
+    flags = gfn.FLAGS
+    flags.light_h, flags.lpix_chunk, flags.mlp_chunk, flags.lvis_far, flags.scene_bbox = gi.GEOM_LIGHT_H, 5, 4096, 1., None
+    rayo, rayd, _ = gi.nerf_rays()
+    rayo, rayd = as_tensors(rayo[:gi.GEOM_RAYS], rayd[:gi.GEOM_RAYS])
+    rayd = tf.linalg.l2_normalize(rayd, axis=1)
+    occu, depth, normal = gfn.compute_depth_and_normal(model, rayo, rayd, cfg)
+    put('geo_occu', occu)
+    put('geo_depth', depth)
+    put('geo_normal', normal)
+    surf = np.asarray(rayo + rayd * depth[:, None])[gi.GEOM_SURF_IDX]
+    nrm = np.asarray(normal)[gi.GEOM_SURF_IDX]
+    put('geo_surf', surf)
+    put('geo_surf_normal', nrm)
+    put('geo_lvis', gfn.compute_light_visibility(model, *as_tensors(surf, nrm), cfg))
+    flags.scene_bbox = gi.GEOM_BBOX
+    occu, depth, normal = gfn.compute_depth_and_normal(model, rayo, rayd, cfg)
+    put('geo_bbox_occu', occu)
+    put('geo_bbox_depth', depth)
+    put('geo_bbox_normal', normal)
+    put('geo_bbox_lvis', gfn.compute_light_visibility(model, *as_tensors(*gi.geom_bbox_points()), cfg))
+    flags.scene_bbox = None
 
 
 # ------------------------------------------------------------------------------------------------ geometry helpers
@@ -228,7 +258,8 @@ def run_nerfactor(tmp, brdf_root, learned):
 
 def main():
     tf.random.set_seed(7)
-    run_nerf()
+    model, cfg = run_nerf()
+    run_geometry(model, cfg)
     run_geom()
     run_shape()
     with tempfile.TemporaryDirectory() as tmp:

@@ -17,11 +17,48 @@ __version__ = '2.3-numpy-shim'
 
 
 class Tensor(_np.ndarray):
+    """float32/int32 array.  `_tangent` ([..., 3], forward-mode derivative with respect to the watched [N, 3] input of
+    the same row) is set by GradientTape.watch and carried only by the operations listed in the GradientTape note."""
+    _tangent = None
+
     def numpy(self):
         return _np.asarray(self)
 
     def get_shape(self):
         return _Shape(self.shape)
+
+    def _lin(self, other, out, scale_self, scale_other):
+        ts, to = self._tangent, getattr(other, '_tangent', None)
+        if ts is None and to is None:
+            return out
+        t = 0
+        if ts is not None:
+            t = t + ts * scale_self
+        if to is not None:
+            t = t + to * scale_other
+        out._tangent = _np.broadcast_to(t, out.shape + (3,)).astype(_np.float32)
+        return out
+
+    def __add__(self, o):
+        return self._lin(o, _np.ndarray.__add__(self, o), 1, 1)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._lin(o, _np.ndarray.__sub__(self, o), 1, -1)
+
+    def __neg__(self):
+        return self._lin(None, _np.ndarray.__neg__(self), -1, 0)
+
+    def __mul__(self, o):
+        if getattr(o, '_tangent', None) is not None:
+            raise NotImplementedError('product of two watched tensors')
+        out = _np.ndarray.__mul__(self, o)
+        if self._tangent is not None:
+            out._tangent = (self._tangent * _np.asarray(o, _np.float32)[..., None]).astype(_np.float32)
+        return out
+
+    __rmul__ = __mul__
 
 
 class _Shape(tuple):
@@ -31,6 +68,8 @@ class _Shape(tuple):
 
 def _t(x, dtype=None):
     """tf.convert_to_tensor's dtype inference: Python float -> float32, Python int -> int32."""
+    if isinstance(x, Tensor) and (dtype is None or x.dtype == as_dtype(dtype)):
+        return x                                   # keeps a forward-mode tangent attached
     if isinstance(x, _np.ndarray):
         a = x
     else:
@@ -103,7 +142,13 @@ def expand_dims(x, axis):
 
 
 def concat(values, axis):
-    return _t(_np.concatenate([_t(v) for v in values], axis))
+    values = [_t(v) for v in values]
+    out = _t(_np.concatenate(values, axis))
+    if any(v._tangent is not None for v in values):
+        ax = axis if axis >= 0 else out.ndim + axis
+        out._tangent = _np.concatenate([v._tangent if v._tangent is not None else _np.zeros(v.shape + (3,), _np.float32)
+                                        for v in values], ax)
+    return out
 
 
 def stack(values, axis=0):
@@ -167,8 +212,25 @@ def _un(f):
     return lambda x, *a, **k: _t(f(_t(x), *a, **k))
 
 
-sin, cos, exp, sqrt, square, abs = (_un(f) for f in (_np.sin, _np.cos, _np.exp, _np.sqrt, _np.square,  # noqa: A001
-                                                       _np.abs))
+exp, sqrt, square, abs = (_un(f) for f in (_np.exp, _np.sqrt, _np.square, _np.abs))  # noqa: A001
+
+
+def sin(x):
+    x = _t(x)
+    out = _t(_np.sin(_np.asarray(x)))
+    if x._tangent is not None:
+        out._tangent = _np.cos(_np.asarray(x))[..., None] * x._tangent
+    return out
+
+
+def cos(x):
+    x = _t(x)
+    out = _t(_np.cos(_np.asarray(x)))
+    if x._tangent is not None:
+        out._tangent = -_np.sin(_np.asarray(x))[..., None] * x._tangent
+    return out
+
+
 acos = _un(_np.arccos)
 
 
@@ -200,6 +262,10 @@ def logical_or(a, b):
     return _np.logical_or(a, b)
 
 
+def logical_and(a, b):
+    return _np.logical_and(a, b)
+
+
 def clip_by_value(x, clip_value_min, clip_value_max):
     x = _t(x)
     return _t(_np.clip(x, _np.asarray(clip_value_min, x.dtype), _np.asarray(clip_value_max, x.dtype)))
@@ -226,7 +292,12 @@ def cumsum(x, axis=0):
 
 
 def matmul(a, b):
-    return _t(_np.matmul(_t(a), _t(b)))
+    a, b = _t(a), _t(b)
+    out = _t(_np.matmul(_np.asarray(a), _np.asarray(b)))
+    if a._tangent is not None:
+        assert a.ndim == 2 and b._tangent is None
+        out._tangent = _np.einsum('ndk,dm->nmk', a._tangent, _np.asarray(b)).astype(_np.float32)
+    return out
 
 
 def einsum(eq, *ops):
@@ -244,7 +315,8 @@ def where(condition, x=None, y=None):
     return _t(_np.where(condition, x, y).astype(_np.result_type(x, y)))
 
 
-def boolean_mask(tensor, mask):
+def boolean_mask(tensor, mask, axis=None):
+    assert axis in (None, 0)
     return _t(_np.asarray(tensor)[_np.asarray(mask, _np.bool_)])
 
 
@@ -309,6 +381,28 @@ def custom_gradient(f):
     return wrapped
 
 
+class GradientTape:
+    """Forward-mode stand-in for the one pattern the reference uses (geometry_from_nerf.py:289-295): watch an [N, 3]
+    tensor, push it through positional encoding and Dense/ReLU layers, ask for the batch Jacobian of an [N, M] output.
+    Tangents ride on Tensor._tangent through: + - * (by an unwatched factor), tf.sin, tf.cos, tf.concat, tf.matmul,
+    tf.nn.relu, tf.identity.  Any other operation drops the tangent and batch_jacobian() then fails loudly."""
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def watch(self, x):
+        assert isinstance(x, Tensor) and x.ndim == 2 and x.shape[1] == 3
+        x._tangent = _np.broadcast_to(_np.eye(3, dtype=_np.float32), (x.shape[0], 3, 3)).copy()
+
+    def batch_jacobian(self, target, source):
+        if getattr(target, '_tangent', None) is None:
+            raise RuntimeError('the watched tensor reached the target through an operation this shim cannot '
+                               'differentiate')
+        return _np.asarray(target._tangent, _np.float32).view(Tensor)
+
+
 def random_normal_initializer(mean=0., stddev=1.):
     def init(shape, dtype='float32'):  # noqa: A002
         return _t((random._rng.standard_normal(tuple(shape)) * stddev + mean).astype(as_dtype(dtype)))
@@ -366,7 +460,10 @@ def _floormod(x, y):
 
 def _relu(x):
     x = _t(x)
-    return _t(_np.maximum(x, _np.asarray(0, x.dtype)))
+    out = _t(_np.maximum(_np.asarray(x), _np.asarray(0, x.dtype)))
+    if x._tangent is not None:
+        out._tangent = (_np.asarray(x) > 0)[..., None] * x._tangent
+    return out
 
 
 def _softplus(x):
@@ -380,8 +477,8 @@ def _pow(x, y):
 
 
 math = _NS(sin=sin, cos=cos, log=_un(_np.log), sigmoid=_sigmoid, cumprod=_cumprod, divide_no_nan=_divide_no_nan,
-           floormod=_floormod, minimum=minimum, maximum=maximum, pow=_pow, sqrt=sqrt, exp=exp, abs=abs,
-           softplus=_softplus)
+           floormod=_floormod, l2_normalize=_l2_normalize, minimum=minimum, maximum=maximum, pow=_pow, sqrt=sqrt,
+           exp=exp, abs=abs, softplus=_softplus)
 linalg = _NS(l2_normalize=_l2_normalize, norm=_norm, cross=_cross)
 nn = _NS(relu=_relu, sigmoid=_sigmoid, softplus=_softplus)
 

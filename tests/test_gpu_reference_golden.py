@@ -155,3 +155,41 @@ def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag):
     assert np.abs(olat[:, idx] - GOLD['%s_test_rgb_olat' % tag]).max() < 6e-2     # one light x 200: steep tonemap
     loss = model.compute_loss(pred, gt, **dict(kw, mode='vali')).cpu().numpy()
     np.testing.assert_allclose(loss, GOLD['%s_vali_loss' % tag], atol=5e-3)
+
+
+# ---------------------------------------------------------------------------------------------- geometry_from_nerf
+@pytest.mark.parametrize('bbox', [False, True])
+def test_geometry_extraction_vs_reference_outputs(nfx_lib, cuda, bbox):
+    """compute_depth_and_normal / compute_light_visibility of the plugin (density-gradient kernel, shadow-ray
+    marching) against what the reference's own functions produced for the same NeRF (bf16 bounds of
+    tests/test_gpu_nerf.py::test_geometry_extraction_vs_oracle)."""
+    from nerfactor_amd.nerfactor import geometry_from_nerf as G
+    from nerfactor_amd.nerfactor.config import make_config
+    cfg = make_config('nerf')
+    model = make('nerf', cuda)
+    nets = common.nerf_nets(seed=gi.NERF_SEED)
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            fill(model.net[pref + part], net[part])
+    box = tuple(float(v) for v in gi.GEOM_BBOX.split(',')) if bbox else None
+    tag = 'geo_bbox_' if bbox else 'geo_'
+    rayo, rayd, _ = gi.nerf_rays()
+    rayo, rayd = rayo[:gi.GEOM_RAYS], nerf_ref.l2_normalize(rayd[:gi.GEOM_RAYS], 1, 1e-12)
+    with torch.no_grad():
+        occu, depth, normal = (t.cpu().numpy() for t in
+                               G.compute_depth_and_normal(model, dev(rayo, cuda), dev(rayd, cuda), cfg, bbox=box))
+    assert np.quantile(np.abs(occu - GOLD[tag + 'occu']), 0.9) <= 3e-2
+    assert np.quantile(np.abs(depth - GOLD[tag + 'depth']), 0.9) <= 5e-2
+    dn = np.abs(normal - GOLD[tag + 'normal']).max(1)
+    assert np.quantile(dn, 0.9) <= 8e-2 and np.median(dn) <= 4e-2, (np.quantile(dn, 0.9), np.median(dn))
+    if bbox:
+        surf, nrm = gi.geom_bbox_points()
+    else:
+        surf, nrm = GOLD['geo_surf'], GOLD['geo_surf_normal']
+    with torch.no_grad():
+        lvis = G.compute_light_visibility(model, dev(surf, cuda), dev(nrm, cuda), cfg, lvis_far=1.,
+                                          light_h=gi.GEOM_LIGHT_H, bbox=box).cpu().numpy()
+    want = GOLD[tag + 'lvis']
+    assert lvis.shape == want.shape
+    assert np.mean((lvis == 0) != (want == 0)) < 0.02                       # same front-lit set
+    assert np.quantile(np.abs(lvis - want), 0.9) <= 4e-2 and np.abs(lvis - want).mean() <= 2e-2
