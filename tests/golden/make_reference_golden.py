@@ -12,6 +12,7 @@ unmodified and configured from the reference's own nerfactor/config/*.ini files 
   nerfactor/models/nerfactor.py            Model.call (test, OLAT relight) / train-mode call with jitter + compute_loss
   nerfactor/models/nerfactor_microfacet.py Model.call + compute_loss
   nerfactor/geometry_from_nerf.py          compute_depth_and_normal (GradientTape normals), compute_light_visibility
+  nerfactor/datasets/nerf.py, nerf_shape.py  Dataset._glob / _load_data / _process_example_postcache (vali, test)
   nerfactor/util/geom.py                   gen_world2local, dir2rusink
   brdf/microfacet/microfacet.py            Microfacet.__call__
 
@@ -41,9 +42,12 @@ from nerfactor.models.nerfactor import Model as NerfactorModel  # noqa: E402
 from nerfactor.models.nerfactor_microfacet import Model as MicrofacetModel  # noqa: E402
 from brdf.microfacet.microfacet import Microfacet  # noqa: E402
 from nerfactor import geometry_from_nerf as gfn  # noqa: E402
+from nerfactor.datasets.nerf import Dataset as NerfDataset  # noqa: E402
+from nerfactor.datasets.nerf_shape import Dataset as ShapeDataset  # noqa: E402
 
 from oracle import nerf_ref, nerfactor_ref  # noqa: E402  (weight generators only)
 from tests import common  # noqa: E402
+from tests import synth_scene  # noqa: E402
 from tests.golden import golden_inputs as gi  # noqa: E402
 
 OUT = {}
@@ -256,6 +260,31 @@ def run_nerfactor(tmp, brdf_root, learned):
     put('%s_olat_keys' % tag, np.array(list(model.novel_olat.keys())))
 
 
+# ------------------------------------------------------------------------------------------------ datasets
+def run_datasets(tmp):
+    """The reference's dataset classes on a synthetic scene in its on-disk layout (tests/synth_scene.py, 12 x 16 views):
+    ray generation from metadata.json, RGBA compositing, the NeRF-derived buffers, flattening to per-ray batches."""
+    data_root, nerf_root = synth_scene.write_scene(tmp, **gi.SCENE_KW)
+    over = dict(data_root=data_root, data_nerf_root=nerf_root, imh=gi.SCENE_KW['imh'])
+
+    def load(ds):       # _process_example_precache: tf.py_function(_load_data, Tout=(string, float32, ...)) casts
+        id_, *arrays = ds._load_data(ds.files[0])
+        return (id_,) + tuple(tf.convert_to_tensor(np.asarray(a, np.float32)) for a in arrays)
+
+    for mode in ('vali', 'test'):
+        ds = NerfDataset(ref_config('nerf.ini', **over), mode)
+        batch = ds._process_example_postcache(*load(ds))
+        assert str(np.asarray(batch[0])[0]) == ('val_000' if mode == 'vali' else 'test_000')
+        put('ds_nerf_%s_hw' % mode, batch[1])
+        for k, v in zip(('rayo', 'rayd', 'rgb'), batch[2:]):
+            put('ds_nerf_%s_%s' % (mode, k), v)
+        ds = ShapeDataset(ref_config('nerfactor.ini', **over), mode)
+        batch = ds._process_example_postcache(*load(ds))
+        for k, v in zip(('rayo', 'rayd', 'rgb', 'alpha', 'xyz', 'normal', 'lvis'), batch[2:]):
+            put('ds_shape_%s_%s' % (mode, k), v)
+    put('ds_n_train_views', np.int32(len(NerfDataset(ref_config('nerf.ini', **over), 'train').files)))
+
+
 def main():
     tf.random.set_seed(7)
     model, cfg = run_nerf()
@@ -263,6 +292,7 @@ def main():
     run_geom()
     run_shape()
     with tempfile.TemporaryDirectory() as tmp:
+        run_datasets(os.path.join(tmp, 'scene'))
         run_brdf(tmp)
         root = os.path.join(tmp, 'merl_npz')
         run_nerfactor(os.path.join(tmp, 'a'), root, learned=True)

@@ -544,5 +544,7 @@ class _Checkpoint:
 
 
 train = _NS(Checkpoint=_Checkpoint)
+data = _NS(experimental=_NS(AUTOTUNE=-1))      # the reference's Dataset.__init__ reads the constant only
+string = _np.str_
 
 from . import keras  # noqa: E402,F401
