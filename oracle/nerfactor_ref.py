@@ -232,11 +232,14 @@ def init_nerfactor_net(rng, z_dim, dtype=np.float32):
 def nerfactor_call(batch, net, lxyz, lareas, light, variant='microfacet', brdf_net=None, f0=0.04,
                    brdf_scale=1., albedo_slope=0.77, albedo_bias=0.03, xyz_scale=1.,
                    to_srgb=True, probes=None, olat=None, xyz_noise=None, normalize_z=False,
-                   quant=None):
+                   quant=None, shape_mode='finetune', albedo_scales=None, albedo_override=None,
+                   brdf_z_override=None):
     """Model.call (nerfactor.py:181-313), shape_mode in (scratch, finetune, frozen).
     batch = (rayo, rgb, alpha, xyz, normal, lvis) flattened [N,...].
     probes: list of [h,w,3] lights -> rgb_probes [N,P,3]; olat: (inten, ambient) -> rgb_olat [N,L,3].
-    xyz_noise: the jitter tensor for the masked points (tf.random.normal stand-in) or None."""
+    xyz_noise: the jitter tensor for the masked points (tf.random.normal stand-in) or None.
+    shape_mode 'nerf' (:204-207, :214-216): normals / visibility are the NeRF-derived buffers of the batch.
+    albedo_scales [3], albedo_override [3] or [N,3], brdf_z_override [z_dim]: the editing hooks of :236-261."""
     rayo, rgb, alpha, xyz, normal, lvis = batch
     dt = xyz.dtype.type
     mask = alpha[:, 0] > 0
@@ -256,6 +259,17 @@ def nerfactor_call(batch, net, lxyz, lareas, light, variant='microfacet', brdf_n
 
     normal_pred, lvis_pred, albedo, brdf_prop = heads(xyz_m)
     jit = heads(xyz_m + xyz_noise) if xyz_noise is not None else (None,) * 4
+    if shape_mode == 'nerf':
+        normal_pred = l2_normalize(normal[mask], 1, 1e-6)
+        lvis_pred = np.clip(lvis[mask], dt(1e-8), dt(1.))
+        jit = (None, None) + tuple(jit[2:])
+    if albedo_scales is not None:
+        albedo = np.asarray(albedo_scales, xyz.dtype).reshape(1, 3) * albedo
+    if albedo_override is not None:
+        ao = np.asarray(albedo_override, xyz.dtype)
+        albedo = np.tile(ao[None, :], (albedo.shape[0], 1)) if ao.ndim == 1 else ao[mask]
+    if brdf_z_override is not None:
+        brdf_prop = np.tile(np.asarray(brdf_z_override, xyz.dtype).reshape(1, -1), (brdf_prop.shape[0], 1))
     if variant == 'microfacet':
         brdf = microfacet(surf2l, surf2c, normal_pred, albedo, brdf_prop, f0=f0)
     else:

@@ -124,3 +124,10 @@ def geom_bbox_points():
     pts = rng.uniform(-1.2, 1.2, (5, 3))
     nrm = rng.normal(size=(5, 3))
     return _f32(pts), _f32(nrm / np.linalg.norm(nrm, axis=1, keepdims=True))
+
+
+def edit_inputs(z_dim):
+    """(albedo_scales [3], albedo_override [3], albedo_override [24,3], brdf_z_override [z_dim])."""
+    rng = np.random.default_rng(49)
+    z = rng.uniform(0.2, 0.8, z_dim)
+    return _f32([0.9, 1.1, 0.8]), _f32([0.6, 0.3, 0.2]), _f32(rng.uniform(0.1, 0.9, (24, 3))), _f32(z)

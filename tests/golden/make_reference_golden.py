@@ -258,6 +258,25 @@ def run_nerfactor(tmp, brdf_root, learned):
     put('%s_train_rgb' % tag, pred['rgb'])
     put('%s_train_loss' % tag, model.compute_loss(pred, gt, **loss_kwargs))
     put('%s_olat_keys' % tag, np.array(list(model.novel_olat.keys())))
+    # the editing hooks of Model.call (used by nerfactor/test.py): albedo scaling / override, BRDF override
+    scales, ao_flat, ao_map, z_over = gi.edit_inputs(z_dim)
+    for name, kw in (('scaled', dict(albedo_scales=tf.convert_to_tensor(scales), brdf_z_override=tf.convert_to_tensor(z_over))),
+                     ('flat_albedo', dict(albedo_override=tf.convert_to_tensor(ao_flat))),
+                     ('albedo_map', dict(albedo_override=tf.convert_to_tensor(ao_map)))):
+        pred, _, _, _ = model.call(batch, mode='test', **kw)
+        put('%s_edit_%s_rgb' % (tag, name), pred['rgb'])
+        put('%s_edit_%s_albedo' % (tag, name), pred['albedo'])
+        put('%s_edit_%s_brdf' % (tag, name), pred['brdf'])
+    if not learned:
+        # shape_mode = nerf: no shape MLPs, the NeRF-derived normals and visibility of the batch are used as they are
+        over_nerf = dict(over, shape_mode='nerf')
+        model = cls(ref_config(ini, **over_nerf), debug=True)
+        for part in ('albedo_mlp', 'albedo_out', 'brdf_z_mlp', 'brdf_z_out'):
+            set_layers(model.net[part], net[part])
+        model._light = tf.Variable(gi.light_probe(gi.LIGHT_SCALE[tag]))
+        pred, gt, loss_kwargs, _ = model.call(batch, mode='test')
+        for k in ('rgb', 'normal', 'lvis'):
+            put('%s_shapenerf_%s' % (tag, k), pred[k])
 
 
 # ------------------------------------------------------------------------------------------------ datasets

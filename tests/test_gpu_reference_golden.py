@@ -158,6 +158,42 @@ def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag):
     np.testing.assert_allclose(loss, GOLD['%s_vali_loss' % tag], atol=5e-3)
 
 
+@pytest.mark.parametrize('tag', ['nfl', 'nfm'])
+def test_nerfactor_plugin_editing_hooks_vs_reference_outputs(nfx_lib, cuda, tag):
+    learned = tag == 'nfl'
+    name = 'nerfactor' if learned else 'nerfactor_microfacet'
+    model = make(name, cuda, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
+                 test_envmap_dir='')
+    net = gi.nerfactor_net(3 if learned else 1)
+    for part in net:
+        fill(model.net[part], net[part])
+    if learned:
+        bnet = gi.brdf_net()
+        fill(model.brdf_model.net['brdf_mlp'], bnet['brdf_mlp'])
+        fill(model.brdf_model.net['brdf_out'], bnet['brdf_out'])
+    model._light.data.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE[tag])))
+    scales, ao_flat, ao_map, z_over = gi.edit_inputs(3 if learned else 1)
+    for ename, edit in (('scaled', dict(albedo_scales=dev(scales, cuda), brdf_z_override=dev(z_over, cuda))),
+                        ('flat_albedo', dict(albedo_override=dev(ao_flat, cuda))),
+                        ('albedo_map', dict(albedo_override=dev(ao_map, cuda)))):
+        pred = model(surface_batch(cuda), mode='test', **edit)[0]
+        for k in ('albedo', 'brdf', 'rgb'):
+            err = np.abs(pred[k].cpu().numpy() - GOLD['%s_edit_%s_%s' % (tag, ename, k)]).max()
+            assert err < 3e-2, (ename, k, err)
+
+
+def test_nerfactor_plugin_shape_mode_nerf_vs_reference_outputs(nfx_lib, cuda):
+    model = make('nerfactor_microfacet', cuda, shape_mode='nerf', test_envmap_dir='')
+    net = gi.nerfactor_net(1)
+    for part in ('albedo_mlp', 'albedo_out', 'brdf_z_mlp', 'brdf_z_out'):
+        fill(model.net[part], net[part])
+    model._light.data.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE['nfm'])))
+    pred = model(surface_batch(cuda), mode='test')[0]
+    for k in ('normal', 'lvis'):
+        np.testing.assert_allclose(pred[k].cpu().numpy(), GOLD['nfm_shapenerf_' + k], atol=1e-5)
+    assert np.abs(pred['rgb'].cpu().numpy() - GOLD['nfm_shapenerf_rgb']).max() < 3e-2
+
+
 # ---------------------------------------------------------------------------------------------- geometry_from_nerf
 @pytest.mark.parametrize('bbox', [False, True])
 def test_geometry_extraction_vs_reference_outputs(nfx_lib, cuda, bbox):
