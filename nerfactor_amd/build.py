@@ -6,6 +6,7 @@ plain HIP shared object behind the C-ABI of include/nfx.h.
 Objects are cached under build/ (git-ignored) keyed on source + header mtimes; the .so stays
 in-tree so it travels to the GPU box with the repository snapshot.
 """
+import fcntl
 import os
 import subprocess
 import sys
@@ -69,18 +70,24 @@ def build(force=False, verbose=False, out=None):
         LIB = os.path.abspath(out)
         OBJDIR = os.path.join(ROOT, 'build', 'obj_' + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(OBJDIR, exist_ok=True)
-    srcs = _sources()
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
-    objs = [o for o, _ in results]
-    rebuilt = any(r for _, r in results)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if res.returncode != 0:
-            raise RuntimeError('link failed:\n' + res.stdout)
+    # one builder at a time: the N ranks of a multi-GPU launch all call build(); the first compiles, the others wait
+    # on the lock and then find everything up to date
+    with open(os.path.join(OBJDIR, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        srcs = _sources()
+        with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+            results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
+        objs = [o for o, _ in results]
+        rebuilt = any(r for _, r in results)
+        if rebuilt or not os.path.exists(LIB):
+            tmp = LIB + '.tmp.%d' % os.getpid()
+            cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', tmp]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                raise RuntimeError('link failed:\n' + res.stdout)
+            os.replace(tmp, LIB)      # a process that already mapped the old file keeps its inode
     return LIB
 
 
