@@ -33,7 +33,7 @@ if os.environ.get('NFX_EXTRA_DEFS'):  # experiment switches, e.g. NFX_EXTRA_DEFS
 # v_accvgpr_read; activations move to AccVGPRs, which MFMA takes as B operands).  NFX_VGPR_FORM_FILES overrides the list.
 VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554)
-PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v5.hip': VGPR_FORM}
+PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v5.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
     PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
 

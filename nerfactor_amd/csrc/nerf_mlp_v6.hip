@@ -19,7 +19,10 @@ constexpr int kNW = 4, kCT = 2;
 // ring size / fetch distance: register-staged 3 slots, chunk K+2 fetched during tile K; LDS-DMA 6 slots (78 = 6 x 13),
 // chunk K+3 issued during tile K and awaited at the end of tile K: when tile K+1 prefetches the head of chunk K+2
 // before ITS barrier, every wave's pieces of that chunk have been behind a barrier already
-template <int DMA> constexpr int ring_of = DMA ? 6 : 3;
+// DMA = 2 (variant 8): register-staged like 0, but chunk K+3 is fetched during tile K into one of TWO register sets and
+// written to its slot at the end of tile K+1: the global loads get two tile times to land instead of one, and the
+// compiler's counted vmcnt lets the newer set stay in flight across the store of the older one.
+template <int DMA> constexpr int ring_of = DMA == 1 ? 6 : 3;
 template <int DMA> constexpr int dist_of = DMA ? 3 : 2;
 template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
 constexpr int kNChunks = nerf::kNChunks;  // 78
@@ -97,6 +100,12 @@ __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Ac
     }
 }
 
+typedef __attribute__((address_space(1))) u32x4 gu32x4;   // explicit global address space: global_load, not flat_load
+
+struct Regs {
+    u32x4 r[2][6];   // two staging sets of up to six 4-KiB pieces (variant 8)
+};
+
 struct Ctx {
     char* smem;
     const char* blob;
@@ -138,7 +147,7 @@ __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
 // `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
 // (1 no weight staging, 2 no barrier, 4 no MFMA, 8 no A reads, 64 no bias reads).
 template <int K, int KS1, int KS2, int AB, int DMA, int KS1A, int KS2A, typename Epi>
-__device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, const bf16x8 (&b1)[KS1A][kCT],
+__device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_bias, const bf16x8 (&b1)[KS1A][kCT],
                                      const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
     constexpr int KS = KS1 + KS2;
     constexpr int PIECES = KS >= 16 ? 8 : 4;
@@ -149,14 +158,22 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
     const int lane = cx.tid & 63;
     const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
     Stage<DMA ? 1 : NL2, kNW> st;
-    if constexpr (DMA && !(AB & 1)) {
+    if constexpr (DMA == 1 && !(AB & 1)) {
         dma_chunk<K2>(cx);
+    } else if constexpr (DMA == 2 && !(AB & 1)) {
+        unsigned long long gb = reinterpret_cast<unsigned long long>(cx.blob);
+        asm volatile("" : "+s"(gb));   // (an integer: a laundered generic pointer would turn the loads into flat_load)
+        const gu32x4* g = reinterpret_cast<const gu32x4*>(gb + (size_t)nerf::chunk_frag_offset(K2) * kFragBytes);
+#pragma unroll
+        for (int k = 0; k < NL2; ++k) rg.r[K & 1][k] = g[k * kPieceThreads + cx.tid];
     } else if constexpr (!(AB & 1)) {
         // opaque per tile: otherwise the ~300 loop-invariant chunk addresses are hoisted out of the point-tile loop
         // and spilled (same cure as variant 2)
-        const char* gb = cx.blob;
+        unsigned long long gb = reinterpret_cast<unsigned long long>(cx.blob);
         asm volatile("" : "+s"(gb));
-        st.load(reinterpret_cast<const u32x4*>(gb + (size_t)nerf::chunk_frag_offset(K2) * kFragBytes), cx.tid);
+        const gu32x4* g = reinterpret_cast<const gu32x4*>(gb + (size_t)nerf::chunk_frag_offset(K2) * kFragBytes);
+#pragma unroll
+        for (int k = 0; k < NL2; ++k) st.r[k] = g[k * kPieceThreads + cx.tid];   // (kNW = 4: one piece group)
     }
     bf16x8 abuf[4];
     abuf[0] = pre.a[0];
@@ -184,10 +201,16 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
     });
     // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
     // mid-tile stalls on vmcnt, L2 latency under this load exceeds half a tile)
-    if constexpr (DMA && !(AB & 1)) {
+    if constexpr (DMA == 1 && !(AB & 1)) {
         // the chunk issued one tile ago must be complete before the barrier; this tile's pieces may stay in flight
         constexpr int kInFlight = nerf::chunk_frags(K2) / kNW;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
+    } else if constexpr (DMA == 2 && !(AB & 1)) {
+        // chunk K+2, fetched during tile K-1 into the other register set, to slot (K+2) % 3 = the slot tile K-1 read
+        constexpr int KP = (K + 2) % kNChunks, NLP = nerf::chunk_frags(KP) / 4;
+        u32x4* dst = reinterpret_cast<u32x4*>(cx.smem + (KP % R) * kSlotBytes);
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) dst[k * kPieceThreads + cx.tid] = rg.r[(K + 1) & 1][k];
     } else if constexpr (!(AB & 1)) {
         st.store(reinterpret_cast<u32x4*>(cx.smem + (K2 % R) * kSlotBytes), cx.tid);
     }
@@ -205,7 +228,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, const float* next_bias, cons
 // A Dense layer of NT tiles starting at chunk K0, outputs to bout.  `prev0` = pending epilogue of tile K0-1;
 // `next_bias` = bias of the tile after this layer's last one.  On return the last tile's epilogue is pending.
 template <int K0, int KS1, int KS2, int NT, bool RELU, int AB, int DMA, int KS1A, int KS2A, int NTA, typename Epi0>
-__device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const float* next_bias,
+__device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias, const float* next_bias,
                                       const bf16x8 (&b1)[KS1A][kCT], const bf16x8 (&b2)[KS2A][kCT],
                                       bf16x8 (&bout)[NTA][kCT], Acc (&accs)[2], Pre& pre, Epi0&& prev0) {
     static_for<0, NT>([&](auto T) {
@@ -213,10 +236,10 @@ __device__ __forceinline__ void layer(const Ctx& cx, const float* bias, const fl
         constexpr int K = K0 + t;
         const float* nb = t == NT - 1 ? next_bias : bias + 32 * (t + 1);
         if constexpr (t == 0) {
-            tile<K, KS1, KS2, AB, DMA>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
+            tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
         } else {
             EpiB<RELU> e{accs[(K - 1) & 1], bout[2 * (t - 1)], bout[2 * (t - 1) + 1]};
-            tile<K, KS1, KS2, AB, DMA>(cx, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
+            tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
         }
     });
 }
@@ -239,6 +262,12 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
            __builtin_amdgcn_readfirstlane(tid >> 6)};
     Acc accs[2];
     Pre pre;
+    Regs rg;
+    if constexpr (DMA == 2) {   // chunk 2 plays "fetched during tile -1": register set 1, stored at the end of tile 0
+        const u32x4* g = reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(2) * kFragBytes);
+#pragma unroll
+        for (int k = 0; k < chunk_frags(2) / 4; ++k) rg.r[1][k] = g[k * kPieceThreads + tid];
+    }
     {   // chunks 0 and 1 -> slots 0 and 1
         Stage<chunk_frags(0) / 4, kNW> s0;
         Stage<chunk_frags(1) / 4, kNW> s1;
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         s1.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(1) * kFragBytes), tid);
         s0.store(reinterpret_cast<u32x4*>(smem), tid);
         s1.store(reinterpret_cast<u32x4*>(smem + kSlotBytes), tid);
-        if constexpr (DMA) {   // fetch distance 3: chunk 2 must be resident before the first tile as well
+        if constexpr (DMA == 1) {   // fetch distance 3: chunk 2 must be resident before the first tile as well
             Stage<chunk_frags(2) / 4, kNW> s2;
             s2.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(2) * kFragBytes), tid);
             s2.store(reinterpret_cast<u32x4*>(smem + 2 * kSlotBytes), tid);
@@ -285,25 +314,25 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         using F = std::false_type;
         // chunk index K: L0 0-7, L1-4 8-39, L5 40-47, L6-7 48-63, bottleneck 64-71, sigma 72, rgb0 73-76, rgb1 77;
         // tile K accumulates in accs[K & 1]
-        layer<0, 4, 0, 8, true, AB, DMA>(cx, bl, bl + 256 * 1, pe, pe, ha, accs, pre, EpiNone{});
-        layer<8, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 1, bl + 256 * 2, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<16, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 2, bl + 256 * 3, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<24, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 3, bl + 256 * 4, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<32, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 4, bl + 256 * 5, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<40, 16, 4, 8, true, AB, DMA>(cx, bl + 256 * 5, bl + 256 * 6, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
-        layer<48, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 6, bl + 256 * 7, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
-        layer<56, 16, 0, 8, true, AB, DMA>(cx, bl + 256 * 7, bias_lds + kBiasBott, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<0, 4, 0, 8, true, AB, DMA>(cx, rg, bl, bl + 256 * 1, pe, pe, ha, accs, pre, EpiNone{});
+        layer<8, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 1, bl + 256 * 2, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<16, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 2, bl + 256 * 3, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<24, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 3, bl + 256 * 4, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<32, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 4, bl + 256 * 5, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<40, 16, 4, 8, true, AB, DMA>(cx, rg, bl + 256 * 5, bl + 256 * 6, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
+        layer<48, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 6, bl + 256 * 7, hb, pe, ha, accs, pre, pend(T{}, accs[1], hb[14], hb[15]));
+        layer<56, 16, 0, 8, true, AB, DMA>(cx, rg, bl + 256 * 7, bias_lds + kBiasBott, ha, pe, hb, accs, pre, pend(T{}, accs[1], ha[14], ha[15]));
         // bottleneck (no activation) hb -> ha; next tile = sigma (bias row 256 of the fused matrix)
-        layer<64, 16, 0, 8, false, AB, DMA>(cx, bias_lds + kBiasBott, bias_lds + kBiasBott + 256, hb, pe, ha, accs, pre,
+        layer<64, 16, 0, 8, false, AB, DMA>(cx, rg, bias_lds + kBiasBott, bias_lds + kBiasBott + 256, hb, pe, ha, accs, pre,
                                        pend(T{}, accs[1], hb[14], hb[15]));
         // sigma tile (K = 72 -> accs[0]); pending: last bottleneck tile (accs[1]); next: rgb_out[0] tile 0
-        tile<72, 16, 0, AB, DMA>(cx, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
+        tile<72, 16, 0, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
         {
             EpiSigma es{accs[0], sigma};
-            layer<73, 16, 2, 4, true, AB, DMA>(cx, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
+            layer<73, 16, 2, 4, true, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
         }
         // rgb_out[1] (K = 77 -> accs[1]); pending: last rgb_out[0] tile (K = 76 -> accs[0]); next: L0 tile 0
-        tile<77, 8, 0, AB, DMA>(cx, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
+        tile<77, 8, 0, AB, DMA>(cx, rg, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < kCT; ++c)
@@ -345,5 +374,6 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
     }
 #endif
     if (ablate == -7) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }
