@@ -32,8 +32,11 @@ if os.environ.get('NFX_EXTRA_DEFS'):  # experiment switches, e.g. NFX_EXTRA_DEFS
 # Per-source extra flags.  -amdgpu-mfma-vgpr-form: MFMA accumulators in ArchVGPRs (the epilogue reads them without
 # v_accvgpr_read; activations move to AccVGPRs, which MFMA takes as B operands).  NFX_VGPR_FORM_FILES overrides the list.
 VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
-# r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554)
-PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v5.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM}
+# r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554),
+# variant 6 1293 -> 1330 TFLOP/s, density-gradient kernel 72.5 -> 68.4 ms per 256 x 256 view; no effect on the
+# backward kernels (nerf_bwd, mlp128_bwd, brdf_bwd)
+PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v5.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
+                  'nerf_geom.hip': VGPR_FORM}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
     PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
 
@@ -52,14 +55,18 @@ def _compile(src, force, verbose):
     obj = os.path.join(OBJDIR, src + '.o')
     spath = os.path.join(CSRC, src)
     newest = max(os.path.getmtime(spath), _headers_mtime())
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
-        return obj, False
     cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + ['-x', 'hip', '-c', spath, '-o', obj]
+    stamp = obj + '.cmd'     # the command line is part of the staleness check (per-file flags, NFX_EXTRA_DEFS)
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == ' '.join(cmd)
+    if not force and same_cmd and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj, False
     if verbose:
         print(' '.join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError('hipcc failed on %s:\n%s' % (src, res.stdout))
+    with open(stamp, 'w') as h:
+        h.write(' '.join(cmd))
     return obj, True
 
 
