@@ -27,11 +27,16 @@ template <int DMA> constexpr int dist_of = DMA ? 3 : 2;
 template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
 constexpr int kNChunks = nerf::kNChunks;  // 78
 
+#ifndef NFX_V6_ADEPTH
+#define NFX_V6_ADEPTH 3
+#endif
+constexpr int kPreA = NFX_V6_ADEPTH;   // A fragments in flight ahead of their MFMAs
+
 struct Acc {
     f32x16 v[kCT];
 };
 struct Pre {
-    bf16x8 a[3];  // first three A fragments of the next tile
+    bf16x8 a[kPreA];  // first A fragments of the next tile
 };
 
 template <bool RELU>
@@ -84,6 +89,22 @@ struct EpiSigma {
 };
 
 __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
+#ifndef NFX_V6_BIAS_READ2
+    // one broadcast read group, the second column tile's accumulators copied from the first: +1.8 % on r01 once the
+    // accumulators live in ArchVGPRs (MFMA VGPR form); a second read group (NFX_V6_BIAS_READ2) costs a full LDS pass
+    const float* bt = bias_tile + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            acc.v[c][4 * g + 0] = v[0];
+            acc.v[c][4 * g + 1] = v[1];
+            acc.v[c][4 * g + 2] = v[2];
+            acc.v[c][4 * g + 3] = v[3];
+        }
+    }
+#else
 #pragma unroll
     for (int c = 0; c < kCT; ++c) {
         int hoff = 4 * (lane >> 5);
@@ -98,6 +119,7 @@ __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Ac
             acc.v[c][4 * g + 3] = v[3];
         }
     }
+#endif
 }
 
 typedef __attribute__((address_space(1))) u32x4 gu32x4;   // explicit global address space: global_load, not flat_load
@@ -151,7 +173,11 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
                                      const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
     constexpr int KS = KS1 + KS2;
     constexpr int PIECES = KS >= 16 ? 8 : 4;
+#ifdef NFX_V6_SP_LATE
+    constexpr int SP = KS >= 16 ? 12 : (PIECES < KS ? PIECES : KS - 1);   // experiment: next tile's bias later in the tile
+#else
     constexpr int SP = PIECES < KS ? PIECES : KS - 1;  // k-step after which the previous tile's epilogue is complete
+#endif
     constexpr int R = ring_of<DMA>;
     constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
     constexpr int NL2 = nerf::chunk_frags(K2) / 4;
@@ -175,15 +201,14 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
 #pragma unroll
         for (int k = 0; k < NL2; ++k) st.r[k] = g[k * kPieceThreads + cx.tid];   // (kNW = 4: one piece group)
     }
-    bf16x8 abuf[4];
-    abuf[0] = pre.a[0];
-    abuf[1] = pre.a[1];
-    abuf[2] = pre.a[2];
+    bf16x8 abuf[kPreA + 1];
+#pragma unroll
+    for (int i = 0; i < kPreA; ++i) abuf[i] = pre.a[i];
     static_for<0, KS>([&](auto S) {
         constexpr int s = decltype(S)::value;
-        if constexpr (s + 3 < KS && !(AB & 8))
-            abuf[(s + 3) % 4] = *reinterpret_cast<const bf16x8*>(f0 + (s + 3) * kFragBytes);
-        const bf16x8 a = abuf[s % 4];
+        if constexpr (s + kPreA < KS && !(AB & 8))
+            abuf[(s + kPreA) % (kPreA + 1)] = *reinterpret_cast<const bf16x8*>(f0 + (s + kPreA) * kFragBytes);
+        const bf16x8 a = abuf[s % (kPreA + 1)];
 #pragma unroll
         for (int c = 0; c < kCT; ++c) {
             const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
@@ -217,7 +242,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     if constexpr (!(AB & 8)) {
         const char* f1 = cx.smem + (K1 % R) * kSlotBytes + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(f1 + i * kFragBytes);
+        for (int i = 0; i < kPreA; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(f1 + i * kFragBytes);
     }
     // (a __builtin_amdgcn_sched_barrier(0) here costs 4 %: it stops the scheduler from draining the tail MFMAs of this
     //  tile behind the barrier; the per-tile laundering of the blob base above is what keeps the weight addresses
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + i * kFragBytes);
+        for (int i = 0; i < kPreA; ++i) pre.a[i] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + i * kFragBytes);
         bias_to_acc(bias_lds + kBiasL0, lane, accs[0]);
     }
     const long long n_tiles = (n_pts + kTilePts - 1) / kTilePts;
