@@ -171,7 +171,7 @@ def main():
     # the figure comes from the committed digest of the same workload (scripts/gpu_pmc.sh ->
     # scripts/pmc_digest.py): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch pair.
     traffic = None
-    variant = os.environ.get("NFX_NERF_VARIANT", "6")
+    variant = os.environ.get("NFX_NERF_VARIANT", "7")
     dig = os.path.join(ROOT, 'profiles', 'r01', 'pmc_variant%s_digest.json' % variant)
     if os.path.exists(dig):
         for k, v in json.load(open(dig)).items():
@@ -194,7 +194,7 @@ def main():
                 "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
                 "kernel_variant": variant},
             "roofline": {
-                "bound": "mfma", "kernel": "nerf_mlp_bf16%s_kernel (coarse + fine launches)" % ("" if variant in ("0", "1") else "_v" + {"7": "6", "8": "6"}.get(variant, variant)),
+                "bound": "mfma", "kernel": "nerf_mlp_bf16%s_kernel (coarse + fine launches)" % {"0": "", "1": "", "7": "_v6_kernel<0, 1> (LDS-DMA weight stream)", "8": "_v6_kernel<0, 2>"}.get(variant, "_v" + variant),
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch pair",
                 "algorithmic_hbm_gb": pts_per_step * 20 / 1e9,

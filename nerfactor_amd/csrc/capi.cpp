@@ -178,7 +178,7 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
     if (prec == NFX_PREC_BF16) {
         // 0: 4 waves x 64 points, register-staged weights; 1: 8 waves x 32 points, register-staged;
         // 2: 8 waves x 32 points, LDS-DMA ring + half-tile phase offset between the wave groups
-        const int variant = env_int("NFX_NERF_VARIANT", 6);
+        const int variant = env_int("NFX_NERF_VARIANT", 7);
         if (variant == 8)  // variant 6 with two staging register sets: chunk K+3 fetched during tile K, stored a tile later
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -8,
                                                           (hipStream_t)stream),

@@ -14,13 +14,13 @@ if [ "${SMOKE:-1}" = "1" ]; then
 echo "=== smoke" | tee $OUT/smoke.log
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5 | tee -a $OUT/smoke.log
 fi
-for v in ${VARIANTS-6 5}; do
+for v in ${VARIANTS-7 6}; do
   echo "=== bench variant $v" | tee $OUT/bench_v$v.log
-  NFX_NERF_VARIANT=$v timeout 900 python bench.py --steps 5 --warmup 2 $( [ "$v" != "6" ] && echo --no-cpu-baseline ) 2>&1 | tail -3 | tee -a $OUT/bench_v$v.log
+  NFX_NERF_VARIANT=$v timeout 900 python bench.py --steps 5 --warmup 2 $( [ "$v" != "7" ] && echo --no-cpu-baseline ) 2>&1 | tail -3 | tee -a $OUT/bench_v$v.log
 done
 if [ "${PROFILE:-1}" = "1" ]; then
   echo "=== rocprofv3 kernel stats"
-  (cd /tmp && NFX_NERF_VARIANT=${PROF_VARIANT:-6} timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o nerf -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+  (cd /tmp && NFX_NERF_VARIANT=${PROF_VARIANT:-7} timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o nerf -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
   ls -R $OUT/prof | head -20
   find $OUT/prof -name "*kernel_stats*" | head -2 | xargs -r head -20
   cat /sys/fs/cgroup/cpu.max 2>/dev/null >> $OUT/gpu.txt

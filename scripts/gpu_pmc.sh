@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 R=$PWD
-OUT=$R/gpurun_out/pmc_v${NFX_NERF_VARIANT:-5}
+OUT=$R/gpurun_out/pmc_v${NFX_NERF_VARIANT:-7}
 mkdir -p $OUT
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -iE "mfma|FETCH_SIZE|WRITE_SIZE|SQ_WAIT|SQ_BUSY|SQ_WAVE_CYC|LDS_BANK|LDS_IDX|GRBM_GUI" | head -60 > $OUT/counters_available.txt
