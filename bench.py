@@ -194,7 +194,10 @@ def main():
                 "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
                 "kernel_variant": variant},
             "roofline": {
-                "bound": "mfma", "kernel": "nerf_mlp_bf16%s_kernel (coarse + fine launches)" % {"0": "", "1": "", "7": "_v6_kernel<0, 1> (LDS-DMA weight stream)", "8": "_v6_kernel<0, 2>"}.get(variant, "_v" + variant),
+                "bound": "mfma", "kernel": "%s (coarse + fine launches)" % {
+                    "0": "nerf_mlp_bf16_kernel<2, 4>", "1": "nerf_mlp_bf16_kernel<1, 8>",
+                    "7": "nerf_mlp_bf16_v6_kernel<0, 1>, LDS-DMA weight stream",
+                    "8": "nerf_mlp_bf16_v6_kernel<0, 2>"}.get(variant, "nerf_mlp_bf16_v%s_kernel" % variant),
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch pair",
                 "algorithmic_hbm_gb": pts_per_step * 20 / 1e9,
