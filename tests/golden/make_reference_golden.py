@@ -302,6 +302,10 @@ def run_datasets(tmp):
         for k, v in zip(('rayo', 'rayd', 'rgb', 'alpha', 'xyz', 'normal', 'lvis'), batch[2:]):
             put('ds_shape_%s_%s' % (mode, k), v)
     put('ds_n_train_views', np.int32(len(NerfDataset(ref_config('nerf.ini', **over), 'train').files)))
+    ds = NerfDataset(ref_config('nerf.ini', **over), 'test', always_all_rays=True, spp=4)     # 2 x 2 rays per pixel
+    batch = ds._process_example_postcache(*load(ds))
+    put('ds_nerf_spp4_hw', batch[1])
+    put('ds_nerf_spp4_rayd', batch[3])
 
 
 def main():
