@@ -184,7 +184,8 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v8)");
         if (variant == 7)  // variant 6 with the weight stream as LDS-DMA (no VGPR staging, counted vmcnt)
-            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -7,
+            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
+                                                          env_int("NFX_ABLATE", 0) > 0 ? 100 + env_int("NFX_ABLATE", 0) : -7,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v7)");
         if (variant == 6)  // variant 5 + 3-slot ring, mid-tile weight store, next tile's operands read before the barrier

@@ -23,7 +23,10 @@ constexpr int kNW = 4, kCT = 2;
 // written to its slot at the end of tile K+1: the global loads get two tile times to land instead of one, and the
 // compiler's counted vmcnt lets the newer set stay in flight across the store of the older one.
 template <int DMA> constexpr int ring_of = DMA == 1 ? 6 : 3;
-template <int DMA> constexpr int dist_of = DMA ? 3 : 2;
+#ifndef NFX_V7_DIST
+#define NFX_V7_DIST 3   // LDS-DMA fetch distance in tiles (3 or 4; the 6-slot ring holds either)
+#endif
+template <int DMA> constexpr int dist_of = DMA == 1 ? NFX_V7_DIST : DMA ? 3 : 2;
 template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
 constexpr int kNChunks = nerf::kNChunks;  // 78
 
@@ -228,7 +231,9 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     // mid-tile stalls on vmcnt, L2 latency under this load exceeds half a tile)
     if constexpr (DMA == 1 && !(AB & 1)) {
         // the chunk issued one tile ago must be complete before the barrier; this tile's pieces may stay in flight
-        constexpr int kInFlight = nerf::chunk_frags(K2) / kNW;
+        // (fetch distance 4: the chunk issued during the previous tile may stay in flight too)
+        constexpr int kInFlight = nerf::chunk_frags(K2) / kNW +
+                                  (NFX_V7_DIST == 4 ? nerf::chunk_frags((K + 3) % kNChunks) / kNW : 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
     } else if constexpr (DMA == 2 && !(AB & 1)) {
         // chunk K+2, fetched during tile K-1 into the other register set, to slot (K+2) % 3 = the slot tile K-1 read
@@ -304,6 +309,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
             Stage<chunk_frags(2) / 4, kNW> s2;
             s2.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(2) * kFragBytes), tid);
             s2.store(reinterpret_cast<u32x4*>(smem + 2 * kSlotBytes), tid);
+            if constexpr (NFX_V7_DIST == 4) {
+                Stage<chunk_frags(3) / 4, kNW> s3;
+                s3.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(3) * kFragBytes), tid);
+                s3.store(reinterpret_cast<u32x4*>(smem + 3 * kSlotBytes), tid);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -395,10 +405,14 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
         NFX_V6_CASE(1) NFX_V6_CASE(2) NFX_V6_CASE(3) NFX_V6_CASE(4) NFX_V6_CASE(8) NFX_V6_CASE(64) NFX_V6_CASE(7)
         NFX_V6_CASE(12) NFX_V6_CASE(75)
 #undef NFX_V6_CASE
+#define NFX_V7_CASE(m) case 100 + m: return launch_v6<m, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+        NFX_V7_CASE(1) NFX_V7_CASE(2) NFX_V7_CASE(3) NFX_V7_CASE(4) NFX_V7_CASE(8) NFX_V7_CASE(64) NFX_V7_CASE(66)
+        NFX_V7_CASE(75)
+#undef NFX_V7_CASE
         default: break;
     }
 #endif
-    if (ablate == -7) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    if (ablate == -7 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
     if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }

@@ -24,6 +24,8 @@ VARIANT = os.environ.get('ABLATE_VARIANT', '2')
 os.environ['NFX_NERF_VARIANT'] = VARIANT
 res = {}
 MASKS = [0, 1, 2, 3, 4, 8, 12, 16, 32, 28, 31] if VARIANT == '2' else [0, 1, 2, 3, 4, 8, 16, 64, 80, 83, 7, 12]
+if VARIANT == '7':   # variant 7 (LDS-DMA): 1 no DMA / vmcnt wait, 2 no barrier, 4 no MFMA, 8 no A reads, 64 no bias reads
+    MASKS = [0, 1, 2, 3, 4, 8, 64, 66, 75]
 for mask in MASKS:
     os.environ['NFX_ABLATE'] = str(mask)
     ops.nerf_mlp_fwd(o, d, z, blob)
