@@ -167,6 +167,18 @@ __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
 #pragma unroll
     for (int i = 0; i < n; ++i) dma_piece(lane_off, g + i * 1024, l + i * 1024);
 }
+// one piece of chunk K (experiment NFX_V7_SPREAD: the pieces are issued over the tile's k-steps, not all at its start)
+template <int K, int I>
+__device__ __forceinline__ void dma_one(const Ctx& cx) {
+    constexpr int n = nerf::chunk_frags(K) / kNW;
+    unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
+    unsigned lds = cx.smem_lds;
+    asm volatile("" : "+s"(base), "+s"(lds));
+    const int piece = cx.wave * n + I;
+    dma_piece((cx.tid & 63) * 16,
+              reinterpret_cast<const char*>(base) + (size_t)nerf::chunk_frag_offset(K) * kFragBytes + piece * 1024,
+              lds + (K % 6) * kSlotBytes + piece * 1024);
+}
 
 // Tile K (global chunk index).  On entry `acc` holds the tile's bias and `pre` its first three A fragments; on exit
 // `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
@@ -187,8 +199,13 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     const int lane = cx.tid & 63;
     const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
     Stage<DMA ? 1 : NL2, kNW> st;
+#ifdef NFX_V7_SPREAD
+    constexpr int kDmaN = nerf::chunk_frags(K2) / kNW, kDmaStride = KS / kDmaN > 0 ? KS / kDmaN : 1;
+#endif
     if constexpr (DMA == 1 && !(AB & 1)) {
+#ifndef NFX_V7_SPREAD
         dma_chunk<K2>(cx);
+#endif
     } else if constexpr (DMA == 2 && !(AB & 1)) {
         unsigned long long gb = reinterpret_cast<unsigned long long>(cx.blob);
         asm volatile("" : "+s"(gb));   // (an integer: a laundered generic pointer would turn the loads into flat_load)
@@ -209,6 +226,17 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     for (int i = 0; i < kPreA; ++i) abuf[i] = pre.a[i];
     static_for<0, KS>([&](auto S) {
         constexpr int s = decltype(S)::value;
+#ifdef NFX_V7_SPREAD
+        if constexpr (DMA == 1 && !(AB & 1)) {
+            // piece i at k-step i * stride; whatever does not fit (short tiles) goes out with the last k-step
+            if constexpr (s % kDmaStride == 0 && s / kDmaStride < kDmaN && s != KS - 1) dma_one<K2, s / kDmaStride>(cx);
+            if constexpr (s == KS - 1)
+                static_for<0, kDmaN>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr (i * kDmaStride >= KS - 1) dma_one<K2, i>(cx);
+                });
+        }
+#endif
         if constexpr (s + kPreA < KS && !(AB & 8))
             abuf[(s + kPreA) % (kPreA + 1)] = *reinterpret_cast<const bf16x8*>(f0 + (s + kPreA) * kFragBytes);
         const bf16x8 a = abuf[s % (kPreA + 1)];
