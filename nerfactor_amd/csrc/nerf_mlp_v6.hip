@@ -188,10 +188,16 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
                                      const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
     constexpr int KS = KS1 + KS2;
     constexpr int PIECES = KS >= 16 ? 8 : 4;
+#ifndef NFX_V6_EOFF
+#define NFX_V6_EOFF 0
+#endif
+    // the previous tile's epilogue starts EOFF k-steps into this tile (long tiles only): its first reads then fall
+    // behind this tile's first MFMAs instead of directly behind the previous tile's last ones (MFMA result latency)
+    constexpr int EOFF = KS >= 16 ? NFX_V6_EOFF : 0;
 #ifdef NFX_V6_SP_LATE
     constexpr int SP = KS >= 16 ? 12 : (PIECES < KS ? PIECES : KS - 1);   // experiment: next tile's bias later in the tile
 #else
-    constexpr int SP = PIECES < KS ? PIECES : KS - 1;  // k-step after which the previous tile's epilogue is complete
+    constexpr int SP = (PIECES < KS ? PIECES : KS - 1) + EOFF;  // k-step after which the previous tile's epilogue is complete
 #endif
     constexpr int R = ring_of<DMA>;
     constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
@@ -249,7 +255,12 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
                 acc.v[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc.v[c], 0, 0, 0);
             }
         }
-        if constexpr (s < PIECES) prev.template run<16 * s / PIECES, 16 * (s + 1) / PIECES>();
+        if constexpr (EOFF > 0 && s == EOFF)
+            // neither VALU nor MFMA may cross this point (SALU, VMEM, DS may): without it the scheduler puts the
+            // epilogue's first reads directly behind the previous tile's last MFMAs again
+            __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);
+        if constexpr (s >= EOFF && s - EOFF < PIECES)
+            prev.template run<16 * (s - EOFF) / PIECES, 16 * (s - EOFF + 1) / PIECES>();
         if constexpr (s == SP) {
             // the other accumulator set is free now: tile K+1's bias goes to its accumulators
             if constexpr (!(AB & 64)) bias_to_acc(next_bias, lane, acc_next);
