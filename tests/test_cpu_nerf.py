@@ -125,6 +125,12 @@ def test_library_exports_every_header_symbol(nfx_lib):
     assert nfx_lib.lib.nfx_version() >= 100
 
 
+def test_integration_guide_names_every_header_symbol():
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = [s for s in _header_symbols() if s not in doc]
+    assert not missing, "INTEGRATION.md does not mention %s" % missing
+
+
 def test_pack_rejects_bad_arguments(nfx_lib):
     from nerfactor_amd import ops
     net = common.nerf_nets()[0]
