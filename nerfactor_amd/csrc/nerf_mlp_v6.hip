@@ -9,6 +9,15 @@
 //     in LDS for a whole tile), so their latency overlaps the tail MFMAs and the barrier,
 //   * the barrier is a bare s_barrier (no lgkmcnt(0) drain).
 // Same blob, bit-identical results to variants 0-5.
+//
+// Three weight-stream modes of the same kernel (template parameter DMA), all built in MFMA VGPR form (build.py):
+//   DMA = 0  variant 6   register-staged as described above;
+//   DMA = 1  variant 7   THE DEFAULT: LDS-DMA (global_load_lds_dwordx4) into a 6-slot ring, chunk k+3 issued at the
+//                        start of tile k, counted s_waitcnt vmcnt before the barrier — no staging VGPRs, no ds_write;
+//   DMA = 2  variant 8   register-staged with two staging sets (chunk k+3 fetched during tile k, stored a tile later).
+// Experiment switches (NFX_EXTRA_DEFS, all measured on r01 and left at their defaults — DESIGN.md section 2):
+//   NFX_V6_BIAS_READ2 (second bias read group instead of register copies), NFX_V6_ADEPTH (A-fragment prefetch depth,
+//   3), NFX_V6_SP_LATE, NFX_V6_EOFF (epilogue start offset, 0), NFX_V7_DIST (DMA fetch distance, 3), NFX_V7_SPREAD.
 #include "mlp_engine.hpp"
 #include "nerf_layout.hpp"
 
