@@ -148,6 +148,8 @@ def linspace01(n, dtype):
     """tf.linspace(0., 1., n) as the TF 2.2 CPU kernel computes it: start + step * i with
     step = (stop - start) / (n - 1) evaluated in the output dtype."""
     dtype = np.dtype(dtype).type
+    if n == 1:
+        return np.zeros(1, dtype)          # tf.linspace(start, stop, 1) == [start]
     step = dtype(1.) / dtype(n - 1)
     return (np.arange(n).astype(dtype) * step).astype(dtype)
 
