@@ -21,6 +21,11 @@
 #include "mlp_engine.hpp"
 #include "nerf_layout.hpp"
 
+#ifdef NFX_V6_TIMING
+__device__ unsigned long long nfx_v6_times[4][128];   // cycle stamp before each tile, all four waves of one block
+__device__ int nfx_v6_idx = -1;
+#endif
+
 namespace nfx {
 namespace v6 {
 
@@ -212,6 +217,9 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
     constexpr int NL2 = nerf::chunk_frags(K2) / 4;
     const int lane = cx.tid & 63;
+#ifdef NFX_V6_TIMING
+    if (blockIdx.x == 7 && lane == 0 && nfx_v6_idx == 0) nfx_v6_times[cx.wave][K] = __builtin_readcyclecounter();
+#endif
     const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
     Stage<DMA ? 1 : NL2, kNW> st;
 #ifdef NFX_V7_SPREAD
@@ -387,6 +395,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
             posenc<10, kCT>(x, h, c, pe);
             posenc<4, kCT>(d, h, c, pv);
         }
+#ifdef NFX_V6_TIMING
+        if (blockIdx.x == 7 && tid == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
+        __syncthreads();
+#endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
         float sigma[kCT];
         const float* bl = bias_lds + kBiasL0;
@@ -464,3 +476,9 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
     if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }
+
+#ifdef NFX_V6_TIMING
+extern "C" int nfx_debug_v6_times(unsigned long long* host512) {
+    return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(nfx_v6_times), sizeof(unsigned long long) * 4 * 128);
+}
+#endif
