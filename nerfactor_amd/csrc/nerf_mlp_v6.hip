@@ -396,8 +396,9 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
             posenc<4, kCT>(d, h, c, pv);
         }
 #ifdef NFX_V6_TIMING
-        if (blockIdx.x == 7 && tid == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
-        __syncthreads();
+        // (set by every lane-0 with the same value: no barrier needed, and a __syncthreads() here crashes the
+        //  'AMDGPU Rewrite AGPR-Copy-MFMA' pass of ROCm 7.2 in MFMA VGPR form)
+        if (blockIdx.x == 7 && lane == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
 #endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
         float sigma[kCT];
