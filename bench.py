@@ -1,19 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — rays/sec of the NeRF coarse+fine render hot path on MI355X.
+"""bench.py — rays/sec (+ PSNR vs the CPU oracle) of the NeRFactor per-ray rendering hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--legs nerf,nerfactor_microfacet,nerfactor]
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): one 800x800 view per GPU, 64 coarse +
-128 fine samples per ray, white background, perturb off, synthetic glorot weights (opaque
-variant), rays from the reference's pin-hole generator.  A "step" = one full pass of the hot path
-over one view's 640 000 rays per GPU: normalise -> gen_z -> coarse MLP -> composite ->
-hierarchical resample -> fine MLP -> composite.  Inputs are resident in HBM before the timed
-region.  N > 1: one process per GPU (torchrun), each rank renders its own view (rays are
-independent; no data-path collective) => weak scaling; value = all rays of all ranks / max time.
+BASELINE.json's metric is "rays/sec (64 samples/ray, 512 light dirs) + PSNR vs TF ref"; one run times, back to back,
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused NeRF MLP, MFMA-bound,
-algorithmic FLOPs / HIP-event kernel time) and, at N == 1, `cpu_baseline` (torch-CPU fp32 port of
-the reference op sequence on the host cores, bounded sample).
+  * leg `nerf` (the headline `value`; BASELINE.json configs[1], SURVEY.md §8d "C2"): 800x800 view, 64 coarse + 128
+    fine samples per ray, white background, perturb off, synthetic glorot weights (opaque variant), rays from the
+    reference's pin-hole generator.  A "step" = one full pass of the hot path over one view's 640 000 rays per GPU:
+    normalise -> gen_z -> coarse MLP -> composite -> hierarchical resample -> fine MLP -> composite;
+  * legs `nerfactor_microfacet` and `nerfactor` (configs[2], "C3", reported under the "nerfactor" key of the same
+    JSON object): full NeRFactor render of 800x800 surface points (60 % foreground), 512 light directions, the
+    trained light + 8 novel probes, through the model plugin (`Model.call(mode='test', relight_probes=True)`):
+    normals / albedo / BRDF-latent MLPs -> light-visibility MLP over the light sphere -> (learned BRDF MLP |
+    microfacet BRDF) -> BRDF x visibility x lighting integral -> pixels.
+
+Inputs are resident in HBM before every timed region; every timed region is bracketed by barrier +
+torch.cuda.synchronize() and EXACTLY K steps long.
+
+N > 1 (one process per GPU under torchrun; rays are independent, no data-path collective): `--scaling weak`
+(default) renders N views per step, EVERY view sharded by contiguous ray ranges over all N ranks (SURVEY §8e:
+rank r owns rays [r n/N, (r+1) n/N) of each view), so per-GPU work stays 640 000 rays per step; `--scaling strong`
+renders ONE view per step sharded the same way.  value = all rays of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the headline leg (fused NeRF MLP,
+MFMA-bound: algorithmic FLOPs / HIP-event time of its launches on the launch stream); each NeRFactor leg carries
+its own `roofline` (light-visibility kernel) and at N == 1 every leg carries a `cpu_baseline` (torch-CPU fp32 port of
+the reference op sequence, bounded sample) whose output doubles as the PSNR / max-abs reference for the GPU frame.
 """
 import argparse
 import json
@@ -29,38 +42,14 @@ sys.path.insert(0, ROOT)
 
 H = W = 800
 N_COARSE, N_FINE = 64, 128
-FLOP_PER_POINT = 2 * 593408          # 593 408 MAC per sample point
+FLOP_PER_POINT = 2 * 593408          # 593 408 MAC per NeRF sample point
+LVIS_MAC, BRDF_MAC = 72320, 53888    # MAC per (point, light) row
+HEAD_MAC = 65664 + 65664             # normal + albedo heads per point (+ 65 408 | 65 920 for the BRDF latent)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+N_LIGHTS, N_PROBES = 512, 8
 
 
-def synth_inputs(rank):
-    from tests import common
-    nets = common.nerf_nets(seed=0)
-    ang = 0.7 * rank
-    cam = (4 * np.cos(ang) * 0.8, 4 * np.sin(ang) * 0.8 - 0.1, 4 * 0.6)
-    rayo, rayd = common.camera_rays(H, W, cam_loc=cam)
-    return nets, rayo, rayd
-
-
-def render_step(ops, o, d_raw, blobs, ev=None):
-    d = ops.l2_normalize3(d_raw, 1e-12)
-    z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
-    if ev is not None:
-        ev[0].record()
-    raw = ops.nerf_mlp_fwd(o, d, z, blobs[0])
-    if ev is not None:
-        ev[1].record()
-    _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
-    z_all = ops.sample_fine(z, w, N_FINE)
-    if ev is not None:
-        ev[2].record()
-    raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1])
-    if ev is not None:
-        ev[3].record()
-    rgb, occu, depth, disp, _ = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)
-    return rgb
-
-
+# ------------------------------------------------------------------------------------------------ helpers
 def host_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -73,10 +62,65 @@ def host_cores():
     return n
 
 
-def cpu_baseline(nets, rayo, rayd, budget_s=20.):
-    """torch-CPU fp32 port of the reference op sequence (oracle/torch_ref.py) on the host cores.
-    The thread count is probed (all usable cores is not always fastest for 65 536-row GEMMs);
-    `cores` reports the count actually used for the timed sample."""
+def psnr_uint8_luma(a, b):
+    """xiuminglib.metric.PSNR('uint8') semantics (the reference's per-view PSNR, models/nerf.py:389-391): luma
+    0.2126/0.7152/0.0722 of the frames quantised by truncation to uint8."""
+    def q(x):
+        return (np.clip(x, 0, 1) * 255).astype(np.uint8).astype(np.float64)
+    w = np.array([0.2126, 0.7152, 0.0722])
+    mse = float(np.mean((q(a) @ w - q(b) @ w) ** 2))
+    return float('inf') if mse == 0 else 10 * np.log10(255. ** 2 / mse)
+
+
+class Shards:
+    """The contiguous ray ranges this rank owns of each view of one step."""
+
+    def __init__(self, n_per_view, rank, world, scaling):
+        from nerfactor_amd import dist as nfx_dist
+        self.n_views = world if scaling == 'weak' else 1
+        self.lo, self.hi = nfx_dist.shard_range(n_per_view, rank, world)
+        self.rays_per_step_all_ranks = self.n_views * n_per_view
+
+
+def timed(step, steps, warmup, barrier):
+    for _ in range(warmup):
+        step(None)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out = step(k)
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+# ------------------------------------------------------------------------------------------------ NeRF leg
+def nerf_render_step(ops, views, blobs, ev=None):
+    """views: [(rayo, rayd)] device tensors (this rank's shard of every view).  ev: per-view 4 events around the two
+    MLP launches."""
+    rgb = None
+    for i, (o, d_raw) in enumerate(views):
+        e = None if ev is None else ev[i]
+        d = ops.l2_normalize3(d_raw, 1e-12)
+        z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
+        if e is not None:
+            e[0].record()
+        raw = ops.nerf_mlp_fwd(o, d, z, blobs[0])
+        if e is not None:
+            e[1].record()
+        _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
+        z_all = ops.sample_fine(z, w, N_FINE)
+        if e is not None:
+            e[2].record()
+        raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1])
+        if e is not None:
+            e[3].record()
+        rgb = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)[0]
+    return rgb
+
+
+def nerf_cpu_reference(nets, rayo, rayd, budget_s, timed_run=True):
+    """torch-CPU fp32 port of the reference op sequence (oracle/torch_ref.py) on a random subset of the view.
+    Returns (cpu_baseline dict | None, ray indices, reference rgb, |sigma_last| of the coarse and fine pass)."""
     from oracle import torch_ref
     tn = [torch_ref.to_torch_net(n) for n in nets]
     idx = np.random.default_rng(0).permutation(rayo.shape[0])
@@ -87,33 +131,299 @@ def cpu_baseline(nets, rayo, rayd, budget_s=20.):
         torch.set_num_threads(threads)
         o, d = torch.from_numpy(rayo[idx[:n]]), torch.from_numpy(rayd[idx[:n]])
         t0 = time.perf_counter()
-        torch_ref.render_rays(o, d, tn[0], tn[1])
-        return time.perf_counter() - t0
+        res = torch_ref.render_rays(o, d, tn[0], tn[1])
+        return time.perf_counter() - t0, res
 
     with torch.no_grad():
+        if not timed_run:      # N > 1: reference frame only (1024 rays), no baseline timing
+            dt, res = run(1024, cands[0])
+            return None, idx[:1024], res
         run(64, cands[-1])  # warm the allocator / BLAS
-        probe = {}
-        for c in cands:
-            probe[c] = run(256, c)
-            if probe[c] > 8.:
-                continue
+        probe = {c: run(256, c)[0] for c in cands}
         best = min(probe, key=probe.get)
         n = int(min(65536, max(256, 256 * budget_s / max(probe[best], 1e-3))))
         n = max(256, (n // 256) * 256)
-        dt = run(n, best)
-    return {
-        "value": n / dt, "unit": "rays/s", "cores": best, "kind": "port",
-        "cores_available": avail,
-        "sample": "%d rays of the same 800x800 view, 64+128 samples, torch-CPU fp32 "
-                  "(oracle/torch_ref.py, mlp_chunk=65536), %.1f s; thread probe %s" % (
-                      n, dt, {k: round(v, 2) for k, v in probe.items()})}
+        dt, res = run(n, best)
+    base = {"value": n / dt, "unit": "rays/s", "cores": best, "kind": "port", "cores_available": avail,
+            "sample": "%d rays of the same 800x800 view, 64+128 samples, torch-CPU fp32 (oracle/torch_ref.py, "
+                      "mlp_chunk=65536), %.1f s; thread probe %s" % (n, dt, {k: round(v, 2) for k, v in probe.items()})}
+    return base, idx[:n], res
 
 
+def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
+    from nerfactor_amd import synth
+    nets = synth.nerf_nets(seed=0)
+    blobs = [ops.pack_nerf_weights(*synth.nerf_layers(n)).to(dev) for n in nets]
+    sh = Shards(H * W, rank, world, args.scaling)
+    views, host_views = [], []
+    for v in range(sh.n_views):
+        ang = 0.7 * v
+        cam = (4 * np.cos(ang) * 0.8, 4 * np.sin(ang) * 0.8 - 0.1, 4 * 0.6)
+        rayo, rayd = synth.camera_rays(H, W, cam_loc=cam)
+        host_views.append((rayo, rayd))
+        views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
+    evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in views] for _ in range(args.steps)]
+    elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k]),
+                         args.steps, args.warmup, barrier)
+    elapsed = max_over_ranks(elapsed)
+    assert torch.isfinite(rgb).all()
+
+    # dominant kernel: the fused NeRF MLP (two launches per view: coarse + fine), HIP events on the launch stream
+    n_local = sh.hi - sh.lo
+    pair_ms = [e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for step in evs for e in step]
+    fine_ms = [e[2].elapsed_time(e[3]) for step in evs for e in step]
+    pts_per_pair = n_local * (N_COARSE + N_COARSE + N_FINE)
+    pair_s = float(np.mean(pair_ms)) * 1e-3
+    achieved = pts_per_pair * FLOP_PER_POINT / pair_s / 1e12
+    fine_tf = n_local * (N_COARSE + N_FINE) * FLOP_PER_POINT / (float(np.mean(fine_ms)) * 1e-3) / 1e12
+
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is the
+    # committed digest of the same workload at N = 1 (scripts/gpu_pmc.sh -> scripts/pmc_digest.py): FETCH_SIZE x 2
+    # (gfx950 correction) + WRITE_SIZE, per launch pair of a whole 640 000-ray view.
+    traffic, traffic_source = None, None
+    variant = os.environ.get("NFX_NERF_VARIANT", "7")
+    for rnd in ('r02', 'r01'):
+        dig = os.path.join(ROOT, 'profiles', rnd, 'pmc_variant%s_digest.json' % variant)
+        if traffic is None and os.path.exists(dig) and n_local == H * W:
+            for k, v in json.load(open(dig)).items():
+                if 'nerf_mlp' in k and 'hbm_write_bytes' in v:
+                    # digest = average over the coarse and the fine dispatch; a launch pair = both
+                    traffic = 2 * (v.get('hbm_read_bytes_corrected', 0) + v['hbm_write_bytes']) / 1e9
+                    traffic_source = "committed PMC digest profiles/%s/%s (not measured in this run)" % (
+                        rnd, os.path.basename(dig))
+    out = {
+        "value": sh.rays_per_step_all_ranks * args.steps / elapsed,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "config": {
+            "workload": "lego_3072-shaped NeRF coarse+fine MLP render, 800x800 rays per view, 64+128 samples "
+                        "(BASELINE.json configs[1]); NeRFactor 512-light render (configs[2]) under \"nerfactor\"",
+            "views_per_step": sh.n_views, "rays_per_view": H * W, "rays_per_step_per_gpu": sh.n_views * n_local,
+            "partition": "each view's rays in contiguous ranges over the ranks",
+            "n_samples_coarse": N_COARSE, "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
+            "kernel_variant": variant},
+        "roofline": {
+            "bound": "mfma", "kernel": "%s (coarse + fine launches)" % {
+                "1": "nerf_mlp_bf16_kernel<1, 8>",
+                "7": "nerf_mlp_bf16_v6_kernel<0, 1>, LDS-DMA weight stream"}.get(variant, "variant %s" % variant),
+            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "traffic": traffic, "traffic_unit": "GB per launch pair", "traffic_source": traffic_source,
+            "algorithmic_hbm_gb": pts_per_pair * 20 / 1e9, "flop_per_launch_pair": pts_per_pair * FLOP_PER_POINT,
+            "avg_launch_pair_ms": pair_s * 1e3, "fine_launch_tflops": fine_tf,
+            "mlp_share_of_step": pair_s * sh.n_views / (elapsed / args.steps)},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        # parity of the timed frame: the CPU port's rays vs the same rays of view 0 of the last timed step
+        base, idx, ref = nerf_cpu_reference(nets, *host_views[0], budget_s=args.cpu_budget, timed_run=(world == 1))
+        sel = idx[(idx >= sh.lo) & (idx < sh.hi)]
+        keep = np.isin(idx, sel)
+        o, d = (torch.from_numpy(a[sel]).to(dev) for a in host_views[0])
+        got = nerf_render_step(ops, [(o, d)], blobs).cpu().numpy()
+        want = ref[1]['rgb'].numpy()[keep]
+        # rays decided by the sign of a near-zero logit at the dist = 1e10 last sample are a discontinuity of the
+        # reference formula: they stay in the PSNR, max-abs is reported with and without them
+        sig = np.minimum(ref[2]['sigma_last_coarse'].numpy()[keep], ref[2]['sigma_last_fine'].numpy()[keep])
+        stable = sig > 0.06     # torch_ref returns |sigma_last|
+        err = np.abs(got - want).max(1)
+        out["parity"] = {
+            "psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err[stable].max()),
+            "max_abs_all_rays": float(err.max()), "rays_compared": int(len(sel)),
+            "rays_excluded_from_max_abs": int((~stable).sum()),
+            "reference": "oracle/torch_ref.py (fp32) on the same rays; tolerance PSNR >= 40 dB, max-abs <= 3e-2"}
+        if base is not None:
+            out["cpu_baseline"] = base
+            out["gpu_over_cpu"] = out["value"] / base["value"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ NeRFactor legs
+class KernelTimer:
+    """HIP-event timing of selected `ops` entry points as the model calls them (events on torch's current stream,
+    which is the stream ops launches on)."""
+
+    def __init__(self, ops, names):
+        self.ops, self.names, self.orig, self.events, self.on = ops, names, {}, {n: [] for n in names}, False
+
+    def __enter__(self):
+        for n in self.names:
+            self.orig[n] = getattr(self.ops, n)
+            setattr(self.ops, n, self._wrap(n, self.orig[n]))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.ops, n, f)
+
+    def _wrap(self, name, fn):
+        def call(*a, **kw):
+            if not self.on:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            self.events[name].append((e0, e1))
+            return r
+        return call
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+
+def nerfactor_nets_of(model, variant):
+    """The model's weights as the oracle's net dict (CPU tensors)."""
+    def pairs(net, name):
+        ks, bs = net[name].kernels_and_biases()
+        return [(k.detach().cpu(), b.detach().cpu()) for k, b in zip(ks, bs)]
+    net = {k: pairs(model.net, k) for k in ('normal_mlp', 'normal_out', 'lvis_mlp', 'lvis_out', 'albedo_mlp',
+                                            'albedo_out', 'brdf_z_mlp', 'brdf_z_out')}
+    brdf_net = None
+    if variant == 'learned':
+        brdf_net = {k: pairs(model.brdf_model.net, k) for k in ('brdf_mlp', 'brdf_out')}
+    return net, brdf_net
+
+
+def nerfactor_cpu_reference(model, variant, batch_host, lights, budget_s, timed_run):
+    from oracle import torch_ref
+    net, brdf_net = nerfactor_nets_of(model, variant)
+    cfg = model.config
+    kw = dict(variant=variant, brdf_net=brdf_net, f0=cfg.getfloat('DEFAULT', 'fresnel_f0', fallback=0.04),
+              brdf_scale=cfg.getfloat('DEFAULT', 'learned_brdf_scale', fallback=1.),
+              albedo_slope=cfg.getfloat('DEFAULT', 'albedo_slope'), albedo_bias=cfg.getfloat('DEFAULT', 'albedo_bias'),
+              to_srgb=cfg.getboolean('DEFAULT', 'linear2srgb'))
+    lxyz, lareas = model.lxyz.cpu(), model.lareas.cpu()
+    lights = lights.cpu()
+    rayo, alpha, xyz = (torch.from_numpy(batch_host[i]) for i in (2, 5, 6))
+    torch.set_num_threads(host_cores())
+
+    def run(n):
+        t0 = time.perf_counter()
+        res = torch_ref.nerfactor_render((rayo[:n], alpha[:n], xyz[:n]), net, lxyz, lareas, lights, **kw)
+        return time.perf_counter() - t0, res
+
+    with torch.no_grad():
+        if not timed_run:
+            return None, 512, run(512)[1]
+        run(16)
+        t_probe = run(128)[0]
+        n = int(min(16384, max(128, 128 * budget_s / max(t_probe, 1e-3))))
+        n = (n // 128) * 128
+        dt, res = run(n)
+    base = {"value": n / dt, "unit": "points/s", "cores": host_cores(), "kind": "port",
+            "sample": "first %d surface points of the same batch (%d foreground), 512 lights, 1+%d lights, torch-CPU "
+                      "fp32 (oracle/torch_ref.py:nerfactor_render, mlp_chunk=65536), %.1f s" % (
+                          n, int(alpha[:n].sum()), lights.shape[0] - 1, dt)}
+    return base, n, res
+
+
+def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
+    from nerfactor_amd import synth
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    variant = 'microfacet' if name == 'nerfactor_microfacet' else 'learned'
+    torch.manual_seed(5)
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
+                      test_envmap_dir='', xyz_jitter_std='0')
+    model = get_model_class(name)(cfg).to(dev)
+    for i, p in enumerate(synth.probes(N_PROBES, seed=20)):
+        model.add_probe('p%d' % i, p)
+    n = H * W
+    sh = Shards(n, rank, world, args.scaling)
+    host_batches, batches, n_fg_local = [], [], 0
+    for v in range(sh.n_views):
+        hb = synth.surface_batch(n, seed=1 + 10 * v, n_lights=N_LIGHTS)
+        host_batches.append(hb)
+        batches.append(tuple(None if a is None else torch.from_numpy(a[sh.lo:sh.hi]).to(dev) for a in hb))
+        n_fg_local += int(hb[5][sh.lo:sh.hi].sum())
+    names = ['lvis_fwd'] + (['brdf_spec_fwd'] if variant == 'learned' else [])
+    with KernelTimer(ops, names) as kt:
+        def step(k):
+            kt.on = k is not None
+            out = None
+            for b in batches:
+                out = model(b, mode='test', relight_probes=True)[0]
+            return out
+        elapsed, pred = timed(step, args.steps, args.warmup, barrier)
+        kt.on = False
+    elapsed = max_over_ranks(elapsed)
+    assert torch.isfinite(pred['rgb_probes']).all()
+    fg_per_call = n_fg_local / sh.n_views
+    lvis_s = kt.mean_ms('lvis_fwd') * 1e-3
+    lvis_tf = fg_per_call * N_LIGHTS * 2 * LVIS_MAC / lvis_s / 1e12
+    out = {
+        "workload": "%s full render (BASELINE.json configs[2]): 800x800 surface points per view (60 %% foreground), "
+                    "512 lights, trained light + %d probes, Model.call(mode='test', relight_probes=True)" % (
+                        name, N_PROBES),
+        "points_per_s": sh.rays_per_step_all_ranks * args.steps / elapsed,
+        "ms_per_step": elapsed / args.steps * 1e3, "ms_per_view_per_gpu": elapsed / args.steps * 1e3 * world / sh.n_views,
+        "foreground_points_per_view": int(host_batches[0][5].sum()),
+        "flop_per_foreground_point_algorithmic": 2 * (N_LIGHTS * LVIS_MAC + HEAD_MAC + 65408),
+        "roofline": {
+            "bound": "mfma", "kernel": "lvis_pre_kernel + resident128_kernel<4, 0> (light visibility, %d x 512 rows)"
+                                       % int(fg_per_call),
+            "achieved": lvis_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": lvis_tf / PEAK_BF16_TFLOPS,
+            "avg_launch_ms": lvis_s * 1e3, "flop_per_launch": fg_per_call * N_LIGHTS * 2 * LVIS_MAC,
+            "executed_tflops": fg_per_call * N_LIGHTS * 2 * 61440 / lvis_s / 1e12,
+            "share_of_step": lvis_s * sh.n_views / (elapsed / args.steps), "traffic": None,
+            "traffic_source": "see profiles/r01/pmc_nerfactor_digest.json (not measured in this run)"},
+    }
+    if variant == 'learned':
+        spec_s = kt.mean_ms('brdf_spec_fwd') * 1e-3
+        out["brdf_spec"] = {"avg_launch_ms": spec_s * 1e3,
+                            "tflops_all_rows": fg_per_call * N_LIGHTS * 2 * BRDF_MAC / spec_s / 1e12}
+    if rank == 0 and not args.no_cpu_baseline:
+        lights = torch.stack([model.light.detach().cpu().reshape(-1, 3)] +
+                             [p.cpu().reshape(-1, 3) for p in model.novel_probes.values()])
+        base, n_s, ref = nerfactor_cpu_reference(model, variant, host_batches[0], lights, args.cpu_budget / 2,
+                                                 timed_run=(world == 1))
+        hi = min(n_s, sh.hi)
+        if hi > 0 and sh.lo == 0:
+            b = tuple(None if a is None else torch.from_numpy(a[:hi]).to(dev) for a in host_batches[0])
+            p = model(b, mode='test', relight_probes=True)[0]
+            got = torch.cat((p['rgb'][:, None], p['rgb_probes']), 1).cpu().numpy()
+            want = ref['rgb'].numpy()[:hi]
+            # points seen at grazing angles: the reference divides the specular term by 4 |l.n| |v.n|
+            # (microfacet.py:57), so a bf16-sized error of the predicted normal is amplified without bound as
+            # v.n -> 0 (the fp32 oracle run with bf16-rounded MLP operands shows the same outliers); they stay in the
+            # PSNR and in max_abs_all_points, max_abs is over |v.n| > 0.05
+            nrm = ref['normal'].numpy()[:hi]
+            vdir = host_batches[0][2][:hi] - host_batches[0][6][:hi]
+            vdir /= np.maximum(np.linalg.norm(vdir, axis=1, keepdims=True), 1e-6)
+            fg = host_batches[0][5][:hi, 0] > 0
+            stable = fg & (np.abs((nrm * vdir).sum(1)) > 0.05)
+            err = np.abs(got - want).max((1, 2))
+            out["parity"] = {
+                "psnr_db": psnr_uint8_luma(got.reshape(-1, 3), want.reshape(-1, 3)),
+                "max_abs": float(err[stable].max()), "max_abs_all_points": float(err.max()),
+                "max_abs_trained_light": float(np.abs(got[:, 0] - want[:, 0])[stable].max()),
+                "frac_points_above_3e-2": float((err[fg] > 3e-2).mean()),
+                "grazing_points_excluded_from_max_abs": int((fg & ~stable).sum()),
+                "max_abs_lvis": float(np.abs(p['lvis'].cpu().numpy() - ref['lvis'].numpy()[:hi]).max()),
+                "max_abs_albedo": float(np.abs(p['albedo'].cpu().numpy() - ref['albedo'].numpy()[:hi]).max()),
+                "max_abs_normal": float(np.abs(p['normal'].cpu().numpy() - nrm).max()),
+                "points_compared": int(hi), "foreground_points_compared": int(fg.sum()),
+                "lights_compared": int(got.shape[1]),
+                "reference": "oracle/torch_ref.py:nerfactor_render (fp32) on the same points; probes are HDR "
+                             "(exp N(0,1)) and the render clips to [0, 1]"}
+            if variant == 'learned':
+                fl = float((ref.get('front_lit_frac') or 0.))
+                out["brdf_spec"]["front_lit_fraction"] = fl
+                out["brdf_spec"]["tflops_algorithmic_front_lit_rows"] = out["brdf_spec"]["tflops_all_rows"] * fl
+        if base is not None:
+            out["cpu_baseline"] = base
+            out["gpu_over_cpu"] = out["points_per_s"] / base["value"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor')
+    ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -121,8 +431,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (
-            args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -130,84 +439,34 @@ def main():
     import torch.distributed as dist
     from nerfactor_amd import dist as nfx_dist
     nfx_dist.init_from_env(backend='nccl', device=dev)
-
     from nerfactor_amd import build
     build.build()
     from nerfactor_amd import ops
-
-    nets, rayo, rayd = synth_inputs(rank)
-    from tests import common
-    blobs = [ops.pack_nerf_weights(*common.nerf_layers(n)).to(dev) for n in nets]
-    o = torch.from_numpy(rayo).to(dev)
-    d = torch.from_numpy(rayd).to(dev)
-    n_rays = o.shape[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        render_step(ops, o, d, blobs)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        rgb = render_step(ops, o, d, blobs, evs[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = nfx_dist.max_over_ranks(elapsed, device=dev)
-    assert torch.isfinite(rgb).all()
+    def max_over_ranks(x):
+        return nfx_dist.max_over_ranks(x, device=dev)
 
-    # dominant kernel: the fused NeRF MLP (two launches per step: coarse + fine)
-    mlp_ms = [e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs]
-    fine_ms = [e[2].elapsed_time(e[3]) for e in evs]
-    pts_per_step = n_rays * (N_COARSE + N_COARSE + N_FINE)
-    mlp_avg_s = float(np.mean(mlp_ms)) * 1e-3
-    achieved = pts_per_step * FLOP_PER_POINT / mlp_avg_s / 1e12
-    fine_tf = n_rays * (N_COARSE + N_FINE) * FLOP_PER_POINT / (float(np.mean(fine_ms)) * 1e-3) / 1e12
-
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so
-    # the figure comes from the committed digest of the same workload (scripts/gpu_pmc.sh ->
-    # scripts/pmc_digest.py): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch pair.
-    traffic = None
-    variant = os.environ.get("NFX_NERF_VARIANT", "7")
-    dig = os.path.join(ROOT, 'profiles', 'r01', 'pmc_variant%s_digest.json' % variant)
-    if os.path.exists(dig):
-        for k, v in json.load(open(dig)).items():
-            if 'nerf_mlp' in k and 'hbm_write_bytes' in v:
-                # digest = average over the coarse and the fine dispatch; a launch pair = both
-                traffic = 2 * (v.get('hbm_read_bytes_corrected', 0) + v['hbm_write_bytes']) / 1e9
+    legs = [s for s in args.legs.split(',') if s]
+    if 'nerf' not in legs:
+        raise SystemExit("--legs must contain the headline leg 'nerf'")
+    nerf = nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks)
+    nerfactor = {name: nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
+                 for name in legs if name != 'nerf'}
     if rank == 0:
-        out = {
-            "metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)",
-            "value": world * n_rays * args.steps / elapsed,
-            "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {
-                "workload": "lego_3072-shaped NeRF coarse+fine MLP render, 800x800 rays per GPU, "
-                            "64+128 samples (BASELINE.json configs[1])",
-                "rays_per_step_per_gpu": n_rays, "n_samples_coarse": N_COARSE,
-                "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
-                "kernel_variant": variant},
-            "roofline": {
-                "bound": "mfma", "kernel": "%s (coarse + fine launches)" % {
-                    "0": "nerf_mlp_bf16_kernel<2, 4>", "1": "nerf_mlp_bf16_kernel<1, 8>",
-                    "7": "nerf_mlp_bf16_v6_kernel<0, 1>, LDS-DMA weight stream",
-                    "8": "nerf_mlp_bf16_v6_kernel<0, 2>"}.get(variant, "nerf_mlp_bf16_v%s_kernel" % variant),
-                "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch pair",
-                "algorithmic_hbm_gb": pts_per_step * 20 / 1e9,
-                "flop_per_launch_pair": pts_per_step * FLOP_PER_POINT,
-                "avg_launch_pair_ms": mlp_avg_s * 1e3, "fine_launch_tflops": fine_tf,
-                "mlp_share_of_step": mlp_avg_s / (elapsed / args.steps)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nets, rayo, rayd)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": nerf.pop("value"),
+               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": nerf.pop("ms_per_step"), "higher_is_better": True, "scaling": args.scaling,
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic"}
+        out.update(nerf)
+        if "parity" in nerf:
+            out["psnr_db"], out["max_abs"] = nerf["parity"]["psnr_db"], nerf["parity"]["max_abs"]
+        if nerfactor:
+            out["nerfactor"] = nerfactor
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -33,6 +33,18 @@ def resize(arr, new_h):
     return np.stack(out, -1).reshape((new_h, new_w) + arr.shape[2:])
 
 
+def gen_rays(to_world, angle_x, imh, imw, sps=1):
+    """Pin-hole rays through the top-left corner of every (sub)pixel, camera looking down -z (reference
+    datasets/nerf.py:172-193, ndc=False).  float64 [imh sps, imw sps, 3] origins and (un-normalised) directions."""
+    n_x, n_y = imw * sps, imh * sps
+    xs, ys = np.meshgrid(np.linspace(0, imw, n_x, endpoint=False), np.linspace(0, imh, n_y, endpoint=False))
+    fl = .5 * imw / np.tan(.5 * angle_x)
+    local = np.stack(((xs - .5 * imw) / fl, -(ys - .5 * imh) / fl, -np.ones_like(xs)), -1)
+    rayd = local @ to_world[:3, :3].T
+    rayo = np.broadcast_to(to_world[:3, 3], rayd.shape).copy()
+    return rayo, rayd
+
+
 class Dataset(BaseDataset):
     def __init__(self, config, mode, debug=False, always_all_rays=False, spp=1, device='cuda'):
         self.meta2img = {}
@@ -105,13 +117,6 @@ class Dataset(BaseDataset):
         return flat(rayo)[sel], flat(rayd)[sel], flat(rgb)[sel]
 
     def _gen_rays(self, to_world, angle_x, imh, imw):
-        """Pin-hole rays through the top-left corner of every (sub)pixel, camera looking down -z."""
         if self.config.getboolean('DEFAULT', 'ndc', fallback=False):
             raise NotImplementedError("ndc rays are marked untested in the reference and not supported")
-        n_x, n_y = imw * self.sps, imh * self.sps
-        xs, ys = np.meshgrid(np.linspace(0, imw, n_x, endpoint=False), np.linspace(0, imh, n_y, endpoint=False))
-        fl = .5 * imw / np.tan(.5 * angle_x)
-        local = np.stack(((xs - .5 * imw) / fl, -(ys - .5 * imh) / fl, -np.ones_like(xs)), -1)
-        rayd = local @ to_world[:3, :3].T
-        rayo = np.broadcast_to(to_world[:3, 3], rayd.shape).copy()
-        return rayo, rayd
+        return gen_rays(to_world, angle_x, imh, imw, self.sps)

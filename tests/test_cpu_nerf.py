@@ -168,3 +168,21 @@ def test_packed_blob_through_lane_emulation_matches_oracle(nfx_lib):
     # and the bf16 path is a small perturbation of the fp32 reference
     want32 = nerf_ref.eval_nerf_at(pts[:, None, :], views[:, None, :], net)[:, 0, :]
     assert np.max(np.abs(got - want32)) < 0.15
+
+
+def test_synth_matches_test_generators():
+    """bench.py's product-side generators (nerfactor_amd/synth.py, no oracle import) produce the arrays of the
+    oracle-based test generators, so bench numbers and test parity refer to the same weights and rays."""
+    from nerfactor_amd import synth
+    for a, b in zip(synth.nerf_nets(0), common.nerf_nets(0)):
+        for name in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            for (k1, b1), (k2, b2) in zip(a[name], b[name]):
+                assert np.array_equal(k1, k2) and np.array_equal(b1, b2), name
+    ro, rd = synth.camera_rays(37, 41, cam_loc=(1., 2., 3.))
+    ro2, rd2 = common.camera_rays(37, 41, cam_loc=(1., 2., 3.))
+    assert np.array_equal(ro, ro2) and np.allclose(rd, rd2, rtol=0, atol=1e-6)
+    import ast
+    src = open(synth.__file__).read()
+    mods = {n.module if isinstance(n, ast.ImportFrom) else a.name for n in ast.walk(ast.parse(src))
+            if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names}
+    assert not any(m and m.split('.')[0] in ('oracle', 'tests') for m in mods), mods

@@ -147,3 +147,35 @@ def test_brdf_pack_through_emulation(nfx_lib, zd):
     x = np.concatenate((z, nerf_ref.embed(rus, 2)), -1)
     want = R.mlp128(x, layers, out, None, quant=nerf_ref.bf16_round)[:, 0]
     np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("variant", ['microfacet', 'learned'])
+def test_torch_port_of_the_render_matches_the_numpy_oracle(variant):
+    """oracle/torch_ref.py:nerfactor_render (the timed CPU baseline and PSNR reference of bench.py's NeRFactor legs)
+    against oracle/nerfactor_ref.py:nerfactor_call, which is the restatement pinned to the reference fixtures."""
+    import torch
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(0)
+    n = 48
+    net = R.init_nerfactor_net(rng, 1 if variant == 'microfacet' else 3)
+    for k in net:
+        net[k] = [(w, rng.uniform(-.2, .2, size=b.shape).astype(np.float32)) for w, b in net[k]]
+    bn = R.init_brdf_mlp(rng, 3)
+    lxyz, lareas = R.gen_light_xyz(16, 32)
+    lxyz, lareas = lxyz.astype(np.float32), lareas.astype(np.float32)
+    xyz = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    alpha = (rng.uniform(size=(n, 1)) < .6).astype(np.float32)
+    rayo = np.broadcast_to(np.array([2.2, -2.4, 1.7], np.float32), (n, 3)).copy()
+    light = rng.uniform(size=(16, 32, 3)).astype(np.float32)
+    probes = [np.exp(rng.normal(size=(16, 32, 3))).astype(np.float32) for _ in range(2)]
+    batch = (rayo, np.zeros((n, 3), np.float32), alpha, xyz, np.ones((n, 3), np.float32), np.ones((n, 512), np.float32))
+    pred = R.nerfactor_call(batch, net, lxyz, lareas, light, variant=variant, brdf_net=bn, probes=probes)[0]
+    t = lambda d: {k: [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in v] for k, v in d.items()}
+    lights = torch.from_numpy(np.stack([light] + probes).reshape(3, -1, 3))
+    out = T.nerfactor_render((torch.from_numpy(rayo), torch.from_numpy(alpha), torch.from_numpy(xyz)), t(net),
+                             torch.from_numpy(lxyz), torch.from_numpy(lareas), lights, variant=variant, brdf_net=t(bn))
+    assert np.abs(out['rgb'][:, 0].numpy() - pred['rgb']).max() < 2e-5
+    assert np.abs(out['rgb'][:, 1:].numpy() - pred['rgb_probes']).max() < 2e-5
+    for k in ('normal', 'lvis', 'albedo', 'brdf'):
+        assert np.abs(out[k].numpy() - pred[k]).max() < 5e-6, k
+    assert (out['rgb'][alpha[:, 0] == 0] == 0).all()
