@@ -27,6 +27,8 @@ int nfx_launch_mlp128_xyz(const float*, long long, float, const void*, int, int,
 int nfx_launch_lvis_pre(const float*, long long, float, const void*, float*, int, hipStream_t);
 int nfx_launch_brdf_spec_v2(const float*, const float*, const float*, const float*, int, const float*, int,
                             const void*, long long, float*, int, int, hipStream_t);
+int nfx_launch_brdf_spec_v3(const float*, const float*, const float*, const float*, int, const float*, int,
+                            const void*, long long, float*, int, int, int, hipStream_t);
 int nfx_launch_lvis_v2(const float*, long long, const float*, int, const float*, const void*, float*, int, int,
                        hipStream_t);
 int nfx_launch_lvis(const float*, long long, const float*, int, const float*, const void*, float*, int,
@@ -187,7 +189,17 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
     if (n == 0) return NFX_OK;
     REQUIRE(xyz && cam && normal && z && lxyz && blob && spec, "nfx_brdf_spec_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_fwd: blob must be 16-byte aligned");
-    const int variant = nfx_env_int("NFX_BRDF_VARIANT", 3);   // as NFX_LVIS_VARIANT
+    // NFX_BRDF_VARIANT: 0 / 2 / 3 / 4 as NFX_LVIS_VARIANT (every row evaluated, back-lit rows zeroed afterwards);
+    // 5 = front-lit rows only (LDS row queue per wave), per-row geometry as in the dense kernels (bit-identical);
+    // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT = column tiles per wave of variants 5 / 6.
+    int variant = nfx_env_int("NFX_BRDF_VARIANT", 6);
+    if (variant >= 5) {
+        const int rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
+                                               nfx_env_int("NFX_BRDF_CT", 4), variant == 6,
+                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
+        if (rc != -1) return nfx_hip_result(rc, "brdf_spec_fwd(v3)");
+        variant = 3;   // shape outside the row queue's limits: dense kernel
+    }
     if (variant >= 2 && variant <= 4)
         return nfx_hip_result(nfx_launch_brdf_spec_v2(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, variant,
                                                       nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),

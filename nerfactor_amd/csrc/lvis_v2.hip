@@ -380,6 +380,246 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Learned-BRDF specular term with FRONT-LIT COMPACTION (nerfactor.py:429-441: the reference evaluates the BRDF MLP on
+// the rows with local l.z > 0 only and scatters them into a zero tensor; about half of the light sphere).
+// Every wave works alone (no barrier after the one-time network load): it owns the points gw, gw + NW, gw + 2 NW, ...
+// (interleaved, so spatially coherent normals do not unbalance the waves), FILLS a private LDS ring with the
+// front-lit (point, light) rows of its next point — ballot + mbcnt prefix, back-lit rows get their 0 right there —
+// and whenever the ring holds a full pass (CT x 32 rows) runs the 17-tile network on rows that may straddle points.
+// GEO = 0: the per-row geometry of resident128_kernel<CT, 1> (same functions, bit-identical outputs).
+// GEO = 1: Rusinkiewicz angles without the two Rodrigues rotations' sin / cos and without the half-vector azimuth
+//          (cos phi_h = h_x / s, sin phi_h = h_y / s, sin theta_h = s = |h_xy|), polynomial acos / atan2, and the
+//          two-band encoding of the three angles from double-angle identities instead of 6 v_sin / v_cos.
+constexpr int kRing = 1024;   // ring entries per wave (4 KiB): (local point index << 10) | light
+static_assert(kLds >= kLdsNet + kNW * kRing * 4, "ring area");
+
+__device__ __forceinline__ float acos_poly(float x) {   // Abramowitz-Stegun 4.4.46, |err| <= 2e-8 + fp32 rounding
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = fmaf(p, ax, 0.0066700901f);
+    p = fmaf(p, ax, -0.0170881256f);
+    p = fmaf(p, ax, 0.0308918810f);
+    p = fmaf(p, ax, -0.0501743046f);
+    p = fmaf(p, ax, 0.0889789874f);
+    p = fmaf(p, ax, -0.2145988016f);
+    p = fmaf(p, ax, 1.5707963050f);
+    const float r = sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979323846f - r : r;
+}
+__device__ __forceinline__ float atan2_poly(float y, float x) {   // Cephes atanf polynomial, |err| <= 3e-7
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+    const bool big = t > 0.4142135623730950f;
+    const float t2 = big ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+    const float zz = t2 * t2;
+    float q = fmaf(8.05374449538e-2f, zz, -1.38776856032e-1f);
+    q = fmaf(q, zz, 1.99777106478e-1f);
+    q = fmaf(q, zz, -3.33329491539e-1f);
+    float r = fmaf(q * zz, t2, t2) + (big ? 0.78539816339744830962f : 0.0f);
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return y < 0.0f ? -r : r;
+}
+
+// B-operand values (slot order of brdf_input_slots(), capi_nerfactor.cpp) of one (point, light) row, lane half h
+template <int GEO>
+__device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float (&lp)[3], const float (&cm)[3],
+                                                const float (&nr)[3], const float* zp, int z_dim, int h,
+                                                float (&v)[16]) {
+    float ldir[3], vdir[3], rot[9], ll[3], vl[3];
+    dir_to(lp, x, ldir);          // shape.py:128-131
+    dir_to(cm, x, vdir);          // shape.py:137-140
+    world2local(nr, rot);         // util/geom.py:119-149
+    mat3_apply(rot, ldir, ll);    // nerfactor.py:418-419
+    mat3_apply(rot, vdir, vl);
+    if constexpr (GEO == 0) {
+        float rus[3];
+        dir2rusink(ll, vl, rus);  // util/geom.py:152-192 with a = light, b = view
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = sin_shifted_small(rus[q % 3] * (float)(1 << (q / 3)), h);
+        v[6] = h ? rus[2] : rus[0];
+        v[7] = h ? zp[0] : rus[1];
+    } else {
+        normalize3(ll, 1e-6f);    // dir2rusink re-normalises its inputs (geom.py:158-159)
+        normalize3(vl, 1e-6f);
+        float hv[3] = {(ll[0] + vl[0]) / 2.0f, (ll[1] + vl[1]) / 2.0f, (ll[2] + vl[2]) / 2.0f};
+        normalize3(hv, 1e-6f);
+        const float cth = fminf(fmaxf(hv[2], -1.0f), 1.0f);
+        const float sxy = sqrtf(hv[0] * hv[0] + hv[1] * hv[1]);           // sin(theta_h) >= 0
+        const float inv = sxy > 0.0f ? __builtin_amdgcn_rcpf(sxy) : 0.0f;
+        const float cph = sxy > 0.0f ? hv[0] * inv : 1.0f, sph = hv[1] * inv;   // atan2(0, 0) = 0
+        // diff = R_y(-theta_h) R_z(-phi_h) b with b = view (geom.py:183)
+        const float t0 = vl[0] * cph + vl[1] * sph, t1 = vl[1] * cph - vl[0] * sph;
+        const float d0 = t0 * cth - vl[2] * sxy, d1 = t1, d2 = vl[2] * cth + t0 * sxy;
+        const float ctd = fminf(fmaxf(d2, -1.0f), 1.0f);
+        const float rxy = sqrtf(d0 * d0 + d1 * d1);                       // sin(theta_d) >= 0
+        const float theta_h = acos_poly(cth), theta_d = acos_poly(ctd);
+        const float pi = 3.14159265358979323846f;
+        float phi_d = atan2_poly(d1, d0);
+        phi_d = phi_d - floorf(phi_d / pi) * pi;                          // tf.math.floormod(x, pi)
+        const float rinv = rxy > 0.0f ? __builtin_amdgcn_rcpf(rxy) : 0.0f;
+        const bool flip = d1 < 0.0f || (d1 == 0.0f && d0 < 0.0f);        // + pi: both signs change
+        const float cpd0 = rxy > 0.0f ? d0 * rinv : 1.0f, spd0 = d1 * rinv;
+        const float cpd = flip ? -cpd0 : cpd0, spd = flip ? -spd0 : spd0;
+        // band 0: (phi_d, theta_h, theta_d), band 1: the doubled angles
+        if (h == 0) {
+            v[0] = spd; v[1] = sxy; v[2] = rxy;
+            v[3] = 2.0f * spd * cpd; v[4] = 2.0f * sxy * cth; v[5] = 2.0f * rxy * ctd;
+        } else {
+            v[0] = cpd; v[1] = cth; v[2] = ctd;
+            v[3] = cpd * cpd - spd * spd; v[4] = cth * cth - sxy * sxy; v[5] = ctd * ctd - rxy * rxy;
+        }
+        v[6] = h ? theta_d : phi_d;
+        v[7] = h ? zp[0] : theta_h;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = 1 + 2 * j + h;
+        v[8 + j] = i < z_dim ? zp[i] : 0.0f;
+    }
+}
+
+template <int CT, int GEO>
+__global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace m128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    {   // the whole network, once
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.blob);
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        for (int i = tid; i < kLdsNet / 16; i += kNW * 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    const char* wlds = smem;
+    const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
+    unsigned* ring = reinterpret_cast<unsigned*>(smem + kLdsNet) + wave * kRing;
+    const int L = a.n_lights;
+    const long long n = a.n;
+    const long long nw = (long long)gridDim.x * kNW, gw = (long long)blockIdx.x * kNW + wave;
+    constexpr int kPass = CT * 32;
+    // fill-side inputs of a point, one element per lane: [x(3) | normal(3)], fetched one point ahead
+    auto load_pt = [&](long long pt) {
+        float r = 0.0f;
+        if (pt < n) {
+            if (lane < 3) r = a.xyz[pt * 3 + lane];
+            else if (lane < 6) r = a.normal[pt * 3 + lane - 3];
+            else if (lane < 9) r = a.cam[pt * 3 + lane - 6];          // touched here so the pass finds it in cache
+            else if (lane < 9 + a.z_dim) r = a.z[pt * a.z_dim + lane - 9];
+        }
+        return r;
+    };
+    long long kfill = 0;
+    int head = 0, cnt = 0;
+    float nxt = load_pt(gw);
+    for (;;) {
+        // ---- fill: front-lit rows of the next points until a whole pass is queued (ring: kPass - 1 + L <= kRing)
+        while (cnt < kPass) {
+            const long long pt = gw + kfill * nw;
+            if (pt >= n) break;
+            const float cur = nxt;
+            nxt = load_pt(pt + nw);
+            float x[3], nr[3], rot[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                x[k] = __shfl(cur, k, 64);
+                nr[k] = __shfl(cur, 3 + k, 64);
+            }
+            world2local(nr, rot);
+            for (int l0 = 0; l0 < L; l0 += 64) {
+                const int l = l0 + lane;
+                const bool valid = l < L;
+                const int lc = valid ? l : L - 1;
+                const float lp[3] = {a.lxyz[lc * 3], a.lxyz[lc * 3 + 1], a.lxyz[lc * 3 + 2]};
+                float ldir[3], ll[3];
+                dir_to(lp, x, ldir);
+                mat3_apply(rot, ldir, ll);
+                const bool fr = valid && ll[2] > 0.0f;                    // nerfactor.py:429-432
+                const unsigned long long mask = __ballot(fr);
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (fr) ring[(head + cnt + pos) & (kRing - 1)] = (unsigned)(kfill << 10) | (unsigned)l;
+                else if (valid) a.out[pt * L + l] = 0.0f;                 // scatter_nd's zeros
+                cnt += __popcll(mask);
+            }
+            ++kfill;
+        }
+        if (cnt == 0) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rows = cnt < kPass ? cnt : kPass;
+        // ---- pass: CT column tiles of 32 queued rows
+        bf16x8 pl[2][CT];
+        long long orow[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int r = c * 32 + p;
+            const bool ok = r < rows;
+            const unsigned e = ring[(head + (ok ? r : 0)) & (kRing - 1)];
+            const long long pt = gw + (long long)(e >> 10) * nw;
+            const int l = (int)(e & 1023u);
+            orow[c] = ok ? pt * L + l : -1;
+            float x[3], lp[3], cm[3], nr[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                x[k] = a.xyz[pt * 3 + k];
+                lp[k] = a.lxyz[l * 3 + k];
+                cm[k] = a.cam[pt * 3 + k];
+                nr[k] = a.normal[pt * 3 + k];
+            }
+            float v[16];
+            brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, h, v);
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+        }
+        bf16x8 ha[8][CT], hb[8][CT];
+        Acc<CT> accs[2];
+        Pre pre;
+        {
+            const char* f0 = wlds + lane * 16;
+            pre.a[0] = *reinterpret_cast<const bf16x8*>(f0);
+            pre.a[1] = *reinterpret_cast<const bf16x8*>(f0 + kFragBytes);
+            InitBias{bias_lds}(lane, accs[0]);
+        }
+#define NFX_LV3_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
+        tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
+#define NFX_LV3_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
+#define NFX_LV3_BIAS(OFF) (InitBias{bias_lds + (OFF)})
+        NFX_LV3_TILE(0, 2, 0, pl, pl, EpiNone{}, NFX_LV3_BIAS(32));
+        NFX_LV3_TILE(1, 2, 0, pl, pl, NFX_LV3_EPI(0, ha, 0), NFX_LV3_BIAS(64));
+        NFX_LV3_TILE(2, 2, 0, pl, pl, NFX_LV3_EPI(1, ha, 1), NFX_LV3_BIAS(96));
+        NFX_LV3_TILE(3, 2, 0, pl, pl, NFX_LV3_EPI(2, ha, 2), NFX_LV3_BIAS(128));
+        NFX_LV3_TILE(4, 8, 0, ha, pl, NFX_LV3_EPI(3, ha, 3), NFX_LV3_BIAS(128 + 32));
+        NFX_LV3_TILE(5, 8, 0, ha, pl, NFX_LV3_EPI(4, hb, 0), NFX_LV3_BIAS(128 + 64));
+        NFX_LV3_TILE(6, 8, 0, ha, pl, NFX_LV3_EPI(5, hb, 1), NFX_LV3_BIAS(128 + 96));
+        NFX_LV3_TILE(7, 8, 0, ha, pl, NFX_LV3_EPI(6, hb, 2), NFX_LV3_BIAS(256));
+        NFX_LV3_TILE(8, 8, 0, hb, pl, NFX_LV3_EPI(7, hb, 3), NFX_LV3_BIAS(256 + 32));
+        NFX_LV3_TILE(9, 8, 0, hb, pl, NFX_LV3_EPI(8, ha, 0), NFX_LV3_BIAS(256 + 64));
+        NFX_LV3_TILE(10, 8, 0, hb, pl, NFX_LV3_EPI(9, ha, 1), NFX_LV3_BIAS(256 + 96));
+        NFX_LV3_TILE(11, 8, 0, hb, pl, NFX_LV3_EPI(10, ha, 2), NFX_LV3_BIAS(384));
+        NFX_LV3_TILE(12, 8, 2, ha, pl, NFX_LV3_EPI(11, ha, 3), NFX_LV3_BIAS(384 + 32));
+        NFX_LV3_TILE(13, 8, 2, ha, pl, NFX_LV3_EPI(12, hb, 0), NFX_LV3_BIAS(384 + 64));
+        NFX_LV3_TILE(14, 8, 2, ha, pl, NFX_LV3_EPI(13, hb, 1), NFX_LV3_BIAS(384 + 96));
+        NFX_LV3_TILE(15, 8, 2, ha, pl, NFX_LV3_EPI(14, hb, 2), NFX_LV3_BIAS(512));
+        NFX_LV3_TILE(16, 8, 0, hb, pl, NFX_LV3_EPI(15, hb, 3), [](int, Acc<CT>&) {});
+#undef NFX_LV3_TILE
+#undef NFX_LV3_EPI
+#undef NFX_LV3_BIAS
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                if (orow[c] >= 0) a.out[orow[c]] = softplusf(accs[0].v[c][0]);   // brdf.py:65
+        }
+        head = (head + rows) & (kRing - 1);
+        cnt -= rows;
+    }
+}
+
 }  // namespace lv2
 }  // namespace nfx
 
@@ -414,6 +654,32 @@ extern "C" int nfx_launch_brdf_spec_v2(const float* xyz, const float* cam, const
     if (ct == 2) return launch_res<2, 1>(a, max_blocks, st);
     if (ct == 3) return launch_res<3, 1>(a, max_blocks, st);
     return launch_res<4, 1>(a, max_blocks, st);
+}
+
+template <int CT, int GEO>
+static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
+    using namespace nfx;
+    const long long want = (a.n + lv2::kNW - 1) / lv2::kNW;       // at least one point per wave
+    const int grid = (int)(want < max_blocks ? want : max_blocks);
+    auto k = lv2::brdf_compact_kernel<CT, GEO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lv2::kLds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(lv2::kNW * 64), lv2::kLds, st, a);
+    return (int)hipGetLastError();
+}
+
+// Front-lit compaction (brdf_compact_kernel).  geo: 0 = reference op sequence per row, 1 = closed-form Rusinkiewicz.
+// Returns -1 when the shape does not fit the ring / entry packing (the caller falls back to the dense kernel).
+extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const float* normal, const float* z,
+                                       int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
+                                       float* spec, int ct, int geo, int max_blocks, hipStream_t st) {
+    if (n <= 0) return 0;
+    const long long waves = (long long)nfx::lv2::kNW * (((n + 3) / 4) < max_blocks ? ((n + 3) / 4) : max_blocks);
+    if (n_lights > 1024 || ct * 32 - 1 + n_lights > nfx::lv2::kRing || (n + waves - 1) / waves >= (1ll << 22)) return -1;
+    nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
+    if (ct == 3) return geo ? launch_compact<3, 1>(a, max_blocks, st) : launch_compact<3, 0>(a, max_blocks, st);
+    return geo ? launch_compact<4, 1>(a, max_blocks, st) : launch_compact<4, 0>(a, max_blocks, st);
 }
 
 #ifdef NFX_LV2_TIMING

@@ -96,13 +96,17 @@ def test_lvis_vs_oracle(nfx_lib, cuda, n, nl_h):
     assert np.max(np.abs(got - want_q)) < 1e-2  # the per-point fold keeps posenc(xyz) sums in fp32
 
 
-@pytest.mark.parametrize("zd", [3, 1])
-def test_brdf_spec_vs_oracle(nfx_lib, cuda, zd):
+@pytest.mark.parametrize("zd,variant,n,nl_h", [(3, "6", 50, 16), (1, "6", 50, 16), (3, "5", 50, 16), (3, "3", 50, 16),
+                                               (3, "6", 1, 16), (3, "6", 700, 4), (2, "6", 1500, 16), (3, "5", 1027, 8)])
+def test_brdf_spec_vs_oracle(nfx_lib, cuda, monkeypatch, zd, variant, n, nl_h):
+    """Learned-BRDF specular term: dense kernel (3), front-lit compaction with the reference's per-row op sequence
+    (5) and with closed-form Rusinkiewicz angles (6, the default) against the oracle; point counts below / above the
+    number of waves of the grid (1024) and light counts that leave the last ballot half empty."""
     from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_BRDF_VARIANT", variant)
     layers, out = net128(40 + zd, zd + 15, 1)
     blob = pack(layers, out, nfx_lib.IN_Z_RUSINK, 1, cuda, z_dim=zd)
-    n = 50
-    rng, lxyz, _, xyz, cam, normal = scene(n, 41)
+    rng, lxyz, _, xyz, cam, normal = scene(n, 41, nl_h)
     z = rng.normal(size=(n, zd)).astype(np.float32)
     got = ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda),
                             dev(lxyz, cuda), blob).cpu().numpy()
@@ -112,9 +116,12 @@ def test_brdf_spec_vs_oracle(nfx_lib, cuda, zd):
     want_q = R.learned_spec(surf2l, surf2c, normal, z, brdf_net, quant=nerf_ref.bf16_round)
     front = np.einsum('nij,nlj->nli', R.gen_world2local(normal), surf2l)[..., 2]
     stable = np.abs(front) > 1e-4  # the front-lit test is a step function of a fp32 dot product
-    assert np.all(got[stable & (front <= 0)] == 0)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert np.all(got[stable & (front <= 0)] == 0) and np.all(got[stable & (front > 0)] > 0)
     assert np.max(np.abs(got - want_q)[stable]) < 6e-3 * max(1., want.max())
     assert np.max(np.abs(got - want)[stable]) < 3e-2 * max(1., want.max())
+    assert ops.brdf_spec_fwd(dev(xyz[:0], cuda), dev(cam[:0], cuda), dev(normal[:0], cuda), dev(z[:0], cuda),
+                             dev(lxyz, cuda), blob).shape == (0, lxyz.shape[0])
 
 
 def _shade_inputs(n, seed):
@@ -313,8 +320,15 @@ def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     blob = pack(layers, out, nfx_lib.IN_Z_RUSINK, 1, cuda, z_dim=3)
     z = rng.normal(size=(n, 3)).astype(np.float32)
     outs = {}
-    for v in ("0", "2", "3", "4"):
+    for v in ("0", "2", "3", "4", "5", "6"):
         monkeypatch.setenv("NFX_BRDF_VARIANT", v)
         outs[v] = ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda), dev(lxyz, cuda), blob)
-    for v in ("2", "3", "4"):
+    for v in ("2", "3", "4", "5"):   # 5 = front-lit compaction with the same per-row arithmetic
         assert torch.equal(outs["0"], outs[v]), "brdf variant " + v
+    monkeypatch.setenv("NFX_BRDF_CT", "3")
+    monkeypatch.setenv("NFX_BRDF_VARIANT", "5")
+    assert torch.equal(outs["0"], ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda),
+                                                    dev(lxyz, cuda), blob))
+    # 6 = closed-form angles: same rows evaluated, values within the rounding of the bf16 MLP inputs
+    assert torch.equal(outs["0"] > 0, outs["6"] > 0)
+    assert (outs["0"] - outs["6"]).abs().max().item() < 2e-2 * max(1., outs["0"].max().item())
