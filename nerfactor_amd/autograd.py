@@ -30,42 +30,42 @@ class Mlp128Xyz(torch.autograd.Function):
     """out = post_scale * act(out(mlp(posenc10(xyz_scale * xyz)))) + post_bias."""
 
     @staticmethod
-    def forward(ctx, xyz, fwd_blob, train_blob_fn, out_dim, out_act, xyz_scale, post_scale, post_bias,
+    def forward(ctx, xyz, fwd_blob, train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, post_bias,
                 *params):
         ctx.save_for_backward(xyz)
-        ctx.cfg = (train_blob_fn, out_dim, out_act, xyz_scale, post_scale, len(params), params)
+        ctx.cfg = (train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, params)
         return ops.mlp128_xyz_fwd(xyz, fwd_blob, out_dim, out_act=out_act, xyz_scale=xyz_scale,
-                                  post_scale=post_scale, post_bias=post_bias)
+                                  post_scale=post_scale, post_bias=post_bias, prec=prec)
 
     @staticmethod
     def backward(ctx, dout):
         (xyz,) = ctx.saved_tensors
-        train_blob_fn, out_dim, out_act, xyz_scale, post_scale, n_params, params = ctx.cfg
+        train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, params = ctx.cfg
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
-                       xyz_scale=xyz_scale, post_scale=post_scale)
-        return (None,) * 8 + tuple(rks) + tuple(rbs)
+                       xyz_scale=xyz_scale, post_scale=post_scale, prec=prec)
+        return (None,) * 9 + tuple(rks) + tuple(rbs)
 
 
 class Lvis(torch.autograd.Function):
     """lvis[n, L] = sigmoid(out(mlp([posenc10(xyz_scale*xyz), posenc4(dir(lxyz - xyz_dir))])))."""
 
     @staticmethod
-    def forward(ctx, xyz, xyz_dir, lxyz, fwd_blob, train_blob_fn, xyz_scale, *params):
+    def forward(ctx, xyz, xyz_dir, lxyz, fwd_blob, train_blob_fn, prec, xyz_scale, *params):
         ctx.save_for_backward(xyz, xyz_dir, lxyz)
-        ctx.cfg = (train_blob_fn, xyz_scale, params)
-        return ops.lvis_fwd(xyz, lxyz, fwd_blob, xyz_scale=xyz_scale, xyz_dir=xyz_dir)
+        ctx.cfg = (train_blob_fn, prec, xyz_scale, params)
+        return ops.lvis_fwd(xyz, lxyz, fwd_blob, xyz_scale=xyz_scale, xyz_dir=xyz_dir, prec=prec)
 
     @staticmethod
     def backward(ctx, dout):
         xyz, xyz_dir, lxyz = ctx.saved_tensors
-        train_blob_fn, xyz_scale, params = ctx.cfg
+        train_blob_fn, prec, xyz_scale, params = ctx.cfg
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ_LDIR, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act='sigmoid',
-                       xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir)
-        return (None,) * 6 + tuple(rks) + tuple(rbs)
+                       xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir, prec=prec)
+        return (None,) * 7 + tuple(rks) + tuple(rbs)
 
 
 class ShadeMicrofacet(torch.autograd.Function):
@@ -94,16 +94,17 @@ class BrdfSpec(torch.autograd.Function):
     """spec[n, L] of the frozen learned BRDF; differentiable w.r.t. the normal and the latent z."""
 
     @staticmethod
-    def forward(ctx, xyz, cam, lxyz, fwd_blob, train_blob_fn, normal, z):
+    def forward(ctx, xyz, cam, lxyz, fwd_blob, train_blob_fn, prec, normal, z):
         ctx.save_for_backward(xyz, cam, lxyz, normal, z)
-        ctx.train_blob_fn = train_blob_fn
-        return ops.brdf_spec_fwd(xyz, cam, normal, z, lxyz, fwd_blob)
+        ctx.train_blob_fn, ctx.prec = train_blob_fn, prec
+        return ops.brdf_spec_fwd(xyz, cam, normal, z, lxyz, fwd_blob, prec=prec)
 
     @staticmethod
     def backward(ctx, dspec):
         xyz, cam, lxyz, normal, z = ctx.saved_tensors
-        d_z, d_normal = ops.brdf_spec_bwd(xyz, cam, normal, z, lxyz, ctx.train_blob_fn(), dspec.contiguous())
-        return (None,) * 5 + (d_normal, d_z)
+        d_z, d_normal = ops.brdf_spec_bwd(xyz, cam, normal, z, lxyz, ctx.train_blob_fn(), dspec.contiguous(),
+                                          prec=ctx.prec)
+        return (None,) * 6 + (d_normal, d_z)
 
 
 class ShadeSpec(torch.autograd.Function):

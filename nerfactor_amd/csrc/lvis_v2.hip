@@ -339,7 +339,16 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
         // chunk K accumulates in accs[K & 1]; layers: L0 K 0-3 (pl -> ha), L1 4-7 (ha -> hb), L2 8-11 (hb -> ha),
         // L3 12-15 ([ha ; pl] -> hb), out 16 (hb -> activation)
 #ifdef NFX_LV2_TIMING
-#define NFX_LV2_STAMP(K) if (blockIdx.x == 7 && tid == 0 && tl == blockIdx.x + 4 * (long long)gridDim.x) nfx_lv2_times[K] = __builtin_readcyclecounter();
+// diagnostic experiments on the "first tile of a layer is 2-3x slower" signature (NFX_LV2_X):
+//   1 = every layer reads the SAME B registers (ha), outputs still go where they went: no fresh B operands
+//   2 = the wave sleeps ~30 k cycles before the first tile of layers 1-3: anything still in flight has landed
+#ifndef NFX_LV2_X
+#define NFX_LV2_X 0
+#endif
+#define NFX_LV2_STAMP(K) \
+    if (NFX_LV2_X == 2 && ((K) == 4 || (K) == 8 || (K) == 12)) { \
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } \
+    if (blockIdx.x == 7 && tid == 0 && tl == blockIdx.x + 4 * (long long)gridDim.x) nfx_lv2_times[K] = __builtin_readcyclecounter();
 #else
 #define NFX_LV2_STAMP(K)
 #endif
@@ -355,10 +364,15 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
         NFX_LV2_TILE(5, 8, 0, ha, pl, NFX_LV2_EPI(4, hb, 0), (InitBias{bias_lds + 128 + 64}));
         NFX_LV2_TILE(6, 8, 0, ha, pl, NFX_LV2_EPI(5, hb, 1), (InitBias{bias_lds + 128 + 96}));
         NFX_LV2_TILE(7, 8, 0, ha, pl, NFX_LV2_EPI(6, hb, 2), (InitBias{bias_lds + 256}));
-        NFX_LV2_TILE(8, 8, 0, hb, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
-        NFX_LV2_TILE(9, 8, 0, hb, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
-        NFX_LV2_TILE(10, 8, 0, hb, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
-        NFX_LV2_TILE(11, 8, 0, hb, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));
+#if defined(NFX_LV2_TIMING) && NFX_LV2_X == 1
+#define NFX_LV2_HB ha
+#else
+#define NFX_LV2_HB hb
+#endif
+        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
+        NFX_LV2_TILE(9, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
+        NFX_LV2_TILE(10, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
+        NFX_LV2_TILE(11, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));
         NFX_LV2_TILE(12, 8, 2, ha, pl, NFX_LV2_EPI(11, ha, 3), init03(128 + 32, 384 + 32));
         NFX_LV2_TILE(13, 8, 2, ha, pl, NFX_LV2_EPI(12, hb, 0), init03(128 + 64, 384 + 64));
         NFX_LV2_TILE(14, 8, 2, ha, pl, NFX_LV2_EPI(13, hb, 1), init03(128 + 96, 384 + 96));

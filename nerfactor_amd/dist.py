@@ -87,6 +87,32 @@ class FlatBucket:
         return self.views, self.flat[-1]
 
 
+def broadcast_model(model, optimizer=None, src=0):
+    """Mirror rank `src`'s model onto every rank: all parameters and buffers (trainable or frozen) and, if given,
+    the optimizer's flat parameter buffer and moments.  tf.distribute.MirroredStrategy creates every variable once
+    and mirrors its initial value (trainvali.py:259-262); with one process per GPU each rank would otherwise keep
+    its own random initialisation and the all-reduced gradient would be a sum of gradients taken at different
+    points.  No-op for a single process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        if optimizer is not None:   # the trainable parameters are views of optimizer.flat: one call moves them all
+            for t in (optimizer.flat, optimizer.m, optimizer.v, optimizer.vhat):
+                dist.broadcast(t, src)
+            own = {p.data_ptr() for p in optimizer.params}
+        else:
+            own = set()
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.data_ptr() not in own:
+                dist.broadcast(t.data, src)
+        it = torch.tensor([0 if optimizer is None else optimizer.iterations], dtype=torch.int64,
+                          device=next(model.parameters()).device)
+        dist.broadcast(it, src)
+        if optimizer is not None:
+            optimizer.iterations = int(it.item())
+            torch.autograd.graph.increment_version(optimizer.params)   # packed-blob caches follow the new values
+
+
 def local_device():
     """cuda:<LOCAL_RANK> (one process per GPU), made current."""
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))

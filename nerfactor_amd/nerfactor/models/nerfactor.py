@@ -302,7 +302,7 @@ class Model(ShapeModel):
             return self._packed('brdf_mlp_train' + self.precision, ks + bs,
                                 lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=self.precision))
         lxyz = self.lxyz.reshape(-1, 3)
-        spec = nfx_grad.BrdfSpec.apply(xyz, cam, lxyz, fwd_blob, train_blob, normal, brdf_prop)
+        spec = nfx_grad.BrdfSpec.apply(xyz, cam, lxyz, fwd_blob, train_blob, self.precision, normal, brdf_prop)
         return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,
                                         self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
                                         albedo, spec, light_vis, light)

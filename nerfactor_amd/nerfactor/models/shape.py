@@ -115,7 +115,8 @@ class Model(BaseModel):
         params = self._params128(body, head)
         if self._wants_grad(params):
             return nfx_grad.Mlp128Xyz.apply(
-                pts, blob, lambda: self._train_blob128(body, head, _capi.IN_XYZ, out_dim), out_dim, out_act,
+                pts, blob, lambda: self._train_blob128(body, head, _capi.IN_XYZ, out_dim), self.precision, out_dim,
+                out_act,
                 self.xyz_scale, post_scale, post_bias, *params)
         return ops.mlp128_xyz_fwd(pts, blob, out_dim, out_act=out_act, xyz_scale=self.xyz_scale,
                                   post_scale=post_scale, post_bias=post_bias, prec=self.precision)
@@ -179,7 +180,8 @@ class Model(BaseModel):
         if self._wants_grad(params):
             lvis = nfx_grad.Lvis.apply(
                 pts, pts if dir_pts is None else dir_pts, lxyz, blob,
-                lambda: self._train_blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1), self.xyz_scale,
+                lambda: self._train_blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1), self.precision,
+                self.xyz_scale,
                 *params)
         else:
             lvis = ops.lvis_fwd(pts, lxyz, blob, xyz_scale=self.xyz_scale, xyz_dir=dir_pts,

@@ -198,6 +198,7 @@ def main(argv=None):
         vali_batches = None
 
     Model = models.get_model_class(config.get('DEFAULT', 'model'))
+    torch.manual_seed(seed)   # the same initial draw on every rank ...
     model = Model(config, debug=args.debug).to(device)
     model.register_trainable()
     optimizer = optim.make_optimizer(model, config)
@@ -211,6 +212,10 @@ def main(argv=None):
         log("Resumed from step:\n\t%s" % manager.latest_checkpoint)
     else:
         log("Started from scratch")
+    # ... and rank 0's values mirrored explicitly (initial weights, light, latent codes, restored checkpoint,
+    # optimizer moments): every replica steps from the same point, as under MirroredStrategy (trainvali.py:259-262)
+    nfx_dist.broadcast_model(model, optimizer)
+    torch.manual_seed(seed * 9973 + 1 + rank)   # per-rank streams for the jitter / perturbation noise
 
     writer_train = ScalarWriter(join(outdir, 'summary_train'), is_main)
     writer_vali = ScalarWriter(join(outdir, 'summary_vali'), is_main)

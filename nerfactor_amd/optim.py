@@ -64,7 +64,7 @@ class AMSGrad:
                          self.beta_2, self.epsilon)
         # the kernel wrote through raw pointers: tell torch (and the models' packed-blob caches) the parameters changed
         torch.autograd.graph.increment_version(self.params)
-        return total
+        return total.clone()   # `total` is a view of the bucket's last slot, overwritten by the next step
 
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'vhat': self.vhat, 'iterations': self.iterations}

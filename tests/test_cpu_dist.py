@@ -77,3 +77,63 @@ def test_single_process_defaults():
     b.pack([torch.ones(4)], 2.0)
     views, loss = b.all_reduce()
     assert float(loss) == 2.0 and float(views[0].sum()) == 4.0
+
+
+def _keras_amsgrad_cpu(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
+    """CPU stand-in for nfx_amsgrad_step (tf.keras Adam(amsgrad=True): epsilon outside the sqrt, bias correction in
+    the step size) so that optim.AMSGrad's bucket / collective / aliasing logic can run under gloo without a GPU."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    torch.maximum(vhat, v, out=vhat)
+    lr_t = lr * (1 - beta2 ** step) ** 0.5 / (1 - beta1 ** step)
+    p.sub_(lr_t * m / (vhat.sqrt() + eps))
+
+
+def _train_worker(rank, world):
+    """ranks that build their models from different RNG states must still train ONE model."""
+    from nerfactor_amd import dist as nd, ops, optim
+    ops.amsgrad_step = _keras_amsgrad_cpu
+    torch.manual_seed(100 + rank)                      # deliberately different initial weights per rank
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+    model.register_buffer('frozen_table', torch.randn(5))
+    opt = optim.AMSGrad(model.parameters(), lr=1e-2)
+    nd.broadcast_model(model, opt)
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(3, 8, 6, generator=g), torch.randn(3, 8, 2, generator=g)
+    lo, hi = nd.shard_range(8, rank, world)
+    losses = []
+    for k in range(3):
+        opt.zero_grad()
+        per_example = ((model(x_all[k, lo:hi]) - y_all[k, lo:hi]) ** 2).mean(-1)
+        weighted = per_example.sum() / 8
+        weighted.backward()
+        losses.append(opt.step(loss=weighted.detach()))
+    # (a) identical replicas
+    flat = [torch.empty_like(opt.flat) for _ in range(world)]
+    dist.all_gather(flat, opt.flat)
+    assert all(torch.equal(flat[0], f) for f in flat[1:])
+    tabs = [torch.empty(5) for _ in range(world)]
+    dist.all_gather(tabs, model.frozen_table)
+    assert torch.equal(tabs[0], tabs[1])
+    # (b) the same trajectory as ONE process on the whole batch, started from rank 0's initial weights
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+    ropt = optim.AMSGrad(ref.parameters(), lr=1e-2)
+    ref_losses = []
+    was = dist.is_initialized
+    for k in range(3):
+        ropt.zero_grad()
+        w = ((ref(x_all[k]) - y_all[k]) ** 2).mean(-1).sum() / 8
+        w.backward()
+        ropt.bucket.flat[-1] = w.detach()            # single-process step: no collective
+        ops.amsgrad_step(ropt.flat, ropt.bucket.flat[:-1], ropt.m, ropt.v, ropt.vhat, ropt.lr, k + 1)
+        ref_losses.append(float(w))
+    assert torch.allclose(opt.flat, ropt.flat, rtol=0, atol=2e-6), (opt.flat - ropt.flat).abs().max()
+    # (c) ADVICE r01 (medium): the returned losses are values, not aliases of the bucket's last slot
+    got = [float(l) for l in losses]
+    assert np.allclose(got, ref_losses, rtol=1e-5) and len(set(got)) == 3, (got, ref_losses)
+
+
+def test_two_ranks_train_one_model():
+    from tests import mp_util
+    mp_util.run_workers(_train_worker, world=2)
