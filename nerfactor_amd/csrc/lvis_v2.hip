@@ -369,7 +369,16 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
 #else
 #define NFX_LV2_HB hb
 #endif
+#if defined(NFX_LV2_TIMING) && NFX_LV2_X == 3     // tile 8 without the pending epilogue (values wrong, timing only)
+        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, EpiNone{}, (InitBias{bias_lds + 256 + 32}));
+#elif defined(NFX_LV2_TIMING) && NFX_LV2_X == 4   // tile 8 without the next tile's bias reads
+        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(7, hb, 3), [](int, Acc<CT>&) {});
+#elif defined(NFX_LV2_TIMING) && NFX_LV2_X == 5   // tile 8 reads tile 7's A fragments again (same LDS addresses)
+        NFX_LV2_STAMP(8)
+        tile<7, 9, 8, 0, CT>(wlds, lane, hb, pl, accs[0], accs[1], pre, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
+#else
         NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
+#endif
         NFX_LV2_TILE(9, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
         NFX_LV2_TILE(10, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
         NFX_LV2_TILE(11, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));

@@ -20,7 +20,7 @@ import torch
 from nerfactor_amd import _capi, ops
 
 from .. import config as default_configs
-from ..util import config as configutil, img as imgutil, math as mathutil
+from ..util import config as configutil, img as imgutil, light as lightutil, math as mathutil
 from .brdf import Model as BRDFModel
 from .shape import Model as ShapeModel, _mae, _mse
 
@@ -75,19 +75,31 @@ class Model(ShapeModel):
         n_j = 2 if self.debug else self.light_res[1]
         self.novel_olat = OrderedDict(
             ('%04d-%04d' % (i, j), (i, j)) for i in range(n_i) for j in range(n_j))
-        # (2) light probes, [h, w, 3] float tensors (resized to light_res by the loader)
+        # (2) light probes: the .hdr / .exr files of test_envmap_dir (nerfactor.py:88-93), resized to light_res with the
+        # reference's antialiased bilinear filter (:169-179); .npy arrays are accepted as an extension
         self.novel_probes = OrderedDict()
         envmap_dir = cfg.get('DEFAULT', 'test_envmap_dir', fallback='')
-        for path in sorted(glob.glob(join(envmap_dir, '*.npy'))) if envmap_dir else []:
-            self.add_probe(basename(path)[:-len('.npy')], np.load(path))
+        paths = []
+        for ext in ('hdr', 'exr', 'npy'):
+            paths += glob.glob(join(envmap_dir, '*.' + ext)) if envmap_dir else []
+        for path in sorted(paths):
+            self.add_probe(basename(path)[:-len('.hdr')], self._load_light(path))
         self.embed_light_h = cfg.getint('DEFAULT', 'embed_light_h', fallback=32)
 
+    def _load_light(self, path):
+        """[light_h, 2 light_h, 3] float32 array of one probe file (nerfactor.py:169-179)."""
+        return lightutil.resize_antialias(lightutil.read_probe(path), new_h=self.light_res[0])
+
     def add_probe(self, name, envmap):
-        env = torch.as_tensor(np.asarray(envmap), dtype=torch.float32)
-        if tuple(env.shape) != self.light_res + (3,):
-            raise ValueError("probe %s has shape %s, expected %s" % (
-                name, tuple(env.shape), self.light_res + (3,)))
-        self.novel_probes[name] = env
+        """Registers a novel light probe; maps of another resolution are resized like the files of test_envmap_dir."""
+        env = np.asarray(envmap, np.float32)
+        if env.ndim != 3 or env.shape[2] != 3:
+            raise ValueError("probe %s has shape %s, expected [h, w, 3]" % (name, tuple(env.shape)))
+        if tuple(env.shape[:2]) != self.light_res:
+            env = lightutil.resize_antialias(env, new_h=self.light_res[0])
+            if tuple(env.shape[:2]) != self.light_res:
+                raise ValueError("probe %s is not a 2:1 latitude-longitude map" % name)
+        self.novel_probes[name] = torch.from_numpy(np.ascontiguousarray(env))
 
     def olat_envmap(self, name):
         """The [h, w, 3] environment map of one OLAT condition (what the reference stores)."""

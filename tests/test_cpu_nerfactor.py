@@ -179,3 +179,71 @@ def test_torch_port_of_the_render_matches_the_numpy_oracle(variant):
     for k in ('normal', 'lvis', 'albedo', 'brdf'):
         assert np.abs(out[k].numpy() - pred[k]).max() < 5e-6, k
     assert (out['rgb'][alpha[:, 0] == 0] == 0).all()
+
+
+def test_hdr_probe_reader_on_hand_assembled_rgbe_bytes(tmp_path):
+    """util/light.py:read_hdr against bytes assembled here from the Radiance RGBE specification (not by the module's own
+    writer): new-style run-length scanlines (marker 2 2 hi lo, per-channel runs > 128 / literals <= 128), a flat
+    scanline, exponent 0 = black, OpenCV's decoding m * 2^(e - 136) that xm.io.hdr.read returns (io/hdr.py:11-27)."""
+    from nerfactor_amd.nerfactor.util import light as L
+    w = 10
+    # scanline 0 (RLE): R = run of 10 x 128; G = literal 0..9; B = run of 4 x 7 then literal 6 values; E = run 10 x 129
+    rle = bytes([2, 2, 0, w]) + bytes([128 + 10, 128]) + bytes([10] + list(range(10))) + \
+        bytes([128 + 4, 7, 6, 1, 2, 3, 4, 5, 6]) + bytes([128 + 10, 129])
+    # scanline 1 (RLE): everything literal, exponents alternate 0 (black) and 136
+    r1 = list(range(100, 110))
+    rle += bytes([2, 2, 0, w]) + bytes([10] + r1) + bytes([10] + r1) + bytes([10] + r1) + \
+        bytes([10] + [0, 136] * 5)
+    path = str(tmp_path / 'p.hdr')
+    with open(path, 'wb') as h:
+        h.write(b'#?RADIANCE\n# made by hand\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y 2 +X 10\n' + rle)
+    img = L.read_hdr(path)
+    assert img.shape == (2, w, 3) and img.dtype == np.float32
+    f = 2. ** (129 - 136)
+    np.testing.assert_array_equal(img[0, :, 0], np.full(w, 128 * f, np.float32))
+    np.testing.assert_array_equal(img[0, :, 1], np.arange(10, dtype=np.float32) * f)
+    np.testing.assert_array_equal(img[0, :, 2], np.float32([7, 7, 7, 7, 1, 2, 3, 4, 5, 6]) * f)
+    np.testing.assert_array_equal(img[1, 0::2], 0.)                                  # exponent byte 0
+    np.testing.assert_array_equal(img[1, 1::2, 0], np.float32(r1[1::2]))             # 2^(136 - 136) = 1
+    # a width below 8 is always stored flat
+    with open(path, 'wb') as h:
+        h.write(b'#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 2\n' + bytes([1, 2, 3, 137, 4, 5, 6, 135]))
+    np.testing.assert_array_equal(L.read_hdr(path), np.float32([[[2, 4, 6], [2, 2.5, 3]]]))
+
+
+def test_probe_resize_is_the_antialiased_triangle_filter():
+    """tf.image.resize(bilinear, antialias=True) (util/img.py:129-130) = a triangle kernel widened by the down-scaling
+    factor on half-pixel centres; torch's antialiased bilinear interpolation implements the same filter and serves as
+    the independent check.  Constant images stay constant, the mean is preserved."""
+    import torch
+    from nerfactor_amd.nerfactor.util import light as L
+    rng = np.random.default_rng(3)
+    for h in (64, 50, 16, 8):
+        img = np.exp(rng.normal(size=(h, 2 * h, 3))).astype(np.float32)
+        got = L.resize_antialias(img, new_h=16)
+        want = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(16, 32),
+                                               mode='bilinear', antialias=True, align_corners=False)
+        np.testing.assert_allclose(got, want[0].permute(1, 2, 0).numpy(), rtol=2e-6, atol=2e-6)
+    assert np.allclose(L.resize_antialias(np.full((40, 80, 3), 2.5, np.float32), new_h=16), 2.5)
+
+
+def test_model_loads_hdr_probes_from_test_envmap_dir(tmp_path):
+    """ADVICE r01 / VERDICT missing #3: a reference config whose test_envmap_dir holds .hdr probes must yield those
+    probes (name = file name without extension), resized to light_res."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from nerfactor_amd.nerfactor.util import light as L
+    rng = np.random.default_rng(5)
+    maps = {'city': np.exp(rng.normal(size=(32, 64, 3))).astype(np.float32),
+            'studio': np.exp(rng.normal(size=(16, 32, 3))).astype(np.float32)}
+    for name, m in maps.items():
+        L.write_hdr(m, str(tmp_path / (name + '.hdr')))
+    cfg = make_config('nerfactor_microfacet', shape_mode='scratch', test_envmap_dir=str(tmp_path))
+    model = get_model_class('nerfactor_microfacet')(cfg)
+    assert list(model.novel_probes) == ['city', 'studio']
+    for name, m in maps.items():
+        p = model.novel_probes[name].numpy()
+        assert p.shape == (16, 32, 3)
+        want = L.resize_antialias(L.read_hdr(str(tmp_path / (name + '.hdr'))), new_h=16)
+        np.testing.assert_array_equal(p, want)
+        assert abs(p.mean() / m.mean() - 1) < 0.02      # RGBE keeps 8 bits of mantissa
