@@ -191,8 +191,13 @@ struct Args {
     float* out;            // [n,L]
 };
 
-template <int CT, int MODE>
-__global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
+// NW = 4: one wave per SIMD with up to 512 registers (CT = 3 | 4).  NW = 8 (CT = 2): two waves per SIMD with 256
+// registers each share the LDS copy of the network — a wave's stalls (epilogue bursts, the slow first tile of a
+// layer, encoder VALU at the start of a point tile) are covered by its partner's MFMAs; an A fragment feeds 2 MFMAs,
+// 64 B/clk of LDS reads per CU at full MFMA rate, a quarter of the ds_read_b128 peak.
+template <int CT, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
+    constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void resident128_kernel(Args a) {
     const int n_lights = a.n_lights;
     const long long n_rows = a.n * n_lights;
     const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-    float* pre_rows = reinterpret_cast<float*>(smem + kLdsNet) + wave * 1024;   // this wave's [CT][256] floats
+    float* pre_rows = reinterpret_cast<float*>(smem + kLdsNet) + wave * CT * 256;   // this wave's [CT][256] floats
     // point of column tile c in point tile t (clamped), and the copy of its pre row: one 16-byte piece per lane
     auto point_of = [&](long long t, int c) {
         const long long m = t * kTileRows + (wave * CT + c) * 32;
@@ -646,17 +651,18 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
 }  // namespace lv2
 }  // namespace nfx
 
-template <int CT, int MODE>
+template <int CT, int MODE, int NW = 4>
 static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     using namespace nfx;
-    const long long rows = a.n * a.n_lights, tile_rows = lv2::kNW * CT * 32;
+    const long long rows = a.n * a.n_lights, tile_rows = NW * CT * 32;
     const long long tiles = (rows + tile_rows - 1) / tile_rows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    auto k = lv2::resident128_kernel<CT, MODE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lv2::kLds);
+    constexpr int lds = lv2::kLdsNet + NW * CT * 1024;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto k = lv2::resident128_kernel<CT, MODE, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(lv2::kNW * 64), lv2::kLds, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -664,6 +670,7 @@ extern "C" int nfx_launch_lvis_v2(const float* xyz, long long n, const float* lx
                                   const void* blob_main, float* lvis, int ct, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
     nfx::lv2::Args a{xyz, lxyz, pre, nullptr, nullptr, nullptr, 0, n, n_lights, (const char*)blob_main, lvis};
+    if (ct == 8) return launch_res<2, 0, 8>(a, max_blocks, st);   // variant 8: 8 waves x 2 column tiles
     if (ct == 2) return launch_res<2, 0>(a, max_blocks, st);
     if (ct == 3) return launch_res<3, 0>(a, max_blocks, st);
     return launch_res<4, 0>(a, max_blocks, st);

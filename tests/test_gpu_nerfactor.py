@@ -311,10 +311,10 @@ def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     layers, out = net128(31, 90, 1)
     blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
     outs = {}
-    for v in ("0", "2", "3", "4"):
+    for v in ("0", "2", "3", "4", "8"):    # 8 = eight waves (two per SIMD) x 2 column tiles
         monkeypatch.setenv("NFX_LVIS_VARIANT", v)
         outs[v] = ops.lvis_fwd(dev(xyz, cuda), dev(lxyz, cuda), blob, xyz_scale=0.9)
-    for v in ("2", "3", "4"):
+    for v in ("2", "3", "4", "8"):
         assert torch.equal(outs["0"], outs[v]), "lvis variant " + v
     layers, out = net128(43, 18, 1)
     blob = pack(layers, out, nfx_lib.IN_Z_RUSINK, 1, cuda, z_dim=3)
