@@ -10,6 +10,7 @@ LIGHT_SCALE = {'nfl': 0.3, 'nfm': 2.}      # keeps most pixels of both variants 
 GEOM_RAYS, GEOM_LIGHT_H, GEOM_SURF_IDX = 16, 8, [3, 4, 5, 11, 13, 15]
 GEOM_BBOX = '-1.5,1.5,-1.5,1.5,-1.5,1.5'
 SCENE_KW = dict(imh=12, imw=16, n_train=2, n_val=1, n_test=1, light_h=4, seed=5)     # tests/synth_scene.write_scene
+GRAD_NERF_RAYS = 32          # rays of the reference-differentiated NeRF training step (make_reference_grad_golden.py)
 BRDF_NAMES = ['alum-bronze', 'blue-fabric', 'chrome', 'delrin', 'nylon']   # sorted, as xm.os.sortglob returns them
 
 
@@ -131,3 +132,11 @@ def edit_inputs(z_dim):
     rng = np.random.default_rng(49)
     z = rng.uniform(0.2, 0.8, z_dim)
     return _f32([0.9, 1.1, 0.8]), _f32([0.6, 0.3, 0.2]), _f32(rng.uniform(0.1, 0.9, (24, 3))), _f32(z)
+
+
+def summary(a, n_sample=2048):
+    """Compact fingerprint of a large tensor for the gradient fixture: [Frobenius norm, sum, n_sample strided elements]
+    (stride = size // n_sample over the flattened array).  Compare with `summary(other)` element by element."""
+    flat = np.asarray(a, np.float64).reshape(-1)
+    stride = max(1, flat.size // n_sample)
+    return np.concatenate(([np.sqrt(np.sum(flat * flat)), flat.sum()], flat[::stride][:n_sample])).astype(np.float32)
