@@ -25,7 +25,16 @@ int nfx_launch_mlp128_bwd(int, const float*, const float*, long long, float, con
                           int, float, const float*, void*, long long, int, hipStream_t);
 int nfx_mlp128_train_feats(int in_kind);
 int nfx_mlp128_train_blob_bytes(int in_kind);
-int nfx_launch_wgrad(const void*, const void*, long long, int, int, long long, float*, float*, hipStream_t);
+struct nfx_wgrad_call {   // one weight-gradient GEMM of a batched launch (train.hip)
+    const void* xt;
+    const void* zt;
+    int k_in, n_out;
+    float* dw;
+    float* db;
+};
+size_t nfx_wgrad_partial_bytes(const nfx_wgrad_call* calls, int n_calls, long long rows);
+int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
+                           hipStream_t st);
 int nfx_launch_amsgrad(float*, const float*, float*, float*, float*, long long, float, float, float, float,
                        hipStream_t);
 
@@ -93,9 +102,23 @@ static long long ld_for(int in_kind, int64_t n, int n_lights) {
     return (rows + 127) / 128 * 128;
 }
 
+// the six weight-gradient GEMMs of one width-128 backward (pointers filled in by the caller)
+static void mlp128_wgrad_calls(int in_kind, int out_dim, nfx_wgrad_call (&calls)[6]) {
+    const int ind = in_dims(in_kind);
+    const int dims[6][2] = {{ind, 128}, {128, 128}, {128, 128}, {128, 128}, {ind, 128}, {128, out_dim}};
+    for (int i = 0; i < 6; ++i) calls[i] = nfx_wgrad_call{nullptr, nullptr, dims[i][0], dims[i][1], nullptr, nullptr};
+}
+static size_t mlp128_feat_bytes(int in_kind, int64_t n, int n_lights) {
+    return ((size_t)nfx_mlp128_train_feats(in_kind) * ld_for(in_kind, n, n_lights) * 2 + 255) / 256 * 256;
+}
+
 size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights) {
     if (!kind_ok(in_kind) || n <= 0) return 0;
-    return (size_t)nfx_mlp128_train_feats(in_kind) * ld_for(in_kind, n, n_lights) * 2;
+    nfx_wgrad_call calls[6];
+    mlp128_wgrad_calls(in_kind, 8, calls);
+    const long long rows = in_kind == NFX_IN_XYZ ? n : n * (long long)n_lights;
+    // feature-major activations / gradients, then the per-slab partial sums of the weight gradients
+    return mlp128_feat_bytes(in_kind, n, n_lights) + nfx_wgrad_partial_bytes(calls, 6, (rows + 15) / 16 * 16);
 }
 
 int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale,
@@ -128,8 +151,7 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     const char* ws = static_cast<const char*>(workspace);
     auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
     const int oH = kx, oDZ = kx + 512, oDZo = kx + 1024;
-    struct Call { const void* xt; const void* zt; int k_in; int n_out; float* dw; float* db; };
-    const Call calls[] = {
+    const nfx_wgrad_call calls[6] = {
         {feat(0), feat(oDZ + 0), ind, 128, dkernels[0], dbiases[0]},
         {feat(oH + 0), feat(oDZ + 128), 128, 128, dkernels[1], dbiases[1]},
         {feat(oH + 128), feat(oDZ + 256), 128, 128, dkernels[2], dbiases[2]},
@@ -137,11 +159,8 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
         {feat(0), feat(oDZ + 384), ind, 128, dkernels[3] + 128 * 128, nullptr},
         {feat(oH + 384), feat(oDZo), 128, out_dim, dkernels[4], dbiases[4]},
     };
-    for (const Call& c : calls) {
-        rc = nfx_hip_result(nfx_launch_wgrad(c.xt, c.zt, ld, c.k_in, c.n_out, rows16, c.dw, c.db, st), "wgrad");
-        if (rc) return rc;
-    }
-    return NFX_OK;
+    void* partial = static_cast<char*>(workspace) + mlp128_feat_bytes(in_kind, n, n_lights);
+    return nfx_hip_result(nfx_launch_wgrad_batch(calls, 6, ld, rows16, partial, st), "wgrad");
 }
 
 // ------------------------------------------------------------------------------------ NeRF MLP backward
@@ -205,9 +224,19 @@ int nfx_nerf_pack_train_weights(const float* const kernels[12], const float* con
 
 static long long nerf_ld(long long n_pts) { return (n_pts + 127) / 128 * 128; }
 
+static const int kNerfWgradDims[14][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256},
+                                          {256, 256}, {256, 256}, {63, 256}, {256, 1}, {256, 256}, {256, 128},
+                                          {27, 128}, {128, 3}};
+static size_t nerf_feat_bytes(long long n_pts) {
+    return ((size_t)nfx::nerf::kTrainFeats * nerf_ld(n_pts) * 2 + 255) / 256 * 256;
+}
+
 size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
-    return (size_t)nfx::nerf::kTrainFeats * nerf_ld((long long)n_rays * n_samples) * 2;
+    nfx_wgrad_call calls[14];
+    for (int i = 0; i < 14; ++i) calls[i] = nfx_wgrad_call{nullptr, nullptr, kNerfWgradDims[i][0], kNerfWgradDims[i][1], nullptr, nullptr};
+    const long long n_pts = (long long)n_rays * n_samples;
+    return nerf_feat_bytes(n_pts) + nfx_wgrad_partial_bytes(calls, 14, (n_pts + 15) / 16 * 16);
 }
 
 int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
@@ -232,8 +261,7 @@ int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64
     const long long rows16 = (n_pts + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in every dZ
     const char* ws = static_cast<const char*>(workspace);
     auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
-    struct Call { const void* xt; const void* zt; int k_in; int n_out; float* dw; float* db; };
-    std::vector<Call> calls;
+    std::vector<nfx_wgrad_call> calls;
     calls.push_back({feat(kOffPe), feat(kOffDZ), 63, 256, dkernels[0], dbiases[0]});
     for (int l = 1; l <= 7; ++l)
         calls.push_back({feat(kOffA + 256 * (l - 1)), feat(kOffDZ + 256 * l), 256, 256, dkernels[l], dbiases[l]});
@@ -243,11 +271,11 @@ int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64
     calls.push_back({feat(kOffBott), feat(kOffDR0), 256, 128, dkernels[10], dbiases[10]});                // rgb_out[0]
     calls.push_back({feat(kOffPv), feat(kOffDR0), 27, 128, dkernels[10] + 256 * 128, nullptr});
     calls.push_back({feat(kOffR0), feat(kOffDRgb), 128, 3, dkernels[11], dbiases[11]});                   // rgb_out[1]
-    for (const Call& c : calls) {
-        rc = nfx_hip_result(nfx_launch_wgrad(c.xt, c.zt, ld, c.k_in, c.n_out, rows16, c.dw, c.db, st), "wgrad");
-        if (rc) return rc;
-    }
-    return NFX_OK;
+    for (size_t i = 0; i < calls.size(); ++i)
+        if (calls[i].k_in != kNerfWgradDims[i][0] || calls[i].n_out != kNerfWgradDims[i][1])
+            return nfx_fail(NFX_EINVAL, "nfx_nerf_mlp_bwd: weight-gradient table out of sync");
+    void* partial = static_cast<char*>(workspace) + nerf_feat_bytes(n_pts);
+    return nfx_hip_result(nfx_launch_wgrad_batch(calls.data(), (int)calls.size(), ld, rows16, partial, st), "wgrad");
 }
 
 int nfx_composite_bwd(const float* rgbs, const float* z, const float* rayd, const float* noise, int64_t n_rays,

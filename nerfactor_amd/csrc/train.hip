@@ -11,6 +11,35 @@
 
 namespace nfx {
 
+// One launch computes up to kWgMaxCalls weight-gradient GEMMs of one backward pass (same rows / leading dimension).
+// Every (row slab, dW block) writes its partial sum to its own slice of `part` with plain stores; wgrad_reduce_kernel
+// then adds the slabs IN SLAB ORDER into dW / db: the gradients are bit-reproducible from run to run (no float
+// atomics anywhere), and a backward pass costs three launches however many layers it has.
+constexpr int kWgMaxCalls = 16;
+struct WgCall {
+    const __bf16* xt;   // [k_in][ld] layer inputs, feature-major
+    const __bf16* zt;   // [n_out][ld] pre-activation gradients, feature-major
+    float* dw;          // [k_in][n_out] fp32, accumulated into
+    float* db;          // [n_out] or null
+    float* part;        // [n_slabs][k_pad][n_pad] partial sums of this call
+    float* bpart;       // [n_slabs][n_pad] partial bias sums (db != null)
+    int k_in, n_out, k_pad, n_pad;
+    int block0;         // index of this call's first dW block in the launch's block list
+    int gy, gz;         // dW blocks along k / n
+};
+struct WgBatch {
+    WgCall c[kWgMaxCalls];
+    int n_calls, n_slabs;
+    long long ld, rows, slab;
+};
+__device__ __forceinline__ int wg_find_call(const WgBatch& b, int block) {
+    int ci = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.n_calls; ++i)
+        if (block >= b.c[i].block0) ci = i;
+    return ci;
+}
+
 // Keras OptimizerV2 Adam._resource_apply_dense with amsgrad (TF 2.2):
 //   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 //   vhat = max(vhat, v);  p -= lr_t * m / (sqrt(vhat) + eps)            (eps = 1e-7)
@@ -33,17 +62,20 @@ __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ 
 //   xt: [k_in][ld] bf16 (feature-major), zt: [n_out][ld] bf16; rows in [row0, row1), multiple of 16.
 //   dW: [k_in][n_out] fp32 (Keras layout), accumulated with atomics.
 constexpr int kWgTiles = 4;  // 4 x 4 tiles of 32 x 32
-__global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__ xt,
-                                                      const __bf16* __restrict__ zt, long long ld,
-                                                      int k_in, int n_out, long long rows,
-                                                      long long slab, float* __restrict__ dw,
-                                                      float* __restrict__ db) {
+__global__ __launch_bounds__(64, 1) void wgrad_kernel(WgBatch bt) {
     const int lane = threadIdx.x, h = lane >> 5, q = lane & 31;
-    const int kb = blockIdx.y * (32 * kWgTiles);  // first input feature of this block
-    const int nb = blockIdx.z * (32 * kWgTiles);  // first output feature of this block
-    const long long r0 = (long long)blockIdx.x * slab;
-    long long r1 = r0 + slab;
-    if (r1 > rows) r1 = rows;
+    const int ci = wg_find_call(bt, blockIdx.y);
+    const WgCall& c = bt.c[ci];
+    const int lb = blockIdx.y - c.block0, by = lb / c.gz, bz = lb % c.gz;
+    const __bf16* __restrict__ xt = c.xt;
+    const __bf16* __restrict__ zt = c.zt;
+    const long long ld = bt.ld;
+    const int k_in = c.k_in, n_out = c.n_out;
+    const int kb = by * (32 * kWgTiles);  // first input feature of this block
+    const int nb = bz * (32 * kWgTiles);  // first output feature of this block
+    const long long r0 = (long long)blockIdx.x * bt.slab;
+    long long r1 = r0 + bt.slab;
+    if (r1 > bt.rows) r1 = bt.rows;
     f32x16 acc[kWgTiles][kWgTiles];
 #pragma unroll
     for (int i = 0; i < kWgTiles; ++i)
@@ -52,10 +84,9 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool do_bias = db != nullptr && blockIdx.y == 0;  // db[f] += sum_rows dZ[f][row], once per slab
+    const bool do_bias = c.db != nullptr && by == 0;  // db[f] += sum_rows dZ[f][row], once per slab
     float bsum[kWgTiles] = {0.f, 0.f, 0.f, 0.f};
-    for (long long k0 = r0; k0 < r1; k0 += 16) {
-        bf16x8 a[kWgTiles], b[kWgTiles];
+    auto load = [&](long long k0, bf16x8 (&a)[kWgTiles], bf16x8 (&b)[kWgTiles]) {
 #pragma unroll
         for (int i = 0; i < kWgTiles; ++i) {
             const int f = kb + 32 * i + q;
@@ -66,6 +97,17 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
             const int f = nb + 32 * j + q;
             b[j] = f < n_out ? *reinterpret_cast<const bf16x8*>(zt + (long long)f * ld + k0 + 8 * h) : zero;
         }
+    };
+    bf16x8 an[kWgTiles], bn[kWgTiles];
+    if (r0 < r1) load(r0, an, bn);
+    for (long long k0 = r0; k0 < r1; k0 += 16) {
+        bf16x8 a[kWgTiles], b[kWgTiles];
+#pragma unroll
+        for (int i = 0; i < kWgTiles; ++i) {
+            a[i] = an[i];
+            b[i] = bn[i];
+        }
+        if (k0 + 16 < r1) load(k0 + 16, an, bn);   // the next k-step's fragments are in flight under this one's MFMAs
         if (do_bias) {
 #pragma unroll
             for (int j = 0; j < kWgTiles; ++j)
@@ -83,9 +125,10 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
         for (int j = 0; j < kWgTiles; ++j) {
             const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);  // the two row halves of a k-step
             const int col = nb + 32 * j + q;
-            if (h == 0 && col < n_out) atomicAdd(db + col, s);
+            if (h == 0) c.bpart[(long long)blockIdx.x * c.n_pad + col] = s;
         }
     }
+    float* part = c.part + (long long)blockIdx.x * c.k_pad * c.n_pad;
 #pragma unroll
     for (int i = 0; i < kWgTiles; ++i)
 #pragma unroll
@@ -94,8 +137,28 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(const __bf16* __restrict__
             for (int r = 0; r < 16; ++r) {
                 const int row = kb + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = nb + 32 * j + q;
-                if (row < k_in && col < n_out) atomicAdd(dw + (long long)row * n_out + col, acc[i][j][r]);
+                if (row < k_in && col < n_out) part[(long long)row * c.n_pad + col] = acc[i][j][r];
             }
+}
+
+// dw[row][col] += sum over slabs (in slab order) of part[slab][row][col]; db likewise.  grid = (elements / 256, calls)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch bt) {
+    const WgCall& c = bt.c[blockIdx.y];
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n_w = (long long)c.k_in * c.n_out;
+    if (e < n_w) {
+        const int row = (int)(e / c.n_out), col = (int)(e % c.n_out);
+        const float* p = c.part + (long long)row * c.n_pad + col;
+        const long long stride = (long long)c.k_pad * c.n_pad;
+        float s = 0.0f;
+        for (int sl = 0; sl < bt.n_slabs; ++sl) s += p[sl * stride];
+        c.dw[e] += s;
+    } else if (c.db != nullptr && e < n_w + c.n_out) {
+        const int col = (int)(e - n_w);
+        float s = 0.0f;
+        for (int sl = 0; sl < bt.n_slabs; ++sl) s += c.bpart[(long long)sl * c.n_pad + col];
+        c.db[col] += s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -112,17 +175,21 @@ constexpr int kWlPitch = 2 * kWlRows + 16;   // bytes per feature row in LDS
 constexpr int kWlTile = 256 * kWlPitch;      // one operand tile
 constexpr int kWlLds = 4 * kWlTile;          // 2 operands x 2 stages = 147456 B
 
-__global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const __bf16* __restrict__ xt, const __bf16* __restrict__ zt,
-                                                           long long ld, int k_in, int n_out, long long rows,
-                                                           long long slab, float* __restrict__ dw,
-                                                           float* __restrict__ db) {
+__global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(WgBatch bt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
-    const int kb = blockIdx.y * 256, nb = blockIdx.z * 256;
+    const int ci = wg_find_call(bt, blockIdx.y);
+    const WgCall& c = bt.c[ci];
+    const int lb = blockIdx.y - c.block0;
+    const __bf16* __restrict__ xt = c.xt;
+    const __bf16* __restrict__ zt = c.zt;
+    const long long ld = bt.ld;
+    const int k_in = c.k_in, n_out = c.n_out;
+    const int kb = (lb / c.gz) * 256, nb = (lb % c.gz) * 256;
     const int wk = wave >> 1, wn = wave & 1;
-    const long long r0 = (long long)blockIdx.x * slab;
-    long long r1 = r0 + slab;
-    if (r1 > rows) r1 = rows;
+    const long long r0 = (long long)blockIdx.x * bt.slab;
+    long long r1 = r0 + bt.slab;
+    if (r1 > bt.rows) r1 = bt.rows;
     const int n_chunks = (int)((r1 - r0 + kWlRows - 1) / kWlRows);
     f32x16 acc[4][4];
 #pragma unroll
@@ -155,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const __bf16* __restr
         }
     };
     const bool active = kb + 128 * wk < k_in && nb + 128 * wn < n_out;  // wave-uniform: quadrant has real features
-    const bool do_bias = db != nullptr && blockIdx.y == 0 && wk == 0;
+    const bool do_bias = c.db != nullptr && kb == 0 && wk == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     load_chunk(r0);
     store_chunk(0);
@@ -194,9 +261,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const __bf16* __restr
         for (int j = 0; j < 4; ++j) {
             const float sm = bsum[j] + __shfl_xor(bsum[j], 32, 64);
             const int col = nb + 128 * wn + 32 * j + q;
-            if (h == 0 && col < n_out) atomicAdd(db + col, sm);
+            if (h == 0) c.bpart[(long long)blockIdx.x * c.n_pad + col] = sm;
         }
     }
+    float* part = c.part + (long long)blockIdx.x * c.k_pad * c.n_pad;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -205,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const __bf16* __restr
             for (int r = 0; r < 16; ++r) {
                 const int row = kb + 128 * wk + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = nb + 128 * wn + 32 * j + q;
-                if (row < k_in && col < n_out) atomicAdd(dw + (long long)row * n_out + col, acc[i][j][r]);
+                if (row < k_in && col < n_out) part[(long long)row * c.n_pad + col] = acc[i][j][r];
             }
 }
 
@@ -219,42 +287,104 @@ int nfx_launch_amsgrad(float* p, const float* g, float* m, float* v, float* vhat
                        vhat, n, lr_t, b1, b2, eps);
     return (int)hipGetLastError();
 }
-int nfx_launch_wgrad(const void* xt, const void* zt, long long ld, int k_in, int n_out, long long rows,
-                     float* dw, float* db, hipStream_t st) {
-    if (rows <= 0) return 0;
+// Host-side description of one GEMM of a batch (capi_train.cpp fills these).
+struct nfx_wgrad_call {
+    const void* xt;
+    const void* zt;
+    int k_in, n_out;
+    float* dw;
+    float* db;
+};
+
+static void wgrad_plan(long long rows, bool* use_lds, long long* slab, int* n_slabs) {
     const char* env = getenv("NFX_WGRAD_LDS");
-    const bool use_lds = env ? atoi(env) != 0 : rows >= 16384;
-    if (use_lds) {
-        // slab: a multiple of 64 rows.  Every slab ends with 64 K fp32 atomics per 256 x 256 block (L2 atomic rate
-        // ~200 G/s measured), so fewer, longer slabs beat more parallelism: r01 sweep on the NeRF step 64/128/256/512
-        // slabs -> 4.88/4.22/4.47/4.95 ms, on the microfacet step 128/256 -> 7.89/7.24 ms  =>  >= 2048 rows per slab
-        // but at least 64 slabs, at most one per CU (NFX_WGRAD_SLABS overrides the slab count)
-        const char* es = getenv("NFX_WGRAD_SLABS");
-        long long slab;
+    *use_lds = env ? atoi(env) != 0 : rows >= 16384;
+    const char* es = getenv("NFX_WGRAD_SLABS");
+    long long sl;
+    if (*use_lds) {
+        // fewer, longer slabs = fewer partial blocks to write and sum; at least 64 slabs, at most one per CU
         if (es && atoi(es) > 0) {
-            slab = rows / atoi(es);
+            sl = rows / atoi(es);
         } else {
-            slab = rows / 256 > 2048 ? rows / 256 : 2048;
+            sl = rows / 256 > 2048 ? rows / 256 : 2048;
             const long long cap = rows / 64 > 256 ? rows / 64 : 256;
-            if (slab > cap) slab = cap;
+            if (sl > cap) sl = cap;
         }
-        slab = (slab + 63) / 64 * 64;
-        if (slab < 256) slab = 256;
-        const unsigned gx = (unsigned)((rows + slab - 1) / slab);
+        sl = (sl + 63) / 64 * 64;
+        if (sl < 256) sl = 256;
+    } else {
+        // latency-bound regime (one wave per block walks its slab with dependent loads): short slabs in parallel
+        sl = es && atoi(es) > 0 ? rows / atoi(es) : 128;
+        sl = (sl + 15) / 16 * 16;
+        if (sl < 16) sl = 16;
+    }
+    *slab = sl;
+    *n_slabs = (int)((rows + sl - 1) / sl);
+}
+static long long wg_round(long long v, int m) { return (v + m - 1) / m * m; }
+
+// bytes of partial-sum workspace a batch needs (16-byte aligned pieces)
+size_t nfx_wgrad_partial_bytes(const nfx_wgrad_call* calls, int n_calls, long long rows) {
+    if (rows <= 0 || n_calls <= 0) return 0;
+    bool lds;
+    long long slab;
+    int n_slabs;
+    wgrad_plan(rows, &lds, &slab, &n_slabs);
+    const int bs = lds ? 256 : 128;
+    size_t total = 0;
+    for (int i = 0; i < n_calls; ++i) {
+        const long long kp = wg_round(calls[i].k_in, bs), np = wg_round(calls[i].n_out, bs);
+        total += (size_t)n_slabs * (kp * np + np) * sizeof(float);
+    }
+    return total;
+}
+
+int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
+                           hipStream_t st) {
+    if (rows <= 0 || n_calls <= 0) return 0;
+    if (n_calls > nfx::kWgMaxCalls) return (int)hipErrorInvalidValue;
+    bool lds;
+    nfx::WgBatch bt;
+    wgrad_plan(rows, &lds, &bt.slab, &bt.n_slabs);
+    bt.n_calls = n_calls;
+    bt.ld = ld;
+    bt.rows = rows;
+    const int bs = lds ? 256 : 128;
+    float* p = static_cast<float*>(partial);
+    int blocks = 0;
+    long long max_elems = 0;
+    for (int i = 0; i < n_calls; ++i) {
+        nfx::WgCall& c = bt.c[i];
+        c.xt = (const __bf16*)calls[i].xt;
+        c.zt = (const __bf16*)calls[i].zt;
+        c.dw = calls[i].dw;
+        c.db = calls[i].db;
+        c.k_in = calls[i].k_in;
+        c.n_out = calls[i].n_out;
+        c.k_pad = (int)wg_round(c.k_in, bs);
+        c.n_pad = (int)wg_round(c.n_out, bs);
+        c.gy = c.k_pad / bs;
+        c.gz = c.n_pad / bs;
+        c.block0 = blocks;
+        blocks += c.gy * c.gz;
+        c.part = p;
+        p += (size_t)bt.n_slabs * c.k_pad * c.n_pad;
+        c.bpart = p;
+        p += (size_t)bt.n_slabs * c.n_pad;
+        const long long el = (long long)c.k_in * c.n_out + c.n_out;
+        if (el > max_elems) max_elems = el;
+    }
+    if (lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::wgrad_lds_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, nfx::kWlLds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(nfx::wgrad_lds_kernel, dim3(gx, (unsigned)((k_in + 255) / 256), (unsigned)((n_out + 255) / 256)),
-                           dim3(256), nfx::kWlLds, st, (const __bf16*)xt, (const __bf16*)zt, ld, k_in, n_out, rows, slab,
-                           dw, db);
-        return (int)hipGetLastError();
+        hipLaunchKernelGGL(nfx::wgrad_lds_kernel, dim3((unsigned)bt.n_slabs, (unsigned)blocks), dim3(256), nfx::kWlLds, st, bt);
+    } else {
+        hipLaunchKernelGGL(nfx::wgrad_kernel, dim3((unsigned)bt.n_slabs, (unsigned)blocks), dim3(64), 0, st, bt);
     }
-    long long slab = 1024;
-    const unsigned gx = (unsigned)((rows + slab - 1) / slab);
-    const unsigned gy = (unsigned)((k_in + 127) / 128);
-    const unsigned gz = (unsigned)((n_out + 127) / 128);
-    hipLaunchKernelGGL(nfx::wgrad_kernel, dim3(gx, gy, gz), dim3(64), 0, st, (const __bf16*)xt, (const __bf16*)zt, ld,
-                       k_in, n_out, rows, slab, dw, db);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(nfx::wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n_calls), dim3(256), 0, st, bt);
     return (int)hipGetLastError();
 }
 }

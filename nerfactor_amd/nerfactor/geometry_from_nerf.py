@@ -13,7 +13,8 @@ lvis.npy, lvis.png} — what datasets/nerf_shape.py reads.  All marching runs on
     the network with GradientTape.batch_jacobian); expected depth / normal from the compositing weights;
   * shadow rays: every (surface point, front-lit light) pair is a ray from lvis_near = 0.1 to lvis_far marched with the
     density-only kernel (nfx_nerf_sigma_fwd), lvis = 1 - sum(weights).
-Views are independent: with N ranks, rank r processes views r, r+N, ... (no collective)."""
+With N ranks the rays of EVERY view are split into N contiguous ranges: each rank marches its rays and
+writes its rows of the .npy files; rank 0 receives uint8 preview rows only."""
 import argparse
 import glob
 import os
@@ -149,36 +150,66 @@ def process_view(config, model, batch, args, bbox):
     if sps != 1:
         raise NotImplementedError("spp > 1: the reference's light-visibility masking assumes one ray per pixel")
     os.makedirs(out_dir, exist_ok=True)
+    # rays within the view are split into contiguous ranges over the ranks: every step below is per
+    # ray at spp = 1, each rank writes its own rows of the .npy files, rank 0 receives uint8 preview rows only
+    rank, ws = nfx_dist.world()
+    lo, hi = nfx_dist.shard_range(h * w, rank, ws)
+    rayo, rayd = rayo[lo:hi], rayd[lo:hi]
     rayd = torch.nn.functional.normalize(rayd, dim=1, eps=1e-12)
     # ------ camera -> object
     occu, exp_depth, exp_normal = compute_depth_and_normal(model, rayo, rayd, config, bbox, args.mlp_chunk)
     occu = torch.where(occu < args.occu_thres, torch.zeros_like(occu), occu)
-    alpha_map = average_supersamples(occu.reshape(h * sps, w * sps), sps).clamp(0., 1.)
+    alpha = occu.clamp(0., 1.)                                   # average_supersamples is the identity at spp = 1
     surf = rayo + rayd * exp_depth[:, None]
-    xyz_map = _alpha_blend(average_supersamples(surf.reshape(h * sps, w * sps, 3), sps), alpha_map)
-    normal_map = average_supersamples(exp_normal.reshape(h * sps, w * sps, 3), sps)
-    bg = normal_map.new_tensor((0., 1., 0.))   # (0, 0, 0) would give (0, 0, 0) tangents
-    normal_map = torch.nn.functional.normalize(_alpha_blend(normal_map, alpha_map, bg), dim=2, eps=1e-12)
-    normal_map = normal_map.clamp(-1., 1.)
+    xyz = _alpha_blend(surf, alpha[:, None])
+    bg = exp_normal.new_tensor((0., 1., 0.))   # (0, 0, 0) would give (0, 0, 0) tangents
+    normal = torch.nn.functional.normalize(_alpha_blend(exp_normal, alpha[:, None], bg), dim=1, eps=1e-12)
+    normal = normal.clamp(-1., 1.)
     # ------ object -> light (the reference masks the per-sample buffers with the averaged alpha: spp = 1 layouts)
-    hit = alpha_map.reshape(-1) > 0.
-    lvis = torch.zeros((h * w, 2 * args.light_h * args.light_h), device=rayo.device)
+    hit = alpha > 0.
+    n_lights = 2 * args.light_h * args.light_h
+    lvis = torch.zeros((hi - lo, n_lights), device=rayo.device)
     if bool(hit.any()):
         lvis_hit = compute_light_visibility(model, surf[hit], exp_normal[hit], config, lvis_far=args.lvis_far,
                                             light_h=args.light_h, bbox=bbox, mlp_chunk=args.mlp_chunk)
         lvis[hit] = lvis_hit.clamp(0., 1.)
-    lvis = (lvis * alpha_map.reshape(-1, 1)).reshape(h, w, -1)
-    # ------ writers (util/geom.py:27-79)
-    alpha_np, xyz_np, normal_np, lvis_np = (t.cpu().numpy() for t in (alpha_map, xyz_map, normal_map, lvis))
-    _write_png(join(out_dir, 'alpha.png'), alpha_np)
-    np.save(join(out_dir, 'xyz.npy'), xyz_np)
-    span = xyz_np.max() - xyz_np.min()
-    _write_png(join(out_dir, 'xyz.png'), (xyz_np - xyz_np.min()) / (span if span > 0 else 1.))
-    np.save(join(out_dir, 'normal.npy'), normal_np)
-    _write_png(join(out_dir, 'normal.png'), (normal_np + 1) / 2)
-    np.save(join(out_dir, 'lvis.npy'), lvis_np)
-    _write_png(join(out_dir, 'lvis.png'), lvis_np.mean(2))
+    lvis = lvis * alpha[:, None]
+    # ------ writers (util/geom.py:27-79): .npy rows by every rank, previews by rank 0
+    shapes = {'xyz': (h, w, 3), 'normal': (h, w, 3), 'lvis': (h, w, n_lights)}
+    if rank == 0:
+        for name, shp in shapes.items():
+            np.lib.format.open_memmap(join(out_dir, name + '.npy.part'), mode='w+', dtype=np.float32, shape=shp).flush()
+    nfx_dist.barrier()
+    for name, t in (('xyz', xyz), ('normal', normal), ('lvis', lvis)):
+        mm = np.lib.format.open_memmap(join(out_dir, name + '.npy.part'), mode='r+')
+        mm.reshape(h * w, -1)[lo:hi] = t.cpu().numpy()
+        mm.flush()
+        del mm
+    xyz_min, xyz_max = _global_min_max(xyz)
+    span = xyz_max - xyz_min
+    q8 = lambda t: (t.clamp(0., 1.) * 255 + .5).to(torch.uint8)
+    rows = {'alpha': q8(alpha[:, None]), 'xyz': q8((xyz - xyz_min) / (span if span > 0 else 1.)),
+            'normal': q8((normal + 1) / 2), 'lvis': q8(lvis.mean(1, keepdim=True))}
+    rows = {k: nfx_dist.gather_cat(v) for k, v in sorted(rows.items())}
+    nfx_dist.barrier()
+    if rank == 0:
+        for name in shapes:
+            os.replace(join(out_dir, name + '.npy.part'), join(out_dir, name + '.npy'))
+        for name, v in rows.items():
+            img = v.cpu().numpy().reshape(h, w, -1)
+            Image.fromarray(img[:, :, 0] if img.shape[2] == 1 else img).save(join(out_dir, name + '.png'))
+    nfx_dist.barrier()
     return out_dir
+
+
+def _global_min_max(t):
+    """(min, max) of a tensor over all ranks, as Python floats."""
+    import torch.distributed as dist
+    lo_hi = torch.stack((t.min() if t.numel() else t.new_tensor(float('inf')),
+                         -t.max() if t.numel() else t.new_tensor(float('inf'))))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN)
+    return float(lo_hi[0]), -float(lo_hi[1])
 
 
 def main(argv=None):
@@ -213,8 +244,7 @@ def main(argv=None):
             except FileNotFoundError:
                 continue
             for batch in dataset.build_pipeline(no_batch=config.getboolean('DEFAULT', 'no_batch'), no_shuffle=True):
-                if i % ws == rank:
-                    done.append(process_view(config, model, batch, args, bbox))
+                done.append(process_view(config, model, batch, args, bbox))   # every rank: its rays of this view
                 i += 1
                 if args.debug:
                     break

@@ -166,24 +166,29 @@ class Model(ShapeModel):
             xyz_j = xyz + (torch.randn_like(xyz) * xyz_jitter_std if xyz_noise is None else xyz_noise)
         else:
             xyz_j = None
+        # The clean and the jittered evaluation of a head share ONE kernel launch per direction (forward, backward,
+        # weight gradients): the two point sets are concatenated and the result is split again.
+        def both(fn, **kw):
+            if not jitter:
+                return fn(xyz, **kw), None
+            n = xyz.shape[0]
+            out = fn(torch.cat((xyz, xyz_j)), **{k: torch.cat((v, v)) for k, v in kw.items()})
+            return out[:n], out[n:]
         # ------ normals
         if self.shape_mode == 'nerf':
             normal_pred, normal_jitter = normal, None
         else:
-            normal_pred = self._pred_normal_at(xyz)
-            normal_jitter = self._pred_normal_at(xyz_j) if jitter else None
+            normal_pred, normal_jitter = both(self._pred_normal_at)
         normal_pred = self._normalize(normal_pred)
         if normal_jitter is not None:
             normal_jitter = self._normalize(normal_jitter)
-        # ------ light visibility
+        # ------ light visibility (the jittered points keep the light directions of the clean ones, shape.py:160-163)
         if self.shape_mode == 'nerf':
             lvis_pred, lvis_jitter = torch.clamp(lvis, 1e-8, 1.), None
         else:
-            lvis_pred = self._pred_lvis_at(xyz)
-            lvis_jitter = self._pred_lvis_at(xyz_j, dir_pts=xyz) if jitter else None
+            lvis_pred, lvis_jitter = both(self._pred_lvis_at, dir_pts=xyz)
         # ------ albedo
-        albedo = self._pred_albedo_at(xyz)
-        albedo_jitter = self._pred_albedo_at(xyz_j) if jitter else None
+        albedo, albedo_jitter = both(self._pred_albedo_at)
         if albedo_scales is not None:
             albedo = torch.as_tensor(albedo_scales, device=albedo.device).reshape(1, 3) * albedo
         if albedo_override is not None:
@@ -193,8 +198,7 @@ class Model(ShapeModel):
         if not self.pred_brdf:
             raise NotImplementedError("pred_brdf=False: the reference calls an undefined "
                                       "_get_default_brdf_at (nerfactor.py:256)")
-        brdf_prop = self._pred_brdf_at(xyz)
-        brdf_prop_jitter = self._pred_brdf_at(xyz_j) if jitter else None
+        brdf_prop, brdf_prop_jitter = both(self._pred_brdf_at)
         if self.normalize_brdf_z:
             brdf_prop = mathutil.safe_l2_normalize(brdf_prop, axis=1)
             if brdf_prop_jitter is not None:
@@ -245,9 +249,7 @@ class Model(ShapeModel):
         bias = self.config.getfloat('DEFAULT', 'albedo_bias', fallback=0.1)
         albedo = self._mlp128_xyz(pts, 'albedo_mlp', 'albedo_out', 3, out_act='sigmoid', post_scale=scale,
                                   post_bias=bias)
-        if not torch.isfinite(albedo).all():
-            raise FloatingPointError("Albedo")
-        return albedo
+        return self.check_numerics(albedo, "Albedo")
 
     def _pred_brdf_at(self, pts):
         return self._mlp128_xyz(pts, 'brdf_z_mlp', 'brdf_z_out', self.z_dim, out_act=self._brdf_z_act())
@@ -365,6 +367,4 @@ class Model(ShapeModel):
             if light_achro_weight > 0:
                 dc = light - torch.roll(light, 1, 2)
                 loss = loss + light_achro_weight * (dc ** 2).sum()
-        if not torch.isfinite(loss).all():
-            raise FloatingPointError("Loss")
-        return loss
+        return self.check_numerics(loss, "Loss")

@@ -186,9 +186,7 @@ class Model(BaseModel):
         else:
             lvis = ops.lvis_fwd(pts, lxyz, blob, xyz_scale=self.xyz_scale, xyz_dir=dir_pts,
                                 prec=self.precision)
-        if not torch.isfinite(lvis).all():
-            raise FloatingPointError("Light visibility")
-        return lvis
+        return self.check_numerics(lvis, "Light visibility")
 
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):
@@ -211,9 +209,7 @@ class Model(BaseModel):
             loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
         if lvis_jitter is not None:
             loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
-        if not torch.isfinite(loss).all():
-            raise FloatingPointError("Loss")
-        return loss
+        return self.check_numerics(loss, "Loss")
 
     # ------------------------------------------------------------------ vis (raw dumps only)
 

@@ -3,8 +3,9 @@
 
     [torchrun --nproc-per-node N] python -m nerfactor_amd.nerfactor.nerf_test --ckpt=<outdir>/checkpoints/ckpt-N
 
-Reads <outdir>.ini, renders every test camera into <outdir>/vis_test/ckpt-N/batch%09d/.  Views are independent:
-with N ranks, rank r renders views r, r+N, ... (weak scaling, no data-path collective)."""
+Reads <outdir>.ini, renders every test camera into <outdir>/vis_test/ckpt-N/batch%09d/.  With N ranks every view's rays
+are split into N contiguous ranges (util/shard.py): each rank renders and quantises its range, rank 0 receives uint8
+rows and writes the images — no data-path collective, and a single view already uses every GPU."""
 import argparse
 import glob
 import sys
@@ -14,7 +15,7 @@ import torch
 
 from .. import dist as nfx_dist
 from . import datasets, models
-from .util import config as configutil
+from .util import config as configutil, shard
 
 
 def parse_args(argv=None):
@@ -46,10 +47,7 @@ def main(argv=None):
     rank, ws = nfx_dist.init_from_env(device=device)
     _, outroot, dataset, datapipe, model = setup(args.ckpt, args.debug, device)
     for batch_i, batch in enumerate(datapipe):
-        if batch_i % ws != rank:
-            continue
-        _, _, _, to_vis = model(batch, mode='test')
-        model.vis_batch(to_vis, join(outroot, 'batch{i:09d}'.format(i=batch_i)), mode='test')
+        shard.render_view(model, batch, join(outroot, 'batch{i:09d}'.format(i=batch_i)), mode='test')
         if args.debug:
             break
     nfx_dist.barrier()

@@ -4,7 +4,8 @@ command line and output layout (nerfactor/test.py:29-200):
     [torchrun --nproc-per-node N] python -m nerfactor_amd.nerfactor.test --ckpt=<outdir>/checkpoints/ckpt-N \\
         [--color_correct_albedo] [--tgt_albedo gold] [--tgt_brdf <merl name>] [--sv_axis_i 0 ...]
 
-Views are independent: rank r renders views r, r+N, ...; OLAT relighting only for the final view, as upstream."""
+With N ranks every view's rays are split into N contiguous ranges (util/shard.py): 4 test views x 8 probes keep 8 GPUs
+busy; rank 0 receives uint8 rows only.  OLAT relighting only for the final view, as upstream."""
 import argparse
 import glob
 import json
@@ -17,7 +18,7 @@ import torch
 from .. import dist as nfx_dist
 from .datasets.nerf import load_rgba, resize
 from .nerf_test import setup
-from .util import config as configutil
+from .util import config as configutil, shard
 
 RAINBOW = ((0.58, 0, 0.83), (0.29, 0, 0.51), (0, 0, 1), (0, 1, 0), (1, 1, 0), (1, 0.5, 0), (1, 0, 0))
 SOLID = {'aluminium': (0.913, 0.921, 0.925), 'gold': (1, 0.843, 0), 'green': (0, 1, 0)}
@@ -89,17 +90,15 @@ def main(argv=None):
         brdf_z_override = brdf.latent_code.z[brdf.brdf_names.index(args.tgt_brdf), :].detach()
 
     for batch_i, batch in enumerate(datapipe):
-        if batch_i % ws != rank:
-            continue
         relight_olat = batch_i == n_views - 1
         albedo_override = None
-        if args.tgt_albedo:
-            albedo_override = get_albedo_override(
-                args.tgt_albedo, batch[6], args.sv_axis_i, args.sv_axis_min, args.sv_axis_max)
-        _, _, _, to_vis = model(
-            batch, mode='test', relight_olat=relight_olat, relight_probes=True, albedo_scales=albedo_scales,
-            albedo_override=albedo_override, brdf_z_override=brdf_z_override)
-        model.vis_batch(to_vis, join(outroot, 'batch{i:09d}'.format(i=batch_i)), mode='test', olat_vis=relight_olat)
+        if args.tgt_albedo:   # evaluated on the whole view, then cut to this rank's rays like the batch itself
+            albedo_override = shard.shard_rows(get_albedo_override(
+                args.tgt_albedo, batch[6], args.sv_axis_i, args.sv_axis_min, args.sv_axis_max), batch[6].shape[0])
+        shard.render_view(
+            model, batch, join(outroot, 'batch{i:09d}'.format(i=batch_i)), mode='test', relight_olat=relight_olat,
+            relight_probes=True, albedo_scales=albedo_scales, albedo_override=albedo_override,
+            brdf_z_override=brdf_z_override)
         if args.debug:
             break
     nfx_dist.barrier()

@@ -41,11 +41,21 @@ def divide_no_nan(a, b):
 
 _ACT = {None: lambda v: v, 'relu': torch.relu, 'sigmoid': torch.sigmoid, 'softplus': torch.nn.functional.softplus}
 
+# Optional operand rounding of every Dense layer (weights and layer inputs to bf16, fp32/fp64 accumulate) with a
+# straight-through gradient: what the MFMA path computes.  Lets a test separate "the kernels differ from the reference"
+# from "a bf16 forward differs from an fp32 forward" (ReLU masks and the sign of L1 smoothness terms flip).
+QUANT = None
+
+
+def bf16_ste(t):
+    return t + (t.detach().float().to(torch.bfloat16).to(t.dtype) - t.detach())
+
 
 def mlp(x, P, name, n_layers, acts, skip_at=None):
+    q = QUANT if QUANT is not None else (lambda t: t)
     h = x
     for i in range(n_layers):
-        h = _ACT[acts[i]](h @ P['net_%s_layer%d.kernel' % (name, i)] + P['net_%s_layer%d.bias' % (name, i)])
+        h = _ACT[acts[i]](q(h) @ q(P['net_%s_layer%d.kernel' % (name, i)]) + P['net_%s_layer%d.bias' % (name, i)])
         if skip_at is not None and i in skip_at:
             h = torch.cat((h, x), -1)
     return h

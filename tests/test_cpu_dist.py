@@ -137,3 +137,56 @@ def _train_worker(rank, world):
 def test_two_ranks_train_one_model():
     from tests import mp_util
     mp_util.run_workers(_train_worker, world=2)
+
+
+class _MockRenderModel(torch.nn.Module):
+    """CPU stand-in for a render plugin: per-ray outputs that depend only on that ray's inputs (what the libnfx kernels
+    guarantee), returned through the plugin contract; vis_rows / write_vis are the product's own (models/base.py)."""
+    def __init__(self):
+        super().__init__()
+        from nerfactor_amd.nerfactor.models.base import Model
+        self.vis_rows, self.write_vis = Model.vis_rows, Model.write_vis
+
+    def forward(self, batch, mode='test', relight_probes=False):
+        id_, hw, rayo, rayd, rgb = batch
+        g = torch.Generator().manual_seed(1)
+        w = torch.randn(3, 3, generator=g)
+        pred_rgb = torch.sigmoid(rayd @ w + rayo.sum(1, keepdim=True))
+        to_vis = {'id': id_, 'hw': hw, 'gt_rgb': rgb, 'pred_rgb': pred_rgb, 'pred_normal': torch.tanh(rayd),
+                  'pred_lvis': torch.sigmoid(rayd @ torch.randn(3, 16, generator=g)),
+                  'pred_albedo': pred_rgb * 0.5}
+        if relight_probes:
+            to_vis['pred_rgb_probes'] = torch.stack((pred_rgb, 1 - pred_rgb), 1)
+        return {}, rgb, {}, to_vis
+
+
+def _view_batch():
+    h, w = 7, 9     # 63 rays: not divisible by 2
+    g = torch.Generator().manual_seed(5)
+    n = h * w
+    return (['test_000'] * n, torch.tensor([[h, w]] * n, dtype=torch.int32), torch.randn(n, 3, generator=g),
+            torch.randn(n, 3, generator=g), torch.rand(n, 3, generator=g))
+
+
+def _render_worker(rank, world):
+    from nerfactor_amd.nerfactor.util import shard
+    shard.render_view(_MockRenderModel(), _view_batch(), os.environ['NFX_TEST_OUTDIR'], mode='test', relight_probes=True)
+
+
+def test_rays_within_view_sharding_stitches_the_one_rank_image(tmp_path):
+    """VERDICT r01 #7 / SURVEY §8e: the render drivers shard the rays OF EACH VIEW over the ranks; rank 0 receives
+    uint8 rows only and must write exactly the files a single process writes."""
+    from nerfactor_amd.nerfactor.util import shard
+    from tests import mp_util
+    one, two = str(tmp_path / 'one'), str(tmp_path / 'two')
+    shard.render_view(_MockRenderModel(), _view_batch(), one, mode='test', relight_probes=True)
+    os.environ['NFX_TEST_OUTDIR'] = two
+    try:
+        mp_util.run_workers(_render_worker, world=2)
+    finally:
+        del os.environ['NFX_TEST_OUTDIR']
+    files = sorted(os.path.relpath(os.path.join(d, f), one) for d, _, fs in os.walk(one) for f in fs)
+    assert 'pred_rgb.png' in files and os.path.join('pred_rgb_probes', '0001.png') in files and 'metadata.json' in files
+    assert files == sorted(os.path.relpath(os.path.join(d, f), two) for d, _, fs in os.walk(two) for f in fs)
+    for f in files:
+        assert open(os.path.join(one, f), 'rb').read() == open(os.path.join(two, f), 'rb').read(), f

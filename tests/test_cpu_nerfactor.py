@@ -247,3 +247,27 @@ def test_model_loads_hdr_probes_from_test_envmap_dir(tmp_path):
         want = L.resize_antialias(L.read_hdr(str(tmp_path / (name + '.hdr'))), new_h=16)
         np.testing.assert_array_equal(p, want)
         assert abs(p.mean() / m.mean() - 1) < 0.02      # RGBE keeps 8 bits of mantissa
+
+
+def test_check_numerics_is_immediate_outside_training_and_deferred_inside():
+    """models/base.py:check_numerics mirrors tf.debugging.check_numerics; inside a training step (autograd recording)
+    the verdict is raised by flush_numerics() instead of stalling the launch queue mid-step."""
+    import torch
+    from nerfactor_amd.nerfactor.models.base import Model
+
+    class M(Model):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+    m = M()
+    bad = torch.tensor([1., float('nan')])
+    with torch.no_grad():
+        assert m.check_numerics(torch.ones(3), "fine") is not None
+        with pytest.raises(FloatingPointError, match="Albedo"):
+            m.check_numerics(bad, "Albedo")
+    assert m.check_numerics(torch.ones(3), "fine").shape == (3,)
+    m.flush_numerics()                       # nothing wrong so far
+    m.check_numerics(torch.ones(3), "fine")
+    m.check_numerics(bad, "Loss")            # recorded, not raised
+    with pytest.raises(FloatingPointError, match="Loss"):
+        m.flush_numerics()
+    m.flush_numerics()                       # the queue was cleared

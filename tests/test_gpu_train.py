@@ -603,3 +603,41 @@ def test_shade_backward_finite_for_grazing_half_vectors(nfx_lib, cuda):
     for name, o in zip(('d_albedo', 'd_normal', 'd_lvis', 'd_rough'), outs):
         assert torch.isfinite(o).all(), name
     assert torch.isfinite(d_light).all()
+
+
+@pytest.mark.parametrize("wgrad_lds", ["0", "1"])
+def test_weight_gradients_are_bit_reproducible(nfx_lib, cuda, monkeypatch, wgrad_lds):
+    """No float atomics in the weight-gradient path: every (row slab, dW block) stores its partial sum and a second
+    kernel adds the slabs in slab order, so two runs of the same backward give identical bits — for the direct-load
+    kernel (short slabs in parallel) and for the LDS-staged one, for the width-128 and the NeRF networks."""
+    from nerfactor_amd import ops
+    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)
+    layers, out = net128(31, 90, 1)
+    ks = [k for k, _ in layers] + [out[0][0]]
+    bs = [b for _, b in layers] + [out[0][1]]
+    blob = ops.pack_mlp128_train_weights(ks, bs, nfx_lib.IN_XYZ_LDIR, 1).to(cuda)
+    rng, lxyz, _, xyz, _, _ = scene(300, 77)
+    dout = dev(rng.normal(size=(300, 512)), cuda)
+    runs = []
+    for _ in range(2):
+        dks = [torch.zeros(k.shape, device=cuda) for k in ks]
+        dbs = [torch.zeros(b.shape, device=cuda) for b in bs]
+        ops.mlp128_bwd(nfx_lib.IN_XYZ_LDIR, dev(xyz, cuda), dout, blob, dks, dbs, out_act='sigmoid', lxyz=dev(lxyz, cuda))
+        runs.append(dks + dbs)
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    assert all(float(g.abs().max()) > 0 for g in runs[0])
+    from tests import common
+    net = common.nerf_nets(seed=3)[0]
+    nks, nbs = common.nerf_layers(net)
+    nblob = ops.pack_nerf_train_weights(nks, nbs).to(cuda)
+    rayo, rayd = common.camera_rays(12, 12)
+    o, d = dev(rayo, cuda), ops.l2_normalize3(dev(rayd, cuda), 1e-12)
+    z = ops.gen_z(2., 6., 48, o.shape[0], device=cuda)
+    d_rgbs = dev(rng.normal(size=(o.shape[0], 48, 4)), cuda)
+    runs = []
+    for _ in range(2):
+        dks = [torch.zeros(k.shape, device=cuda) for k in nks]
+        dbs = [torch.zeros(b.shape, device=cuda) for b in nbs]
+        ops.nerf_mlp_bwd(o, d, z, d_rgbs, nblob, dks, dbs)
+        runs.append(dks + dbs)
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
