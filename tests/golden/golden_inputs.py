@@ -75,10 +75,47 @@ def microfacet_inputs():
     return _f32(l), _f32(v), _f32(nrm), _f32(alb), _f32(rough)
 
 
-def surface_batch(n_lights):
-    """(rayo, rgb, alpha, xyz, normal, lvis) of 24 surface points, 5 of them background (alpha = 0)."""
-    rng = np.random.default_rng(35)
-    n = 24
+def trained_nerf_nets():
+    """Coarse + fine NeRF networks fitted to the unit-sphere scene (tests/golden/make_trained_nerf_weights.py), stored
+    as float16: empty space sits at a robustly negative density, so no ray of the fixtures is decided by the sign of
+    a near-zero last-sample logit."""
+    import os
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nerf_trained_fp16.npz'))
+    nets = []
+    for pref in ('coarse_', 'fine_'):
+        net = {}
+        for part, n in (('enc', 8), ('sigma_out', 1), ('bottleneck', 1), ('rgb_out', 2)):
+            net[part] = [(_f32(w['net_%s%s_layer%d.kernel' % (pref, part, i)]),
+                          _f32(w['net_%s%s_layer%d.bias' % (pref, part, i)])) for i in range(n)]
+        nets.append(net)
+    return nets
+
+
+NERF1K_HW = (32, 32)            # the 1024-ray view of the larger NeRF fixture
+GEO1K_RAYS = slice(384, 640)    # 8 image rows through the middle of that view (geometry fixture, 256 rays)
+GEO1K_SURF = 24                 # surface points of the light-visibility fixture on the trained NeRF (x 8 x 16 lights)
+SURF256 = 256                   # surface points of the larger NeRFactor fixture
+LVIS_STRIDE = 8                 # every 8th light of the 512 is stored for the 256-point fixtures
+
+
+def nerf1k_rays():
+    rayo, rayd = common.camera_rays(*NERF1K_HW, cam_loc=(1.9, -2.8, 2.1))
+    rng = np.random.default_rng(36)
+    return _f32(rayo), _f32(rayd), _f32(rng.uniform(0, 1, (rayo.shape[0], 3)))
+
+
+def surface_batch(n_lights, n=24, seed=35):
+    """(rayo, rgb, alpha, xyz, normal, lvis) of n surface points, about a fifth of them background (alpha = 0)."""
+    rng = np.random.default_rng(seed)
+    if n != 24:
+        xyz = rng.uniform(-1, 1, (n, 3))
+        normal = rng.normal(size=(n, 3))
+        normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+        rayo = np.tile(np.float32([[2.2, -2.4, 1.9]]), (n, 1))
+        rgb = rng.uniform(0, 1, (n, 3))
+        alpha = rng.uniform(0.3, 1, (n, 1)) * (rng.uniform(size=(n, 1)) > 0.2)
+        lvis = rng.uniform(0, 1, (n, n_lights))
+        return _f32(rayo), _f32(rgb), _f32(alpha), _f32(xyz), _f32(normal), _f32(lvis)
     xyz = rng.uniform(-1, 1, (n, 3))
     normal = rng.normal(size=(n, 3))
     normal /= np.linalg.norm(normal, axis=1, keepdims=True)

@@ -103,6 +103,42 @@ def run_nerf():
     return model, cfg
 
 
+def run_nerf_trained():
+    """The larger fixture: 1024 rays of a 32 x 32 view through the TRAINED networks (tests/golden/nerf_trained_fp16.npz)."""
+    cfg = ref_config('nerf.ini')
+    model = NerfModel(cfg)
+    nets = gi.trained_nerf_nets()
+    for pref, net in zip(('coarse_', 'fine_'), nets):
+        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            set_layers(model.net[pref + part], net[part])
+    put('nerf1k_weight_checksum', gi.checksum_nerf(nets))
+    rayo, rayd, gt = gi.nerf1k_rays()
+    n = rayo.shape[0]
+    batch = (np.array([b'x'] * n), np.tile(np.int32([gi.NERF1K_HW]), (n, 1))) + as_tensors(rayo, rayd, gt)
+    pred, gt_t, loss_kwargs, to_vis = model.call(batch, mode='test')
+    for lvl in ('coarse', 'fine'):
+        for k in ('rgb', 'occu', 'depth'):
+            put('nerf1k_%s_%s' % (lvl, k), to_vis['%s_%s' % (lvl, k)])
+    put('nerf1k_loss', model.compute_loss(pred, gt_t, **loss_kwargs))
+    # geometry_from_nerf on the same trained field: a real surface (the unit sphere), 256 rays + 24 x 128 shadow rays
+    flags = gfn.FLAGS
+    flags.light_h, flags.lpix_chunk, flags.mlp_chunk, flags.lvis_far, flags.scene_bbox = gi.GEOM_LIGHT_H, 8, 65536, 1., None
+    ro, rd = as_tensors(rayo[gi.GEO1K_RAYS], rayd[gi.GEO1K_RAYS])
+    rd = tf.linalg.l2_normalize(rd, axis=1)
+    occu, depth, normal = gfn.compute_depth_and_normal(model, ro, rd, cfg)
+    put('geo1k_occu', occu)
+    put('geo1k_depth', depth)
+    put('geo1k_normal', normal)
+    hit = np.flatnonzero(np.asarray(occu) > 0.5)
+    idx = hit[np.linspace(0, len(hit) - 1, gi.GEO1K_SURF).astype(int)]
+    surf = np.asarray(ro + rd * depth[:, None])[idx]
+    nrm = np.asarray(normal)[idx]
+    put('geo1k_surf_idx', idx.astype(np.int32))
+    put('geo1k_surf', surf)
+    put('geo1k_surf_normal', nrm)
+    put('geo1k_lvis', gfn.compute_light_visibility(model, *as_tensors(surf, nrm), cfg))
+
+
 # ------------------------------------------------------------------------------------------------ geometry_from_nerf
 def run_geometry(model, cfg):
     """The reference's surface extraction on the same NeRF: 128 + 192 samples per ray, normals from the batch Jacobian
@@ -220,6 +256,36 @@ class RecordNormal:
         return x
 
 
+def run_nerfactor_256(tmp, brdf_root, learned):
+    """The larger surface fixture: 256 points x 512 lights in test mode (no jitter); light visibility stored for every
+    8th light."""
+    paths, envdir = nerfactor_workdir(tmp, brdf_root)
+    tag = 'nfl256' if learned else 'nfm256'
+    ini = 'nerfactor.ini' if learned else 'nerfactor_microfacet.ini'
+    over = dict(shape_model_ckpt=paths['shape'], test_envmap_dir=envdir, embed_light_h=16)
+    if learned:
+        over['brdf_model_ckpt'] = paths['brdf']
+    model = (NerfactorModel if learned else MicrofacetModel)(ref_config(ini, **over), debug=True)
+    net = gi.nerfactor_net(3 if learned else 1)
+    for part in net:
+        set_layers(model.net[part], net[part])
+    if learned:
+        bnet = gi.brdf_net()
+        set_layers(model.brdf_model.net['brdf_mlp'], bnet['brdf_mlp'])
+        set_layers(model.brdf_model.net['brdf_out'], bnet['brdf_out'])
+    model._light = tf.Variable(gi.light_probe(gi.LIGHT_SCALE['nfl' if learned else 'nfm']))
+    rayo, rgb, alpha, xyz, normal, lvis = gi.surface_batch(512, n=gi.SURF256, seed=37)
+    n = rayo.shape[0]
+    batch = (np.array([b'x'] * n), np.tile(np.int32([[16, n // 16]]), (n, 1))) + as_tensors(
+        rayo, np.zeros_like(rayo), rgb, alpha, xyz, normal, lvis)
+    pred, gt, loss_kwargs, _ = model.call(batch, mode='test')
+    for k in ('rgb', 'normal', 'albedo', 'brdf'):
+        put('%s_%s' % (tag, k), pred[k])
+    put('%s_lvis' % tag, np.asarray(pred['lvis'])[:, ::gi.LVIS_STRIDE])
+    loss_kwargs['mode'] = 'vali'
+    put('%s_vali_loss' % tag, model.compute_loss(pred, gt, **loss_kwargs))
+
+
 def run_nerfactor(tmp, brdf_root, learned):
     paths, envdir = nerfactor_workdir(tmp, brdf_root)
     tag = 'nfl' if learned else 'nfm'
@@ -312,6 +378,7 @@ def main():
     tf.random.set_seed(7)
     model, cfg = run_nerf()
     run_geometry(model, cfg)
+    run_nerf_trained()
     run_geom()
     run_shape()
     with tempfile.TemporaryDirectory() as tmp:
@@ -320,6 +387,8 @@ def main():
         root = os.path.join(tmp, 'merl_npz')
         run_nerfactor(os.path.join(tmp, 'a'), root, learned=True)
         run_nerfactor(os.path.join(tmp, 'b'), root, learned=False)
+        run_nerfactor_256(os.path.join(tmp, 'c'), root, learned=True)
+        run_nerfactor_256(os.path.join(tmp, 'd'), root, learned=False)
     path = os.path.join(HERE, 'reference_models.npz')
     np.savez_compressed(path, **OUT)
     print('wrote %s (%.1f KiB)' % (path, os.path.getsize(path) / 1024))
