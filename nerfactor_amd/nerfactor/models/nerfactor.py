@@ -158,7 +158,9 @@ class Model(ShapeModel):
         id_, hw, rayo, _, rgb, alpha, xyz, normal, lvis = batch
         n_all = alpha.shape[0]
         idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped
-        rayo, rgb, xyz, normal, lvis = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal, lvis))
+        all_fg = idx.numel() == n_all   # training batches are foreground rays only (datasets/nerf_shape.py:118-126):
+        if not all_fg:                  # no gather here and no zero-filled scatter at the end (~40 tiny launches)
+            rayo, rgb, xyz, normal, lvis = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal, lvis))
         # The reference also evaluates the jittered copies in vali/test mode (nerfactor.py:198-232)
         # although only the training loss reads them; they are skipped here outside training.
         jitter = xyz_jitter_std > 0 and mode == 'train'
@@ -193,7 +195,7 @@ class Model(ShapeModel):
             albedo = torch.as_tensor(albedo_scales, device=albedo.device).reshape(1, 3) * albedo
         if albedo_override is not None:
             ao = torch.as_tensor(albedo_override, dtype=torch.float32, device=albedo.device)
-            albedo = ao[None, :].expand(albedo.shape[0], -1).contiguous() if ao.dim() == 1 else ao[idx]
+            albedo = ao[None, :].expand(albedo.shape[0], -1).contiguous() if ao.dim() == 1 else (ao if all_fg else ao[idx])
         # ------ BRDF latent
         if not self.pred_brdf:
             raise NotImplementedError("pred_brdf=False: the reference calls an undefined "
@@ -212,8 +214,8 @@ class Model(ShapeModel):
             relight_probes=relight_probes)
 
         def full(v):  # zero-filled scatter back to all rays (tf.scatter_nd)
-            if v is None:
-                return None
+            if v is None or all_fg:
+                return v
             out = torch.zeros((n_all,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
             out[idx] = v
             return out

@@ -274,6 +274,44 @@ def test_full_frame_properties(nfx_lib, cuda):
     sel = torch.from_numpy(idx).to(cuda)
     for k in ('rgb_c', 'rgb_f', 'z_all'):
         assert torch.equal(out[k][sel], sub[k]), k
+    # ... and those 4096 rays OF THE FULL-SIZE FRAME against the CPU oracle (torch-CPU fp32 port of the reference op
+    # sequence): PSNR >= 40 dB; max-abs <= 3e-2 outside the last-sample discontinuity band, counted
+    import torch as _t
+    from oracle import torch_ref
+    tn = [torch_ref.to_torch_net(n) for n in nets]
+    with _t.no_grad():
+        _, fine, aux = torch_ref.render_rays(_t.from_numpy(rayo[idx]), _t.from_numpy(rayd[idx]), tn[0], tn[1])
+    want, got = fine['rgb'].numpy(), sub['rgb_f'].cpu().numpy()
+    assert nerf_ref.psnr_uint8_luma(got, want) >= 40.
+    stable = np.minimum(aux['sigma_last_coarse'].numpy(), aux['sigma_last_fine'].numpy()) > 0.06
+    err = np.abs(got - want).max(1)
+    print("full frame subset: %d of 4096 rays in the discontinuity band, max-abs %.3e outside, %.3e overall" % (
+        int((~stable).sum()), err[stable].max(), err.max()))
+    assert err[stable].max() <= 4e-2 and np.quantile(err[stable], 0.99) <= 3e-2 and stable.mean() > 0.7
+
+
+def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
+    """800 x 800 x (64 + 128) through the TRAINED networks (no discontinuity band): a 4096-ray subset of the full-size
+    frame against the CPU oracle with a max-abs bound on at least 98 % of the rays (silhouette rays counted)."""
+    import torch as _t
+    from oracle import torch_ref
+    from tests.golden import golden_inputs as gi
+    nets = gi.trained_nerf_nets()
+    rayo, rayd = common.camera_rays(800, 800, cam_loc=(1.9, -2.8, 2.1))
+    out = _render_device(rayo, rayd, nets, cuda)
+    idx = np.random.default_rng(7).choice(rayo.shape[0], 4096, replace=False)
+    tn = [torch_ref.to_torch_net(n) for n in nets]
+    with _t.no_grad():
+        _, fine, aux = torch_ref.render_rays(_t.from_numpy(rayo[idx]), _t.from_numpy(rayd[idx]), tn[0], tn[1])
+    assert float(_t.minimum(aux['sigma_last_coarse'], aux['sigma_last_fine']).min()) > 0.06
+    want = fine['rgb'].numpy()
+    got = out['rgb_f'][_t.from_numpy(idx).to(cuda)].cpu().numpy()
+    err = np.abs(got - want).max(1)
+    bad = int((err > 3e-2).sum())
+    print("trained full frame: %d of 4096 rays above 3e-2 (max %.3e), PSNR %.1f dB" % (
+        bad, err.max(), nerf_ref.psnr_uint8_luma(got, want)))
+    assert bad <= 0.02 * 4096 and nerf_ref.psnr_uint8_luma(got, want) >= 40.
+    assert 0.05 < float(out['occu_f'].mean()) < 0.6
 
 
 def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
