@@ -420,8 +420,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
 // GEO = 1: Rusinkiewicz angles without the two Rodrigues rotations' sin / cos and without the half-vector azimuth
 //          (cos phi_h = h_x / s, sin phi_h = h_y / s, sin theta_h = s = |h_xy|), polynomial acos / atan2, and the
 //          two-band encoding of the three angles from double-angle identities instead of 6 v_sin / v_cos.
-constexpr int kRing = 1024;   // ring entries per wave (4 KiB): (local point index << 10) | light
-static_assert(kLds >= kLdsNet + kNW * kRing * 4, "ring area");
+// ring of queued rows per wave: 1024 entries of 16 bits = (point slot << 10) | light, point slot = local point index
+// mod 8 (a pass decodes it against the index of the newest filled point; the fill loop never lets the queue span 8
+// points).  2 KiB per wave: 8 waves (two per SIMD) fit next to the network.
+constexpr int kRing = 1024;
+typedef unsigned short ring_t;
+static_assert(kLdsNet + 8 * kRing * (int)sizeof(ring_t) <= 160 * 1024, "ring area");
 
 __device__ __forceinline__ float acos_poly(float x) {   // Abramowitz-Stegun 4.4.46, |err| <= 2e-8 + fp32 rounding
     const float ax = fabsf(x);
@@ -510,8 +514,12 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
     }
 }
 
-template <int CT, int GEO>
-__global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
+// NW = 4: one wave per SIMD (CT = 3 | 4).  NW = 8, CT = 2: two waves per SIMD — while one wave fills its queue and
+// computes the Rusinkiewicz inputs of its next pass (pure VALU, ~30 % of a one-wave-per-SIMD kernel's time), its
+// partner's MFMAs keep the matrix pipe busy.
+template <int CT, int GEO, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
+    constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
     }
     const char* wlds = smem;
     const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
-    unsigned* ring = reinterpret_cast<unsigned*>(smem + kLdsNet) + wave * kRing;
+    ring_t* ring = reinterpret_cast<ring_t*>(smem + kLdsNet) + wave * kRing;
     const int L = a.n_lights;
     const long long n = a.n;
     const long long nw = (long long)gridDim.x * kNW, gw = (long long)blockIdx.x * kNW + wave;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
         }
         return r;
     };
-    long long kfill = 0;
+    long long kfill = 0, k_head = 0;   // next point to fill; point of the oldest queued row
     int head = 0, cnt = 0;
     float nxt = load_pt(gw);
     for (;;) {
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
         while (cnt < kPass) {
             const long long pt = gw + kfill * nw;
             if (pt >= n) break;
+            if (cnt > 0 && kfill - k_head >= 7) break;   // the queue may span at most 8 points (3-bit point slot)
             const float cur = nxt;
             nxt = load_pt(pt + nw);
             float x[3], nr[3], rot[9];
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
                 const unsigned long long mask = __ballot(fr);
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (fr) ring[(head + cnt + pos) & (kRing - 1)] = (unsigned)(kfill << 10) | (unsigned)l;
+                if (fr) ring[(head + cnt + pos) & (kRing - 1)] = (ring_t)(((kfill & 7) << 10) | l);
                 else if (valid) a.out[pt * L + l] = 0.0f;                 // scatter_nd's zeros
                 cnt += __popcll(mask);
             }
@@ -587,7 +596,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
             const int r = c * 32 + p;
             const bool ok = r < rows;
             const unsigned e = ring[(head + (ok ? r : 0)) & (kRing - 1)];
-            const long long pt = gw + (long long)(e >> 10) * nw;
+            const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);   // slot -> local point index
+            const long long pt = gw + kk * nw;
             const int l = (int)(e & 1023u);
             orow[c] = ok ? pt * L + l : -1;
             float x[3], lp[3], cm[3], nr[3];
@@ -645,6 +655,12 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_compact_kernel(Args a) {
         }
         head = (head + rows) & (kRing - 1);
         cnt -= rows;
+        if (cnt > 0) {
+            const unsigned e = ring[head];
+            k_head = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);
+        } else {
+            k_head = kfill;
+        }
     }
 }
 
@@ -686,30 +702,31 @@ extern "C" int nfx_launch_brdf_spec_v2(const float* xyz, const float* cam, const
     return launch_res<4, 1>(a, max_blocks, st);
 }
 
-template <int CT, int GEO>
+template <int CT, int GEO, int NW>
 static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     using namespace nfx;
-    const long long want = (a.n + lv2::kNW - 1) / lv2::kNW;       // at least one point per wave
+    const long long want = (a.n + NW - 1) / NW;       // at least one point per wave
     const int grid = (int)(want < max_blocks ? want : max_blocks);
-    auto k = lv2::brdf_compact_kernel<CT, GEO>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lv2::kLds);
+    constexpr int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t);
+    auto k = lv2::brdf_compact_kernel<CT, GEO, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(lv2::kNW * 64), lv2::kLds, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
 // Front-lit compaction (brdf_compact_kernel).  geo: 0 = reference op sequence per row, 1 = closed-form Rusinkiewicz.
-// Returns -1 when the shape does not fit the ring / entry packing (the caller falls back to the dense kernel).
+// ct: 3 | 4 column tiles with one wave per SIMD, 2 = two column tiles with TWO waves per SIMD (8 waves per workgroup).
+// Returns -1 when the shape does not fit the row queue (the caller falls back to the dense kernel).
 extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const float* normal, const float* z,
                                        int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
                                        float* spec, int ct, int geo, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
-    const long long waves = (long long)nfx::lv2::kNW * (((n + 3) / 4) < max_blocks ? ((n + 3) / 4) : max_blocks);
-    if (n_lights > 1024 || ct * 32 - 1 + n_lights > nfx::lv2::kRing || (n + waves - 1) / waves >= (1ll << 22)) return -1;
+    if (n_lights > 1024 || ct * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;
     nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
-    if (ct == 3) return geo ? launch_compact<3, 1>(a, max_blocks, st) : launch_compact<3, 0>(a, max_blocks, st);
-    return geo ? launch_compact<4, 1>(a, max_blocks, st) : launch_compact<4, 0>(a, max_blocks, st);
+    if (ct == 2) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 8>(a, max_blocks, st);
+    if (ct == 3) return geo ? launch_compact<3, 1, 4>(a, max_blocks, st) : launch_compact<3, 0, 4>(a, max_blocks, st);
+    return geo ? launch_compact<4, 1, 4>(a, max_blocks, st) : launch_compact<4, 0, 4>(a, max_blocks, st);
 }
 
 #ifdef NFX_LV2_TIMING

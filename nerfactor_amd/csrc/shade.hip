@@ -37,17 +37,24 @@ __device__ __forceinline__ void load_point(const ShadeArgs& a, long long pt, Poi
 }
 
 // T[c] = brdf[n,l,c] * lvis[n,l]*[cos>0] * cos[n,l] * area[l]     (nerfactor.py:325-336)
-__device__ __forceinline__ void light_transport(const ShadeArgs& a, const PointCtx& pc, long long pt, int l,
-                                                const float* lxyz_s, const float* area_s, float (&T)[3]) {
+// lvis_l / spec_l: the point's visibility and (learned BRDF) specular value for light l, already in registers.
+__device__ __forceinline__ void light_transport_v(const ShadeArgs& a, const PointCtx& pc, int l, float lvis_l,
+                                                  float spec_l, const float* lxyz_s, const float* area_s,
+                                                  float (&T)[3]) {
     const float lp[3] = {lxyz_s[3 * l], lxyz_s[3 * l + 1], lxyz_s[3 * l + 2]};
     float ldir[3];
     dir_to(lp, pc.x, ldir);  // shape.py:128-131
     const float cosv = dot3(ldir, pc.nrm);
-    const float lv = cosv > 0.0f ? a.lvis[pt * a.n_lights + l] : 0.0f;
-    const float s = a.spec ? a.spec[pt * a.n_lights + l] * a.spec_scale : microfacet_spec(pc.mp, ldir, a.f0);
+    const float lv = cosv > 0.0f ? lvis_l : 0.0f;
+    const float s = a.spec ? spec_l * a.spec_scale : microfacet_spec(pc.mp, ldir, a.f0);
     const float k = lv * cosv * area_s[l];
 #pragma unroll
     for (int c = 0; c < 3; ++c) T[c] = (s + pc.alb_pi[c]) * k;
+}
+__device__ __forceinline__ void light_transport(const ShadeArgs& a, const PointCtx& pc, long long pt, int l,
+                                                const float* lxyz_s, const float* area_s, float (&T)[3]) {
+    light_transport_v(a, pc, l, a.lvis[pt * a.n_lights + l], a.spec ? a.spec[pt * a.n_lights + l] : 0.0f, lxyz_s,
+                      area_s, T);
 }
 
 __device__ __forceinline__ float tonemap(float v, int to_srgb) {
@@ -55,7 +62,9 @@ __device__ __forceinline__ float tonemap(float v, int to_srgb) {
     return to_srgb ? linear2srgb1(v) : v;
 }
 
-constexpr int kShadeWaves = 4;
+// 8 waves per workgroup share one LDS copy of the lights (63 KiB at 9 probes): two workgroups = 4 waves per SIMD; with
+// 4 waves per workgroup the kernel ran 2 waves per SIMD and stalled on every visibility row (r02: 2.5 -> see profiles)
+constexpr int kShadeWaves = 8;
 constexpr int kLightsPerPass = 8;  // per lane -> 512 lights per pass
 
 // LDS: lxyz[L*3] | area[L] | lights[P*L*3] | part[kShadeWaves][P*3]
@@ -72,18 +81,42 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_kernel(ShadeArgs a) {
     for (int i = tid; i < P * L * 3; i += blockDim.x) light_s[i] = a.lights[i];
     __syncthreads();
     float* part = part_s + wave * P * 3;
-    for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < a.n;
-         pt += (long long)gridDim.x * kShadeWaves) {
+    const long long stride = (long long)gridDim.x * kShadeWaves;
+    // the visibility / specular rows of the NEXT point are fetched while this one is shaded (first pass of lights)
+    float lvn[kLightsPerPass], spn[kLightsPerPass];
+    auto fetch = [&](long long pt) {
+#pragma unroll
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            const int l = k * 64 + lane;
+            const bool ok = pt < a.n && l < L;
+            lvn[k] = ok ? a.lvis[pt * L + l] : 0.0f;
+            spn[k] = ok && a.spec ? a.spec[pt * L + l] : 0.0f;
+        }
+    };
+    long long pt = (long long)blockIdx.x * kShadeWaves + wave;
+    fetch(pt);
+    for (; pt < a.n; pt += stride) {
         PointCtx pc;
         load_point(a, pt, pc);
+        float lvc[kLightsPerPass], spc[kLightsPerPass];
+#pragma unroll
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            lvc[k] = lvn[k];
+            spc[k] = spn[k];
+        }
+        fetch(pt + stride);
         for (int i = lane; i < P * 3; i += 64) part[i] = 0.0f;
         for (int l0 = 0; l0 < L; l0 += 64 * kLightsPerPass) {
             float T[kLightsPerPass][3];
 #pragma unroll
             for (int k = 0; k < kLightsPerPass; ++k) {
                 const int l = l0 + k * 64 + lane;
-                if (l < L) light_transport(a, pc, pt, l, lxyz_s, area_s, T[k]);
-                else T[k][0] = T[k][1] = T[k][2] = 0.0f;
+                if (l < L) {
+                    if (l0 == 0) light_transport_v(a, pc, l, lvc[k], spc[k], lxyz_s, area_s, T[k]);
+                    else light_transport(a, pc, pt, l, lxyz_s, area_s, T[k]);
+                } else {
+                    T[k][0] = T[k][1] = T[k][2] = 0.0f;
+                }
             }
             for (int p = 0; p < P; ++p) {
                 float s[3] = {0.f, 0.f, 0.f};
@@ -193,7 +226,7 @@ int nfx_launch_shade(const float* xyz, const float* cam, const float* normal, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     long long blocks = (n + nfx::kShadeWaves - 1) / nfx::kShadeWaves;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;   // two resident workgroups per CU, each stages the lights once and loops over points
     hipLaunchKernelGGL(nfx::shade_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
                        make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
                                  lights, n, n_lights, n_probes, to_srgb, 0.f, 0.f, out));

@@ -159,8 +159,12 @@ class Model(ShapeModel):
         n_all = alpha.shape[0]
         idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped
         all_fg = idx.numel() == n_all   # training batches are foreground rays only (datasets/nerf_shape.py:118-126):
+        rgb_all, normal_all, lvis_all = rgb, normal, lvis
         if not all_fg:                  # no gather here and no zero-filled scatter at the end (~40 tiny launches)
-            rayo, rgb, xyz, normal, lvis = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal, lvis))
+            rayo, rgb, xyz, normal = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal))
+            # the [n, 512] ground-truth visibility is only gathered where it is an INPUT (shape_mode = nerf); as an
+            # output (gt['lvis'] = scatter of the gathered rows) it is one masked copy, not gather + fill + scatter
+            lvis = lvis[idx].contiguous() if self.shape_mode == 'nerf' else None
         # The reference also evaluates the jittered copies in vali/test mode (nerfactor.py:198-232)
         # although only the training loss reads them; they are skipped here outside training.
         jitter = xyz_jitter_std > 0 and mode == 'train'
@@ -226,7 +230,13 @@ class Model(ShapeModel):
             pred['rgb_olat'] = full(rgb_olat)
         if rgb_probes is not None:
             pred['rgb_probes'] = full(rgb_probes)
-        gt = {'rgb': full(rgb), 'normal': full(normal), 'lvis': full(lvis), 'alpha': alpha}
+        if all_fg:
+            gt = {'rgb': rgb, 'normal': normal, 'lvis': lvis, 'alpha': alpha}
+        else:   # tf.scatter_nd of the foreground rows = the inputs with the background rows zeroed
+            fg = alpha[:, :1] > 0
+            gt = {'rgb': torch.where(fg, rgb_all, torch.zeros_like(rgb_all)),
+                  'normal': torch.where(fg, normal_all, torch.zeros_like(normal_all)),
+                  'lvis': torch.where(fg, lvis_all, torch.zeros_like(lvis_all[:1, :1])), 'alpha': alpha}
         loss_kwargs = {
             'mode': mode, 'normal_jitter': full(normal_jitter), 'lvis_jitter': full(lvis_jitter),
             'brdf_prop_jitter': full(brdf_prop_jitter), 'albedo_jitter': full(albedo_jitter)}

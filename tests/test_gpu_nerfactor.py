@@ -325,10 +325,11 @@ def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
         outs[v] = ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda), dev(lxyz, cuda), blob)
     for v in ("2", "3", "4", "5"):   # 5 = front-lit compaction with the same per-row arithmetic
         assert torch.equal(outs["0"], outs[v]), "brdf variant " + v
-    monkeypatch.setenv("NFX_BRDF_CT", "3")
     monkeypatch.setenv("NFX_BRDF_VARIANT", "5")
-    assert torch.equal(outs["0"], ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda),
-                                                    dev(lxyz, cuda), blob))
+    for ct in ("3", "2", "4"):     # 2 = eight waves per workgroup (two per SIMD), 16-bit row queue
+        monkeypatch.setenv("NFX_BRDF_CT", ct)
+        assert torch.equal(outs["0"], ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda),
+                                                        dev(z, cuda), dev(lxyz, cuda), blob)), ct
     # 6 = closed-form angles: same rows evaluated, values within the rounding of the bf16 MLP inputs
     assert torch.equal(outs["0"] > 0, outs["6"] > 0)
     assert (outs["0"] - outs["6"]).abs().max().item() < 2e-2 * max(1., outs["0"].max().item())
