@@ -12,8 +12,17 @@ Formats (restated from TensorFlow's public sources; no file of the reference is 
   * object-based (TF2) checkpoints name variables `<attr path>/.ATTRIBUTES/VARIABLE_VALUE`; the reference's models sit
     under `net/`, its layers are attributes `net_<network>_layer<i>` (models/base.py:81-104) with Keras variables
     `kernel` / `bias`, the light probe is `_light`, the BRDF codes `latent_code/_z`.
-PARITY UNPINNED: no TensorFlow and no released checkpoint is available in this environment; the reader is tested
-against an independent writer of the same public format (tests/tf_bundle_writer.py) only."""
+  * the string entry `_CHECKPOINTABLE_OBJECT_GRAPH` holds a TrackableObjectGraph proto: nodes {1 children {1 node_id,
+    2 local_name}, 2 attributes {1 name, 2 full_name, 3 checkpoint_key}}.  A variable's checkpoint key is the FIRST path
+    the saver found to it; for tf.keras.Model subclasses the automatic `layer_with_weights-N` dependencies come before
+    attribute names, so released checkpoints may be keyed `net/layer_with_weights-0/kernel/...`.  `to_state_dict`
+    therefore resolves every model attribute path (`net/net_coarse_enc_layer0/kernel`) by WALKING THE OBJECT GRAPH to
+    the node and taking whatever key that node was saved under; plain key matching is the fallback for bundles
+    without a graph.
+PARITY: no TensorFlow and no released checkpoint is available in this environment.  Pinned without TensorFlow:
+crc32c against the published check value, the table / proto decoding against bytes hand-assembled from the format
+specifications inside the test (tests/test_cpu_tf_ckpt.py), block and tensor checksums verified on read.  Still
+unpinned: that TensorFlow 2.2's writer makes no choice this reader does not expect (e.g. a compressed index)."""
 import glob
 import struct
 
@@ -36,11 +45,42 @@ def _varint(buf, pos):
         shift += 7
 
 
-def _block(data, offset, size):
+_CRC_TABLE = None
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli, reflected polynomial 0x82f63b78): the checksum of table blocks and tensor payloads."""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82f63b78 if c & 1 else 0)
+            tab.append(c)
+        _CRC_TABLE = np.array(tab, np.uint32)
+    c = 0xffffffff
+    tab = _CRC_TABLE
+    for b in bytes(data):
+        c = int(tab[(c ^ b) & 0xff]) ^ (c >> 8)
+    return c ^ 0xffffffff
+
+
+def masked_crc(data):
+    """LevelDB / TensorFlow crc masking: rotate right by 15 bits and add a constant."""
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def _block(data, offset, size, verify=True):
     raw = data[offset:offset + size]
     ctype = data[offset + size]
     if ctype != 0:
         raise NotImplementedError("compressed SSTable block (type %d): the bundle writer emits none" % ctype)
+    if verify:
+        want = struct.unpack_from('<I', data, offset + size + 1)[0]
+        if masked_crc(data[offset:offset + size + 1]) != want:
+            raise ValueError("SSTable block at %d: checksum mismatch (corrupt index file)" % offset)
     return raw
 
 
@@ -116,7 +156,7 @@ def parse_entry(value):
     if 7 in msg:
         raise NotImplementedError("sliced (partitioned) variables are not supported")
     return {'dtype': msg.get(1, [0])[0], 'shape': tuple(shape), 'shard_id': msg.get(3, [0])[0],
-            'offset': msg.get(4, [0])[0], 'size': msg.get(5, [0])[0]}
+            'offset': msg.get(4, [0])[0], 'size': msg.get(5, [0])[0], 'crc': msg.get(6, [None])[0]}
 
 
 def read_index(prefix):
@@ -132,8 +172,53 @@ def read_index(prefix):
     return entries, header
 
 
-def load_tensors(prefix, names=None):
-    """{name: np.ndarray} for the numeric tensors of the checkpoint (strings, e.g. the object graph, are skipped)."""
+def read_string_tensor(prefix, name):
+    """Bytes of a scalar DT_STRING entry (e.g. `_CHECKPOINTABLE_OBJECT_GRAPH`) or None: the payload is a varint
+    length followed by the bytes (tensor_bundle.cc WriteStringTensor: lengths, a 4-byte length checksum, the bytes)."""
+    entries, header = read_index(prefix)
+    e = entries.get(name)
+    if e is None or e['dtype'] != 7:
+        return None
+    n_shards = header.get(1, [1])[0] if header else 1
+    with open('%s.data-%05d-of-%05d' % (prefix, e['shard_id'], n_shards), 'rb') as h:
+        h.seek(e['offset'])
+        raw = h.read(e['size'])
+    n, pos = _varint(raw, 0)
+    if pos + 4 + n == len(raw):      # TF >= 1.x layout: [varint length][4-byte masked crc of the lengths][bytes]
+        pos += 4
+    return raw[pos:pos + n]
+
+
+def parse_object_graph(blob):
+    """TrackableObjectGraph -> list of nodes: {'children': {local_name: node_id}, 'attributes': {name: checkpoint_key}}."""
+    nodes = []
+    for raw in _parse_message(blob).get(1, []):
+        msg = _parse_message(raw)
+        children, attrs = {}, {}
+        for c in msg.get(1, []):
+            cm = _parse_message(c)
+            children[cm.get(2, [b''])[0].decode()] = cm.get(1, [0])[0]
+        for a in msg.get(2, []):
+            am = _parse_message(a)
+            attrs[am.get(1, [b''])[0].decode()] = am.get(3, [b''])[0].decode()
+        nodes.append({'children': children, 'attributes': attrs})
+    return nodes
+
+
+def resolve_path(nodes, path):
+    """Checkpoint key of the variable reached from the root by the attribute path `a/b/c` (None if there is none)."""
+    node = 0
+    for part in path.split('/'):
+        nxt = nodes[node]['children'].get(part)
+        if nxt is None:
+            return None
+        node = nxt
+    return nodes[node]['attributes'].get('VARIABLE_VALUE')
+
+
+def load_tensors(prefix, names=None, verify=False):
+    """{name: np.ndarray} for the numeric tensors of the checkpoint (strings, e.g. the object graph, are skipped).
+    verify: check every tensor's crc32c (pure-Python loop: ~1 s per MiB; off by default, on in the tests)."""
     entries, header = read_index(prefix)
     n_shards = header.get(1, [1])[0] if header else 1
     shards = {}
@@ -147,6 +232,8 @@ def load_tensors(prefix, names=None):
         if sid not in shards:
             shards[sid] = np.memmap('%s.data-%05d-of-%05d' % (prefix, sid, n_shards), dtype=np.uint8, mode='r')
         raw = np.asarray(shards[sid][e['offset']:e['offset'] + e['size']])
+        if verify and e.get('crc') is not None and masked_crc(raw.tobytes()) != e['crc']:
+            raise ValueError("tensor %s: checksum mismatch (corrupt data shard)" % name)
         if e['dtype'] == 14:                           # bfloat16 -> float32
             arr = (raw.view('<u2').astype(np.uint32) << 16).view(np.float32)
         else:
@@ -159,13 +246,21 @@ def is_tf_checkpoint(path):
     return bool(glob.glob(glob.escape(path) + '.index'))
 
 
-def to_state_dict(tensors, root='net'):
-    """TF object-graph variable names under `root` -> names of a torch state_dict of the mirrored model:
+def to_state_dict(tensors, root='net', graph=None, wanted=None):
+    """Checkpoint tensors -> names of a torch state_dict of the mirrored model.
+    With the object graph (`graph` = parse_object_graph(...)) and the model's own parameter names (`wanted`, e.g.
+    'net_coarse_enc_layer0.kernel'), every name is resolved by walking root/<attr>/<attr>... to its node: this finds
+    the tensor whatever key the saver chose for it.  Without a graph: plain key matching,
     'net/net_coarse_enc_layer0/kernel/.ATTRIBUTES/VARIABLE_VALUE' -> 'net_coarse_enc_layer0.kernel'."""
-    pref = root + '/'
     out = {}
+    if graph is not None and wanted is not None:
+        for name in wanted:
+            key = resolve_path(graph, root + '/' + name.replace('.', '/'))
+            if key is not None and key in tensors:
+                out[name] = tensors[key]
+    pref = root + '/'
     for name, arr in tensors.items():
         if not name.startswith(pref) or not name.endswith(SUFFIX):
             continue
-        out[name[len(pref):-len(SUFFIX)].replace('/', '.')] = arr
+        out.setdefault(name[len(pref):-len(SUFFIX)].replace('/', '.'), arr)
     return out

