@@ -276,12 +276,28 @@ class Model(ShapeModel):
         return {'spec': spec, 'spec_scale': self.config.getfloat('DEFAULT', 'learned_brdf_scale')}
 
     def _eval_brdf_at(self, pts2l, pts2c, normal, albedo, brdf_prop, xyz=None, cam=None):
-        """[N, L, 3] BRDF values (explicit tensor, reference signature).  The renderer does not
-        use this — it hands the terms of `_brdf_terms` to the fused kernels."""
-        if xyz is None or cam is None:
-            raise ValueError("pass xyz= and cam=: directions are recomputed from points in libnfx")
-        t = self._brdf_terms(xyz, cam, normal, brdf_prop)
-        return albedo[:, None, :] / np.pi + t['spec'][:, :, None] * t['spec_scale']
+        """[N, L, 3] BRDF values from explicit directions — the reference signature (nerfactor.py:413-461).  The renderer
+        does not use this (it hands the terms of `_brdf_terms` to the fused kernels, which recompute the directions
+        from points); given `xyz` and `cam` the fused kernel is used here too, otherwise the frozen prior is evaluated
+        on the given directions: local frames, Rusinkiewicz angles (nfx_dir2rusink), front-lit rows through the MLP."""
+        scale = self.config.getfloat('DEFAULT', 'learned_brdf_scale')
+        if xyz is not None and cam is not None:
+            t = self._brdf_terms(xyz, cam, normal, brdf_prop)
+            return albedo[:, None, :] / np.pi + t['spec'][:, :, None] * t['spec_scale']
+        from ..util import geom as geomutil
+        n, nl = pts2l.shape[:2]
+        rot = geomutil.gen_world2local(normal)
+        vdir = torch.einsum('jkl,jl->jk', rot, pts2c)
+        ldir = torch.einsum('jkl,jnl->jnk', rot, pts2l).reshape(-1, 3)
+        vrep = vdir[:, None, :].expand(n, nl, 3).reshape(-1, 3)
+        front = ldir[:, 2] > 0
+        spec = torch.zeros(n * nl, dtype=albedo.dtype, device=albedo.device)
+        if bool(front.any()):
+            rusink = geomutil.dir2rusink(ldir[front].contiguous(), vrep[front].contiguous())
+            z = brdf_prop[:, None, :].expand(n, nl, brdf_prop.shape[1]).reshape(-1, brdf_prop.shape[1])[front]
+            with torch.no_grad():
+                spec[front] = self.brdf_model._eval_brdf_at(z, rusink)[0][:, 0]
+        return albedo[:, None, :] / np.pi + spec.reshape(n, nl, 1).expand(n, nl, 3) * scale
 
     def _render(self, xyz, cam, normal, albedo, brdf_prop, light_vis, relight_olat=False,
                 relight_probes=False, white_light_override=False, white_lvis_override=False):
