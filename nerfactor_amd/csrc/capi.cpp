@@ -38,16 +38,10 @@ extern "C" {
 // launchers (defined in the .hip files)
 int nfx_launch_nerf_mlp_bf16(const float*, const float*, const float*, long long, int, const void*,
                              float*, int, int, hipStream_t);
-int nfx_launch_nerf_mlp_bf16_v2(const float*, const float*, const float*, long long, int, const void*,
-                                float*, int, int, hipStream_t);
-int nfx_launch_nerf_mlp_bf16_v5(const float*, const float*, const float*, long long, int, const void*, float*, int,
-                                int, hipStream_t);
 int nfx_launch_nerf_mlp_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
                            hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v6(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                 int, hipStream_t);
-int nfx_launch_nerf_mlp_bf16_v3(const float*, const float*, const float*, long long, int, const void*,
-                                float*, int, hipStream_t);
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
 int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
 int nfx_launch_composite(const float*, const float*, const float*, const float*, long long, int, int,
@@ -176,34 +170,27 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
     const long long n_pts = (long long)n_rays * n_samples;
     const int blocks = env_int("NFX_NERF_BLOCKS", 256);
     if (prec == NFX_PREC_BF16) {
-        // 0: 4 waves x 64 points, register-staged weights; 1: 8 waves x 32 points, register-staged;
-        // 2: 8 waves x 32 points, LDS-DMA ring + half-tile phase offset between the wave groups
+        // NFX_NERF_VARIANT: 7 (default) = one wave per SIMD, 64 points per wave, epilogue software-pipelined under the
+        // next tile's MFMAs, weight stream by LDS-DMA into a 6-slot ring (nerf_mlp_v6.hip); 6 / 8 = the same kernel
+        // with register-staged weights (one / two staging sets); 1 = the 8 waves x 32 points reference geometry with
+        // two waves per SIMD, 0 = 4 x 64 plain (nerf_mlp.hip).  All bit-identical.  The intermediate variants 2, 3, 5
+        // of r01 live in scripts/experiments/ (not built).
         const int variant = env_int("NFX_NERF_VARIANT", 7);
-        if (variant == 8)  // variant 6 with two staging register sets: chunk K+3 fetched during tile K, stored a tile later
+        if (variant == 8)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -8,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v8)");
-        if (variant == 7)  // variant 6 with the weight stream as LDS-DMA (no VGPR staging, counted vmcnt)
+        if (variant == 7)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
                                                           env_int("NFX_ABLATE", 0) > 0 ? 100 + env_int("NFX_ABLATE", 0) : -7,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v7)");
-        if (variant == 6)  // variant 5 + 3-slot ring, mid-tile weight store, next tile's operands read before the barrier
+        if (variant == 6)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
                                                           env_int("NFX_ABLATE", 0), (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v6)");
-        if (variant == 5)  // one wave per SIMD, 64 points per wave, epilogue software-pipelined under the next tile's MFMAs
-            return hip_result(nfx_launch_nerf_mlp_bf16_v5(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
-                              "nerf_mlp_fwd(bf16, v5)");
-        if (variant == 3)  // segment-level LOAD/COMP anti-phase between the two waves of a SIMD, 6-slot DMA ring
-            return hip_result(nfx_launch_nerf_mlp_bf16_v3(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          (hipStream_t)stream),
-                              "nerf_mlp_fwd(bf16, v3)");
-        if (variant == 2)
-            return hip_result(nfx_launch_nerf_mlp_bf16_v2(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
-                              "nerf_mlp_fwd(bf16, v2)");
+        if (variant != 0 && variant != 1)
+            return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8)", variant);
         return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
                                                    blocks, (hipStream_t)stream),
                           "nerf_mlp_fwd(bf16)");

@@ -59,7 +59,7 @@ def test_normalize_and_gen_z(nfx_lib, cuda):
     assert ops.gen_z(2., 6., 64, 0, device=cuda).shape == (0, 64)  # empty batch
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8"])
+@pytest.mark.parametrize("variant", ["0", "1", "6", "7", "8"])
 @pytest.mark.parametrize("n_rays,n_samples", [(1, 64), (300, 64), (77, 192), (4, 5)])
 def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monkeypatch):
     from nerfactor_amd import ops
@@ -81,7 +81,7 @@ def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monk
     assert np.max(np.abs(got - want)) < 0.2  # raw logits / 8x-scaled sigma, pre-activation
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "5", "6", "7", "8"])
+@pytest.mark.parametrize("variant", ["1", "6", "7", "8"])
 def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch, variant):
     """More tiles than workgroups (persistent loop, wrapped weight stream) must equal tile-by-tile."""
     from nerfactor_amd import ops
@@ -325,10 +325,10 @@ def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     rayd = dev(nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12), cuda)
     z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
     outs = {}
-    for v in ("1", "2", "3", "4", "5", "6", "7", "8"):
+    for v in ("0", "1", "6", "7", "8"):
         monkeypatch.setenv("NFX_NERF_VARIANT", v)
         outs[v] = [ops.nerf_mlp_fwd(rayo, rayd, z, blob) for _ in range(3)]
-    for t in outs["1"][1:] + outs["2"] + outs["3"] + outs["4"] + outs["5"] + outs["6"] + outs["7"] + outs["8"]:
+    for t in outs["1"][1:] + outs["0"] + outs["6"] + outs["7"] + outs["8"]:
         assert torch.equal(outs["1"][0], t)
 
 
