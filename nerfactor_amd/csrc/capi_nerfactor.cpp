@@ -192,12 +192,11 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
     // NFX_BRDF_VARIANT: 0 / 2 / 3 / 4 as NFX_LVIS_VARIANT (every row evaluated, back-lit rows zeroed afterwards);
     // 5 = front-lit rows only (LDS row queue per wave), per-row geometry as in the dense kernels (bit-identical);
     // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT = column tiles per wave of variants 5 / 6
-    // (2, the default = eight waves per workgroup, two per SIMD: a wave's queue filling and geometry run under its
-    // partner's MFMAs; 3 | 4 = one wave per SIMD).
+    // (2 | 3 | 4, default 4; always one wave per SIMD — the two-waves-per-SIMD form is not deterministic, lvis_v2.hip).
     int variant = nfx_env_int("NFX_BRDF_VARIANT", 6);
     if (variant >= 5) {
         const int rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
-                                               nfx_env_int("NFX_BRDF_CT", 2), variant == 6,
+                                               nfx_env_int("NFX_BRDF_CT", 4), variant == 6,
                                                nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
         if (rc != -1) return nfx_hip_result(rc, "brdf_spec_fwd(v3)");
         variant = 3;   // shape outside the row queue's limits: dense kernel

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
 constexpr int kRing = 1024;
 typedef unsigned short ring_t;
 static_assert(kLdsNet + 8 * kRing * (int)sizeof(ring_t) <= 160 * 1024, "ring area");
+__device__ __forceinline__ int ring_wrap(int i, int cap) { return i >= cap ? i - cap : i; }   // i < 2 cap
 
 __device__ __forceinline__ float acos_poly(float x) {   // Abramowitz-Stegun 4.4.46, |err| <= 2e-8 + fp32 rounding
     const float ax = fabsf(x);
@@ -514,15 +515,23 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
     }
 }
 
-// NW = 4: one wave per SIMD (CT = 3 | 4).  NW = 8, CT = 2: two waves per SIMD — while one wave fills its queue and
-// computes the Rusinkiewicz inputs of its next pass (pure VALU, ~30 % of a one-wave-per-SIMD kernel's time), its
-// partner's MFMAs keep the matrix pipe busy.
+// NW = 4: one wave per SIMD (CT = 2 | 3 | 4) — the only shipped form.
+// NW = 8, CT = 2 (two waves per SIMD: one wave's fill / Rusinkiewicz VALU under its partner's MFMAs) measured 5.7-6.1
+// ms against 6.5 ms per 200 000 x 512 rows, but is NOT deterministic on MI355X: a few thousand of 10^8 rows come out
+// wrong, in groups of 16 lanes of the second column tile, run to run different.  Everything a wave touches is private
+// to it (registers, its ring, its points); the same tile code with two waves per SIMD is bit-stable in
+// resident128_kernel<2, 0, 8> (10^10 rows, scripts/experiments/soak_lvis8.py), whose partner wave never streams
+// gathers.  32 idle cycles before each tile's first accumulator read cut the failures 100 x, one LDS read group per
+// column tile raises them 10 x (profiles/r02/brdf_8wave_race/): a result-latency margin the compiler's fixed wait
+// states do not cover once a partner wave's VMEM / LDS returns compete for the register file.  Compiled only with
+// -DNFX_EXPERIMENT_BRDF_NW8 (NFX_BRDF_CT=8), for scripts/experiments/diag_brdf*.py.
 template <int CT, int GEO, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
     constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: point indices and ring base live in SGPRs
     {   // the whole network, once
         const u32x4* src = reinterpret_cast<const u32x4*>(a.blob);
         u32x4* dst = reinterpret_cast<u32x4*>(smem);
@@ -531,38 +540,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
     }
     const char* wlds = smem;
     const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
-    ring_t* ring = reinterpret_cast<ring_t*>(smem + kLdsNet) + wave * kRing;
+    constexpr int kCap = kRing;
+    ring_t* ring = reinterpret_cast<ring_t*>(smem + kLdsNet) + wave * kCap;
     const int L = a.n_lights;
     const long long n = a.n;
     const long long nw = (long long)gridDim.x * kNW, gw = (long long)blockIdx.x * kNW + wave;
     constexpr int kPass = CT * 32;
-    // fill-side inputs of a point, one element per lane: [x(3) | normal(3)], fetched one point ahead
-    auto load_pt = [&](long long pt) {
-        float r = 0.0f;
-        if (pt < n) {
-            if (lane < 3) r = a.xyz[pt * 3 + lane];
-            else if (lane < 6) r = a.normal[pt * 3 + lane - 3];
-            else if (lane < 9) r = a.cam[pt * 3 + lane - 6];          // touched here so the pass finds it in cache
-            else if (lane < 9 + a.z_dim) r = a.z[pt * a.z_dim + lane - 9];
-        }
-        return r;
-    };
     long long kfill = 0, k_head = 0;   // next point to fill; point of the oldest queued row
     int head = 0, cnt = 0;
-    float nxt = load_pt(gw);
     for (;;) {
         // ---- fill: front-lit rows of the next points until a whole pass is queued (ring: kPass - 1 + L <= kRing)
         while (cnt < kPass) {
             const long long pt = gw + kfill * nw;
             if (pt >= n) break;
             if (cnt > 0 && kfill - k_head >= 7) break;   // the queue may span at most 8 points (3-bit point slot)
-            const float cur = nxt;
-            nxt = load_pt(pt + nw);
+            // the point's position and normal: wave-uniform scalar loads (a partner wave's MFMAs cover their latency)
             float x[3], nr[3], rot[9];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                x[k] = __shfl(cur, k, 64);
-                nr[k] = __shfl(cur, 3 + k, 64);
+                x[k] = a.xyz[pt * 3 + k];
+                nr[k] = a.normal[pt * 3 + k];
             }
             world2local(nr, rot);
             for (int l0 = 0; l0 < L; l0 += 64) {
@@ -577,7 +574,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 const unsigned long long mask = __ballot(fr);
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (fr) ring[(head + cnt + pos) & (kRing - 1)] = (ring_t)(((kfill & 7) << 10) | l);
+                if (fr) ring[ring_wrap(head + cnt + pos, kCap)] = (ring_t)(((kfill & 7) << 10) | l);
                 else if (valid) a.out[pt * L + l] = 0.0f;                 // scatter_nd's zeros
                 cnt += __popcll(mask);
             }
@@ -595,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         for (int c = 0; c < CT; ++c) {
             const int r = c * 32 + p;
             const bool ok = r < rows;
-            const unsigned e = ring[(head + (ok ? r : 0)) & (kRing - 1)];
+            const unsigned e = ring[ring_wrap(head + (ok ? r : 0), kCap)];
             const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);   // slot -> local point index
             const long long pt = gw + kk * nw;
             const int l = (int)(e & 1023u);
@@ -653,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             for (int c = 0; c < CT; ++c)
                 if (orow[c] >= 0) a.out[orow[c]] = softplusf(accs[0].v[c][0]);   // brdf.py:65
         }
-        head = (head + rows) & (kRing - 1);
+        head = ring_wrap(head + rows, kCap);
         cnt -= rows;
         if (cnt > 0) {
             const unsigned e = ring[head];
@@ -716,15 +713,19 @@ static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t s
 }
 
 // Front-lit compaction (brdf_compact_kernel).  geo: 0 = reference op sequence per row, 1 = closed-form Rusinkiewicz.
-// ct: 3 | 4 column tiles with one wave per SIMD, 2 = two column tiles with TWO waves per SIMD (8 waves per workgroup).
+// ct: 2 | 3 | 4 column tiles per wave, one wave per SIMD (anything else: 4).
 // Returns -1 when the shape does not fit the row queue (the caller falls back to the dense kernel).
 extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const float* normal, const float* z,
                                        int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
                                        float* spec, int ct, int geo, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
-    if (n_lights > 1024 || ct * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;
+    const int tiles = ct == 8 ? 2 : ct;
+    if (n_lights > 1024 || tiles * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;
     nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
-    if (ct == 2) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 8>(a, max_blocks, st);
+#ifdef NFX_EXPERIMENT_BRDF_NW8
+    if (ct == 8) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 8>(a, max_blocks, st);
+#endif
+    if (ct == 2) return geo ? launch_compact<2, 1, 4>(a, max_blocks, st) : launch_compact<2, 0, 4>(a, max_blocks, st);
     if (ct == 3) return geo ? launch_compact<3, 1, 4>(a, max_blocks, st) : launch_compact<3, 0, 4>(a, max_blocks, st);
     return geo ? launch_compact<4, 1, 4>(a, max_blocks, st) : launch_compact<4, 0, 4>(a, max_blocks, st);
 }

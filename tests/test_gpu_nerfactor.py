@@ -326,13 +326,53 @@ def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     for v in ("2", "3", "4", "5"):   # 5 = front-lit compaction with the same per-row arithmetic
         assert torch.equal(outs["0"], outs[v]), "brdf variant " + v
     monkeypatch.setenv("NFX_BRDF_VARIANT", "5")
-    for ct in ("3", "2", "4"):     # 2 = eight waves per workgroup (two per SIMD), 16-bit row queue
+    for ct in ("3", "2", "4"):     # column tiles per wave (always one wave per SIMD)
         monkeypatch.setenv("NFX_BRDF_CT", ct)
         assert torch.equal(outs["0"], ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda),
                                                         dev(z, cuda), dev(lxyz, cuda), blob)), ct
     # 6 = closed-form angles: same rows evaluated, values within the rounding of the bf16 MLP inputs
     assert torch.equal(outs["0"] > 0, outs["6"] > 0)
     assert (outs["0"] - outs["6"]).abs().max().item() < 2e-2 * max(1., outs["0"].max().item())
+
+
+def test_lvis8_bit_identical_at_scale(nfx_lib, cuda, monkeypatch):
+    """The default light-visibility kernel runs two waves per SIMD; a sibling kernel of that shape proved non-
+    deterministic (profiles/r02/brdf_8wave_race/).  100 000 points x 512 lights, three launches: every row equals the
+    one-wave-per-SIMD kernel's, launch after launch."""
+    from nerfactor_amd import ops
+    n = 100000
+    rng, lxyz, _, xyz, _, _ = scene(n, 31, 16)
+    layers, out = net128(30, 90, 1)
+    blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
+    args = (dev(xyz, cuda), dev(lxyz, cuda), blob)
+    monkeypatch.setenv("NFX_LVIS_VARIANT", "4")
+    ref = ops.lvis_fwd(*args)
+    monkeypatch.delenv("NFX_LVIS_VARIANT")       # the default (8)
+    for _ in range(3):
+        assert torch.equal(ref, ops.lvis_fwd(*args))
+
+
+def test_brdf_spec_default_is_deterministic_at_scale(nfx_lib, cuda, monkeypatch):
+    """Default learned-BRDF kernel (front-lit compaction, closed-form angles) on 100 000 points x 512 lights: launch
+    after launch the same bits, the front-lit pattern of the dense kernel, and values within the closed-form bound
+    for all but the rows whose phi_d sits on the 0 / pi wrap (counted)."""
+    from nerfactor_amd import ops
+    n, zd = 100000, 3
+    rng, lxyz, _, xyz, cam, normal = scene(n, 41, 16)
+    layers, out = net128(40 + zd, zd + 15, 1)
+    blob = pack(layers, out, nfx_lib.IN_Z_RUSINK, 1, cuda, z_dim=zd)
+    z = rng.normal(size=(n, zd)).astype(np.float32)
+    args = (dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda), dev(lxyz, cuda), blob)
+    monkeypatch.delenv("NFX_BRDF_VARIANT", raising=False)
+    monkeypatch.delenv("NFX_BRDF_CT", raising=False)
+    first = ops.brdf_spec_fwd(*args)
+    for _ in range(3):
+        assert torch.equal(first, ops.brdf_spec_fwd(*args))
+    monkeypatch.setenv("NFX_BRDF_VARIANT", "3")
+    dense = ops.brdf_spec_fwd(*args)
+    assert torch.equal(dense > 0, first > 0)
+    far = ((dense - first).abs() > 1e-2).sum().item()
+    assert far <= 40, far        # measured 15 of 5.1e7 rows: phi_d within rounding of the wrap, where the bands flip sign
 
 
 def test_eval_brdf_at_has_the_reference_signature(nfx_lib, cuda):
