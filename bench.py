@@ -150,6 +150,22 @@ def nerf_cpu_reference(nets, rayo, rayd, budget_s, timed_run=True):
     return base, idx[:n], res
 
 
+
+def committed_traffic(kernel_substr, scale=1):
+    """(GB per launch, source) of a kernel from the newest committed PMC digest (scripts/gpu_r02_final.sh ->
+    scripts/pmc_digest.py: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the kernel's dispatches of
+    this very command at N = 1).  rocprofv3 counter passes cannot run inside this process, so the figure is a committed
+    constant and the line says so."""
+    for rnd, name in (('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'), ('r01', 'pmc_nerfactor_digest.json')):
+        dig = os.path.join(ROOT, 'profiles', rnd, name)
+        if not os.path.exists(dig):
+            continue
+        for k, v in json.load(open(dig)).items():
+            if isinstance(v, dict) and kernel_substr in k and 'hbm_write_bytes' in v:
+                return (scale * (v.get('hbm_read_bytes_corrected', 0) + v['hbm_write_bytes']) / 1e9,
+                        "committed PMC digest profiles/%s/%s (not measured in this run)" % (rnd, name))
+    return None, None
+
 def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     from nerfactor_amd import synth
     nets = synth.nerf_nets(seed=0)
@@ -180,17 +196,9 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is the
     # committed digest of the same workload at N = 1 (scripts/gpu_pmc.sh -> scripts/pmc_digest.py): FETCH_SIZE x 2
     # (gfx950 correction) + WRITE_SIZE, per launch pair of a whole 640 000-ray view.
-    traffic, traffic_source = None, None
     variant = os.environ.get("NFX_NERF_VARIANT", "7")
-    for rnd in ('r02', 'r01'):
-        dig = os.path.join(ROOT, 'profiles', rnd, 'pmc_variant%s_digest.json' % variant)
-        if traffic is None and os.path.exists(dig) and n_local == H * W:
-            for k, v in json.load(open(dig)).items():
-                if 'nerf_mlp' in k and 'hbm_write_bytes' in v:
-                    # digest = average over the coarse and the fine dispatch; a launch pair = both
-                    traffic = 2 * (v.get('hbm_read_bytes_corrected', 0) + v['hbm_write_bytes']) / 1e9
-                    traffic_source = "committed PMC digest profiles/%s/%s (not measured in this run)" % (
-                        rnd, os.path.basename(dig))
+    # digest = average over the coarse and the fine dispatch; a launch pair = both
+    traffic, traffic_source = committed_traffic('nerf_mlp', scale=2) if n_local == H * W and variant == "7" else (None, None)
     out = {
         "value": sh.rays_per_step_all_ranks * args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -350,6 +358,14 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     fg_per_call = n_fg_local / sh.n_views
     lvis_s = kt.mean_ms('lvis_fwd') * 1e-3
     lvis_tf = fg_per_call * N_LIGHTS * 2 * LVIS_MAC / lvis_s / 1e12
+    # algorithmic bytes per foreground point: 512 visibilities written, the 1-KiB pre-activation row written by
+    # lvis_pre and read once by the main kernel, the position read
+    lv_traffic, lv_source = None, None
+    if world == 1:
+        a, src = committed_traffic('resident128_kernel')
+        b, _ = committed_traffic('lvis_pre_kernel')
+        if a is not None and b is not None:
+            lv_traffic, lv_source = a + b, src
     out = {
         "workload": "%s full render (BASELINE.json configs[2]): 800x800 surface points per view (60 %% foreground), "
                     "512 lights, trained light + %d probes, Model.call(mode='test', relight_probes=True)" % (
@@ -359,13 +375,17 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         "foreground_points_per_view": int(host_batches[0][5].sum()),
         "flop_per_foreground_point_algorithmic": 2 * (N_LIGHTS * LVIS_MAC + HEAD_MAC + 65408),
         "roofline": {
-            "bound": "mfma", "kernel": "lvis_pre_kernel + resident128_kernel<4, 0> (light visibility, %d x 512 rows)"
+            "bound": "mfma", "kernel": "lvis_pre_kernel + %s (light visibility, %%d x 512 rows)" % {
+                "8": "resident128_kernel<2, 0, 8>", "4": "resident128_kernel<4, 0, 4>"}.get(
+                    os.environ.get("NFX_LVIS_VARIANT", "8"), "variant " + os.environ.get("NFX_LVIS_VARIANT", "8"))
                                        % int(fg_per_call),
             "achieved": lvis_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": lvis_tf / PEAK_BF16_TFLOPS,
             "avg_launch_ms": lvis_s * 1e3, "flop_per_launch": fg_per_call * N_LIGHTS * 2 * LVIS_MAC,
             "executed_tflops": fg_per_call * N_LIGHTS * 2 * 61440 / lvis_s / 1e12,
-            "share_of_step": lvis_s * sh.n_views / (elapsed / args.steps), "traffic": None,
-            "traffic_source": "see profiles/r01/pmc_nerfactor_digest.json (not measured in this run)"},
+            "share_of_step": lvis_s * sh.n_views / (elapsed / args.steps),
+            "traffic": lv_traffic, "traffic_unit": "GB per launch (lvis_pre + light-visibility kernel)",
+            "traffic_source": lv_source,
+            "algorithmic_hbm_gb": fg_per_call * (N_LIGHTS * 4 + 2 * 1024 + 12) / 1e9},
     }
     if variant == 'learned':
         spec_s = kt.mean_ms('brdf_spec_fwd') * 1e-3

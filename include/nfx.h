@@ -245,6 +245,22 @@ int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *d
                       const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
                       float *dev_d_z, float *dev_d_normal, void *stream);
 
+/* The BRDF prior on EXPLICIT rows — evaluation and one training step's backward of models/brdf.py
+ * (reference nerfactor/models/brdf.py:57-66 `_eval_brdf_at`, :87-136 `call`/`compute_loss`, trained by
+ * trainvali.py:273-295).  Row r < n evaluates (z[r, :z_dim], rusink[r, :3] = (phi_d, theta_h, theta_d)); with
+ * reci != 0 there are 2 n rows and row n + r repeats the inputs with phi_d + pi (brdf.py:103-106).  `blob` is the
+ * BRDF train blob (nfx_brdf_pack_train_weights).
+ *   nfx_brdf_rows_fwd: dev_out[rows] = softplus(out(mlp([z, posenc2(rusink)]))).
+ *   nfx_brdf_rows_bwd: given dev_dout[rows] = dLoss/d out, WRITES dev_d_z[rows, z_dim] = dLoss/d z per row and
+ *     ACCUMULATES the weight gradients into dev_dkernels / dev_dbiases (Keras layout, as nfx_mlp128_bwd).    */
+int nfx_brdf_rows_fwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
+                      const void *dev_blob, int prec, float *dev_out, void *stream);
+size_t nfx_brdf_rows_bwd_workspace_bytes(int z_dim, int64_t n, int reci);
+int nfx_brdf_rows_bwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
+                      const void *dev_blob, int prec, const float *dev_dout, void *dev_workspace,
+                      size_t workspace_bytes, float *dev_d_z, float *const dev_dkernels[5],
+                      float *const dev_dbiases[5], void *stream);
+
 /* Backward of nfx_shade_fwd for ONE light (n_probes = 1, the trained light): given dev_drgb [n,3] =
  * dLoss/d rgb, writes d_albedo [n,3], d_normal [n,3], d_lvis [n,L] and either d_rough [n]
  * (microfacet, dev_spec == NULL) or d_spec [n,L] (given specular term); ACCUMULATES d_light [L,3]

@@ -65,6 +65,9 @@ SIGNATURES = {
     'nfx_brdf_train_packed_bytes': (_sz, []),
     'nfx_brdf_pack_train_weights': (_i, [_pp, _pp, _i, _i, _p, _sz]),
     'nfx_brdf_spec_bwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p]),
+    'nfx_brdf_rows_fwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_brdf_rows_bwd_workspace_bytes': (_sz, [_i, _i64, _i]),
+    'nfx_brdf_rows_bwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p, _sz, _p, _pp, _pp, _p]),
     'nfx_shade_bwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p,
                            _p, _p]),
     'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),

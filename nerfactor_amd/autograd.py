@@ -107,6 +107,31 @@ class BrdfSpec(torch.autograd.Function):
         return (None,) * 6 + (d_normal, d_z)
 
 
+class BrdfRows(torch.autograd.Function):
+    """(brdf, brdf_reci)[n] of the BRDF prior on explicit (z, Rusinkiewicz) rows — models/brdf.py:_eval_brdf_at.
+    Differentiable w.r.t. the MLP parameters and z (the latent codes); the Rusinkiewicz coordinates are data."""
+
+    @staticmethod
+    def forward(ctx, z, rusink, train_blob_fn, prec, *params):
+        ctx.save_for_backward(z, rusink)
+        ctx.cfg = (train_blob_fn, prec, params)
+        out = ops.brdf_rows_fwd(z, rusink, train_blob_fn(), reci=True, prec=prec)
+        n = z.shape[0]
+        return out[:n], out[n:]
+
+    @staticmethod
+    def backward(ctx, d_brdf, d_reci):
+        z, rusink = ctx.saved_tensors
+        train_blob_fn, prec, params = ctx.cfg
+        ks, bs = list(params[:5]), list(params[5:])
+        (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
+        n = z.shape[0]
+        dout = torch.cat((d_brdf.reshape(n), d_reci.reshape(n)))
+        d_rows = ops.brdf_rows_bwd(z, rusink, train_blob_fn(), dout, dks, dbs, reci=True, prec=prec)
+        d_z = (d_rows[:n] + d_rows[n:]) if ctx.needs_input_grad[0] else None
+        return (d_z, None, None, None) + tuple(rks) + tuple(rbs)
+
+
 class ShadeSpec(torch.autograd.Function):
     """rgb[n,3] under the trained light with brdf = albedo/pi + spec_scale * spec (nerfactor.py:459-461)."""
 

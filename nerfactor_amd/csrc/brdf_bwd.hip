@@ -12,6 +12,7 @@
 #include "geom_ad.hpp"
 #include "mlp128_layout.hpp"
 #include "mlp_engine.hpp"
+#include "feat_store.hpp"
 
 namespace nfx {
 namespace brdfbwd {
@@ -192,6 +193,147 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The BRDF prior on EXPLICIT rows (models/brdf.py:57-66, 87-136): row r < n evaluates (z[r], rusink[r]); with
+// `rows` = 2 n the rows r >= n repeat the inputs with phi_d + pi (the reciprocal Rusinkiewicz coordinates that share
+// the ground truth, brdf.py:103-106).  BWD = false: out[rows] = softplus(logit) — the stream wraps after the forward
+// chunks of the train blob.  BWD = true: the forward is re-computed, d logit = dout * sigmoid(logit), the dgrad chain
+// runs as in brdf_spec_bwd_kernel, d_z[rows, z_dim] is stored per row, and the layer inputs X (LOGICAL Embedder order
+// [z | rusink | sin, cos band 0 | sin, cos band 1], so dW comes out in the Keras layout), h0..h3 and the
+// pre-activation gradients dZ0..dZ3, dZ_out go feature-major to `wsp` for the weight-gradient GEMMs (train.hip).
+constexpr int kRowsX = 32;                       // feature rows reserved for the network input
+constexpr int kOffH = kRowsX, kOffDZ = kRowsX + 512, kOffDZo = kRowsX + 1024, kRowFeats = kRowsX + 1032;
+
+template <bool BWD>
+__global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(
+    const float* __restrict__ z, int z_dim, const float* __restrict__ rusink, long long n, long long rows,
+    const char* __restrict__ blob, const float* __restrict__ dout, float* __restrict__ out_or_dz,
+    __bf16* __restrict__ wsp, long long ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace m128;
+    using namespace nfx::bwd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + kWeightBytes);
+        for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
+    }
+    WStream ws;
+    ws.gbase = reinterpret_cast<const u32x4*>(blob);
+    ws.gend = reinterpret_cast<const u32x4*>(blob + (BWD ? kWeightBytes : kFwdFrags * 1024));
+    ws.gnext = ws.gbase;
+    ws.ring = smem;
+    stream_prologue<1, kNW>(ws, tid);
+    const long long n_tiles = (rows + kRows - 1) / kRows;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row = tile * kRows + wave * 32 + p;
+        const bool valid = row < rows;
+        const long long rc = valid ? row : rows - 1;
+        const long long src = rc >= n ? rc - n : rc;
+        float rus[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rus[k] = rusink[src * 3 + k];
+        if (rc >= n) rus[0] = rus[0] + 3.14159265358979323846f;   // brdf.py:103
+        const float* zp = z + src * z_dim;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = sin_shifted_small(rus[q % 3] * (float)(1 << (q / 3)), h);
+        v[6] = h ? rus[2] : rus[0];
+        v[7] = h ? zp[0] : rus[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = 1 + 2 * j + h;
+            v[8 + j] = i < z_dim ? zp[i] : 0.0f;
+        }
+        bf16x8 bin[2][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bin[s][0][j] = (__bf16)v[8 * s + j];
+        bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
+        layer<2, 0, 4, 1, 2, true, kNW>(ws, tid, bias_lds, bin, bin, h0);
+        layer<8, 0, 4, 2, 2, true, kNW>(ws, tid, bias_lds + 128, h0, bin, h1);
+        layer<8, 0, 4, 2, 3, true, kNW>(ws, tid, bias_lds + 256, h1, bin, h2);
+        layer<8, 2, 4, 3, 2, true, kNW>(ws, tid, bias_lds + 384, h2, bin, h3);
+        f32x16 logit[1];
+        tile_raw<8, 0, 1, kNW>(ws, tid, bias_lds + 512, h3, bin, logit);   // next chunk: dOut (BWD) or L0 (4 frags each)
+        if constexpr (!BWD) {
+            if (valid && h == 0) out_or_dz[row] = softplusf(logit[0][0]);   // brdf.py:65
+        } else {
+            FeatStore fs;
+            {
+                unsigned long long ld2 = (unsigned long long)ld * 2, b = reinterpret_cast<unsigned long long>(wsp);
+                asm volatile("" : "+s"(ld2), "+s"(b));
+                fs.base = reinterpret_cast<char*>(b);
+                fs.ld2 = ld2;
+                fs.roff = (unsigned)(row * 2);
+            }
+            {   // network input, logical order
+                FeatStore f3 = fs, f2 = fs, f1 = fs;
+                f3.roff = fs.roff + (h ? (unsigned)(3 * fs.ld2) : 0u);   // cosines sit 3 features after the sines
+                f2.roff = fs.roff + (h ? (unsigned)(2 * fs.ld2) : 0u);   // theta_d sits 2 features after phi_d
+                f1.roff = fs.roff + (h ? (unsigned)fs.ld2 : 0u);         // z_{i+1} after z_i
+#pragma unroll
+                for (int q = 0; q < 6; ++q) st16(f3, z_dim + 3 + 6 * (q / 3) + (q % 3), bin[0][0][q]);
+                st16(f2, z_dim, bin[0][0][6]);
+                if (h == 0) st16(fs, z_dim + 1, bin[0][0][7]);
+                else st16(fs, 0, bin[0][0][7]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (1 + 2 * j + h < z_dim) st16(f1, 1 + 2 * j, bin[1][0][j]);
+            }
+            store_hidden<8>(fs, kOffH + 0, h, h0);
+            store_hidden<8>(fs, kOffH + 128, h, h1);
+            store_hidden<8>(fs, kOffH + 256, h, h2);
+            store_hidden<8>(fs, kOffH + 384, h, h3);
+            // ---- d logit (row 0 of the out tile lives in reg 0 of the half-0 lanes)
+            float g = 0.f;
+            if (valid && h == 0) g = dout[row] * sigmoidf(logit[0][0]);      // softplus' = sigmoid
+            bf16x8 dzo[1][1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dzo[0][0][j] = (__bf16)0.f;
+            dzo[0][0][0] = (__bf16)g;
+            {
+                FeatStore f4 = relaunder(fs);
+                f4.roff = fs.roff + (h ? (unsigned)(4 * fs.ld2) : 0u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st16(f4, kOffDZo + r, dzo[0][0][r]);
+            }
+            // ---- dgrad chain
+            bf16x8 dz3[8][1], dz2[8][1], dz1[8][1], dz0[8][1];
+            static_for<0, 4>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                f32x16 acc[1];
+                tile_init<1, 0, (t == 3 ? 2 : 1), kNW>(
+                    ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dzo, dzo, acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = (float)h3[2 * t + (r >> 3)][0][r & 7];
+                    dz3[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
+                }
+            });
+            store_hidden<8>(fs, kOffDZ + 384, h, dz3);
+            f32x16 dx[1];  // gradient w.r.t. the 32 input slots of this lane's half
+            tile_init<8, 0, 2, kNW>(ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dz3, dz3, dx);   // W3[128:, :] dZ3
+            dgrad_layer<8, 2, 2>(ws, tid, dz3, h2, dz2);
+            store_hidden<8>(fs, kOffDZ + 256, h, dz2);
+            dgrad_layer<8, 2, 2>(ws, tid, dz2, h1, dz1);
+            store_hidden<8>(fs, kOffDZ + 128, h, dz1);
+            dgrad_layer<8, 2, 2>(ws, tid, dz1, h0, dz0);
+            store_hidden<8>(fs, kOffDZ + 0, h, dz0);
+            tile_init<8, 0, 1, kNW>(ws, tid, [&](f32x16(&a)[1]) {}, dz0, dz0, dx);                     // += W0 dZ0
+            if (valid) {   // d z: slot (k-step 0, elem 7) of half 1 holds z_0, k-step 1 elem j of half hh holds z_{1+2j+hh}
+                float* dzr = out_or_dz + row * z_dim;
+                if (h == 1) dzr[0] = dx[0][7];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (1 + 2 * j + h < z_dim) dzr[1 + 2 * j + h] = dx[0][8 + j];
+            }
+        }
+    }
+}
+
 }  // namespace brdfbwd
 }  // namespace nfx
 
@@ -211,5 +353,25 @@ int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* no
     hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
                        z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, d_z, d_normal);
     return (int)hipGetLastError();
+}
+int nfx_brdf_rows_feats(void) { return nfx::brdfbwd::kRowFeats; }
+// bwd = 0: out_or_dz = out[rows]; bwd = 1: out_or_dz = d_z[rows, z_dim], wsp = feature-major workspace [kRowFeats][ld]
+int nfx_launch_brdf_rows(int bwd, const float* z, int z_dim, const float* rusink, long long n, long long rows,
+                         const void* blob, const float* dout, float* out_or_dz, void* wsp, long long ld,
+                         int max_blocks, hipStream_t st) {
+    using namespace nfx;
+    if (rows <= 0) return 0;
+    const long long tiles = (rows + brdfbwd::kRows - 1) / brdfbwd::kRows;
+    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
+    const int lds = 2 * kSlotBytes + m128::kMainBiasFloats * 4;
+    auto launch = [&](auto k) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, z, z_dim, rusink, n, rows,
+                           (const char*)blob, dout, out_or_dz, (__bf16*)wsp, ld);
+        return (int)hipGetLastError();
+    };
+    return bwd ? launch(brdfbwd::brdf_rows_kernel<true>) : launch(brdfbwd::brdf_rows_kernel<false>);
 }
 }

@@ -400,6 +400,76 @@ int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, c
                           "brdf_spec_bwd");
 }
 
+// ---------------------------------------------------------------- the BRDF prior on explicit rows (f-4)
+int nfx_brdf_rows_feats(void);
+int nfx_launch_brdf_rows(int, const float*, int, const float*, long long, long long, const void*, const float*, float*,
+                         void*, long long, int, hipStream_t);
+
+static void brdf_rows_wgrad_calls(int z_dim, nfx_wgrad_call (&calls)[6]) {
+    const int ind = z_dim + 15;
+    const int dims[6][2] = {{ind, 128}, {128, 128}, {128, 128}, {128, 128}, {ind, 128}, {128, 1}};
+    for (int i = 0; i < 6; ++i) calls[i] = nfx_wgrad_call{nullptr, nullptr, dims[i][0], dims[i][1], nullptr, nullptr};
+}
+static long long brdf_rows_ld(int64_t rows) { return (rows + 127) / 128 * 128; }
+static size_t brdf_rows_feat_bytes(int64_t rows) {
+    return ((size_t)nfx_brdf_rows_feats() * brdf_rows_ld(rows) * 2 + 255) / 256 * 256;
+}
+
+int nfx_brdf_rows_fwd(const float* z, int z_dim, const float* rusink, int64_t n, int reci, const void* blob, int prec,
+                      float* out, void* stream) {
+    REQUIRE(n >= 0, "nfx_brdf_rows_fwd: n < 0");
+    REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_rows_fwd: z_dim %d unsupported", z_dim);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_rows_fwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(z && rusink && blob && out, "nfx_brdf_rows_fwd: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_rows_fwd: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_brdf_rows(0, z, z_dim, rusink, n, reci ? 2 * n : n, blob, nullptr, out, nullptr, 0,
+                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                          "brdf_rows_fwd");
+}
+
+size_t nfx_brdf_rows_bwd_workspace_bytes(int z_dim, int64_t n, int reci) {
+    if (n <= 0 || z_dim < 1 || z_dim > nfx::m128::kMaxZDim) return 0;
+    const int64_t rows = reci ? 2 * n : n;
+    nfx_wgrad_call calls[6];
+    brdf_rows_wgrad_calls(z_dim, calls);
+    return brdf_rows_feat_bytes(rows) + nfx_wgrad_partial_bytes(calls, 6, (rows + 15) / 16 * 16);
+}
+
+int nfx_brdf_rows_bwd(const float* z, int z_dim, const float* rusink, int64_t n, int reci, const void* blob, int prec,
+                      const float* dout, void* workspace, size_t workspace_bytes, float* d_z,
+                      float* const dkernels[5], float* const dbiases[5], void* stream) {
+    REQUIRE(n >= 0, "nfx_brdf_rows_bwd: n < 0");
+    REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_rows_bwd: z_dim %d unsupported", z_dim);
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_rows_bwd: only bf16 is built");
+    if (n == 0) return NFX_OK;
+    REQUIRE(z && rusink && blob && dout && workspace && d_z && dkernels && dbiases, "nfx_brdf_rows_bwd: null pointer");
+    for (int i = 0; i < 5; ++i) REQUIRE(dkernels[i] && dbiases[i], "nfx_brdf_rows_bwd: gradient buffer %d null", i);
+    REQUIRE(workspace_bytes >= nfx_brdf_rows_bwd_workspace_bytes(z_dim, n, reci), "nfx_brdf_rows_bwd: workspace too small");
+    if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_brdf_rows_bwd: blob and workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = reci ? 2 * n : n;
+    const long long ld = brdf_rows_ld(rows), rows16 = (rows + 15) / 16 * 16;
+    int rc = nfx_hip_result(nfx_launch_brdf_rows(1, z, z_dim, rusink, n, rows, blob, dout, d_z, workspace, ld,
+                                                 nfx_env_int("NFX_M128_BLOCKS", 256), st), "brdf_rows_bwd");
+    if (rc) return rc;
+    const int ind = z_dim + 15;
+    const char* ws = static_cast<const char*>(workspace);
+    auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
+    const int oH = 32, oDZ = 32 + 512, oDZo = 32 + 1024;
+    const nfx_wgrad_call calls[6] = {
+        {feat(0), feat(oDZ + 0), ind, 128, dkernels[0], dbiases[0]},
+        {feat(oH + 0), feat(oDZ + 128), 128, 128, dkernels[1], dbiases[1]},
+        {feat(oH + 128), feat(oDZ + 256), 128, 128, dkernels[2], dbiases[2]},
+        {feat(oH + 256), feat(oDZ + 384), 128, 128, dkernels[3], dbiases[3]},
+        {feat(0), feat(oDZ + 384), ind, 128, dkernels[3] + 128 * 128, nullptr},
+        {feat(oH + 384), feat(oDZo), 128, 1, dkernels[4], dbiases[4]},
+    };
+    void* partial = static_cast<char*>(workspace) + brdf_rows_feat_bytes(rows);
+    return nfx_hip_result(nfx_launch_wgrad_batch(calls, 6, ld, rows16, partial, st), "wgrad");
+}
+
 int nfx_launch_shade_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float,
                          float, const float*, const float*, const float*, const float*, long long, int, int,
                          const float*, float*, float*, float*, float*, float*, float*, hipStream_t);

@@ -1,12 +1,13 @@
 """models.brdf.Model — the MERL BRDF prior: a latent-code-conditioned MLP on Rusinkiewicz
 coordinates (reference: nerfactor/models/brdf.py:34-136).  NeRFactor evaluates its frozen
 `brdf_mlp`/`brdf_out` per (surface point, light) inside nfx_brdf_spec_fwd; this class owns the
-weights, the latent codes and the config surface."""
+weights, the latent codes and the config surface, and trains on the same fused template (row f-4)."""
 from os.path import basename
 import glob
 
 import torch
 
+from ... import autograd as nfx_grad, ops
 from ..networks import mlp
 from ..networks.embedder import Embedder
 from ..networks.layers import LatentCode
@@ -54,22 +55,35 @@ class Model(BaseModel):
         return {'rusink': Embedder(incl_input=True, in_dims=3, log2_max_freq=n_freqs - 1,
                                    n_freqs=n_freqs)}
 
+    def _train_blob(self):
+        """Forward + dgrad + input-gradient fragments of the prior (cached, re-packed on the device after a step)."""
+        ks, bs = self.net['brdf_mlp'].kernels_and_biases()
+        ko, bo = self.net['brdf_out'].kernels_and_biases()
+        return self._packed('brdf_rows' + self.precision, ks + ko + bs + bo,
+                            lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=self.precision))
+
     def _eval_brdf_at(self, z, rusink):
-        """Explicit-row evaluation (z [M, z_dim], rusink [M, 3]) -> (brdf, brdf_reci) [M, 1]; plain
-        torch (the MERL prior is trained once, off the per-ray hot path — SURVEY.md §8f-4)."""
-        body, head = self.net['brdf_mlp'], self.net['brdf_out']
-        emb = self.embedder['rusink']
-        brdf = head(body(torch.cat((z, emb(rusink)), 1)))
-        reci = torch.cat((rusink[:, :1] + torch.pi, rusink[:, 1:]), 1)  # reciprocity: phi_d + pi
-        brdf_reci = head(body(torch.cat((z, emb(reci)), 1)))
-        return brdf, brdf_reci
+        """Explicit-row evaluation (z [M, z_dim], rusink [M, 3]) -> (brdf, brdf_reci) [M, 1] (brdf.py:57-66, 101-106):
+        one fused libnfx launch for both halves (nfx_brdf_rows_fwd); under autograd the backward is one
+        nfx_brdf_rows_bwd (dgrad chain, d z, weight-gradient GEMMs).  `mlp_chunk` is not needed: nothing of size
+        M x width is materialised in the forward."""
+        ks, bs = self.net['brdf_mlp'].kernels_and_biases()
+        ko, bo = self.net['brdf_out'].kernels_and_biases()
+        params = tuple(ks + ko) + tuple(bs + bo)
+        z, rusink = z.float().contiguous(), rusink.float().contiguous()
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params)):
+            brdf, reci = nfx_grad.BrdfRows.apply(z, rusink, self._train_blob, self.precision, *params)
+        else:
+            out = ops.brdf_rows_fwd(z, rusink, self._train_blob(), reci=True, prec=self.precision)
+            brdf, reci = out[:z.shape[0]], out[z.shape[0]:]
+        return brdf[:, None], reci[:, None]
 
     # ------------------------------------------------------------------ training of the prior (brdf.py:87-136)
     def call(self, batch, mode='train'):
-        """batch = (id_, i, envmap_h, ims, spp, rusink[N,3], refl[N,1]) of datasets/brdf_merl.py.  The prior is a
-        128-wide MLP on 18 inputs trained once on the MERL tables, off the per-ray hot path: it runs in torch
-        (autograd) under the same driver / optimizer kernel; NeRFactor evaluates and differentiates the frozen
-        prior through libnfx (nfx_brdf_spec_fwd / nfx_brdf_spec_bwd)."""
+        """batch = (id_, i, envmap_h, ims, spp, rusink[N,3], refl[N,1]) of datasets/brdf_merl.py.  The 18-input
+        128-wide MLP runs — forward, backward and weight gradients — on the fused width-128 template of libnfx
+        (nfx_brdf_rows_fwd / nfx_brdf_rows_bwd), like the surface MLPs; the latent codes get their gradient from the
+        kernel's d z through the gather below."""
         self._validate_mode(mode)
         if mode != 'train' and torch.is_grad_enabled():
             with torch.no_grad():
@@ -83,10 +97,7 @@ class Model(BaseModel):
             z = z.reshape(1, -1).expand(rusink.shape[0], -1)
         else:
             z = self.latent_code(i)
-        chunks = [self._eval_brdf_at(z[lo:lo + self.mlp_chunk], rusink[lo:lo + self.mlp_chunk])
-                  for lo in range(0, rusink.shape[0], self.mlp_chunk)]
-        brdf = torch.cat([c[0] for c in chunks], 0)
-        brdf_reci = torch.cat([c[1] for c in chunks], 0)
+        brdf, brdf_reci = self._eval_brdf_at(z, rusink)
         pred = {'brdf': brdf, 'brdf_reci': brdf_reci}
         gt = {'brdf': refl}
         to_vis = {'id': id_, 'i': i, 'z': z, 'gt_brdf': refl, 'envmap_h': envmap_h, 'ims': ims, 'spp': spp}

@@ -504,3 +504,35 @@ def brdf_spec_bwd(xyz, cam, normal, z, lxyz, blob, dspec, prec='bf16'):
                                 _ptr(z), z.shape[1], _ptr(lxyz), nl, _ptr(blob), _PREC[prec], n, _ptr(dspec),
                                 _ptr(d_z), _ptr(d_normal), _stream()), 'nfx_brdf_spec_bwd')
     return d_z, d_normal
+
+
+def brdf_rows_fwd(z, rusink, blob, reci=True, prec='bf16'):
+    """The BRDF prior on explicit rows: out[n] (reci=False) or out[2n] (rows n.. = the same inputs at phi_d + pi) =
+    softplus(out(mlp([z, posenc2(rusink)]))).  `blob` = pack_brdf_train_weights(...)."""
+    z = _dev(z, 'z', (None, None))
+    n = z.shape[0]
+    rusink = _dev(rusink, 'rusink', (n, 3))
+    out = torch.empty(((2 if reci else 1) * n,), dtype=torch.float32, device=z.device)
+    check(lib.nfx_brdf_rows_fwd(_ptr(z), z.shape[1], _ptr(rusink), n, int(bool(reci)), _ptr(blob), _PREC[prec],
+                                _ptr(out), _stream()), 'nfx_brdf_rows_fwd')
+    return out
+
+
+def brdf_rows_bwd(z, rusink, blob, dout, dkernels, dbiases, reci=True, prec='bf16'):
+    """d_z[rows, z_dim] (per row: sum the two halves for the gradient of z[n]) from dout[rows]; ACCUMULATES the weight
+    gradients into `dkernels` / `dbiases` (5 fp32 CUDA tensors each, Keras layout)."""
+    z = _dev(z, 'z', (None, None))
+    n, zd = z.shape
+    rows = (2 if reci else 1) * n
+    rusink = _dev(rusink, 'rusink', (n, 3))
+    dout = _dev(dout.reshape(rows), 'dout', (rows,))
+    for t in list(dkernels) + list(dbiases):
+        _dev(t, 'gradient buffer')
+    d_z = torch.empty((rows, zd), dtype=torch.float32, device=z.device)
+    ws_bytes = lib.nfx_brdf_rows_bwd_workspace_bytes(zd, n, int(bool(reci)))
+    ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=z.device)
+    karr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dkernels])
+    barr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dbiases])
+    check(lib.nfx_brdf_rows_bwd(_ptr(z), zd, _ptr(rusink), n, int(bool(reci)), _ptr(blob), _PREC[prec], _ptr(dout),
+                                _ptr(ws), ws.numel() * 2, _ptr(d_z), karr, barr, _stream()), 'nfx_brdf_rows_bwd')
+    return d_z

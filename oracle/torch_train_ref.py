@@ -275,6 +275,19 @@ def nerfactor_loss(P, batch, xyz_noise, lxyz, lareas, hp, variant='microfacet', 
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+def brdf_prior_loss(P, ind, rusink, refl):
+    """models/brdf.py:87-136 in train mode with loss = l2 on log reflectance (config/brdf.ini), keep_batch=True
+    (trainvali.py:280): per row (log refl - log brdf)^2 + (log refl - log brdf_reci)^2, brdf_reci at phi_d + pi.
+    P holds net_brdf_{mlp,out}_layer*.{kernel,bias} and the latent table 'latent_code._z' [n_brdfs, z_dim]."""
+    z = P['latent_code._z'][ind.long()]          # tf.gather_nd of the variable: scatter-add gradient
+    def run(r):
+        return mlp128(torch.cat((z, embed(r, 2)), 1), P, 'brdf', 'softplus')
+    reci = torch.cat((rusink[:, :1] + math.pi, rusink[:, 1:]), 1)
+    brdf, brdf_reci = run(rusink), run(reci)
+    lg = torch.log(refl)
+    return ((lg - torch.log(brdf)) ** 2).mean(1) + ((lg - torch.log(brdf_reci)) ** 2).mean(1)
+
+
 class KerasAMSGrad:
     """tf.keras.optimizers.Adam(learning_rate = lr | ExponentialDecay(lr, decay_steps, decay_rate), amsgrad=True) on a
     dict of tensors: t = iterations + 1, lr_t = lr(iterations) sqrt(1 - b2^t) / (1 - b1^t), epsilon 1e-7 outside the

@@ -2,7 +2,7 @@
 
     python tests/golden/make_reference_grad_golden.py        (build container only: needs /root/reference)
 
-The reference's unmodified nerfactor/models/{nerf,nerfactor_microfacet,nerfactor}.py run on tests/golden/tf_shim_torch
+The reference's unmodified nerfactor/models/{nerf,nerfactor_microfacet,nerfactor,brdf}.py run on tests/golden/tf_shim_torch
 (the TensorFlow calls they make, implemented on torch-CPU tensors), so `tf.GradientTape().gradient` is reverse-mode
 autodiff through the reference's own Python — including its tf.custom_gradient backward functions
 (nerfactor/util/math.py:24-60: safe_acos, safe_atan2), its tf.stop_gradient on the fine samples (models/nerf.py:143),
@@ -39,6 +39,7 @@ from nerfactor.util import io as ioutil  # noqa: E402
 from nerfactor.models.nerf import Model as NerfModel  # noqa: E402
 from nerfactor.models.nerfactor import Model as NerfactorModel  # noqa: E402
 from nerfactor.models.nerfactor_microfacet import Model as MicrofacetModel  # noqa: E402
+from nerfactor.models.brdf import Model as BrdfModel  # noqa: E402
 
 from tests import common  # noqa: E402
 from tests.golden import golden_inputs as gi  # noqa: E402
@@ -88,6 +89,9 @@ def named_variables(model):
     light = getattr(model, '_light', None)
     if light is not None and any(v is light for v in model.trainable_variables):
         out['_light'] = light
+    code = getattr(model, 'latent_code', None)
+    if code is not None and any(v is code._z for v in model.trainable_variables):
+        out['latent_code._z'] = code._z
     assert len(out) == len(model.trainable_variables), (len(out), len(model.trainable_variables))
     return out
 
@@ -226,12 +230,34 @@ def run_nerfactor(tmp, learned):
     train(tag, model, batch, n, cfg)
 
 
+# ------------------------------------------------------------------------------------------------ BRDF prior
+def run_brdf(tmp):
+    """models/brdf.py:87-136 on the 192 (identity, Rusinkiewicz, reflectance) rows of golden_inputs.brdf_batch():
+    gradients of the MLP and of the latent codes (tf.gather_nd of a variable), loss on log reflectance."""
+    root = os.path.join(tmp, 'merl_npz')
+    os.makedirs(root)
+    for name in gi.BRDF_NAMES:
+        open(os.path.join(root, 'train_%s.npz' % name), 'wb').close()
+    cfg = ref_config('brdf.ini', data_root=root)
+    model = BrdfModel(cfg)
+    bnet = gi.brdf_net()
+    set_layers(model.net['brdf_mlp'], bnet['brdf_mlp'])
+    set_layers(model.net['brdf_out'], bnet['brdf_out'])
+    model.latent_code.z = gi.latent_codes()
+    i, rusink, refl = gi.brdf_batch()
+    n = rusink.shape[0]
+    batch = (np.array([b'x'] * n), tf.convert_to_tensor(i), None, None, None,
+             tf.convert_to_tensor(rusink), tf.convert_to_tensor(refl))
+    train('brdf', model, batch, n, cfg)
+
+
 def main():
     tf.random.set_seed(11)
     run_nerf()
     with tempfile.TemporaryDirectory() as tmp:
         run_nerfactor(os.path.join(tmp, 'a'), learned=False)
         run_nerfactor(os.path.join(tmp, 'b'), learned=True)
+        run_brdf(os.path.join(tmp, 'c'))
     path = os.path.join(HERE, 'reference_grads.npz')
     np.savez_compressed(path, **OUT)
     print('wrote %s (%.1f KiB, %d arrays)' % (path, os.path.getsize(path) / 1024, len(OUT)))

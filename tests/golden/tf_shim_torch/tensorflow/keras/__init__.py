@@ -19,6 +19,9 @@ def _collect(obj, out, seen, only_trainable):
         if obj.trainable or not only_trainable:
             for v in obj.variables():
                 _collect(v, out, seen, only_trainable)
+            for v in obj.__dict__.values():     # Keras tracks variables assigned as attributes (layers.LatentCode._z)
+                if isinstance(v, _torch.Tensor):
+                    _collect(v, out, seen, only_trainable)
     elif isinstance(obj, (Model, Sequential)):
         if getattr(obj, 'trainable', True) or not only_trainable:
             for v in obj.__dict__.values():

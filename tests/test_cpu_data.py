@@ -171,7 +171,7 @@ def test_shard_and_ragged_gather_two_ranks():
 
 
 def test_brdf_merl_dataset_and_prior_model_on_cpu(tmp_path):
-    """datasets/brdf_merl.py + models/brdf.py call / compute_loss (plain torch: the prior is off the hot path)."""
+    """datasets/brdf_merl.py batches and the construction of models/brdf.py (its call needs the GPU: tests/test_gpu_train.py)."""
     from nerfactor_amd.nerfactor.models import get_model_class
     root = str(tmp_path / 'merl')
     names = synth_scene.write_merl(root)
@@ -190,20 +190,13 @@ def test_brdf_merl_dataset_and_prior_model_on_cpu(tmp_path):
     torch.manual_seed(0)
     model = get_model_class('brdf')(cfg)
     assert model.brdf_names == sorted(names) and model.latent_code.z.shape == (3, 3)
-    pred, gt, kw, to_vis = model(batches[0], mode='train')
-    loss = model.compute_loss(pred, gt, keep_batch=True, **kw)
-    assert loss.shape == (64,) and torch.isfinite(loss).all() and (pred['brdf'] > 0).all()
-    loss.sum().backward()
-    assert model.latent_code._z.grad is not None and float(model.latent_code._z.grad.abs().sum()) > 0
-    # reciprocity branch: phi_d + pi
-    b2, _ = model._eval_brdf_at(model.latent_code(batches[0][1]),
-                                torch.cat((batches[0][5][:, :1] + torch.pi, batches[0][5][:, 1:]), 1))
-    assert torch.allclose(b2, pred['brdf_reci'], atol=1e-6)
-    # interpolated identity at test time: z = w1 z1 + w2 z2
+    # the prior runs on the fused width-128 template of libnfx (row f-4): there is no CPU path, it fails loudly
+    from nerfactor_amd._capi import NfxError
+    with pytest.raises((NfxError, RuntimeError)):
+        model(batches[0], mode='train')
+    # interpolated identities of the test split parse back into (material, weight) pairs
     tb = [b for b in te.build_pipeline(no_batch=True, no_shuffle=True)][4]
     assert int(tb[1][0]) == -1
     _, w1, rest = tb[0][0].split('_', 2)
     m1, w2, m2 = model._split_interp_id(rest)
-    p2, _, _, vis = model(tb, mode='test')
-    want = float(w1) * model.latent_code.z[model.brdf_names.index(m1)] + float(w2) * model.latent_code.z[model.brdf_names.index(m2)]
-    assert torch.allclose(vis['z'][0], want, atol=1e-6) and p2['brdf'].shape == (512, 1)
+    assert m1 in names and m2 in names and abs(float(w1) + float(w2) - 1) < 1e-6

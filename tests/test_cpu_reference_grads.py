@@ -157,12 +157,39 @@ def test_nerfactor_train_step_matches_the_reference(tag, dtype):
     check(tag, None, losses, grad1, snaps, 5e-3, 3e-3 if dtype == torch.float32 else 1e-3, list(P))
 
 
+def brdf_params(dtype):
+    P = {}
+    for part, pairs in gi.brdf_net().items():
+        for i, (k, b) in enumerate(pairs):
+            P['net_%s_layer%d.kernel' % (part, i)] = torch.tensor(k, dtype=dtype, requires_grad=True)
+            P['net_%s_layer%d.bias' % (part, i)] = torch.tensor(b, dtype=dtype, requires_grad=True)
+    P['latent_code._z'] = torch.tensor(gi.latent_codes(), dtype=dtype, requires_grad=True)
+    return P
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_brdf_prior_train_step_matches_the_reference(dtype):
+    """Row f-4: models/brdf.py trained by trainvali.py's step — MLP and latent-code gradients, 10 Adam(amsgrad) steps."""
+    P = brdf_params(dtype)
+    ind, rusink, refl = gi.brdf_batch()
+    ind, rusink, refl = torch.tensor(ind), torch.tensor(rusink, dtype=dtype), torch.tensor(refl, dtype=dtype)
+    assert int(FIX['brdf/draws_per_step_normal']) == 0 and int(FIX['brdf/draws_per_step_uniform']) == 0
+    losses, grad1, snaps = run_steps('brdf', P, lambda P, step: T.brdf_prior_loss(P, ind, rusink, refl), 1e-2,
+                                     rusink.shape[0])
+    check('brdf', None, losses, grad1, snaps, 1e-2, 2e-3 if dtype == torch.float32 else 1e-3, list(P))
+
+
 def oracle_first_step_grads(tag, quant=False, dtype=torch.float64):
     """Gradient of every trainable tensor at step 1 from the oracle, optionally with the bf16 operand rounding of the
     MFMA path in every Dense layer (straight-through) — what a bf16 forward can at best agree with."""
     T.QUANT = T.bf16_ste if quant else None
     try:
-        if tag == 'nerf':
+        if tag == 'brdf':
+            P = brdf_params(dtype)
+            ind, rusink, refl = gi.brdf_batch()
+            per_ray = T.brdf_prior_loss(P, torch.tensor(ind), torch.tensor(rusink, dtype=dtype),
+                                        torch.tensor(refl, dtype=dtype))
+        elif tag == 'nerf':
             P = nerf_params(dtype)
             rayo, rayd, gt = (torch.tensor(a[:gi.GRAD_NERF_RAYS], dtype=dtype) for a in gi.nerf_rays())
             u = [torch.tensor(FIX['nerf/uniform_%03d' % i], dtype=dtype) for i in range(2)]

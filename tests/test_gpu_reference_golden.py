@@ -122,10 +122,11 @@ def test_brdf_prior_plugin_vs_reference_outputs(nfx_lib, cuda, tmp_path):
     n = rusink.shape[0]
     batch = (['x'] * n, torch.from_numpy(i).to(cuda), None, None, None, dev(rusink, cuda), dev(refl, cuda))
     pred, gt, kw, to_vis = model(batch, mode='vali')
-    np.testing.assert_allclose(pred['brdf'].cpu().numpy(), GOLD['brdf_pred'], rtol=1e-4)
-    np.testing.assert_allclose(pred['brdf_reci'].cpu().numpy(), GOLD['brdf_pred_reci'], rtol=1e-4)
+    # fused bf16 template (nfx_brdf_rows_fwd): bf16 operand rounding of an 18 -> 128 x 4 -> 1 softplus MLP
+    np.testing.assert_allclose(pred['brdf'].cpu().numpy(), GOLD['brdf_pred'], rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(pred['brdf_reci'].cpu().numpy(), GOLD['brdf_pred_reci'], rtol=2e-2, atol=2e-3)
     np.testing.assert_array_equal(to_vis['z'].cpu().numpy(), GOLD['brdf_z'])
-    np.testing.assert_allclose(float(model.compute_loss(pred, gt, **kw)), float(GOLD['brdf_loss']), rtol=1e-4)
+    np.testing.assert_allclose(float(model.compute_loss(pred, gt, **kw)), float(GOLD['brdf_loss']), rtol=2e-2)
     np.testing.assert_allclose(model.latent_code.interp(0.25, 0, 0.75, 2).detach().cpu().numpy(),
                                GOLD['brdf_interp'], rtol=1e-6)
 
