@@ -288,6 +288,31 @@ int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_
                      int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                      void *stream);
 
+/* The per-ray training losses of the surface models (nerfactor.py:463-541, shape.py:239-277 `compute_loss`) as one
+ * launch: loss[ray] = sum_t w_t * mean_d f_t(A_t[ray, d] - B_t[ray, d]), f = square (keras MSE) or abs (MAE), A / B
+ * optionally alpha-blended onto the background first (util/img.py:alpha_blend: x * alpha + bg * (1 - alpha)).
+ * nfx_pair_loss_bwd: given dev_dloss[n] writes d loss / d A into term.ga and d loss / d B into term.gb where those
+ * are non-NULL (NFX_LOSS_ACCUM_*: add to what an earlier term of the SAME call wrote — a tensor used in two terms). */
+#define NFX_LOSS_MAX_TERMS 8
+#define NFX_LOSS_MSE 0
+#define NFX_LOSS_MAE 1
+#define NFX_LOSS_BLEND_A 1
+#define NFX_LOSS_BLEND_B 2
+#define NFX_LOSS_ACCUM_A 4
+#define NFX_LOSS_ACCUM_B 8
+typedef struct nfx_loss_term {
+    const float *a, *b; /* [n, d] each */
+    float *ga, *gb;     /* backward outputs [n, d] or NULL */
+    int d;
+    float w;
+    int kind;  /* NFX_LOSS_MSE | NFX_LOSS_MAE */
+    int flags; /* NFX_LOSS_BLEND_* | NFX_LOSS_ACCUM_* */
+} nfx_loss_term;
+int nfx_pair_loss_fwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
+                      float *dev_loss, void *stream);
+int nfx_pair_loss_bwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
+                      const float *dev_dloss, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Geometry extraction from a trained NeRF (geometry_from_nerf.py:177-350).   */
 /* ------------------------------------------------------------------------ */

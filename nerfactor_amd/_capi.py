@@ -70,6 +70,8 @@ SIGNATURES = {
     'nfx_brdf_rows_bwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p, _sz, _p, _pp, _pp, _p]),
     'nfx_shade_bwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p,
                            _p, _p]),
+    'nfx_pair_loss_fwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
+    'nfx_pair_loss_bwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
     'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),
     'nfx_amsgrad_step': (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _i64, _p]),
     'nfx_nerf_sigma_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),

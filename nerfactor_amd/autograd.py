@@ -194,3 +194,41 @@ class Composite(torch.autograd.Function):
         rgbs, z, rayd, noise = ctx.saved_tensors
         d_rgbs = ops.composite_bwd(rgbs, z, rayd, d_rgb.contiguous(), white_bg=ctx.white_bg, noise=noise)
         return d_rgbs, None, None, None, None, None
+
+
+class PairLoss(torch.autograd.Function):
+    """Per-ray weighted sum of MSE / MAE terms between (optionally alpha-blended) tensor pairs — the surface models'
+    compute_loss (nerfactor.py:463-541, shape.py:239-277) as one forward and one backward launch.
+
+    spec = ((ia, ib, weight, kind, blend_a, blend_b), ...) indexes into `tensors`; a tensor may appear in several
+    terms (its gradient is accumulated inside the kernel, in term order)."""
+
+    @staticmethod
+    def forward(ctx, alpha, bg, spec, *tensors):
+        tensors = tuple(t.contiguous() for t in tensors)
+        terms = [(tensors[ia], tensors[ib], w, kind, ba, bb) for ia, ib, w, kind, ba, bb in spec]
+        ctx.save_for_backward(alpha, *tensors)
+        ctx.bg, ctx.spec = bg, spec
+        return ops.pair_loss_fwd(terms, alpha=alpha, bg=bg)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        alpha, *tensors = ctx.saved_tensors
+        need = ctx.needs_input_grad[3:]
+        bufs = [torch.empty_like(t) if nd else None for t, nd in zip(tensors, need)]
+        written = [False] * len(tensors)
+        terms, grads = [], []
+        for ia, ib, w, kind, ba, bb in ctx.spec:
+            if bufs[ia] is None and bufs[ib] is None:
+                continue
+            terms.append((tensors[ia], tensors[ib], w, kind, ba, bb))
+            if ia == ib:
+                raise ValueError("PairLoss: a term needs two different tensors")
+            grads.append((bufs[ia], bufs[ib], written[ia], written[ib]))
+            written[ia] = written[ia] or bufs[ia] is not None
+            written[ib] = written[ib] or bufs[ib] is not None
+        if terms:
+            ops.pair_loss_bwd(terms, grads, dloss.contiguous(), alpha=alpha, bg=ctx.bg)
+        # a tensor that needs a gradient but is in no term (cannot happen through the models) gets zeros
+        out = [b if (b is None or wr) else torch.zeros_like(b) for b, wr in zip(bufs, written)]
+        return (None, None, None) + tuple(out)

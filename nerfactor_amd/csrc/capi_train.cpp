@@ -492,6 +492,37 @@ int nfx_shade_bwd(const float* xyz, const float* cam, const float* normal, const
                           "shade_bwd");
 }
 
+int nfx_launch_pair_loss(int, const nfx_loss_term*, int, const float*, float, long long, float*, const float*,
+                         hipStream_t);
+static int pair_loss_check(const char* who, const nfx_loss_term* terms, int n_terms, int64_t n, bool bwd) {
+    REQUIRE(n >= 0, "%s: n < 0", who);
+    REQUIRE(terms && n_terms >= 1 && n_terms <= NFX_LOSS_MAX_TERMS, "%s: 1..%d terms", who, NFX_LOSS_MAX_TERMS);
+    for (int i = 0; i < n_terms; ++i) {
+        REQUIRE(terms[i].a && terms[i].b && terms[i].d >= 1, "%s: term %d has a null operand or d < 1", who, i);
+        REQUIRE(terms[i].kind == NFX_LOSS_MSE || terms[i].kind == NFX_LOSS_MAE, "%s: term %d: unknown kind", who, i);
+        if (!bwd) continue;
+        REQUIRE(!(terms[i].flags & NFX_LOSS_ACCUM_A) || terms[i].ga, "%s: term %d accumulates into a null ga", who, i);
+        REQUIRE(!(terms[i].flags & NFX_LOSS_ACCUM_B) || terms[i].gb, "%s: term %d accumulates into a null gb", who, i);
+    }
+    return NFX_OK;
+}
+int nfx_pair_loss_fwd(const nfx_loss_term* terms, int n_terms, const float* alpha, float bg, int64_t n, float* loss,
+                      void* stream) {
+    if (int rc = pair_loss_check("nfx_pair_loss_fwd", terms, n_terms, n, false)) return rc;
+    if (n == 0) return NFX_OK;
+    REQUIRE(loss, "nfx_pair_loss_fwd: null output");
+    return nfx_hip_result(nfx_launch_pair_loss(0, terms, n_terms, alpha, bg, n, loss, nullptr, (hipStream_t)stream),
+                          "pair_loss_fwd");
+}
+int nfx_pair_loss_bwd(const nfx_loss_term* terms, int n_terms, const float* alpha, float bg, int64_t n,
+                      const float* dloss, void* stream) {
+    if (int rc = pair_loss_check("nfx_pair_loss_bwd", terms, n_terms, n, true)) return rc;
+    if (n == 0) return NFX_OK;
+    REQUIRE(dloss, "nfx_pair_loss_bwd: null dloss");
+    return nfx_hip_result(nfx_launch_pair_loss(1, terms, n_terms, alpha, bg, n, nullptr, dloss, (hipStream_t)stream),
+                          "pair_loss_bwd");
+}
+
 int nfx_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, int64_t n, float lr, float beta1,
                      float beta2, float eps, int64_t step, void* stream) {
     REQUIRE(n >= 0 && step >= 1, "nfx_amsgrad_step: bad n/step");

@@ -10,6 +10,17 @@ import numpy as np
 from .nerf import Dataset as NeRFDataset, load_rgba, resize
 
 
+
+def mark_all_foreground(alpha):
+    """Tags an alpha tensor whose rays are all known (on the host) to be foreground."""
+    alpha._nfx_all_foreground = True
+    return alpha
+
+
+def known_all_foreground(alpha):
+    return bool(getattr(alpha, '_nfx_all_foreground', False))
+
+
 class Dataset(NeRFDataset):
     def __init__(self, config, mode, debug=False, always_all_rays=False, device='cuda'):
         self.meta2buf = {}
@@ -77,4 +88,14 @@ class Dataset(NeRFDataset):
             return arrs
         cand = np.arange(arrs[3].shape[0]) if alpha_thres is None else np.nonzero(arrs[3][:, 0] > alpha_thres)[0]
         sel = cand[self._rng.integers(0, cand.shape[0], size=self.bs)]
+        self._drew_foreground_only = alpha_thres is not None and alpha_thres >= 0
         return tuple(a[sel] for a in arrs)
+
+    def _to_device(self, batch):
+        """Training rays are drawn from alpha > 0.9 (nerf_shape.py:102-107): the batch says so, and the models skip the
+        foreground compaction — a torch.nonzero whose row count the host would have to wait for, with the whole
+        previous step still in the launch queue — for it (models/nerfactor.py, models/shape.py)."""
+        out = super()._to_device(batch)
+        if self.__dict__.pop('_drew_foreground_only', False):
+            mark_all_foreground(out[5])
+        return out

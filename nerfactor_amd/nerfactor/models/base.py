@@ -80,8 +80,8 @@ class Model(torch.nn.Module):
     def check_numerics(self, tensor, message):
         """tf.debugging.check_numerics: raises FloatingPointError(message) on Inf / NaN.  While autograd is recording
         (a training step) the verdict stays on the device and is raised by flush_numerics() — called by
-        optim.train_step before the NEXT step and by the drivers at the end of an epoch — so that a step enqueues all
-        of its kernels without a host round trip in the middle (the GPU idled ~1.7 ms of a 5.3 ms step behind them)."""
+        optim.train_step at the start of the following steps and, blocking, by the drivers at the end of an epoch — so
+        that a step enqueues all of its kernels without a host round trip."""
         ok = torch.isfinite(tensor).all()
         if torch.is_grad_enabled():
             self.__dict__.setdefault('_pending_numerics', []).append((message, ok))
@@ -89,13 +89,32 @@ class Model(torch.nn.Module):
             raise FloatingPointError(message)
         return tensor
 
-    def flush_numerics(self):
+    def flush_numerics(self, block=False):
+        """Ships the verdicts recorded since the last call to pinned host memory (asynchronous copy + event) and raises
+        for every earlier group whose copy has landed.  Never waits for the GPU unless `block`: a blocking read of the
+        previous step's flags would make the host wait for that whole step before issuing the next one (measured:
+        1.8 ms of a 4.6 ms NeRFactor step with the GPU idle meanwhile); a NaN is reported one or two steps late."""
+        import collections
         pending = self.__dict__.get('_pending_numerics', [])
         self.__dict__['_pending_numerics'] = []
+        inflight = self.__dict__.setdefault('_numerics_inflight', collections.deque())
         if pending:
-            flags = torch.stack([ok for _, ok in pending]).cpu()
-            for (message, _), ok in zip(pending, flags):
+            flags = torch.stack([ok for _, ok in pending])
+            if flags.is_cuda:
+                host = torch.empty(flags.shape, dtype=flags.dtype, pin_memory=True)
+                host.copy_(flags, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+            else:
+                host, event = flags, None
+            inflight.append(([m for m, _ in pending], host, event))
+        while inflight and (block or inflight[0][2] is None or inflight[0][2].query()):
+            messages, host, event = inflight.popleft()
+            if event is not None:
+                event.synchronize()
+            for message, ok in zip(messages, host):
                 if not bool(ok):
+                    inflight.clear()
                     raise FloatingPointError(message)
 
     # ------------------------------------------------------------------ packed-weight cache

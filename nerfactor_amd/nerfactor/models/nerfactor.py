@@ -17,9 +17,10 @@ from os.path import basename, join
 import numpy as np
 import torch
 
-from nerfactor_amd import _capi, ops
+from nerfactor_amd import _capi, autograd as nfx_grad, ops
 
 from .. import config as default_configs
+from ..datasets.nerf_shape import known_all_foreground
 from ..util import config as configutil, img as imgutil, light as lightutil, math as mathutil
 from .brdf import Model as BRDFModel
 from .shape import Model as ShapeModel, _mae, _mse
@@ -157,8 +158,13 @@ class Model(ShapeModel):
         xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         id_, hw, rayo, _, rgb, alpha, xyz, normal, lvis = batch
         n_all = alpha.shape[0]
-        idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped
-        all_fg = idx.numel() == n_all   # training batches are foreground rays only (datasets/nerf_shape.py:118-126):
+        # training batches are foreground rays only (datasets/nerf_shape.py:102-107) and say so: no compaction, and
+        # above all no torch.nonzero, whose row count the host can only read after the whole previous step has drained
+        if known_all_foreground(alpha):
+            idx, all_fg = None, True
+        else:
+            idx = torch.nonzero(alpha[:, 0] > 0)[:, 0]  # 100 % background rays are dropped
+            all_fg = idx.numel() == n_all
         rgb_all, normal_all, lvis_all = rgb, normal, lvis
         if not all_fg:                  # no gather here and no zero-filled scatter at the end (~40 tiny launches)
             rayo, rgb, xyz, normal = (t[idx].contiguous() for t in (rayo, rgb, xyz, normal))
@@ -365,27 +371,58 @@ class Model(ShapeModel):
         brdf_prop_jitter = kwargs.pop('brdf_prop_jitter')
         alpha = gt['alpha']
         bg = 1. if self.white_bg else 0.
+        smooth_kind = 'mae' if smooth is _mae else 'mse'
+        shape_terms = mode != 'vali' and self.shape_mode in ('scratch', 'finetune')
+        if pred['rgb'].is_cuda:
+            # one libnfx launch forward, one backward (loss.hip) instead of ~70 + ~80 elementwise torch launches
+            tensors, spec = [], []
 
-        def on_bg(x):
-            return imgutil.alpha_blend(x, alpha, torch.full_like(x, bg))
+            def slot(t):
+                for i, u in enumerate(tensors):
+                    if u is t:
+                        return i
+                tensors.append(t)
+                return len(tensors) - 1
 
-        rgb_pred, rgb_gt = on_bg(pred['rgb']), on_bg(gt['rgb'])
-        normal_pred, normal_gt = on_bg(pred['normal']), on_bg(gt['normal'])
-        lvis_pred, lvis_gt = on_bg(pred['lvis']), on_bg(gt['lvis'])
-        loss = _mse(rgb_gt, rgb_pred)
-        if mode == 'vali':
-            return loss
-        if self.shape_mode in ('scratch', 'finetune'):
-            loss = loss + normal_loss_weight * _mse(normal_gt, normal_pred)
-            loss = loss + lvis_loss_weight * _mse(lvis_gt, lvis_pred)
-            if normal_jitter is not None:
-                loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
-            if lvis_jitter is not None:
-                loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
-        if albedo_jitter is not None:
-            loss = loss + self.albedo_smooth_weight * smooth(pred['albedo'], albedo_jitter)
-        if brdf_prop_jitter is not None:
-            loss = loss + self.brdf_smooth_weight * smooth(pred['brdf'], brdf_prop_jitter)
+            def term(a, b, w, kind, blend_a, blend_b):
+                spec.append((slot(a), slot(b), float(w), kind, blend_a, blend_b))
+            term(pred['rgb'], gt['rgb'], 1., 'mse', True, True)
+            if mode != 'vali':
+                if shape_terms:
+                    term(pred['normal'], gt['normal'], normal_loss_weight, 'mse', True, True)
+                    term(pred['lvis'], gt['lvis'], lvis_loss_weight, 'mse', True, True)
+                    if normal_jitter is not None:    # the blended prediction against the raw jittered one, as upstream
+                        term(pred['normal'], normal_jitter, self.normal_smooth_weight, smooth_kind, True, False)
+                    if lvis_jitter is not None:
+                        term(pred['lvis'], lvis_jitter, self.lvis_smooth_weight, smooth_kind, True, False)
+                if albedo_jitter is not None:
+                    term(pred['albedo'], albedo_jitter, self.albedo_smooth_weight, smooth_kind, False, False)
+                if brdf_prop_jitter is not None:
+                    term(pred['brdf'], brdf_prop_jitter, self.brdf_smooth_weight, smooth_kind, False, False)
+            loss = nfx_grad.PairLoss.apply(alpha, bg, tuple(spec), *tensors)
+            if mode == 'vali':
+                return loss
+        else:   # host tensors (the loss definition in plain torch; nothing of the render path runs there)
+            def on_bg(x):
+                return imgutil.alpha_blend(x, alpha, torch.full_like(x, bg))
+
+            rgb_pred, rgb_gt = on_bg(pred['rgb']), on_bg(gt['rgb'])
+            normal_pred, normal_gt = on_bg(pred['normal']), on_bg(gt['normal'])
+            lvis_pred, lvis_gt = on_bg(pred['lvis']), on_bg(gt['lvis'])
+            loss = _mse(rgb_gt, rgb_pred)
+            if mode == 'vali':
+                return loss
+            if shape_terms:
+                loss = loss + normal_loss_weight * _mse(normal_gt, normal_pred)
+                loss = loss + lvis_loss_weight * _mse(lvis_gt, lvis_pred)
+                if normal_jitter is not None:
+                    loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
+                if lvis_jitter is not None:
+                    loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
+            if albedo_jitter is not None:
+                loss = loss + self.albedo_smooth_weight * smooth(pred['albedo'], albedo_jitter)
+            if brdf_prop_jitter is not None:
+                loss = loss + self.brdf_smooth_weight * smooth(pred['brdf'], brdf_prop_jitter)
         if mode == 'train':
             light = self.light
             if light_tv_weight > 0:

@@ -199,16 +199,28 @@ class Model(BaseModel):
         lvis_jitter = kwargs.pop('lvis_jitter')
         alpha = gt['alpha']
         bg = 1. if self.white_bg else 0.
-        normal_pred = imgutil.alpha_blend(pred['normal'], alpha, torch.full_like(gt['normal'], bg))
-        normal_gt = imgutil.alpha_blend(gt['normal'], alpha, torch.full_like(gt['normal'], bg))
-        lvis_pred = imgutil.alpha_blend(pred['lvis'], alpha, torch.full_like(gt['lvis'], bg))
-        lvis_gt = imgutil.alpha_blend(gt['lvis'], alpha, torch.full_like(gt['lvis'], bg))
-        loss = normal_loss_weight * _mse(normal_gt, normal_pred) + \
-            lvis_loss_weight * _mse(lvis_gt, lvis_pred)
-        if normal_jitter is not None:
-            loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
-        if lvis_jitter is not None:
-            loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
+        if pred['normal'].is_cuda:   # one libnfx launch forward, one backward (loss.hip)
+            kind = 'mae' if smooth is _mae else 'mse'
+            tensors = [pred['normal'], gt['normal'], pred['lvis'], gt['lvis']]
+            spec = [(0, 1, normal_loss_weight, 'mse', True, True), (2, 3, lvis_loss_weight, 'mse', True, True)]
+            if normal_jitter is not None:
+                tensors.append(normal_jitter)
+                spec.append((0, len(tensors) - 1, self.normal_smooth_weight, kind, True, False))
+            if lvis_jitter is not None:
+                tensors.append(lvis_jitter)
+                spec.append((2, len(tensors) - 1, self.lvis_smooth_weight, kind, True, False))
+            loss = nfx_grad.PairLoss.apply(alpha, bg, tuple(spec), *tensors)
+        else:                        # host tensors: the loss definition in plain torch
+            normal_pred = imgutil.alpha_blend(pred['normal'], alpha, torch.full_like(gt['normal'], bg))
+            normal_gt = imgutil.alpha_blend(gt['normal'], alpha, torch.full_like(gt['normal'], bg))
+            lvis_pred = imgutil.alpha_blend(pred['lvis'], alpha, torch.full_like(gt['lvis'], bg))
+            lvis_gt = imgutil.alpha_blend(gt['lvis'], alpha, torch.full_like(gt['lvis'], bg))
+            loss = normal_loss_weight * _mse(normal_gt, normal_pred) + \
+                lvis_loss_weight * _mse(lvis_gt, lvis_pred)
+            if normal_jitter is not None:
+                loss = loss + self.normal_smooth_weight * smooth(normal_pred, normal_jitter)
+            if lvis_jitter is not None:
+                loss = loss + self.lvis_smooth_weight * smooth(lvis_pred, lvis_jitter)
         return self.check_numerics(loss, "Loss")
 
     # ------------------------------------------------------------------ vis (raw dumps only)

@@ -252,7 +252,7 @@ def main(argv=None):
                 break
         if not batch_time:
             raise RuntimeError("Dataset is empty")
-        model.flush_numerics()   # the last step's check_numerics verdicts
+        model.flush_numerics(block=True)   # every outstanding check_numerics verdict of the epoch
         step += 1
 
         if step % ckpt_period == 0:

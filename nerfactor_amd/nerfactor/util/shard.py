@@ -14,7 +14,13 @@ def shard_batch(batch):
         return batch
     n = len(batch[0]) if batch[0] is not None else next(len(x) for x in batch if x is not None)
     lo, hi = nfx_dist.shard_range(n, rank, ws)
-    return tuple(None if x is None else x[lo:hi] for x in batch)
+
+    def part(x):
+        y = x[lo:hi]
+        if getattr(x, '_nfx_all_foreground', False):    # a slice of foreground-only rays is foreground-only
+            y._nfx_all_foreground = True
+        return y
+    return tuple(None if x is None else part(x) for x in batch)
 
 
 def shard_rows(t, n_total):

@@ -536,3 +536,52 @@ def brdf_rows_bwd(z, rusink, blob, dout, dkernels, dbiases, reci=True, prec='bf1
     check(lib.nfx_brdf_rows_bwd(_ptr(z), zd, _ptr(rusink), n, int(bool(reci)), _ptr(blob), _PREC[prec], _ptr(dout),
                                 _ptr(ws), ws.numel() * 2, _ptr(d_z), karr, barr, _stream()), 'nfx_brdf_rows_bwd')
     return d_z
+
+
+# ------------------------------------------------------------------------------ fused per-ray losses
+class _LossTerm(ctypes.Structure):   # include/nfx.h: nfx_loss_term
+    _fields_ = [('a', ctypes.c_void_p), ('b', ctypes.c_void_p), ('ga', ctypes.c_void_p), ('gb', ctypes.c_void_p),
+                ('d', ctypes.c_int), ('w', ctypes.c_float), ('kind', ctypes.c_int), ('flags', ctypes.c_int)]
+
+
+LOSS_KIND = {'mse': 0, 'mae': 1}
+LOSS_BLEND_A, LOSS_BLEND_B, LOSS_ACCUM_A, LOSS_ACCUM_B = 1, 2, 4, 8
+
+
+def _loss_table(terms, grads=None):
+    """terms: [(a, b, weight, kind, blend_a, blend_b)]; grads: per term (ga, gb, accum_a, accum_b) or None."""
+    if not 1 <= len(terms) <= 8:
+        raise _capi.NfxError("pair_loss: 1..8 terms")
+    n = terms[0][0].shape[0]
+    table = (_LossTerm * len(terms))()
+    for i, (a, b, w, kind, blend_a, blend_b) in enumerate(terms):
+        a = _dev(a, 'loss operand', (n, None))
+        b = _dev(b, 'loss operand', (n, a.shape[1]))
+        flags = (LOSS_BLEND_A if blend_a else 0) | (LOSS_BLEND_B if blend_b else 0)
+        ga = gb = None
+        if grads is not None:
+            ga, gb, acc_a, acc_b = grads[i]
+            flags |= (LOSS_ACCUM_A if acc_a else 0) | (LOSS_ACCUM_B if acc_b else 0)
+        table[i] = _LossTerm(a.data_ptr(), b.data_ptr(), ga.data_ptr() if ga is not None else None,
+                             gb.data_ptr() if gb is not None else None, a.shape[1], float(w), LOSS_KIND[kind], flags)
+    return table, n
+
+
+def pair_loss_fwd(terms, alpha=None, bg=0.):
+    """loss[n] = sum_t w_t mean_d f_t(A_t - B_t) with optional alpha blending of A / B onto `bg` (nfx.h)."""
+    table, n = _loss_table(terms)
+    dev = terms[0][0].device
+    alpha = None if alpha is None else _dev(alpha.reshape(n), 'alpha', (n,))
+    loss = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(lib.nfx_pair_loss_fwd(table, len(terms), _ptr(alpha), float(bg), n, _ptr(loss), _stream()),
+          'nfx_pair_loss_fwd')
+    return loss
+
+
+def pair_loss_bwd(terms, grads, dloss, alpha=None, bg=0.):
+    """Writes / accumulates d loss / d A, d loss / d B into the buffers of `grads` (see _loss_table)."""
+    table, n = _loss_table(terms, grads)
+    alpha = None if alpha is None else _dev(alpha.reshape(n), 'alpha', (n,))
+    dloss = _dev(dloss.reshape(n), 'dloss', (n,))
+    check(lib.nfx_pair_loss_bwd(table, len(terms), _ptr(alpha), float(bg), n, _ptr(dloss), _stream()),
+          'nfx_pair_loss_bwd')

@@ -89,7 +89,7 @@ def train_step(model, batch, optimizer, global_bs):
     """distributed_train_step (trainvali.py:273-295): per-example loss summed / global batch size,
     backward through the libnfx kernels, one collective, one fused optimizer kernel."""
     if hasattr(model, 'flush_numerics'):
-        model.flush_numerics()   # check_numerics verdicts of the PREVIOUS step: long finished, no stall
+        model.flush_numerics()   # ships the previous step's check_numerics verdicts, raises for landed ones; never blocks
     optimizer.zero_grad()
     pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
     loss_kwargs['keep_batch'] = True

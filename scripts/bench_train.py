@@ -49,6 +49,8 @@ def main():
     cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
     batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))), torch.ones(n, 1, device=dev), xyz,
              nrm, t(rng.uniform(size=(n, 512))))
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    mark_all_foreground(batch[5])   # as datasets/nerf_shape.py tags its training batches (rays drawn from alpha > 0.9)
     if args.model == 'nerf':   # rays from the camera towards the unit cube
         batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
     global_bs = n * world

@@ -400,4 +400,5 @@ def test_eval_brdf_at_has_the_reference_signature(nfx_lib, cuda):
                 for k in ('brdf_mlp', 'brdf_out')}
     want = R.learned_brdf(R.calc_ldir(xyz, lxyz), R.calc_vdir(cam, xyz), normal, albedo.cpu().numpy(), z.cpu().numpy(),
                           brdf_net, 1.)
-    assert np.abs(a.cpu().numpy() - want)[stable.cpu().numpy()].max() < 2e-3
+    # the prior itself runs on the fused bf16 template (nfx_brdf_rows_fwd) in both routes: bf16 bound against fp64
+    assert np.abs(a.cpu().numpy() - want)[stable.cpu().numpy()].max() < 3e-2 * max(1., float(want.max()))

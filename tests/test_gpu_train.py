@@ -641,3 +641,67 @@ def test_weight_gradients_are_bit_reproducible(nfx_lib, cuda, monkeypatch, wgrad
         ops.nerf_mlp_bwd(o, d, z, d_rgbs, nblob, dks, dbs)
         runs.append(dks + dbs)
     assert all(torch.equal(a, b) for a, b in zip(*runs))
+
+
+def test_numerics_verdicts_do_not_block_the_launch_queue(nfx_lib, cuda):
+    """check_numerics under autograd leaves its verdict on the device; flush_numerics() ships it asynchronously and
+    raises once the copy has landed (or at once with block=True) — the host never waits for the previous step."""
+    from nerfactor_amd.nerfactor.models.base import Model
+
+    class M(Model):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+    m = M()
+    good, bad = torch.ones(8, device=cuda), torch.tensor([1., float('inf')], device=cuda)
+    m.check_numerics(good, "fine")
+    m.flush_numerics()
+    m.check_numerics(bad, "Normal")
+    try:
+        m.flush_numerics()                          # enqueued; raises here only if the copy has already landed
+        landed = False
+    except FloatingPointError as e:
+        assert "Normal" in str(e)
+        landed = True
+    if not landed:
+        torch.cuda.synchronize()
+        with pytest.raises(FloatingPointError, match="Normal"):
+            m.flush_numerics()                      # landed by now
+    m.check_numerics(bad, "Loss")
+    with pytest.raises(FloatingPointError, match="Loss"):
+        m.flush_numerics(block=True)
+    m.flush_numerics(block=True)
+
+
+@pytest.mark.parametrize("kind", ["mae", "mse"])
+def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
+    """loss.hip against the torch formulation of the surface models' compute_loss (alpha blending as
+    util/img.py:alpha_blend, keras MSE / MAE = mean over the last axis): values and every gradient, with a tensor that
+    appears in two terms (its gradient accumulates), D = 3 / 512 / 1, background rays (alpha = 0) and ties."""
+    from nerfactor_amd import autograd as nfx_grad
+    from nerfactor_amd.nerfactor.util import img as imgutil
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n = 1031
+    mk = lambda d, grad: torch.rand(n, d, generator=g).to(cuda).requires_grad_(grad)
+    rgb_p, rgb_g = mk(3, True), mk(3, False)
+    lv_p, lv_g, lv_j = mk(512, True), mk(512, False), mk(512, True)
+    r_p, r_j = mk(1, True), mk(1, True)
+    with torch.no_grad():
+        lv_j[:, :7] = lv_p[:, :7]            # exact ties: sign(0) = 0
+    alpha = (torch.rand(n, 1, generator=g) > 0.3).float().to(cuda) * torch.rand(n, 1, generator=g).to(cuda)
+    bg = 1.
+    f = (lambda a, b: (a - b).abs().mean(-1)) if kind == 'mae' else (lambda a, b: ((a - b) ** 2).mean(-1))
+    on_bg = lambda x: imgutil.alpha_blend(x, alpha, torch.full_like(x, bg))
+    want = ((on_bg(rgb_g) - on_bg(rgb_p)) ** 2).mean(-1) + 0.1 * ((on_bg(lv_g) - on_bg(lv_p)) ** 2).mean(-1) \
+        + 0.05 * f(on_bg(lv_p), lv_j) + 0.01 * f(r_p, r_j)
+    up = torch.rand(n, generator=g).to(cuda)
+    tensors = [rgb_p, lv_p, lv_j, r_p, r_j]
+    want_g = torch.autograd.grad((want * up).sum(), tensors)
+    spec = ((0, 1, 1., 'mse', True, True), (2, 3, 0.1, 'mse', True, True), (2, 4, 0.05, kind, True, False),
+            (5, 6, 0.01, kind, False, False))
+    got = nfx_grad.PairLoss.apply(alpha, bg, spec, rgb_p, rgb_g, lv_p, lv_g, lv_j, r_p, r_j)
+    got_g = torch.autograd.grad((got * up).sum(), tensors)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-7)
+    for a, b in zip(got_g, want_g):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9), float((a - b).abs().max())
+    # deterministic
+    assert torch.equal(got, nfx_grad.PairLoss.apply(alpha, bg, spec, rgb_p, rgb_g, lv_p, lv_g, lv_j, r_p, r_j))
