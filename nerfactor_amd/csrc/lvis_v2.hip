@@ -79,7 +79,6 @@ struct InitBias {   // broadcast LDS reads of the bias tile
     const float* bias_tile;
     template <int CT>
     __device__ __forceinline__ void operator()(int lane, Acc<CT>& acc) const {
-#ifndef NFX_LV2_BIAS_READS
         // one read group, the other column tiles' accumulators by register copy (accumulators are ArchVGPRs here):
         // light-visibility kernel 17.57 -> 17.1 ms on r01; NFX_LV2_BIAS_READS restores one read group per column tile
         const float* bt = bias_tile + 4 * (lane >> 5);
@@ -94,22 +93,6 @@ struct InitBias {   // broadcast LDS reads of the bias tile
                 acc.v[c][4 * g + 3] = v[3];
             }
         }
-#else
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            int hoff = 4 * (lane >> 5);
-            asm volatile("" : "+v"(hoff));
-            const float* bt = bias_tile + hoff;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
-                acc.v[c][4 * g + 0] = v[0];
-                acc.v[c][4 * g + 1] = v[1];
-                acc.v[c][4 * g + 2] = v[2];
-                acc.v[c][4 * g + 3] = v[3];
-            }
-        }
-#endif
     }
 };
 template <int CT>
@@ -344,15 +327,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
         // chunk K accumulates in accs[K & 1]; layers: L0 K 0-3 (pl -> ha), L1 4-7 (ha -> hb), L2 8-11 (hb -> ha),
         // L3 12-15 ([ha ; pl] -> hb), out 16 (hb -> activation)
 #ifdef NFX_LV2_TIMING
-// diagnostic experiments on the "first tile of a layer is 2-3x slower" signature (NFX_LV2_X):
-//   1 = every layer reads the SAME B registers (ha), outputs still go where they went: no fresh B operands
-//   2 = the wave sleeps ~30 k cycles before the first tile of layers 1-3: anything still in flight has landed
-#ifndef NFX_LV2_X
-#define NFX_LV2_X 0
-#endif
+// cycle stamp per tile of one wave (scripts/lv2_timing.py; the r02 first-tile experiments are in DESIGN.md section 2c)
 #define NFX_LV2_STAMP(K) \
-    if (NFX_LV2_X == 2 && ((K) == 4 || (K) == 8 || (K) == 12)) { \
-        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } \
     if (blockIdx.x == 7 && tid == 0 && tl == blockIdx.x + 4 * (long long)gridDim.x) nfx_lv2_times[K] = __builtin_readcyclecounter();
 #else
 #define NFX_LV2_STAMP(K)
@@ -369,24 +345,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
         NFX_LV2_TILE(5, 8, 0, ha, pl, NFX_LV2_EPI(4, hb, 0), (InitBias{bias_lds + 128 + 64}));
         NFX_LV2_TILE(6, 8, 0, ha, pl, NFX_LV2_EPI(5, hb, 1), (InitBias{bias_lds + 128 + 96}));
         NFX_LV2_TILE(7, 8, 0, ha, pl, NFX_LV2_EPI(6, hb, 2), (InitBias{bias_lds + 256}));
-#if defined(NFX_LV2_TIMING) && NFX_LV2_X == 1
-#define NFX_LV2_HB ha
-#else
-#define NFX_LV2_HB hb
-#endif
-#if defined(NFX_LV2_TIMING) && NFX_LV2_X == 3     // tile 8 without the pending epilogue (values wrong, timing only)
-        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, EpiNone{}, (InitBias{bias_lds + 256 + 32}));
-#elif defined(NFX_LV2_TIMING) && NFX_LV2_X == 4   // tile 8 without the next tile's bias reads
-        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(7, hb, 3), [](int, Acc<CT>&) {});
-#elif defined(NFX_LV2_TIMING) && NFX_LV2_X == 5   // tile 8 reads tile 7's A fragments again (same LDS addresses)
-        NFX_LV2_STAMP(8)
-        tile<7, 9, 8, 0, CT>(wlds, lane, hb, pl, accs[0], accs[1], pre, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
-#else
-        NFX_LV2_TILE(8, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
-#endif
-        NFX_LV2_TILE(9, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
-        NFX_LV2_TILE(10, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
-        NFX_LV2_TILE(11, 8, 0, NFX_LV2_HB, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));
+        NFX_LV2_TILE(8, 8, 0, hb, pl, NFX_LV2_EPI(7, hb, 3), (InitBias{bias_lds + 256 + 32}));
+        NFX_LV2_TILE(9, 8, 0, hb, pl, NFX_LV2_EPI(8, ha, 0), (InitBias{bias_lds + 256 + 64}));
+        NFX_LV2_TILE(10, 8, 0, hb, pl, NFX_LV2_EPI(9, ha, 1), (InitBias{bias_lds + 256 + 96}));
+        NFX_LV2_TILE(11, 8, 0, hb, pl, NFX_LV2_EPI(10, ha, 2), init03(128, 384));
         NFX_LV2_TILE(12, 8, 2, ha, pl, NFX_LV2_EPI(11, ha, 3), init03(128 + 32, 384 + 32));
         NFX_LV2_TILE(13, 8, 2, ha, pl, NFX_LV2_EPI(12, hb, 0), init03(128 + 64, 384 + 64));
         NFX_LV2_TILE(14, 8, 2, ha, pl, NFX_LV2_EPI(13, hb, 1), init03(128 + 96, 384 + 96));

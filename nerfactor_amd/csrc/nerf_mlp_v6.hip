@@ -15,9 +15,10 @@
 //   DMA = 1  variant 7   THE DEFAULT: LDS-DMA (global_load_lds_dwordx4) into a 6-slot ring, chunk k+3 issued at the
 //                        start of tile k, counted s_waitcnt vmcnt before the barrier — no staging VGPRs, no ds_write;
 //   DMA = 2  variant 8   register-staged with two staging sets (chunk k+3 fetched during tile k, stored a tile later).
-// Experiment switches (NFX_EXTRA_DEFS, all measured on r01 and left at their defaults — DESIGN.md section 2):
-//   NFX_V6_BIAS_READ2 (second bias read group instead of register copies), NFX_V6_ADEPTH (A-fragment prefetch depth,
-//   3), NFX_V6_SP_LATE, NFX_V6_EOFF (epilogue start offset, 0), NFX_V7_DIST (DMA fetch distance, 3), NFX_V7_SPREAD.
+// The r01 experiment switches (second bias read group, A-prefetch depth, epilogue start offset, DMA fetch distance,
+// DMA pieces spread over the k-steps) were all measured and left at the values now hard-wired here — DESIGN.md
+// section 2 has the numbers; what remains switchable is the timing build (NFX_V6_TIMING) and the ablation masks
+// (NFX_ABLATION_BUILD).
 #include "mlp_engine.hpp"
 #include "nerf_layout.hpp"
 
@@ -37,17 +38,12 @@ constexpr int kNW = 4, kCT = 2;
 // written to its slot at the end of tile K+1: the global loads get two tile times to land instead of one, and the
 // compiler's counted vmcnt lets the newer set stay in flight across the store of the older one.
 template <int DMA> constexpr int ring_of = DMA == 1 ? 6 : 3;
-#ifndef NFX_V7_DIST
-#define NFX_V7_DIST 3   // LDS-DMA fetch distance in tiles (3 or 4; the 6-slot ring holds either)
-#endif
-template <int DMA> constexpr int dist_of = DMA == 1 ? NFX_V7_DIST : DMA ? 3 : 2;
+constexpr int kDmaDist = 3;   // LDS-DMA fetch distance in tiles (4 measured the same; the 6-slot ring holds either)
+template <int DMA> constexpr int dist_of = DMA == 1 ? kDmaDist : DMA ? 3 : 2;
 template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
 constexpr int kNChunks = nerf::kNChunks;  // 78
 
-#ifndef NFX_V6_ADEPTH
-#define NFX_V6_ADEPTH 3
-#endif
-constexpr int kPreA = NFX_V6_ADEPTH;   // A fragments in flight ahead of their MFMAs
+constexpr int kPreA = 3;   // A fragments in flight ahead of their MFMAs (2 / 3 / 4 measured: 1373 / 1372 / 1363 TFLOP/s)
 
 struct Acc {
     f32x16 v[kCT];
@@ -106,7 +102,6 @@ struct EpiSigma {
 };
 
 __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
-#ifndef NFX_V6_BIAS_READ2
     // one broadcast read group, the second column tile's accumulators copied from the first: +1.8 % on r01 once the
     // accumulators live in ArchVGPRs (MFMA VGPR form); a second read group (NFX_V6_BIAS_READ2) costs a full LDS pass
     const float* bt = bias_tile + 4 * (lane >> 5);
@@ -121,22 +116,6 @@ __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Ac
             acc.v[c][4 * g + 3] = v[3];
         }
     }
-#else
-#pragma unroll
-    for (int c = 0; c < kCT; ++c) {
-        int hoff = 4 * (lane >> 5);
-        asm volatile("" : "+v"(hoff));  // a second read group per column tile instead of 16 register copies
-        const float* bt = bias_tile + hoff;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * g);
-            acc.v[c][4 * g + 0] = v[0];
-            acc.v[c][4 * g + 1] = v[1];
-            acc.v[c][4 * g + 2] = v[2];
-            acc.v[c][4 * g + 3] = v[3];
-        }
-    }
-#endif
 }
 
 typedef __attribute__((address_space(1))) u32x4 gu32x4;   // explicit global address space: global_load, not flat_load
@@ -202,17 +181,9 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
                                      const bf16x8 (&b2)[KS2A][kCT], Acc& acc, Acc& acc_next, Pre& pre, Epi&& prev) {
     constexpr int KS = KS1 + KS2;
     constexpr int PIECES = KS >= 16 ? 8 : 4;
-#ifndef NFX_V6_EOFF
-#define NFX_V6_EOFF 0
-#endif
-    // the previous tile's epilogue starts EOFF k-steps into this tile (long tiles only): its first reads then fall
-    // behind this tile's first MFMAs instead of directly behind the previous tile's last ones (MFMA result latency)
-    constexpr int EOFF = KS >= 16 ? NFX_V6_EOFF : 0;
-#ifdef NFX_V6_SP_LATE
-    constexpr int SP = KS >= 16 ? 12 : (PIECES < KS ? PIECES : KS - 1);   // experiment: next tile's bias later in the tile
-#else
+    // (starting the previous tile's epilogue two k-steps into the tile, behind its first MFMAs, measured no gain on r01)
+    constexpr int EOFF = 0;
     constexpr int SP = (PIECES < KS ? PIECES : KS - 1) + EOFF;  // k-step after which the previous tile's epilogue is complete
-#endif
     constexpr int R = ring_of<DMA>;
     constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
     constexpr int NL2 = nerf::chunk_frags(K2) / 4;
@@ -222,13 +193,8 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
 #endif
     const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
     Stage<DMA ? 1 : NL2, kNW> st;
-#ifdef NFX_V7_SPREAD
-    constexpr int kDmaN = nerf::chunk_frags(K2) / kNW, kDmaStride = KS / kDmaN > 0 ? KS / kDmaN : 1;
-#endif
     if constexpr (DMA == 1 && !(AB & 1)) {
-#ifndef NFX_V7_SPREAD
         dma_chunk<K2>(cx);
-#endif
     } else if constexpr (DMA == 2 && !(AB & 1)) {
         unsigned long long gb = reinterpret_cast<unsigned long long>(cx.blob);
         asm volatile("" : "+s"(gb));   // (an integer: a laundered generic pointer would turn the loads into flat_load)
@@ -249,17 +215,6 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     for (int i = 0; i < kPreA; ++i) abuf[i] = pre.a[i];
     static_for<0, KS>([&](auto S) {
         constexpr int s = decltype(S)::value;
-#ifdef NFX_V7_SPREAD
-        if constexpr (DMA == 1 && !(AB & 1)) {
-            // piece i at k-step i * stride; whatever does not fit (short tiles) goes out with the last k-step
-            if constexpr (s % kDmaStride == 0 && s / kDmaStride < kDmaN && s != KS - 1) dma_one<K2, s / kDmaStride>(cx);
-            if constexpr (s == KS - 1)
-                static_for<0, kDmaN>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    if constexpr (i * kDmaStride >= KS - 1) dma_one<K2, i>(cx);
-                });
-        }
-#endif
         if constexpr (s + kPreA < KS && !(AB & 8))
             abuf[(s + kPreA) % (kPreA + 1)] = *reinterpret_cast<const bf16x8*>(f0 + (s + kPreA) * kFragBytes);
         const bf16x8 a = abuf[s % (kPreA + 1)];
@@ -289,7 +244,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
         // the chunk issued one tile ago must be complete before the barrier; this tile's pieces may stay in flight
         // (fetch distance 4: the chunk issued during the previous tile may stay in flight too)
         constexpr int kInFlight = nerf::chunk_frags(K2) / kNW +
-                                  (NFX_V7_DIST == 4 ? nerf::chunk_frags((K + 3) % kNChunks) / kNW : 0);
+                                  (kDmaDist == 4 ? nerf::chunk_frags((K + 3) % kNChunks) / kNW : 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
     } else if constexpr (DMA == 2 && !(AB & 1)) {
         // chunk K+2, fetched during tile K-1 into the other register set, to slot (K+2) % 3 = the slot tile K-1 read
@@ -365,7 +320,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
             Stage<chunk_frags(2) / 4, kNW> s2;
             s2.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(2) * kFragBytes), tid);
             s2.store(reinterpret_cast<u32x4*>(smem + 2 * kSlotBytes), tid);
-            if constexpr (NFX_V7_DIST == 4) {
+            if constexpr (kDmaDist == 4) {
                 Stage<chunk_frags(3) / 4, kNW> s3;
                 s3.load(reinterpret_cast<const u32x4*>(blob + (size_t)chunk_frag_offset(3) * kFragBytes), tid);
                 s3.store(reinterpret_cast<u32x4*>(smem + 3 * kSlotBytes), tid);
