@@ -234,16 +234,19 @@ int nfx_nerf_mlp_bwd(const float *dev_rayo, const float *dev_rayd, const float *
                      float *const dev_dbiases[12], void *stream);
 
 /* Backward of nfx_brdf_spec_fwd (frozen prior, so no weight gradients): given dev_dspec [n, L] =
- * dLoss/d spec, ACCUMULATES dLoss/d z into dev_d_z [n, z_dim] and dLoss/d normal into dev_d_normal
- * [n, 3] (atomics; zero or pre-fill them).  `blob` is the BRDF train blob
- * (nfx_brdf_train_packed_bytes / nfx_brdf_pack_train_weights).                                  */
+ * dLoss/d spec, ADDS dLoss/d z to dev_d_z [n, z_dim] and dLoss/d normal to dev_d_normal [n, 3] (zero or pre-fill
+ * them).  The sums over a point's lights are taken in 64-bit fixed point inside `dev_workspace`
+ * (nfx_brdf_spec_bwd_workspace_bytes(z_dim, n), 8-byte aligned): independent of the order the waves arrive in, hence
+ * bit-reproducible.  `blob` is the BRDF train blob (nfx_brdf_train_packed_bytes / nfx_brdf_pack_train_weights).  */
 size_t nfx_brdf_train_packed_bytes(void);
 int nfx_brdf_pack_train_weights(const float *const kernels[5], const float *const biases[5],
                                 int z_dim, int prec, void *blob, size_t blob_bytes);
+size_t nfx_brdf_spec_bwd_workspace_bytes(int z_dim, int64_t n);
 int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                       const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
                       const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
-                      float *dev_d_z, float *dev_d_normal, void *stream);
+                      float *dev_d_z, float *dev_d_normal, void *dev_workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* The BRDF prior on EXPLICIT rows — evaluation and one training step's backward of models/brdf.py
  * (reference nerfactor/models/brdf.py:57-66 `_eval_brdf_at`, :87-136 `call`/`compute_loss`, trained by
@@ -263,16 +266,19 @@ int nfx_brdf_rows_bwd(const float *dev_z, int z_dim, const float *dev_rusink, in
 
 /* Backward of nfx_shade_fwd for ONE light (n_probes = 1, the trained light): given dev_drgb [n,3] =
  * dLoss/d rgb, writes d_albedo [n,3], d_normal [n,3], d_lvis [n,L] and either d_rough [n]
- * (microfacet, dev_spec == NULL) or d_spec [n,L] (given specular term); ACCUMULATES d_light [L,3]
- * (atomics; zero it before the first call of a step).  Gradients flow to the normal both through
- * cos = l.n and through the BRDF; none to positions, camera or light geometry.  */
+ * (microfacet, dev_spec == NULL) or d_spec [n,L] (given specular term); ADDS the light's gradient to d_light [L,3]
+ * when that is non-NULL (zero it before the first call of a step) — summed over the points in 64-bit fixed point
+ * inside `dev_workspace` (nfx_shade_bwd_workspace_bytes(n_lights), 8-byte aligned), so the result is independent of
+ * the order of the atomics: bit-reproducible.  Gradients flow to the normal both through cos = l.n and through the
+ * BRDF; none to positions, camera or light geometry.  */
+size_t nfx_shade_bwd_workspace_bytes(int n_lights);
 int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
                   const float *dev_lareas, const float *dev_light, int64_t n, int n_lights,
                   int linear2srgb, const float *dev_drgb, float *dev_d_albedo, float *dev_d_rough,
                   float *dev_d_spec, float *dev_d_normal, float *dev_d_lvis, float *dev_d_light,
-                  void *stream);
+                  void *dev_workspace, size_t workspace_bytes, void *stream);
 
 /* Device-side re-packing of any blob produced by the nfx_*_pack_*weights functions (all of them are pure gathers of
  * the parameters).  One map entry (two int32) per 32-bit word of the blob: (a, -2) = the fp32 value src[a];
@@ -287,6 +293,12 @@ int nfx_pack_gather(const float *dev_src, const int32_t *dev_map, int64_t n_word
 int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
                      int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                      void *stream);
+/* The same update with lr_t read from device memory (dev_lr_t[0] = nfx_amsgrad_step_size(lr, beta1, beta2, step),
+ * written by the host before the launch): a training step captured in a hipGraph replays with the step size of the
+ * current step, not the one of the step it was captured at (nerfactor_amd/optim.py:GraphedTrainStep).            */
+float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step);
+int nfx_amsgrad_step_dev(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
+                         int64_t n, const float *dev_lr_t, float beta1, float beta2, float eps, void *stream);
 
 /* The per-ray training losses of the surface models (nerfactor.py:463-541, shape.py:239-277 `compute_loss`) as one
  * launch: loss[ray] = sum_t w_t * mean_d f_t(A_t[ray, d] - B_t[ray, d]), f = square (keras MSE) or abs (MAE), A / B

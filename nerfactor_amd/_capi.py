@@ -64,16 +64,20 @@ SIGNATURES = {
     'nfx_nerf_mlp_bwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p, _sz, _pp, _pp, _p]),
     'nfx_brdf_train_packed_bytes': (_sz, []),
     'nfx_brdf_pack_train_weights': (_i, [_pp, _pp, _i, _i, _p, _sz]),
-    'nfx_brdf_spec_bwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p]),
+    'nfx_brdf_spec_bwd_workspace_bytes': (_sz, [_i, _i64]),
+    'nfx_brdf_spec_bwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _sz, _p]),
     'nfx_brdf_rows_fwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_brdf_rows_bwd_workspace_bytes': (_sz, [_i, _i64, _i]),
     'nfx_brdf_rows_bwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p, _sz, _p, _pp, _pp, _p]),
+    'nfx_shade_bwd_workspace_bytes': (_sz, [_i]),
     'nfx_shade_bwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p,
-                           _p, _p]),
+                           _p, _p, _sz, _p]),
     'nfx_pair_loss_fwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
     'nfx_pair_loss_bwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
     'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),
     'nfx_amsgrad_step': (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _i64, _p]),
+    'nfx_amsgrad_step_size': (_f, [_f, _f, _f, _i64]),
+    'nfx_amsgrad_step_dev': (_i, [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _p]),
     'nfx_nerf_sigma_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_nerf_geom_packed_bytes': (_sz, [_i]),
     'nfx_nerf_pack_geom_weights': (_i, [_pp, _pp, _i, _p, _sz]),

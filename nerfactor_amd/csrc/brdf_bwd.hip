@@ -50,11 +50,29 @@ __device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (
     });
 }
 
+constexpr double kFxScale = 1099511627776.0;   // 2^40 per unit: resolution 9e-13, range +-8e6
+__device__ __forceinline__ unsigned long long to_fx(float v) {
+    return (unsigned long long)__double2ll_rn((double)v * kFxScale);
+}
+// fx[n, z_dim + 3] -> d_z[n, z_dim] += , d_normal[n, 3] +=
+__global__ void brdf_fx_finish_kernel(const long long* __restrict__ fx, long long n, int z_dim, float* __restrict__ d_z,
+                                      float* __restrict__ d_normal) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = z_dim + 3;
+    if (i >= n * w) return;
+    const long long pt = i / w;
+    const int c = (int)(i % w);
+    const float v = (float)((double)fx[i] / kFxScale);
+    if (c < z_dim) d_z[pt * z_dim + c] += v;
+    else d_normal[pt * 3 + (c - z_dim)] += v;
+}
+
 __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ cam, const float* __restrict__ normal,
     const float* __restrict__ z, int z_dim, const float* __restrict__ lxyz, int n_lights,
-    const char* __restrict__ blob, long long n, const float* __restrict__ dspec, float* __restrict__ d_z,
-    float* __restrict__ d_normal) {
+    const char* __restrict__ blob, long long n, const float* __restrict__ dspec, long long* __restrict__ fx) {
+    // fx: [n, z_dim + 3] fixed-point (2^40) sums of d z and d normal over the point's lights — integer atomics, so the
+    // 16 waves that share a point may arrive in any order (float atomics made the step's gradients run-dependent)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
@@ -182,13 +200,14 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
             for (int i = 0; i < m128::kMaxZDim; ++i) dzv[i] += __shfl_xor(dzv[i], o, 64);
         }
         if (valid && p == 0) {
+            unsigned long long* row = reinterpret_cast<unsigned long long*>(fx + pt * (z_dim + 3));
             if (h == 0) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) atomicAdd(d_normal + pt * 3 + a, dn[a]);
+                for (int a = 0; a < 3; ++a) atomicAdd(row + z_dim + a, to_fx(dn[a]));
             }
 #pragma unroll
             for (int i = 0; i < m128::kMaxZDim; ++i)
-                if (i < z_dim && ((i == 0) ? h == 1 : ((i - 1) & 1) == h)) atomicAdd(d_z + pt * z_dim + i, dzv[i]);
+                if (i < z_dim && ((i == 0) ? h == 1 : ((i - 1) & 1) == h)) atomicAdd(row + i, to_fx(dzv[i]));
         }
     }
 }
@@ -341,7 +360,7 @@ extern "C" {
 int nfx_brdf_train_blob_bytes(void) { return nfx::brdfbwd::kBlobBytes; }
 int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
                              const float* lxyz, int n_lights, const void* blob, long long n, const float* dspec,
-                             float* d_z, float* d_normal, int max_blocks, hipStream_t st) {
+                             float* d_z, float* d_normal, void* workspace, int max_blocks, hipStream_t st) {
     using namespace nfx;
     if (n <= 0) return 0;
     const long long tiles = (n * n_lights + brdfbwd::kRows - 1) / brdfbwd::kRows;
@@ -350,8 +369,13 @@ int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* no
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(brdfbwd::brdf_spec_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
+    const long long words = n * (z_dim + 3);
+    e = hipMemsetAsync(workspace, 0, sizeof(long long) * (size_t)words, st);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
-                       z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, d_z, d_normal);
+                       z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, static_cast<long long*>(workspace));
+    hipLaunchKernelGGL(brdfbwd::brdf_fx_finish_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const long long*>(workspace), n, z_dim, d_z, d_normal);
     return (int)hipGetLastError();
 }
 int nfx_brdf_rows_feats(void) { return nfx::brdfbwd::kRowFeats; }

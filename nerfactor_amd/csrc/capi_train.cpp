@@ -37,6 +37,7 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
                            hipStream_t st);
 int nfx_launch_amsgrad(float*, const float*, float*, float*, float*, long long, float, float, float, float,
                        hipStream_t);
+float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step);
 
 static bool kind_ok(int k) { return k == NFX_IN_XYZ || k == NFX_IN_XYZ_LDIR; }
 static int in_dims(int k) { return k == NFX_IN_XYZ ? 63 : 90; }
@@ -305,7 +306,7 @@ int nfx_pack_gather(const float* src, const int32_t* map, int64_t n_words, void*
 
 int nfx_brdf_train_blob_bytes(void);
 int nfx_launch_brdf_spec_bwd(const float*, const float*, const float*, const float*, int, const float*, int,
-                             const void*, long long, const float*, float*, float*, int, hipStream_t);
+                             const void*, long long, const float*, float*, float*, void*, int, hipStream_t);
 
 size_t nfx_brdf_train_packed_bytes(void) { return (size_t)nfx_brdf_train_blob_bytes(); }
 
@@ -385,18 +386,26 @@ int nfx_brdf_pack_train_weights(const float* const kernels[5], const float* cons
     return NFX_OK;
 }
 
+size_t nfx_brdf_spec_bwd_workspace_bytes(int z_dim, int64_t n) {
+    return n > 0 && z_dim >= 1 ? sizeof(long long) * (size_t)n * (z_dim + 3) : 0;
+}
+
 int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
                       const float* lxyz, int n_lights, const void* blob, int prec, int64_t n, const float* dspec,
-                      float* d_z, float* d_normal, void* stream) {
+                      float* d_z, float* d_normal, void* workspace, size_t workspace_bytes, void* stream) {
     REQUIRE(n >= 0, "nfx_brdf_spec_bwd: n < 0");
     REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_spec_bwd: z_dim %d unsupported", z_dim);
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_brdf_spec_bwd: n_lights (%d) must be a multiple of 32", n_lights);
     if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_spec_bwd: only bf16 is built");
     if (n == 0) return NFX_OK;
     REQUIRE(xyz && cam && normal && z && lxyz && blob && dspec && d_z && d_normal, "nfx_brdf_spec_bwd: null pointer");
-    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd: blob must be 16-byte aligned");
+    REQUIRE(workspace && workspace_bytes >= nfx_brdf_spec_bwd_workspace_bytes(z_dim, n),
+            "nfx_brdf_spec_bwd: workspace of nfx_brdf_spec_bwd_workspace_bytes(z_dim, n) bytes required");
+    if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 8))
+        return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd: blob must be 16-byte, workspace 8-byte aligned");
     return nfx_hip_result(nfx_launch_brdf_spec_bwd(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, dspec, d_z,
-                                                   d_normal, nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                   d_normal, workspace, nfx_env_int("NFX_M128_BLOCKS", 256),
+                                                   (hipStream_t)stream),
                           "brdf_spec_bwd");
 }
 
@@ -472,13 +481,15 @@ int nfx_brdf_rows_bwd(const float* z, int z_dim, const float* rusink, int64_t n,
 
 int nfx_launch_shade_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float,
                          float, const float*, const float*, const float*, const float*, long long, int, int,
-                         const float*, float*, float*, float*, float*, float*, float*, hipStream_t);
+                         const float*, float*, float*, float*, float*, float*, float*, void*, hipStream_t);
+
+size_t nfx_shade_bwd_workspace_bytes(int n_lights) { return n_lights > 0 ? sizeof(long long) * 3 * (size_t)n_lights : 0; }
 
 int nfx_shade_bwd(const float* xyz, const float* cam, const float* normal, const float* albedo, const float* rough,
                   const float* spec, float spec_scale, float f0, const float* lvis, const float* lxyz,
                   const float* lareas, const float* light, int64_t n, int n_lights, int linear2srgb,
                   const float* drgb, float* d_albedo, float* d_rough, float* d_spec, float* d_normal, float* d_lvis,
-                  float* d_light, void* stream) {
+                  float* d_light, void* workspace, size_t workspace_bytes, void* stream) {
     REQUIRE(n >= 0 && n_lights > 0, "nfx_shade_bwd: bad shape");
     REQUIRE((size_t)7 * n_lights * sizeof(float) <= 160 * 1024, "nfx_shade_bwd: too many lights (%d)", n_lights);
     if (n == 0) return NFX_OK;
@@ -486,9 +497,14 @@ int nfx_shade_bwd(const float* xyz, const float* cam, const float* normal, const
     REQUIRE(rough || spec, "nfx_shade_bwd: need roughness (microfacet) or a specular term");
     REQUIRE(d_albedo && d_normal, "nfx_shade_bwd: d_albedo and d_normal are required outputs");
     REQUIRE(spec ? d_spec != nullptr : d_rough != nullptr, "nfx_shade_bwd: missing BRDF-parameter gradient output");
+    if (d_light) {
+        REQUIRE(workspace && workspace_bytes >= nfx_shade_bwd_workspace_bytes(n_lights),
+                "nfx_shade_bwd: d_light needs a workspace of nfx_shade_bwd_workspace_bytes(n_lights) bytes");
+        if (!ALIGNED(workspace, 8)) return nfx_fail(NFX_EALIGN, "nfx_shade_bwd: workspace must be 8-byte aligned");
+    }
     return nfx_hip_result(nfx_launch_shade_bwd(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
                                                lareas, light, n, n_lights, linear2srgb, drgb, d_albedo, d_rough,
-                                               d_spec, d_normal, d_lvis, d_light, (hipStream_t)stream),
+                                               d_spec, d_normal, d_lvis, d_light, workspace, (hipStream_t)stream),
                           "shade_bwd");
 }
 
@@ -528,9 +544,22 @@ int nfx_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, 
     REQUIRE(n >= 0 && step >= 1, "nfx_amsgrad_step: bad n/step");
     if (n == 0) return NFX_OK;
     REQUIRE(p && g && m && v && vhat, "nfx_amsgrad_step: null pointer");
-    const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);
-    const float lr_t = (float)((double)lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+    const float lr_t = nfx_amsgrad_step_size(lr, beta1, beta2, step);
     return nfx_hip_result(nfx_launch_amsgrad(p, g, m, v, vhat, n, lr_t, beta1, beta2, eps, (hipStream_t)stream),
                           "amsgrad_step");
+}
+int nfx_launch_amsgrad_dev(float*, const float*, float*, float*, float*, long long, const float*, float, float, float,
+                           hipStream_t);
+float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step) {
+    const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);
+    return (float)((double)lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+}
+int nfx_amsgrad_step_dev(float* p, const float* g, float* m, float* v, float* vhat, int64_t n, const float* dev_lr_t,
+                         float beta1, float beta2, float eps, void* stream) {
+    REQUIRE(n >= 0, "nfx_amsgrad_step_dev: bad n");
+    if (n == 0) return NFX_OK;
+    REQUIRE(p && g && m && v && vhat && dev_lr_t, "nfx_amsgrad_step_dev: null pointer");
+    return nfx_hip_result(nfx_launch_amsgrad_dev(p, g, m, v, vhat, n, dev_lr_t, beta1, beta2, eps, (hipStream_t)stream),
+                          "amsgrad_step_dev");
 }
 }  // extern "C"

@@ -266,7 +266,8 @@ namespace nfx {
 struct ShadeBwdArgs {
     ShadeArgs f;          // forward inputs; f.lights = the trained light [L,3]; f.out unused
     const float* drgb;    // [n,3]
-    float *d_albedo, *d_rough, *d_spec, *d_normal, *d_lvis, *d_light;  // d_light [L,3] is ACCUMULATED
+    float *d_albedo, *d_rough, *d_spec, *d_normal, *d_lvis;
+    long long* d_light_fx;   // [L,3] fixed-point (2^40) sums of the light gradient: integer atomics are order-independent
 };
 
 __device__ __forceinline__ float tonemap_grad(float s, int to_srgb) {
@@ -332,6 +333,15 @@ __device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp,
     return spec;
 }
 
+// The light's gradient d_light[l, c] = sum over points of dS_c b_c k is accumulated as 64-bit fixed point (2^40 per
+// unit: resolution 9e-13, range +-8e6): integer addition is associative, so the result does not depend on the order the
+// atomics land in — two runs of a training step give the same bits (float atomics did not).
+constexpr double kLightFxScale = 1099511627776.0;
+__global__ void light_fx_finish_kernel(const long long* __restrict__ fx, float* __restrict__ d_light, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d_light[i] += (float)((double)fx[i] / kLightFxScale);
+}
+
 __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const ShadeArgs& f = a.f;
@@ -388,7 +398,9 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArg
                 T += dS[c] * b * lg;
                 U += dS[c] * lg;
                 d_alb[c] += dS[c] * k * lg / pi;
-                if (a.d_light) atomicAdd(a.d_light + 3 * l + c, dS[c] * b * k);
+                if (a.d_light_fx)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.d_light_fx + 3 * l + c),
+                              (unsigned long long)__double2ll_rn((double)(dS[c] * b * k) * kLightFxScale));
             }
             if (a.d_lvis) a.d_lvis[pt * L + l] = front ? cosv * area * T : 0.0f;
             const float d_cos = front ? lvis * area * T : 0.0f;
@@ -434,13 +446,18 @@ extern "C" int nfx_launch_shade_bwd(const float* xyz, const float* cam, const fl
                                     const float* lvis, const float* lxyz, const float* lareas, const float* light,
                                     long long n, int n_lights, int to_srgb, const float* drgb, float* d_albedo,
                                     float* d_rough, float* d_spec, float* d_normal, float* d_lvis, float* d_light,
-                                    hipStream_t st) {
+                                    void* workspace, hipStream_t st) {
     if (n <= 0) return 0;
     nfx::ShadeBwdArgs a;
     a.f = make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas, light, n, n_lights, 1,
                     to_srgb, 0.f, 0.f, nullptr);
     a.drgb = drgb; a.d_albedo = d_albedo; a.d_rough = d_rough; a.d_spec = d_spec; a.d_normal = d_normal;
-    a.d_lvis = d_lvis; a.d_light = d_light;
+    a.d_lvis = d_lvis;
+    a.d_light_fx = d_light ? static_cast<long long*>(workspace) : nullptr;
+    if (a.d_light_fx) {
+        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(long long) * 3 * (size_t)n_lights, st);
+        if (e != hipSuccess) return (int)e;
+    }
     const size_t lds = sizeof(float) * (size_t)7 * n_lights;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -448,5 +465,8 @@ extern "C" int nfx_launch_shade_bwd(const float* xyz, const float* cam, const fl
     long long blocks = (n + nfx::kShadeWaves - 1) / nfx::kShadeWaves;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(nfx::shade_bwd_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st, a);
+    if (a.d_light_fx)
+        hipLaunchKernelGGL(nfx::light_fx_finish_kernel, dim3((3 * n_lights + 255) / 256), dim3(256), 0, st,
+                           a.d_light_fx, d_light, 3 * n_lights);
     return (int)hipGetLastError();
 }

@@ -57,6 +57,23 @@ __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ 
     vhat[i] = vh;
     p[i] = p[i] - lr_t * mi / (sqrtf(vh) + eps);
 }
+// the same update with the step size read from device memory: a captured hipGraph replays it with the step size of
+// the CURRENT step (the host refreshes the word before each replay) instead of the one baked in at capture time
+__global__ void amsgrad_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, float* __restrict__ vhat, long long n,
+                                   const float* __restrict__ lr_t_dev, float b1, float b2, float eps) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lr_t = lr_t_dev[0];
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.0f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
+    const float vh = fmaxf(vhat[i], vi);
+    m[i] = mi;
+    v[i] = vi;
+    vhat[i] = vh;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vh) + eps);
+}
 
 // One wave owns a [<=128 x <=128] block of dW (grid y, z) and a slab of rows (grid x).
 //   xt: [k_in][ld] bf16 (feature-major), zt: [n_out][ld] bf16; rows in [row0, row1), multiple of 16.
@@ -285,6 +302,13 @@ int nfx_launch_amsgrad(float* p, const float* g, float* m, float* v, float* vhat
     if (n <= 0) return 0;
     hipLaunchKernelGGL(nfx::amsgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v,
                        vhat, n, lr_t, b1, b2, eps);
+    return (int)hipGetLastError();
+}
+int nfx_launch_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vhat, long long n,
+                           const float* lr_t_dev, float b1, float b2, float eps, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(nfx::amsgrad_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v,
+                       vhat, n, lr_t_dev, b1, b2, eps);
     return (int)hipGetLastError();
 }
 // Host-side description of one GEMM of a batch (capi_train.cpp fills these).

@@ -237,14 +237,22 @@ def main(argv=None):
         model.compile_batch_vis(vis_dirs, join(vis_epoch[mode].format(e=step), 'all'), mode=mode)
         maintain_epoch_queue(queues[mode], vis_epoch[mode].format(e=step))
 
+    # extra ini key (not in the reference): hip_graph = true captures the training step in a hipGraph per batch shape
+    # (optim.GraphedTrainStep); single-process runs with foreground-tagged batches only, eager otherwise
+    if config.getboolean('DEFAULT', 'hip_graph', fallback=False):
+        graphed = optim.GraphedTrainStep(model, optimizer, global_bs_train)
+        run_step = lambda b: graphed(b)
+    else:
+        run_step = lambda b: optim.train_step(model, b, optimizer, global_bs_train)
+
     while step < epochs:
         # ------ one epoch = every training view once, n_rays_per_step rays each ------
         losses, batch_vis, batch_time = [], [], []
         pipe = dataset_train.build_pipeline(no_batch=no_batch, seed=seed + step)  # same order on every rank
         for batch_i, batch in enumerate(pipe):
             t0 = time.time()
-            loss, to_vis = optim.train_step(model, shard_batch(batch), optimizer, global_bs_train)
-            losses.append(loss)           # device scalars: no host sync inside the epoch
+            loss, to_vis = run_step(shard_batch(batch))
+            losses.append(loss.clone())   # device scalars: no host sync inside the epoch (a graphed step reuses its output)
             batch_time.append(time.time() - t0)
             if batch_i < vis_train_batches:
                 batch_vis.append(gather_vis(to_vis))

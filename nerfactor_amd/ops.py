@@ -462,10 +462,23 @@ def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):
                                eps, step, _stream()), 'nfx_amsgrad_step')
 
 
+def amsgrad_step_size(lr, step, beta1=0.9, beta2=0.999):
+    """lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step), evaluated as the library does (double, rounded once)."""
+    return float(lib.nfx_amsgrad_step_size(lr, beta1, beta2, step))
+
+
+def amsgrad_step_dev(p, g, m, v, vhat, lr_t_dev, beta1=0.9, beta2=0.999, eps=1e-7):
+    """amsgrad_step with the step size read from the 1-element CUDA tensor `lr_t_dev` (hipGraph-replayable)."""
+    for t in (p, g, m, v, vhat, lr_t_dev):
+        _dev(t, 'optimizer buffer')
+    check(lib.nfx_amsgrad_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), _ptr(lr_t_dev), beta1,
+                                   beta2, eps, _stream()), 'nfx_amsgrad_step_dev')
+
+
 def shade_bwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light, drgb, d_light, rough=None, spec=None,
               spec_scale=1., f0=0.04, linear2srgb=True):
     """Backward of shade_fwd for one light [L,3].  Returns (d_albedo, d_normal, d_lvis, d_rough|d_spec);
-    accumulates into d_light [L,3]."""
+    adds the light's gradient to d_light [L,3] (order-independent fixed-point sum: bit-reproducible)."""
     xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
         xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
     light = _dev(light, 'light', (nl, 3))
@@ -477,10 +490,11 @@ def shade_bwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, light, drgb, d_light
     d_lvis = torch.empty((n, nl), dtype=torch.float32, device=dev_)
     d_rough = torch.empty((n,), dtype=torch.float32, device=dev_) if spec is None else None
     d_spec = torch.empty((n, nl), dtype=torch.float32, device=dev_) if spec is not None else None
+    ws = torch.empty((max(lib.nfx_shade_bwd_workspace_bytes(nl), 8) // 8,), dtype=torch.int64, device=dev_)
     check(lib.nfx_shade_bwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec), spec_scale,
                             f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), _ptr(light), n, nl, int(linear2srgb),
                             _ptr(drgb), _ptr(d_albedo), _ptr(d_rough), _ptr(d_spec), _ptr(d_normal), _ptr(d_lvis),
-                            _ptr(d_light), _stream()), 'nfx_shade_bwd')
+                            _ptr(d_light), _ptr(ws), ws.numel() * 8, _stream()), 'nfx_shade_bwd')
     return d_albedo, d_normal, d_lvis, (d_rough if spec is None else d_spec)
 
 
@@ -500,9 +514,11 @@ def brdf_spec_bwd(xyz, cam, normal, z, lxyz, blob, dspec, prec='bf16'):
     dspec = _dev(dspec, 'dspec', (n, nl))
     d_z = torch.zeros_like(z)
     d_normal = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device)
+    ws = torch.empty((max(lib.nfx_brdf_spec_bwd_workspace_bytes(z.shape[1], n), 8) // 8,), dtype=torch.int64,
+                     device=xyz.device)
     check(lib.nfx_brdf_spec_bwd(_ptr(xyz), _ptr(_dev(cam, 'cam', (n, 3))), _ptr(_dev(normal, 'normal', (n, 3))),
                                 _ptr(z), z.shape[1], _ptr(lxyz), nl, _ptr(blob), _PREC[prec], n, _ptr(dspec),
-                                _ptr(d_z), _ptr(d_normal), _stream()), 'nfx_brdf_spec_bwd')
+                                _ptr(d_z), _ptr(d_normal), _ptr(ws), ws.numel() * 8, _stream()), 'nfx_brdf_spec_bwd')
     return d_z, d_normal
 
 

@@ -47,7 +47,7 @@ class AMSGrad:
     def zero_grad(self):
         self.bucket.flat.zero_()
 
-    def step(self, loss=0.):
+    def step(self, loss=0., lr_t_dev=None):
         """All-reduce [grads | loss] (sum over ranks), apply the update; returns the summed loss."""
         self.bucket.flat[-1] = loss
         _, total = self.bucket.all_reduce()
@@ -58,13 +58,23 @@ class AMSGrad:
             for gv in self.bucket.views:
                 nrm = gv.norm()
                 gv.mul_(torch.clamp(self.clipnorm / (nrm + 1e-12), max=1.))
+        if lr_t_dev is not None:
+            # captured in a hipGraph: the step size comes from device memory (GraphedTrainStep refreshes it and does
+            # the host-side bookkeeping — iterations, version counters — around every replay)
+            ops.amsgrad_step_dev(self.flat, g, self.m, self.v, self.vhat, lr_t_dev, self.beta_1, self.beta_2,
+                                 self.epsilon)
+            return total.clone()
         lr = self.current_lr()
         self.iterations += 1
         ops.amsgrad_step(self.flat, g, self.m, self.v, self.vhat, lr, self.iterations, self.beta_1,
                          self.beta_2, self.epsilon)
-        # the kernel wrote through raw pointers: tell torch (and the models' packed-blob caches) the parameters changed
-        torch.autograd.graph.increment_version(self.params)
+        self.mark_updated()
         return total.clone()   # `total` is a view of the bucket's last slot, overwritten by the next step
+
+    def mark_updated(self):
+        """The update kernel wrote through raw pointers: tell torch (and the models' packed-blob caches, which key on the
+        version counters) that the parameters changed."""
+        torch.autograd.graph.increment_version(self.params)
 
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'vhat': self.vhat, 'iterations': self.iterations}
@@ -98,3 +108,81 @@ def train_step(model, batch, optimizer, global_bs):
     weighted.backward()
     total = optimizer.step(loss=weighted.detach())
     return total, to_vis
+
+
+class GraphedTrainStep:
+    """train_step captured once per batch shape in a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~170 launches
+    of a NeRFactor step become one graph launch.  What makes the step capturable: no host round trip inside it
+    (asynchronous check_numerics verdicts, the dataset's foreground tag instead of torch.nonzero), every libnfx launch
+    goes to torch's current stream, workspaces come from torch's (graph-private) allocator, and the AMSGrad kernel
+    reads its step size from device memory.  Per replay the host copies the batch into the static input tensors,
+    writes the step size, launches the graph, advances `iterations` and bumps the parameters' version counters.
+    Batches that are not tagged foreground-only (dynamic shapes) and multi-process runs fall back to train_step."""
+
+    def __init__(self, model, optimizer, global_bs, warmup=2):
+        self.model, self.opt, self.global_bs, self.warmup = model, optimizer, global_bs, warmup
+        self.graphs = {}
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=optimizer.flat.device)
+        self.seen = {}
+
+    @staticmethod
+    def _key(batch):
+        return tuple((tuple(t.shape), t.dtype) if isinstance(t, torch.Tensor) else None for t in batch)
+
+    def _capturable(self, batch):
+        from .nerfactor.datasets.nerf_shape import known_all_foreground
+        if nfx_dist.world()[1] > 1:
+            return False
+        alpha = batch[5] if len(batch) > 5 else None       # NeRF batches (5 fields) have no compaction at all
+        return alpha is None or known_all_foreground(alpha)
+
+    def _eager(self, batch):
+        return train_step(self.model, batch, self.opt, self.global_bs)
+
+    def _body(self, static):
+        model, opt = self.model, self.opt
+        opt.zero_grad()
+        pred, gt, loss_kwargs, to_vis = model(static, mode='train')
+        loss_kwargs['keep_batch'] = True
+        weighted = model.compute_loss(pred, gt, **loss_kwargs).sum() / self.global_bs
+        weighted.backward()
+        total = opt.step(loss=weighted.detach(), lr_t_dev=self.lr_t)
+        pending = model.__dict__.get('_pending_numerics', [])
+        model.__dict__['_pending_numerics'] = []
+        flags = torch.stack([ok for _, ok in pending]) if pending else None
+        return total, to_vis, [m for m, _ in pending], flags
+
+    def __call__(self, batch):
+        if not self._capturable(batch):
+            return self._eager(batch)
+        key = self._key(batch)
+        n_seen = self.seen.get(key, 0)
+        self.seen[key] = n_seen + 1
+        if n_seen < self.warmup:            # host-side packers, hipFuncSetAttribute, allocator pools: warm before capture
+            return self._eager(batch)
+        model, opt = self.model, self.opt
+        if key not in self.graphs:
+            from .nerfactor.datasets.nerf_shape import known_all_foreground, mark_all_foreground
+            model.flush_numerics(block=True)
+            static = tuple(t.clone() if isinstance(t, torch.Tensor) else t for t in batch)
+            if len(batch) > 5 and known_all_foreground(batch[5]):
+                mark_all_foreground(static[5])
+            self.lr_t.fill_(ops.amsgrad_step_size(opt.current_lr(), opt.iterations + 1, opt.beta_1, opt.beta_2))
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                outs = self._body(static)
+            self.graphs[key] = (graph, static, outs)
+            # the capture did not execute anything: fall through and replay it for this batch
+        graph, static, (total, to_vis, messages, flags) = self.graphs[key]
+        for dst, src in zip(static, batch):
+            if isinstance(dst, torch.Tensor):
+                dst.copy_(src, non_blocking=True)
+        self.lr_t.fill_(ops.amsgrad_step_size(opt.current_lr(), opt.iterations + 1, opt.beta_1, opt.beta_2))
+        graph.replay()
+        opt.iterations += 1
+        opt.mark_updated()
+        if flags is not None:               # this step's check_numerics verdicts, shipped like the eager path does
+            model.__dict__.setdefault('_pending_numerics', []).extend(zip(messages, flags.clone().unbind(0)))
+            model.flush_numerics()
+        return total, to_vis

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rays', type=int, default=1024)
+    ap.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (optim.GraphedTrainStep)')
     ap.add_argument('--model', default='nerfactor_microfacet',
                     choices=['nerfactor_microfacet', 'nerfactor', 'shape', 'nerf'])
     args = ap.parse_args()
@@ -54,14 +55,16 @@ def main():
     if args.model == 'nerf':   # rays from the camera towards the unit cube
         batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
     global_bs = n * world
-    for _ in range(args.warmup):
-        optim.train_step(model, batch, opt, global_bs)
+    step = optim.GraphedTrainStep(model, opt, global_bs) if args.graph else (
+        lambda b: optim.train_step(model, b, opt, global_bs))
+    for _ in range(args.warmup + (3 if args.graph else 0)):
+        step(batch)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = optim.train_step(model, batch, opt, global_bs)
+        loss, _ = step(batch)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -73,7 +76,7 @@ def main():
         else:
             flops, what = 3 * 2 * (rows * 72320 + 2 * 3 * n * 65664), "512 lights, jitter on"
         print(json.dumps({
-            "workload": "%s train step, %d rays/GPU (weak), %s" % (args.model, n, what),
+            "workload": "%s train step, %d rays/GPU (weak), %s%s" % (args.model, n, what, ", hipGraph" if args.graph else ""),
             "n_gpus": world, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
             "mlp_flops_per_step_per_gpu": flops, "mlp_tflops": flops / dt / 1e12,
             "final_loss": float(loss)}))

@@ -705,3 +705,82 @@ def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-9), float((a - b).abs().max())
     # deterministic
     assert torch.equal(got, nfx_grad.PairLoss.apply(alpha, bg, spec, rgb_p, rgb_g, lv_p, lv_g, lv_j, r_p, r_j))
+
+
+@pytest.mark.parametrize("name", ["shape", "nerfactor_microfacet"])
+def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name):
+    """optim.GraphedTrainStep (the step captured in a hipGraph and replayed) against optim.train_step: with the jitter
+    off the two are the same kernels in the same order, so losses, parameters and optimizer state after 6 steps on
+    changing batches must agree bit for bit; the version counters move, so an eager vali call afterwards sees the
+    trained weights."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    from nerfactor_amd.nerfactor.models import get_model_class
+    extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if name != 'shape' else {}
+    n = 256
+
+    def batches():
+        rng = np.random.default_rng(7)
+        out = []
+        for _ in range(6):
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+            xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+            nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
+            cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+            out.append((None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+                        mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz, nrm, t(rng.uniform(size=(n, 512)))))
+        return out
+
+    def run(graph):
+        torch.manual_seed(11)
+        cfg = make_config(name, xyz_jitter_std='0', **extra)
+        model = get_model_class(name)(cfg).to(cuda)
+        opt = optim.make_optimizer(model, cfg)
+        step = optim.GraphedTrainStep(model, opt, n, warmup=2) if graph else (lambda b: optim.train_step(model, b, opt, n))
+        losses = [step(b)[0].clone() for b in batches()]
+        model.flush_numerics(block=True)
+        with torch.no_grad():
+            vali = model(batches()[0], mode='vali')[0]
+        return torch.stack(losses), opt.flat.clone(), opt.vhat.clone(), opt.iterations, vali, step
+
+    l0, p0, v0, it0, vali0, _ = run(False)
+    l1, p1, v1, it1, vali1, step = run(True)
+    assert len(step.graphs) == 1 and it0 == it1 == 6
+    assert torch.equal(l0, l1), (l0, l1)     # every gradient is order-independent (ordered wgrad, fixed-point d_light)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    for k in vali0:
+        if isinstance(vali0[k], torch.Tensor):
+            assert torch.equal(vali0[k], vali1[k]), k
+
+
+@pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor"])
+def test_whole_step_gradients_are_bit_reproducible(nfx_lib, cuda, name):
+    """No floating-point atomics are left in the training path (ordered weight-gradient reduction, fixed-point sums
+    for the light gradient in shade_bwd and for d z / d normal in brdf_spec_bwd): the same step run twice from the
+    same state gives identical gradients for every trainable tensor, the light included."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(4)
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='')
+    model = get_model_class(name)(cfg).to(cuda)
+    opt = optim.make_optimizer(model, cfg)
+    rng = np.random.default_rng(9)
+    n = 300
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+    nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+             mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz, nrm, t(rng.uniform(size=(n, 512))))
+    noise = t(rng.normal(size=(n, 3)) * 0.01)
+    grads = []
+    for _ in range(2):
+        opt.zero_grad()
+        pred, gt, kw, _ = model(batch, mode='train', xyz_noise=noise)
+        (model.compute_loss(pred, gt, keep_batch=True, **kw).sum() / n).backward()
+        grads.append(opt.bucket.flat.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert float(model._light.grad.abs().max()) > 0
