@@ -30,6 +30,7 @@ struct WgCall {
 struct WgBatch {
     WgCall c[kWgMaxCalls];
     int n_calls, n_slabs;
+    int wide_only;      // NFX_WGRAD_NARROW=0: the 256 x 256 block form also for narrow GEMMs (A/B)
     long long ld, rows, slab;
 };
 __device__ __forceinline__ int wg_find_call(const WgBatch& b, int block) {
@@ -191,6 +192,157 @@ constexpr int kWlRows = 64;                  // rows per chunk
 constexpr int kWlPitch = 2 * kWlRows + 16;   // bytes per feature row in LDS
 constexpr int kWlTile = 256 * kWlPitch;      // one operand tile
 constexpr int kWlLds = 4 * kWlTile;          // 2 operands x 2 stages = 147456 B
+
+// Narrow GEMMs (k_in, n_out <= 128: every GEMM of a width-128 network): the 256 x 256 block form would leave three of
+// the four waves idle and half of the staging loads empty, i.e. 32 KB in flight per CU — the kernel ran at 2.6 TB/s,
+// bound by memory latency.  Here a chunk is 128 rows (256-byte runs per feature row, 64 KB per chunk and workgroup),
+// every thread stages 8 useful pieces per operand, and the four waves split the chunk's rows (two 16-row k-steps each)
+// accumulating the FULL 128 x 128 block; at the end the four accumulators are added through LDS in a fixed order
+// (1 -> 0, 3 -> 2, 2 -> 0), so the workgroup still writes one partial block and the result stays order-independent.
+constexpr int kWnRows = 128;
+constexpr int kWnPitch = 2 * kWnRows + 16;    // 272 B: conflict-free ds_read_b128 across 16 features
+constexpr int kWnTile = 128 * kWnPitch;       // one operand tile
+static_assert(4 * kWnTile <= kWlLds && 2 * 65536 + 2048 <= kWlLds, "narrow mode fits the LDS of the wide one");
+
+__device__ __forceinline__ void wgrad_lds_narrow(const WgBatch& bt, const WgCall& c, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    const __bf16* __restrict__ xt = c.xt;
+    const __bf16* __restrict__ zt = c.zt;
+    const long long ld = bt.ld;
+    const int k_in = c.k_in, n_out = c.n_out;
+    const long long r0 = (long long)blockIdx.x * bt.slab;
+    long long r1 = r0 + bt.slab;
+    if (r1 > bt.rows) r1 = bt.rows;
+    const int n_chunks = (int)((r1 - r0 + kWnRows - 1) / kWnRows);
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 sx[8], sz[8];   // piece p = i * 256 + tid -> feature p >> 4, 16-byte part (8 rows) p & 15
+    auto load_chunk = [&](long long row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 256 + tid, f = pp >> 4, part = pp & 15;
+            const long long row = row0 + part * 8;
+            const bool rok = row < r1;
+            sx[i] = (f < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + (long long)f * ld + row) : zero4;
+            sz[i] = (f < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + (long long)f * ld + row) : zero4;
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        char* bx = smem + stage * 2 * kWnTile;
+        char* bz = bx + kWnTile;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pp = i * 256 + tid, f = pp >> 4, part = pp & 15;
+            *reinterpret_cast<u32x4*>(bx + f * kWnPitch + part * 16) = sx[i];
+            *reinterpret_cast<u32x4*>(bz + f * kWnPitch + part * 16) = sz[i];
+        }
+    };
+    const bool do_bias = c.db != nullptr;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    load_chunk(r0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        if (ch + 1 < n_chunks) load_chunk(r0 + (long long)(ch + 1) * kWnRows);
+        const char* bx = smem + (ch & 1) * 2 * kWnTile + q * kWnPitch + h * 16;
+        const char* bz = bx + kWnTile;
+#pragma unroll 1
+        for (int ss = 0; ss < 2; ++ss) {   // rolled: 32 fragment registers live next to the 256 accumulators
+            const int s = 2 * wave + ss;   // this wave's two 16-row k-steps of the chunk
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(bx + 32 * i * kWnPitch + s * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bz + 32 * j * kWnPitch + s * 32);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += (float)b[j][e];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (ch + 1 < n_chunks) store_chunk((ch + 1) & 1);
+        __syncthreads();
+    }
+    // ---- the four row-partial accumulators -> wave 0, in a fixed order; slot e of lane l at (e * 64 + l) * 16 bytes
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    float* bred = reinterpret_cast<float*>(smem + 2 * 65536);   // [4 waves][128 columns]
+    auto put = [&](int region) {
+        f32x4* dst = red + region * 4096 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    dst[((i * 4 + j) * 4 + g) * 64] = v;
+                }
+    };
+    auto add = [&](int region) {
+        const f32x4* src = red + region * 4096 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = src[((i * 4 + j) * 4 + g) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += v[e];
+                }
+    };
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sm = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            if (h == 0) bred[wave * 128 + 32 * j + q] = sm;
+        }
+    }
+    if (wave & 1) put(wave >> 1);
+    __syncthreads();
+    if (!(wave & 1)) add(wave >> 1);
+    __syncthreads();
+    if (wave == 2) put(0);
+    __syncthreads();
+    if (wave != 0) return;
+    add(0);
+    if (do_bias && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 32 * j + lane;
+            c.bpart[(long long)blockIdx.x * c.n_pad + col] =
+                ((bred[col] + bred[128 + col]) + bred[256 + col]) + bred[384 + col];
+        }
+    }
+    float* part = c.part + (long long)blockIdx.x * c.k_pad * c.n_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = 32 * j + q;
+                if (row < k_in && col < n_out) part[(long long)row * c.n_pad + col] = acc[i][j][r];
+            }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_lds_narrow_kernel(WgBatch bt) {   // every call: k_in, n_out <= 128
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_lds_narrow(bt, bt.c[wg_find_call(bt, blockIdx.y)], smem);
+}
 
 __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(WgBatch bt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -373,6 +525,10 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
     bt.n_calls = n_calls;
     bt.ld = ld;
     bt.rows = rows;
+    {
+        const char* en = getenv("NFX_WGRAD_NARROW");
+        bt.wide_only = en && atoi(en) == 0;
+    }
     const int bs = lds ? 256 : 128;
     float* p = static_cast<float*>(partial);
     int blocks = 0;
@@ -398,7 +554,15 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
         const long long el = (long long)c.k_in * c.n_out + c.n_out;
         if (el > max_elems) max_elems = el;
     }
-    if (lds) {
+    bool all_narrow = !bt.wide_only;
+    for (int i = 0; i < n_calls; ++i) all_narrow = all_narrow && calls[i].k_in <= 128 && calls[i].n_out <= 128;
+    if (lds && all_narrow) {   // width-128 networks: 128-row chunks, the four waves split the rows (wgrad_lds_narrow)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::wgrad_lds_narrow_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, nfx::kWlLds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nfx::wgrad_lds_narrow_kernel, dim3((unsigned)bt.n_slabs, (unsigned)blocks), dim3(256),
+                           nfx::kWlLds, st, bt);
+    } else if (lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::wgrad_lds_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, nfx::kWlLds);
         if (e != hipSuccess) return (int)e;
