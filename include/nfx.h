@@ -95,6 +95,10 @@ int nfx_mlp128_pack_weights(const float *const kernels[5], const float *const bi
  * eps = 1e-12; shape.py:131,140 use eps = 1e-6 via util/math.py:63-64).      */
 int nfx_l2_normalize3(const float *dev_in, float *dev_out, int64_t n, float eps, void *stream);
 
+/* tf.debugging.check_numerics (nerfactor.py:205-233, shape.py:222-232, ...) in one pass: ORs 1 into *dev_flag (an
+ * int32 the caller zeroed) if any of the n floats is Inf or NaN.  dev_x must be 16-byte aligned.               */
+int nfx_any_nonfinite(const float *dev_x, int64_t n, int *dev_flag, void *stream);
+
 /* Stratified depths, Model.gen_z (nerf.py:120-136).  z [n_rays, n_samples].
  * dev_u: NULL (no perturbation) or uniform [0,1) randoms [n_rays, n_samples]
  * drawn by the caller (the reference draws them with tf.random.uniform).     */

@@ -43,6 +43,7 @@ int nfx_launch_nerf_mlp_x3(const float*, const float*, const float*, long long, 
 int nfx_launch_nerf_mlp_bf16_v6(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                 int, hipStream_t);
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
+int nfx_launch_nonfinite(const float*, long long, int*, hipStream_t);
 int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
 int nfx_launch_composite(const float*, const float*, const float*, const float*, long long, int, int,
                          float*, float*, float*, float*, float*, hipStream_t);
@@ -148,6 +149,15 @@ int nfx_l2_normalize3(const float* in, float* out, int64_t n, float eps, void* s
     REQUIRE(n >= 0, "nfx_l2_normalize3: n < 0");
     REQUIRE(n == 0 || (in && out), "nfx_l2_normalize3: null pointer");
     return hip_result(nfx_launch_l2_normalize3(in, out, n, eps, (hipStream_t)stream), "l2_normalize3");
+}
+
+int nfx_any_nonfinite(const float* x, int64_t n, int* flag, void* stream) {
+    REQUIRE(n >= 0, "nfx_any_nonfinite: n < 0");
+    REQUIRE(flag, "nfx_any_nonfinite: null flag");
+    if (n == 0) return NFX_OK;
+    REQUIRE(x, "nfx_any_nonfinite: null tensor");
+    if (!ALIGNED(x, 16)) return nfx_fail(NFX_EALIGN, "nfx_any_nonfinite: tensor must be 16-byte aligned");
+    return hip_result(nfx_launch_nonfinite(x, n, flag, (hipStream_t)stream), "any_nonfinite");
 }
 
 int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp, const float* u,

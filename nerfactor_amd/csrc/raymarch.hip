@@ -362,3 +362,32 @@ int nfx_launch_composite_bwd(const float* rgbs, const float* z, const float* ray
     return (int)hipGetLastError();
 }
 }
+
+namespace nfx {
+// tf.debugging.check_numerics as ONE pass over the tensor (torch.isfinite(x).all() is abs + compare + reduce with two
+// full-size temporaries — 1.1 ms per 800 x 800 NeRFactor view for the [n, 512] visibilities alone): ORs 1 into *flag
+// if any element has an all-ones exponent.  16-byte loads, grid-stride.
+__global__ __launch_bounds__(256) void nonfinite_kernel(const unsigned* __restrict__ x, long long n, int* __restrict__ flag) {
+    const long long n4 = n / 4;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint4 v = x4[i];
+        bad = bad || (v.x & 0x7f800000u) == 0x7f800000u || (v.y & 0x7f800000u) == 0x7f800000u ||
+              (v.z & 0x7f800000u) == 0x7f800000u || (v.w & 0x7f800000u) == 0x7f800000u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4))
+        bad = bad || (x[4 * n4 + threadIdx.x] & 0x7f800000u) == 0x7f800000u;
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace nfx
+
+extern "C" int nfx_launch_nonfinite(const float* x, long long n, int* flag, hipStream_t st) {
+    if (n <= 0) return 0;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nfx::nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned*>(x), n, flag);
+    return (int)hipGetLastError();
+}

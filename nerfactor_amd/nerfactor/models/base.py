@@ -82,7 +82,10 @@ class Model(torch.nn.Module):
         (a training step) the verdict stays on the device and is raised by flush_numerics() — called by
         optim.train_step at the start of the following steps and, blocking, by the drivers at the end of an epoch — so
         that a step enqueues all of its kernels without a host round trip."""
-        ok = torch.isfinite(tensor).all()
+        if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.data_ptr() % 16 == 0:
+            ok = ops.all_finite(tensor.detach())      # one pass, no full-size temporaries
+        else:
+            ok = torch.isfinite(tensor).all()
         if torch.is_grad_enabled():
             self.__dict__.setdefault('_pending_numerics', []).append((message, ok))
         elif not bool(ok):

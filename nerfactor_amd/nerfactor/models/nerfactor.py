@@ -332,8 +332,8 @@ class Model(ShapeModel):
                 keep = [i * self.light_res[1] + j for (i, j) in self.novel_olat.values()]
                 rgb_olat = rgb_olat[:, keep]
         for name, v in (("OLAT Renders", rgb_olat), ("Light Probe Renders", rgb_probes)):
-            if v is not None and not torch.isfinite(v).all():
-                raise FloatingPointError(name)
+            if v is not None:
+                self.check_numerics(v, name)
         return rgb, rgb_olat, rgb_probes
 
     def _render_train(self, xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb):

@@ -163,6 +163,14 @@ def l2_normalize3(x, eps):
     return out
 
 
+def all_finite(x):
+    """0-dim bool CUDA tensor: no Inf / NaN in the fp32 tensor `x` (one read of x; tf.debugging.check_numerics)."""
+    x = _dev(x, 'x')
+    flag = torch.zeros((), dtype=torch.int32, device=x.device)
+    check(lib.nfx_any_nonfinite(_ptr(x), x.numel(), _ptr(flag), _stream()), 'nfx_any_nonfinite')
+    return flag == 0
+
+
 def gen_z(near, far, n_samples, n_rays, lin_in_disp=False, u=None, device='cuda'):
     u = _dev(u, 'u', (n_rays, n_samples))
     z = torch.empty((n_rays, n_samples), dtype=torch.float32, device=device)

@@ -402,3 +402,20 @@ def test_eval_brdf_at_has_the_reference_signature(nfx_lib, cuda):
                           brdf_net, 1.)
     # the prior itself runs on the fused bf16 template (nfx_brdf_rows_fwd) in both routes: bf16 bound against fp64
     assert np.abs(a.cpu().numpy() - want)[stable.cpu().numpy()].max() < 3e-2 * max(1., float(want.max()))
+
+
+def test_all_finite_kernel(nfx_lib, cuda):
+    """nfx_any_nonfinite (check_numerics in one pass) against torch.isfinite(x).all(): clean tensors of awkward sizes,
+    one NaN / +Inf / -Inf anywhere including the scalar tail, empty tensors."""
+    from nerfactor_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for n in (0, 1, 3, 4, 5, 1023, 4096, 1000003):
+        x = (torch.randn(n, generator=g) * 1e30).to(cuda)
+        assert bool(ops.all_finite(x)) == bool(torch.isfinite(x).all())
+        for pos, bad in ((0, float('nan')), (n - 1, float('inf')), (n // 2, float('-inf'))):
+            if n == 0:
+                continue
+            y = x.clone()
+            y[pos] = bad
+            assert not bool(ops.all_finite(y)), (n, pos)
+    assert bool(ops.all_finite(torch.full((70,), 3.4e38, device=cuda)))          # the largest finite float
