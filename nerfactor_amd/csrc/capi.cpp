@@ -226,6 +226,7 @@ int nfx_composite_fwd(const float* rgbs, const float* z, const float* rayd, cons
 int nfx_sample_fine(const float* z, const float* weights, int64_t n_rays, int n_coarse, int n_fine,
                     const float* u, float* z_all, void* stream) {
     REQUIRE(n_rays >= 0, "nfx_sample_fine: n_rays < 0");
+    REQUIRE(n_coarse <= 258, "nfx_sample_fine: at most 258 coarse samples (256 pdf bins), got %d", n_coarse);
     REQUIRE(n_coarse >= 3 && n_fine >= 2, "nfx_sample_fine: need n_coarse >= 3 and n_fine >= 2 (got %d, %d)",
             n_coarse, n_fine);
     REQUIRE((size_t)4 * (2 * (n_coarse - 1) + n_coarse + n_fine) * 4 <= 64 * 1024,

@@ -234,24 +234,40 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(
 
     for (int i = lane; i < nc; i += 64) zall[i] = zr[i];
     for (int i = lane; i < ncdf; i += 64) mid[i] = 0.5f * (zr[i + 1] + zr[i]);  // nerf.py:140
-    // util/math.py:72-76 with the oracle's summation order (sequential, left to right); only the two running sums are
-    // serial — the nb divisions run across the wave
+    // util/math.py:72-76 with the oracle's summation order (sequential, left to right).  The two running sums are serial
+    // by definition; they run on values held one per lane (weights loaded in parallel, element i fetched with a
+    // wave-uniform readlane) instead of lane 0 walking global memory / LDS one dependent access at a time — r01: 12 k
+    // cycles per ray, 1.35 ms per 640 000 rays.  Up to 4 x 64 bins.
+    constexpr int kMaxSeg = 4;
+    float wv[kMaxSeg];
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; ++k) wv[k] = (64 * k + lane < nb) ? wr[1 + 64 * k + lane] : 0.f;
     float denom = 0.f;
-    if (lane == 0) {
-        for (int i = 0; i < nb; ++i) denom += wr[1 + i];
-        denom += 1e-5f;
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; ++k) {
+        const int cnt = nb - 64 * k < 64 ? nb - 64 * k : 64;
+        for (int i = 0; i < cnt; ++i) denom += __shfl(wv[k], i, 64);
     }
-    denom = __shfl(denom, 0, 64);
-    for (int i = lane; i < nb; i += 64) cdf[1 + i] = wr[1 + i] / denom;   // pdf, turned into the cdf in place below
-    __syncthreads();
-    if (lane == 0) {
-        float acc = 0.f;
-        cdf[0] = 0.f;
-        for (int i = 0; i < nb; ++i) {
-            acc += cdf[1 + i];
-            cdf[1 + i] = acc;
+    denom += 1e-5f;
+    float pdf[kMaxSeg], cv[kMaxSeg];
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; ++k) {
+        pdf[k] = wv[k] / denom;
+        cv[k] = 0.f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; ++k) {
+        const int cnt = nb - 64 * k < 64 ? nb - 64 * k : 64;
+        for (int i = 0; i < cnt; ++i) {
+            acc += __shfl(pdf[k], i, 64);
+            if (lane == i) cv[k] = acc;
         }
     }
+    if (lane == 0) cdf[0] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; ++k)
+        if (64 * k + lane < nb) cdf[1 + 64 * k + lane] = cv[k];
     __syncthreads();
     for (int i = lane; i < nf; i += 64) {
         const float uu = u ? u[rc * nf + i] : linspace01(i, nf);

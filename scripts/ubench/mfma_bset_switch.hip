@@ -15,6 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NT = 16;   // tiles: X X X X Y Y Y Y X X X X Y Y Y Y
 
+// MODE 5 / 6: as 0, but Y receives NEW VALUES (converted from the accumulators) before some of its tiles.
 // MODE 0: X, Y in ArchVGPRs; 1: X Arch, Y Acc; 2: X, Y in AccVGPRs; 3: as 2, Y rewritten (v_accvgpr_write) before its
 // first tile of the second round; 4: as 0 with a single set (no switch) as the control
 template <int MODE>
@@ -52,6 +53,16 @@ __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, unsigne
                     by[s][c] = __builtin_bit_cast(bf16x8, v);
                 }
         }
+        if ((MODE == 5 && tile == 12) || (MODE == 6 && (tile == 5 || tile == 6 || tile == 12 || tile == 13))) {
+            // NEW VALUES in Y (not the same bits written again): converted from floats, as an epilogue would
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        by[s][c][j] = (__bf16)(acc[c][(j + s + tile) & 15] * 1e-3f + (float)by[s][c][j] * 0.5f);
+        }
         __builtin_amdgcn_sched_barrier(0);
         ts[tile] = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
@@ -60,10 +71,10 @@ __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, unsigne
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (!useY) {
-                    if (MODE >= 2 && MODE != 4) MFMA_A(acc[c], a[s], bx[s][c]);
+                    if (MODE >= 2 && MODE < 4) MFMA_A(acc[c], a[s], bx[s][c]);
                     else MFMA_V(acc[c], a[s], bx[s][c]);
                 } else {
-                    if (MODE >= 1) MFMA_A(acc[c], a[s], by[s][c]);
+                    if (MODE >= 1 && MODE < 5) MFMA_A(acc[c], a[s], by[s][c]);
                     else MFMA_V(acc[c], a[s], by[s][c]);
                 }
             }
@@ -103,5 +114,7 @@ int main() {
     run<1>(in, out, t, "X Arch, Y Acc");
     run<2>(in, out, t, "X Acc, Y Acc");
     run<3>(in, out, t, "X Acc, Y Acc, Y rewritten before tile 12");
+    run<5>(in, out, t, "X Arch, Y Arch, Y gets NEW VALUES (from the accumulators) before tile 12");
+    run<6>(in, out, t, "X Arch, Y Arch, Y gets new values before tiles 5, 6, 12, 13");
     return 0;
 }
