@@ -425,9 +425,38 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
                                                 const float (&nr)[3], const float* zp, int z_dim, int h,
                                                 float (&v)[16]) {
     float ldir[3], vdir[3], rot[9], ll[3], vl[3];
-    dir_to(lp, x, ldir);          // shape.py:128-131
-    dir_to(cm, x, vdir);          // shape.py:137-140
-    world2local(nr, rot);         // util/geom.py:119-149
+    if constexpr (GEO == 0) {
+        dir_to(lp, x, ldir);          // shape.py:128-131
+        dir_to(cm, x, vdir);          // shape.py:137-140
+        world2local(nr, rot);         // util/geom.py:119-149
+    } else {
+        // same formulas with v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences (~22 instructions per
+        // normalisation, eight of them per row, executed at dependent-issue latency by a lone wave)
+        auto nrm = [](float (&v)[3]) {
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(dot3(v, v), 1e-6f));
+            v[0] *= inv; v[1] *= inv; v[2] *= inv;
+        };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ldir[k] = lp[k] - x[k];
+            vdir[k] = cm[k] - x[k];
+        }
+        nrm(ldir);
+        nrm(vdir);
+        float n[3] = {nr[0], nr[1], nr[2]}, t[3], b[3];
+        nrm(n);
+        const float zax[3] = {0.0f + 1e-6f, 0.0f + 1e-6f, 1.0f + 1e-6f};   // geom.py:128
+        cross3(n, zax, t);
+        nrm(t);
+        cross3(n, t, b);
+        nrm(b);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rot[k] = t[k];
+            rot[3 + k] = b[k];
+            rot[6 + k] = n[k];
+        }
+    }
     mat3_apply(rot, ldir, ll);    // nerfactor.py:418-419
     mat3_apply(rot, vdir, vl);
     if constexpr (GEO == 0) {
@@ -438,10 +467,14 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
         v[6] = h ? rus[2] : rus[0];
         v[7] = h ? zp[0] : rus[1];
     } else {
-        normalize3(ll, 1e-6f);    // dir2rusink re-normalises its inputs (geom.py:158-159)
-        normalize3(vl, 1e-6f);
-        float hv[3] = {(ll[0] + vl[0]) / 2.0f, (ll[1] + vl[1]) / 2.0f, (ll[2] + vl[2]) / 2.0f};
-        normalize3(hv, 1e-6f);
+        auto nrm = [](float (&v)[3]) {
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(dot3(v, v), 1e-6f));
+            v[0] *= inv; v[1] *= inv; v[2] *= inv;
+        };
+        nrm(ll);                  // dir2rusink re-normalises its inputs (geom.py:158-159)
+        nrm(vl);
+        float hv[3] = {(ll[0] + vl[0]) * 0.5f, (ll[1] + vl[1]) * 0.5f, (ll[2] + vl[2]) * 0.5f};
+        nrm(hv);
         const float cth = fminf(fmaxf(hv[2], -1.0f), 1.0f);
         const float sxy = sqrtf(hv[0] * hv[0] + hv[1] * hv[1]);           // sin(theta_h) >= 0
         const float inv = sxy > 0.0f ? __builtin_amdgcn_rcpf(sxy) : 0.0f;
@@ -475,6 +508,68 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
         const int i = 1 + 2 * j + h;
         v[8 + j] = i < z_dim ? zp[i] : 0.0f;
     }
+}
+
+// The closed-form geometry of ONE (point, light) row with the values of BOTH lane halves: S[q] is what the half-0 lane
+// of the row's column puts into input slot q (sines, phi_d, theta_h), C[q] what the half-1 lane does (cosines, theta_d;
+// slot 7 of half 1 is z_0, loaded by the caller).  brdf_compact_kernel lets the half-0 lane of column p compute the row
+// of column tile 2k and the half-1 lane the row of tile 2k + 1, and swaps halves with v_permlane32_swap: each lane
+// runs the geometry of CT / 2 rows instead of CT (the two halves used to compute the same row twice).
+__device__ __forceinline__ void brdf_row_geometry(const float (&x)[3], const float (&lp)[3], const float (&cm)[3],
+                                                  const float (&nr)[3], float (&S)[8], float (&C)[8]) {
+    auto nrm = [](float (&v)[3]) {
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(dot3(v, v), 1e-6f));
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    };
+    float ldir[3], vdir[3], rot[9], ll[3], vl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ldir[k] = lp[k] - x[k];
+        vdir[k] = cm[k] - x[k];
+    }
+    nrm(ldir);
+    nrm(vdir);
+    float n[3] = {nr[0], nr[1], nr[2]}, t[3], b[3];
+    nrm(n);
+    const float zax[3] = {0.0f + 1e-6f, 0.0f + 1e-6f, 1.0f + 1e-6f};   // geom.py:128
+    cross3(n, zax, t);
+    nrm(t);
+    cross3(n, t, b);
+    nrm(b);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rot[k] = t[k];
+        rot[3 + k] = b[k];
+        rot[6 + k] = n[k];
+    }
+    mat3_apply(rot, ldir, ll);
+    mat3_apply(rot, vdir, vl);
+    nrm(ll);
+    nrm(vl);
+    float hv[3] = {(ll[0] + vl[0]) * 0.5f, (ll[1] + vl[1]) * 0.5f, (ll[2] + vl[2]) * 0.5f};
+    nrm(hv);
+    const float cth = fminf(fmaxf(hv[2], -1.0f), 1.0f);
+    const float sxy = sqrtf(hv[0] * hv[0] + hv[1] * hv[1]);
+    const float inv = sxy > 0.0f ? __builtin_amdgcn_rcpf(sxy) : 0.0f;
+    const float cph = sxy > 0.0f ? hv[0] * inv : 1.0f, sph = hv[1] * inv;
+    const float t0 = vl[0] * cph + vl[1] * sph, t1 = vl[1] * cph - vl[0] * sph;
+    const float d0 = t0 * cth - vl[2] * sxy, d1 = t1, d2 = vl[2] * cth + t0 * sxy;
+    const float ctd = fminf(fmaxf(d2, -1.0f), 1.0f);
+    const float rxy = sqrtf(d0 * d0 + d1 * d1);
+    const float theta_h = acos_poly(cth), theta_d = acos_poly(ctd);
+    const float pi = 3.14159265358979323846f;
+    float phi_d = atan2_poly(d1, d0);
+    phi_d = phi_d - floorf(phi_d / pi) * pi;
+    const float rinv = rxy > 0.0f ? __builtin_amdgcn_rcpf(rxy) : 0.0f;
+    const bool flip = d1 < 0.0f || (d1 == 0.0f && d0 < 0.0f);
+    const float cpd0 = rxy > 0.0f ? d0 * rinv : 1.0f, spd0 = d1 * rinv;
+    const float cpd = flip ? -cpd0 : cpd0, spd = flip ? -spd0 : spd0;
+    S[0] = spd; S[1] = sxy; S[2] = rxy;
+    S[3] = 2.0f * spd * cpd; S[4] = 2.0f * sxy * cth; S[5] = 2.0f * rxy * ctd;
+    S[6] = phi_d; S[7] = theta_h;
+    C[0] = cpd; C[1] = cth; C[2] = ctd;
+    C[3] = cpd * cpd - spd * spd; C[4] = cth * cth - sxy * sxy; C[5] = ctd * ctd - rxy * rxy;
+    C[6] = theta_d; C[7] = 0.0f;
 }
 
 // NW = 4: one wave per SIMD (CT = 2 | 3 | 4) — the only shipped form.
@@ -550,29 +645,82 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         // ---- pass: CT column tiles of 32 queued rows
         bf16x8 pl[2][CT];
         long long orow[CT];
+        long long rpt[CT];
+        int rl[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int r = c * 32 + p;
             const bool ok = r < rows;
             const unsigned e = ring[ring_wrap(head + (ok ? r : 0), kCap)];
             const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);   // slot -> local point index
-            const long long pt = gw + kk * nw;
-            const int l = (int)(e & 1023u);
-            orow[c] = ok ? pt * L + l : -1;
-            float x[3], lp[3], cm[3], nr[3];
+            rpt[c] = gw + kk * nw;
+            rl[c] = (int)(e & 1023u);
+            orow[c] = ok ? rpt[c] * L + rl[c] : -1;
+        }
+        if constexpr (GEO == 1 && CT % 2 == 0) {
+            // lane half h runs the geometry of the row of column tile 2k + h; one v_permlane32_swap per input slot
+            // hands each half its own values of both rows (brdf_row_geometry)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                x[k] = a.xyz[pt * 3 + k];
-                lp[k] = a.lxyz[l * 3 + k];
-                cm[k] = a.cam[pt * 3 + k];
-                nr[k] = a.normal[pt * 3 + k];
+            for (int k2 = 0; k2 < CT; k2 += 2) {
+                const long long pt = h ? rpt[k2 + 1] : rpt[k2];
+                const int l = h ? rl[k2 + 1] : rl[k2];
+                float x[3], lp[3], cm[3], nr[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    x[k] = a.xyz[pt * 3 + k];
+                    lp[k] = a.lxyz[l * 3 + k];
+                    cm[k] = a.cam[pt * 3 + k];
+                    nr[k] = a.normal[pt * 3 + k];
+                }
+                float S[8], C[8];
+                brdf_row_geometry(x, lp, cm, nr, S, C);
+                float v[2][16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    // S = [half 0: S(row 2k) ; half 1: S(row 2k+1)], C likewise; swap(S.hi, C.lo):
+                    //   first  = [S(row 2k) ; C(row 2k)]     = slot q of column tile 2k for both halves
+                    //   second = [S(row 2k+1) ; C(row 2k+1)] = slot q of column tile 2k + 1
+                    float first = S[q], second = C[q];
+                    // (s_nop 1: the two wait states a VALU write of either operand needs before the swap reads it)
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(first), "+v"(second));
+                    v[0][q] = first;
+                    v[1][q] = second;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const float* zp = a.z + rpt[k2 + cc] * a.z_dim;
+                    if (h) v[cc][7] = zp[0];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 1 + 2 * j + h;
+                        v[cc][8 + j] = i < a.z_dim ? zp[i] : 0.0f;
+                    }
+#pragma unroll
+                    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pl[sidx][k2 + cc][j] = (__bf16)v[cc][8 * sidx + j];
+                }
             }
-            float v[16];
-            brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, h, v);
+        } else {
 #pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx)
+            for (int c = 0; c < CT; ++c) {
+                const long long pt = rpt[c];
+                const int l = rl[c];
+                float x[3], lp[3], cm[3], nr[3];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+                for (int k = 0; k < 3; ++k) {
+                    x[k] = a.xyz[pt * 3 + k];
+                    lp[k] = a.lxyz[l * 3 + k];
+                    cm[k] = a.cam[pt * 3 + k];
+                    nr[k] = a.normal[pt * 3 + k];
+                }
+                float v[16];
+                brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, h, v);
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+            }
         }
         bf16x8 ha[8][CT], hb[8][CT];
         Acc<CT> accs[2];
