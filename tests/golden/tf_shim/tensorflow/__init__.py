@@ -199,8 +199,8 @@ def range(start, limit=None, delta=1, dtype=None):  # noqa: A001
     return _t(a, dtype)
 
 
-def meshgrid(*args):
-    return [_t(g) for g in _np.meshgrid(*args)]
+def meshgrid(*args, indexing='xy'):
+    return [_t(g) for g in _np.meshgrid(*args, indexing=indexing)]
 
 
 def roll(x, shift, axis):

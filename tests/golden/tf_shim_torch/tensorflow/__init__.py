@@ -164,8 +164,8 @@ def range(start, limit=None, delta=1, dtype=None):  # noqa: A001
     return _t(a, dtype)
 
 
-def meshgrid(*args):
-    return list(_torch.meshgrid(*[_t(a) for a in args], indexing='xy'))
+def meshgrid(*args, indexing='xy'):
+    return list(_torch.meshgrid(*[_t(a) for a in args], indexing=indexing))
 
 
 def roll(x, shift, axis):
@@ -462,7 +462,10 @@ class _Random:
         self._rng = _np.random.default_rng(seed)
 
     def uniform(self, shape, minval=0., maxval=1., dtype=float32):  # noqa: A002
-        return _t((self._rng.random(_ints(shape)) * (maxval - minval) + minval).astype(_np.float32))
+        x = self._rng.random(_ints(shape)) * (maxval - minval) + minval
+        if dtype in (int32, int64):      # integer draws lie in [minval, maxval) (datasets/nerf.py:123)
+            return _t(_np.floor(x).astype(_np.int32 if dtype == int32 else _np.int64))
+        return _t(x.astype(_np.float32))
 
     def normal(self, shape, mean=0., stddev=1., dtype=float32):  # noqa: A002
         return _t((self._rng.standard_normal(_ints(shape)) * stddev + mean).astype(_np.float32))
