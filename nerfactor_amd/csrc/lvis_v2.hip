@@ -593,8 +593,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.blob);
         u32x4* dst = reinterpret_cast<u32x4*>(smem);
         for (int i = tid; i < kLdsNet / 16; i += kNW * 64) dst[i] = src[i];
+        // the light positions too (<= 12 KiB): the queue fill classifies all of them for every point, and a pass
+        // gathers one per row — LDS reads instead of global loads with a vmcnt(0) per 64 lights
+        float* ldst = reinterpret_cast<float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t));
+        for (int i = tid; i < 3 * a.n_lights; i += kNW * 64) ldst[i] = a.lxyz[i];
         __syncthreads();
     }
+    const float* lx = reinterpret_cast<const float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t));
     const char* wlds = smem;
     const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
     constexpr int kCap = kRing;
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 const int l = l0 + lane;
                 const bool valid = l < L;
                 const int lc = valid ? l : L - 1;
-                const float lp[3] = {a.lxyz[lc * 3], a.lxyz[lc * 3 + 1], a.lxyz[lc * 3 + 2]};
+                const float lp[3] = {lx[lc * 3], lx[lc * 3 + 1], lx[lc * 3 + 2]};
                 float ldir[3], ll[3];
                 dir_to(lp, x, ldir);
                 mat3_apply(rot, ldir, ll);
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     x[k] = a.xyz[pt * 3 + k];
-                    lp[k] = a.lxyz[l * 3 + k];
+                    lp[k] = lx[l * 3 + k];
                     cm[k] = a.cam[pt * 3 + k];
                     nr[k] = a.normal[pt * 3 + k];
                 }
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     x[k] = a.xyz[pt * 3 + k];
-                    lp[k] = a.lxyz[l * 3 + k];
+                    lp[k] = lx[l * 3 + k];
                     cm[k] = a.cam[pt * 3 + k];
                     nr[k] = a.normal[pt * 3 + k];
                 }
@@ -814,7 +819,8 @@ static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t s
     using namespace nfx;
     const long long want = (a.n + NW - 1) / NW;       // at least one point per wave
     const int grid = (int)(want < max_blocks ? want : max_blocks);
-    constexpr int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t);
+    const int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t) + (a.n_lights * 12 + 15) / 16 * 16;
+    if (lds > 160 * 1024) return -1;   // (the caller falls back to the dense kernel)
     auto k = lv2::brdf_compact_kernel<CT, GEO, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
