@@ -190,3 +190,21 @@ def test_rays_within_view_sharding_stitches_the_one_rank_image(tmp_path):
     assert files == sorted(os.path.relpath(os.path.join(d, f), two) for d, _, fs in os.walk(two) for f in fs)
     for f in files:
         assert open(os.path.join(one, f), 'rb').read() == open(os.path.join(two, f), 'rb').read(), f
+
+
+def test_graphed_step_only_captures_static_single_process_batches():
+    """optim.GraphedTrainStep captures a step only when nothing in it depends on data-dependent shapes: batches whose
+    alpha the dataset tagged foreground-only (or NeRF batches, which have no compaction), single process."""
+    import types
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    opt = types.SimpleNamespace(flat=torch.zeros(4))
+    g = optim.GraphedTrainStep(model=None, optimizer=opt, global_bs=8)
+    n = 8
+    surf = lambda alpha: (None, None, torch.zeros(n, 3), torch.zeros(n, 3), torch.zeros(n, 3), alpha, torch.zeros(n, 3),
+                          torch.zeros(n, 3), torch.zeros(n, 16))
+    assert not g._capturable(surf(torch.ones(n, 1)))                        # untagged: may hold background rays
+    assert g._capturable(surf(mark_all_foreground(torch.ones(n, 1))))
+    assert g._capturable((None, None, torch.zeros(n, 3), torch.zeros(n, 3), torch.zeros(n, 3)))   # NeRF batch
+    a, b = surf(mark_all_foreground(torch.ones(n, 1))), surf(mark_all_foreground(torch.ones(n, 1)))
+    assert g._key(a) == g._key(b) and g._key(a) != g._key(surf(mark_all_foreground(torch.ones(4, 1))))
