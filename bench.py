@@ -454,11 +454,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
+    # NFX_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo — exercises the whole N > 1 code path (sharding, barriers,
+    # max over ranks, rank-0 assembly) on a one-GPU box; the numbers mean nothing (the ranks share one GPU)
+    rehearsal = os.environ.get('NFX_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     from nerfactor_amd import dist as nfx_dist
-    nfx_dist.init_from_env(backend='nccl', device=dev)
+    nfx_dist.init_from_env(backend='gloo' if rehearsal else 'nccl', device=None if rehearsal else dev)
     from nerfactor_amd import build
     build.build()
     from nerfactor_amd import ops
@@ -480,6 +485,8 @@ def main():
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic"}
+        if rehearsal:
+            out["rehearsal"] = "all ranks share GPU 0 over gloo: a functional check of the N > 1 path, not a measurement"
         if nerf is not None:   # (profiling runs may time the NeRFactor legs alone: --legs nerfactor)
             out.update(nerf)
             if "parity" in nerf:
