@@ -456,7 +456,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
     # NFX_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo — exercises the whole N > 1 code path (sharding, barriers,
     # max over ranks, rank-0 assembly) on a one-GPU box; the numbers mean nothing (the ranks share one GPU)
-    rehearsal = os.environ.get('NFX_BENCH_REHEARSAL') == '1'
+    rehearsal = os.environ.get('NFX_BENCH_REHEARSAL') == '1' or os.environ.get('NFX_REHEARSAL') == '1'
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -15,6 +15,12 @@ import torch
 import torch.distributed as dist
 
 
+def rehearsal():
+    """NFX_REHEARSAL=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo — a functional
+    check of the multi-process paths (sharded rendering, parameter broadcast, the gradient bucket) on a one-GPU box."""
+    return os.environ.get('NFX_REHEARSAL') == '1'
+
+
 def init_from_env(backend=None, device=None):
     """Initialise the default process group from torchrun's environment; returns (rank, world)."""
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -22,6 +28,8 @@ def init_from_env(backend=None, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        if rehearsal():
+            backend, device = 'gloo', None
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kwargs = {}
@@ -115,7 +123,7 @@ def broadcast_model(model, optimizer=None, src=0):
 
 def local_device():
     """cuda:<LOCAL_RANK> (one process per GPU), made current."""
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    dev = torch.device('cuda', 0 if rehearsal() else int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev)
     return dev
 

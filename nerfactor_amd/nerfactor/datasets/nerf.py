@@ -53,7 +53,10 @@ class Dataset(BaseDataset):
             raise ValueError("Samples per pixel must be a square number")
         self.sps = int(sps)
         self.always_all_rays = always_all_rays
-        self._rng = np.random.default_rng()
+        # ray / row sampling: seeded from the config (`seed`, default 0) so that every rank of a multi-process run draws
+        # the SAME batch — the ranks then take disjoint shards of one global batch, as MirroredStrategy distributes one
+        # dataset element (trainvali.py:85,100) — and a run is reproducible (the reference's tf.random draws are not)
+        self._rng = np.random.default_rng([config.getint('DEFAULT', 'seed', fallback=0), len(mode)])
         super().__init__(config, mode, debug=debug, device=device)
 
     def _get_batch_size(self):
