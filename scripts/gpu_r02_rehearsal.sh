@@ -47,3 +47,30 @@ for f in ims:
     worst = max(worst, int(np.abs(x - y).max()))
 print('test renders: %d views, max |uint8 diff| between the two trained models %d' % (len(ims), worst))
 PY
+# ---- stage 1 / 2 of the workflow: a NeRF trained once (one process), then nerf_test and geometry_from_nerf by one
+# process and by two ranks (rays of every view split over the ranks; float maps written by both ranks into one
+# memory-mapped file, uint8 previews gathered on rank 0)
+OVN="data_root=$S/data,imh=24,n_rays_per_step=128,vali_batches=1,vis_train_batches=1,epochs=2,ckpt_period=2,vali_period=2,n_samples_coarse=16,n_samples_fine=32,lr=5e-4,outroot=$S/out_nerf"
+python -m nerfactor_amd.nerfactor.trainvali --config=nerf.ini --config_override="$OVN" > $OUT/train_nerf.log 2>&1 || { echo "nerf trainvali FAILED"; tail -5 $OUT/train_nerf.log; }
+geo() {  # name, launcher...
+  local name=$1; shift
+  "$@" -m nerfactor_amd.nerfactor.geometry_from_nerf --trained_nerf=$S/out_nerf/lr5e-4 --out_root=$S/surf_$name --lvis_far=1 --scene_bbox=-1.5,1.5,-1.5,1.5,-1.5,1.5 > $OUT/geo_$name.log 2>&1 || { echo "geometry_from_nerf $name FAILED"; tail -5 $OUT/geo_$name.log; }
+}
+geo one python
+NFX_REHEARSAL=1 geo two python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519
+python - <<PY
+import glob, numpy as np
+from PIL import Image
+views = sorted(glob.glob('$S/surf_one/*/xyz.npy'))
+worst = {}
+for f in views:
+    for name in ('xyz.npy', 'normal.npy', 'lvis.npy'):
+        a, b = np.load(f.replace('xyz.npy', name)), np.load(f.replace('surf_one', 'surf_two').replace('xyz.npy', name))
+        assert a.shape == b.shape, (f, name, a.shape, b.shape)
+        worst[name] = max(worst.get(name, 0.), float(np.abs(a - b).max()))
+    for name in ('alpha.png', 'normal.png', 'lvis.png'):
+        a = np.asarray(Image.open(f.replace('xyz.npy', name))).astype(int)
+        b = np.asarray(Image.open(f.replace('surf_one', 'surf_two').replace('xyz.npy', name))).astype(int)
+        worst[name] = max(worst.get(name, 0), int(np.abs(a - b).max()))
+print('geometry_from_nerf, %d views, one process vs two ranks: max |diff|' % len(views), worst)
+PY
