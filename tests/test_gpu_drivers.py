@@ -178,3 +178,47 @@ def test_nerf_test_driver(nfx_lib, cuda, scene, tmp_path):
     out = nerf_test.main(['--ckpt=' + join(outdir, 'checkpoints', 'ckpt-1')])
     bdirs = sorted(glob.glob(join(out, 'batch?????????')))
     assert len(bdirs) == 3 and exists(join(bdirs[0], 'fine_rgb.png')) and exists(join(bdirs[1], 'coarse_rgb.png'))
+
+
+def test_two_ranks_reproduce_the_one_process_training_and_render(nfx_lib, cuda, scene):
+    """The multi-process paths end to end on this one GPU (NFX_REHEARSAL=1: both ranks on GPU 0, collectives over gloo):
+    trainvali — parameters broadcast from rank 0, every batch sharded over the ranks, one [gradients | loss] all-reduce
+    per step — and test.py — each view's rays split over the ranks, uint8 rows gathered on rank 0 — against the same
+    commands run by one process (jitter off, so the two differ only by fp32 summation order)."""
+    import socket
+    import subprocess
+    import sys
+    from PIL import Image
+    root = scene[0]
+
+    def run(name, launcher, env):
+        ov = _override(scene, outroot=join(root, 'reh_' + name), epochs=3, ckpt_period=3, vali_period=3,
+                       use_nerf_alpha=False, shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='',
+                       xyz_jitter_std=0, seed=3)
+        e = dict(os.environ, **env)
+        for mod, arg in (('trainvali', ['--config=nerfactor_microfacet.ini', '--config_override=' + ov]),
+                         ('test', ['--ckpt=' + join(root, 'reh_' + name, 'lr5e-3', 'checkpoints', 'ckpt-1')])):
+            res = subprocess.run(launcher + ['-m', 'nerfactor_amd.nerfactor.' + mod] + arg, env=e, cwd=os.getcwd(),
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert res.returncode == 0, res.stdout[-3000:]
+        return join(root, 'reh_' + name, 'lr5e-3')
+
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    one = run('one', [sys.executable], {})
+    two = run('two', [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                      '--master-addr=127.0.0.1', '--master-port=%d' % port], {'NFX_REHEARSAL': '1'})
+    a = torch.load(join(one, 'checkpoints', 'ckpt-1'), map_location='cpu')['net']
+    b = torch.load(join(two, 'checkpoints', 'ckpt-1'), map_location='cpu')['net']
+    diff = torch.cat([(a[k].float() - b[k].float()).abs().reshape(-1) for k in a if a[k].dtype.is_floating_point])
+    assert float(diff.mean()) < 2e-4 and float(diff.quantile(0.99)) < 5e-3, (float(diff.mean()), float(diff.max()))
+    l1 = [v for _, t, v in _scalars(join(one, 'summary_train', 'scalars.csv')) if t == 'loss_train']
+    l2 = [v for _, t, v in _scalars(join(two, 'summary_train', 'scalars.csv')) if t == 'loss_train']
+    np.testing.assert_allclose(l1, l2, rtol=2e-3)
+    ims = sorted(glob.glob(join(one, 'vis_test', 'ckpt-1', 'batch*', 'pred_rgb.png')))
+    assert len(ims) == 3
+    for f in ims:
+        x = np.asarray(Image.open(f)).astype(int)
+        y = np.asarray(Image.open(f.replace('reh_one', 'reh_two'))).astype(int)
+        assert x.shape == y.shape and np.abs(x - y).max() <= 3, f
