@@ -94,7 +94,7 @@ def timed(step, steps, warmup, barrier):
 
 
 # ------------------------------------------------------------------------------------------------ NeRF leg
-def nerf_render_step(ops, views, blobs, ev=None):
+def nerf_render_step(ops, views, blobs, ev=None, prec='bf16'):
     """views: [(rayo, rayd)] device tensors (this rank's shard of every view).  ev: per-view 4 events around the two
     MLP launches."""
     rgb = None
@@ -104,14 +104,14 @@ def nerf_render_step(ops, views, blobs, ev=None):
         z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
         if e is not None:
             e[0].record()
-        raw = ops.nerf_mlp_fwd(o, d, z, blobs[0])
+        raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
         if e is not None:
             e[1].record()
         _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
         z_all = ops.sample_fine(z, w, N_FINE)
         if e is not None:
             e[2].record()
-        raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1])
+        raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1], prec)
         if e is not None:
             e[3].record()
         rgb = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)[0]
@@ -169,7 +169,7 @@ def committed_traffic(kernel_substr, scale=1):
 def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     from nerfactor_amd import synth
     nets = synth.nerf_nets(seed=0)
-    blobs = [ops.pack_nerf_weights(*synth.nerf_layers(n)).to(dev) for n in nets]
+    blobs = [ops.pack_nerf_weights(*synth.nerf_layers(n), prec=args.precision).to(dev) for n in nets]
     sh = Shards(H * W, rank, world, args.scaling)
     views, host_views = [], []
     for v in range(sh.n_views):
@@ -179,7 +179,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         host_views.append((rayo, rayd))
         views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in views] for _ in range(args.steps)]
-    elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k]),
+    elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k], args.precision),
                          args.steps, args.warmup, barrier)
     elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(rgb).all()
@@ -225,7 +225,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         sel = idx[(idx >= sh.lo) & (idx < sh.hi)]
         keep = np.isin(idx, sel)
         o, d = (torch.from_numpy(a[sel]).to(dev) for a in host_views[0])
-        got = nerf_render_step(ops, [(o, d)], blobs).cpu().numpy()
+        got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision).cpu().numpy()
         want = ref[1]['rgb'].numpy()[keep]
         # rays decided by the sign of a near-zero logit at the dist = 1e10 last sample are a discontinuity of the
         # reference formula: they stay in the PSNR, max-abs is reported with and without them
@@ -331,7 +331,7 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     variant = 'microfacet' if name == 'nerfactor_microfacet' else 'learned'
     torch.manual_seed(5)
     cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
-                      test_envmap_dir='', xyz_jitter_std='0')
+                      test_envmap_dir='', xyz_jitter_std='0', precision=args.precision)
     model = get_model_class(name)(cfg).to(dev)
     for i, p in enumerate(synth.probes(N_PROBES, seed=20)):
         model.add_probe('p%d' % i, p)
@@ -445,6 +445,8 @@ def main():
     ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor')
     ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=('bf16', 'fp32'), default='bf16',
+                    help="MLP operand type: bf16 (the headline) or fp32 = bf16 hi/lo pairs, 3 MFMAs per product")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -484,7 +486,8 @@ def main():
         out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic"}
+               "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-class: hi/lo operand pairs)",
+               "data": "synthetic"}
         if rehearsal:
             out["rehearsal"] = "all ranks share GPU 0 over gloo: a functional check of the N > 1 path, not a measurement"
         if nerf is not None:   # (profiling runs may time the NeRFactor legs alone: --legs nerfactor)

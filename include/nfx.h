@@ -18,9 +18,10 @@
  *   - `prec`: NFX_PREC_BF16 = bf16 operands / fp32 accumulate on the MFMA path;
  *     NFX_PREC_FP32 = fp32-class accuracy on the same pipe: every operand a bf16 hi/lo
  *     pair (16 significant bits), three MFMAs per product, fp32 accumulate (stated
- *     tolerance 2e-4 on rgb; ~5x the v_mfma_f32_32x32x2_f32 peak).  Built for the NeRF
- *     MLP forward (nfx_nerf_pack_weights / nfx_nerf_mlp_fwd); every other entry point
- *     returns NFX_ENOSUP for it.
+ *     tolerance 2e-4 on rgb; ~2x the v_mfma_f32_32x32x2_f32 peak).  Built for the
+ *     forward kernels: nfx_nerf_pack_weights / nfx_nerf_mlp_fwd and nfx_mlp128_pack_weights /
+ *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd; the
+ *     geometry, training-blob and backward entry points return NFX_ENOSUP for it.
  *   - re-entrant: no global mutable state; concurrent calls on different streams
  *     are legal.
  */

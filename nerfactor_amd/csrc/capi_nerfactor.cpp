@@ -43,6 +43,9 @@ int nfx_launch_shade_olat(const float*, const float*, const float*, const float*
                           int, float*, hipStream_t);
 int nfx_launch_dir2rusink(const float*, const float*, long long, float*, hipStream_t);
 size_t nfx_shade_olat_lds_bytes(int n_lights);
+int nfx_mlp128_x3_weight_bytes(int in_kind);   // mlp128_x3.hip
+int nfx_launch_mlp128_x3(int, const float*, const float*, const float*, const float*, const float*, const float*, int,
+                         long long, int, float, const void*, int, int, float, float, float*, int, hipStream_t);
 
 // ------------------------------------------------------------------------------ packing
 static int in_dims_of(int in_kind, int z_dim) {
@@ -56,7 +59,14 @@ static int in_dims_of(int in_kind, int z_dim) {
 
 size_t nfx_mlp128_packed_bytes(int in_kind, int z_dim, int out_dim, int prec) {
     using namespace nfx::m128;
-    if (prec != NFX_PREC_BF16 || out_dim < 1 || out_dim > 8) return 0;
+    if (out_dim < 1 || out_dim > 8) return 0;
+    if (prec == NFX_PREC_FP32) {   // mlp128_x3.hip: [hi fragments | lo fragments | biases]
+        if (in_kind != NFX_IN_XYZ && in_kind != NFX_IN_XYZ_LDIR &&
+            !(in_kind == NFX_IN_Z_RUSINK && z_dim >= 1 && z_dim <= kMaxZDim))
+            return 0;
+        return 2 * (size_t)nfx_mlp128_x3_weight_bytes(in_kind) + kMainBiasFloats * sizeof(float);
+    }
+    if (prec != NFX_PREC_BF16) return 0;
     if (in_kind == NFX_IN_XYZ) return kMainBytes;
     if (in_kind == NFX_IN_XYZ_LDIR) return (size_t)kPreBytes + kMainBytes;
     if (in_kind == NFX_IN_Z_RUSINK && z_dim >= 1 && z_dim <= kMaxZDim) return kMainBytes;
@@ -80,19 +90,74 @@ static void brdf_input_slots(int zd, int* slots /*[2][2][8]*/) {
     }
 }
 
+// One half (hi or lo) of the NFX_PREC_FP32 blob: the plain five layers, the light-visibility input NOT folded.
+static int pack_m128_x3_half(const float* const kernels[5], const float* const biases[5], int in_kind, int z_dim,
+                             int out_dim, uint8_t* w, float* b) {
+    using namespace nfx::pack;
+    const uint8_t* w0 = w;
+    const Seg hid{kHidden, 128, 0, nullptr};
+    int slots[32];
+    brdf_input_slots(z_dim, slots);
+    std::vector<Seg> in0, in3{hid};
+    int p0 = 4, p3 = 12;
+    if (in_kind == NFX_IN_Z_RUSINK) {
+        in0 = {Seg{kRaw, 2, 0, slots}};
+        in3.push_back(Seg{kRaw, 2, 128, slots});
+    } else {
+        in0 = {Seg{kPosEnc, 10, 0, nullptr}};
+        in3.push_back(Seg{kPosEnc, 10, 128, nullptr});
+        if (in_kind == NFX_IN_XYZ_LDIR) {
+            in0.push_back(Seg{kPosEnc, 4, 63, nullptr});
+            in3.push_back(Seg{kPosEnc, 4, 128 + 63, nullptr});
+            p0 = 8;
+            p3 = 16;
+        }
+    }
+    w += pack_layer_bf16(in0, {{kernels[0], biases[0], 128}}, 4, p0, w, b);
+    w += pack_layer_bf16({hid}, {{kernels[1], biases[1], 128}}, 4, 8, w, b + 128);
+    w += pack_layer_bf16({hid}, {{kernels[2], biases[2], 128}}, 4, 8, w, b + 256);
+    w += pack_layer_bf16(in3, {{kernels[3], biases[3], 128}}, 4, p3, w, b + 384);
+    w += pack_layer_bf16({hid}, {{kernels[4], biases[4], out_dim}}, 1, 8, w, b + 512);
+    return w - w0 == nfx_mlp128_x3_weight_bytes(in_kind) ? 0 : 1;
+}
+
 int nfx_mlp128_pack_weights(const float* const kernels[5], const float* const biases[5], int in_kind,
                             int z_dim, int out_dim, int prec, void* blob, size_t blob_bytes) {
     using namespace nfx::m128;
     using namespace nfx::pack;
     REQUIRE(kernels && biases && blob, "nfx_mlp128_pack_weights: null argument");
     for (int i = 0; i < 5; ++i) REQUIRE(kernels[i] && biases[i], "nfx_mlp128_pack_weights: layer %d null", i);
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_pack_weights: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_mlp128_pack_weights: bad prec %d", prec);
     const size_t need = nfx_mlp128_packed_bytes(in_kind, z_dim, out_dim, prec);
     REQUIRE(need != 0, "nfx_mlp128_pack_weights: unsupported configuration (in_kind %d, z_dim %d, out_dim %d)",
             in_kind, z_dim, out_dim);
     REQUIRE(blob_bytes >= need, "nfx_mlp128_pack_weights: blob too small (%zu < %zu)", blob_bytes, need);
     const int in_dims = in_dims_of(in_kind, z_dim);
     uint8_t* w = static_cast<uint8_t*>(blob);
+    if (prec == NFX_PREC_FP32) {
+        static const int out_cols[5] = {128, 128, 128, 128, 0};
+        std::vector<std::vector<float>> lo(5);
+        const float* lo_ptr[5];
+        for (int i = 0; i < 5; ++i) {
+            const int rows = i == 0 ? in_dims : i == 3 ? 128 + in_dims : 128;
+            const size_t cnt = (size_t)rows * (i == 4 ? out_dim : out_cols[i]);
+            lo[i].resize(cnt);
+            for (size_t k = 0; k < cnt; ++k) {
+                const uint32_t bits = (uint32_t)f32_to_bf16_rne(kernels[i][k]) << 16;
+                float hi;
+                memcpy(&hi, &bits, 4);
+                lo[i][k] = kernels[i][k] - hi;
+            }
+            lo_ptr[i] = lo[i].data();
+        }
+        const size_t wb = nfx_mlp128_x3_weight_bytes(in_kind);
+        std::vector<float> sink(kMainBiasFloats);
+        memset(w, 0, need);
+        if (pack_m128_x3_half(kernels, biases, in_kind, z_dim, out_dim, w, reinterpret_cast<float*>(w + 2 * wb)) ||
+            pack_m128_x3_half(lo_ptr, biases, in_kind, z_dim, out_dim, w + wb, sink.data()))
+            return nfx_fail(NFX_EINVAL, "nfx_mlp128_pack_weights: layout mismatch (fp32)");
+        return NFX_OK;
+    }
     const Seg hid{kHidden, 128, 0, nullptr};
     int slots[32];
     brdf_input_slots(z_dim, slots);
@@ -134,10 +199,15 @@ int nfx_mlp128_xyz_fwd(const float* xyz, int64_t n, float xyz_scale, const void*
     REQUIRE(n >= 0, "nfx_mlp128_xyz_fwd: n < 0");
     REQUIRE(out_dim >= 1 && out_dim <= 8, "nfx_mlp128_xyz_fwd: out_dim %d not in [1, 8]", out_dim);
     REQUIRE(out_act >= 0 && out_act <= 3, "nfx_mlp128_xyz_fwd: bad activation %d", out_act);
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_xyz_fwd: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_mlp128_xyz_fwd: bad prec %d", prec);
     if (n == 0) return NFX_OK;
     REQUIRE(xyz && blob && out, "nfx_mlp128_xyz_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_mlp128_xyz_fwd: blob must be 16-byte aligned");
+    if (prec == NFX_PREC_FP32)
+        return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_XYZ, xyz, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, 1,
+                                                   xyz_scale, blob, out_dim, out_act, post_scale, post_bias, out,
+                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                              "mlp128_xyz_fwd(fp32)");
     return nfx_hip_result(nfx_launch_mlp128_xyz(xyz, n, xyz_scale, blob, out_dim, out_act, post_scale, post_bias,
                                                 out, nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
                           "mlp128_xyz_fwd");
@@ -152,8 +222,16 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
     REQUIRE(n >= 0, "nfx_lvis_fwd: n < 0");
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_lvis_fwd: n_lights (%d) must be a positive multiple of 32",
             n_lights);
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_lvis_fwd: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_lvis_fwd: bad prec %d", prec);
     if (n == 0) return NFX_OK;
+    if (prec == NFX_PREC_FP32) {   // no per-point fold, no workspace
+        REQUIRE(xyz && lxyz && blob && lvis, "nfx_lvis_fwd: null pointer");
+        if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_lvis_fwd: blob must be 16-byte aligned");
+        return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_XYZ_LDIR, xyz, xyz_dir ? xyz_dir : xyz, lxyz, nullptr, nullptr,
+                                                   nullptr, 0, n, n_lights, xyz_scale, blob, 1, 2, 1.0f, 0.0f, lvis,
+                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                              "lvis_fwd(fp32)");
+    }
     REQUIRE(xyz && lxyz && blob && lvis && workspace, "nfx_lvis_fwd: null pointer");
     REQUIRE(workspace_bytes >= nfx_lvis_workspace_bytes(n), "nfx_lvis_fwd: workspace too small (%zu < %zu)",
             workspace_bytes, nfx_lvis_workspace_bytes(n));
@@ -185,10 +263,15 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
             nfx::m128::kMaxZDim);
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_brdf_spec_fwd: n_lights (%d) must be a multiple of 32",
             n_lights);
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_brdf_spec_fwd: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_brdf_spec_fwd: bad prec %d", prec);
     if (n == 0) return NFX_OK;
     REQUIRE(xyz && cam && normal && z && lxyz && blob && spec, "nfx_brdf_spec_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_fwd: blob must be 16-byte aligned");
+    if (prec == NFX_PREC_FP32)
+        return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_Z_RUSINK, xyz, nullptr, lxyz, cam, normal, z, z_dim, n, n_lights,
+                                                   1.0f, blob, 1, 3, 1.0f, 0.0f, spec,
+                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                              "brdf_spec_fwd(fp32)");
     // NFX_BRDF_VARIANT: 0 / 2 / 3 / 4 as NFX_LVIS_VARIANT (every row evaluated, back-lit rows zeroed afterwards);
     // 5 = front-lit rows only (LDS row queue per wave), per-row geometry as in the dense kernels (bit-identical);
     // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT = column tiles per wave of variants 5 / 6

@@ -79,3 +79,37 @@ def test_fp32_split_blob_is_hi_lo_of_the_bf16_blob(nfx_lib):
     with pytest.raises(ops.NotAGather):
         ops.DevicePacker(lambda k, b: ops.pack_nerf_weights(k, b, 'fp32'), ops.NERF_LAYER_SHAPES,
                          [(s[1],) for s in ops.NERF_LAYER_SHAPES])
+
+
+def test_fp32_split_blobs_of_the_width128_networks(nfx_lib):
+    """NFX_PREC_FP32 of the surface MLPs (mlp128_x3.hip): [hi | lo | biases] with the bf16 blob's fragment order for
+    the xyz heads and the learned BRDF; the light-visibility blob is the plain 90-input network (no per-point fold):
+    168 fragments per half."""
+    from nerfactor_amd import _capi, ops
+    rng = np.random.default_rng(6)
+    for kind, in_dims, zd, frags in ((_capi.IN_XYZ, 63, 0, 136), (_capi.IN_Z_RUSINK, 18, 3, 136),
+                                     (_capi.IN_XYZ_LDIR, 90, 0, 168)):
+        shapes = [(in_dims, 128), (128, 128), (128, 128), (128 + in_dims, 128), (128, 1)]
+        ks = [rng.normal(size=s).astype(np.float32) for s in shapes]
+        bs = [rng.normal(size=(s[1],)).astype(np.float32) for s in shapes]
+        f32 = ops.pack_mlp128_weights(ks, bs, kind, 1, z_dim=zd, prec='fp32').numpy()
+        nw = frags * 1024
+        assert f32.size == 2 * nw + 544 * 4
+        ks_lo = [k - (_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).reshape(k.shape) for k in ks]
+        if kind != _capi.IN_XYZ_LDIR:
+            b16 = ops.pack_mlp128_weights(ks, bs, kind, 1, z_dim=zd).numpy()
+            assert np.array_equal(f32[:nw], b16[:nw]) and np.array_equal(f32[2 * nw:], b16[nw:])
+            assert np.array_equal(f32[nw:2 * nw], ops.pack_mlp128_weights(ks_lo, bs, kind, 1, z_dim=zd).numpy()[:nw])
+        else:
+            # every kernel entry appears exactly once in the hi half (zero padding aside), its residual in the lo half
+            hi = (f32[:nw].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+            lo = (f32[nw:2 * nw].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+            want_hi = np.concatenate([(_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).ravel() for k in ks])
+            want_lo = np.concatenate([(_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).ravel() for k in ks_lo])
+            assert np.array_equal(np.sort(hi[hi != 0]), np.sort(want_hi[want_hi != 0]))
+            assert np.array_equal(np.sort(lo[lo != 0]), np.sort(want_lo[want_lo != 0]))
+            biases = f32[2 * nw:].view(np.float32)
+            assert np.array_equal(biases[:512], np.concatenate(bs[:4])) and biases[512] == bs[4][0]
+        with pytest.raises(ops.NotAGather):
+            ops.DevicePacker(lambda k, b: ops.pack_mlp128_weights(k, b, kind, 1, z_dim=zd, prec='fp32'), shapes,
+                             [(s[1],) for s in shapes])
