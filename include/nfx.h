@@ -20,8 +20,9 @@
  *     pair (16 significant bits), three MFMAs per product, fp32 accumulate (stated
  *     tolerance 2e-4 on rgb; ~2x the v_mfma_f32_32x32x2_f32 peak).  Built for the
  *     forward kernels: nfx_nerf_pack_weights / nfx_nerf_mlp_fwd and nfx_mlp128_pack_weights /
- *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd; the
- *     geometry, training-blob and backward entry points return NFX_ENOSUP for it.
+ *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd, and the
+ *     geometry pair nfx_nerf_pack_geom_weights / nfx_nerf_sigma_fwd / nfx_nerf_sigma_grad; the
+ *     training-blob and backward entry points return NFX_ENOSUP for it.
  *   - re-entrant: no global mutable state; concurrent calls on different streams
  *     are legal.
  */

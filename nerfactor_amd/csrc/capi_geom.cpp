@@ -24,21 +24,25 @@ int nfx_launch_nerf_sigma_geo(const float*, const float*, const float*, long lon
                               hipStream_t);
 int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                hipStream_t);
+int nfx_launch_nerf_sigma_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                             hipStream_t);   // nerf_geom_x3.hip
+int nfx_launch_nerf_sigma_grad_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
+                                  hipStream_t);
 
-size_t nfx_nerf_geom_packed_bytes(int prec) { return prec == NFX_PREC_BF16 ? (size_t)nfx::nerf::kGeoBlobBytes : 0; }
+size_t nfx_nerf_geom_packed_bytes(int prec) {
+    using namespace nfx::nerf;
+    if (prec == NFX_PREC_BF16) return (size_t)kGeoBlobBytes;
+    if (prec == NFX_PREC_FP32) return 2 * (size_t)kGeoWeightBytes + kGeoFloats * sizeof(float);   // [hi | lo | floats]
+    return 0;
+}
+}  // extern "C"
 
-int nfx_nerf_pack_geom_weights(const float* const kernels[12], const float* const biases[12], int prec, void* blob,
-                               size_t blob_bytes) {
+// The bf16 fragments of nerf_geom_layout.hpp's chunk sequence at w0 and its kGeoFloats floats at fl.
+static int pack_geom_half(const float* const kernels[12], const float* const biases[12], uint8_t* w0, float* fl) {
     using namespace nfx;
     using namespace nfx::pack;
-    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_geom_weights: null argument");
-    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_geom_weights: layer %d null", i);
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_pack_geom_weights: only bf16 is built");
-    REQUIRE(blob_bytes >= (size_t)nerf::kGeoBlobBytes, "nfx_nerf_pack_geom_weights: blob too small (%zu < %d)",
-            blob_bytes, nerf::kGeoBlobBytes);
-    uint8_t* w0 = static_cast<uint8_t*>(blob);
-    std::vector<uint8_t> fwd(nfx_nerf_packed_bytes(prec));
-    int rc = nfx_nerf_pack_weights(kernels, biases, prec, fwd.data(), fwd.size());
+    std::vector<uint8_t> fwd(nfx_nerf_packed_bytes(NFX_PREC_BF16));
+    int rc = nfx_nerf_pack_weights(kernels, biases, NFX_PREC_BF16, fwd.data(), fwd.size());
     if (rc) return rc;
     // forward: encoder chunks 0..63 and the sigma tile (chunk 72 = 9th tile of the fused [bottleneck | sigma_out])
     const size_t enc_bytes = (size_t)nerf::chunk_frag_offset(64) * 1024;
@@ -82,22 +86,59 @@ int nfx_nerf_pack_geom_weights(const float* const kernels[12], const float* cons
     for (int l = 5; l >= 1; --l) dgrad(l);
     igrad(0, 0);
     if (w != w0 + nerf::kGeoWeightBytes) return nfx_fail(NFX_EINVAL, "nfx_nerf_pack_geom_weights: layout mismatch");
-    float* fl = reinterpret_cast<float*>(w0 + nerf::kGeoWeightBytes);
     const float* fb = reinterpret_cast<const float*>(fwd.data() + nerf::kWeightBytes);
     memcpy(fl, fb + nerf::kBiasL0, 8 * 256 * 4);
     memcpy(fl + nerf::kGeoBiasSig, fb + nerf::kBiasBott + 256, 32 * 4);
-    // sigma_out kernel in fp32: the kernel rounds it to bf16 when it forms dZ7, as the forward's packed copy is
+    // sigma_out kernel in fp32: the bf16 kernel rounds it to bf16 when it forms dZ7, as the forward's packed copy is;
+    // the fp32-class kernel splits it into a hi / lo pair
     memcpy(fl + nerf::kGeoWSig, kernels[8], 256 * 4);
     return NFX_OK;
+}
+
+extern "C" {
+int nfx_nerf_pack_geom_weights(const float* const kernels[12], const float* const biases[12], int prec, void* blob,
+                               size_t blob_bytes) {
+    using namespace nfx;
+    REQUIRE(kernels && biases && blob, "nfx_nerf_pack_geom_weights: null argument");
+    for (int i = 0; i < 12; ++i) REQUIRE(kernels[i] && biases[i], "nfx_nerf_pack_geom_weights: layer %d null", i);
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_nerf_pack_geom_weights: bad prec %d", prec);
+    REQUIRE(blob_bytes >= nfx_nerf_geom_packed_bytes(prec), "nfx_nerf_pack_geom_weights: blob too small (%zu < %zu)",
+            blob_bytes, nfx_nerf_geom_packed_bytes(prec));
+    uint8_t* w0 = static_cast<uint8_t*>(blob);
+    if (prec == NFX_PREC_BF16) return pack_geom_half(kernels, biases, w0, reinterpret_cast<float*>(w0 + nerf::kGeoWeightBytes));
+    // NFX_PREC_FP32 (nerf_geom_x3.hip): the chunk sequence of hi = bf16(W), then of lo = bf16(W - hi), then the floats
+    static const int rows[12] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
+    static const int cols[12] = {256, 256, 256, 256, 256, 256, 256, 256, 1, 256, 128, 3};
+    std::vector<std::vector<float>> lo(12);
+    const float* lo_ptr[12];
+    for (int i = 0; i < 12; ++i) {
+        const size_t n = (size_t)rows[i] * cols[i];
+        lo[i].resize(n);
+        for (size_t k = 0; k < n; ++k) {
+            const uint32_t bits = (uint32_t)pack::f32_to_bf16_rne(kernels[i][k]) << 16;
+            float hi;
+            memcpy(&hi, &bits, 4);
+            lo[i][k] = kernels[i][k] - hi;
+        }
+        lo_ptr[i] = lo[i].data();
+    }
+    std::vector<float> sink(nerf::kGeoFloats);
+    int rc = pack_geom_half(kernels, biases, w0, reinterpret_cast<float*>(w0 + 2 * (size_t)nerf::kGeoWeightBytes));
+    if (rc) return rc;
+    return pack_geom_half(lo_ptr, biases, w0 + nerf::kGeoWeightBytes, sink.data());
 }
 
 int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
                        const void* blob, int prec, float* sigma, void* stream) {
     REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_fwd: bad shape");
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_sigma_fwd: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_nerf_sigma_fwd: bad prec %d", prec);
     if (n_rays == 0) return NFX_OK;
     REQUIRE(rayo && rayd && z && blob && sigma, "nfx_nerf_sigma_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_fwd: blob must be 16-byte aligned");
+    if (prec == NFX_PREC_FP32)
+        return nfx_hip_result(nfx_launch_nerf_sigma_x3(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
+                                                       sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                              "nerf_sigma_fwd(fp32)");
     return nfx_hip_result(nfx_launch_nerf_sigma_geo(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
                                                     sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
                           "nerf_sigma_fwd");
@@ -106,11 +147,16 @@ int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int
 int nfx_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
                         const void* geom_blob, int prec, float* normal_sigma, void* stream) {
     REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_grad: bad shape");
-    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_nerf_sigma_grad: only bf16 is built");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_nerf_sigma_grad: bad prec %d", prec);
     if (n_rays == 0) return NFX_OK;
     REQUIRE(rayo && rayd && z && geom_blob && normal_sigma, "nfx_nerf_sigma_grad: null pointer");
     if (!ALIGNED(geom_blob, 16) || !ALIGNED(normal_sigma, 16))
         return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_grad: blob and output must be 16-byte aligned");
+    if (prec == NFX_PREC_FP32)
+        return nfx_hip_result(nfx_launch_nerf_sigma_grad_x3(rayo, rayd, z, (long long)n_rays * n_samples, n_samples,
+                                                            geom_blob, normal_sigma,
+                                                            nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                              "nerf_sigma_grad(fp32)");
     return nfx_hip_result(nfx_launch_nerf_sigma_grad(rayo, rayd, z, (long long)n_rays * n_samples, n_samples,
                                                      geom_blob, normal_sigma, nfx_env_int("NFX_NERF_BLOCKS", 256),
                                                      (hipStream_t)stream),

@@ -113,3 +113,21 @@ def test_fp32_split_blobs_of_the_width128_networks(nfx_lib):
         with pytest.raises(ops.NotAGather):
             ops.DevicePacker(lambda k, b: ops.pack_mlp128_weights(k, b, kind, 1, z_dim=zd, prec='fp32'), shapes,
                              [(s[1],) for s in shapes])
+
+
+def test_fp32_split_blob_of_the_density_gradient_kernel(nfx_lib):
+    """NFX_PREC_FP32 geometry blob (nerf_geom_x3.hip) = [the bf16 blob's fragments | the same chunk sequence packed from
+    W - bf16(W) | the bf16 blob's floats: encoder biases, sigma bias tile, sigma_out kernel in fp32]."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(7)
+    ks = [rng.normal(size=s).astype(np.float32) for s in ops.NERF_LAYER_SHAPES]
+    bs = [rng.normal(size=(s[1],)).astype(np.float32) for s in ops.NERF_LAYER_SHAPES]
+    b16 = ops.pack_nerf_geom_weights(ks, bs).numpy()
+    f32 = ops.pack_nerf_geom_weights(ks, bs, 'fp32').numpy()
+    n_floats = 8 * 256 + 32 + 256
+    nw = b16.size - 4 * n_floats
+    assert f32.size == 2 * nw + 4 * n_floats
+    assert np.array_equal(f32[:nw], b16[:nw]) and np.array_equal(f32[2 * nw:], b16[nw:])
+    ks_lo = [k - (_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).reshape(k.shape) for k in ks]
+    assert np.array_equal(f32[nw:2 * nw], ops.pack_nerf_geom_weights(ks_lo, bs).numpy()[:nw])
+    assert np.array_equal(f32[2 * nw:].view(np.float32)[-256:], ks[8][:, 0])
