@@ -35,10 +35,6 @@ class Dataset(BaseDataset):
                     test_ids.append('%06d_%f_%s_%f_%s' % (k, a, mats[a_i], 1 - a, mats[a_i + 1]))
                     k += 1
         self.paths = {'train': train_paths, 'vali': vali_paths, 'test': test_ids}
-        # ray / row sampling: seeded from the config (`seed`, default 0) so that every rank of a multi-process run draws
-        # the SAME batch — the ranks then take disjoint shards of one global batch, as MirroredStrategy distributes one
-        # dataset element (trainvali.py:85,100) — and a run is reproducible (the reference's tf.random draws are not)
-        self._rng = np.random.default_rng([config.getint('DEFAULT', 'seed', fallback=0), len(mode)])
         super().__init__(config, mode, debug=debug, device=device)
 
     def _get_batch_size(self):
@@ -66,10 +62,17 @@ class Dataset(BaseDataset):
             refl = np.asarray(data['refl'], np.float32).reshape(-1, 1)
         return id_, i, envmap_h, ims, spp, rusink, refl
 
-    def _process_example_postcache(self, id_, i, envmap_h, ims, spp, rusink, refl):
+    def _process_example_postcache(self, id_, i, envmap_h, ims, spp, rusink, refl, rng=None, gather=None):
         if self.mode == 'train':
-            sel = self._rng.integers(0, rusink.shape[0], size=self.bs)
-            rusink, refl = rusink[sel], refl[sel]
+            rng = self._batch_rng(0, 0) if rng is None else rng
+            sel = rng.integers(0, rusink.shape[0], size=self.bs)
+            if gather is None:
+                rusink, refl = rusink[sel], refl[sel]
+            else:
+                rusink, refl = gather('rusink', rusink, sel), gather('refl', refl, sel)
         n = rusink.shape[0]
         tile = lambda v: np.full((n,), v, np.int32)
-        return [id_] * n, tile(i), tile(envmap_h), tile(ims), tile(spp), rusink, refl
+        ints = np.stack([tile(v) for v in (i, envmap_h, ims, spp)])
+        if gather is not None:
+            ints = gather('ints', ints, None)
+        return [id_] * n, ints[0], ints[1], ints[2], ints[3], rusink, refl

@@ -53,10 +53,6 @@ class Dataset(BaseDataset):
             raise ValueError("Samples per pixel must be a square number")
         self.sps = int(sps)
         self.always_all_rays = always_all_rays
-        # ray / row sampling: seeded from the config (`seed`, default 0) so that every rank of a multi-process run draws
-        # the SAME batch — the ranks then take disjoint shards of one global batch, as MirroredStrategy distributes one
-        # dataset element (trainvali.py:85,100) — and a run is reproducible (the reference's tf.random draws are not)
-        self._rng = np.random.default_rng([config.getint('DEFAULT', 'seed', fallback=0), len(mode)])
         super().__init__(config, mode, debug=debug, device=device)
 
     def _get_batch_size(self):
@@ -106,18 +102,23 @@ class Dataset(BaseDataset):
         bg = 1. if white_bg else 0.
         return id_, rayo, rayd, (rgb * alpha + bg * (1. - alpha)).astype(np.float32)
 
-    def _process_example_postcache(self, id_, rayo, rayd, rgb):
+    def _process_example_postcache(self, id_, rayo, rayd, rgb, rng=None, gather=None):
         hw = np.array(rgb.shape[:2], np.int32)
-        rayo, rayd, rgb = self._sample_rays(rayo, rayd, rgb)
+        rayo, rayd, rgb = self._sample_rays(rayo, rayd, rgb, rng=rng, gather=gather)
         n = rgb.shape[0]
-        return [id_] * n, np.tile(hw[None], (n, 1)), rayo, rayd, rgb
+        hw = np.tile(hw[None], (n, 1))
+        return [id_] * n, hw if gather is None else gather('hw', hw, None), rayo, rayd, rgb
 
-    def _sample_rays(self, rayo, rayd, rgb):
+    def _sample_rays(self, rayo, rayd, rgb, rng=None, gather=None):
         flat = lambda a: a.reshape(-1, a.shape[-1])
+        arrs = flat(rayo), flat(rayd), flat(rgb)
         if self.mode in ('vali', 'test') or self.always_all_rays:
-            return flat(rayo), flat(rayd), flat(rgb)
-        sel = self._rng.integers(0, rgb.shape[0] * rgb.shape[1], size=self.bs)
-        return flat(rayo)[sel], flat(rayd)[sel], flat(rgb)[sel]
+            return arrs
+        rng = self._batch_rng(0, 0) if rng is None else rng
+        sel = rng.integers(0, rgb.shape[0] * rgb.shape[1], size=self.bs)
+        if gather is None:
+            return tuple(a[sel] for a in arrs)
+        return tuple(gather(k, a, sel) for k, a in zip(('rayo', 'rayd', 'rgb'), arrs))
 
     def _gen_rays(self, to_world, angle_x, imh, imw):
         if self.config.getboolean('DEFAULT', 'ndc', fallback=False):

@@ -24,6 +24,7 @@ def known_all_foreground(alpha):
 class Dataset(NeRFDataset):
     def __init__(self, config, mode, debug=False, always_all_rays=False, device='cuda'):
         self.meta2buf = {}
+        self._candidates = {}   # view id -> indices of its foreground rays
         super().__init__(config, mode, debug=debug, always_all_rays=always_all_rays, device=device)
 
     def _glob(self):
@@ -75,27 +76,39 @@ class Dataset(NeRFDataset):
         return (self._parse_id(metadata_path), rayo, rayd, rgb.astype(np.float32), alpha.astype(np.float32),
                 xyz, normal.astype(np.float32), lvis)
 
-    def _process_example_postcache(self, id_, rayo, rayd, rgb, alpha, xyz, normal, lvis):
-        hw = np.array(rgb.shape[:2], np.int32)
-        arrs = self._sample_rays(rayo, rayd, rgb, alpha, xyz, normal, lvis)
-        n = arrs[2].shape[0]
-        return ([id_] * n, np.tile(hw[None], (n, 1))) + arrs
+    ALPHA_THRES = 0.9    # training rays are drawn from alpha > 0.9 (nerf_shape.py:102-107)
 
-    def _sample_rays(self, rayo, rayd, rgb, alpha, xyz, normal, lvis, alpha_thres=0.9):
+    def _process_example_postcache(self, id_, rayo, rayd, rgb, alpha, xyz, normal, lvis, rng=None, gather=None):
+        hw = np.array(rgb.shape[:2], np.int32)
+        arrs = self._sample_rays(id_, rayo, rayd, rgb, alpha, xyz, normal, lvis, rng=rng, gather=gather)
+        n = arrs[2].shape[0]
+        hw = np.tile(hw[None], (n, 1))
+        return ([id_] * n, hw if gather is None else gather('hw', hw, None)) + arrs
+
+    def _sample_rays(self, id_, rayo, rayd, rgb, alpha, xyz, normal, lvis, rng=None, gather=None):
         flat = lambda a: a.reshape(a.shape[0] * a.shape[1], -1)
         arrs = tuple(flat(a) for a in (rayo, rayd, rgb, alpha, xyz, normal, lvis))
-        if self.mode in ('vali', 'test') or self.always_all_rays:
+        if not self._batch_is_foreground_only():
             return arrs
-        cand = np.arange(arrs[3].shape[0]) if alpha_thres is None else np.nonzero(arrs[3][:, 0] > alpha_thres)[0]
-        sel = cand[self._rng.integers(0, cand.shape[0], size=self.bs)]
-        self._drew_foreground_only = alpha_thres is not None and alpha_thres >= 0
-        return tuple(a[sel] for a in arrs)
+        cand = self._candidates.get(id_)
+        if cand is None:
+            cand = np.nonzero(arrs[3][:, 0] > self.ALPHA_THRES)[0]
+            if self.config.getboolean('DEFAULT', 'cache', fallback=True):
+                self._candidates[id_] = cand
+        rng = self._batch_rng(0, 0) if rng is None else rng
+        sel = cand[rng.integers(0, cand.shape[0], size=self.bs)]
+        if gather is None:
+            return tuple(a[sel] for a in arrs)
+        return tuple(gather(k, a, sel) for k, a in zip(('rayo', 'rayd', 'rgb', 'alpha', 'xyz', 'normal', 'lvis'), arrs))
+
+    def _batch_is_foreground_only(self):
+        return self.mode == 'train' and not self.always_all_rays
 
     def _to_device(self, batch):
-        """Training rays are drawn from alpha > 0.9 (nerf_shape.py:102-107): the batch says so, and the models skip the
-        foreground compaction — a torch.nonzero whose row count the host would have to wait for, with the whole
-        previous step still in the launch queue — for it (models/nerfactor.py, models/shape.py)."""
+        """A training batch says that its rays are all foreground, and the models skip the foreground compaction — a
+        torch.nonzero whose row count the host would have to wait for, with the whole previous step still in the
+        launch queue — for it (models/nerfactor.py, models/shape.py)."""
         out = super()._to_device(batch)
-        if self.__dict__.pop('_drew_foreground_only', False):
+        if self._batch_is_foreground_only():
             mark_all_foreground(out[5])
         return out

@@ -107,7 +107,19 @@ def train_step(model, batch, optimizer, global_bs):
     weighted = per_example.sum() / global_bs   # tf.nn.compute_average_loss
     weighted.backward()
     total = optimizer.step(loss=weighted.detach())
-    return total, to_vis
+    return total, _detached(to_vis)
+
+
+def _detached(to_vis):
+    """The visualisation tensors without their autograd history.  A caller that keeps `to_vis` across steps (trainvali
+    does, for the first batches of an epoch) would otherwise keep the step's graph nodes alive, among them the
+    parameters' AccumulateGrad nodes — created on the stream of THAT step; a later step captured in a hipGraph on
+    torch's capture stream then finds them on the default stream, autograd joins the default stream into the capture
+    ("AccumulateGrad node's stream does not match ..."), and ending the capture crashes (seen with
+    scripts/bench_loader.py at the end of round 2)."""
+    if isinstance(to_vis, dict):
+        return {k: v.detach() if isinstance(v, torch.Tensor) else v for k, v in to_vis.items()}
+    return to_vis
 
 
 class GraphedTrainStep:
@@ -150,7 +162,7 @@ class GraphedTrainStep:
         pending = model.__dict__.get('_pending_numerics', [])
         model.__dict__['_pending_numerics'] = []
         flags = torch.stack([ok for _, ok in pending]) if pending else None
-        return total, to_vis, [m for m, _ in pending], flags
+        return total, _detached(to_vis), [m for m, _ in pending], flags
 
     def __call__(self, batch):
         if not self._capturable(batch):

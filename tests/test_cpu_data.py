@@ -215,3 +215,54 @@ def test_training_batches_say_they_are_foreground_only(scene):
     assert not known_all_foreground(va[5]) and not bool((va[5] > 0).all())
     assert known_all_foreground(shard.shard_batch(tr)[5])
     assert not known_all_foreground(mark_all_foreground(torch.ones(4, 1))[:2])   # plain slicing drops the tag
+
+
+def test_prefetched_training_batches_are_the_plain_ones(scene):
+    """datasets/base.py read-ahead (the reference's .prefetch, datasets/base.py:110-113): a batch is a pure function of
+    (ini seed, mode, pipeline seed, position), so the producer thread running ahead changes nothing — same batches with
+    and without it, the same again when an epoch is abandoned half way (its thread ends) and restarted, different rays
+    for a different pipeline seed or ini seed."""
+    import threading
+
+    def dict_cfg(model, data_root, **kw):
+        return make_config(model, data_root=data_root, outroot=join(scene[0], 'out'), n_rays_per_step=64, **kw)
+    for name, model in (('nerf_shape', 'shape'), ('nerf', 'nerf'), ('brdf_merl', 'brdf')):
+        if name == 'brdf_merl':
+            from tests import synth_scene
+            root = join(scene[0], 'merl_prefetch')
+            synth_scene.write_merl(root)
+            cfgs = {p: dict_cfg(model, root, prefetch=p) for p in (0, 2)}
+        else:
+            cfgs = {p: _cfg(model, scene, prefetch=p) for p in (0, 2)}
+        Dataset = get_dataset_class(name)
+
+        def epochs(cfg, seeds=(0, 1)):
+            ds = Dataset(cfg, 'train', device='cpu')
+            return [[t for t in b if isinstance(t, torch.Tensor)] for s in seeds for b in ds.build_pipeline(no_batch=True, seed=s)]
+        plain, ahead = epochs(cfgs[0]), epochs(cfgs[2])
+        assert len(plain) == len(ahead) >= 4
+        for a, b in zip(plain, ahead):
+            assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+        n = len(plain) // 2
+        assert not all(torch.equal(x, y) for x, y in zip(plain[0], plain[n]))          # another pipeline seed
+        ds = Dataset(cfgs[2], 'train', device='cpu')
+        first = ds.build_pipeline(no_batch=True, seed=0).take(1)
+        assert not [t for t in threading.enumerate() if t.name == 'nfx-prefetch']      # abandoned epoch: thread gone
+        again = ds.build_pipeline(no_batch=True, seed=0).take(2)
+        for a, b in zip([t for t in first[0] if isinstance(t, torch.Tensor)], [t for t in again[0] if isinstance(t, torch.Tensor)]):
+            assert torch.equal(a, b)
+        assert all(torch.equal(x, y) for x, y in zip([t for t in again[1] if isinstance(t, torch.Tensor)], plain[1]))
+        cfg_other = _cfg(model, scene, seed=7) if name != 'brdf_merl' else dict_cfg(model, root, seed=7)
+        other = epochs(cfg_other, seeds=(0,))
+        assert not all(torch.equal(x, y) for x, y in zip(other[0], plain[0]))          # another ini seed
+
+
+def test_prefetch_errors_surface_in_the_consumer(scene, monkeypatch):
+    Dataset = get_dataset_class('nerf_shape')
+    ds = Dataset(_cfg('shape', scene, prefetch=2), 'train', device='cpu')
+
+    def boom(*a, **k):
+        raise RuntimeError("corrupt view")
+    monkeypatch.setattr(ds, '_process_example_postcache', boom)
+    with pytest.raises(RuntimeError, match="corrupt view"):
+        list(ds.build_pipeline(no_batch=True, seed=0))
