@@ -198,7 +198,9 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     # (gfx950 correction) + WRITE_SIZE, per launch pair of a whole 640 000-ray view.
     variant = os.environ.get("NFX_NERF_VARIANT", "7")
     # digest = average over the coarse and the fine dispatch; a launch pair = both
-    traffic, traffic_source = committed_traffic('nerf_mlp', scale=2) if n_local == H * W and variant == "7" else (None, None)
+    fp32 = args.precision == 'fp32'
+    traffic, traffic_source = committed_traffic('nerf_mlp', scale=2) if n_local == H * W and variant == "7" and not fp32 \
+        else (None, None)
     out = {
         "value": sh.rays_per_step_all_ranks * args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -210,9 +212,10 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
             "n_samples_coarse": N_COARSE, "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
             "kernel_variant": variant},
         "roofline": {
-            "bound": "mfma", "kernel": "%s (coarse + fine launches)" % {
-                "1": "nerf_mlp_bf16_kernel<1, 8>",
-                "7": "nerf_mlp_bf16_v6_kernel<0, 1>, LDS-DMA weight stream"}.get(variant, "variant %s" % variant),
+            "bound": "mfma", "kernel": "%s (coarse + fine launches)" % (
+                "nerf_mlp_x3_kernel, 3 MFMAs per product: achieved counts the algorithmic FLOPs once" if fp32 else {
+                    "1": "nerf_mlp_bf16_kernel<1, 8>",
+                    "7": "nerf_mlp_bf16_v6_kernel<0, 1>, LDS-DMA weight stream"}.get(variant, "variant %s" % variant)),
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_unit": "GB per launch pair", "traffic_source": traffic_source,
             "algorithmic_hbm_gb": pts_per_pair * 20 / 1e9, "flop_per_launch_pair": pts_per_pair * FLOP_PER_POINT,
@@ -361,7 +364,7 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     # algorithmic bytes per foreground point: 512 visibilities written, the 1-KiB pre-activation row written by
     # lvis_pre and read once by the main kernel, the position read
     lv_traffic, lv_source = None, None
-    if world == 1:
+    if world == 1 and args.precision == 'bf16':
         a, src = committed_traffic('resident128_kernel')
         b, _ = committed_traffic('lvis_pre_kernel')
         if a is not None and b is not None:
@@ -375,9 +378,12 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         "foreground_points_per_view": int(host_batches[0][5].sum()),
         "flop_per_foreground_point_algorithmic": 2 * (N_LIGHTS * LVIS_MAC + HEAD_MAC + 65408),
         "roofline": {
-            "bound": "mfma", "kernel": "lvis_pre_kernel + %s (light visibility, %%d x 512 rows)" % {
+            "bound": "mfma", "kernel": ("mlp128_x3_kernel<1> (light visibility, %d x 512 rows; 3 MFMAs per product, "
+                                        "plain 90-dim input: achieved counts the bf16 path's algorithmic FLOPs)"
+                                        if args.precision == 'fp32' else
+                                        "lvis_pre_kernel + %s (light visibility, %%d x 512 rows)" % {
                 "8": "resident128_kernel<2, 0, 8>", "4": "resident128_kernel<4, 0, 4>"}.get(
-                    os.environ.get("NFX_LVIS_VARIANT", "8"), "variant " + os.environ.get("NFX_LVIS_VARIANT", "8"))
+                    os.environ.get("NFX_LVIS_VARIANT", "8"), "variant " + os.environ.get("NFX_LVIS_VARIANT", "8")))
                                        % int(fg_per_call),
             "achieved": lvis_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": lvis_tf / PEAK_BF16_TFLOPS,
             "avg_launch_ms": lvis_s * 1e3, "flop_per_launch": fg_per_call * N_LIGHTS * 2 * LVIS_MAC,

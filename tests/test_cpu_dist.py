@@ -208,3 +208,15 @@ def test_graphed_step_only_captures_static_single_process_batches():
     assert g._capturable((None, None, torch.zeros(n, 3), torch.zeros(n, 3), torch.zeros(n, 3)))   # NeRF batch
     a, b = surf(mark_all_foreground(torch.ones(n, 1))), surf(mark_all_foreground(torch.ones(n, 1)))
     assert g._key(a) == g._key(b) and g._key(a) != g._key(surf(mark_all_foreground(torch.ones(4, 1))))
+
+
+def test_train_step_hands_back_detached_visualisation_tensors():
+    """optim._detached: what a training step returns for visualisation must not keep the step's autograd graph (and
+    with it the parameters' AccumulateGrad nodes) alive across steps — DESIGN.md §3b, the hipGraph capture."""
+    from nerfactor_amd import optim
+    w = torch.ones(3, requires_grad=True)
+    to_vis = {'id': ['a'], 'hw': torch.tensor([[2, 2]]), 'pred_rgb': w * 2., 'gt_rgb': torch.zeros(3)}
+    out = optim._detached(to_vis)
+    assert out['id'] == ['a'] and out['pred_rgb'].grad_fn is None and not out['pred_rgb'].requires_grad
+    assert torch.equal(out['pred_rgb'], to_vis['pred_rgb']) and out['gt_rgb'] is not None
+    assert optim._detached(None) is None
