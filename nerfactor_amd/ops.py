@@ -261,7 +261,7 @@ def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., xyz_dir=None, prec='bf16'):
     lxyz = _dev(lxyz, 'lxyz', (None, 3))
     n, nl = xyz.shape[0], lxyz.shape[0]
     out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
-    ws_bytes = lib.nfx_lvis_workspace_bytes(n)
+    ws_bytes = 0 if prec == 'fp32' else lib.nfx_lvis_workspace_bytes(n)   # (the fp32-class kernel has no per-point fold)
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=xyz.device)
     check(lib.nfx_lvis_fwd(_ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
                            ws.numel() * 4, _ptr(out), _stream()), 'nfx_lvis_fwd')
