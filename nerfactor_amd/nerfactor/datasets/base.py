@@ -81,10 +81,13 @@ class Dataset:
         return False
 
     def _prefetch_depth(self):
-        """Read-ahead depth: training batches bound for a GPU by default; on a CPU device only when the ini asks for it
-        (plain read-ahead, no page-locked memory — what the CPU tests exercise)."""
+        """Read-ahead depth.  Training batches: ini key `prefetch`, default 2 when they are bound for a GPU, 0 on a CPU
+        device (there only when the ini asks for it: plain read-ahead without page-locked memory — what the CPU tests
+        exercise).  Whole validation / test views: ini key `prefetch_views`, default 0 (set 1 or 2 to overlap the disk
+        reads of the next view with the rendering of the current one; each view in flight is 1.4 GB of host memory at
+        800 x 800 x 512 lights)."""
         if self.mode != 'train':
-            return 0
+            return self.config.getint('DEFAULT', 'prefetch_views', fallback=0)
         on_gpu = torch.device(self.device).type == 'cuda' and torch.cuda.is_available()
         return self.config.getint('DEFAULT', 'prefetch', fallback=2 if on_gpu else 0)
 
@@ -92,8 +95,15 @@ class Dataset:
         return len(self.files)
 
     def _load_cached(self, path):
-        if not self.config.getboolean('DEFAULT', 'cache', fallback=True):
-            return self._process_example_precache(path)
+        """The pre-cache stage of one file.  Kept for the lifetime of the dataset only in training mode (`cache`, default
+        true: every epoch revisits every view, as tf.data's .cache() serves the re-iterated training pipeline); a
+        validation / test pipeline visits a view once — 1.4 GB of buffers per 800 x 800 x 512-light view — so only the
+        most recent one is remembered (the batch-size probe of datasets/nerf.py reads view 0 before the pipeline)."""
+        if self.mode != 'train' or not self.config.getboolean('DEFAULT', 'cache', fallback=True):
+            last = self.__dict__.get('_last_loaded')
+            if last is None or last[0] != path:
+                last = self._last_loaded = (path, self._process_example_precache(path))
+            return last[1]
         if path not in self._cache:
             self._cache[path] = self._process_example_precache(path)
         return self._cache[path]
@@ -134,7 +144,11 @@ class Dataset:
 
     # ------------------------------------------------------------------ read-ahead
     def _prefetched(self, files, epoch, depth):
-        """Batches of one epoch, produced `depth` ahead by a thread into page-locked staging slots."""
+        """Batches of one epoch, produced `depth` ahead by a thread: training batches (a gather of n_rays_per_step rows)
+        into page-locked staging slots; whole validation / test views as they come from the pre-cache stage — there the
+        read-ahead overlaps the disk reads and decoding of the next view with the rendering of the current one (the
+        reference's parallel .map + .prefetch, datasets/base.py:96-113)."""
+        staged = self.mode == 'train'
         slots = [_StagingSlot() for _ in range(depth + 2)]   # depth queued + one being filled + one being copied from
         ready = queue.Queue(maxsize=depth)
         stop = threading.Event()
@@ -175,8 +189,8 @@ class Dataset:
                             np.take(array, rows, axis=0, out=out.numpy(), mode='clip')   # ('raise' buffers the output)
                         return out
                     batch = self._process_example_postcache(*self._load_cached(f), rng=self._batch_rng(epoch, i),
-                                                            gather=gather)
-                    if not put((slot, batch, None)):
+                                                            gather=gather if staged else None)
+                    if not put((slot if staged else None, batch, None)):
                         return
                 put((None, None, None))
             except BaseException as e:     # surfaces in the consumer, not in a dead thread
@@ -192,9 +206,10 @@ class Dataset:
                 if batch is None:
                     return
                 out = self._to_device(batch)
-                if device_index is None:   # host "device": .to() aliased the staging buffers, which will be refilled
+                if device_index is None and slot is not None:   # host "device": .to() aliased the staging buffers
                     out = tuple(x.clone() if isinstance(x, torch.Tensor) else x for x in out)
-                slot.copies_issued()
+                if slot is not None:
+                    slot.copies_issued()
                 yield out
         finally:
             stop.set()

@@ -266,3 +266,25 @@ def test_prefetch_errors_surface_in_the_consumer(scene, monkeypatch):
     monkeypatch.setattr(ds, '_process_example_postcache', boom)
     with pytest.raises(RuntimeError, match="corrupt view"):
         list(ds.build_pipeline(no_batch=True, seed=0))
+
+
+def test_whole_view_pipelines_read_ahead_and_do_not_hoard_views(scene):
+    """Validation / test pipelines: views read ahead by the producer thread (ini prefetch_views) are the same views in
+    the same order; only the training dataset keeps every pre-cache result (a test pass visits each 1.4 GB view once)."""
+    Dataset = get_dataset_class('nerf_shape')
+    views = {}
+    for p in (0, 1, 3):
+        ds = Dataset(_cfg('shape', scene, prefetch_views=p), 'test', device='cpu')
+        views[p] = list(ds.build_pipeline(no_batch=True, no_shuffle=True))
+        assert len(ds._cache) == 0 and len(views[p]) == ds.get_n_views() == 2
+    for p in (1, 3):
+        for a, b in zip(views[0], views[p]):
+            assert a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+    va = Dataset(_cfg('shape', scene, prefetch_views=1), 'vali', device='cpu')
+    assert len(va.build_pipeline(no_batch=True).take(1)) == 1 and len(va._cache) == 0
+    tr = Dataset(_cfg('shape', scene), 'train', device='cpu')
+    list(tr.build_pipeline(no_batch=True, seed=0))
+    assert len(tr._cache) == tr.get_n_views() and len(tr._candidates) == tr.get_n_views()
+    nocache = Dataset(_cfg('shape', scene, cache='false'), 'train', device='cpu')
+    list(nocache.build_pipeline(no_batch=True, seed=0))
+    assert len(nocache._cache) == 0 and len(nocache._candidates) == 0
