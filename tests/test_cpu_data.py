@@ -288,3 +288,25 @@ def test_whole_view_pipelines_read_ahead_and_do_not_hoard_views(scene):
     nocache = Dataset(_cfg('shape', scene, cache='false'), 'train', device='cpu')
     list(nocache.build_pipeline(no_batch=True, seed=0))
     assert len(nocache._cache) == 0 and len(nocache._candidates) == 0
+
+
+def test_write_vis_per_light_images_round_trip(tmp_path):
+    """Model.write_vis: [rays, lights, 3] rows (OLAT / probe relighting) become one PNG per light through a single
+    transposing pass and the PNG encoder pool; every file holds exactly its light's column."""
+    from PIL import Image
+    from nerfactor_amd.nerfactor.models.base import Model, _lights_major
+    h, w, nl = 5, 7, 9
+    rng = np.random.default_rng(3)
+    olat = rng.integers(0, 256, size=(h * w, nl, 3), dtype=np.uint8)
+    assert np.array_equal(_lights_major(torch.from_numpy(olat)), olat.transpose(1, 0, 2))
+    assert np.array_equal(_lights_major(olat[:, ::2]), olat[:, ::2].transpose(1, 0, 2))      # non-contiguous input
+    rows = {'id': 'v', 'hw': (h, w), 'pred_rgb_olat': torch.from_numpy(olat),
+            'pred_alpha': torch.from_numpy(olat[:, 0, :1].copy()), 'pred_rgb': olat[:, 1].copy(),
+            'skipped': torch.zeros(3, 3, dtype=torch.uint8)}
+    Model.write_vis(rows, str(tmp_path))
+    for i in range(nl):
+        got = np.asarray(Image.open(str(tmp_path / 'pred_rgb_olat' / ('%04d.png' % i))))
+        assert np.array_equal(got, olat[:, i].reshape(h, w, 3))
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / 'pred_alpha.png'))), olat[:, 0, 0].reshape(h, w))
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / 'pred_rgb.png'))), olat[:, 1].reshape(h, w, 3))
+    assert not (tmp_path / 'skipped.png').exists()
