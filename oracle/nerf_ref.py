@@ -27,6 +27,15 @@ def bf16_round(x):
     return u.view(np.float32).reshape(x.shape)
 
 
+def bf16_pair_round(x):
+    """The operand the fp32-class kernels see (mlp_x3.hpp: hi = bf16(x), lo = bf16(x - hi)): hi + lo, 16 significant
+    bits.  With it as `quant`, an oracle MLP reproduces those kernels up to the dropped lo x lo products (2^-18
+    relative) and fp32 summation order."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_round(x)
+    return hi + bf16_round(x - hi)
+
+
 def l2_normalize(x, axis, eps):
     """tf.linalg.l2_normalize: x * rsqrt(max(sum(x^2), eps)) (nerf.py:157 eps=1e-12;
     util/math.py:63-64 eps=1e-6)."""
