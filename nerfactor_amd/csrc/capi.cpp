@@ -198,6 +198,10 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -8,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v8)");
+        if (variant == 10)   // EXPERIMENT: variant 7 with 32-bit point-index arithmetic (falls back to 7 for >= 2^31 points)
+            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -10,
+                                                          (hipStream_t)stream),
+                              "nerf_mlp_fwd(bf16, v10)");
         if (variant == 7 || variant == 9)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
                                                           env_int("NFX_ABLATE", 0) > 0 ? 100 + env_int("NFX_ABLATE", 0) : -7,
@@ -208,7 +212,7 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
                                                           env_int("NFX_ABLATE", 0), (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v6)");
         if (variant != 0 && variant != 1)
-            return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8, 9)", variant);
+            return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8, 9, 10)", variant);
         return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
                                                    blocks, (hipStream_t)stream),
                           "nerf_mlp_fwd(bf16)");

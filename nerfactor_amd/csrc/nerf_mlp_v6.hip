@@ -285,7 +285,10 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
     });
 }
 
-template <int AB, int DMA>
+// IDX32 (experiment, NFX_NERF_VARIANT=10, written at the end of round 2 without a GPU): point index / samples per ray
+// in 32 bits (n_pts < 2^31) — the two 64-bit divisions at the top of the point-tile loop are ≈340 of its ≈1150
+// instructions (scripts/isa_tile_stats.py).  The default instantiation's instruction stream is unchanged by this parameter.
+template <int AB, int DMA, bool IDX32 = false>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         for (int c = 0; c < kCT; ++c) {
             m[c] = tl * kTilePts + wave * (32 * kCT) + c * 32 + p;
             const long long mm = m[c] < n_pts ? m[c] : n_pts - 1;
-            const long long ray = mm / n_samples;
+            long long ray;
+            if constexpr (IDX32) ray = (long long)((unsigned)mm / (unsigned)n_samples);
+            else ray = mm / n_samples;
             const float zz = zbuf[mm];
             float x[3], d[3];
 #pragma unroll
@@ -395,14 +400,14 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
 }  // namespace v6
 }  // namespace nfx
 
-template <int AB, int DMA>
+template <int AB, int DMA, bool IDX32 = false>
 static int launch_v6(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                      const void* blob, float* out, int max_blocks, hipStream_t stream) {
     using namespace nfx;
     const int tile_pts = v6::kNW * 32 * v6::kCT;
     const long long n_tiles = (n_pts + tile_pts - 1) / tile_pts;
     const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA>;
+    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA, IDX32>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        v6::lds_of<DMA>);
     if (e != hipSuccess) return (int)e;
@@ -428,7 +433,8 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
         default: break;
     }
 #endif
-    if (ablate == -7 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    if (ablate == -10 && n_pts < (1ll << 31)) return launch_v6<0, 1, true>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 10
+    if (ablate == -7 || ablate == -10 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
     if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }
