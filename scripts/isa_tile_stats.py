@@ -32,7 +32,7 @@ def assembly():
     return open(out).read().split('\n')
 
 
-def segments(lines, kernel='nerf_mlp_bf16_v6_kernelILi0ELi1EE'):
+def segments(lines, kernel='nerf_mlp_bf16_v6_kernelILi0ELi1ELb0EE'):
     label = lambda l: l.startswith('_Z') and ':' in l          # `<mangled name>: ; @<mangled name>`
     start = next(i for i, l in enumerate(lines) if label(l) and kernel in l.split(':')[0])
     end = next(i for i in range(start + 1, len(lines)) if label(lines[i]) or '.end_amdhsa_kernel' in lines[i])
