@@ -23,6 +23,9 @@ class Model(BaseModel):
         self.mlp_chunk = cfg.getint('DEFAULT', 'mlp_chunk')
         self.normal_smooth_weight = cfg.getfloat('DEFAULT', 'normal_smooth_weight', fallback=0.)
         self.lvis_smooth_weight = cfg.getfloat('DEFAULT', 'lvis_smooth_weight', fallback=0.)
+        self.normal_precision = cfg.get('DEFAULT', 'normal_precision', fallback='fp32')
+        if self.normal_precision not in ('bf16', 'fp32'):
+            raise ValueError("normal_precision = %s (bf16 | fp32)" % self.normal_precision)
         self.embedder = self._init_embedder()
         self.net = self._init_net()
         # big world-space coordinates (e.g. MVS reconstructions) are scaled before the MLPs
@@ -80,14 +83,15 @@ class Model(BaseModel):
                 for name, L in (('xyz', lx), ('ldir', ll), ('vdir', lv))}
 
     # ------------------------------------------------------------------ packed weights
-    def _blob128(self, body_name, head_name, in_kind, out_dim, z_dim=0, nets=None):
+    def _blob128(self, body_name, head_name, in_kind, out_dim, z_dim=0, nets=None, prec=None):
         nets = self.net if nets is None else nets
+        prec = self.precision if prec is None else prec
         ks, bs = nets[body_name].kernels_and_biases()
         ko, bo = nets[head_name].kernels_and_biases()
         ks, bs = ks + ko, bs + bo
         return self._packed(
-            body_name + self.precision, ks + bs,
-            lambda k, b: ops.pack_mlp128_weights(k, b, in_kind, out_dim, z_dim=z_dim, prec=self.precision))
+            body_name + prec, ks + bs,
+            lambda k, b: ops.pack_mlp128_weights(k, b, in_kind, out_dim, z_dim=z_dim, prec=prec))
 
     def _train_blob128(self, body_name, head_name, in_kind, out_dim, nets=None):
         """Forward + dgrad fragments for the fused backward kernel (packed lazily, cached like _blob128)."""
@@ -109,17 +113,20 @@ class Model(BaseModel):
     def _wants_grad(params):
         return torch.is_grad_enabled() and any(p.requires_grad for p in params)
 
-    def _mlp128_xyz(self, pts, body, head, out_dim, out_act=None, post_scale=1., post_bias=0.):
-        """One xyz-conditioned head; differentiable w.r.t. its weights when autograd is recording."""
-        blob = self._blob128(body, head, _capi.IN_XYZ, out_dim)
+    def _mlp128_xyz(self, pts, body, head, out_dim, out_act=None, post_scale=1., post_bias=0., infer_prec=None):
+        """One xyz-conditioned head; differentiable w.r.t. its weights when autograd is recording.  `infer_prec`:
+        operand type of the forward-only evaluation (vali / test / render) when it differs from `precision`."""
         params = self._params128(body, head)
         if self._wants_grad(params):
+            blob = self._blob128(body, head, _capi.IN_XYZ, out_dim)
             return nfx_grad.Mlp128Xyz.apply(
                 pts, blob, lambda: self._train_blob128(body, head, _capi.IN_XYZ, out_dim), self.precision, out_dim,
                 out_act,
                 self.xyz_scale, post_scale, post_bias, *params)
+        prec = self.precision if infer_prec is None else infer_prec
+        blob = self._blob128(body, head, _capi.IN_XYZ, out_dim, prec=prec)
         return ops.mlp128_xyz_fwd(pts, blob, out_dim, out_act=out_act, xyz_scale=self.xyz_scale,
-                                  post_scale=post_scale, post_bias=post_bias, prec=self.precision)
+                                  post_scale=post_scale, post_bias=post_bias, prec=prec)
 
     # ------------------------------------------------------------------ geometry helpers
     def _calc_ldir(self, pts):
@@ -167,8 +174,16 @@ class Model(BaseModel):
         return pred, gt, loss_kwargs, to_vis
 
     def _pred_normal_at(self, pts, eps=1e-6):
-        """Raw (un-normalised) normals, +eps so an all-zero prediction cannot break the tangents."""
-        return self._mlp128_xyz(pts, 'normal_mlp', 'normal_out', 3, out_act=None, post_bias=eps)
+        """Raw (un-normalised) normals, +eps so an all-zero prediction cannot break the tangents.
+
+        Rendering evaluates this head with fp32-class operands (bf16 hi / lo pairs, mlp128_x3.hip) even when
+        `precision = bf16` (ini key `normal_precision`, default fp32): the microfacet BRDF divides by
+        4 |l.n| |v.n| (microfacet.py:57), which amplifies a bf16-sized error of the normal without bound towards
+        grazing directions — 0.37 max-abs on the rendered 800 x 800 frame in round 2 — while the head is 0.2 % of a
+        render's matrix work.  A training step (autograd recording) keeps the bf16 forward its backward kernel
+        re-computes, so the gradient stays the exact derivative of the function the loss saw."""
+        return self._mlp128_xyz(pts, 'normal_mlp', 'normal_out', 3, out_act=None, post_bias=eps,
+                                infer_prec=self.normal_precision)
 
     def _pred_lvis_at(self, pts, surf2l=None, dir_pts=None):
         """[N,L] visibility of every light from every point.  Directions are recomputed in the
