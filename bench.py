@@ -15,6 +15,12 @@ BASELINE.json's metric is "rays/sec (64 samples/ray, 512 light dirs) + PSNR vs T
     normals / albedo / BRDF-latent MLPs -> light-visibility MLP over the light sphere -> (learned BRDF MLP |
     microfacet BRDF) -> BRDF x visibility x lighting integral -> pixels.
 
+  * leg `train` (configs[3], "C4", under the "train" key): optim.train_step of `nerfactor_microfacet`, `nerfactor` and
+    `nerf` at 1024 rays per GPU and step (weak scaling, `n_rays_per_step` of config/*.ini) — forward, fused loss,
+    backward through the libnfx kernels, ONE all-reduce of [gradients | loss] (RCCL when N > 1), fused AMSGrad;
+  * leg `olat` (the OLAT half of configs[4], under the "olat" key): one 800x800 view with `relight_olat=True`
+    (512 one-light-at-a-time renders per point, nerfactor.py:348-364), HBM-bound on the rows it writes.
+
 Inputs are resident in HBM before every timed region; every timed region is bracketed by barrier +
 torch.cuda.synchronize() and EXACTLY K steps long.
 
@@ -47,6 +53,7 @@ LVIS_MAC, BRDF_MAC = 72320, 53888    # MAC per (p
 HEAD_MAC = 65664 + 65664             # normal + albedo heads per point (+ 65 408 | 65 920 for the BRDF latent)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 N_LIGHTS, N_PROBES = 512, 8
+PEAK_HBM_GBS = 8000.0                # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -243,7 +250,37 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         if base is not None:
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = out["value"] / base["value"]
+        out["parity_fitted_weights"] = nerf_fitted_parity(args, ops, dev, host_views[0])
     return out
+
+
+def nerf_fitted_parity(args, ops, dev, host_view, n=2048):
+    """The same render on the NeRF weights FITTED to a scene (tests/golden/nerf_trained_fp16.npz, the networks of the
+    reference fixtures; empty space sits at a robustly negative density): the glorot "opaque variant" weights of the
+    timed frame put ~9 % of the rays on the reference formula's own discontinuity (alpha_last = [sigma_last > 0],
+    DESIGN.md §4), fitted weights < 2 % — max-abs is reported over ALL rays and outside the counted band."""
+    from oracle import torch_ref
+    from tests.golden import golden_inputs as gi
+    nets = gi.trained_nerf_nets()
+    from nerfactor_amd import synth
+    blobs = [ops.pack_nerf_weights(*synth.nerf_layers(net), prec=args.precision).to(dev) for net in nets]
+    idx = np.sort(np.random.default_rng(1).permutation(host_view[0].shape[0])[:n])
+    o, d = host_view[0][idx], host_view[1][idx]
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        ref = torch_ref.render_rays(torch.from_numpy(o), torch.from_numpy(d), *[torch_ref.to_torch_net(x) for x in nets])
+    got = nerf_render_step(ops, [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))], blobs,
+                           prec=args.precision).cpu().numpy()
+    want = ref[1]['rgb'].numpy()
+    sig = np.minimum(ref[2]['sigma_last_coarse'].numpy(), ref[2]['sigma_last_fine'].numpy())
+    stable = sig > 0.06
+    err = np.abs(got - want).max(1)
+    return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err[stable].max()),
+            "max_abs_all_rays": float(err.max()), "rays_compared": int(n),
+            "rays_excluded_from_max_abs": int((~stable).sum()),
+            "frac_rays_above_3e-2": float((err > 3e-2).mean()),
+            "weights": "tests/golden/nerf_trained_fp16.npz (fitted to the unit-sphere scene)",
+            "reference": "oracle/torch_ref.py (fp32) on the same rays of the timed view"}
 
 
 # ------------------------------------------------------------------------------------------------ NeRFactor legs
@@ -279,6 +316,9 @@ class KernelTimer:
     def mean_ms(self, name):
         ev = self.events[name]
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+    def all_ms(self, name):
+        return [a.elapsed_time(b) for a, b in self.events[name]]
 
 
 def nerfactor_nets_of(model, variant):
@@ -408,22 +448,26 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
             p = model(b, mode='test', relight_probes=True)[0]
             got = torch.cat((p['rgb'][:, None], p['rgb_probes']), 1).cpu().numpy()
             want = ref['rgb'].numpy()[:hi]
-            # points seen at grazing angles: the reference divides the specular term by 4 |l.n| |v.n|
-            # (microfacet.py:57), so a bf16-sized error of the predicted normal is amplified without bound as
-            # v.n -> 0 (the fp32 oracle run with bf16-rounded MLP operands shows the same outliers); they stay in the
-            # PSNR and in max_abs_all_points, max_abs is over |v.n| > 0.05
+            # No point is excused: max_abs is over every foreground point and all nine lights.  (Round 2 excluded view
+            # directions grazing the predicted normal, |n.v| < 0.05, where spec / (4 |l.n| |v.n|) of microfacet.py:57
+            # amplified the bf16 error of the normal head; that head now runs with fp32-class operands.)  The grazing
+            # subset is still reported, as information.
             nrm = ref['normal'].numpy()[:hi]
             vdir = host_batches[0][2][:hi] - host_batches[0][6][:hi]
             vdir /= np.maximum(np.linalg.norm(vdir, axis=1, keepdims=True), 1e-6)
             fg = host_batches[0][5][:hi, 0] > 0
-            stable = fg & (np.abs((nrm * vdir).sum(1)) > 0.05)
+            grazing = fg & (np.abs((nrm * vdir).sum(1)) <= 0.05)
             err = np.abs(got - want).max((1, 2))
             out["parity"] = {
                 "psnr_db": psnr_uint8_luma(got.reshape(-1, 3), want.reshape(-1, 3)),
-                "max_abs": float(err[stable].max()), "max_abs_all_points": float(err.max()),
-                "max_abs_trained_light": float(np.abs(got[:, 0] - want[:, 0])[stable].max()),
+                "max_abs": float(err[fg].max()), "max_abs_all_points": float(err.max()),
+                "max_abs_trained_light": float(np.abs(got[:, 0] - want[:, 0])[fg].max()),
                 "frac_points_above_3e-2": float((err[fg] > 3e-2).mean()),
-                "grazing_points_excluded_from_max_abs": int((fg & ~stable).sum()),
+                "points_above_3e-2": int((err[fg] > 3e-2).sum()),
+                "grazing_points_excluded_from_max_abs": 0,
+                "grazing_points_abs_n_dot_v_below_0.05": int(grazing.sum()),
+                "max_abs_outside_grazing": float(err[fg & ~grazing].max()),
+                "normal_head_precision": model.normal_precision,
                 "max_abs_lvis": float(np.abs(p['lvis'].cpu().numpy() - ref['lvis'].numpy()[:hi]).max()),
                 "max_abs_albedo": float(np.abs(p['albedo'].cpu().numpy() - ref['albedo'].numpy()[:hi]).max()),
                 "max_abs_normal": float(np.abs(p['normal'].cpu().numpy() - nrm).max()),
@@ -441,6 +485,135 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ train leg (configs[3])
+TRAIN_RAYS = 1024          # n_rays_per_step of config/*.ini; per GPU (weak scaling)
+TRAIN_STEPS_PER_BENCH_STEP = 20
+
+
+def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
+    """K x 20 eager optim.train_step calls of one model at 1024 rays per GPU (SURVEY.md §8d "C4", trainvali.py:273-295):
+    forward (clean + jittered points), fused loss, backward through the libnfx kernels, one all-reduce of the flat
+    [gradients | loss] bucket over all ranks, fused AMSGrad.  The batch is resident in HBM and the same every step
+    (the loader is measured by scripts/bench_loader.py)."""
+    from nerfactor_amd import dist as nfx_dist, optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(5)                                   # identical initial weights on every rank
+    extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if 'nerfactor' in name else {}
+    cfg = make_config(name, precision=args.precision, **extra)
+    model = get_model_class(name)(cfg).to(dev)
+    opt = optim.make_optimizer(model, cfg)
+    nfx_dist.broadcast_model(model, opt)
+    rng = np.random.default_rng(100 + rank)
+    n = TRAIN_RAYS
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+    nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    if name == 'nerf':       # rays from the camera towards the unit cube
+        batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
+    else:
+        batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+                 mark_all_foreground(torch.ones(n, 1, device=dev)), xyz, nrm, t(rng.uniform(size=(n, 512))))
+    global_bs = n * world
+    steps = args.steps * TRAIN_STEPS_PER_BENCH_STEP
+    bwd_names = ['nerf_mlp_bwd'] if name == 'nerf' else ['mlp128_bwd']
+    losses = []
+    with KernelTimer(ops, bwd_names) as kt:
+        def step(k):
+            kt.on = k is not None
+            loss, _ = optim.train_step(model, batch, opt, global_bs)
+            if k is not None:
+                losses.append(loss)
+            return loss
+        elapsed, _ = timed(step, steps, max(3, args.warmup), barrier)
+        kt.on = False
+    elapsed = max_over_ranks(elapsed)
+    model.flush_numerics(block=True)
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(losses).all(), "non-finite training loss in the timed steps"
+    dt = elapsed / steps
+    if name == 'nerf':
+        # per ray 64 coarse + 192 fine points; forward + re-computed forward + dgrad + wgrad = 4 x the forward MACs
+        flops = 4 * n * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT
+        what = "64+128 samples per ray, perturb on; FLOPs = 4 x forward (forward, re-computed forward, dgrad, wgrad)"
+        dom, per_step = 'nerf_mlp_bwd', 2
+    else:
+        rows = n * N_LIGHTS * 2                                # clean + jittered visibility rows
+        flops = 3 * 2 * (rows * LVIS_MAC + 2 * 3 * n * 65664)   # SURVEY §8d: 2 (jitter) x 3 (fwd + dgrad + wgrad) x forward
+        what = "512 lights, xyz jitter on; FLOPs = 2 (clean + jittered) x 3 (forward, dgrad, wgrad) x the four trainable MLPs' forward"
+        dom, per_step = 'mlp128_bwd', 4
+    calls = np.asarray(kt.all_ms(dom))
+    if calls.size != steps * per_step:
+        per_step = max(1, calls.size // steps)
+    calls = calls[:steps * per_step].reshape(steps, per_step)  # per step: the calls in launch order
+    big = calls.max(1)                                          # the largest call of a step (light visibility / fine net)
+    tf = flops / dt / 1e12
+    return {
+        "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),
+        "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
+        "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
+        "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
+            torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if world > 1 else "none (one rank)",
+        "roofline": {"bound": "mfma", "kernel": "whole step; largest backward call = ops.%s (fused backward + batched "
+                                                "weight-gradient launches)" % dom,
+                     "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
+                     "flop_per_step_per_gpu": flops, "traffic": None,
+                     "largest_backward_call_ms": float(big.mean()),
+                     "backward_calls_ms_per_step": float(calls.sum(1).mean())},
+    }
+
+
+# ------------------------------------------------------------------------------------------------ OLAT leg (configs[4])
+def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
+    """One-light-at-a-time relighting of an 800 x 800 view (test.py:182, nerfactor.py:348-364): the render of the
+    nerfactor_microfacet leg plus shade_olat_kernel, which writes 512 x 3 floats per foreground point — HBM-bound."""
+    from nerfactor_amd import synth
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    name = 'nerfactor_microfacet'
+    torch.manual_seed(5)
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
+                      test_envmap_dir='', xyz_jitter_std='0', precision=args.precision)
+    model = get_model_class(name)(cfg).to(dev)
+    n = H * W
+    sh = Shards(n, rank, world, args.scaling)
+    batches, n_fg_local = [], 0
+    for v in range(sh.n_views):
+        hb = synth.surface_batch(n, seed=1 + 10 * v, n_lights=N_LIGHTS)
+        batches.append(tuple(None if a is None else torch.from_numpy(a[sh.lo:sh.hi]).to(dev) for a in hb))
+        n_fg_local += int(hb[5][sh.lo:sh.hi].sum())
+    with KernelTimer(ops, ['shade_olat_fwd']) as kt:
+        def step(k):
+            kt.on = k is not None
+            out = None
+            for b in batches:
+                out = model(b, mode='test', relight_olat=True)[0]['rgb_olat'][:1]
+            return out
+        elapsed, out = timed(step, args.steps, args.warmup, barrier)
+        kt.on = False
+    elapsed = max_over_ranks(elapsed)
+    assert torch.isfinite(out).all()
+    fg_per_call = n_fg_local / sh.n_views
+    k_s = kt.mean_ms('shade_olat_fwd') * 1e-3
+    # algorithmic bytes: 512 x 12 B written per foreground point; read: the point's visibility row (2 KiB) + 52 B
+    alg = fg_per_call * (N_LIGHTS * 12 + N_LIGHTS * 4 + 52)
+    gbs = alg / k_s / 1e9
+    return {
+        "workload": "nerfactor_microfacet OLAT relighting (BASELINE.json configs[4], OLAT half): 800x800 surface points "
+                    "per view (60 % foreground), 512 one-light renders per point, Model.call(mode='test', relight_olat=True)",
+        "points_per_s": sh.rays_per_step_all_ranks * args.steps / elapsed,
+        "ms_per_step": elapsed / args.steps * 1e3, "ms_per_view_per_gpu": elapsed / args.steps * 1e3 * world / sh.n_views,
+        "olat_images_per_s": N_LIGHTS * sh.n_views * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "kernel": "shade_olat_kernel (%d foreground points x 512 lights x 3 floats written)"
+                                               % int(fg_per_call),
+                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                     "avg_launch_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                     "share_of_step": k_s * sh.n_views / (elapsed / args.steps)},
+    }
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -448,7 +621,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor')
+    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat')
+    ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
     ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=('bf16', 'fp32'), default='bf16',
@@ -487,13 +661,17 @@ def main():
     legs = [s for s in args.legs.split(',') if s]
     nerf = nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'nerf' in legs else None
     nerfactor = {name: nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
-                 for name in legs if name != 'nerf'}
+                 for name in legs if name in ('nerfactor_microfacet', 'nerfactor')}
+    train = {name: train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
+             for name in args.train_models.split(',') if name} if 'train' in legs and args.precision == 'bf16' else {}
+    olat = olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'olat' in legs else None
     if rank == 0:
         out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-class: hi/lo operand pairs)",
-               "data": "synthetic"}
+               "data": "synthetic", "world_size": world,
+               "collective_backend": (dist.get_backend() if dist.is_initialized() else "none (single process)")}
         if rehearsal:
             out["rehearsal"] = "all ranks share GPU 0 over gloo: a functional check of the N > 1 path, not a measurement"
         if nerf is not None:   # (profiling runs may time the NeRFactor legs alone: --legs nerfactor)
@@ -502,6 +680,10 @@ def main():
                 out["psnr_db"], out["max_abs"] = nerf["parity"]["psnr_db"], nerf["parity"]["max_abs"]
         if nerfactor:
             out["nerfactor"] = nerfactor
+        if train:
+            out["train"] = train
+        if olat is not None:
+            out["olat"] = olat
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

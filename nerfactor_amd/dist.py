@@ -142,23 +142,32 @@ def sum_over_ranks(tensor):
 
 
 def gather_cat(tensor, dst=0):
-    """Ragged concatenation along dim 0 of every rank's tensor on `dst` (ranks hold contiguous ray
-    shards of sizes differing by at most one: pad to the maximum, all_gather, trim).  Other ranks
-    get their own shard back.  Off the hot path: validation / visualisation only."""
+    """Ragged concatenation along dim 0 of every rank's tensor ON `dst` ONLY (ranks hold contiguous ray shards);
+    other ranks get their own shard back.  Point-to-point: every other rank sends its shard to `dst`, which receives
+    straight into its slice of the result — no padding, nothing lands on the ranks that would throw it away (an
+    all_gather of an 800 x 800 x 512-light OLAT view would put the whole ~1 GB view on every GPU).  Off the hot path:
+    validation / visualisation only."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tensor
-    ws = dist.get_world_size()
+    ws, rank = dist.get_world_size(), dist.get_rank()
     n = torch.tensor([tensor.shape[0]], dtype=torch.int64, device=tensor.device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
-    pad = torch.zeros((max(sizes),) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
-    pad[:tensor.shape[0]] = tensor
-    parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad)
-    if dist.get_rank() != dst:
+    tensor = tensor.contiguous()
+    if rank != dst:
+        if sizes[rank]:
+            dist.send(tensor, dst)
         return tensor
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
+    out = torch.empty((sum(sizes),) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    off = 0
+    for r, s in enumerate(sizes):
+        if r == dst:
+            out[off:off + s] = tensor
+        elif s:
+            dist.recv(out[off:off + s], r)
+        off += s
+    return out
 
 
 def gather_objects(obj):

@@ -124,13 +124,10 @@ class CheckpointManager:
 
 
 def shard_batch(batch):
-    """Contiguous ray shard of this rank for every per-ray field of a flat batch tuple."""
-    rank, ws = nfx_dist.world()
-    if ws == 1:
-        return batch
-    n = len(batch[0])
-    lo, hi = nfx_dist.shard_range(n, rank, ws)
-    return tuple(x[lo:hi] for x in batch)
+    """Contiguous ray shard of this rank for every per-ray field of a flat batch tuple (util/shard.py: keeps the
+    dataset's foreground-only tag, so a multi-rank training step skips the torch.nonzero compaction as well)."""
+    from .util import shard as shardutil
+    return shardutil.shard_batch(batch)
 
 
 def vali_step(model, batch, global_bs):

@@ -1,7 +1,8 @@
 """Rays-within-view sharding for the render drivers (the reference's analogue is MirroredStrategy
 splitting the flat per-ray batch over replicas, trainvali.py:85,100): rank r renders the contiguous ray range
 [r n / N, (r + 1) n / N) of EVERY view — so 4 test views keep 8 GPUs busy — quantises its own rows, and only uint8 rows
-travel to rank 0, which writes the images.  No collective on the data path."""
+travel, point to point, to rank 0 (dist.gather_cat: send / recv into rank 0's buffer), which writes the images.  No
+collective on the data path."""
 import torch
 
 from ... import dist as nfx_dist

@@ -197,4 +197,16 @@ class GraphedTrainStep:
         if flags is not None:               # this step's check_numerics verdicts, shipped like the eager path does
             model.__dict__.setdefault('_pending_numerics', []).extend(zip(messages, flags.clone().unbind(0)))
             model.flush_numerics()
-        return total, to_vis
+        return total.clone(), self._live_vis(to_vis, batch)
+
+    @staticmethod
+    def _live_vis(to_vis, batch):
+        """What the caller may keep: the captured `to_vis` tensors are the graph's static outputs, overwritten by every
+        replay (trainvali keeps the first steps' entries until the end of the epoch), and its non-tensor fields froze
+        at the capture-time batch — so tensors are cloned and `id` is taken from the live batch."""
+        if not isinstance(to_vis, dict):
+            return to_vis
+        out = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in to_vis.items()}
+        if 'id' in out and len(batch) > 0 and not isinstance(batch[0], torch.Tensor):
+            out['id'] = batch[0]
+        return out

@@ -69,6 +69,10 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = nfx_dist.max_over_ranks(time.perf_counter() - t0, device=dev) / args.steps
+    if hasattr(model, 'flush_numerics'):
+        model.flush_numerics(block=True)      # raises FloatingPointError if any step's check_numerics failed
+    if not np.isfinite(float(loss)):
+        raise SystemExit("bench_train: non-finite loss %r after the timed steps — the timing means nothing" % float(loss))
     if rank == 0:
         rows = n * 512 * 2  # clean + jittered visibility rows
         if args.model == 'nerf':   # forward + recomputed forward + dgrad + wgrad of (64 + 192) points per ray

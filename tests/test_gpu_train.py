@@ -707,12 +707,16 @@ def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
     assert torch.equal(got, nfx_grad.PairLoss.apply(alpha, bg, spec, rgb_p, rgb_g, lv_p, lv_g, lv_j, r_p, r_j))
 
 
-@pytest.mark.parametrize("name", ["shape", "nerfactor_microfacet"])
-def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name):
-    """optim.GraphedTrainStep (the step captured in a hipGraph and replayed) against optim.train_step: with the jitter
-    off the two are the same kernels in the same order, so losses, parameters and optimizer state after 6 steps on
-    changing batches must agree bit for bit; the version counters move, so an eager vali call afterwards sees the
-    trained weights."""
+@pytest.mark.parametrize("name,jitter,steps", [("shape", "0.01", 200), ("nerfactor_microfacet", "0.01", 200),
+                                               ("nerfactor", "0.01", 200), ("nerfactor_microfacet", "0", 12)])
+def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, steps):
+    """optim.GraphedTrainStep (the step captured in a hipGraph and replayed) against optim.train_step: the two are the
+    same kernels in the same order and torch's generator hands a replay the noise the eager step would have drawn, so
+    losses, parameters and optimizer state after 200 steps on changing batches — xyz jitter ON, as the shipped configs
+    train — must agree bit for bit and stay finite (round 2's six-step, jitter-off form missed that its benchmark ended
+    in NaN; scripts/diag_graph_diverge.py is the step-by-step version of this test).  The version counters move, so an
+    eager vali call afterwards sees the trained weights; the `to_vis` a replay returns belongs to the caller (clones of
+    the graph's static outputs, `id` of the live batch)."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
@@ -723,35 +727,51 @@ def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name):
     def batches():
         rng = np.random.default_rng(7)
         out = []
-        for _ in range(6):
+        for i in range(6):
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
             xyz = t(rng.uniform(-1, 1, size=(n, 3)))
             nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
             cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
-            out.append((None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+            out.append((['view%d' % i] * n, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
                         mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz, nrm, t(rng.uniform(size=(n, 512)))))
         return out
 
     def run(graph):
         torch.manual_seed(11)
-        cfg = make_config(name, xyz_jitter_std='0', **extra)
+        cfg = make_config(name, xyz_jitter_std=jitter, **extra)
         model = get_model_class(name)(cfg).to(cuda)
         opt = optim.make_optimizer(model, cfg)
         step = optim.GraphedTrainStep(model, opt, n, warmup=2) if graph else (lambda b: optim.train_step(model, b, opt, n))
-        losses = [step(b)[0].clone() for b in batches()]
+        bs = batches()
+        losses, kept = [], []
+        for i in range(steps):
+            loss, to_vis = step(bs[i % len(bs)])
+            losses.append(loss)
+            if i in (3, 4):           # replays (the capture happens at step 2): what trainvali keeps for an epoch
+                kept.append(to_vis)
         model.flush_numerics(block=True)
         with torch.no_grad():
             vali = model(batches()[0], mode='vali')[0]
-        return torch.stack(losses), opt.flat.clone(), opt.vhat.clone(), opt.iterations, vali, step
+        return torch.stack(losses), opt.flat.clone(), opt.vhat.clone(), opt.iterations, vali, step, kept
 
-    l0, p0, v0, it0, vali0, _ = run(False)
-    l1, p1, v1, it1, vali1, step = run(True)
-    assert len(step.graphs) == 1 and it0 == it1 == 6
+    l0, p0, v0, it0, vali0, _, kept0 = run(False)
+    l1, p1, v1, it1, vali1, step, kept1 = run(True)
+    assert len(step.graphs) == 1 and it0 == it1 == steps
+    assert bool(torch.isfinite(l0).all()) and bool(torch.isfinite(p0).all())
     assert torch.equal(l0, l1), (l0, l1)     # every gradient is order-independent (ordered wgrad, fixed-point d_light)
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
     for k in vali0:
         if isinstance(vali0[k], torch.Tensor):
             assert torch.equal(vali0[k], vali1[k]), k
+    # the kept to_vis of two consecutive replays: each equals the eager step's and they differ from one another
+    for a, b in zip(kept0, kept1):
+        assert a['id'] == b['id']
+        for k in a:
+            if isinstance(a[k], torch.Tensor):
+                assert torch.equal(a[k], b[k]), k
+    assert kept1[0]['id'] != kept1[1]['id']
+    key = 'pred_lvis' if 'pred_lvis' in kept1[0] else 'pred_normal'
+    assert not torch.equal(kept1[0][key], kept1[1][key])
 
 
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor"])
