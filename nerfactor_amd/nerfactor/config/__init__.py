@@ -50,6 +50,13 @@ CONFIGS['nerfactor_microfacet'] = dict(
      if k not in ('default_z', 'learned_brdf_scale')},
     model='nerfactor_microfacet', rough_min='0.1', default_rough='0.3', fresnel_f0='0.04',
     brdf_smooth_weight='0')
+# the reference's remaining shipped .ini files (config/*.ini) differ from the ones above in a few keys each
+CONFIGS['shape_mvs'] = dict(CONFIGS['shape'], dataset='mvs_shape', xyz_scale='1e-3')              # DTU scenes have huge XYZs
+CONFIGS['nerfactor_mvs'] = dict(CONFIGS['nerfactor'], dataset='mvs_shape', xyz_scale='1e-3')
+CONFIGS['nerfactor_no_geom_opt'] = dict(CONFIGS['nerfactor'], shape_mode='nerf')                 # (the file's name; its outroot says "no_geom_refine")
+CONFIGS['nerfactor_no_geom_pretrain'] = dict(CONFIGS['nerfactor'], shape_mode='scratch')
+CONFIGS['nerfactor_no_smooth'] = dict(CONFIGS['nerfactor'], normal_smooth_weight='0', lvis_smooth_weight='0',
+                                      albedo_smooth_weight='0', brdf_smooth_weight='0')
 
 
 def make_config(name, **overrides):

@@ -44,11 +44,16 @@ class Dataset(NeRFDataset):
                 self.meta2buf[m] = paths
         return keep
 
-    def _process_example_precache(self, metadata_path):
-        cfg = self.config
+    def _rays_of(self, metadata_path):
+        """(rayo, rayd) [H, W, 3] float32 of one view; the MVS variant (datasets/mvs_shape.py) has camera positions only."""
         c2w, angle_x, imh, imw = self._read_camera(metadata_path)
         rayo, rayd = self._gen_rays(c2w, angle_x, imh, imw)
-        rayo, rayd = rayo.astype(np.float32), rayd.astype(np.float32)
+        return rayo.astype(np.float32), rayd.astype(np.float32)
+
+    def _process_example_precache(self, metadata_path):
+        cfg = self.config
+        imh = cfg.getint('DEFAULT', 'imh')
+        rayo, rayd = self._rays_of(metadata_path)
         paths = self.meta2buf[metadata_path]
         xyz = np.load(paths['xyz']).astype(np.float32)
         normal = np.load(paths['normal']).astype(np.float32)
@@ -69,6 +74,8 @@ class Dataset(NeRFDataset):
             alpha = alpha[:, :, 0]
         if imh != xyz.shape[0]:
             xyz, normal, lvis, alpha, rgb = (resize(a, imh) for a in (xyz, normal, lvis, alpha, rgb))
+        if rayo.shape[0] != xyz.shape[0]:       # rays at the metadata's resolution, buffers at imh (MVS views)
+            rayo, rayd = resize(rayo, xyz.shape[0]), resize(rayd, xyz.shape[0])
         if np.isclose(xyz, rayo).all(axis=2).any():
             raise ValueError("Found XYZs coinciding with the camera")
         normal = normal / np.maximum(np.linalg.norm(normal, axis=2, keepdims=True), 1e-12)

@@ -10,6 +10,7 @@ LIGHT_SCALE = {'nfl': 0.3, 'nfm': 2.}      # keeps most pixels of both variants 
 GEOM_RAYS, GEOM_LIGHT_H, GEOM_SURF_IDX = 16, 8, [3, 4, 5, 11, 13, 15]
 GEOM_BBOX = '-1.5,1.5,-1.5,1.5,-1.5,1.5'
 SCENE_KW = dict(imh=12, imw=16, n_train=2, n_val=1, n_test=1, light_h=4, seed=5)     # tests/synth_scene.write_scene
+MVS_SCENE_KW = dict(imh=12, imw=16, n_train=2, n_val=1, n_test=1, light_h=16, seed=3)  # tests/synth_scene.write_mvs_scene
 GRAD_NERF_RAYS = 32          # rays of the reference-differentiated NeRF training step (make_reference_grad_golden.py)
 BRDF_NAMES = ['alum-bronze', 'blue-fabric', 'chrome', 'delrin', 'nylon']   # sorted, as xm.os.sortglob returns them
 

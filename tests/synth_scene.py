@@ -65,6 +65,34 @@ def write_scene(root, imh=16, imw=16, n_train=3, n_val=1, n_test=2, light_h=16, 
     return data_root, nerf_root
 
 
+def write_mvs_scene(root, imh=12, imw=16, n_train=2, n_val=1, n_test=1, light_h=16, seed=3, xyz_units=1000.):
+    """The same sphere in the layout datasets/mvs_shape.py reads (reference mvs_shape.py:28-121): everything of a view
+    in <root>/<split>_%03d/ — metadata.json with cam_loc / imh / imw only, the four surface buffers, rgba.png for
+    train / val — plus <root>/lights.npz (models/shape.py:63-69).  Coordinates in `xyz_units` (DTU scenes are
+    millimetre-sized; the MVS configs set xyz_scale = 1e-3)."""
+    rng = np.random.default_rng(seed)
+    light_xyz, light_areas = nerfactor_ref.gen_light_xyz(light_h, 2 * light_h)
+    os.makedirs(root, exist_ok=True)
+    np.savez(join(root, 'lights.npz'), lxyzs=(light_xyz * xyz_units).astype(np.float32), lareas=light_areas.astype(np.float32))
+    for split, n in (('train', n_train), ('val', n_val), ('test', n_test)):
+        for i in range(n):
+            v = rng.normal(size=3)
+            v[2] = abs(v[2]) + 0.3
+            cam_loc = 4. * v / np.linalg.norm(v)
+            _, rgb, _, alpha, xyz, normal, lvis = _view(cam_loc, imh, imw, light_xyz.reshape(-1, 3))
+            view = join(root, '%s_%03d' % (split, i))
+            os.makedirs(view, exist_ok=True)
+            with open(join(view, 'metadata.json'), 'w') as h:
+                json.dump({'cam_loc': [float(x) * xyz_units for x in cam_loc], 'imh': imh, 'imw': imw}, h)
+            if split != 'test':
+                _png(join(view, 'rgba.png'), np.concatenate((rgb, alpha[..., None]), -1))
+            _png(join(view, 'alpha.png'), alpha)
+            np.save(join(view, 'xyz.npy'), (xyz * xyz_units).astype(np.float32))
+            np.save(join(view, 'normal.npy'), (normal * 1.7).astype(np.float32))     # un-normalised on disk: the loader re-normalises
+            np.save(join(view, 'lvis.npy'), (lvis * 1.2 - 0.1).astype(np.float32))   # out of [0, 1] on disk: the loader clips
+    return root
+
+
 def write_merl(root, names=('alum-bronze', 'blue_rubber', 'gold-metallic-paint'), n_rows=4096, seed=0):
     """Tiny stand-in for the pre-processed MERL tables (datasets/brdf_merl.py layout): <root>/{train,vali}_<name>.npz
     and one test.npz; reflectance = a smooth positive lobe of the Rusinkiewicz angles, different per material."""

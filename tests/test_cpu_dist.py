@@ -220,3 +220,27 @@ def test_train_step_hands_back_detached_visualisation_tensors():
     assert out['id'] == ['a'] and out['pred_rgb'].grad_fn is None and not out['pred_rgb'].requires_grad
     assert torch.equal(out['pred_rgb'], to_vis['pred_rgb']) and out['gt_rgb'] is not None
     assert optim._detached(None) is None
+
+
+def _gather_cat_worker(rank, world):
+    from nerfactor_amd import dist as nd
+    from nerfactor_amd.nerfactor.util import shard as shardutil
+    n = 1001                                    # not divisible by 3: ragged shards
+    full = (torch.arange(n * 4 * 3) % 251).to(torch.uint8).reshape(n, 4, 3)
+    lo, hi = nd.shard_range(n)
+    rows = {'hw': (7, 143), 'id': 'v', 'pred_rgb': full[lo:hi].clone(), 'flat': full[lo:hi, 0, 0].clone()}
+    out = shardutil.gather_rows(rows)
+    if rank == 0:                               # rank 0 alone holds the stitched view, in ray order
+        assert torch.equal(out['pred_rgb'], full) and torch.equal(out['flat'], full[:, 0, 0])
+        assert out['hw'] == (7, 143) and out['id'] == 'v'
+    else:
+        assert out is None
+    got = nd.gather_cat(full[lo:hi].clone(), dst=1)
+    assert torch.equal(got, full if rank == 1 else full[lo:hi])
+
+
+def test_rank0_gather_of_uint8_rows_is_point_to_point_and_ragged():
+    """dist.gather_cat / util.shard.gather_rows ("rank 0 optionally gathers uint8 frames only"): three
+    ranks with ragged shards; only the destination rank assembles the view."""
+    from tests.mp_util import run_workers
+    run_workers(_gather_cat_worker, world=3)
