@@ -56,7 +56,9 @@ def test_nerf_plugin_render_vs_reference_outputs(nfx_lib, cuda, prec):
     band = 0.06 if prec == 'bf16' else 1e-2
     ok_c = np.abs(aux['rgbs_coarse'][:, -1, 3]) > band
     ok_f = ok_c & (np.abs(aux['rgbs_fine'][:, -1, 3]) > band)
-    assert ok_f.mean() > 0.7
+    # 56 of the 64 rays of this glorot ("opaque variant") fixture are outside the band (8 inside, counted here; the fitted
+    # weights of test_trained_nerf_1024_rays_vs_reference_outputs have < 2 % inside) — an exact count, so a drift of the oracle shows
+    assert int(ok_f.sum()) == (56 if prec == 'bf16' else 64), int(ok_f.sum())
     tol_rgb, tol_occu, tol_med = (3e-2, 8e-2, 5e-3) if prec == 'bf16' else (2e-3, 2e-3, 1e-4)
     for lvl, ok in (('coarse', ok_c), ('fine', ok_f)):
         rgb = to_vis[lvl + '_rgb'].cpu().numpy()
