@@ -28,6 +28,9 @@ def main():
     ap.add_argument('--jitter', default='0.01')
     ap.add_argument('--seed', type=int, default=11)
     ap.add_argument('--data-seed', type=int, default=7)
+    ap.add_argument('--batches', type=int, default=8)
+    ap.add_argument('--keep-vis', action='store_true', help='keep the to_vis of steps 3 and 4 alive, as trainvali does')
+    ap.add_argument('--ids', action='store_true', help='batch[0] = list of view ids (as the datasets produce)')
     ap.add_argument('--same-batch', action='store_true', help='feed one batch every step (what bench_train.py does)')
     args = ap.parse_args()
     from nerfactor_amd import build
@@ -44,11 +47,11 @@ def main():
         rng = np.random.default_rng(args.data_seed)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         out = []
-        for _ in range(1 if args.same_batch else 8):
+        for bi in range(1 if args.same_batch else args.batches):
             xyz = t(rng.uniform(-1, 1, size=(n, 3)))
             nrm = torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1)
             cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
-            out.append((None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+            out.append(((['view%d' % bi] * n) if args.ids else None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
                         mark_all_foreground(torch.ones(n, 1, device=dev)), xyz, nrm, t(rng.uniform(size=(n, 512)))))
         return out
 
@@ -60,9 +63,12 @@ def main():
         step = optim.GraphedTrainStep(model, opt, n, warmup=2) if graph else (
             lambda b: optim.train_step(model, b, opt, n))
         bs = batches()
-        losses, flats, grads = [], [], []
+        losses, flats, grads, kept = [], [], [], []
         for i in range(args.steps):
-            losses.append(step(bs[i % len(bs)])[0].clone())
+            loss, to_vis = step(bs[i % len(bs)])
+            losses.append(loss.clone())
+            if args.keep_vis and i in (3, 4):
+                kept.append(to_vis)
             flats.append(opt.flat.clone())
             grads.append(opt.bucket.flat.clone())
         torch.cuda.synchronize()
