@@ -370,8 +370,7 @@ int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* no
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     const long long words = n * (z_dim + 3);
-    e = hipMemsetAsync(workspace, 0, sizeof(long long) * (size_t)words, st);
-    if (e != hipSuccess) return (int)e;
+    launch_zero_words(workspace, words, st);   // (a kernel, not hipMemsetAsync: nfx_common.hpp)
     hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
                        z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, static_cast<long long*>(workspace));
     hipLaunchKernelGGL(brdfbwd::brdf_fx_finish_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,

@@ -27,6 +27,15 @@ __device__ unsigned long long nfx_v6_times[4][128];   // cycle stamp before each
 __device__ int nfx_v6_idx = -1;
 #endif
 
+// Round-3 experiment mask for the cycle-stamp build (-DNFX_V6_XP=<bits>, never set in the product build):
+//   1  no epilogue at all (the B arrays are never rewritten)
+//   2  the epilogue converts into a scratch register set instead of the next layer's B operands (same VALU work, the
+//      MFMAs never see a freshly written B register)
+//   4  every epilogue result is moved through an AccVGPR before it lands in the B array
+#ifndef NFX_V6_XP
+#define NFX_V6_XP 0
+#endif
+
 namespace nfx {
 namespace v6 {
 
@@ -125,6 +134,9 @@ struct Regs {
 };
 
 struct Ctx {
+#if NFX_V6_XP & 2
+    bf16x8 (&scratch)[2][kCT];
+#endif
     char* smem;
     const char* blob;
     int tid;
@@ -231,7 +243,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
             // neither VALU nor MFMA may cross this point (SALU, VMEM, DS may): without it the scheduler puts the
             // epilogue's first reads directly behind the previous tile's last MFMAs again
             __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);
-        if constexpr (s >= EOFF && s - EOFF < PIECES)
+        if constexpr (s >= EOFF && s - EOFF < PIECES && !(NFX_V6_XP & 1))
             prev.template run<16 * (s - EOFF) / PIECES, 16 * (s - EOFF + 1) / PIECES>();
         if constexpr (s == SP) {
             // the other accumulator set is free now: tile K+1's bias goes to its accumulators
@@ -279,8 +291,15 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
         if constexpr (t == 0) {
             tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
         } else {
+#if NFX_V6_XP & 2
+            EpiB<RELU> e{accs[(K - 1) & 1], cx.scratch[0], cx.scratch[1]};
+#else
             EpiB<RELU> e{accs[(K - 1) & 1], bout[2 * (t - 1)], bout[2 * (t - 1) + 1]};
+#endif
             tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
+#if NFX_V6_XP & 2
+            asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
+#endif
         }
     });
 }
@@ -302,8 +321,14 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
     }
     typedef __attribute__((address_space(3))) char lds_char;
+#if NFX_V6_XP & 2
+    bf16x8 xp_scratch[2][kCT];
+    Ctx cx{xp_scratch, smem, blob, tid, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem),
+           __builtin_amdgcn_readfirstlane(tid >> 6)};
+#else
     Ctx cx{smem, blob, tid, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem),
            __builtin_amdgcn_readfirstlane(tid >> 6)};
+#endif
     Acc accs[2];
     Pre pre;
     Regs rg;
@@ -361,10 +386,24 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         if (blockIdx.x == 7 && lane == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
 #endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
+#if NFX_V6_XP & 3
+#pragma unroll
+        for (int i_ = 0; i_ < 16; ++i_)
+#pragma unroll
+            for (int c_ = 0; c_ < kCT; ++c_) {
+                asm volatile("" : "=v"(ha[i_][c_]));
+                asm volatile("" : "=v"(hb[i_][c_]));
+                if (i_ < 8) asm volatile("" : "=v"(r0[i_][c_]));
+            }
+#endif
         float sigma[kCT];
         const float* bl = bias_lds + kBiasL0;
         auto pend = [&](auto relu_tag, const Acc& a, bf16x8(&lo)[kCT], bf16x8(&hi)[kCT]) {
+#if NFX_V6_XP & 2
+            return EpiB<decltype(relu_tag)::value>{a, cx.scratch[0], cx.scratch[1]};
+#else
             return EpiB<decltype(relu_tag)::value>{a, lo, hi};
+#endif
         };
         using T = std::true_type;
         using F = std::false_type;
@@ -420,7 +459,9 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
                                            int n_samples, const void* blob, float* out, int max_blocks, int ablate,
                                            hipStream_t stream) {
     if (n_pts <= 0) return 0;
-#ifdef NFX_ABLATION_BUILD
+#if defined(NFX_ABLATION_BUILD) && defined(NFX_V6_FEW)
+    if (ablate == 175) return launch_v6<75, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+#elif defined(NFX_ABLATION_BUILD)
     switch (ablate) {
 #define NFX_V6_CASE(m) case m: return launch_v6<m, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
         NFX_V6_CASE(1) NFX_V6_CASE(2) NFX_V6_CASE(3) NFX_V6_CASE(4) NFX_V6_CASE(8) NFX_V6_CASE(64) NFX_V6_CASE(7)

@@ -75,6 +75,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Zero-fill of a 64-bit-word buffer as a KERNEL (a template so that the header can be included by several files).
+// The fixed-point gradient accumulators (shade_bwd's light gradient, brdf_spec_bwd's d z / d normal) are cleared in
+// front of the kernel that adds into them with integer atomics.  Round 2 cleared them with hipMemsetAsync: correct in
+// stream order, but captured into a hipGraph it becomes a MEMSET NODE, and replays of the NeRFactor training steps
+// (the only steps with these accumulators) drifted away from the eager step after ~100 replays — a few wrong low bits
+// of the light gradient at first, NaN / 2e5 losses in round 2's benchmark — while the shape model, which has no such
+// node, stayed bit-identical for 200 steps (tests/test_gpu_train.py::test_graphed_train_step_equals_the_eager_one).
+// Kernel nodes are ordered like kernels.
+template <int UNUSED = 0>
+__global__ void zero_words_kernel(unsigned long long* p, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+inline void launch_zero_words(void* p, long long n_words, hipStream_t st) {
+    if (n_words <= 0) return;
+    hipLaunchKernelGGL(zero_words_kernel<0>, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st,
+                       static_cast<unsigned long long*>(p), n_words);
+}
+
 // bf16 pack helpers --------------------------------------------------------------------
 __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5,
                                         float a6, float a7) {

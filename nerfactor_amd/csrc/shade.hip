@@ -145,38 +145,98 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_kernel(ShadeArgs a) {
 }
 
 // OLAT: rgb[n, l, c] = tonemap(inten * T[l][c] + ambient * sum_l' T[l'][c])   (nerfactor.py:79-84,348-354)
-// LDS: lxyz[L*3] | area[L] | T[kShadeWaves][L*3]
+// LDS: lxyz[L*3] | area[L].  HBM-bound on what it writes (12 B x L per point; read: the point's visibility / specular
+// rows).  One wave per point; a lane keeps the transport of its 8 lights (l = lane + 64 k) in registers, the wave sums
+// them for the ambient term and every lane stores its lights' three channels as one 12-byte piece (768 contiguous bytes
+// per store instruction) — round 2's form staged T through LDS, read it back channel by channel (i % 3) and ran a
+// libm powf per output float: 3.1 ms per 384 030 points = 1.0 TB/s.  The visibility / specular rows of the NEXT point
+// are fetched while this one is shaded, as in shade_kernel.
+struct f32x3_t {
+    float x, y, z;
+};
+// linear2srgb with v_log_f32 / v_exp_f32 (1 ulp each): |error| <= 1e-6 on [0, 1] against powf — 1536 tonemaps per
+// point make the libm pow the whole cost of the kernel otherwise
+__device__ __forceinline__ float tonemap_fast(float v, int to_srgb) {
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    if (!to_srgb) return v;
+    const float p = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f));
+    return v <= 0.0031308f ? v * 12.92f : 1.055f * p - 0.055f;
+}
+
 __global__ __launch_bounds__(kShadeWaves * 64) void shade_olat_kernel(ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int L = a.n_lights;
     float* lxyz_s = sm;
     float* area_s = lxyz_s + 3 * L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* T_s = area_s + L + (size_t)wave * L * 3;
     for (int i = tid; i < 3 * L; i += blockDim.x) lxyz_s[i] = a.lxyz[i];
     for (int i = tid; i < L; i += blockDim.x) area_s[i] = a.lareas[i];
     __syncthreads();
-    for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < a.n;
-         pt += (long long)gridDim.x * kShadeWaves) {
+    const long long stride = (long long)gridDim.x * kShadeWaves;
+    float lvn[kLightsPerPass], spn[kLightsPerPass];
+    auto fetch = [&](long long pt) {
+#pragma unroll
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            const int l = k * 64 + lane;
+            const bool ok = pt < a.n && l < L;
+            lvn[k] = ok ? a.lvis[pt * L + l] : 0.0f;
+            spn[k] = ok && a.spec ? a.spec[pt * L + l] : 0.0f;
+        }
+    };
+    long long pt = (long long)blockIdx.x * kShadeWaves + wave;
+    fetch(pt);
+    for (; pt < a.n; pt += stride) {
         PointCtx pc;
         load_point(a, pt, pc);
-        float tot[3] = {0.f, 0.f, 0.f};
-        for (int l = lane; l < L; l += 64) {
-            float T[3];
-            light_transport(a, pc, pt, l, lxyz_s, area_s, T);
+        float lvc[kLightsPerPass], spc[kLightsPerPass];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                T_s[3 * l + c] = T[c];
-                tot[c] += T[c];
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            lvc[k] = lvn[k];
+            spc[k] = spn[k];
+        }
+        fetch(pt + stride);
+        float T0[kLightsPerPass][3];          // the first 512 lights stay in registers
+        float tot[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            const int l = k * 64 + lane;
+            if (l < L) light_transport_v(a, pc, l, lvc[k], spc[k], lxyz_s, area_s, T0[k]);
+            else T0[k][0] = T0[k][1] = T0[k][2] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tot[c] += T0[k][c];
+        }
+        if (a.ambient != 0.0f || L > 64 * kLightsPerPass) {
+            for (int l = 64 * kLightsPerPass + lane; l < L; l += 64) {   // (more than 512 lights: summed here, re-evaluated below)
+                float T[3];
+                light_transport(a, pc, pt, l, lxyz_s, area_s, T);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tot[c] += T[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tot[c] = wave_sum(tot[c]) * a.ambient;
+        } else {
+            tot[0] = tot[1] = tot[2] = 0.0f;
+        }
+        float* o = a.out + pt * L * 3;
+#pragma unroll
+        for (int k = 0; k < kLightsPerPass; ++k) {
+            const int l = k * 64 + lane;
+            if (l < L) {
+                f32x3_t v;
+                v.x = tonemap_fast(a.olat_inten * T0[k][0] + tot[0], a.to_srgb);
+                v.y = tonemap_fast(a.olat_inten * T0[k][1] + tot[1], a.to_srgb);
+                v.z = tonemap_fast(a.olat_inten * T0[k][2] + tot[2], a.to_srgb);
+                *reinterpret_cast<f32x3_t*>(o + 3 * l) = v;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tot[c] = wave_sum(tot[c]) * a.ambient;
-        float* o = a.out + pt * L * 3;
-        for (int i = lane; i < 3 * L; i += 64) {
-            const int c = i % 3;
-            const float amb = c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]);
-            o[i] = tonemap(a.olat_inten * T_s[i] + amb, a.to_srgb);
+        for (int l = 64 * kLightsPerPass + lane; l < L; l += 64) {
+            float T[3];
+            light_transport(a, pc, pt, l, lxyz_s, area_s, T);
+            f32x3_t v;
+            v.x = tonemap_fast(a.olat_inten * T[0] + tot[0], a.to_srgb);
+            v.y = tonemap_fast(a.olat_inten * T[1] + tot[1], a.to_srgb);
+            v.z = tonemap_fast(a.olat_inten * T[2] + tot[2], a.to_srgb);
+            *reinterpret_cast<f32x3_t*>(o + 3 * l) = v;
         }
     }
 }
@@ -213,9 +273,7 @@ size_t nfx_shade_lds_bytes(int n_lights, int n_probes) {
     return sizeof(float) * ((size_t)4 * n_lights + (size_t)n_probes * n_lights * 3 +
                             (size_t)nfx::kShadeWaves * n_probes * 3);
 }
-size_t nfx_shade_olat_lds_bytes(int n_lights) {
-    return sizeof(float) * ((size_t)4 * n_lights + (size_t)nfx::kShadeWaves * n_lights * 3);
-}
+size_t nfx_shade_olat_lds_bytes(int n_lights) { return sizeof(float) * (size_t)4 * n_lights; }
 int nfx_launch_shade(const float* xyz, const float* cam, const float* normal, const float* albedo,
                      const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
                      const float* lxyz, const float* lareas, const float* lights, long long n, int n_lights,
@@ -454,10 +512,7 @@ extern "C" int nfx_launch_shade_bwd(const float* xyz, const float* cam, const fl
     a.drgb = drgb; a.d_albedo = d_albedo; a.d_rough = d_rough; a.d_spec = d_spec; a.d_normal = d_normal;
     a.d_lvis = d_lvis;
     a.d_light_fx = d_light ? static_cast<long long*>(workspace) : nullptr;
-    if (a.d_light_fx) {
-        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(long long) * 3 * (size_t)n_lights, st);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (a.d_light_fx) nfx::launch_zero_words(workspace, 3ll * n_lights, st);   // (a kernel, not hipMemsetAsync: nfx_common.hpp)
     const size_t lds = sizeof(float) * (size_t)7 * n_lights;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
