@@ -31,7 +31,10 @@ __device__ int nfx_v6_idx = -1;
 //   1  no epilogue at all (the B arrays are never rewritten)
 //   2  the epilogue converts into a scratch register set instead of the next layer's B operands (same VALU work, the
 //      MFMAs never see a freshly written B register)
-//   4  every epilogue result is moved through an AccVGPR before it lands in the B array
+//   8  the freshly converted B registers of a tile make a round trip through a private LDS area (ds_write_b128 +
+//      ds_read_b128): their last writer is an LDS return, like the A fragments', not a VALU instruction
+//  32  every freshly converted B register is re-written by a plain v_mov_b32 (is the cost specific to the packed
+//      16-bit writers v_cvt_pk_bf16_f32 / v_pk_max_i16?)
 #ifndef NFX_V6_XP
 #define NFX_V6_XP 0
 #endif
@@ -93,10 +96,43 @@ struct EpiB {
                 else cvt_pair<RELU>(acc.v[c][r], acc.v[c][r + 1], hi[c], r - 8);
             }
     }
+    // experiment NFX_V6_XP & 8: `area` = this lane's 16-byte column of a 4 x 1 KiB private LDS area
+    __device__ __forceinline__ void finish(char* area) {
+#if NFX_V6_XP & 8
+        volatile u32x4* p = reinterpret_cast<volatile u32x4*>(area);
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            p[(2 * c) * 64] = __builtin_bit_cast(u32x4, lo[c]);
+            p[(2 * c + 1) * 64] = __builtin_bit_cast(u32x4, hi[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            lo[c] = __builtin_bit_cast(bf16x8, (u32x4)p[(2 * c) * 64]);
+            hi[c] = __builtin_bit_cast(bf16x8, (u32x4)p[(2 * c + 1) * 64]);
+        }
+#endif
+#if NFX_V6_XP & 32
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            u32x4 a = __builtin_bit_cast(u32x4, lo[c]), b = __builtin_bit_cast(u32x4, hi[c]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned x = a[q], y = b[q];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(y));
+                a[q] = x;
+                b[q] = y;
+            }
+            lo[c] = __builtin_bit_cast(bf16x8, a);
+            hi[c] = __builtin_bit_cast(bf16x8, b);
+        }
+#endif
+    }
 };
 struct EpiNone {
     template <int R0, int R1>
     __device__ __forceinline__ void run() {}
+    __device__ __forceinline__ void finish(char*) {}
 };
 struct EpiSigma {
     const Acc& acc;
@@ -108,6 +144,7 @@ struct EpiSigma {
             for (int c = 0; c < kCT; ++c) sigma[c] = acc.v[c][0];
         }
     }
+    __device__ __forceinline__ void finish(char*) {}
 };
 
 __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
@@ -248,6 +285,9 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
         if constexpr (s == SP) {
             // the other accumulator set is free now: tile K+1's bias goes to its accumulators
             if constexpr (!(AB & 64)) bias_to_acc(next_bias, lane, acc_next);
+#if NFX_V6_XP & (8 | 32)
+            prev.finish(cx.smem + lds_of<DMA> + cx.wave * 4096 + lane * 16);
+#endif
         }
     });
     // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
@@ -448,9 +488,9 @@ static int launch_v6(const float* rayo, const float* rayd, const float* z, long 
     const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
     auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA, IDX32>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       v6::lds_of<DMA>);
+                                       v6::lds_of<DMA> + ((NFX_V6_XP & 8) ? 16384 : 0));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::lds_of<DMA>, stream, rayo, rayd, z, n_pts, n_samples,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::lds_of<DMA> + ((NFX_V6_XP & 8) ? 16384 : 0), stream, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (float4*)out);
     return (int)hipGetLastError();
 }
