@@ -35,7 +35,7 @@ VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554),
 # variant 6 1293 -> 1330 TFLOP/s, density-gradient kernel 72.5 -> 68.4 ms per 256 x 256 view; no effect on the
 # backward kernels (nerf_bwd, mlp128_bwd, brdf_bwd)
-PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM, 'nerf_mlp_v9.hip': VGPR_FORM,
+PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
                   'nerf_geom.hip': VGPR_FORM}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
     PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}

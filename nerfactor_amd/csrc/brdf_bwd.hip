@@ -47,6 +47,8 @@ __device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (
             const float hv = (float)hact[2 * t + (r >> 3)][0][r & 7];
             dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
         }
+        mfma_operand_fence(dout[2 * t][0]);
+        mfma_operand_fence(dout[2 * t + 1][0]);
     });
 }
 
@@ -122,9 +124,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
         }
         bf16x8 bin[2][1];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bin[s][0][j] = (__bf16)v[8 * s + j];
+            mfma_operand_fence(bin[s][0]);
+        }
         // ---- forward (re-computed)
         bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
         layer<2, 0, 4, 1, 2, true, kNW>(ws, tid, bias_lds, bin, bin, h0);
@@ -152,6 +156,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
                 const float hv = (float)h3[2 * t + (r >> 3)][0][r & 7];
                 dz3[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
             }
+            mfma_operand_fence(dz3[2 * t][0]);
+            mfma_operand_fence(dz3[2 * t + 1][0]);
         });
         f32x16 dx[1];  // gradient w.r.t. the 32 input slots of this lane's half: reg r <-> (s = r>>3, j = r&7)
         tile_init<8, 0, 2, kNW>(ws, tid, [&](f32x16(&a)[1]) { zero_acc<1>(a); }, dz3, dz3, dx);   // W3[128:, :] dZ3
@@ -267,9 +273,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(
         }
         bf16x8 bin[2][1];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bin[s][0][j] = (__bf16)v[8 * s + j];
+            mfma_operand_fence(bin[s][0]);
+        }
         bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
         layer<2, 0, 4, 1, 2, true, kNW>(ws, tid, bias_lds, bin, bin, h0);
         layer<8, 0, 4, 2, 2, true, kNW>(ws, tid, bias_lds + 128, h0, bin, h1);
@@ -331,6 +339,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(
                     const float hv = (float)h3[2 * t + (r >> 3)][0][r & 7];
                     dz3[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
                 }
+                mfma_operand_fence(dz3[2 * t][0]);
+                mfma_operand_fence(dz3[2 * t + 1][0]);
             });
             store_hidden<8>(fs, kOffDZ + 384, h, dz3);
             f32x16 dx[1];  // gradient w.r.t. the 32 input slots of this lane's half

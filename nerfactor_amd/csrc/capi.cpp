@@ -42,8 +42,6 @@ int nfx_launch_nerf_mlp_x3(const float*, const float*, const float*, long long, 
                            hipStream_t);
 int nfx_launch_nerf_mlp_bf16_v6(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                 int, hipStream_t);
-int nfx_launch_nerf_mlp_bf16_v9(const float*, const float*, const float*, long long, int, const void*, float*, int,
-                                hipStream_t);   // nerf_mlp_v9.hip (experiment)
 int nfx_launch_l2_normalize3(const float*, float*, long long, float, hipStream_t);
 int nfx_launch_nonfinite(const float*, long long, int*, hipStream_t);
 int nfx_launch_gen_z(float, float, int, long long, int, const float*, float*, hipStream_t);
@@ -188,21 +186,11 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
         // two waves per SIMD, 0 = 4 x 64 plain (nerf_mlp.hip).  All bit-identical.  The intermediate variants 2, 3, 5
         // of r01 live in scripts/experiments/ (not built).
         const int variant = env_int("NFX_NERF_VARIANT", 7);
-        if (variant == 9) {   // EXPERIMENT (nerf_mlp_v9.hip): variant 7 with the loop-top work under earlier tiles' MFMAs
-            const int rc = nfx_launch_nerf_mlp_bf16_v9(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                       (hipStream_t)stream);
-            if (rc != -1) return hip_result(rc, "nerf_mlp_fwd(bf16, v9)");
-            // (>= 2^31 points: the default kernel)
-        }
         if (variant == 8)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -8,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v8)");
-        if (variant == 10)   // EXPERIMENT: variant 7 with 32-bit point-index arithmetic (falls back to 7 for >= 2^31 points)
-            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -10,
-                                                          (hipStream_t)stream),
-                              "nerf_mlp_fwd(bf16, v10)");
-        if (variant == 7 || variant == 9)
+        if (variant == 7)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
                                                           env_int("NFX_ABLATE", 0) > 0 ? 100 + env_int("NFX_ABLATE", 0) : -7,
                                                           (hipStream_t)stream),
@@ -212,7 +200,7 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
                                                           env_int("NFX_ABLATE", 0), (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v6)");
         if (variant != 0 && variant != 1)
-            return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8, 9, 10)", variant);
+            return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8)", variant);
         return hip_result(nfx_launch_nerf_mlp_bf16(rayo, rayd, z, n_pts, n_samples, blob, rgbs, variant,
                                                    blocks, (hipStream_t)stream),
                           "nerf_mlp_fwd(bf16)");

@@ -245,7 +245,7 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
     // NFX_LVIS_VARIANT: 0 = 8 waves x 32 rows with streamed weights (mlp128.hip); 2 | 3 | 4 = network resident in LDS,
     // one wave per SIMD with that many 32-row column tiles (lvis_v2.hip)
     const int variant = nfx_env_int("NFX_LVIS_VARIANT", 8);   // 8 (default) = 8 waves (two per SIMD) x 2 column tiles
-    if ((variant >= 2 && variant <= 4) || variant == 8 || variant == 9)   // (9: experiment, 8 with 32-bit row indices)
+    if ((variant >= 2 && variant <= 4) || variant == 8)
         return nfx_hip_result(nfx_launch_lvis_v2(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis,
                                                  variant, blocks, (hipStream_t)stream),
                               "lvis_fwd(v2)");

@@ -49,6 +49,8 @@ __device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j)
         w = __builtin_elementwise_max(w, z);
         pr = __builtin_bit_cast(b2, w);
     }
+    // (the converted pair is an MFMA operand of the next layer: mlp_engine.hpp, "MFMA operands written by packed ...")
+    pr = __builtin_bit_cast(b2, mfma_operand_dword(__builtin_bit_cast(unsigned, pr)));
     dst[j] = pr[0];
     dst[j + 1] = pr[1];
 }
@@ -178,10 +180,7 @@ struct Args {
 // registers each share the LDS copy of the network — a wave's stalls (epilogue bursts, the slow first tile of a
 // layer, encoder VALU at the start of a point tile) are covered by its partner's MFMAs; an A fragment feeds 2 MFMAs,
 // 64 B/clk of LDS reads per CU at full MFMA rate, a quarter of the ds_read_b128 peak.
-// IDX32 (experiment, NFX_LVIS_VARIANT=9, written at the end of round 2 without a GPU): the row -> (point, light) index
-// arithmetic in 32 bits (n x n_lights < 2^31) — the 64-bit divisions cost ≈100 scalar multiplies and four slow-path
-// branches per row tile, and the branches cut the loop body into scheduling regions.
-template <int CT, int MODE, int NW, bool IDX32 = false>
+template <int CT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
     constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,14 +200,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
     const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     float* pre_rows = reinterpret_cast<float*>(smem + kLdsNet) + wave * CT * 256;   // this wave's [CT][256] floats
     // point of column tile c in point tile t (clamped), and the copy of its pre row: one 16-byte piece per lane
-    auto div_l = [&](long long v) -> long long {
-        if constexpr (IDX32) return (long long)((unsigned)v / (unsigned)n_lights);
-        else return v / n_lights;
-    };
-    auto mod_l = [&](long long v) -> int {
-        if constexpr (IDX32) return (int)((unsigned)v % (unsigned)n_lights);
-        else return (int)(v % n_lights);
-    };
+    auto div_l = [&](long long v) -> long long { return v / n_lights; };
+    auto mod_l = [&](long long v) -> int { return (int)(v % n_lights); };
     auto point_of = [&](long long t, int c) {
         const long long m = t * kTileRows + (wave * CT + c) * 32;
         return div_l(m < n_rows ? m : 0);
@@ -313,9 +306,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
                     v[8 + j] = i < a.z_dim ? a.z[pt * a.z_dim + i] : 0.0f;
                 }
 #pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx)
+                for (int sidx = 0; sidx < 2; ++sidx) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+                    mfma_operand_fence(pl[sidx][c]);
+                }
                 pre_pt[c] = nullptr;
             }
         }
@@ -712,9 +707,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                         v[cc][8 + j] = i < a.z_dim ? zp[i] : 0.0f;
                     }
 #pragma unroll
-                    for (int sidx = 0; sidx < 2; ++sidx)
+                    for (int sidx = 0; sidx < 2; ++sidx) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) pl[sidx][k2 + cc][j] = (__bf16)v[cc][8 * sidx + j];
+                        mfma_operand_fence(pl[sidx][k2 + cc]);
+                    }
                 }
             }
         } else {
@@ -733,9 +730,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 float v[16];
                 brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, h, v);
 #pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx)
+                for (int sidx = 0; sidx < 2; ++sidx) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pl[sidx][c][j] = (__bf16)v[8 * sidx + j];
+                    mfma_operand_fence(pl[sidx][c]);
+                }
             }
         }
         bf16x8 ha[8][CT], hb[8][CT];
@@ -790,7 +789,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
 }  // namespace lv2
 }  // namespace nfx
 
-template <int CT, int MODE, int NW = 4, bool IDX32 = false>
+template <int CT, int MODE, int NW = 4>
 static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     using namespace nfx;
     const long long rows = a.n * a.n_lights, tile_rows = NW * CT * 32;
@@ -798,7 +797,7 @@ static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     constexpr int lds = lv2::kLdsNet + NW * CT * 1024;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto k = lv2::resident128_kernel<CT, MODE, NW, IDX32>;
+    auto k = lv2::resident128_kernel<CT, MODE, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, a);
@@ -809,8 +808,7 @@ extern "C" int nfx_launch_lvis_v2(const float* xyz, long long n, const float* lx
                                   const void* blob_main, float* lvis, int ct, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
     nfx::lv2::Args a{xyz, lxyz, pre, nullptr, nullptr, nullptr, 0, n, n_lights, (const char*)blob_main, lvis};
-    if (ct == 9 && n * n_lights < (1ll << 31)) return launch_res<2, 0, 8, true>(a, max_blocks, st);   // experiment
-    if (ct == 8 || ct == 9) return launch_res<2, 0, 8>(a, max_blocks, st);   // variant 8: 8 waves x 2 column tiles
+    if (ct == 8) return launch_res<2, 0, 8>(a, max_blocks, st);   // variant 8: 8 waves x 2 column tiles
     if (ct == 2) return launch_res<2, 0>(a, max_blocks, st);
     if (ct == 3) return launch_res<3, 0>(a, max_blocks, st);
     return launch_res<4, 0>(a, max_blocks, st);

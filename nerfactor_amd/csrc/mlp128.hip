@@ -229,9 +229,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void brdf_spec_kernel(
         }
         bf16x8 bin[2][1], ha[8][1], hb[8][1];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bin[s][0][j] = (__bf16)v[8 * s + j];
+            mfma_operand_fence(bin[s][0]);
+        }
         layer<2, 0, 4, kNL0, kNLH, true, kNW>(ws, tid, bias_lds, bin, bin, ha);
         mid_layers<kNL3>(ws, tid, bias_lds, ha, hb, bin);
         layer<8, 2, 4, kNL3, kNLOut, true, kNW>(ws, tid, bias_lds + 384, ha, bin, hb);

@@ -63,6 +63,8 @@ __device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (
             const float hv = (float)hact[2 * t + (r >> 3)][0][r & 7];
             dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
         }
+        mfma_operand_fence(dout[2 * t][0]);
+        mfma_operand_fence(dout[2 * t + 1][0]);
     });
 }
 
@@ -170,6 +172,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_kernel(
                 const float hv = (float)h3[2 * t + (r >> 3)][0][r & 7];
                 dz3[2 * t + (r >> 3)][0][r & 7] = (__bf16)(hv > 0.f ? acc[0][r] : 0.f);
             }
+            mfma_operand_fence(dz3[2 * t][0]);
+            mfma_operand_fence(dz3[2 * t + 1][0]);
         });
         store_hidden<8>(fs, G::kOffDZ + 384, h, dz3);
         dgrad_layer<8, G::kNLH, G::kNLH>(ws, tid, dz3, h2, dz2);   // W3[:128, :]

@@ -31,6 +31,34 @@ constexpr int kSlotFrags = 24;                    // largest chunk: K = 320 -> 2
 constexpr int kSlotBytes = kSlotFrags * kFragBytes;
 constexpr int kPieceThreads = 256;                // a "piece" = 256 lanes x 16 B = 4 KiB
 
+// --------------------------------------------------------------------------------------
+// MFMA operands written by packed 16-bit VALU instructions (found in round 3, profiles/r03/nerf_first_tile/).
+// On MI355X an MFMA that reads an A / B operand register whose LAST WRITER was v_cvt_pk_bf16_f32 or v_pk_max_i16 — the
+// two instructions every epilogue here ends with — runs at about half rate the first time it reads that register:
+// the "first tile of every layer takes two tile times" signature of rounds 1 and 2 (9 % of a NeRF pass, ~14 % of the
+// LDS-resident kernels).  Cycle stamps of the default NeRF kernel: first tile of a layer 2600-3400 cycles against
+// 1450-1650 for the others; with the epilogue converting into scratch registers (the MFMAs never see a freshly written
+// operand) 1300-1960; with each converted register re-written by a plain `v_mov_b32 v, v` 1400-1900, whole pass
+// 131.0 k -> 123.3 k cycles.  A 32-bit move of the register onto itself is enough (v_mov_b64 works too); the elapsed
+// time since the write does not matter (a 30 k-cycle sleep changed nothing in round 2) and nothing in the ISA documents
+// announces it.  Every conversion that produces an MFMA operand goes through these helpers.
+// -DNFX_NO_OPERAND_FENCE compiles them out (A/B builds).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mfma_operand_dword(unsigned x) {
+#ifndef NFX_NO_OPERAND_FENCE
+    asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+#endif
+    return x;
+}
+__device__ __forceinline__ void mfma_operand_fence(bf16x8& v) {
+#ifndef NFX_NO_OPERAND_FENCE
+    u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = mfma_operand_dword(w[q]);
+    v = __builtin_bit_cast(bf16x8, w);
+#endif
+}
+
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) {
@@ -213,6 +241,8 @@ __device__ __forceinline__ void acc_to_b(const f32x16 (&acc)[CT], bf16x8 (&lo)[C
             lo[c][j] = (__bf16)v0;
             hi[c][j] = (__bf16)v1;
         }
+        mfma_operand_fence(lo[c]);
+        mfma_operand_fence(hi[c]);
     }
 }
 
@@ -319,9 +349,11 @@ __device__ __forceinline__ void posenc(const float (&x)[3], int h, int c,
             }
     }
 #pragma unroll
-    for (int s = 0; s < PeSlots<L>::kKS; ++s)
+    for (int s = 0; s < PeSlots<L>::kKS; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[s][c][j] = (__bf16)v[8 * s + j];
+        mfma_operand_fence(out[s][c]);
+    }
 }
 
 }  // namespace nfx

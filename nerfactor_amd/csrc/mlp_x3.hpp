@@ -96,6 +96,10 @@ __device__ __forceinline__ void acc_to_pair(const f32x16& acc, Pair& lo8, Pair& 
         hi8.hi[j] = a;
         hi8.lo[j] = b;
     }
+    mfma_operand_fence(lo8.hi);   // (mlp_engine.hpp: operands written by packed conversions)
+    mfma_operand_fence(lo8.lo);
+    mfma_operand_fence(hi8.hi);
+    mfma_operand_fence(hi8.lo);
 }
 
 template <int KS1, int KS2, int NT, int NL_SELF, int NL_NEXT, bool RELU, int KS1A, int KS2A, int NTA>
@@ -124,6 +128,11 @@ __device__ __forceinline__ void posenc_pair(const float (&x)[3], int h, Pair (&o
         split(v, a, b);
         out[q >> 3].hi[q & 7] = a;
         out[q >> 3].lo[q & 7] = b;
+    }
+#pragma unroll
+    for (int s = 0; s < PeSlots<L>::kKS; ++s) {
+        mfma_operand_fence(out[s].hi);
+        mfma_operand_fence(out[s].lo);
     }
 }
 

@@ -57,6 +57,8 @@ __device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (
             const bool on = MASK ? mask_bit(m, t, r) : true;
             dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(on ? acc[0][r] : 0.f);
         }
+        mfma_operand_fence(dout[2 * t][0]);
+        mfma_operand_fence(dout[2 * t + 1][0]);
         store_tile(fs, feat0 + 32 * t, h, dout[2 * t][0], dout[2 * t + 1][0]);
         __builtin_amdgcn_sched_barrier(0);
     });

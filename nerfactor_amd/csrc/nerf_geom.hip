@@ -37,6 +37,8 @@ __device__ __forceinline__ void dgrad(WStream& ws, int tid, const bf16x8 (&dz)[1
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(bwd::mask_bit(m, t, r) ? acc[0][r] : 0.f);
+        mfma_operand_fence(dout[2 * t][0]);
+        mfma_operand_fence(dout[2 * t + 1][0]);
     });
 }
 
@@ -103,12 +105,15 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_grad_kernel(
         // ------------------------------------------------------------------ reverse sweep
         // dZ7 = mask7 . W_sigma (the same vector for every point: no MFMA)
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float wv = fl[kGeoWSig + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
                 ha[2 * t + (r >> 3)][0][r & 7] = (__bf16)(bwd::mask_bit(mk[7], t, r) ? wv : 0.f);
             }
+            mfma_operand_fence(ha[2 * t][0]);
+            mfma_operand_fence(ha[2 * t + 1][0]);
+        }
         f32x16 dpe[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)

@@ -27,14 +27,10 @@ __device__ unsigned long long nfx_v6_times[4][128];   // cycle stamp before each
 __device__ int nfx_v6_idx = -1;
 #endif
 
-// Round-3 experiment mask for the cycle-stamp build (-DNFX_V6_XP=<bits>, never set in the product build):
-//   1  no epilogue at all (the B arrays are never rewritten)
-//   2  the epilogue converts into a scratch register set instead of the next layer's B operands (same VALU work, the
-//      MFMAs never see a freshly written B register)
-//   8  the freshly converted B registers of a tile make a round trip through a private LDS area (ds_write_b128 +
-//      ds_read_b128): their last writer is an LDS return, like the A fragments', not a VALU instruction
-//  32  every freshly converted B register is re-written by a plain v_mov_b32 (is the cost specific to the packed
-//      16-bit writers v_cvt_pk_bf16_f32 / v_pk_max_i16?)
+// Experiment mask of the cycle-stamp build (-DNFX_V6_XP=<bits>, never set in the product build; scripts/build_v6_xp.sh):
+//   2  the epilogue converts into a scratch register set instead of the next layer's B operands — same VALU work, the
+//      MFMAs never read a freshly converted register: how round 3 tied the slow first tile of every layer to the
+//      operands' last writer (mlp_engine.hpp).  -DNFX_NO_OPERAND_FENCE restores the round-2 instruction stream.
 #ifndef NFX_V6_XP
 #define NFX_V6_XP 0
 #endif
@@ -77,6 +73,8 @@ __device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j)
         w = __builtin_elementwise_max(w, z);
         pr = __builtin_bit_cast(b2, w);
     }
+    // (the converted pair is an MFMA operand of the next layer: mlp_engine.hpp, "MFMA operands written by packed ...")
+    pr = __builtin_bit_cast(b2, mfma_operand_dword(__builtin_bit_cast(unsigned, pr)));
     dst[j] = pr[0];
     dst[j + 1] = pr[1];
 }
@@ -96,43 +94,10 @@ struct EpiB {
                 else cvt_pair<RELU>(acc.v[c][r], acc.v[c][r + 1], hi[c], r - 8);
             }
     }
-    // experiment NFX_V6_XP & 8: `area` = this lane's 16-byte column of a 4 x 1 KiB private LDS area
-    __device__ __forceinline__ void finish(char* area) {
-#if NFX_V6_XP & 8
-        volatile u32x4* p = reinterpret_cast<volatile u32x4*>(area);
-#pragma unroll
-        for (int c = 0; c < kCT; ++c) {
-            p[(2 * c) * 64] = __builtin_bit_cast(u32x4, lo[c]);
-            p[(2 * c + 1) * 64] = __builtin_bit_cast(u32x4, hi[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < kCT; ++c) {
-            lo[c] = __builtin_bit_cast(bf16x8, (u32x4)p[(2 * c) * 64]);
-            hi[c] = __builtin_bit_cast(bf16x8, (u32x4)p[(2 * c + 1) * 64]);
-        }
-#endif
-#if NFX_V6_XP & 32
-#pragma unroll
-        for (int c = 0; c < kCT; ++c) {
-            u32x4 a = __builtin_bit_cast(u32x4, lo[c]), b = __builtin_bit_cast(u32x4, hi[c]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned x = a[q], y = b[q];
-                asm volatile("v_mov_b32 %0, %0" : "+v"(x));
-                asm volatile("v_mov_b32 %0, %0" : "+v"(y));
-                a[q] = x;
-                b[q] = y;
-            }
-            lo[c] = __builtin_bit_cast(bf16x8, a);
-            hi[c] = __builtin_bit_cast(bf16x8, b);
-        }
-#endif
-    }
 };
 struct EpiNone {
     template <int R0, int R1>
     __device__ __forceinline__ void run() {}
-    __device__ __forceinline__ void finish(char*) {}
 };
 struct EpiSigma {
     const Acc& acc;
@@ -144,7 +109,6 @@ struct EpiSigma {
             for (int c = 0; c < kCT; ++c) sigma[c] = acc.v[c][0];
         }
     }
-    __device__ __forceinline__ void finish(char*) {}
 };
 
 __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
@@ -280,14 +244,11 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
             // neither VALU nor MFMA may cross this point (SALU, VMEM, DS may): without it the scheduler puts the
             // epilogue's first reads directly behind the previous tile's last MFMAs again
             __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);
-        if constexpr (s >= EOFF && s - EOFF < PIECES && !(NFX_V6_XP & 1))
+        if constexpr (s >= EOFF && s - EOFF < PIECES)
             prev.template run<16 * (s - EOFF) / PIECES, 16 * (s - EOFF + 1) / PIECES>();
         if constexpr (s == SP) {
             // the other accumulator set is free now: tile K+1's bias goes to its accumulators
             if constexpr (!(AB & 64)) bias_to_acc(next_bias, lane, acc_next);
-#if NFX_V6_XP & (8 | 32)
-            prev.finish(cx.smem + lds_of<DMA> + cx.wave * 4096 + lane * 16);
-#endif
         }
     });
     // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
@@ -344,10 +305,7 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
     });
 }
 
-// IDX32 (experiment, NFX_NERF_VARIANT=10, written at the end of round 2 without a GPU): point index / samples per ray
-// in 32 bits (n_pts < 2^31) — the two 64-bit divisions at the top of the point-tile loop are ≈340 of its ≈1150
-// instructions (scripts/isa_tile_stats.py).  The default instantiation's instruction stream is unchanged by this parameter.
-template <int AB, int DMA, bool IDX32 = false>
+template <int AB, int DMA>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
@@ -407,9 +365,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         for (int c = 0; c < kCT; ++c) {
             m[c] = tl * kTilePts + wave * (32 * kCT) + c * 32 + p;
             const long long mm = m[c] < n_pts ? m[c] : n_pts - 1;
-            long long ray;
-            if constexpr (IDX32) ray = (long long)((unsigned)mm / (unsigned)n_samples);
-            else ray = mm / n_samples;
+            const long long ray = mm / n_samples;
             const float zz = zbuf[mm];
             float x[3], d[3];
 #pragma unroll
@@ -426,7 +382,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         if (blockIdx.x == 7 && lane == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
 #endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
-#if NFX_V6_XP & 3
+#if NFX_V6_XP & 2   // never written in this experiment: opaque, distinct registers
 #pragma unroll
         for (int i_ = 0; i_ < 16; ++i_)
 #pragma unroll
@@ -479,18 +435,18 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
 }  // namespace v6
 }  // namespace nfx
 
-template <int AB, int DMA, bool IDX32 = false>
+template <int AB, int DMA>
 static int launch_v6(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                      const void* blob, float* out, int max_blocks, hipStream_t stream) {
     using namespace nfx;
     const int tile_pts = v6::kNW * 32 * v6::kCT;
     const long long n_tiles = (n_pts + tile_pts - 1) / tile_pts;
     const int grid = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA, IDX32>;
+    auto kern = v6::nerf_mlp_bf16_v6_kernel<AB, DMA>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       v6::lds_of<DMA> + ((NFX_V6_XP & 8) ? 16384 : 0));
+                                       v6::lds_of<DMA>);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::lds_of<DMA> + ((NFX_V6_XP & 8) ? 16384 : 0), stream, rayo, rayd, z, n_pts, n_samples,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(v6::kNW * 64), v6::lds_of<DMA>, stream, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (float4*)out);
     return (int)hipGetLastError();
 }
@@ -499,7 +455,7 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
                                            int n_samples, const void* blob, float* out, int max_blocks, int ablate,
                                            hipStream_t stream) {
     if (n_pts <= 0) return 0;
-#if defined(NFX_ABLATION_BUILD) && defined(NFX_V6_FEW)
+#if defined(NFX_ABLATION_BUILD) && defined(NFX_V6_FEW)   // (experiment builds: the register-only tile alone)
     if (ablate == 175) return launch_v6<75, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 #elif defined(NFX_ABLATION_BUILD)
     switch (ablate) {
@@ -514,8 +470,7 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
         default: break;
     }
 #endif
-    if (ablate == -10 && n_pts < (1ll << 31)) return launch_v6<0, 1, true>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 10
-    if (ablate == -7 || ablate == -10 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    if (ablate == -7 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
     if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
 }

@@ -78,11 +78,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Zero-fill of a 64-bit-word buffer as a KERNEL (a template so that the header can be included by several files).
 // The fixed-point gradient accumulators (shade_bwd's light gradient, brdf_spec_bwd's d z / d normal) are cleared in
 // front of the kernel that adds into them with integer atomics.  Round 2 cleared them with hipMemsetAsync: correct in
-// stream order, but captured into a hipGraph it becomes a MEMSET NODE, and replays of the NeRFactor training steps
-// (the only steps with these accumulators) drifted away from the eager step after ~100 replays — a few wrong low bits
-// of the light gradient at first, NaN / 2e5 losses in round 2's benchmark — while the shape model, which has no such
-// node, stayed bit-identical for 200 steps (tests/test_gpu_train.py::test_graphed_train_step_equals_the_eager_one).
-// Kernel nodes are ordered like kernels.
+// stream order, but captured into a hipGraph it becomes a MEMSET NODE, and with it the replayed NeRFactor training
+// step (the only steps with these accumulators) left the eager step at replay 94 of 200 — low bits of the loss at
+// first, 0.22 against 0.065 at the end; NaN / 2e5 in round 2's benchmark — while the shape model, which has no such
+// node, stayed bit-identical.  With this kernel in its place the eager and the replayed step agree bit for bit over 200
+// steps for all models (tests/test_gpu_train.py::test_graphed_train_step_equals_the_eager_one,
+// profiles/r03/graph_divergence/).  Kernel nodes are ordered like kernels.
 template <int UNUSED = 0>
 __global__ void zero_words_kernel(unsigned long long* p, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
