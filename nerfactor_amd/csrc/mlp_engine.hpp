@@ -32,26 +32,27 @@ constexpr int kSlotBytes = kSlotFrags * kFragBytes;
 constexpr int kPieceThreads = 256;                // a "piece" = 256 lanes x 16 B = 4 KiB
 
 // --------------------------------------------------------------------------------------
-// MFMA operands written by packed 16-bit VALU instructions (found in round 3, profiles/r03/nerf_first_tile/).
-// On MI355X an MFMA that reads an A / B operand register whose LAST WRITER was v_cvt_pk_bf16_f32 or v_pk_max_i16 — the
-// two instructions every epilogue here ends with — runs at about half rate the first time it reads that register:
-// the "first tile of every layer takes two tile times" signature of rounds 1 and 2 (9 % of a NeRF pass, ~14 % of the
-// LDS-resident kernels).  Cycle stamps of the default NeRF kernel: first tile of a layer 2600-3400 cycles against
-// 1450-1650 for the others; with the epilogue converting into scratch registers (the MFMAs never see a freshly written
-// operand) 1300-1960; with each converted register re-written by a plain `v_mov_b32 v, v` 1400-1900, whole pass
-// 131.0 k -> 123.3 k cycles.  A 32-bit move of the register onto itself is enough (v_mov_b64 works too); the elapsed
-// time since the write does not matter (a 30 k-cycle sleep changed nothing in round 2) and nothing in the ISA documents
-// announces it.  Every conversion that produces an MFMA operand goes through these helpers.
-// -DNFX_NO_OPERAND_FENCE compiles them out (A/B builds).
+// MFMA operands written by packed 16-bit VALU instructions — a round-3 finding that is NOT a lever (DESIGN.md §2d,
+// profiles/r03/nerf_first_tile/).  In the cycle-stamp build of the NeRF kernel an MFMA that reads an A / B operand
+// register whose LAST WRITER was v_cvt_pk_bf16_f32 or v_pk_max_i16 — the two instructions every epilogue here ends
+// with — runs at about half rate the first time it reads that register: the "first tile of every layer takes two tile
+// times" signature rounds 1 and 2 chased (first tile 2600-3400 cycles against 1450-1650; 1300-1960 with the epilogue
+// converting into scratch registers; 1400-1900 with every converted register re-written by a plain `v_mov_b32 v, v`,
+// whole pass 131.0 k -> 123.3 k cycles; elapsed time since the write does not matter).  But the stamps' branches cut the
+// scheduling regions at every tile: that build is a different, 27 % slower kernel (131 k cycles per pass against 103 k).
+// In the PRODUCT schedule the same "operands never rewritten" experiment is worth 3.5 % (1518 against 1466 TFLOP/s),
+// and the moves that heal it cost more than they recover: -1.6 % (v_mov_b32 per pair), -1.0 % (eight v_mov_b64 per
+// tile); the light-visibility kernel -2.7 %, the density-gradient kernel -19 %.  The helpers stay as an opt-in
+// (-DNFX_OPERAND_FENCE) at every place an MFMA operand is converted, for whoever re-measures on another toolchain.
 // --------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned mfma_operand_dword(unsigned x) {
-#ifndef NFX_NO_OPERAND_FENCE
-    asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+#ifdef NFX_OPERAND_FENCE
+    asm("v_mov_b32 %0, %0" : "+v"(x));   // (not volatile: free to move between the instructions around it)
 #endif
     return x;
 }
 __device__ __forceinline__ void mfma_operand_fence(bf16x8& v) {
-#ifndef NFX_NO_OPERAND_FENCE
+#ifdef NFX_OPERAND_FENCE
     u32x4 w = __builtin_bit_cast(u32x4, v);
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = mfma_operand_dword(w[q]);

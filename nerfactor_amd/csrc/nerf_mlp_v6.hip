@@ -30,9 +30,14 @@ __device__ int nfx_v6_idx = -1;
 // Experiment mask of the cycle-stamp build (-DNFX_V6_XP=<bits>, never set in the product build; scripts/build_v6_xp.sh):
 //   2  the epilogue converts into a scratch register set instead of the next layer's B operands — same VALU work, the
 //      MFMAs never read a freshly converted register: how round 3 tied the slow first tile of every layer to the
-//      operands' last writer (mlp_engine.hpp).  -DNFX_NO_OPERAND_FENCE restores the round-2 instruction stream.
+//      operands' last writer (mlp_engine.hpp); in the product schedule (no stamps) the same experiment is worth 3.5 %.
 #ifndef NFX_V6_XP
 #define NFX_V6_XP 0
+#endif
+// operand-fence experiments in the PRODUCT schedule (scripts/build_v6_variant.sh): 1 = v_mov_b32 behind every converted
+// pair, 2 = eight v_mov_b64 once a tile's epilogue is complete.  Both are slower than no fence.
+#ifndef NFX_V6_FENCE
+#define NFX_V6_FENCE 0
 #endif
 
 namespace nfx {
@@ -73,8 +78,9 @@ __device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j)
         w = __builtin_elementwise_max(w, z);
         pr = __builtin_bit_cast(b2, w);
     }
-    // (the converted pair is an MFMA operand of the next layer: mlp_engine.hpp, "MFMA operands written by packed ...")
+#if NFX_V6_FENCE == 1   // (mlp_engine.hpp, "MFMA operands written by packed ...": measured, not shipped)
     pr = __builtin_bit_cast(b2, mfma_operand_dword(__builtin_bit_cast(unsigned, pr)));
+#endif
     dst[j] = pr[0];
     dst[j + 1] = pr[1];
 }
@@ -94,10 +100,30 @@ struct EpiB {
                 else cvt_pair<RELU>(acc.v[c][r], acc.v[c][r + 1], hi[c], r - 8);
             }
     }
+    __device__ __forceinline__ void finish() {
+#if NFX_V6_FENCE == 2
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < kCT; ++c) {
+            u64x2 a = __builtin_bit_cast(u64x2, lo[c]), b = __builtin_bit_cast(u64x2, hi[c]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned long long x = a[q], y = b[q];
+                asm("v_mov_b64 %0, %0" : "+v"(x));
+                asm("v_mov_b64 %0, %0" : "+v"(y));
+                a[q] = x;
+                b[q] = y;
+            }
+            lo[c] = __builtin_bit_cast(bf16x8, a);
+            hi[c] = __builtin_bit_cast(bf16x8, b);
+        }
+#endif
+    }
 };
 struct EpiNone {
     template <int R0, int R1>
     __device__ __forceinline__ void run() {}
+    __device__ __forceinline__ void finish() {}
 };
 struct EpiSigma {
     const Acc& acc;
@@ -109,6 +135,7 @@ struct EpiSigma {
             for (int c = 0; c < kCT; ++c) sigma[c] = acc.v[c][0];
         }
     }
+    __device__ __forceinline__ void finish() {}
 };
 
 __device__ __forceinline__ void bias_to_acc(const float* bias_tile, int lane, Acc& acc) {
@@ -148,44 +175,56 @@ struct Ctx {
 // DMA = 1: the weight stream goes global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
 // staging, no ds_write, no lgkmcnt drain); completion is tracked with counted s_waitcnt vmcnt (the pieces of chunk
 // K+2 must have landed before the barrier that ends tile K+1, those of chunk K+3 may still be in flight).
-__device__ __forceinline__ void dma_piece(unsigned lane_off, const char* gbase, unsigned lds_dst) {
+// r03: all pieces of a chunk in ONE statement — M0 is saved, set and restored once, and the pieces are addressed
+// through the instruction's immediate offset, which the hardware adds to the global AND to the LDS address (the pieces of a
+// wave are 1 KiB apart in both).  The r02 form issued every piece as its own statement: 8 instructions per piece (two
+// 64-bit address adds, one LDS address add, M0 save / set / s_nop / restore) = 32-48 scalar instructions in the first two
+// MFMA gaps of every tile, where a lone wave can hide five (MI355X_MICROARCH.md).  Only the fragments a tile really
+// multiplies are fetched (the chunks of layer 0, layer 5 and rgb_out[0] are padded to 8 / 24 fragments in the blob):
+// 298 pieces per pass instead of 318.
+constexpr int used_frags(int k) { return k < 8 ? 4 : k < 40 ? 16 : k < 48 ? 20 : k < 73 ? 16 : k < 77 ? 18 : 8; }
+constexpr int dma_pieces(int k) { return (used_frags(k) + kNW - 1) / kNW; }   // 1-KiB pieces per wave: 1 | 4 | 5 | 2
+template <int N>
+__device__ __forceinline__ void dma_pieces_asm(unsigned lane_off, const char* gbase, unsigned lds_dst) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-        : "memory");
+    static_assert(N == 1 || N == 2 || N == 4 || N == 5, "piece count");
+    // (N = 5: the 13-bit signed offset reaches 4095, so the statement is centred on the third piece)
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase + 2048), "s"(lds_dst + 2048) : "memory");
 }
 template <int K>
 __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
-    constexpr int n = nerf::chunk_frags(K) / kNW;   // 1-KiB pieces per wave
+    constexpr int n = dma_pieces(K);
     unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
     unsigned lds = cx.smem_lds;
     asm volatile("" : "+s"(base), "+s"(lds));       // per tile: keeps the piece addresses out of the loop preheader
     const int piece0 = cx.wave * n;
     const char* g = reinterpret_cast<const char*>(base) + (size_t)nerf::chunk_frag_offset(K) * kFragBytes + piece0 * 1024;
     const unsigned l = lds + (K % 6) * kSlotBytes + piece0 * 1024;
-    const unsigned lane_off = (cx.tid & 63) * 16;
-#pragma unroll
-    for (int i = 0; i < n; ++i) dma_piece(lane_off, g + i * 1024, l + i * 1024);
+    dma_pieces_asm<n>((cx.tid & 63) * 16, g, l);
 }
-// one piece of chunk K (experiment NFX_V7_SPREAD: the pieces are issued over the tile's k-steps, not all at its start)
-template <int K, int I>
-__device__ __forceinline__ void dma_one(const Ctx& cx) {
-    constexpr int n = nerf::chunk_frags(K) / kNW;
-    unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
-    unsigned lds = cx.smem_lds;
-    asm volatile("" : "+s"(base), "+s"(lds));
-    const int piece = cx.wave * n + I;
-    dma_piece((cx.tid & 63) * 16,
-              reinterpret_cast<const char*>(base) + (size_t)nerf::chunk_frag_offset(K) * kFragBytes + piece * 1024,
-              lds + (K % 6) * kSlotBytes + piece * 1024);
-}
-
 // Tile K (global chunk index).  On entry `acc` holds the tile's bias and `pre` its first three A fragments; on exit
 // `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
 // (1 no weight staging, 2 no barrier, 4 no MFMA, 8 no A reads, 64 no bias reads).
@@ -249,6 +288,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
         if constexpr (s == SP) {
             // the other accumulator set is free now: tile K+1's bias goes to its accumulators
             if constexpr (!(AB & 64)) bias_to_acc(next_bias, lane, acc_next);
+            prev.finish();
         }
     });
     // chunk K+2 to its slot as late as possible (its global loads had the whole tile to land; measured: storing at
@@ -256,8 +296,7 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     if constexpr (DMA == 1 && !(AB & 1)) {
         // the chunk issued one tile ago must be complete before the barrier; this tile's pieces may stay in flight
         // (fetch distance 4: the chunk issued during the previous tile may stay in flight too)
-        constexpr int kInFlight = nerf::chunk_frags(K2) / kNW +
-                                  (kDmaDist == 4 ? nerf::chunk_frags((K + 3) % kNChunks) / kNW : 0);
+        constexpr int kInFlight = dma_pieces(K2) + (kDmaDist == 4 ? dma_pieces((K + 3) % kNChunks) : 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
     } else if constexpr (DMA == 2 && !(AB & 1)) {
         // chunk K+2, fetched during tile K-1 into the other register set, to slot (K+2) % 3 = the slot tile K-1 read
@@ -291,6 +330,9 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
         const float* nb = t == NT - 1 ? next_bias : bias + 32 * (t + 1);
         if constexpr (t == 0) {
             tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
+#if NFX_V6_XP & 2
+            asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
+#endif
         } else {
 #if NFX_V6_XP & 2
             EpiB<RELU> e{accs[(K - 1) & 1], cx.scratch[0], cx.scratch[1]};
@@ -382,14 +424,28 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         if (blockIdx.x == 7 && lane == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
 #endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
-#if NFX_V6_XP & 2   // never written in this experiment: opaque, distinct registers
+#if NFX_V6_XP & 2   // never written in this experiment: distinct registers holding activation-like values (half of them
+                    // zero, the rest in [0, 1): the matrix pipe's power draw — and with it the clock DVFS grants —
+                    // depends on the operand data, all-zero operands ran 18 % "faster")
 #pragma unroll
         for (int i_ = 0; i_ < 16; ++i_)
 #pragma unroll
             for (int c_ = 0; c_ < kCT; ++c_) {
-                asm volatile("" : "=v"(ha[i_][c_]));
-                asm volatile("" : "=v"(hb[i_][c_]));
-                if (i_ < 8) asm volatile("" : "=v"(r0[i_][c_]));
+                u32x4 w = __builtin_bit_cast(u32x4, pe[i_ & 3][c_]);
+#pragma unroll
+                for (int q_ = 0; q_ < 4; ++q_) {
+                    unsigned x = (w[q_] * (2654435761u + 977u * i_)) & 0x7fff0000u;   // one positive bf16 + one zero per dword
+                    x = (x & 0x00ff0000u) | 0x3f000000u;                             // [0.5, 1)
+                    asm volatile("" : "+v"(x));
+                    w[q_] = (i_ + q_) & 1 ? x : (x >> 16);
+                }
+                ha[i_][c_] = __builtin_bit_cast(bf16x8, w);
+                hb[i_][c_] = __builtin_bit_cast(bf16x8, w);
+                asm volatile("" : "+v"(hb[i_][c_]));
+                if (i_ < 8) {
+                    r0[i_][c_] = __builtin_bit_cast(bf16x8, w);
+                    asm volatile("" : "+v"(r0[i_][c_]));
+                }
             }
 #endif
         float sigma[kCT];
@@ -418,12 +474,18 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
                                        pend(T{}, accs[1], hb[14], hb[15]));
         // sigma tile (K = 72 -> accs[0]); pending: last bottleneck tile (accs[1]); next: rgb_out[0] tile 0
         tile<72, 16, 0, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
+#if NFX_V6_XP & 2
+        asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
+#endif
         {
             EpiSigma es{accs[0], sigma};
             layer<73, 16, 2, 4, true, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
         }
         // rgb_out[1] (K = 77 -> accs[1]); pending: last rgb_out[0] tile (K = 76 -> accs[0]); next: L0 tile 0
         tile<77, 8, 0, AB, DMA>(cx, rg, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
+#if NFX_V6_XP & 2
+        asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
+#endif
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < kCT; ++c)
