@@ -6,6 +6,14 @@ import torch
 
 from . import _capi, ops
 
+# Operand type of every BACKWARD kernel (fused dgrad chains, weight-gradient GEMMs) and of the train blobs they read.
+# `precision = fp32` selects the fp32-class forward kernels (bf16 hi / lo operand pairs, three MFMAs per product); its
+# gradients are still formed by the bf16-operand backward kernels, which re-compute their own bf16 forward for the ReLU
+# masks — mixed precision in the usual sense: fp32-class values and losses, gradients with bf16 operand rounding
+# (~0.4 % relative noise, tests/test_gpu_reference_grads.py).  The C-ABI backward entry points themselves return
+# NFX_ENOSUP for NFX_PREC_FP32 (include/nfx.h): there is no hi / lo backward kernel.
+GRAD_PREC = 'bf16'
+
 
 def _targets(params):
     """Where the backward kernels accumulate the gradient of each parameter.  The libnfx weight-gradient kernels ADD
@@ -44,7 +52,7 @@ class Mlp128Xyz(torch.autograd.Function):
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
-                       xyz_scale=xyz_scale, post_scale=post_scale, prec=prec)
+                       xyz_scale=xyz_scale, post_scale=post_scale, prec=GRAD_PREC)
         return (None,) * 9 + tuple(rks) + tuple(rbs)
 
 
@@ -64,7 +72,7 @@ class Lvis(torch.autograd.Function):
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         ops.mlp128_bwd(_capi.IN_XYZ_LDIR, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act='sigmoid',
-                       xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir, prec=prec)
+                       xyz_scale=xyz_scale, lxyz=lxyz, xyz_dir=xyz_dir, prec=GRAD_PREC)
         return (None,) * 7 + tuple(rks) + tuple(rbs)
 
 
@@ -103,7 +111,7 @@ class BrdfSpec(torch.autograd.Function):
     def backward(ctx, dspec):
         xyz, cam, lxyz, normal, z = ctx.saved_tensors
         d_z, d_normal = ops.brdf_spec_bwd(xyz, cam, normal, z, lxyz, ctx.train_blob_fn(), dspec.contiguous(),
-                                          prec=ctx.prec)
+                                          prec=GRAD_PREC)
         return (None,) * 6 + (d_normal, d_z)
 
 
@@ -115,7 +123,7 @@ class BrdfRows(torch.autograd.Function):
     def forward(ctx, z, rusink, train_blob_fn, prec, *params):
         ctx.save_for_backward(z, rusink)
         ctx.cfg = (train_blob_fn, prec, params)
-        out = ops.brdf_rows_fwd(z, rusink, train_blob_fn(), reci=True, prec=prec)
+        out = ops.brdf_rows_fwd(z, rusink, train_blob_fn(), reci=True, prec=GRAD_PREC)   # (the rows kernels: bf16 only)
         n = z.shape[0]
         return out[:n], out[n:]
 
@@ -127,7 +135,7 @@ class BrdfRows(torch.autograd.Function):
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         n = z.shape[0]
         dout = torch.cat((d_brdf.reshape(n), d_reci.reshape(n)))
-        d_rows = ops.brdf_rows_bwd(z, rusink, train_blob_fn(), dout, dks, dbs, reci=True, prec=prec)
+        d_rows = ops.brdf_rows_bwd(z, rusink, train_blob_fn(), dout, dks, dbs, reci=True, prec=GRAD_PREC)
         d_z = (d_rows[:n] + d_rows[n:]) if ctx.needs_input_grad[0] else None
         return (d_z, None, None, None) + tuple(rks) + tuple(rbs)
 
@@ -169,7 +177,7 @@ class NerfMlp(torch.autograd.Function):
         train_blob_fn, prec, params = ctx.cfg
         ks, bs = list(params[:12]), list(params[12:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
-        ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs.contiguous(), train_blob_fn(), dks, dbs, prec)
+        ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs.contiguous(), train_blob_fn(), dks, dbs, GRAD_PREC)
         return (None,) * 6 + tuple(rks) + tuple(rbs)
 
 

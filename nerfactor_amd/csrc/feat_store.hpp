@@ -33,6 +33,13 @@ __device__ __forceinline__ void st16(const FeatStore& fs, int feat, __bf16 v) {
     gbf16_ptr rowp = (gbf16_ptr)a;
     *(gbf16_ptr)((__attribute__((address_space(1))) char*)rowp + fs.roff) = v;
 }
+#ifdef NFX_XP_ST32   // TIMING EXPERIMENT ONLY (wrong layout): one dword store per adjacent feature pair instead of two 16-bit stores
+__device__ __forceinline__ void st32(const FeatStore& fs, int feat, unsigned v) {
+    typedef __attribute__((address_space(1))) unsigned* gu32_ptr;
+    const unsigned long long a = reinterpret_cast<unsigned long long>(fs.base) + (unsigned long long)feat * fs.ld2;
+    *(gu32_ptr)((__attribute__((address_space(1))) char*)a + 2u * fs.roff) = v;   // row * 4: 256 distinct bytes per wave store
+}
+#endif
 // B-operand registers of a hidden activation (k-step s, element j <-> feature F(s,h,j)) -> feature-major
 template <int KS>
 __device__ __forceinline__ void store_hidden(const FeatStore& fs0, int feat0, int h, const bf16x8 (&b)[KS][1]) {
@@ -41,10 +48,18 @@ __device__ __forceinline__ void store_hidden(const FeatStore& fs0, int feat0, in
     FeatStore f2 = fs;
     f2.roff = fs.roff + (h ? (unsigned)(4 * fs.ld2) : 0u);  // + 4 features for half 1 (needs 4*ld2 < 4 GiB)
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int s = 0; s < KS; ++s) {
+#ifdef NFX_XP_ST32
+        const u32x4 w = __builtin_bit_cast(u32x4, b[s][0]);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+            st32(f2, feat0 + 32 * (s >> 1) + 16 * (s & 1) + (j & 3) + 8 * (j >> 2), w[j >> 1]);
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             st16(f2, feat0 + 32 * (s >> 1) + 16 * (s & 1) + (j & 3) + 8 * (j >> 2), b[s][0][j]);
+#endif
+    }
 }
 // posenc slots (mlp_engine.hpp:posenc) -> logical Embedder order [x, sin f0, cos f0, ...] starting at e0
 template <int L, int KS>
@@ -74,11 +89,20 @@ __device__ __forceinline__ void store_tile(const FeatStore& fs0, int feat0, int 
     const FeatStore fs = relaunder(fs0);
     FeatStore f2 = fs;
     f2.roff = fs.roff + (h ? (unsigned)(4 * fs.ld2) : 0u);
+#ifdef NFX_XP_ST32
+    const u32x4 wl = __builtin_bit_cast(u32x4, lo), wh = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        st32(f2, feat0 + (j & 3) + 8 * (j >> 2), wl[j >> 1]);
+        st32(f2, feat0 + 16 + (j & 3) + 8 * (j >> 2), wh[j >> 1]);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         st16(f2, feat0 + (j & 3) + 8 * (j >> 2), lo[j]);
         st16(f2, feat0 + 16 + (j & 3) + 8 * (j >> 2), hi[j]);
     }
+#endif
 }
 // ReLU mask bits of a pre-activation tile: accumulator register r of tile t <-> bit 16*(t&1) + r of word t>>1
 // (= B slot (2t + (r>>3), r&7) of the activation).

@@ -59,8 +59,8 @@ class Model(BaseModel):
         """Forward + dgrad + input-gradient fragments of the prior (cached, re-packed on the device after a step)."""
         ks, bs = self.net['brdf_mlp'].kernels_and_biases()
         ko, bo = self.net['brdf_out'].kernels_and_biases()
-        return self._packed('brdf_rows' + self.precision, ks + ko + bs + bo,
-                            lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=self.precision))
+        return self._packed('brdf_rows' + nfx_grad.GRAD_PREC, ks + ko + bs + bo,
+                            lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=nfx_grad.GRAD_PREC))
 
     def _eval_brdf_at(self, z, rusink):
         """Explicit-row evaluation (z [M, z_dim], rusink [M, 3]) -> (brdf, brdf_reci) [M, 1] (brdf.py:57-66, 101-106):
@@ -74,7 +74,7 @@ class Model(BaseModel):
         if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params)):
             brdf, reci = nfx_grad.BrdfRows.apply(z, rusink, self._train_blob, self.precision, *params)
         else:
-            out = ops.brdf_rows_fwd(z, rusink, self._train_blob(), reci=True, prec=self.precision)
+            out = ops.brdf_rows_fwd(z, rusink, self._train_blob(), reci=True, prec=nfx_grad.GRAD_PREC)   # rows kernels: bf16 only
             brdf, reci = out[:z.shape[0]], out[z.shape[0]:]
         return brdf[:, None], reci[:, None]
 

@@ -8,7 +8,7 @@ nerfactor/models/nerf.py:33-300), ray marching on libnfx:
 """
 import torch
 
-from nerfactor_amd import autograd, ops
+from nerfactor_amd import autograd, autograd as nfx_grad, ops
 
 from ..networks import mlp
 from ..networks.embedder import Embedder
@@ -134,8 +134,8 @@ class Model(BaseModel):
 
     def _nerf_train_blob(self, pref):
         ks, bs = self._nerf_params(pref)
-        return self._packed(pref + 'train' + self.precision, ks + bs,
-                            lambda k, b: ops.pack_nerf_train_weights(k, b, self.precision))
+        return self._packed(pref + 'train' + nfx_grad.GRAD_PREC, ks + bs,
+                            lambda k, b: ops.pack_nerf_train_weights(k, b, nfx_grad.GRAD_PREC))
 
     def _eval_rays(self, rayo, rayd, z, pref):
         """rgbs[N,S,4]; differentiable w.r.t. the network weights while autograd is recording."""

@@ -347,8 +347,8 @@ class Model(ShapeModel):
             ks, bs = nets['brdf_mlp'].kernels_and_biases()
             ko, bo = nets['brdf_out'].kernels_and_biases()
             ks, bs = ks + ko, bs + bo
-            return self._packed('brdf_mlp_train' + self.precision, ks + bs,
-                                lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=self.precision))
+            return self._packed('brdf_mlp_train' + nfx_grad.GRAD_PREC, ks + bs,
+                                lambda k, b: ops.pack_brdf_train_weights(k, b, self.z_dim, prec=nfx_grad.GRAD_PREC))
         lxyz = self.lxyz.reshape(-1, 3)
         spec = nfx_grad.BrdfSpec.apply(xyz, cam, lxyz, fwd_blob, train_blob, self.precision, normal, brdf_prop)
         return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,

@@ -100,8 +100,8 @@ class Model(BaseModel):
         ko, bo = nets[head_name].kernels_and_biases()
         ks, bs = ks + ko, bs + bo
         return self._packed(
-            body_name + '_train' + self.precision, ks + bs,
-            lambda k, b: ops.pack_mlp128_train_weights(k, b, in_kind, out_dim, prec=self.precision))
+            body_name + '_train' + nfx_grad.GRAD_PREC, ks + bs,
+            lambda k, b: ops.pack_mlp128_train_weights(k, b, in_kind, out_dim, prec=nfx_grad.GRAD_PREC))
 
     def _params128(self, body_name, head_name, nets=None):
         nets = self.net if nets is None else nets

@@ -805,3 +805,52 @@ def test_whole_step_gradients_are_bit_reproducible(nfx_lib, cuda, name):
         grads.append(opt.bucket.flat.clone())
     assert torch.equal(grads[0], grads[1])
     assert float(model._light.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor", "nerf", "shape"])
+def test_precision_fp32_trains(nfx_lib, cuda, name):
+    """`precision = fp32` (the reference computes in fp32, trainvali.py:110-127): the forward runs the fp32-class kernels
+    (bf16 hi / lo operand pairs), the backward the bf16-operand kernels (autograd.GRAD_PREC) — a run no longer stops at its
+    first backward call.  Checked: the step's loss equals the fp32-class forward's (not the bf16 one's), eight AMSGrad
+    steps on one batch are finite and bring the loss down, and the gradient of step 1 agrees with the all-bf16 step's
+    within bf16 operand noise (relative Frobenius <= 5 %)."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    from nerfactor_amd.nerfactor.models import get_model_class
+    n = 192
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    if name == 'nerf':
+        batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
+    else:
+        batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+                 mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz,
+                 torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1), t(rng.uniform(size=(n, 512))))
+    extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if 'nerfactor' in name else {}
+    if name == 'nerf':
+        extra = dict(perturb='False')
+
+    def run(prec, steps):
+        torch.manual_seed(21)
+        cfg = make_config(name, precision=prec, xyz_jitter_std='0', **extra)
+        model = get_model_class(name)(cfg).to(cuda)
+        opt = optim.make_optimizer(model, cfg)
+        losses, grad = [], None
+        for i in range(steps):
+            losses.append(float(optim.train_step(model, batch, opt, n)[0]))
+            if i == 0:
+                grad = opt.bucket.flat[:-1].clone()
+        model.flush_numerics(block=True)
+        return losses, grad
+
+    l32, g32 = run('fp32', 8)
+    l16, g16 = run('bf16', 1)
+    assert all(np.isfinite(l32)) and l32[-1] < l32[0], l32
+    rel = float((g32 - g16).norm() / g16.norm())
+    assert rel < 5e-2, rel
+    assert abs(l32[0] - l16[0]) < 2e-2 * abs(l16[0]) + 1e-4, (l32[0], l16[0])
+    print(name, "fp32-class training: loss %.5f -> %.5f (bf16 first loss %.5f), step-1 gradient vs bf16 step: %.2e" % (
+        l32[0], l32[-1], l16[0], rel))
