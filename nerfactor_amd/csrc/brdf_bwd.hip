@@ -294,21 +294,19 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(
                 asm volatile("" : "+s"(ld2), "+s"(b));
                 fs.base = reinterpret_cast<char*>(b);
                 fs.ld2 = ld2;
-                fs.roff = (unsigned)(row * 2);
+                fs.roff = (unsigned)(row * 4);   // pair layout: one dword per row and feature pair (feat_store.hpp)
             }
-            {   // network input, logical order
-                FeatStore f3 = fs, f2 = fs, f1 = fs;
-                f3.roff = fs.roff + (h ? (unsigned)(3 * fs.ld2) : 0u);   // cosines sit 3 features after the sines
-                f2.roff = fs.roff + (h ? (unsigned)(2 * fs.ld2) : 0u);   // theta_d sits 2 features after phi_d
-                f1.roff = fs.roff + (h ? (unsigned)fs.ld2 : 0u);         // z_{i+1} after z_i
+            {   // network input, logical order [z | rusink, sin, cos bands]: half 0 / half 1 hold different features
 #pragma unroll
-                for (int q = 0; q < 6; ++q) st16(f3, z_dim + 3 + 6 * (q / 3) + (q % 3), bin[0][0][q]);
-                st16(f2, z_dim, bin[0][0][6]);
-                if (h == 0) st16(fs, z_dim + 1, bin[0][0][7]);
-                else st16(fs, 0, bin[0][0][7]);
+                for (int q = 0; q < 6; ++q) {   // cosines sit 3 features after the sines
+                    const int fa = z_dim + 3 + 6 * (q / 3) + (q % 3);
+                    st16_ab(fs, fa, fa + 3, h, bin[0][0][q]);
+                }
+                st16_ab(fs, z_dim, z_dim + 2, h, bin[0][0][6]);          // theta_d sits 2 features after phi_d
+                st16_ab(fs, z_dim + 1, 0, h, bin[0][0][7]);              // half 0: theta_h, half 1: z_0
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (1 + 2 * j + h < z_dim) st16(f1, 1 + 2 * j, bin[1][0][j]);
+                    if (1 + 2 * j + h < z_dim) st16_ab(fs, 1 + 2 * j, 2 + 2 * j, h, bin[1][0][j]);   // z_{i+1} after z_i
             }
             store_hidden<8>(fs, kOffH + 0, h, h0);
             store_hidden<8>(fs, kOffH + 128, h, h1);

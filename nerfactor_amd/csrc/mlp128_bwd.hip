@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_kernel(
             asm volatile("" : "+s"(ld2), "+s"(b));
             fs.base = reinterpret_cast<char*>(b);
             fs.ld2 = ld2;
-            fs.roff = (unsigned)(row * 2);
+            fs.roff = (unsigned)(row * 4);   // pair layout: one dword per row and feature pair (feat_store.hpp)
         }
         const bool valid = row < n_rows;
         const long long rc = valid ? row : n_rows - 1;
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_kernel(
         store_hidden<8>(fs, G::kOffDZ + 128, h, dz1);
         dgrad_layer<8, G::kNLH, G::kNL0>(ws, tid, dz1, h0, dz0);   // W1; next chunk = L0 of the next tile
         store_hidden<8>(fs, G::kOffDZ + 0, h, dz0);
+        // (r03: all eight store_hidden groups issued here, behind the tile's last weight chunk, measured 2.98-4.4 ms per
+        //  step against 2.75: the stores are better off spread between the chunks)
     }
 }
 

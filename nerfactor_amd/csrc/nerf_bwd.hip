@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_kernel(
             asm volatile("" : "+s"(ld2), "+s"(b));
             fs.base = reinterpret_cast<char*>(b);
             fs.ld2 = ld2;
-            fs.roff = (unsigned)(row * 2);
+            fs.roff = (unsigned)(row * 4);   // pair layout: one dword per row and feature pair (feat_store.hpp)
         }
         const bool valid = row < n_pts;
         const long long mm = valid ? row : n_pts - 1;

@@ -2,9 +2,10 @@
 //   amsgrad_step   tf.keras.optimizers.Adam(amsgrad=True) dense update          trainvali.py:110-127
 //   wgrad_bf16     dW[K,N] += X[rows,K]^T dZ[rows,N] from feature-major bf16    (tape.gradient, trainvali.py:284)
 //                  (+ db[N] += sum_rows dZ[rows,N], folded into the same pass)
-// Activations / pre-activation gradients arrive FEATURE-MAJOR ([feature][row], bf16) from the fused
-// backward kernels, so an MFMA operand fragment (one feature x 8 consecutive rows) is one 16-byte
-// global load — no LDS transposition anywhere.
+// Activations / pre-activation gradients arrive FEATURE-PAIR-major ([feature >> 1][row][feature & 1], bf16:
+// feat_store.hpp) from the fused backward kernels: 16 bytes = 4 consecutive rows of two adjacent features.  An MFMA
+// operand fragment (one feature x 8 consecutive rows) is two such pieces with the feature's halves picked out by
+// v_perm_b32 — done once per piece while the LDS-staged kernels stage their tiles, per fragment in the direct kernel.
 #include <stdlib.h>
 
 #include "nfx_common.hpp"
@@ -17,8 +18,8 @@ namespace nfx {
 // atomics anywhere), and a backward pass costs three launches however many layers it has.
 constexpr int kWgMaxCalls = 16;
 struct WgCall {
-    const __bf16* xt;   // [k_in][ld] layer inputs, feature-major
-    const __bf16* zt;   // [n_out][ld] pre-activation gradients, feature-major
+    const __bf16* xt;   // layer inputs, [ceil(k_in / 2)][ld][2] (first feature even)
+    const __bf16* zt;   // pre-activation gradients, [ceil(n_out / 2)][ld][2]
     float* dw;          // [k_in][n_out] fp32, accumulated into
     float* db;          // [n_out] or null
     float* part;        // [n_slabs][k_pad][n_pad] partial sums of this call
@@ -33,6 +34,25 @@ struct WgBatch {
     int wide_only;      // NFX_WGRAD_NARROW=0: the 256 x 256 block form also for narrow GEMMs (A/B)
     long long ld, rows, slab;
 };
+// the two features of a 16-byte piece (4 rows x [even, odd]) as 8 bytes each: rows r .. r+3 of one feature
+__device__ __forceinline__ void wg_split(const u32x4& v, unsigned (&even)[2], unsigned (&odd)[2]) {
+    even[0] = __builtin_amdgcn_perm(v[1], v[0], 0x05040100u);
+    even[1] = __builtin_amdgcn_perm(v[3], v[2], 0x05040100u);
+    odd[0] = __builtin_amdgcn_perm(v[1], v[0], 0x07060302u);
+    odd[1] = __builtin_amdgcn_perm(v[3], v[2], 0x07060302u);
+}
+// feature f's fragment (8 consecutive rows from `row`) straight from global memory
+__device__ __forceinline__ bf16x8 wg_fragment(const __bf16* __restrict__ t, long long ld, int f, long long row) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(t + ((long long)(f >> 1) * ld + row) * 2);
+    const u32x4 lo = p[0], hi = p[1];
+    const unsigned sel = (f & 1) ? 0x07060302u : 0x05040100u;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(lo[1], lo[0], sel);
+    r[1] = __builtin_amdgcn_perm(lo[3], lo[2], sel);
+    r[2] = __builtin_amdgcn_perm(hi[1], hi[0], sel);
+    r[3] = __builtin_amdgcn_perm(hi[3], hi[2], sel);
+    return __builtin_bit_cast(bf16x8, r);
+}
 __device__ __forceinline__ int wg_find_call(const WgBatch& b, int block) {
     int ci = 0;
 #pragma unroll 1
@@ -108,12 +128,12 @@ __global__ __launch_bounds__(64, 1) void wgrad_kernel(WgBatch bt) {
 #pragma unroll
         for (int i = 0; i < kWgTiles; ++i) {
             const int f = kb + 32 * i + q;
-            a[i] = f < k_in ? *reinterpret_cast<const bf16x8*>(xt + (long long)f * ld + k0 + 8 * h) : zero;
+            a[i] = f < k_in ? wg_fragment(xt, ld, f, k0 + 8 * h) : zero;
         }
 #pragma unroll
         for (int j = 0; j < kWgTiles; ++j) {
             const int f = nb + 32 * j + q;
-            b[j] = f < n_out ? *reinterpret_cast<const bf16x8*>(zt + (long long)f * ld + k0 + 8 * h) : zero;
+            b[j] = f < n_out ? wg_fragment(zt, ld, f, k0 + 8 * h) : zero;
         }
     };
     bf16x8 an[kWgTiles], bn[kWgTiles];
@@ -222,25 +242,31 @@ __device__ __forceinline__ void wgrad_lds_narrow(const WgBatch& bt, const WgCall
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 sx[8], sz[8];   // piece p = i * 256 + tid -> feature p >> 4, 16-byte part (8 rows) p & 15
+    u32x4 sx[8], sz[8];   // piece p = i * 256 + tid -> feature pair p >> 5, 16-byte part (4 rows x 2 features) p & 31
     auto load_chunk = [&](long long row0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pp = i * 256 + tid, f = pp >> 4, part = pp & 15;
-            const long long row = row0 + part * 8;
+            const int pp = i * 256 + tid, pr = pp >> 5, part = pp & 31;
+            const long long row = row0 + part * 4;
             const bool rok = row < r1;
-            sx[i] = (f < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + (long long)f * ld + row) : zero4;
-            sz[i] = (f < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + (long long)f * ld + row) : zero4;
+            sx[i] = (2 * pr < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + ((long long)pr * ld + row) * 2) : zero4;
+            sz[i] = (2 * pr < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + ((long long)pr * ld + row) * 2) : zero4;
         }
     };
-    auto store_chunk = [&](int stage) {
+    auto store_chunk = [&](int stage) {   // the LDS tiles stay [feature][row]: the pairs are split here
         char* bx = smem + stage * 2 * kWnTile;
         char* bz = bx + kWnTile;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pp = i * 256 + tid, f = pp >> 4, part = pp & 15;
-            *reinterpret_cast<u32x4*>(bx + f * kWnPitch + part * 16) = sx[i];
-            *reinterpret_cast<u32x4*>(bz + f * kWnPitch + part * 16) = sz[i];
+            const int pp = i * 256 + tid, pr = pp >> 5, part = pp & 31;
+            unsigned e[2], o[2];
+            wg_split(sx[i], e, o);
+            *reinterpret_cast<u32x2*>(bx + (2 * pr) * kWnPitch + part * 8) = u32x2{e[0], e[1]};
+            *reinterpret_cast<u32x2*>(bx + (2 * pr + 1) * kWnPitch + part * 8) = u32x2{o[0], o[1]};
+            wg_split(sz[i], e, o);
+            *reinterpret_cast<u32x2*>(bz + (2 * pr) * kWnPitch + part * 8) = u32x2{e[0], e[1]};
+            *reinterpret_cast<u32x2*>(bz + (2 * pr + 1) * kWnPitch + part * 8) = u32x2{o[0], o[1]};
         }
     };
     const bool do_bias = c.db != nullptr;
@@ -368,26 +394,32 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(WgBatch bt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    // staging: piece p = i * 256 + tid -> feature p >> 3, 16-byte part p & 7
+    // staging: piece p = i * 256 + tid -> feature pair p >> 4 (of this block's 128), 16-byte part (4 rows x 2 features) p & 15
     u32x4 sx[8], sz[8];
     auto load_chunk = [&](long long row0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pp = i * 256 + tid, f = pp >> 3, part = pp & 7;
-            const long long row = row0 + part * 8;  // rows beyond r1 inside the last chunk: zero (ld is padded, but
+            const int pp = i * 256 + tid, pr = pp >> 4, part = pp & 15;
+            const long long row = row0 + part * 4;  // rows beyond r1 inside the last chunk: zero (ld is padded, but
             const bool rok = row < r1;              // another slab's rows must not be counted twice)
-            sx[i] = (kb + f < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + (long long)(kb + f) * ld + row) : zero4;
-            sz[i] = (nb + f < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + (long long)(nb + f) * ld + row) : zero4;
+            sx[i] = (kb + 2 * pr < k_in && rok) ? *reinterpret_cast<const u32x4*>(xt + ((long long)(kb / 2 + pr) * ld + row) * 2) : zero4;
+            sz[i] = (nb + 2 * pr < n_out && rok) ? *reinterpret_cast<const u32x4*>(zt + ((long long)(nb / 2 + pr) * ld + row) * 2) : zero4;
         }
     };
-    auto store_chunk = [&](int stage) {
+    auto store_chunk = [&](int stage) {   // the LDS tiles stay [feature][row]: the pairs are split here
         char* bx = smem + stage * 2 * kWlTile;
         char* bz = bx + kWlTile;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pp = i * 256 + tid, f = pp >> 3, part = pp & 7;
-            *reinterpret_cast<u32x4*>(bx + f * kWlPitch + part * 16) = sx[i];
-            *reinterpret_cast<u32x4*>(bz + f * kWlPitch + part * 16) = sz[i];
+            const int pp = i * 256 + tid, pr = pp >> 4, part = pp & 15;
+            unsigned e[2], o[2];
+            wg_split(sx[i], e, o);
+            *reinterpret_cast<u32x2*>(bx + (2 * pr) * kWlPitch + part * 8) = u32x2{e[0], e[1]};
+            *reinterpret_cast<u32x2*>(bx + (2 * pr + 1) * kWlPitch + part * 8) = u32x2{o[0], o[1]};
+            wg_split(sz[i], e, o);
+            *reinterpret_cast<u32x2*>(bz + (2 * pr) * kWlPitch + part * 8) = u32x2{e[0], e[1]};
+            *reinterpret_cast<u32x2*>(bz + (2 * pr + 1) * kWlPitch + part * 8) = u32x2{o[0], o[1]};
         }
     };
     const bool active = kb + 128 * wk < k_in && nb + 128 * wn < n_out;  // wave-uniform: quadrant has real features

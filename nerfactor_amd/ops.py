@@ -366,7 +366,7 @@ def mlp128_bwd(in_kind, xyz, dout, blob, dkernels, dbiases, out_act=None, xyz_sc
     for t in list(dkernels) + list(dbiases):
         _dev(t, 'gradient buffer')
     ws_bytes = lib.nfx_mlp128_bwd_workspace_bytes(in_kind, n, nl)
-    ws = torch.empty((max(ws_bytes, 16) // 2 + _XP_WS_MARGIN,), dtype=torch.bfloat16, device=xyz.device)
+    ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=xyz.device)
     karr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dkernels])
     barr = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in dbiases])
     check(lib.nfx_mlp128_bwd(in_kind, _ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob),
@@ -398,7 +398,6 @@ def composite_bwd(rgbs, z, rayd, d_rgb, white_bg=True, noise=None):
     return out
 
 
-_XP_WS_MARGIN = (32 << 20) if os.environ.get('NFX_XP_WS_MARGIN') else 0   # (timing experiments that store out of layout)
 NERF_BWD_MAX_POINTS = 1 << 19   # ~5 GB of feature-major workspace per call; more rays are processed in slices
 
 
@@ -421,7 +420,7 @@ def nerf_mlp_bwd(rayo, rayd, z, d_rgbs, blob, dkernels, dbiases, prec='bf16'):
         hi = min(n, lo + rays_per_call)
         ws_bytes = lib.nfx_nerf_bwd_workspace_bytes(hi - lo, s)
         if ws is None or ws.numel() * 2 < ws_bytes:
-            ws = torch.empty((max(ws_bytes, 16) // 2 + _XP_WS_MARGIN,), dtype=torch.bfloat16, device=z.device)
+            ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=z.device)
         check(lib.nfx_nerf_mlp_bwd(_ptr(rayo[lo:hi]), _ptr(rayd[lo:hi]), _ptr(z[lo:hi]), hi - lo, s, _ptr(blob),
                                    _PREC[prec], _ptr(d_rgbs[lo:hi]), _ptr(ws), ws.numel() * 2, karr, barr,
                                    _stream()), 'nfx_nerf_mlp_bwd')
