@@ -159,11 +159,12 @@ def nerf_cpu_reference(nets, rayo, rayd, budget_s, timed_run=True):
 
 
 def committed_traffic(kernel_substr, scale=1):
-    """(GB per launch, source) of a kernel from the newest committed PMC digest (scripts/gpu_r02_final.sh ->
+    """(GB per launch, source) of a kernel from the newest committed PMC digest (scripts/gpu_r03_final.sh ->
     scripts/pmc_digest.py: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the kernel's dispatches of
     this very command at N = 1).  rocprofv3 counter passes cannot run inside this process, so the figure is a committed
     constant and the line says so."""
-    for rnd, name in (('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'), ('r01', 'pmc_nerfactor_digest.json')):
+    for rnd, name in (('r03', 'pmc_digest.json'), ('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'),
+                      ('r01', 'pmc_nerfactor_digest.json')):
         dig = os.path.join(ROOT, 'profiles', rnd, name)
         if not os.path.exists(dig):
             continue
