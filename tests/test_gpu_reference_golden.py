@@ -134,12 +134,18 @@ def test_brdf_prior_plugin_vs_reference_outputs(nfx_lib, cuda, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------- NeRFactor
+@pytest.mark.parametrize('prec', ['bf16', 'fp32'])
 @pytest.mark.parametrize('tag', ['nfl', 'nfm'])
-def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag):
+def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag, prec):
+    """Model.call(mode='test', relight_olat=True) against the REFERENCE's own outputs (reference_models.npz).
+    bf16 operands: 3e-2 on every [0, 1]-valued output; `precision = fp32` (fp32-class kernels): 3e-4 on the MLP heads,
+    1e-3 on rgb, 6e-3 on the x200 OLAT renders — held to the reference fixtures themselves, not to the oracle's float64
+    re-evaluation (the CPU oracle sits within 1e-5 / 1e-4 of these fixtures, tests/test_cpu_reference_golden.py)."""
     learned = tag == 'nfl'
     name = 'nerfactor' if learned else 'nerfactor_microfacet'
+    tol_head, tol_rgb, tol_olat = (3e-2, 3e-2, 6e-2) if prec == 'bf16' else (3e-4, 1e-3, 6e-3)
     model = make(name, cuda, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
-                 test_envmap_dir='')
+                 test_envmap_dir='', precision=prec)
     net = gi.nerfactor_net(3 if learned else 1)
     for part in net:
         fill(model.net[part], net[part])
@@ -149,16 +155,19 @@ def test_nerfactor_plugin_vs_reference_outputs(nfx_lib, cuda, tag):
         fill(model.brdf_model.net['brdf_out'], bnet['brdf_out'])
     model._light.data.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE[tag])))
     pred, gt, kw, _ = model(surface_batch(cuda), mode='test', relight_olat=True)
+    errs = {}
     for k in ('normal', 'lvis', 'albedo', 'brdf', 'rgb'):
-        err = np.abs(pred[k].cpu().numpy() - GOLD['%s_test_%s' % (tag, k)]).max()
-        assert err < 3e-2, (k, err)
+        errs[k] = float(np.abs(pred[k].cpu().numpy() - GOLD['%s_test_%s' % (tag, k)]).max())
+        assert errs[k] < (tol_rgb if k == 'rgb' else tol_head), (k, errs[k])
     keys = [str(k) for k in GOLD['%s_olat_keys' % tag]]
     idx = [int(k[:4]) * 32 + int(k[5:]) for k in keys]
     olat = pred['rgb_olat'].cpu().numpy()
     assert olat.shape == (24, 512, 3)
-    assert np.abs(olat[:, idx] - GOLD['%s_test_rgb_olat' % tag]).max() < 6e-2     # one light x 200: steep tonemap
+    errs['olat'] = float(np.abs(olat[:, idx] - GOLD['%s_test_rgb_olat' % tag]).max())
+    assert errs['olat'] < tol_olat, errs     # one light x 200: steep tonemap
     loss = model.compute_loss(pred, gt, **dict(kw, mode='vali')).cpu().numpy()
-    np.testing.assert_allclose(loss, GOLD['%s_vali_loss' % tag], atol=5e-3)
+    np.testing.assert_allclose(loss, GOLD['%s_vali_loss' % tag], atol=5e-3 if prec == 'bf16' else 2e-4)
+    print(tag, prec, 'max-abs vs the reference fixtures:', errs)
 
 
 @pytest.mark.parametrize('tag', ['nfl', 'nfm'])
