@@ -352,11 +352,16 @@ __device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp,
     // Derivatives in overflow-free closed form (the literal chain rule through q^2 E^2 and tan^2 produces inf - inf
     // for grazing half vectors, |h.n| < ~1e-6, which 512 lights x 1024 rays hit every few steps):
     //   q^2 E^2 = W^2 with W = q E = 1 + (a2 - 1) q  in [min(1,a2), max(1,a2)]   =>  D = a2 chi / (pi W^2)
+    // Every quotient is a divide_no_nan, as in the forward (microfacet.py:92-104): where the reference's denominator
+    // pi q^2 E^2 = pi W^2 is 0 its gradient is 0.  r03: with the roughness driven to 0 (sigmoid output 7e-17 after 115
+    // steps on noise targets: a2 = rough^4 underflows to 0) and a half vector exactly along the normal (q = 1), W = 0
+    // and the plain quotients gave 0 / 0 -> NaN in d rough, i.e. NaN in every parameter one optimizer step later.
     float dD_dq = 0.f, dD_da2 = 0.f;
     if (chi > 0.f && q > 0.f) {
-        const float W = 1.0f + (a2 - 1.0f) * q, W3 = W * W * W;
-        dD_dq = -2.0f * a2 * (a2 - 1.0f) / (pi * W3);
-        dD_da2 = (W - 2.0f * a2 * q) / (pi * W3);
+        const float W = 1.0f + (a2 - 1.0f) * q;
+        const float inv_w2 = div_no_nan(1.0f, pi * (W * W)), inv_w = div_no_nan(1.0f, W);
+        dD_dq = -2.0f * a2 * (a2 - 1.0f) * inv_w2 * inv_w;
+        dD_da2 = inv_w2 * (1.0f - 2.0f * a2 * q * inv_w);
     }
     const float cv = mp.cos_v, ct = dot3(hv, mp.v);
     const float chig = div_no_nan(ct, cv) > 0.0f ? 1.0f : 0.0f;
@@ -369,8 +374,9 @@ __device__ __forceinline__ float microfacet_spec_grad(const MicrofacetPoint& mp,
     float dG_dcv = 0.f, dG_da2 = 0.f;
     if (chig > 0.f && cv2 > 0.0f && cv2 < 1.0f) {
         const float c = fabsf(cv), r = sqrtf(a2 + (1.0f - a2) * p), cr2 = (c + r) * (c + r);
-        dG_dcv = (cv > 0.f ? 1.f : -1.f) * 2.0f * a2 / (r * cr2);
-        dG_da2 = -(1.0f - p) * c / (r * cr2);
+        const float inv = div_no_nan(1.0f, r * cr2);
+        dG_dcv = (cv > 0.f ? 1.f : -1.f) * 2.0f * a2 * inv;
+        dG_da2 = -(1.0f - p) * c * inv;
     }
     const float cl = dot3(l, mp.n);
     const float den = 4.0f * fabsf(cl) * fabsf(cv);
@@ -491,7 +497,8 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArg
             for (int c = 0; c < 3; ++c) a.d_normal[3 * pt + c] = d_dir[c] + (d_nhat[c] - nh[c] * proj) / nn;
             if (a.d_rough && !f.spec) {
                 const float r = f.rough[pt];
-                a.d_rough[pt] = d_a2 * 4.0f * r * r * r;  // a2 = rough^4
+                const float da2_dr = 4.0f * r * r * r;      // a2 = rough^4
+                a.d_rough[pt] = da2_dr == 0.0f ? 0.0f : d_a2 * da2_dr;   // (an underflowed roughness gets no gradient, never inf x 0)
             }
         }
     }
