@@ -12,10 +12,17 @@ if [ "${TESTS:-1}" = "1" ]; then
   timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -6 $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.log
 fi
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/prof_run.log 2>&1)
+if [ "${BENCH:-1}" = "1" ]; then
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json
+fi
+# rocprofv3 kernel stats of the same command, the render legs and the training legs traced separately: the NeRF MLP and
+# light-visibility kernels also run (on 1024 rays) inside the training steps, which would blur their per-launch averages
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --legs nerf,nerfactor_microfacet,nerfactor,olat > $OUT/prof_run.log 2>&1)
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv; rm -rf $OUT/prof
 head -8 $OUT/bench_kernel_stats.csv | cut -c1-150
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs train > $OUT/prof_train_run.log 2>&1)
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_train_legs_kernel_stats.csv; rm -rf $OUT/prof
+head -8 $OUT/bench_train_legs_kernel_stats.csv | cut -c1-150
 if [ "${PMC:-1}" = "1" ]; then
   run_pass() {
     local name=$1; shift
