@@ -101,6 +101,12 @@ int nfx_l2_normalize3(const float *dev_in, float *dev_out, int64_t n, float eps,
  * int32 the caller zeroed) if any of the n floats is Inf or NaN.  dev_x must be 16-byte aligned.               */
 int nfx_any_nonfinite(const float *dev_x, int64_t n, int *dev_flag, void *stream);
 
+/* tf.scatter_nd of the alpha > 0 rows into a zero tensor (nerfactor.py:295-306, shape.py:171-176) in one pass:
+ * dev_dst[i, :] = dev_src[dev_row_of[i], :] where dev_row_of[i] >= 0, zeros elsewhere.  dev_src [m, d], dev_row_of
+ * [n_all] int32 (compact row of every full row, or -1), dev_dst [n_all, d].  Every output element is written.  */
+int nfx_scatter_rows(const float *dev_src, const int32_t *dev_row_of, int64_t n_all, int d, float *dev_dst,
+                     void *stream);
+
 /* Stratified depths, Model.gen_z (nerf.py:120-136).  z [n_rays, n_samples].
  * dev_u: NULL (no perturbation) or uniform [0,1) randoms [n_rays, n_samples]
  * drawn by the caller (the reference draws them with tf.random.uniform).     */

@@ -41,6 +41,7 @@ SIGNATURES = {
     'nfx_mlp128_pack_weights': (_i, [_pp, _pp, _i, _i, _i, _i, _p, _sz]),
     'nfx_l2_normalize3': (_i, [_p, _p, _i64, _f, _p]),
     'nfx_any_nonfinite': (_i, [_p, _i64, _p, _p]),
+    'nfx_scatter_rows': (_i, [_p, _p, _i64, _i, _p, _p]),
     'nfx_gen_z': (_i, [_f, _f, _i, _i64, _i, _p, _p, _p]),
     'nfx_nerf_mlp_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_composite_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p]),

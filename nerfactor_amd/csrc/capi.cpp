@@ -160,6 +160,22 @@ int nfx_any_nonfinite(const float* x, int64_t n, int* flag, void* stream) {
     return hip_result(nfx_launch_nonfinite(x, n, flag, (hipStream_t)stream), "any_nonfinite");
 }
 
+int nfx_launch_scatter_rows(const float*, const int*, long long, int, float*, hipStream_t);
+int nfx_scatter_rows(const float* src, const int32_t* row_of, int64_t n_all, int d, float* dst, void* stream) {
+    REQUIRE(n_all >= 0 && d >= 1, "nfx_scatter_rows: bad shape (%lld rows of %d)", (long long)n_all, d);
+    if (n_all == 0) return NFX_OK;
+    REQUIRE(row_of && dst, "nfx_scatter_rows: null pointer");   // (src may be null when no row is selected)
+    // at most 2^32 - 1 elements (or float4 groups) per launch: slice the rows
+    const long long per_row = d % 4 == 0 ? d / 4 : d, max_rows = ((1ll << 32) - 1) / per_row;
+    for (long long r0 = 0; r0 < n_all; r0 += max_rows) {
+        const long long nr = n_all - r0 < max_rows ? n_all - r0 : max_rows;
+        const int rc = hip_result(nfx_launch_scatter_rows(src, row_of + r0, nr, d, dst + r0 * d, (hipStream_t)stream),
+                                  "scatter_rows");
+        if (rc) return rc;
+    }
+    return NFX_OK;
+}
+
 int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp, const float* u,
               float* z, void* stream) {
     REQUIRE(n_samples >= 2, "nfx_gen_z: n_samples must be >= 2 (got %d)", n_samples);

@@ -223,9 +223,18 @@ class Model(ShapeModel):
             xyz, rayo, normal_pred, albedo, brdf_prop, lvis_pred, relight_olat=relight_olat,
             relight_probes=relight_probes)
 
+        row_of = []   # [n_all] int32: compact row of every ray, -1 for the background (built on first use)
+
         def full(v):  # zero-filled scatter back to all rays (tf.scatter_nd)
             if v is None or all_fg:
                 return v
+            if v.is_cuda and v.dtype == torch.float32 and not (torch.is_grad_enabled() and v.requires_grad):
+                # one pass that writes every output row once (nfx_scatter_rows) instead of zeros + index_put_
+                if not row_of:
+                    r = torch.full((n_all,), -1, dtype=torch.int32, device=v.device)
+                    r[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=v.device)
+                    row_of.append(r)
+                return ops.scatter_rows(v.contiguous(), row_of[0], n_all)
             out = torch.zeros((n_all,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
             out[idx] = v
             return out

@@ -172,6 +172,23 @@ def all_finite(x):
     return flag == 0
 
 
+def scatter_rows(src, row_of, n_all=None):
+    """out[i] = src[row_of[i]] where row_of[i] >= 0, zeros elsewhere (tf.scatter_nd of the foreground rows): ONE pass that
+    writes every output element once.  src [m, ...] fp32, row_of [n_all] int32."""
+    src = _dev(src, 'src')
+    row_of = row_of.contiguous()
+    if not row_of.is_cuda or row_of.dtype != torch.int32:
+        raise _capi.NfxError("scatter_rows: row_of must be a CUDA int32 tensor")
+    n_all = row_of.shape[0] if n_all is None else n_all
+    d = 1
+    for k in src.shape[1:]:
+        d *= int(k)
+    out = torch.empty((n_all,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    check(lib.nfx_scatter_rows(_ptr(src), ctypes.c_void_p(row_of.data_ptr()), n_all, d, _ptr(out), _stream()),
+          'nfx_scatter_rows')
+    return out
+
+
 def gen_z(near, far, n_samples, n_rays, lin_in_disp=False, u=None, device='cuda'):
     u = _dev(u, 'u', (n_rays, n_samples))
     z = torch.empty((n_rays, n_samples), dtype=torch.float32, device=device)

@@ -545,3 +545,26 @@ def test_all_finite_kernel(nfx_lib, cuda):
             y[pos] = bad
             assert not bool(ops.all_finite(y)), (n, pos)
     assert bool(ops.all_finite(torch.full((70,), 3.4e38, device=cuda)))          # the largest finite float
+
+
+@pytest.mark.parametrize("shape", [(1000, 512), (777, 3), (640, 9, 3), (33, 1), (5, 6)])
+def test_scatter_rows_is_tf_scatter_nd_of_the_foreground_rows(nfx_lib, cuda, shape):
+    """nfx_scatter_rows against zeros + index_put_ (the reference's tf.scatter_nd, nerfactor.py:295-306): bit-equal, every
+    output element written (the output buffer is pre-filled with NaN by the allocator trick below)."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(4)
+    n_all = shape[0] * 2 + 7
+    mask = np.zeros(n_all, bool)
+    mask[rng.permutation(n_all)[:shape[0]]] = True
+    idx = torch.from_numpy(np.nonzero(mask)[0]).to(cuda)
+    src = dev(rng.normal(size=shape), cuda)
+    row_of = torch.full((n_all,), -1, dtype=torch.int32, device=cuda)
+    row_of[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=cuda)
+    junk = torch.full((n_all,) + shape[1:], float('nan'), device=cuda)   # make stale NaNs likely in the next allocation
+    del junk
+    got = ops.scatter_rows(src, row_of, n_all)
+    want = torch.zeros((n_all,) + shape[1:], device=cuda)
+    want[idx] = src
+    assert torch.equal(got, want)
+    with pytest.raises(nfx_lib.NfxError):
+        ops.scatter_rows(src, row_of.long(), n_all)
