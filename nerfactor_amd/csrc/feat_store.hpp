@@ -11,6 +11,12 @@
 // A feature offset handed to the GEMMs must be even (all of them are: mlp128_bwd.hip Geo, nerf_train_layout.hpp).
 #pragma once
 #include "mlp_engine.hpp"
+// Non-temporal stores (r03): the backward kernels write 1-2 GB of activations per call THROUGH the L2 their weight
+// stream lives in; with plain stores the weight lines are evicted all the time (nerf_bwd ring kernel: TCP->TCC read
+// latency 789 cycles, 379 with `nt`; kernel 558 -> 515 us).  -DNFX_FEAT_NT=0 for the A/B.
+#ifndef NFX_FEAT_NT
+#define NFX_FEAT_NT 1
+#endif
 
 namespace nfx {
 namespace bwd {
@@ -42,7 +48,11 @@ __device__ __forceinline__ unsigned long long pair_base(const FeatStore& fs, int
 // one value: feature `feat` of this lane's row (lane offset `loff` relative to the pair row, default the plain row)
 __device__ __forceinline__ void st16_at(const FeatStore& fs, int feat, unsigned loff, __bf16 v) {
     typedef __attribute__((address_space(1))) __bf16* gbf16_ptr;
+#if NFX_FEAT_NT
+    __builtin_nontemporal_store(v, (gbf16_ptr)((__attribute__((address_space(1))) char*)pair_base(fs, feat) + loff));
+#else
     *(gbf16_ptr)((__attribute__((address_space(1))) char*)pair_base(fs, feat) + loff) = v;
+#endif
 }
 __device__ __forceinline__ void st16(const FeatStore& fs, int feat, __bf16 v) {
     st16_at(fs, feat, fs.roff + 2u * (unsigned)(feat & 1), v);
@@ -58,7 +68,11 @@ __device__ __forceinline__ void st16_ab(const FeatStore& fs, int fa, int fb, int
 // the dword of an EVEN feature and its successor
 __device__ __forceinline__ void st32(const FeatStore& fs, int feat_even, unsigned v) {
     typedef __attribute__((address_space(1))) unsigned* gu32_ptr;
+#if NFX_FEAT_NT
+    __builtin_nontemporal_store(v, (gu32_ptr)((__attribute__((address_space(1))) char*)pair_base(fs, feat_even) + fs.roff));
+#else
     *(gu32_ptr)((__attribute__((address_space(1))) char*)pair_base(fs, feat_even) + fs.roff) = v;
+#endif
 }
 // B-operand registers of a hidden activation (k-step s, element j <-> feature F(s,h,j)): dword j / 2 = features
 // (F, F + 1) with F even.  `feat0` even.

@@ -8,6 +8,7 @@
 //   3. dgrad chain dH_{l-1}^T = W_l dZ_l^T with the register-resident MFMA dataflow of the forward
 //      (nerf_train_layout.hpp lists the transposed "layers"), masked by the ReLU bits, every dZ written feature-major.
 // Sample positions carry no gradient (z_fine is under stop_gradient, nerf.py:145; rays are data).
+#include <cstdlib>
 #include "feat_store.hpp"
 #include "nerf_train_layout.hpp"
 
@@ -163,6 +164,264 @@ __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the same arithmetic with the weight stream on an LDS-DMA ring.
+// The kernel above gives a chunk ONE chunk time to arrive (register-staged double buffer) and, because gfx9 counts loads
+// and stores in one in-order `vmcnt`, every wait for a staged chunk is also a wait for the 8 activation stores issued
+// before it: each of the 152 chunks of a 128-row tile paid a store round trip (≈4400 cycles per chunk against 1024
+// cycles of MFMA work).  Here chunk i + 5 is fetched by `global_load_lds_dwordx4` while chunk i is consumed (6 slots of
+// 20 KiB) and the wait behind chunk i names exactly what may still be in flight: the pieces of chunks i + 2 .. i + 5
+// and the 8 stores of each of the last four epilogues (<= 52 of the counter's 63).  Chunks the backward does not use
+// (sigma_out, rgb_out[1] forward tiles) are not fetched at all.  Same MFMA order and operands as the kernel above
+// (scripts/grad_identity.py: bit-identical workspace and gradients).
+namespace nring {
+#ifndef NFX_NRING_D
+#define NFX_NRING_D 5   // fetch distance in chunks (experiments: 2 .. 5; 6 would exceed the 6-bit counter)
+#endif
+constexpr int kSeq = 152, kD = NFX_NRING_D, kR = kD + 1, kSlot = 20 * 1024, kEpiStores = 8;
+constexpr int kLds = kR * kSlot + nerf::kBiasFloats * 4;
+static_assert(kLds <= 160 * 1024, "LDS");
+// chunk i of a tile's sequence: first fragment in the train blob / 1-KiB pieces per wave
+constexpr int off(int i) {
+    if (i < 72) return nerf::chunk_frag_offset(i);                 // enc[0..7], bottleneck
+    if (i < 76) return nerf::chunk_frag_offset(i + 1);             // rgb_out[0] (the sigma chunk is skipped)
+    const int j = i - 76;
+    return nerf::kFrags + (j < 4 ? j * 4 : j < 12 ? 16 + (j - 4) * 8 : j < 20 ? 80 + (j - 12) * 20 : 240 + (j - 20) * 16);
+}
+constexpr int pieces(int i) {
+    if (i >= kSeq) return 0;
+    if (i < 8) return 1;
+    if (i < 40) return 4;
+    if (i < 48) return 5;
+    if (i < 72) return 4;
+    if (i < 76) return 5;
+    const int j = i - 76;
+    return j < 4 ? 1 : j < 12 ? 2 : j < 20 ? 5 : 4;
+}
+// what may still be in flight when chunk i + 1 must have landed: the wait sits behind the MFMAs of chunk i and before
+// its epilogue, so the stores of epilogues max(0, i + 1 - kD) .. i - 1 are younger than the fetch of chunk i + 1
+// (i = -1: the wait behind the priming fetches)
+constexpr int allow(int i) {
+    int n = kEpiStores * (i < 0 ? 0 : i < kD - 1 ? i : kD - 1);
+    for (int j = i + 2; j <= i + kD; ++j) n += pieces(j);
+    return n;
+}
+constexpr int max_allow() {
+    int m = 0;
+    for (int i = 0; i < kSeq; ++i) m = allow(i) > m ? allow(i) : m;
+    return m;
+}
+static_assert(max_allow() <= 63, "vmcnt is a 6-bit counter");
+static_assert(off(kSeq - 1) + 16 == nerf::kTrainFrags, "sequence covers the train blob");
+
+struct Ctx {
+    char* smem;
+    unsigned smem_lds;
+    const char* blob;
+    int lane, wave;   // wave: wave-uniform
+};
+
+template <int N>
+__device__ __forceinline__ void dma(unsigned lane_off, const char* gbase, unsigned lds_dst) {
+    unsigned keep;
+    static_assert(N == 1 || N == 2 || N == 4 || N == 5, "pieces per wave");
+    // (N = 5: the 13-bit signed offset ends at 4095, so the statement is centred on the third piece)
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase + 2048), "s"(lds_dst + 2048) : "memory");
+}
+// fetch chunk F of the sequence into its slot (F % kR; last read by chunk F - kR, whose closing barrier every wave
+// has passed: F is fetched during chunk F - kD = F - kR + 1, or before chunk 0 for the first kD)
+template <int F>
+__device__ __forceinline__ void fetch(const Ctx& cx) {
+    if constexpr (F < kSeq) {
+        constexpr int n = pieces(F);
+        unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
+        unsigned lds = cx.smem_lds;
+        asm volatile("" : "+s"(base), "+s"(lds));   // per chunk: keeps the 152 address pairs out of the loop preheader
+        const int piece0 = cx.wave * n;
+        dma<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)off(F) * 1024 + piece0 * 1024,
+               lds + (unsigned)(F % kR) * kSlot + (unsigned)piece0 * 1024u);
+    }
+}
+// chunk I: acc (initialised by the caller) += W_tile [b1 ; b2]; returns with chunk I + 1 landed and published
+template <int I, int KS1, int KS2, int KS1A, int KS2A>
+__device__ __forceinline__ void chunk(const Ctx& cx, const bf16x8 (&b1)[KS1A][1], const bf16x8 (&b2)[KS2A][1],
+                                      f32x16 (&acc)[1]) {
+    fetch<I + kD>(cx);
+    const char* f0 = cx.smem + (I % kR) * kSlot + cx.lane * 16;
+    mma_k<KS1>(f0, b1, acc);
+    if constexpr (KS2 > 0) mma_k<KS2>(f0 + KS1 * kFragBytes, b2, acc);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(allow(I)) : "memory");
+}
+
+template <int I0, int KS1, int KS2, int NT, bool RELU, int KS1A, int KS2A, int NTA>
+__device__ __forceinline__ void fwd_layer(const Ctx& cx, const float* bias, const bf16x8 (&b1)[KS1A][1],
+                                          const bf16x8 (&b2)[KS2A][1], bf16x8 (&bout)[NTA][1], const FeatStore& fs,
+                                          int feat0, unsigned (&m)[NT / 2]) {
+    const int h = cx.lane >> 5;
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[1];
+        bias_init<1>(bias + 32 * t, h, acc);
+        chunk<I0 + t, KS1, KS2>(cx, b1, b2, acc);
+        if constexpr (RELU) {
+            const unsigned bits = relu_bits16(acc[0]);
+            if constexpr (t & 1) m[t >> 1] |= bits << 16;
+            else m[t >> 1] = bits;
+        }
+        acc_to_b<RELU, 1>(acc, bout[2 * t], bout[2 * t + 1]);
+        store_tile(fs, feat0 + 32 * t, h, bout[2 * t][0], bout[2 * t + 1][0]);   // kEpiStores dword stores
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+template <int I0, int KS1, int KS2, int NT, bool MASK, int KS1A, int KS2A, int NTA>
+__device__ __forceinline__ void dgrad_layer(const Ctx& cx, const bf16x8 (&dz)[KS1A][1], const bf16x8 (&b2)[KS2A][1],
+                                            const unsigned (&m)[NT / 2], bf16x8 (&dout)[NTA][1], const FeatStore& fs,
+                                            int feat0) {
+    const int h = cx.lane >> 5;
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[1];
+        zero_init<1>(acc);
+        chunk<I0 + t, KS1, KS2>(cx, dz, b2, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool on = MASK ? mask_bit(m, t, r) : true;
+            dout[2 * t + (r >> 3)][0][r & 7] = (__bf16)(on ? acc[0][r] : 0.f);
+        }
+        mfma_operand_fence(dout[2 * t][0]);
+        mfma_operand_fence(dout[2 * t + 1][0]);
+        store_tile(fs, feat0 + 32 * t, h, dout[2 * t][0], dout[2 * t + 1][0]);   // kEpiStores dword stores
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+}  // namespace nring
+
+__global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_ring_kernel(
+    const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
+    int n_samples, const char* __restrict__ blob, const float4* __restrict__ d_rgbs, __bf16* __restrict__ wsp,
+    long long ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using namespace nerf;
+    constexpr int NW = kNerfNW;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* bias_lds = reinterpret_cast<float*>(smem + nring::kR * nring::kSlot);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + kTrainWeightBytes);
+        for (int i = tid; i < kBiasFloats; i += NW * 64) bias_lds[i] = bsrc[i];
+        __syncthreads();
+    }
+    typedef __attribute__((address_space(3))) char lds_char;
+    const nring::Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave};
+    const long long n_tiles = (n_pts + kNerfRows - 1) / kNerfRows;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row = tile * kNerfRows + wave * 32 + p;  // < ld (ld is a multiple of kNerfRows)
+        FeatStore fs;
+        {
+            unsigned long long ld2 = (unsigned long long)ld * 2, b = reinterpret_cast<unsigned long long>(wsp);
+            asm volatile("" : "+s"(ld2), "+s"(b));
+            fs.base = reinterpret_cast<char*>(b);
+            fs.ld2 = ld2;
+            fs.roff = (unsigned)(row * 4);
+        }
+        const bool valid = row < n_pts;
+        const long long mm = valid ? row : n_pts - 1;
+        bf16x8 pe[4][1], pv[2][1];
+        bf16x8 dzo[1][1], dsg[1][1];
+        // every load of the tile and every store that is not a chunk epilogue happens HERE, before the ring is primed:
+        // the counted waits below know of nothing else in the vmcnt window
+        {
+            const long long ray = mm / n_samples;
+            const float zz = zbuf[mm];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && h == 0) g = d_rgbs[row];
+            float x[3], d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = rayd[ray * 3 + k];
+                x[k] = rayo[ray * 3 + k] + d[k] * zz;
+            }
+            posenc<10, 1>(x, h, 0, pe);
+            posenc<4, 1>(d, h, 0, pv);
+            store_posenc<10, 4>(fs, kOffPe, h, pe);
+            store_posenc<4, 2>(fs, kOffPv, h, pv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dzo[0][0][j] = (__bf16)0.f;
+                dsg[0][0][j] = (__bf16)0.f;
+            }
+            dzo[0][0][0] = (__bf16)g.x;
+            dzo[0][0][1] = (__bf16)g.y;
+            dzo[0][0][2] = (__bf16)g.z;
+            dsg[0][0][0] = (__bf16)g.w;
+            if (h == 0) {
+                st16(fs, kOffDRgb + 0, dzo[0][0][0]);
+                st16(fs, kOffDRgb + 1, dzo[0][0][1]);
+                st16(fs, kOffDRgb + 2, dzo[0][0][2]);
+                st16(fs, kOffDSig, dsg[0][0][0]);
+            }
+            // the operands are final before the first DMA leaves: no compiler-placed vmcnt wait inside the window
+            u32x4 w0 = __builtin_bit_cast(u32x4, dzo[0][0]), w1 = __builtin_bit_cast(u32x4, dsg[0][0]);
+            asm volatile("" : "+v"(w0), "+v"(w1));
+            dzo[0][0] = __builtin_bit_cast(bf16x8, w0);
+            dsg[0][0] = __builtin_bit_cast(bf16x8, w1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, nring::kD>([&](auto F) { nring::fetch<decltype(F)::value>(cx); });
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(nring::allow(-1)) : "memory");   // chunk 0 landed
+        // ------------------------------------------------------------------ forward (re-computed)
+        unsigned mk[8][4], mr[2], mnone[4];
+        bf16x8 ha[16][1], hb[16][1];
+        nring::fwd_layer<0, 4, 0, 8, true>(cx, bias_lds + kBiasL0, pe, pe, ha, fs, kOffA + 0 * 256, mk[0]);
+        nring::fwd_layer<8, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 1, ha, pe, hb, fs, kOffA + 1 * 256, mk[1]);
+        nring::fwd_layer<16, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 2, hb, pe, ha, fs, kOffA + 2 * 256, mk[2]);
+        nring::fwd_layer<24, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 3, ha, pe, hb, fs, kOffA + 3 * 256, mk[3]);
+        nring::fwd_layer<32, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 4, hb, pe, ha, fs, kOffA + 4 * 256, mk[4]);
+        nring::fwd_layer<40, 16, 4, 8, true>(cx, bias_lds + kBiasL0 + 256 * 5, ha, pe, hb, fs, kOffA + 5 * 256, mk[5]);
+        nring::fwd_layer<48, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 6, hb, pe, ha, fs, kOffA + 6 * 256, mk[6]);
+        nring::fwd_layer<56, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 7, ha, pe, hb, fs, kOffA + 7 * 256, mk[7]);
+        nring::fwd_layer<64, 16, 0, 8, false>(cx, bias_lds + kBiasBott, hb, pe, ha, fs, kOffBott, mnone);  // bottleneck
+        bf16x8 r0[8][1];
+        nring::fwd_layer<72, 16, 2, 4, true>(cx, bias_lds + kBiasRgb0, ha, pv, r0, fs, kOffR0, mr);
+        // ------------------------------------------------------------------ dgrad chain
+        bf16x8 dr0[8][1];
+        nring::dgrad_layer<76, 1, 0, 4, true>(cx, dzo, dzo, mr, dr0, fs, kOffDR0);               // D1: rgb_out[1]^T
+        nring::dgrad_layer<80, 8, 0, 8, false>(cx, dr0, dzo, mnone, ha, fs, kOffDBott);          // D2: into the bottleneck
+        nring::dgrad_layer<88, 16, 1, 8, true>(cx, ha, dsg, mk[7], hb, fs, kOffDZ + 7 * 256);    // D3: [bott | sigma]^T
+        nring::dgrad_layer<96, 16, 0, 8, true>(cx, hb, dsg, mk[6], ha, fs, kOffDZ + 6 * 256);    // enc[7]^T
+        nring::dgrad_layer<104, 16, 0, 8, true>(cx, ha, dsg, mk[5], hb, fs, kOffDZ + 5 * 256);   // enc[6]^T
+        nring::dgrad_layer<112, 16, 0, 8, true>(cx, hb, dsg, mk[4], ha, fs, kOffDZ + 4 * 256);   // enc[5][:256]^T
+        nring::dgrad_layer<120, 16, 0, 8, true>(cx, ha, dsg, mk[3], hb, fs, kOffDZ + 3 * 256);   // enc[4]^T
+        nring::dgrad_layer<128, 16, 0, 8, true>(cx, hb, dsg, mk[2], ha, fs, kOffDZ + 2 * 256);   // enc[3]^T
+        nring::dgrad_layer<136, 16, 0, 8, true>(cx, ha, dsg, mk[1], hb, fs, kOffDZ + 1 * 256);   // enc[2]^T
+        nring::dgrad_layer<144, 16, 0, 8, true>(cx, hb, dsg, mk[0], ha, fs, kOffDZ + 0 * 256);   // enc[1]^T
+    }
+}
+
 }  // namespace bwd
 }  // namespace nfx
 
@@ -173,11 +432,13 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     if (n_pts <= 0) return 0;
     const long long tiles = (n_pts + bwd::kNerfRows - 1) / bwd::kNerfRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    auto k = bwd::nerf_bwd_kernel;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       bwd::kNerfBwdLds);
+    // r03 default: weights through the LDS-DMA ring; NFX_NERF_BWD=0 keeps the register-staged kernel (identity reference)
+    static const bool use_ring = [] { const char* e = getenv("NFX_NERF_BWD"); return !e || atoi(e) != 0; }();
+    auto k = use_ring ? bwd::nerf_bwd_ring_kernel : bwd::nerf_bwd_kernel;
+    const int lds = use_ring ? bwd::nring::kLds : bwd::kNerfBwdLds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(bwd::kNerfNW * 64), bwd::kNerfBwdLds, st, rayo, rayd, z, n_pts, n_samples,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(bwd::kNerfNW * 64), lds, st, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (const float4*)d_rgbs, (__bf16*)wsp, ld);
     return (int)hipGetLastError();
 }

@@ -25,6 +25,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rays', type=int, default=1024)
     ap.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (optim.GraphedTrainStep)')
+    ap.add_argument('--no-update', action='store_true',
+                    help='forward + loss + backward only (kernel experiments whose gradients are garbage must not '
+                         'reach the weights: operand data changes the clock)')
     ap.add_argument('--model', default='nerfactor_microfacet',
                     choices=['nerfactor_microfacet', 'nerfactor', 'shape', 'nerf'])
     args = ap.parse_args()
@@ -57,6 +60,14 @@ def main():
     global_bs = n * world
     step = optim.GraphedTrainStep(model, opt, global_bs) if args.graph else (
         lambda b: optim.train_step(model, b, opt, global_bs))
+    if args.no_update:
+        def step(b):
+            opt.zero_grad()
+            pred, gt, kw, _ = model(b, mode='train')
+            kw['keep_batch'] = True
+            loss = model.compute_loss(pred, gt, **kw).sum() / global_bs
+            loss.backward()
+            return loss.detach(), None
     for _ in range(args.warmup + (3 if args.graph else 0)):
         step(batch)
     torch.cuda.synchronize()
