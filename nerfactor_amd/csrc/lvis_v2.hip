@@ -516,42 +516,49 @@ __device__ __forceinline__ void brdf_row_inputs(const float (&x)[3], const float
     }
 }
 
-// The closed-form geometry of ONE (point, light) row with the values of BOTH lane halves: S[q] is what the half-0 lane
+// The closed-form geometry of ONE (point, light) row (brdf_point_frame + brdf_row_angles) with the values of BOTH lane halves: S[q] is what the half-0 lane
 // of the row's column puts into input slot q (sines, phi_d, theta_h), C[q] what the half-1 lane does (cosines, theta_d;
 // slot 7 of half 1 is z_0, loaded by the caller).  brdf_compact_kernel lets the half-0 lane of column p compute the row
 // of column tile 2k and the half-1 lane the row of tile 2k + 1, and swaps halves with v_permlane32_swap: each lane
 // runs the geometry of CT / 2 rows instead of CT (the two halves used to compute the same row twice).
-__device__ __forceinline__ void brdf_row_geometry(const float (&x)[3], const float (&lp)[3], const float (&cm)[3],
-                                                  const float (&nr)[3], float (&S)[8], float (&C)[8]) {
-    auto nrm = [](float (&v)[3]) {
-        const float inv = __builtin_amdgcn_rsqf(fmaxf(dot3(v, v), 1e-6f));
-        v[0] *= inv; v[1] *= inv; v[2] *= inv;
-    };
-    float ldir[3], vdir[3], rot[9], ll[3], vl[3];
+__device__ __forceinline__ void nrm_rsq(float (&v)[3]) {
+    const float inv = __builtin_amdgcn_rsqf(fmaxf(dot3(v, v), 1e-6f));
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+// The per-POINT half of the row geometry: local frame [t; b; n] of the normal and the view direction in it.  The queue
+// fill computes it once per point and parks it in LDS (r03); brdf_row_angles is what is left per (point, light) row.
+// Same operations in the same order as the per-row form of round 2: the rows come out bit-identical.
+__device__ __forceinline__ void brdf_point_frame(const float (&x)[3], const float (&cm)[3], const float (&nr)[3],
+                                                 float (&rot)[9], float (&vl)[3]) {
+    float vdir[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        ldir[k] = lp[k] - x[k];
-        vdir[k] = cm[k] - x[k];
-    }
-    nrm(ldir);
-    nrm(vdir);
+    for (int k = 0; k < 3; ++k) vdir[k] = cm[k] - x[k];
+    nrm_rsq(vdir);
     float n[3] = {nr[0], nr[1], nr[2]}, t[3], b[3];
-    nrm(n);
+    nrm_rsq(n);
     const float zax[3] = {0.0f + 1e-6f, 0.0f + 1e-6f, 1.0f + 1e-6f};   // geom.py:128
     cross3(n, zax, t);
-    nrm(t);
+    nrm_rsq(t);
     cross3(n, t, b);
-    nrm(b);
+    nrm_rsq(b);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         rot[k] = t[k];
         rot[3 + k] = b[k];
         rot[6 + k] = n[k];
     }
-    mat3_apply(rot, ldir, ll);
     mat3_apply(rot, vdir, vl);
+    nrm_rsq(vl);
+}
+__device__ __forceinline__ void brdf_row_angles(const float (&x)[3], const float (&lp)[3], const float (&rot)[9],
+                                                const float (&vl)[3], float (&S)[8], float (&C)[8]) {
+    auto nrm = [](float (&v)[3]) { nrm_rsq(v); };
+    float ldir[3], ll[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ldir[k] = lp[k] - x[k];
+    nrm(ldir);
+    mat3_apply(rot, ldir, ll);
     nrm(ll);
-    nrm(vl);
     float hv[3] = {(ll[0] + vl[0]) * 0.5f, (ll[1] + vl[1]) * 0.5f, (ll[2] + vl[2]) * 0.5f};
     nrm(hv);
     const float cth = fminf(fmaxf(hv[2], -1.0f), 1.0f);
@@ -610,12 +617,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
     const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
     constexpr int kCap = kRing;
     ring_t* ring = reinterpret_cast<ring_t*>(smem + kLdsNet) + wave * kCap;
+    // per-point table of the wave (kPark): 8 slots (the ring's 3-bit point slot) x 32 floats =
+    //   [x(3) | view dir in the local frame(3) | local frame t, b, n (9) | z_0 | z_1, z_3, .. (8) | z_2, z_4, .. (8)]
+    constexpr bool kPark = GEO == 1 && CT % 2 == 0;
+    float* ptab = reinterpret_cast<float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t) + (a.n_lights * 12 + 15) / 16 * 16)
+                  + wave * (8 * 32);
     const int L = a.n_lights;
     const long long n = a.n;
     const long long nw = (long long)gridDim.x * kNW, gw = (long long)blockIdx.x * kNW + wave;
     constexpr int kPass = CT * 32;
     long long kfill = 0, k_head = 0;   // next point to fill; point of the oldest queued row
     int head = 0, cnt = 0;
+#ifdef NFX_LV2_TIMING
+    // phase cycles of wave 0 of block 7, summed over its passes (scripts/brdf_phases.py): [48] fill, [49] row gathers +
+    // geometry + operand build, [50] the 17 tiles + output, [51] passes
+    unsigned long long ph_fill = 0, ph_geo = 0, ph_net = 0, ph_n = 0, ph_t = __builtin_readcyclecounter();
+#define NFX_PHASE(ACC) { const unsigned long long now_ = __builtin_readcyclecounter(); ACC += now_ - ph_t; ph_t = now_; }
+#else
+#define NFX_PHASE(ACC)
+#endif
     for (;;) {
         // ---- fill: front-lit rows of the next points until a whole pass is queued (ring: kPass - 1 + L <= kRing)
         while (cnt < kPass) {
@@ -630,11 +650,44 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 nr[k] = a.normal[pt * 3 + k];
             }
             world2local(nr, rot);
+            if constexpr (kPark) {
+                float cm[3], prot[9], pvl[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cm[k] = a.cam[pt * 3 + k];
+                brdf_point_frame(x, cm, nr, prot, pvl);
+                const float* zp = a.z + pt * a.z_dim;
+                float zv[17];
+#pragma unroll
+                for (int i = 0; i < 17; ++i) zv[i] = i < a.z_dim ? zp[i] : 0.0f;
+                if (lane == 0) {
+                    f32x4* ps = reinterpret_cast<f32x4*>(ptab + (int)(kfill & 7) * 32);
+                    ps[0] = f32x4{x[0], x[1], x[2], pvl[0]};
+                    ps[1] = f32x4{pvl[1], pvl[2], prot[0], prot[1]};
+                    ps[2] = f32x4{prot[2], prot[3], prot[4], prot[5]};
+                    ps[3] = f32x4{prot[6], prot[7], prot[8], zv[0]};
+                    ps[4] = f32x4{zv[1], zv[3], zv[5], zv[7]};
+                    ps[5] = f32x4{zv[9], zv[11], zv[13], zv[15]};
+                    ps[6] = f32x4{zv[2], zv[4], zv[6], zv[8]};
+                    ps[7] = f32x4{zv[10], zv[12], zv[14], zv[16]};
+                }
+            }
+            // the light of the NEXT 64-group is read while this one is classified (a lone wave has nothing else to
+            // put under an LDS round trip)
+            float lpn[3];
+            {
+                const int lc = lane < L ? lane : L - 1;
+                lpn[0] = lx[lc * 3]; lpn[1] = lx[lc * 3 + 1]; lpn[2] = lx[lc * 3 + 2];
+            }
             for (int l0 = 0; l0 < L; l0 += 64) {
                 const int l = l0 + lane;
                 const bool valid = l < L;
-                const int lc = valid ? l : L - 1;
-                const float lp[3] = {lx[lc * 3], lx[lc * 3 + 1], lx[lc * 3 + 2]};
+                const float lp[3] = {lpn[0], lpn[1], lpn[2]};
+                if (l0 + 64 < L) {
+                    const int ln = l + 64 < L ? l + 64 : L - 1;
+                    lpn[0] = lx[ln * 3]; lpn[1] = lx[ln * 3 + 1]; lpn[2] = lx[ln * 3 + 2];
+                }
+                // (classifying by the sign of n . (light - x) instead — the normalisations are positive scalings — measured
+                // 1 % and flips 1 row in 10^8 where the product rounds to 0: not taken)
                 float ldir[3], ll[3];
                 dir_to(lp, x, ldir);
                 mat3_apply(rot, ldir, ll);
@@ -652,17 +705,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        NFX_PHASE(ph_fill)
         const int rows = cnt < kPass ? cnt : kPass;
         // ---- pass: CT column tiles of 32 queued rows
         bf16x8 pl[2][CT];
         long long orow[CT];
         long long rpt[CT];
-        int rl[CT];
+        int rl[CT], rslot[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int r = c * 32 + p;
             const bool ok = r < rows;
             const unsigned e = ring[ring_wrap(head + (ok ? r : 0), kCap)];
+            rslot[c] = (int)(e >> 10);
             const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);   // slot -> local point index
             rpt[c] = gw + kk * nw;
             rl[c] = (int)(e & 1023u);
@@ -670,21 +725,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         }
         if constexpr (GEO == 1 && CT % 2 == 0) {
             // lane half h runs the geometry of the row of column tile 2k + h; one v_permlane32_swap per input slot
-            // hands each half its own values of both rows (brdf_row_geometry)
+            // hands each half its own values of both rows (brdf_row_angles; the per-point half comes from the table)
 #pragma unroll
             for (int k2 = 0; k2 < CT; k2 += 2) {
-                const long long pt = h ? rpt[k2 + 1] : rpt[k2];
                 const int l = h ? rl[k2 + 1] : rl[k2];
-                float x[3], lp[3], cm[3], nr[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    x[k] = a.xyz[pt * 3 + k];
-                    lp[k] = lx[l * 3 + k];
-                    cm[k] = a.cam[pt * 3 + k];
-                    nr[k] = a.normal[pt * 3 + k];
-                }
+                const f32x4* ps = reinterpret_cast<const f32x4*>(ptab + (h ? rslot[k2 + 1] : rslot[k2]) * 32);
+                const f32x4 q0 = ps[0], q1 = ps[1], q2 = ps[2], q3 = ps[3];
+                const float x[3] = {q0[0], q0[1], q0[2]}, vl[3] = {q0[3], q1[0], q1[1]};
+                const float rot[9] = {q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2]};
+                const float lp[3] = {lx[l * 3], lx[l * 3 + 1], lx[l * 3 + 2]};
                 float S[8], C[8];
-                brdf_row_geometry(x, lp, cm, nr, S, C);
+                brdf_row_angles(x, lp, rot, vl, S, C);
                 float v[2][16];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -699,12 +750,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    const float* zp = a.z + rpt[k2 + cc] * a.z_dim;
-                    if (h) v[cc][7] = zp[0];
+                    // the latent code of the row's point: z_0 (slot 7 of half 1) and this half's z_{1 + 2j + h}
+                    const f32x4* pz = reinterpret_cast<const f32x4*>(ptab + rslot[k2 + cc] * 32);
+                    const f32x4 za = pz[4 + 2 * h], zb = pz[5 + 2 * h];
+                    if (h) v[cc][7] = pz[3][3];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = 1 + 2 * j + h;
-                        v[cc][8 + j] = i < a.z_dim ? zp[i] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        v[cc][8 + j] = za[j];
+                        v[cc][12 + j] = zb[j];
                     }
 #pragma unroll
                     for (int sidx = 0; sidx < 2; ++sidx) {
@@ -740,13 +793,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         bf16x8 ha[8][CT], hb[8][CT];
         Acc<CT> accs[2];
         Pre pre;
+#ifdef NFX_LV2_TIMING
+        asm volatile("" :: "v"(pl[0][0]), "v"(pl[1][CT - 1]));   // the operands exist before the stamp
+        __builtin_amdgcn_sched_barrier(0);
+        NFX_PHASE(ph_geo)
+#endif
         {
             const char* f0 = wlds + lane * 16;
             pre.a[0] = *reinterpret_cast<const bf16x8*>(f0);
             pre.a[1] = *reinterpret_cast<const bf16x8*>(f0 + kFragBytes);
             InitBias{bias_lds}(lane, accs[0]);
         }
+#ifdef NFX_LV2_TIMING
+#define NFX_LV3_STAMP(K) if (blockIdx.x == 7 && tid == 0 && ph_n == 40) nfx_lv2_times[K] = __builtin_readcyclecounter();
+#else
+#define NFX_LV3_STAMP(K)
+#endif
 #define NFX_LV3_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
+        NFX_LV3_STAMP(K) \
         tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
 #define NFX_LV3_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
 #define NFX_LV3_BIAS(OFF) (InitBias{bias_lds + (OFF)})
@@ -767,7 +831,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         NFX_LV3_TILE(14, 8, 2, ha, pl, NFX_LV3_EPI(13, hb, 1), NFX_LV3_BIAS(384 + 96));
         NFX_LV3_TILE(15, 8, 2, ha, pl, NFX_LV3_EPI(14, hb, 2), NFX_LV3_BIAS(512));
         NFX_LV3_TILE(16, 8, 0, hb, pl, NFX_LV3_EPI(15, hb, 3), [](int, Acc<CT>&) {});
+        NFX_LV3_STAMP(17)
 #undef NFX_LV3_TILE
+#undef NFX_LV3_STAMP
 #undef NFX_LV3_EPI
 #undef NFX_LV3_BIAS
         if (h == 0) {
@@ -775,6 +841,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             for (int c = 0; c < CT; ++c)
                 if (orow[c] >= 0) a.out[orow[c]] = softplusf(accs[0].v[c][0]);   // brdf.py:65
         }
+#ifdef NFX_LV2_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        NFX_PHASE(ph_net)
+        ++ph_n;
+#endif
         head = ring_wrap(head + rows, kCap);
         cnt -= rows;
         if (cnt > 0) {
@@ -784,6 +855,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             k_head = kfill;
         }
     }
+#ifdef NFX_LV2_TIMING
+    if (blockIdx.x == 7 && tid == 0) {
+        nfx_lv2_times[48] = ph_fill;
+        nfx_lv2_times[49] = ph_geo;
+        nfx_lv2_times[50] = ph_net;
+        nfx_lv2_times[51] = ph_n;
+    }
+#endif
+#undef NFX_PHASE
 }
 
 }  // namespace lv2
@@ -829,7 +909,8 @@ static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t s
     using namespace nfx;
     const long long want = (a.n + NW - 1) / NW;       // at least one point per wave
     const int grid = (int)(want < max_blocks ? want : max_blocks);
-    const int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t) + (a.n_lights * 12 + 15) / 16 * 16;
+    const int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t) + (a.n_lights * 12 + 15) / 16 * 16 +
+                    NW * 8 * 32 * 4;   // + the per-point tables (8 slots x 128 B per wave)
     if (lds > 160 * 1024) return -1;   // (the caller falls back to the dense kernel)
     auto k = lv2::brdf_compact_kernel<CT, GEO, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
