@@ -223,7 +223,7 @@ int nfx_nerf_pack_train_weights(const float* const kernels[12], const float* con
     return NFX_OK;
 }
 
-static long long nerf_ld(long long n_pts) { return (n_pts + 127) / 128 * 128; }
+static long long nerf_ld(long long n_pts) { return (n_pts + 255) / 256 * 256; }   // whole 256-row tiles (nerf_bwd.hip)
 
 static const int kNerfWgradDims[14][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256},
                                           {256, 256}, {256, 256}, {63, 256}, {256, 1}, {256, 256}, {256, 128},

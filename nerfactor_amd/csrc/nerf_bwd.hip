@@ -179,57 +179,90 @@ namespace nring {
 #ifndef NFX_NRING_D
 #define NFX_NRING_D 5   // fetch distance in chunks (experiments: 2 .. 5; 6 would exceed the 6-bit counter)
 #endif
-constexpr int kSeq = 152, kD = NFX_NRING_D, kR = kD + 1, kSlot = 20 * 1024, kEpiStores = 8;
-constexpr int kLds = kR * kSlot + nerf::kBiasFloats * 4;
-static_assert(kLds <= 160 * 1024, "LDS");
-// chunk i of a tile's sequence: first fragment in the train blob / 1-KiB pieces per wave
+constexpr int kSeq = 152, kD = NFX_NRING_D, kR = kD + 1, kEpiStores = 8;
+// chunk i of a tile's sequence: first fragment in the train blob
 constexpr int off(int i) {
     if (i < 72) return nerf::chunk_frag_offset(i);                 // enc[0..7], bottleneck
     if (i < 76) return nerf::chunk_frag_offset(i + 1);             // rgb_out[0] (the sigma chunk is skipped)
     const int j = i - 76;
     return nerf::kFrags + (j < 4 ? j * 4 : j < 12 ? 16 + (j - 4) * 8 : j < 20 ? 80 + (j - 12) * 20 : 240 + (j - 20) * 16);
 }
-constexpr int pieces(int i) {
-    if (i >= kSeq) return 0;
-    if (i < 8) return 1;
-    if (i < 40) return 4;
-    if (i < 48) return 5;
-    if (i < 72) return 4;
-    if (i < 76) return 5;
-    const int j = i - 76;
-    return j < 4 ? 1 : j < 12 ? 2 : j < 20 ? 5 : 4;
-}
-// what may still be in flight when chunk i + 1 must have landed: the wait sits behind the MFMAs of chunk i and before
-// its epilogue, so the stores of epilogues max(0, i + 1 - kD) .. i - 1 are younger than the fetch of chunk i + 1
-// (i = -1: the wait behind the priming fetches)
-constexpr int allow(int i) {
-    int n = kEpiStores * (i < 0 ? 0 : i < kD - 1 ? i : kD - 1);
-    for (int j = i + 2; j <= i + kD; ++j) n += pieces(j);
-    return n;
-}
-constexpr int max_allow() {
-    int m = 0;
-    for (int i = 0; i < kSeq; ++i) m = allow(i) > m ? allow(i) : m;
-    return m;
-}
-static_assert(max_allow() <= 63, "vmcnt is a 6-bit counter");
 static_assert(off(kSeq - 1) + 16 == nerf::kTrainFrags, "sequence covers the train blob");
+// NW waves per workgroup = NW x 32 rows per tile on one weight stream.  NW = 4: one wave per SIMD.  NW = 8: two per
+// SIMD (<= 256 registers each), half the L2 weight traffic per row, and one wave's epilogue under its partner's MFMAs.
+template <int NW>
+struct Cfg {
+    // 1-KiB pieces per wave (every wave the same number: the wait counts are immediates).  NW = 8 rounds a chunk up to
+    // a multiple of 8 fragments — the blob's own padding, or the first fragments of the next chunk (never past the
+    // blob: the last chunk has 16)
+    static constexpr int pieces(int i) {
+        if (i >= kSeq || i < 0) return 0;
+        const int j = i - 76;
+        const int used = i < 8 ? 4 : i < 40 ? 16 : i < 48 ? 20 : i < 72 ? 16 : i < 76 ? 18
+                       : j < 4 ? 1 : j < 12 ? 8 : j < 20 ? 17 : 16;
+        return (used + NW - 1) / NW;
+    }
+    static constexpr int kSlot = (NW == 4 ? 20 : 24) * 1024;
+    static constexpr int kLds = kR * kSlot + nerf::kBiasFloats * 4;
+    // what may still be in flight when chunk i + 1 must have landed: the wait sits behind the MFMAs of chunk i and
+    // before its epilogue, so the stores of epilogues max(0, i + 1 - kD) .. i - 1 are younger than the fetch of chunk
+    // i + 1 (i = -1: the wait behind the priming fetches)
+    static constexpr int allow(int i) {
+        int n = kEpiStores * (i < 0 ? 0 : i < kD - 1 ? i : kD - 1);
+        for (int j = i + 2; j <= i + kD; ++j) n += pieces(j);
+        return n;
+    }
+    static constexpr int max_allow() {
+        int m = 0;
+        for (int i = 0; i < kSeq; ++i) m = allow(i) > m ? allow(i) : m;
+        return m;
+    }
+    static constexpr int max_pieces() {
+        int m = 0;
+        for (int i = 0; i < kSeq; ++i) m = pieces(i) > m ? pieces(i) : m;
+        return m;
+    }
+    static_assert(kLds <= 160 * 1024, "LDS");
+    static_assert(max_allow() <= 63, "vmcnt is a 6-bit counter");
+    static_assert(max_pieces() * NW * 1024 <= kSlot, "slot");
+};
 
 struct Ctx {
     char* smem;
     unsigned smem_lds;
     const char* blob;
     int lane, wave;   // wave: wave-uniform
+    unsigned bias_addr;   // LDS byte address of bias[4 h]: opaque, so every tile's bias read is this register + an immediate
 };
+// mlp_engine.hpp:bias_init with the tile's offset as an immediate (the compiler otherwise forms the 76 per-tile lane
+// addresses ahead of the loop and spills them: one scratch reload per chunk, each draining the DMA window)
+__device__ __forceinline__ void bias_acc(const Ctx& cx, int off_floats, f32x16& acc) {
+    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<lds_f32x4*>((lds_cchar*)(uintptr_t)cx.bias_addr + (off_floats + 8 * g) * 4);
+        acc[4 * g + 0] = v[0];
+        acc[4 * g + 1] = v[1];
+        acc[4 * g + 2] = v[2];
+        acc[4 * g + 3] = v[3];
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void dma(unsigned lane_off, const char* gbase, unsigned lds_dst) {
     unsigned keep;
-    static_assert(N == 1 || N == 2 || N == 4 || N == 5, "pieces per wave");
+    static_assert(N >= 1 && N <= 5, "pieces per wave");
     // (N = 5: the 13-bit signed offset ends at 4095, so the statement is centred on the third piece)
     if constexpr (N == 1)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
     else if constexpr (N == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
@@ -254,39 +287,39 @@ __device__ __forceinline__ void dma(unsigned lane_off, const char* gbase, unsign
 }
 // fetch chunk F of the sequence into its slot (F % kR; last read by chunk F - kR, whose closing barrier every wave
 // has passed: F is fetched during chunk F - kD = F - kR + 1, or before chunk 0 for the first kD)
-template <int F>
+template <int NW, int F>
 __device__ __forceinline__ void fetch(const Ctx& cx) {
     if constexpr (F < kSeq) {
-        constexpr int n = pieces(F);
+        constexpr int n = Cfg<NW>::pieces(F);
         unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
         unsigned lds = cx.smem_lds;
         asm volatile("" : "+s"(base), "+s"(lds));   // per chunk: keeps the 152 address pairs out of the loop preheader
         const int piece0 = cx.wave * n;
         dma<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)off(F) * 1024 + piece0 * 1024,
-               lds + (unsigned)(F % kR) * kSlot + (unsigned)piece0 * 1024u);
+               lds + (unsigned)(F % kR) * Cfg<NW>::kSlot + (unsigned)piece0 * 1024u);
     }
 }
 // chunk I: acc (initialised by the caller) += W_tile [b1 ; b2]; returns with chunk I + 1 landed and published
-template <int I, int KS1, int KS2, int KS1A, int KS2A>
+template <int NW, int I, int KS1, int KS2, int KS1A, int KS2A>
 __device__ __forceinline__ void chunk(const Ctx& cx, const bf16x8 (&b1)[KS1A][1], const bf16x8 (&b2)[KS2A][1],
                                       f32x16 (&acc)[1]) {
-    fetch<I + kD>(cx);
-    const char* f0 = cx.smem + (I % kR) * kSlot + cx.lane * 16;
+    fetch<NW, I + kD>(cx);
+    const char* f0 = cx.smem + (I % kR) * Cfg<NW>::kSlot + cx.lane * 16;
     mma_k<KS1>(f0, b1, acc);
     if constexpr (KS2 > 0) mma_k<KS2>(f0 + KS1 * kFragBytes, b2, acc);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(allow(I)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Cfg<NW>::allow(I)) : "memory");
 }
 
-template <int I0, int KS1, int KS2, int NT, bool RELU, int KS1A, int KS2A, int NTA>
-__device__ __forceinline__ void fwd_layer(const Ctx& cx, const float* bias, const bf16x8 (&b1)[KS1A][1],
+template <int NW, int I0, int KS1, int KS2, int NT, bool RELU, int KS1A, int KS2A, int NTA>
+__device__ __forceinline__ void fwd_layer(const Ctx& cx, int bias_off, const bf16x8 (&b1)[KS1A][1],
                                           const bf16x8 (&b2)[KS2A][1], bf16x8 (&bout)[NTA][1], const FeatStore& fs,
                                           int feat0, unsigned (&m)[NT / 2]) {
     const int h = cx.lane >> 5;
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
         f32x16 acc[1];
-        bias_init<1>(bias + 32 * t, h, acc);
-        chunk<I0 + t, KS1, KS2>(cx, b1, b2, acc);
+        bias_acc(cx, bias_off + 32 * t, acc[0]);
+        chunk<NW, I0 + t, KS1, KS2>(cx, b1, b2, acc);
         if constexpr (RELU) {
             const unsigned bits = relu_bits16(acc[0]);
             if constexpr (t & 1) m[t >> 1] |= bits << 16;
@@ -297,7 +330,7 @@ __device__ __forceinline__ void fwd_layer(const Ctx& cx, const float* bias, cons
         __builtin_amdgcn_sched_barrier(0);
     });
 }
-template <int I0, int KS1, int KS2, int NT, bool MASK, int KS1A, int KS2A, int NTA>
+template <int NW, int I0, int KS1, int KS2, int NT, bool MASK, int KS1A, int KS2A, int NTA>
 __device__ __forceinline__ void dgrad_layer(const Ctx& cx, const bf16x8 (&dz)[KS1A][1], const bf16x8 (&b2)[KS2A][1],
                                             const unsigned (&m)[NT / 2], bf16x8 (&dout)[NTA][1], const FeatStore& fs,
                                             int feat0) {
@@ -306,7 +339,7 @@ __device__ __forceinline__ void dgrad_layer(const Ctx& cx, const bf16x8 (&dz)[KS
         constexpr int t = decltype(T)::value;
         f32x16 acc[1];
         zero_init<1>(acc);
-        chunk<I0 + t, KS1, KS2>(cx, dz, b2, acc);
+        chunk<NW, I0 + t, KS1, KS2>(cx, dz, b2, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool on = MASK ? mask_bit(m, t, r) : true;
@@ -320,26 +353,29 @@ __device__ __forceinline__ void dgrad_layer(const Ctx& cx, const bf16x8 (&dz)[KS
 }
 }  // namespace nring
 
-__global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_ring_kernel(
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, const float4* __restrict__ d_rgbs, __bf16* __restrict__ wsp,
     long long ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
-    constexpr int NW = kNerfNW;
+    constexpr int kRows = NW * 32;
+    using RC = nring::Cfg<NW>;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* bias_lds = reinterpret_cast<float*>(smem + nring::kR * nring::kSlot);
+    float* bias_lds = reinterpret_cast<float*>(smem + nring::kR * RC::kSlot);
     {
         const float* bsrc = reinterpret_cast<const float*>(blob + kTrainWeightBytes);
         for (int i = tid; i < kBiasFloats; i += NW * 64) bias_lds[i] = bsrc[i];
         __syncthreads();
     }
     typedef __attribute__((address_space(3))) char lds_char;
-    const nring::Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave};
-    const long long n_tiles = (n_pts + kNerfRows - 1) / kNerfRows;
+    nring::Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave, 0u};
+    cx.bias_addr = (unsigned)(uintptr_t)(lds_char*)smem + (unsigned)(nring::kR * RC::kSlot) + 16u * (unsigned)h;
+    const long long n_tiles = (n_pts + kRows - 1) / kRows;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long row = tile * kNerfRows + wave * 32 + p;  // < ld (ld is a multiple of kNerfRows)
+        const long long row = tile * kRows + wave * 32 + p;  // < ld (ld is a multiple of 256)
         FeatStore fs;
         {
             unsigned long long ld2 = (unsigned long long)ld * 2, b = reinterpret_cast<unsigned long long>(wsp);
@@ -390,35 +426,36 @@ __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_ring_kernel(
             dzo[0][0] = __builtin_bit_cast(bf16x8, w0);
             dsg[0][0] = __builtin_bit_cast(bf16x8, w1);
         }
+        asm volatile("" : "+v"(cx.bias_addr));
         __builtin_amdgcn_sched_barrier(0);
-        static_for<0, nring::kD>([&](auto F) { nring::fetch<decltype(F)::value>(cx); });
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(nring::allow(-1)) : "memory");   // chunk 0 landed
+        static_for<0, nring::kD>([&](auto F) { nring::fetch<NW, decltype(F)::value>(cx); });
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RC::allow(-1)) : "memory");   // chunk 0 landed
         // ------------------------------------------------------------------ forward (re-computed)
         unsigned mk[8][4], mr[2], mnone[4];
         bf16x8 ha[16][1], hb[16][1];
-        nring::fwd_layer<0, 4, 0, 8, true>(cx, bias_lds + kBiasL0, pe, pe, ha, fs, kOffA + 0 * 256, mk[0]);
-        nring::fwd_layer<8, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 1, ha, pe, hb, fs, kOffA + 1 * 256, mk[1]);
-        nring::fwd_layer<16, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 2, hb, pe, ha, fs, kOffA + 2 * 256, mk[2]);
-        nring::fwd_layer<24, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 3, ha, pe, hb, fs, kOffA + 3 * 256, mk[3]);
-        nring::fwd_layer<32, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 4, hb, pe, ha, fs, kOffA + 4 * 256, mk[4]);
-        nring::fwd_layer<40, 16, 4, 8, true>(cx, bias_lds + kBiasL0 + 256 * 5, ha, pe, hb, fs, kOffA + 5 * 256, mk[5]);
-        nring::fwd_layer<48, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 6, hb, pe, ha, fs, kOffA + 6 * 256, mk[6]);
-        nring::fwd_layer<56, 16, 0, 8, true>(cx, bias_lds + kBiasL0 + 256 * 7, ha, pe, hb, fs, kOffA + 7 * 256, mk[7]);
-        nring::fwd_layer<64, 16, 0, 8, false>(cx, bias_lds + kBiasBott, hb, pe, ha, fs, kOffBott, mnone);  // bottleneck
+        nring::fwd_layer<NW, 0, 4, 0, 8, true>(cx, kBiasL0, pe, pe, ha, fs, kOffA + 0 * 256, mk[0]);
+        nring::fwd_layer<NW, 8, 16, 0, 8, true>(cx, kBiasL0 + 256 * 1, ha, pe, hb, fs, kOffA + 1 * 256, mk[1]);
+        nring::fwd_layer<NW, 16, 16, 0, 8, true>(cx, kBiasL0 + 256 * 2, hb, pe, ha, fs, kOffA + 2 * 256, mk[2]);
+        nring::fwd_layer<NW, 24, 16, 0, 8, true>(cx, kBiasL0 + 256 * 3, ha, pe, hb, fs, kOffA + 3 * 256, mk[3]);
+        nring::fwd_layer<NW, 32, 16, 0, 8, true>(cx, kBiasL0 + 256 * 4, hb, pe, ha, fs, kOffA + 4 * 256, mk[4]);
+        nring::fwd_layer<NW, 40, 16, 4, 8, true>(cx, kBiasL0 + 256 * 5, ha, pe, hb, fs, kOffA + 5 * 256, mk[5]);
+        nring::fwd_layer<NW, 48, 16, 0, 8, true>(cx, kBiasL0 + 256 * 6, hb, pe, ha, fs, kOffA + 6 * 256, mk[6]);
+        nring::fwd_layer<NW, 56, 16, 0, 8, true>(cx, kBiasL0 + 256 * 7, ha, pe, hb, fs, kOffA + 7 * 256, mk[7]);
+        nring::fwd_layer<NW, 64, 16, 0, 8, false>(cx, kBiasBott, hb, pe, ha, fs, kOffBott, mnone);  // bottleneck
         bf16x8 r0[8][1];
-        nring::fwd_layer<72, 16, 2, 4, true>(cx, bias_lds + kBiasRgb0, ha, pv, r0, fs, kOffR0, mr);
+        nring::fwd_layer<NW, 72, 16, 2, 4, true>(cx, kBiasRgb0, ha, pv, r0, fs, kOffR0, mr);
         // ------------------------------------------------------------------ dgrad chain
         bf16x8 dr0[8][1];
-        nring::dgrad_layer<76, 1, 0, 4, true>(cx, dzo, dzo, mr, dr0, fs, kOffDR0);               // D1: rgb_out[1]^T
-        nring::dgrad_layer<80, 8, 0, 8, false>(cx, dr0, dzo, mnone, ha, fs, kOffDBott);          // D2: into the bottleneck
-        nring::dgrad_layer<88, 16, 1, 8, true>(cx, ha, dsg, mk[7], hb, fs, kOffDZ + 7 * 256);    // D3: [bott | sigma]^T
-        nring::dgrad_layer<96, 16, 0, 8, true>(cx, hb, dsg, mk[6], ha, fs, kOffDZ + 6 * 256);    // enc[7]^T
-        nring::dgrad_layer<104, 16, 0, 8, true>(cx, ha, dsg, mk[5], hb, fs, kOffDZ + 5 * 256);   // enc[6]^T
-        nring::dgrad_layer<112, 16, 0, 8, true>(cx, hb, dsg, mk[4], ha, fs, kOffDZ + 4 * 256);   // enc[5][:256]^T
-        nring::dgrad_layer<120, 16, 0, 8, true>(cx, ha, dsg, mk[3], hb, fs, kOffDZ + 3 * 256);   // enc[4]^T
-        nring::dgrad_layer<128, 16, 0, 8, true>(cx, hb, dsg, mk[2], ha, fs, kOffDZ + 2 * 256);   // enc[3]^T
-        nring::dgrad_layer<136, 16, 0, 8, true>(cx, ha, dsg, mk[1], hb, fs, kOffDZ + 1 * 256);   // enc[2]^T
-        nring::dgrad_layer<144, 16, 0, 8, true>(cx, hb, dsg, mk[0], ha, fs, kOffDZ + 0 * 256);   // enc[1]^T
+        nring::dgrad_layer<NW, 76, 1, 0, 4, true>(cx, dzo, dzo, mr, dr0, fs, kOffDR0);               // D1: rgb_out[1]^T
+        nring::dgrad_layer<NW, 80, 8, 0, 8, false>(cx, dr0, dzo, mnone, ha, fs, kOffDBott);          // D2: into the bottleneck
+        nring::dgrad_layer<NW, 88, 16, 1, 8, true>(cx, ha, dsg, mk[7], hb, fs, kOffDZ + 7 * 256);    // D3: [bott | sigma]^T
+        nring::dgrad_layer<NW, 96, 16, 0, 8, true>(cx, hb, dsg, mk[6], ha, fs, kOffDZ + 6 * 256);    // enc[7]^T
+        nring::dgrad_layer<NW, 104, 16, 0, 8, true>(cx, ha, dsg, mk[5], hb, fs, kOffDZ + 5 * 256);   // enc[6]^T
+        nring::dgrad_layer<NW, 112, 16, 0, 8, true>(cx, hb, dsg, mk[4], ha, fs, kOffDZ + 4 * 256);   // enc[5][:256]^T
+        nring::dgrad_layer<NW, 120, 16, 0, 8, true>(cx, ha, dsg, mk[3], hb, fs, kOffDZ + 3 * 256);   // enc[4]^T
+        nring::dgrad_layer<NW, 128, 16, 0, 8, true>(cx, hb, dsg, mk[2], ha, fs, kOffDZ + 2 * 256);   // enc[3]^T
+        nring::dgrad_layer<NW, 136, 16, 0, 8, true>(cx, ha, dsg, mk[1], hb, fs, kOffDZ + 1 * 256);   // enc[2]^T
+        nring::dgrad_layer<NW, 144, 16, 0, 8, true>(cx, hb, dsg, mk[0], ha, fs, kOffDZ + 0 * 256);   // enc[1]^T
     }
 }
 
@@ -434,11 +471,15 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     // r03 default: weights through the LDS-DMA ring; NFX_NERF_BWD=0 keeps the register-staged kernel (identity reference)
     static const bool use_ring = [] { const char* e = getenv("NFX_NERF_BWD"); return !e || atoi(e) != 0; }();
-    auto k = use_ring ? bwd::nerf_bwd_ring_kernel : bwd::nerf_bwd_kernel;
-    const int lds = use_ring ? bwd::nring::kLds : bwd::kNerfBwdLds;
+    static const int ring_nw = [] { const char* e = getenv("NFX_NERF_BWD_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
+    auto k = !use_ring ? bwd::nerf_bwd_kernel : ring_nw == 8 ? bwd::nerf_bwd_ring_kernel<8> : bwd::nerf_bwd_ring_kernel<4>;
+    const int nw = use_ring ? ring_nw : bwd::kNerfNW;
+    const int lds = !use_ring ? bwd::kNerfBwdLds : ring_nw == 8 ? bwd::nring::Cfg<8>::kLds : bwd::nring::Cfg<4>::kLds;
+    const long long tiles_nw = (n_pts + nw * 32 - 1) / (nw * 32);
+    const int grid_nw = (int)(tiles_nw < max_blocks ? tiles_nw : max_blocks);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(bwd::kNerfNW * 64), lds, st, rayo, rayd, z, n_pts, n_samples,
+    hipLaunchKernelGGL(k, dim3(grid_nw), dim3(nw * 64), lds, st, rayo, rayd, z, n_pts, n_samples,
                        (const char*)blob, (const float4*)d_rgbs, (__bf16*)wsp, ld);
     return (int)hipGetLastError();
 }
