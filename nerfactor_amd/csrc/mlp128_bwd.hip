@@ -465,6 +465,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_ring_kernel(
 }  // namespace bwd
 }  // namespace nfx
 
+extern "C" int nfx_env_int(const char* name, int dflt);   // capi.cpp
+
 extern "C" {
 int nfx_launch_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, long long n, float xyz_scale,
                           const float* lxyz, int n_lights, const void* blob, int out_dim, int out_act,
@@ -475,7 +477,7 @@ int nfx_launch_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, l
     const long long rows = in_kind == 0 ? n : n * n_lights;
     const long long tiles = (rows + bwd::kRows - 1) / bwd::kRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    static const bool use_ring = [] { const char* e = getenv("NFX_M128_BWD"); return !e || atoi(e) != 0; }();
+    const bool use_ring = nfx_env_int("NFX_M128_BWD", 1) != 0;   // (per call, like every knob: INTEGRATION.md)
     if (use_ring) {   // r03 default: dgrad weights resident in LDS, forward weights through a DMA ring
         const int rl = bwd::ring::kLds;
         auto launch = [&](auto k) {

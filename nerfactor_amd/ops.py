@@ -184,6 +184,10 @@ def scatter_rows(src, row_of, n_all=None):
     for k in src.shape[1:]:
         d *= int(k)
     out = torch.empty((n_all,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n_all == 0 or d == 0:   # e.g. [n, 0, 3]: a render with no light probes
+        return out
+    if src.shape[0] == 0:      # no foreground row at all
+        return out.zero_()
     check(lib.nfx_scatter_rows(_ptr(src), ctypes.c_void_p(row_of.data_ptr()), n_all, d, _ptr(out), _stream()),
           'nfx_scatter_rows')
     return out

@@ -550,7 +550,8 @@ def test_all_finite_kernel(nfx_lib, cuda):
 @pytest.mark.parametrize("shape", [(1000, 512), (777, 3), (640, 9, 3), (33, 1), (5, 6)])
 def test_scatter_rows_is_tf_scatter_nd_of_the_foreground_rows(nfx_lib, cuda, shape):
     """nfx_scatter_rows against zeros + index_put_ (the reference's tf.scatter_nd, nerfactor.py:295-306): bit-equal, every
-    output element written (the output buffer is pre-filled with NaN by the allocator trick below)."""
+    output element written (the output buffer is pre-filled with NaN by the allocator trick below).  [n, 0, 3] is what a
+    test render without light probes scatters (the drivers' tests found it), [0, d] a view without foreground."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(4)
     n_all = shape[0] * 2 + 7

@@ -841,6 +841,49 @@ def test_whole_step_gradients_are_bit_reproducible(nfx_lib, cuda, name):
     assert float(model._light.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("name,n", [("nerf", 37), ("nerf", 1024), ("nerfactor_microfacet", 300), ("shape", 37)])
+def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, monkeypatch, name, n):
+    """The r03 backward kernels (weights through an LDS-DMA ring with hand-counted vmcnt waits; NeRF: 4 or 8 waves per
+    workgroup) run the same MFMAs on the same operands as the register-staged kernels of rounds 1-2: every gradient of
+    a whole step is bit-identical.  A wait that is one count too generous shows up here as a changed bit."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(11)
+    extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if 'nerfactor' in name else {}
+    cfg = make_config(name, **extra)
+    model = get_model_class(name)(cfg).to(cuda)
+    opt = optim.make_optimizer(model, cfg)
+    rng = np.random.default_rng(12)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    xyz = t(rng.uniform(-1, 1, size=(n, 3)))
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    if name == 'nerf':
+        batch = (None, None, cam, xyz - cam, t(rng.uniform(size=(n, 3))))
+    else:
+        batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
+                 mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz,
+                 torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1), t(rng.uniform(size=(n, 512))))
+
+    def grads(**env):
+        for k in ('NFX_NERF_BWD', 'NFX_NERF_BWD_NW', 'NFX_M128_BWD'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(13)   # the NeRF step draws its stratified samples and noise
+        opt.zero_grad()
+        pred, gt, kw, _ = model(batch, mode='train')
+        (model.compute_loss(pred, gt, keep_batch=True, **kw).sum() / n).backward()
+        return opt.bucket.flat.clone()
+
+    ref = grads(NFX_NERF_BWD='0', NFX_M128_BWD='0')
+    assert float(ref.abs().max()) > 0
+    assert torch.equal(grads(), ref)                                     # the defaults: rings, NeRF with 8 waves
+    if name == 'nerf':
+        assert torch.equal(grads(NFX_NERF_BWD_NW='4'), ref)
+
+
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor", "nerf", "shape"])
 def test_precision_fp32_trains(nfx_lib, cuda, name):
     """`precision = fp32` (the reference computes in fp32, trainvali.py:110-127): the forward runs the fp32-class kernels
