@@ -547,7 +547,7 @@ def test_all_finite_kernel(nfx_lib, cuda):
     assert bool(ops.all_finite(torch.full((70,), 3.4e38, device=cuda)))          # the largest finite float
 
 
-@pytest.mark.parametrize("shape", [(1000, 512), (777, 3), (640, 9, 3), (33, 1), (5, 6)])
+@pytest.mark.parametrize("shape", [(1000, 512), (777, 3), (640, 9, 3), (33, 1), (5, 6), (40, 0, 3), (0, 5)])
 def test_scatter_rows_is_tf_scatter_nd_of_the_foreground_rows(nfx_lib, cuda, shape):
     """nfx_scatter_rows against zeros + index_put_ (the reference's tf.scatter_nd, nerfactor.py:295-306): bit-equal, every
     output element written (the output buffer is pre-filled with NaN by the allocator trick below).  [n, 0, 3] is what a
