@@ -274,13 +274,16 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
                               "brdf_spec_fwd(fp32)");
     // NFX_BRDF_VARIANT: 0 / 2 / 3 / 4 as NFX_LVIS_VARIANT (every row evaluated, back-lit rows zeroed afterwards);
     // 5 = front-lit rows only (LDS row queue per wave), per-row geometry as in the dense kernels (bit-identical);
-    // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT = column tiles per wave of variants 5 / 6
-    // (2 | 3 | 4, default 4; always one wave per SIMD — the two-waves-per-SIMD form is not deterministic, lvis_v2.hip).
+    // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT of variants 5 / 6: 8 (default) = 8 waves x 2
+    // column tiles, two waves per SIMD (up to 640 lights); 2 | 3 | 4 column tiles per wave, one wave per SIMD.
     int variant = nfx_env_int("NFX_BRDF_VARIANT", 6);
     if (variant >= 5) {
-        const int rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
-                                               nfx_env_int("NFX_BRDF_CT", 4), variant == 6,
-                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
+        const int ct = nfx_env_int("NFX_BRDF_CT", 8);
+        int rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, ct, variant == 6,
+                                         nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
+        if (rc == -1 && ct == 8)   // more lights than the 8-wave row queues hold: the 4-wave form
+            rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, 4, variant == 6,
+                                         nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
         if (rc != -1) return nfx_hip_result(rc, "brdf_spec_fwd(v3)");
         variant = 3;   // shape outside the row queue's limits: dense kernel
     }

@@ -391,9 +391,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
 // ring of queued rows per wave: 1024 entries of 16 bits = (point slot << 10) | light, point slot = local point index
 // mod 8 (a pass decodes it against the index of the newest filled point; the fill loop never lets the queue span 8
 // points).  2 KiB per wave: 8 waves (two per SIMD) fit next to the network.
+#ifndef NFX_BRDF_SWAP
+#define NFX_BRDF_SWAP 1   // 1 ds_bpermute (default) | 0 __builtin_amdgcn_permlane32_swap | 2 hand-timed asm: brdf_compact_kernel's header
+#endif
 constexpr int kRing = 1024;
 typedef unsigned short ring_t;
-static_assert(kLdsNet + 8 * kRing * (int)sizeof(ring_t) <= 160 * 1024, "ring area");
+// queue geometry per wave: ring entries and point slots.  4 waves: 1024 entries, 8 slots.  8 waves (experiment form):
+// 704 entries (>= 64 - 1 + 512 lights), 4 slots — what fits beside the network, the lights and the point tables
+template <int NW> struct Queue {
+    static constexpr int kCap = NW == 8 ? 704 : kRing, kSlots = NW == 8 ? 4 : 8;
+    static constexpr int lds_bytes(int n_lights) {
+        return kLdsNet + NW * kCap * (int)sizeof(ring_t) + (n_lights * 12 + 15) / 16 * 16 + NW * kSlots * 32 * 4;
+    }
+};
 __device__ __forceinline__ int ring_wrap(int i, int cap) { return i >= cap ? i - cap : i; }   // i < 2 cap
 
 __device__ __forceinline__ float acos_poly(float x) {   // Abramowitz-Stegun 4.4.46, |err| <= 2e-8 + fp32 rounding
@@ -585,16 +595,17 @@ __device__ __forceinline__ void brdf_row_angles(const float (&x)[3], const float
     C[6] = theta_d; C[7] = 0.0f;
 }
 
-// NW = 4: one wave per SIMD (CT = 2 | 3 | 4) — the only shipped form.
-// NW = 8, CT = 2 (two waves per SIMD: one wave's fill / Rusinkiewicz VALU under its partner's MFMAs) measured 5.7-6.1
-// ms against 6.5 ms per 200 000 x 512 rows, but is NOT deterministic on MI355X: a few thousand of 10^8 rows come out
-// wrong, in groups of 16 lanes of the second column tile, run to run different.  Everything a wave touches is private
-// to it (registers, its ring, its points); the same tile code with two waves per SIMD is bit-stable in
-// resident128_kernel<2, 0, 8> (10^10 rows, scripts/experiments/soak_lvis8.py), whose partner wave never streams
-// gathers.  32 idle cycles before each tile's first accumulator read cut the failures 100 x, one LDS read group per
-// column tile raises them 10 x (profiles/r02/brdf_8wave_race/): a result-latency margin the compiler's fixed wait
-// states do not cover once a partner wave's VMEM / LDS returns compete for the register file.  Compiled only with
-// -DNFX_EXPERIMENT_BRDF_NW8 (NFX_BRDF_CT=8), for scripts/experiments/diag_brdf*.py.
+// NW = 8, CT = 2 (default since r03): two waves per SIMD — one wave's queue fill and Rusinkiewicz VALU run under its
+//   partner's MFMAs.  NW = 4 (CT = 2 | 3 | 4): one wave per SIMD, the shipped form of round 2.
+// Round 2 measured the 8-wave form faster but NOT deterministic (a few thousand of 10^8 rows wrong, in groups of 16
+// lanes of the second column tile, different from run to run) and did not find out why.  Round 3 did: the exchange of
+// the two lane halves' geometry by v_permlane32_swap_b32.  With a partner wave on the SIMD the swap reads operands a
+// VALU instruction wrote two wait states earlier before they have landed — with the hand-placed `s_nop 1` of rounds
+// 1-2 (NFX_BRDF_SWAP=2: 11 000 rows of 10^8 wrong per call) AND with the compiler's own
+// __builtin_amdgcn_permlane32_swap, whose hazard recogniser places the same two wait states (NFX_BRDF_SWAP=0: 2 200
+// rows).  Through ds_bpermute (NFX_BRDF_SWAP=1, the default: the LDS crossbar, counted by lgkmcnt) the 8-wave kernel is
+// bit-identical to the 4-wave one on every call (scripts/brdf_nw8_soak.py).  One wave per SIMD never showed the fault
+// (10^10 rows in round 2), but the shipped form does not depend on those wait states any more.
 template <int CT, int GEO, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
     constexpr int kNW = NW;
@@ -608,20 +619,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         for (int i = tid; i < kLdsNet / 16; i += kNW * 64) dst[i] = src[i];
         // the light positions too (<= 12 KiB): the queue fill classifies all of them for every point, and a pass
         // gathers one per row — LDS reads instead of global loads with a vmcnt(0) per 64 lights
-        float* ldst = reinterpret_cast<float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t));
+        float* ldst = reinterpret_cast<float*>(smem + kLdsNet + kNW * Queue<NW>::kCap * (int)sizeof(ring_t));
         for (int i = tid; i < 3 * a.n_lights; i += kNW * 64) ldst[i] = a.lxyz[i];
         __syncthreads();
     }
-    const float* lx = reinterpret_cast<const float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t));
+    const float* lx = reinterpret_cast<const float*>(smem + kLdsNet + kNW * Queue<NW>::kCap * (int)sizeof(ring_t));
     const char* wlds = smem;
     const float* bias_lds = reinterpret_cast<const float*>(smem + kMainWeightBytes);
-    constexpr int kCap = kRing;
+    constexpr int kCap = Queue<NW>::kCap, kSlots = Queue<NW>::kSlots;
     ring_t* ring = reinterpret_cast<ring_t*>(smem + kLdsNet) + wave * kCap;
     // per-point table of the wave (kPark): 8 slots (the ring's 3-bit point slot) x 32 floats =
     //   [x(3) | view dir in the local frame(3) | local frame t, b, n (9) | z_0 | z_1, z_3, .. (8) | z_2, z_4, .. (8)]
     constexpr bool kPark = GEO == 1 && CT % 2 == 0;
-    float* ptab = reinterpret_cast<float*>(smem + kLdsNet + kNW * kRing * (int)sizeof(ring_t) + (a.n_lights * 12 + 15) / 16 * 16)
-                  + wave * (8 * 32);
+    float* ptab = reinterpret_cast<float*>(smem + kLdsNet + kNW * kCap * (int)sizeof(ring_t) + (a.n_lights * 12 + 15) / 16 * 16)
+                  + wave * (kSlots * 32);
     const int L = a.n_lights;
     const long long n = a.n;
     const long long nw = (long long)gridDim.x * kNW, gw = (long long)blockIdx.x * kNW + wave;
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         while (cnt < kPass) {
             const long long pt = gw + kfill * nw;
             if (pt >= n) break;
-            if (cnt > 0 && kfill - k_head >= 7) break;   // the queue may span at most 8 points (3-bit point slot)
+            if (cnt > 0 && kfill - k_head >= kSlots - 1) break;   // the queue may span at most kSlots points (point slot)
             // the point's position and normal: wave-uniform scalar loads (a partner wave's MFMAs cover their latency)
             float x[3], nr[3], rot[9];
 #pragma unroll
@@ -660,7 +671,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
 #pragma unroll
                 for (int i = 0; i < 17; ++i) zv[i] = i < a.z_dim ? zp[i] : 0.0f;
                 if (lane == 0) {
-                    f32x4* ps = reinterpret_cast<f32x4*>(ptab + (int)(kfill & 7) * 32);
+                    f32x4* ps = reinterpret_cast<f32x4*>(ptab + (int)(kfill & (kSlots - 1)) * 32);
                     ps[0] = f32x4{x[0], x[1], x[2], pvl[0]};
                     ps[1] = f32x4{pvl[1], pvl[2], prot[0], prot[1]};
                     ps[2] = f32x4{prot[2], prot[3], prot[4], prot[5]};
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 const unsigned long long mask = __ballot(fr);
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (fr) ring[ring_wrap(head + cnt + pos, kCap)] = (ring_t)(((kfill & 7) << 10) | l);
+                if (fr) ring[ring_wrap(head + cnt + pos, kCap)] = (ring_t)(((kfill & (kSlots - 1)) << 10) | l);
                 else if (valid) a.out[pt * L + l] = 0.0f;                 // scatter_nd's zeros
                 cnt += __popcll(mask);
             }
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             const bool ok = r < rows;
             const unsigned e = ring[ring_wrap(head + (ok ? r : 0), kCap)];
             rslot[c] = (int)(e >> 10);
-            const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);   // slot -> local point index
+            const long long kk = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & (kSlots - 1));   // slot -> local point index
             rpt[c] = gw + kk * nw;
             rl[c] = (int)(e & 1023u);
             orow[c] = ok ? rpt[c] * L + rl[c] : -1;
@@ -743,8 +754,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                     //   first  = [S(row 2k) ; C(row 2k)]     = slot q of column tile 2k for both halves
                     //   second = [S(row 2k+1) ; C(row 2k+1)] = slot q of column tile 2k + 1
                     float first = S[q], second = C[q];
-                    // (s_nop 1: the two wait states a VALU write of either operand needs before the swap reads it)
+#if NFX_BRDF_SWAP == 1      // the exchange through ds_bpermute (LDS crossbar, counted by lgkmcnt)
+                    const float recv = __shfl_xor(h ? first : second, 32, 64);
+                    first = h ? recv : first;
+                    second = h ? second : recv;
+#elif NFX_BRDF_SWAP == 2    // rounds 1-2: hand-timed wait states — WRONG with a partner wave on the SIMD (see the kernel's header)
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(first), "+v"(second));
+#else                       // the compiler's own v_permlane32_swap (its hazard recogniser places the wait states)
+                    {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(first), __float_as_uint(second), false, false);
+                        first = __uint_as_float(sw[0]);
+                        second = __uint_as_float(sw[1]);
+                    }
+#endif
                     v[0][q] = first;
                     v[1][q] = second;
                 }
@@ -850,7 +872,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         cnt -= rows;
         if (cnt > 0) {
             const unsigned e = ring[head];
-            k_head = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & 7);
+            k_head = (kfill - 1) - (((kfill - 1) - (long long)(e >> 10)) & (kSlots - 1));
         } else {
             k_head = kfill;
         }
@@ -909,8 +931,8 @@ static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t s
     using namespace nfx;
     const long long want = (a.n + NW - 1) / NW;       // at least one point per wave
     const int grid = (int)(want < max_blocks ? want : max_blocks);
-    const int lds = lv2::kLdsNet + NW * lv2::kRing * (int)sizeof(lv2::ring_t) + (a.n_lights * 12 + 15) / 16 * 16 +
-                    NW * 8 * 32 * 4;   // + the per-point tables (8 slots x 128 B per wave)
+    const int lds = lv2::Queue<NW>::lds_bytes(a.n_lights);   // network + row rings + lights + per-point tables
+    if (CT * 32 - 1 + a.n_lights > lv2::Queue<NW>::kCap) return -1;
     if (lds > 160 * 1024) return -1;   // (the caller falls back to the dense kernel)
     auto k = lv2::brdf_compact_kernel<CT, GEO, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -920,18 +942,16 @@ static int launch_compact(const nfx::lv2::Args& a, int max_blocks, hipStream_t s
 }
 
 // Front-lit compaction (brdf_compact_kernel).  geo: 0 = reference op sequence per row, 1 = closed-form Rusinkiewicz.
-// ct: 2 | 3 | 4 column tiles per wave, one wave per SIMD (anything else: 4).
+// ct: 8 = 8 waves x 2 column tiles (two waves per SIMD); 2 | 3 | 4 column tiles per wave, one wave per SIMD (anything else: 4).
 // Returns -1 when the shape does not fit the row queue (the caller falls back to the dense kernel).
 extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const float* normal, const float* z,
                                        int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
                                        float* spec, int ct, int geo, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
     const int tiles = ct == 8 ? 2 : ct;
-    if (n_lights > 1024 || tiles * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;
+    if (n_lights > 1024 || tiles * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;   // (launch_compact checks its own ring)
     nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
-#ifdef NFX_EXPERIMENT_BRDF_NW8
     if (ct == 8) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 8>(a, max_blocks, st);
-#endif
     if (ct == 2) return geo ? launch_compact<2, 1, 4>(a, max_blocks, st) : launch_compact<2, 0, 4>(a, max_blocks, st);
     if (ct == 3) return geo ? launch_compact<3, 1, 4>(a, max_blocks, st) : launch_compact<3, 0, 4>(a, max_blocks, st);
     return geo ? launch_compact<4, 1, 4>(a, max_blocks, st) : launch_compact<4, 0, 4>(a, max_blocks, st);

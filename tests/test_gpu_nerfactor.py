@@ -452,7 +452,7 @@ def test_row_mlp_kernel_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     for v in ("2", "3", "4", "5"):   # 5 = front-lit compaction with the same per-row arithmetic
         assert torch.equal(outs["0"], outs[v]), "brdf variant " + v
     monkeypatch.setenv("NFX_BRDF_VARIANT", "5")
-    for ct in ("3", "2", "4"):     # column tiles per wave (always one wave per SIMD)
+    for ct in ("3", "2", "4", "8"):     # column tiles per wave, one wave per SIMD; 8 = eight waves x 2 tiles, two per SIMD
         monkeypatch.setenv("NFX_BRDF_CT", ct)
         assert torch.equal(outs["0"], ops.brdf_spec_fwd(dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda),
                                                         dev(z, cuda), dev(lxyz, cuda), blob)), ct
@@ -494,6 +494,14 @@ def test_brdf_spec_default_is_deterministic_at_scale(nfx_lib, cuda, monkeypatch)
     first = ops.brdf_spec_fwd(*args)
     for _ in range(3):
         assert torch.equal(first, ops.brdf_spec_fwd(*args))
+    # the default runs two waves per SIMD (r03).  That form was non-deterministic in round 2 — v_permlane32_swap reads
+    # stale operands when a partner wave shares the SIMD (lvis_v2.hip) — and now exchanges the lane halves through
+    # ds_bpermute: every launch equals the one-wave-per-SIMD kernel bit for bit
+    monkeypatch.setenv("NFX_BRDF_CT", "4")
+    one_wave = ops.brdf_spec_fwd(*args)
+    monkeypatch.delenv("NFX_BRDF_CT")
+    for _ in range(5):
+        assert torch.equal(one_wave, ops.brdf_spec_fwd(*args))
     monkeypatch.setenv("NFX_BRDF_VARIANT", "3")
     dense = ops.brdf_spec_fwd(*args)
     assert torch.equal(dense > 0, first > 0)
