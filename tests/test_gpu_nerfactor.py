@@ -101,11 +101,13 @@ def test_lvis_vs_oracle(nfx_lib, cuda, n, nl_h):
 
 
 @pytest.mark.parametrize("zd,variant,n,nl_h", [(3, "6", 50, 16), (1, "6", 50, 16), (3, "5", 50, 16), (3, "3", 50, 16),
-                                               (3, "6", 1, 16), (3, "6", 700, 4), (2, "6", 1500, 16), (3, "5", 1027, 8)])
+                                               (3, "6", 1, 16), (3, "6", 700, 4), (2, "6", 1500, 16), (3, "5", 1027, 8),
+                                               (3, "6", 300, 20)])
 def test_brdf_spec_vs_oracle(nfx_lib, cuda, monkeypatch, zd, variant, n, nl_h):
     """Learned-BRDF specular term: dense kernel (3), front-lit compaction with the reference's per-row op sequence
     (5) and with closed-form Rusinkiewicz angles (6, the default) against the oracle; point counts below / above the
-    number of waves of the grid (1024) and light counts that leave the last ballot half empty."""
+    number of waves of the grid (1024 / 2048), light counts that leave the last ballot half empty, and 800 lights — more
+    than the row queues of the default two-waves-per-SIMD form hold, so the one-wave-per-SIMD form runs."""
     from nerfactor_amd import ops
     monkeypatch.setenv("NFX_BRDF_VARIANT", variant)
     layers, out = net128(40 + zd, zd + 15, 1)
