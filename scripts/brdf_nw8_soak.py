@@ -1,7 +1,9 @@
-"""Soak of the two-waves-per-SIMD form of brdf_compact_kernel (experiment build: -DNFX_EXPERIMENT_BRDF_NW8, NFX_BRDF_CT=8)
-against the shipped 4-wave kernel: REPS calls of 200 000 x 512 rows, every output compared bit for bit on the device.
-Round 2 found this form non-deterministic (a few thousand of 10^8 rows wrong per call) while a pass still gathered its
-rows' inputs from global memory; since round 3 a pass reads LDS only."""
+"""Soak of the two-waves-per-SIMD form of brdf_compact_kernel (NFX_BRDF_CT=8, the default since round 3) against the
+one-wave-per-SIMD form (NFX_BRDF_CT=4): REPS calls of 200 000 x 512 rows, every output compared bit for bit on the device.
+Round 2 found the 8-wave form non-deterministic (a few thousand of 10^8 rows wrong per call); round 3 traced it to
+v_permlane32_swap (lvis_v2.hip, brdf_compact_kernel's header).  To reproduce the fault build the library with
+-DNFX_BRDF_SWAP=0 (the compiler's builtin swap) or =2 (the hand-timed asm of rounds 1-2) and point NFX_LIB_PATH at it:
+    bash scripts/build_obj_variant.sh lvis_v2.hip swap0 -DNFX_BRDF_SWAP=0 -mllvm -amdgpu-mfma-vgpr-form"""
 import os
 import sys
 import time
