@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "geom.hpp"
+#include "lds_dma.hpp"
 #include "mlp128_layout.hpp"
 #include "mlp_engine.hpp"
 #include "feat_store.hpp"
@@ -234,20 +235,6 @@ struct Ctx {
     int lane, wave;   // wave: wave-uniform
     int cur;          // ring slot of the sub-chunk being consumed (wave-uniform)
 };
-template <int N>
-__device__ __forceinline__ void dma(unsigned lane_off, const char* gbase, unsigned lds_dst) {
-    unsigned keep;
-    static_assert(N == 1 || N == 2, "pieces per wave");
-    if constexpr (N == 1)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-}
 // start of sub-chunk K: fetch sub-chunk K + kD into the slot kD ahead (last read kR - kD = 1 sub-chunk ago: every wave
 // has passed the barrier that ended it)
 template <int KSX, int K>
@@ -259,7 +246,7 @@ __device__ __forceinline__ void begin(const Ctx& cx) {
     int slot = cx.cur + kD;
     slot = slot >= kR ? slot - kR : slot;
     const int piece0 = cx.wave * n;
-    dma<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX>::off(F) * 1024 + piece0 * 1024,
+    lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX>::off(F) * 1024 + piece0 * 1024,
            lds + (unsigned)slot * kSlot + (unsigned)piece0 * 1024u);
 }
 template <int KSX, int K>

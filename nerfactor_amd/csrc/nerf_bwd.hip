@@ -10,6 +10,7 @@
 // Sample positions carry no gradient (z_fine is under stop_gradient, nerf.py:145; rays are data).
 #include <cstdlib>
 #include "feat_store.hpp"
+#include "lds_dma.hpp"
 #include "nerf_train_layout.hpp"
 
 namespace nfx {
@@ -249,42 +250,6 @@ __device__ __forceinline__ void bias_acc(const Ctx& cx, int off_floats, f32x16& 
     }
 }
 
-template <int N>
-__device__ __forceinline__ void dma(unsigned lane_off, const char* gbase, unsigned lds_dst) {
-    unsigned keep;
-    static_assert(N >= 1 && N <= 5, "pieces per wave");
-    // (N = 5: the 13-bit signed offset ends at 4095, so the statement is centred on the third piece)
-    if constexpr (N == 1)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else if constexpr (N == 3)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else if constexpr (N == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else if constexpr (N == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase + 2048), "s"(lds_dst + 2048) : "memory");
-}
 // fetch chunk F of the sequence into its slot (F % kR; last read by chunk F - kR, whose closing barrier every wave
 // has passed: F is fetched during chunk F - kD = F - kR + 1, or before chunk 0 for the first kD)
 template <int NW, int F>
@@ -295,7 +260,7 @@ __device__ __forceinline__ void fetch(const Ctx& cx) {
         unsigned lds = cx.smem_lds;
         asm volatile("" : "+s"(base), "+s"(lds));   // per chunk: keeps the 152 address pairs out of the loop preheader
         const int piece0 = cx.wave * n;
-        dma<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)off(F) * 1024 + piece0 * 1024,
+        lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)off(F) * 1024 + piece0 * 1024,
                lds + (unsigned)(F % kR) * Cfg<NW>::kSlot + (unsigned)piece0 * 1024u);
     }
 }

@@ -20,6 +20,7 @@
 // section 2 has the numbers; what remains switchable is the timing build (NFX_V6_TIMING) and the ablation masks
 // (NFX_ABLATION_BUILD).
 #include "mlp_engine.hpp"
+#include "lds_dma.hpp"
 #include "nerf_layout.hpp"
 
 #ifdef NFX_V6_TIMING
@@ -184,36 +185,6 @@ struct Ctx {
 // 298 pieces per pass instead of 318.
 constexpr int used_frags(int k) { return k < 8 ? 4 : k < 40 ? 16 : k < 48 ? 20 : k < 73 ? 16 : k < 77 ? 18 : 8; }
 constexpr int dma_pieces(int k) { return (used_frags(k) + kNW - 1) / kNW; }   // 1-KiB pieces per wave: 1 | 4 | 5 | 2
-template <int N>
-__device__ __forceinline__ void dma_pieces_asm(unsigned lane_off, const char* gbase, unsigned lds_dst) {
-    unsigned keep;
-    static_assert(N == 1 || N == 2 || N == 4 || N == 5, "piece count");
-    // (N = 5: the 13-bit signed offset reaches 4095, so the statement is centred on the third piece)
-    if constexpr (N == 1)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else if constexpr (N == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else if constexpr (N == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_off), "s"(gbase + 2048), "s"(lds_dst + 2048) : "memory");
-}
 template <int K>
 __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
     constexpr int n = dma_pieces(K);
@@ -223,7 +194,7 @@ __device__ __forceinline__ void dma_chunk(const Ctx& cx) {
     const int piece0 = cx.wave * n;
     const char* g = reinterpret_cast<const char*>(base) + (size_t)nerf::chunk_frag_offset(K) * kFragBytes + piece0 * 1024;
     const unsigned l = lds + (K % 6) * kSlotBytes + piece0 * 1024;
-    dma_pieces_asm<n>((cx.tid & 63) * 16, g, l);
+    lds_dma_pieces<n>((cx.tid & 63) * 16, g, l);
 }
 // Tile K (global chunk index).  On entry `acc` holds the tile's bias and `pre` its first three A fragments; on exit
 // `acc_next` / `pre` hold the same for tile K+1 (bias from `next_bias`).  AB: timing-only ablation mask
