@@ -48,3 +48,108 @@ def test_the_model_catches_the_known_bad_configurations():
     assert any(v[0] == 'RAW' for v in violations(ring=6, dist=3, landed_after=2))
     # a ring as small as the fetch distance can never work
     assert violations(ring=4, dist=4, landed_after=2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The NeRF backward's weight ring (nerf_bwd.hip, namespace nring): hand-counted `s_waitcnt vmcnt` on gfx9, where loads
+# AND stores retire through one in-order counter.  The model replays one wave's VMEM instruction stream for one row tile
+# and checks that every wait (a) forces the chunk it is there for to have landed, (b) leaves everything in flight that
+# it may — it is exact, not merely safe — and (c) that the 6-bit counter is never asked to hold more than 63.
+# ----------------------------------------------------------------------------------------------------------------------
+import os
+import re
+
+N_SEQ, EPI_STORES = 152, 8
+
+
+def nring_used(i):
+    """fragments chunk i of the tile's sequence needs (nerf_bwd.hip:Cfg::pieces; nerf_train_layout.hpp)"""
+    j = i - 76
+    return (4 if i < 8 else 16 if i < 40 else 20 if i < 48 else 16 if i < 72 else 18 if i < 76
+            else 1 if j < 4 else 8 if j < 12 else 17 if j < 20 else 16)
+
+
+def nring_pieces(i, nw):
+    return 0 if i < 0 or i >= N_SEQ else -(-nring_used(i) // nw)
+
+
+def nring_allow(i, nw, d):
+    n = EPI_STORES * (0 if i < 0 else min(i, d - 1))
+    return n + sum(nring_pieces(j, nw) for j in range(i + 2, i + d + 1))
+
+
+def replay_nring(nw, d, allow=nring_allow):
+    """-> (problems, max counter value).  The stream of one wave: priming fetches, then per chunk
+    [fetch chunk i + d] [MFMAs] [wait] [barrier] [8 epilogue stores]."""
+    stream, problems, peak = [], [], 0          # stream: ('dma', chunk) | ('st', chunk), oldest first; retired ones removed
+
+    def wait(k, must_have_landed, where):
+        nonlocal stream
+        if len(stream) > k:
+            stream = stream[len(stream) - k:]    # in-order counter: only the k youngest may still be in flight
+        if any(op == ('dma', must_have_landed) for op in stream):
+            problems.append(('chunk %d may not have landed' % must_have_landed, where))
+
+    def issue(op, n):
+        nonlocal peak
+        stream.extend([op] * n)
+        peak = max(peak, len(stream))
+
+    for f in range(d):
+        issue(('dma', f), nring_pieces(f, nw))
+    wait(allow(-1, nw, d), 0, 'priming')
+    for i in range(N_SEQ):
+        issue(('dma', i + d), nring_pieces(i + d, nw))
+        before = list(stream)
+        k = allow(i, nw, d)
+        if i + 1 < N_SEQ:
+            wait(k, i + 1, 'chunk %d' % i)
+            # exactness: one more retired instruction than necessary would be a stall the schedule does not need
+            need = [op for op in before if op == ('dma', i + 1)]
+            if need and len(before) > k and before[len(before) - k - 1] != ('dma', i + 1):
+                problems.append(('wait behind chunk %d retires more than chunk %d' % (i, i + 1), k))
+        issue(('st', i), EPI_STORES)
+    return problems, peak
+
+
+@pytest.mark.parametrize('nw', [4, 8])
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+def test_nerf_backward_ring_waits_are_exact_and_fit_the_counter(nw, d):
+    problems, peak = replay_nring(nw, d)
+    assert problems == []
+    # the most the counter would hold if nothing retired before a wait forces it to.  The shipped form (8 waves) stays
+    # below the 6-bit limit everywhere; with 4 waves and a distance of 5 the enc[5] / rgb_out[0] / D3 regions (5 pieces
+    # per chunk) reach 52 allowed + 8 stores + 5 pieces = 65: there the hardware holds the wave's next VMEM issue until
+    # two older instructions have retired — a possible stall, never a miscount (the waits stay exact)
+    assert peak <= 63 or (nw, d, peak) == (4, 5, 65), peak
+    # slot reuse: chunk F goes to slot F % (d + 1) while chunk F - d is consumed; the slot's previous occupant F - d - 1
+    # was last read one chunk earlier, and that chunk's closing barrier lies in between
+    for f in range(d + 1, N_SEQ):
+        assert f - (d + 1) < f - d
+
+
+def test_nerf_backward_ring_model_catches_a_miscounted_wait():
+    # one store too many allowed in flight: the chunk the wait is there for may still be on its way
+    loose = lambda i, nw, d: nring_allow(i, nw, d) + 1
+    assert replay_nring(4, 5, allow=loose)[0]
+    # one too few: safe, but no longer exact
+    tight = lambda i, nw, d: max(nring_allow(i, nw, d) - 1, 0)
+    assert any('retires more' in p[0] for p in replay_nring(8, 5, allow=tight)[0])
+    # a fetch distance of 6 does not fit the 6-bit counter with 4 waves (the static_assert of Cfg<4>)
+    assert replay_nring(4, 6)[1] > 63
+
+
+def test_nerf_backward_ring_model_is_the_kernel_source():
+    """The constants restated above are the ones in nerf_bwd.hip (a changed kernel must change this model)."""
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'nerfactor_amd', 'csrc', 'nerf_bwd.hip')).read()
+    assert re.search(r'kSeq = 152, kD = NFX_NRING_D, kR = kD \+ 1, kEpiStores = 8;', src)
+    assert '#define NFX_NRING_D 5' in src
+    assert ('const int used = i < 8 ? 4 : i < 40 ? 16 : i < 48 ? 20 : i < 72 ? 16 : i < 76 ? 18' in src
+            and ': j < 4 ? 1 : j < 12 ? 8 : j < 20 ? 17 : 16;' in src)
+    assert 'int n = kEpiStores * (i < 0 ? 0 : i < kD - 1 ? i : kD - 1);' in src
+    assert 'for (int j = i + 2; j <= i + kD; ++j) n += pieces(j);' in src
+    # eight dword stores per epilogue: feat_store.hpp:store_tile issues two st32 per even j < 8
+    fs = open(os.path.join(os.path.dirname(__file__), '..', 'nerfactor_amd', 'csrc', 'feat_store.hpp')).read()
+    body = fs[fs.index('void store_tile('):]
+    body = body[:body.index('\n}\n')]
+    assert 'for (int j = 0; j < 8; j += 2)' in body and body.count('st32(') == 2
