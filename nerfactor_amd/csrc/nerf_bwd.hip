@@ -170,12 +170,15 @@ __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_kernel(
 // Round 3: the same arithmetic with the weight stream on an LDS-DMA ring.
 // The kernel above gives a chunk ONE chunk time to arrive (register-staged double buffer) and, because gfx9 counts loads
 // and stores in one in-order `vmcnt`, every wait for a staged chunk is also a wait for the 8 activation stores issued
-// before it: each of the 152 chunks of a 128-row tile paid a store round trip (≈4400 cycles per chunk against 1024
-// cycles of MFMA work).  Here chunk i + 5 is fetched by `global_load_lds_dwordx4` while chunk i is consumed (6 slots of
-// 20 KiB) and the wait behind chunk i names exactly what may still be in flight: the pieces of chunks i + 2 .. i + 5
-// and the 8 stores of each of the last four epilogues (<= 52 of the counter's 63).  Chunks the backward does not use
-// (sigma_out, rgb_out[1] forward tiles) are not fetched at all.  Same MFMA order and operands as the kernel above
-// (scripts/grad_identity.py: bit-identical workspace and gradients).
+// before it.  Here chunk i + 5 is fetched by `global_load_lds_dwordx4` (lds_dma.hpp) while chunk i is consumed — 6 slots
+// of 20 KiB (4 waves) or 24 KiB (8 waves) — and the wait behind chunk i names exactly what may still be in flight: the
+// pieces of chunks i + 2 .. i + 5 and the 8 stores of each of the last four epilogues (<= 52 / 44 of the counter's 63;
+// tests/test_cpu_ring_protocol.py replays the stream).  Chunks the backward does not use (sigma_out, rgb_out[1] forward
+// tiles) are not fetched at all.  Same MFMA order and operands as the kernel above: bit-identical workspace and
+// gradients (scripts/grad_identity.py, tests/test_gpu_train.py::test_ring_backward_kernels_equal_the_register_staged_ones).
+// What the measurements of the round say bounds it: not the fetch distance but the 64 requests a CU's
+// L1 keeps in flight towards L2 — hence non-temporal activation stores (feat_store.hpp: the weights stay in L2) and
+// 8 waves per weight fetch.
 namespace nring {
 #ifndef NFX_NRING_D
 #define NFX_NRING_D 5   // fetch distance in chunks (experiments: 2 .. 5; 6 would exceed the 6-bit counter)
