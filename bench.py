@@ -204,7 +204,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is the
     # committed digest of the same workload at N = 1 (scripts/gpu_pmc.sh -> scripts/pmc_digest.py): FETCH_SIZE x 2
     # (gfx950 correction) + WRITE_SIZE, per launch pair of a whole 640 000-ray view.
-    variant = os.environ.get("NFX_NERF_VARIANT", "7")
+    variant = str(ops._capi.get_option("nerf_variant") or 7)
     # digest = average over the coarse and the fine dispatch; a launch pair = both
     fp32 = args.precision == 'fp32'
     traffic, traffic_source = committed_traffic('nerf_mlp', scale=2) if n_local == H * W and variant == "7" and not fp32 \
@@ -424,7 +424,7 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                                         if args.precision == 'fp32' else
                                         "lvis_pre_kernel + %s (light visibility, %%d x 512 rows)" % {
                 "8": "resident128_kernel<2, 0, 8>", "4": "resident128_kernel<4, 0, 4>"}.get(
-                    os.environ.get("NFX_LVIS_VARIANT", "8"), "variant " + os.environ.get("NFX_LVIS_VARIANT", "8")))
+                    str(ops._capi.get_option("lvis_variant") or 8), "variant %s" % ops._capi.get_option("lvis_variant")))
                                        % int(fg_per_call),
             "achieved": lvis_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": lvis_tf / PEAK_BF16_TFLOPS,
             "avg_launch_ms": lvis_s * 1e3, "flop_per_launch": fg_per_call * N_LIGHTS * 2 * LVIS_MAC,
@@ -522,18 +522,32 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     global_bs = n * world
     steps = min(args.steps * TRAIN_STEPS_PER_BENCH_STEP, TRAIN_STEPS_MAX)
     bwd_names = ['nerf_mlp_bwd'] if name == 'nerf' else ['mlp128_bwd']
-    losses = []
+    losses, errors = [], []
     with KernelTimer(ops, bwd_names) as kt:
         def step(k):
             kt.on = k is not None
-            loss, _ = optim.train_step(model, batch, opt, global_bs)
+            try:
+                loss, _ = optim.train_step(model, batch, opt, global_bs)
+            except FloatingPointError as e:
+                # check_numerics verdicts are raised by train_step's FIRST statement (flush_numerics), before any
+                # collective of the step, and only on the rank that saw the non-finite tensor.  Leaving the loop here
+                # would strand the other ranks in this step's all_reduce: record it, run the step, and let
+                # all ranks agree on the failure after the timed region.
+                errors.append(str(e))
+                loss, _ = optim.train_step(model, batch, opt, global_bs)
             if k is not None:
                 losses.append(loss)
             return loss
         elapsed, _ = timed(step, steps, max(3, args.warmup), barrier)
         kt.on = False
     elapsed = max_over_ranks(elapsed)
-    model.flush_numerics(block=True)
+    try:
+        model.flush_numerics(block=True)
+    except FloatingPointError as e:
+        errors.append(str(e))
+    if max_over_ranks(1. if errors else 0.) > 0:      # collective: every rank leaves the leg together
+        return {"error": "check_numerics raised during the timed steps on at least one rank%s" % (
+            ": " + errors[0] if errors else " (not this one)")}
     losses = torch.stack(losses).cpu().numpy()
     assert np.isfinite(losses).all(), "non-finite training loss in the timed steps"
     dt = elapsed / steps
@@ -668,10 +682,8 @@ def main():
     train = {}
     if 'train' in legs and args.precision == 'bf16':
         for name in (m for m in args.train_models.split(',') if m):
-            try:
-                train[name] = train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
-            except FloatingPointError as e:   # tf.debugging.check_numerics semantics: reported, the other legs still count
-                train[name] = {"error": "check_numerics raised during the timed steps: %s" % e}
+            # (a check_numerics failure comes back as {"error": ...}, agreed on by all ranks inside the leg)
+            train[name] = train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
     olat = olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'olat' in legs else None
     if rank == 0:
         out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,

@@ -23,8 +23,8 @@
  *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd, and the
  *     geometry pair nfx_nerf_pack_geom_weights / nfx_nerf_sigma_fwd / nfx_nerf_sigma_grad; the
  *     training-blob and backward entry points return NFX_ENOSUP for it.
- *   - re-entrant: no global mutable state; concurrent calls on different streams
- *     are legal.
+ *   - re-entrant: no global mutable state besides the option table of nfx_set_option
+ *     (atomic integers); concurrent calls on different streams are legal.
  */
 #ifndef NFX_H_
 #define NFX_H_
@@ -34,6 +34,14 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+
+/* Exported symbols: the library is built with -fvisibility=hidden; exactly the functions declared here with NFX_API
+ * are visible to the dynamic linker (tests/test_cpu_capi_exports.py compares `nm -D` with this header). */
+#if defined(__GNUC__)
+#define NFX_API __attribute__((visibility("default")))
+#else
+#define NFX_API
 #endif
 
 #define NFX_OK 0
@@ -50,9 +58,21 @@ extern "C" {
 #define NFX_ACT_SIGMOID 2
 #define NFX_ACT_SOFTPLUS 3
 
-int nfx_version(void);
+NFX_API int nfx_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */
-int nfx_last_error(char *buf, size_t len);
+NFX_API int nfx_last_error(char *buf, size_t len);
+
+/* Process-wide integer options: kernel-variant selectors kept for A/B measurements and the identity tests, and the
+ * persistent-grid sizes.  The library reads NO environment variable; a host sets what it wants before the calls it
+ * should affect (set / unset are atomic, but not ordered against calls in flight on other threads).  Keys:
+ *   nerf_variant (7)  nerf_blocks (256)  m128_blocks (256)  lvis_variant (8)  brdf_variant (6)  brdf_ct (4)
+ *   nerf_bwd (1)  nerf_bwd_nw (8)  m128_bwd (1)  wgrad_lds / wgrad_slabs / wgrad_narrow (by row count)
+ *   wgrad_fused (1)
+ * (defaults in parentheses; every variant of a selector computes the same function, most of them bit-identically —
+ * DESIGN.md).  An unknown key is NFX_EINVAL.  nfx_unset_option returns a key to its default. */
+NFX_API int nfx_set_option(const char *key, int value);
+NFX_API int nfx_unset_option(const char *key);
+NFX_API int nfx_get_option(const char *key, int *value, int *is_set);
 
 /* ------------------------------------------------------------------------ */
 /* Weight packing (host side, no GPU needed).                                */
@@ -68,8 +88,8 @@ int nfx_last_error(char *buf, size_t len);
  * bottleneck Dense(256); rgb_out Dense(128, relu) -> Dense(3).
  * kernels[i]/biases[i], i = 0..7 enc layers, 8 sigma_out, 9 bottleneck,
  * 10 rgb_out[0], 11 rgb_out[1].  n_freqs_xyz = 10, n_freqs_view = 4.        */
-size_t nfx_nerf_packed_bytes(int prec);
-int nfx_nerf_pack_weights(const float *const kernels[12], const float *const biases[12],
+NFX_API size_t nfx_nerf_packed_bytes(int prec);
+NFX_API int nfx_nerf_pack_weights(const float *const kernels[12], const float *const biases[12],
                           int prec, void *blob, size_t blob_bytes);
 
 /* Width-128 surface MLP of nerfactor/models/shape.py:79-94 and
@@ -84,8 +104,8 @@ int nfx_nerf_pack_weights(const float *const kernels[12], const float *const bia
 #define NFX_IN_XYZ 0
 #define NFX_IN_XYZ_LDIR 1
 #define NFX_IN_Z_RUSINK 2
-size_t nfx_mlp128_packed_bytes(int in_kind, int z_dim, int out_dim, int prec);
-int nfx_mlp128_pack_weights(const float *const kernels[5], const float *const biases[5],
+NFX_API size_t nfx_mlp128_packed_bytes(int in_kind, int z_dim, int out_dim, int prec);
+NFX_API int nfx_mlp128_pack_weights(const float *const kernels[5], const float *const biases[5],
                             int in_kind, int z_dim, int out_dim, int prec, void *blob,
                             size_t blob_bytes);
 
@@ -95,29 +115,29 @@ int nfx_mlp128_pack_weights(const float *const kernels[5], const float *const bi
 
 /* rayd <- rayd * rsqrt(max(sum(rayd^2), eps))   (nerf.py:157, tf.linalg.l2_normalize,
  * eps = 1e-12; shape.py:131,140 use eps = 1e-6 via util/math.py:63-64).      */
-int nfx_l2_normalize3(const float *dev_in, float *dev_out, int64_t n, float eps, void *stream);
+NFX_API int nfx_l2_normalize3(const float *dev_in, float *dev_out, int64_t n, float eps, void *stream);
 
 /* tf.debugging.check_numerics (nerfactor.py:205-233, shape.py:222-232, ...) in one pass: ORs 1 into *dev_flag (an
  * int32 the caller zeroed) if any of the n floats is Inf or NaN.  dev_x must be 16-byte aligned.               */
-int nfx_any_nonfinite(const float *dev_x, int64_t n, int *dev_flag, void *stream);
+NFX_API int nfx_any_nonfinite(const float *dev_x, int64_t n, int *dev_flag, void *stream);
 
 /* tf.scatter_nd of the alpha > 0 rows into a zero tensor (nerfactor.py:295-306, shape.py:171-176) in one pass:
  * dev_dst[i, :] = dev_src[dev_row_of[i], :] where dev_row_of[i] >= 0, zeros elsewhere.  dev_src [m, d], dev_row_of
  * [n_all] int32 (compact row of every full row, or -1), dev_dst [n_all, d].  Every output element is written.  */
-int nfx_scatter_rows(const float *dev_src, const int32_t *dev_row_of, int64_t n_all, int d, float *dev_dst,
+NFX_API int nfx_scatter_rows(const float *dev_src, const int32_t *dev_row_of, int64_t n_all, int d, float *dev_dst,
                      void *stream);
 
 /* Stratified depths, Model.gen_z (nerf.py:120-136).  z [n_rays, n_samples].
  * dev_u: NULL (no perturbation) or uniform [0,1) randoms [n_rays, n_samples]
  * drawn by the caller (the reference draws them with tf.random.uniform).     */
-int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp,
+NFX_API int nfx_gen_z(float near, float far, int n_samples, int64_t n_rays, int lin_in_disp,
               const float *dev_u, float *dev_z, void *stream);
 
 /* Fused point generation + positional encoding + NeRF MLP,
  * Model._eval_nerf_at (nerf.py:256-290) with pts = rayo + rayd * z (nerf.py:162-164)
  * and views = rayd never materialised.  rayd must already be normalised.
  * out: rgbs [n_rays, n_samples, 4] = (raw rgb, raw sigma) exactly as nerf.py:282. */
-int nfx_nerf_mlp_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z,
+NFX_API int nfx_nerf_mlp_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z,
                      int64_t n_rays, int n_samples, const void *dev_blob, int prec,
                      float *dev_rgbs, void *stream);
 
@@ -126,7 +146,7 @@ int nfx_nerf_mlp_fwd(const float *dev_rayo, const float *dev_rayd, const float *
  * dev_noise: NULL or N(0,1)*noise_std already scaled, [n_rays, n_samples].
  * Outputs (any may be NULL): rgb [n,3] (already blended onto bg = white_bg ? 1 : 0),
  * occu [n], depth [n], disp [n], weights [n, n_samples].                     */
-int nfx_composite_fwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
+NFX_API int nfx_composite_fwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
                       const float *dev_noise, int64_t n_rays, int n_samples, int white_bg,
                       float *dev_rgb, float *dev_occu, float *dev_depth, float *dev_disp,
                       float *dev_weights, void *stream);
@@ -136,7 +156,7 @@ int nfx_composite_fwd(const float *dev_rgbs, const float *dev_z, const float *de
  * searchsorted(side='right'), lerp, then sort(concat(z_coarse, z_fine)).
  * dev_u: NULL => deterministic u = linspace(0,1,n_fine); else [n_rays, n_fine].
  * out: z_all [n_rays, n_coarse + n_fine] ascending.                          */
-int nfx_sample_fine(const float *dev_z, const float *dev_weights, int64_t n_rays, int n_coarse,
+NFX_API int nfx_sample_fine(const float *dev_z, const float *dev_weights, int64_t n_rays, int n_coarse,
                     int n_fine, const float *dev_u, float *dev_z_all, void *stream);
 
 /* ------------------------------------------------------------------------ */
@@ -146,7 +166,7 @@ int nfx_sample_fine(const float *dev_z, const float *dev_weights, int64_t n_rays
 /* Width-128 MLP on posenc10(xyz_scale * xyz): _pred_normal_at (shape.py:196-211),
  * _pred_albedo_at (nerfactor.py:377-396), _pred_brdf_at (nerfactor.py:398-411).
  * out [n, out_dim] = post_scale * act(out(mlp(pe))) + post_bias.             */
-int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const void *dev_blob,
+NFX_API int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const void *dev_blob,
                        int out_dim, int out_act, float post_scale, float post_bias, int prec,
                        float *dev_out, void *stream);
 
@@ -158,8 +178,8 @@ int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale, const v
  * un-jittered ones: nerfactor.py:195,226.)  dev_lxyz [n_lights, 3].  out [n, n_lights].   */
 /* The posenc(xyz) rows of layers 0 and 3 are evaluated once per point into a caller-provided
  * workspace of nfx_lvis_workspace_bytes(n) bytes (16-byte aligned); n_lights % 32 == 0.      */
-size_t nfx_lvis_workspace_bytes(int64_t n);
-int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
+NFX_API size_t nfx_lvis_workspace_bytes(int64_t n);
+NFX_API int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
                  const float *dev_lxyz, int n_lights, const void *dev_blob, int prec,
                  void *dev_workspace, size_t workspace_bytes, float *dev_lvis, void *stream);
 
@@ -175,8 +195,8 @@ int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, floa
  * relighting loops of nerfactor.py:348-364 become the n_probes axis.
  * out rgb [n, n_probes, 3].                                                  */
 /* Dynamic LDS the shading kernels need for a given sphere / probe count (must be <= 160 KiB). */
-size_t nfx_shade_lds_bytes(int n_lights, int n_probes);
-int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+NFX_API size_t nfx_shade_lds_bytes(int n_lights, int n_probes);
+NFX_API int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
                   const float *dev_lareas, const float *dev_lights, int64_t n, int n_lights,
@@ -184,7 +204,7 @@ int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_n
 
 /* One-light-at-a-time relighting (nerfactor.py:79-84,348-354): light_l = inten*onehot(l)+ambient.
  * out rgb_olat [n, n_lights, 3].                                             */
-int nfx_shade_olat_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+NFX_API int nfx_shade_olat_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                        const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                        float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
                        const float *dev_lareas, float olat_inten, float ambient, int64_t n,
@@ -194,12 +214,12 @@ int nfx_shade_olat_fwd(const float *dev_xyz, const float *dev_cam, const float *
  * gen_world2local (util/geom.py:119-149), dir2rusink (util/geom.py:152-192),
  * frozen BRDF MLP (models/brdf.py:57-66) on [z, pe2(rusink)], softplus;
  * 0 for back-lit (local l.z <= 0) directions.  out spec [n, n_lights].       */
-int nfx_brdf_spec_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+NFX_API int nfx_brdf_spec_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                       const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
                       const void *dev_blob, int prec, int64_t n, float *dev_spec, void *stream);
 
 /* Rusinkiewicz coordinates (phi_d, theta_h, theta_d), util/geom.py:152-192. a,b [n,3]. */
-int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev_rusink,
+NFX_API int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev_rusink,
                    void *stream);
 
 /* ------------------------------------------------------------------------ */
@@ -213,11 +233,11 @@ int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev
  * rows = n (NFX_IN_XYZ) or n * n_lights (NFX_IN_XYZ_LDIR, row = point * n_lights + light).
  * The forward is re-computed inside; `blob` is the TRAIN blob (forward + dgrad fragments).
  * Workspace: nfx_mlp128_bwd_workspace_bytes() bytes, 16-byte aligned.  No input gradients.    */
-size_t nfx_mlp128_train_packed_bytes(int in_kind);
-int nfx_mlp128_pack_train_weights(const float *const kernels[5], const float *const biases[5],
+NFX_API size_t nfx_mlp128_train_packed_bytes(int in_kind);
+NFX_API int nfx_mlp128_pack_train_weights(const float *const kernels[5], const float *const biases[5],
                                   int in_kind, int out_dim, int prec, void *blob, size_t blob_bytes);
-size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights);
-int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, int64_t n,
+NFX_API size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights);
+NFX_API int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, int64_t n,
                    float xyz_scale, const float *dev_lxyz, int n_lights, const void *dev_blob,
                    int out_dim, int out_act, float post_scale, const float *dev_dout,
                    void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
@@ -227,7 +247,7 @@ int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, 
  * dLoss/d rgb (the composited, background-blended colour), writes dev_d_rgbs [n_rays, S, 4] = dLoss/d rgbs
  * (sigmoid and relu derivatives applied).  Same rgbs / z / rayd / noise / white_bg as the forward call.  Sample
  * positions carry no gradient (nerf.py:145).  16-byte aligned rgbs / d_rgbs.                                  */
-int nfx_composite_bwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
+NFX_API int nfx_composite_bwd(const float *dev_rgbs, const float *dev_z, const float *dev_rayd,
                       const float *dev_noise, int64_t n_rays, int n_samples, int white_bg,
                       const float *dev_d_rgb, float *dev_d_rgbs, void *stream);
 
@@ -236,11 +256,11 @@ int nfx_composite_bwd(const float *dev_rgbs, const float *dev_z, const float *de
  * dev_dkernels[i] ([in, out] fp32) / dev_dbiases[i].  The forward is re-computed inside; `blob` is the TRAIN
  * blob (forward + dgrad fragments).  Workspace: nfx_nerf_bwd_workspace_bytes() bytes (feature-major bf16
  * activations and pre-activation gradients, ~10 KB per sample point), 16-byte aligned.  No input gradients. */
-size_t nfx_nerf_train_packed_bytes(int prec);
-int nfx_nerf_pack_train_weights(const float *const kernels[12], const float *const biases[12],
+NFX_API size_t nfx_nerf_train_packed_bytes(int prec);
+NFX_API int nfx_nerf_pack_train_weights(const float *const kernels[12], const float *const biases[12],
                                 int prec, void *blob, size_t blob_bytes);
-size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples);
-int nfx_nerf_mlp_bwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+NFX_API size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples);
+NFX_API int nfx_nerf_mlp_bwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
                      int n_samples, const void *dev_blob, int prec, const float *dev_d_rgbs,
                      void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[12],
                      float *const dev_dbiases[12], void *stream);
@@ -250,11 +270,11 @@ int nfx_nerf_mlp_bwd(const float *dev_rayo, const float *dev_rayd, const float *
  * them).  The sums over a point's lights are taken in 64-bit fixed point inside `dev_workspace`
  * (nfx_brdf_spec_bwd_workspace_bytes(z_dim, n), 8-byte aligned): independent of the order the waves arrive in, hence
  * bit-reproducible.  `blob` is the BRDF train blob (nfx_brdf_train_packed_bytes / nfx_brdf_pack_train_weights).  */
-size_t nfx_brdf_train_packed_bytes(void);
-int nfx_brdf_pack_train_weights(const float *const kernels[5], const float *const biases[5],
+NFX_API size_t nfx_brdf_train_packed_bytes(void);
+NFX_API int nfx_brdf_pack_train_weights(const float *const kernels[5], const float *const biases[5],
                                 int z_dim, int prec, void *blob, size_t blob_bytes);
-size_t nfx_brdf_spec_bwd_workspace_bytes(int z_dim, int64_t n);
-int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+NFX_API size_t nfx_brdf_spec_bwd_workspace_bytes(int z_dim, int64_t n);
+NFX_API int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                       const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
                       const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
                       float *dev_d_z, float *dev_d_normal, void *dev_workspace, size_t workspace_bytes,
@@ -268,10 +288,10 @@ int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const float *d
  *   nfx_brdf_rows_fwd: dev_out[rows] = softplus(out(mlp([z, posenc2(rusink)]))).
  *   nfx_brdf_rows_bwd: given dev_dout[rows] = dLoss/d out, WRITES dev_d_z[rows, z_dim] = dLoss/d z per row and
  *     ACCUMULATES the weight gradients into dev_dkernels / dev_dbiases (Keras layout, as nfx_mlp128_bwd).    */
-int nfx_brdf_rows_fwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
+NFX_API int nfx_brdf_rows_fwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
                       const void *dev_blob, int prec, float *dev_out, void *stream);
-size_t nfx_brdf_rows_bwd_workspace_bytes(int z_dim, int64_t n, int reci);
-int nfx_brdf_rows_bwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
+NFX_API size_t nfx_brdf_rows_bwd_workspace_bytes(int z_dim, int64_t n, int reci);
+NFX_API int nfx_brdf_rows_bwd(const float *dev_z, int z_dim, const float *dev_rusink, int64_t n, int reci,
                       const void *dev_blob, int prec, const float *dev_dout, void *dev_workspace,
                       size_t workspace_bytes, float *dev_d_z, float *const dev_dkernels[5],
                       float *const dev_dbiases[5], void *stream);
@@ -283,8 +303,8 @@ int nfx_brdf_rows_bwd(const float *dev_z, int z_dim, const float *dev_rusink, in
  * inside `dev_workspace` (nfx_shade_bwd_workspace_bytes(n_lights), 8-byte aligned), so the result is independent of
  * the order of the atomics: bit-reproducible.  Gradients flow to the normal both through cos = l.n and through the
  * BRDF; none to positions, camera or light geometry.  */
-size_t nfx_shade_bwd_workspace_bytes(int n_lights);
-int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+NFX_API size_t nfx_shade_bwd_workspace_bytes(int n_lights);
+NFX_API int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,
                   const float *dev_lareas, const float *dev_light, int64_t n, int n_lights,
@@ -297,19 +317,19 @@ int nfx_shade_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_n
  * (a, b) = the bf16 pair {src[a], src[b]}, low half first; a negative index gives 0.  `src` is the concatenation
  * of the network's fp32 parameters on the device, the map a device int32 array built once from the host packer
  * (nerfactor_amd/ops.py:DevicePacker).  Lets a training step refresh its blobs without a device->host round trip. */
-int nfx_pack_gather(const float *dev_src, const int32_t *dev_map, int64_t n_words, void *dev_blob, void *stream);
+NFX_API int nfx_pack_gather(const float *dev_src, const int32_t *dev_map, int64_t n_words, void *dev_blob, void *stream);
 
 /* tf.keras.optimizers.Adam(amsgrad=True) dense update on flat fp32 buffers (trainvali.py:116-127):
  * lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step); m, v, vhat updated in place;
  * p -= lr_t * m / (sqrt(vhat) + eps).  `step` is 1-based.                                      */
-int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
+NFX_API int nfx_amsgrad_step(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
                      int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                      void *stream);
 /* The same update with lr_t read from device memory (dev_lr_t[0] = nfx_amsgrad_step_size(lr, beta1, beta2, step),
  * written by the host before the launch): a training step captured in a hipGraph replays with the step size of the
  * current step, not the one of the step it was captured at (nerfactor_amd/optim.py:GraphedTrainStep).            */
-float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step);
-int nfx_amsgrad_step_dev(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
+NFX_API float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step);
+NFX_API int nfx_amsgrad_step_dev(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
                          int64_t n, const float *dev_lr_t, float beta1, float beta2, float eps, void *stream);
 
 /* The per-ray training losses of the surface models (nerfactor.py:463-541, shape.py:239-277 `compute_loss`) as one
@@ -332,9 +352,9 @@ typedef struct nfx_loss_term {
     int kind;  /* NFX_LOSS_MSE | NFX_LOSS_MAE */
     int flags; /* NFX_LOSS_BLEND_* | NFX_LOSS_ACCUM_* */
 } nfx_loss_term;
-int nfx_pair_loss_fwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
+NFX_API int nfx_pair_loss_fwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
                       float *dev_loss, void *stream);
-int nfx_pair_loss_bwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
+NFX_API int nfx_pair_loss_bwd(const nfx_loss_term *terms, int n_terms, const float *dev_alpha, float bg, int64_t n,
                       const float *dev_dloss, void *stream);
 
 /* ------------------------------------------------------------------------ */
@@ -344,16 +364,16 @@ int nfx_pair_loss_bwd(const nfx_loss_term *terms, int n_terms, const float *dev_
 /* sigma[n_rays, S] = sigma_out(enc(posenc(rayo + rayd z))) BEFORE the relu (eval_sigma_mlp, :322-350), from the
  * GEOM blob (nfx_nerf_pack_geom_weights, whose first 65 chunks are the encoder + the sigma tile): the bottleneck /
  * rgb head is neither evaluated nor streamed.  Bit-identical to the sigma of nfx_nerf_mlp_fwd.                 */
-int nfx_nerf_sigma_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+NFX_API int nfx_nerf_sigma_fwd(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
                        int n_samples, const void *dev_geom_blob, int prec, float *dev_sigma, void *stream);
 
 /* out[n_rays, S, 4] = (n_x, n_y, n_z, sigma_raw) with n = -l2_normalize(d relu(sigma_raw)/dx, eps 1e-12): the
  * per-sample normal of compute_depth_and_normal (:280-297, GradientTape.batch_jacobian there).  `geom_blob` =
  * nfx_nerf_pack_geom_weights (encoder + sigma tile, transposed encoder, input-gradient tiles).  16-byte aligned out. */
-size_t nfx_nerf_geom_packed_bytes(int prec);
-int nfx_nerf_pack_geom_weights(const float *const kernels[12], const float *const biases[12], int prec,
+NFX_API size_t nfx_nerf_geom_packed_bytes(int prec);
+NFX_API int nfx_nerf_pack_geom_weights(const float *const kernels[12], const float *const biases[12], int prec,
                                void *blob, size_t blob_bytes);
-int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
                         int n_samples, const void *dev_geom_blob, int prec, float *dev_normal_sigma,
                         void *stream);
 
@@ -363,9 +383,9 @@ int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, const floa
 
 /* D[32,32] = A[32,16] * B[16,32] through one v_mfma_f32_32x32x16_bf16 with the operand
  * lane maps documented in DESIGN.md; used by the GPU tests to pin the fragment layout. */
-int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
+NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
 /* out[i] = (which ? cos : sin)(in[i]) with the kernel's own range reduction.  */
-int nfx_selftest_sincos(const float *dev_in, int64_t n, int which, float *dev_out, void *stream);
+NFX_API int nfx_selftest_sincos(const float *dev_in, int64_t n, int which, float *dev_out, void *stream);
 
 #ifdef __cplusplus
 }

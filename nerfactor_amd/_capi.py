@@ -35,6 +35,9 @@ _pp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     'nfx_version': (_i, []),
     'nfx_last_error': (_i, [ctypes.c_char_p, _sz]),
+    'nfx_set_option': (_i, [ctypes.c_char_p, _i]),
+    'nfx_unset_option': (_i, [ctypes.c_char_p]),
+    'nfx_get_option': (_i, [ctypes.c_char_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'nfx_nerf_packed_bytes': (_sz, [_i]),
     'nfx_nerf_pack_weights': (_i, [_pp, _pp, _i, _p, _sz]),
     'nfx_mlp128_packed_bytes': (_sz, [_i, _i, _i, _i]),
@@ -108,3 +111,54 @@ def last_error():
 def check(rc, what):
     if rc != 0:
         raise NfxError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+# ------------------------------------------------------------------------------- options
+OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused')
+
+
+def set_option(key, value):
+    """nfx_set_option: a process-wide integer option of the library (kernel-variant selectors, grid sizes)."""
+    check(lib.nfx_set_option(key.encode(), int(value)), 'nfx_set_option(%s)' % key)
+
+
+def unset_option(key):
+    check(lib.nfx_unset_option(key.encode()), 'nfx_unset_option(%s)' % key)
+
+
+def get_option(key):
+    """-> the set value, or None when the option is at its default."""
+    v, isset = _i(0), _i(0)
+    check(lib.nfx_get_option(key.encode(), ctypes.byref(v), ctypes.byref(isset)), 'nfx_get_option(%s)' % key)
+    return v.value if isset.value else None
+
+
+class option:
+    """with option('brdf_ct', 8): ...   — sets an option for the block and restores what was there before."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.prev = get_option(self.key)
+        if self.value is None:
+            unset_option(self.key)
+        else:
+            set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            unset_option(self.key)
+        else:
+            set_option(self.key, self.prev)
+        return False
+
+
+# The library reads no environment variable; the binding forwards NFX_<KEY> once, here, so that
+# `NFX_BRDF_CT=8 python bench.py` keeps working for A/B runs from a shell.
+for _k in OPTION_KEYS:
+    _v = os.environ.get('NFX_' + _k.upper())
+    if _v not in (None, ''):
+        set_option(_k, int(_v))

@@ -21,10 +21,8 @@ LIB = os.path.join(HERE, 'libnfx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: the fp32 stages follow the reference's op order (mul then add), fused
 # multiply-adds appear only where written as fmaf().
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',
          '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include')]
-if os.environ.get('NFX_ABLATION_BUILD'):  # diagnostic instantiations of the v2 kernel
-    FLAGS.append('-DNFX_ABLATION_BUILD')
 if os.environ.get('NFX_EXTRA_DEFS'):  # experiment switches, e.g. NFX_EXTRA_DEFS='-DNFX_V5_BIAS_COPY'
     FLAGS += os.environ['NFX_EXTRA_DEFS'].split()
 
@@ -88,7 +86,8 @@ def build(force=False, verbose=False, out=None):
         rebuilt = any(r for _, r in results)
         if rebuilt or not os.path.exists(LIB):
             tmp = LIB + '.tmp.%d' % os.getpid()
-            cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', tmp]
+            cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC',
+                   '-Wl,--version-script=' + os.path.join(CSRC, 'libnfx.map')] + objs + ['-o', tmp]
             if verbose:
                 print(' '.join(cmd), flush=True)
             res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
 // pre-activation gradients dZ0..dZ3, dZ_out go feature-major to `wsp` for the weight-gradient GEMMs (train.hip).
 constexpr int kRowsX = 32;                       // feature rows reserved for the network input
 constexpr int kOffH = kRowsX, kOffDZ = kRowsX + 512, kOffDZo = kRowsX + 1024, kRowFeats = kRowsX + 1032;
+static_assert(kRowsX % 2 == 0, "feature-pair-major storage (feat_store.hpp): every group starts on an even feature");
 
 template <bool BWD>
 __global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/nfx.h"
@@ -61,13 +62,63 @@ int nfx_last_error(char* buf, size_t len) {
     return NFX_OK;
 }
 
-// Tuning knobs (process-wide, read-only after first use): kernel variant and persistent grid size.
-int nfx_env_int(const char* name, int dflt);
-#define env_int nfx_env_int
-int nfx_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
+// Options (nfx.h: nfx_set_option / nfx_get_option): process-wide integers, set by the host before the calls they
+// affect.  No environment variable is read by the library; the Python binding forwards NFX_<KEY> variables once, at
+// import (nerfactor_amd/_capi.py).  A key that was never set reads as the default of its call site.
+namespace {
+struct Option {
+    const char* key;
+    std::atomic<int> value;
+    std::atomic<int> is_set;
+};
+Option g_options[] = {
+    {"nerf_variant", {0}, {0}},   // NeRF MLP forward: 7 (default) | 6 | 8 | 1 | 0 — all bit-identical
+    {"nerf_blocks", {0}, {0}},    // persistent grid of the NeRF kernels (default 256)
+    {"m128_blocks", {0}, {0}},    // persistent grid of the width-128 kernels (default 256)
+    {"lvis_variant", {0}, {0}},   // light visibility: 8 (default) | 2 | 3 | 4 | 0 — all bit-identical
+    {"brdf_variant", {0}, {0}},   // learned BRDF: 6 (default) | 5 | 2 | 3 | 4 | 0
+    {"brdf_ct", {0}, {0}},        // column tiles of brdf variants 5 / 6: 4 (default) | 2 | 3; 8 = two waves per SIMD (variant 6 only)
+    {"nerf_bwd", {0}, {0}},       // 1 (default) = LDS-DMA ring backward, 0 = register-staged identity reference
+    {"nerf_bwd_nw", {0}, {0}},    // waves of the NeRF ring backward: 8 (default) | 4
+    {"m128_bwd", {0}, {0}},       // as nerf_bwd for the width-128 networks
+    {"wgrad_lds", {0}, {0}},      // force the LDS-staged weight-gradient GEMM on (1) / off (0); default by row count
+    {"wgrad_slabs", {0}, {0}},    // number of row slabs of a weight-gradient batch (default by row count)
+    {"wgrad_narrow", {0}, {0}},   // 0 = width-128 networks through the wide kernel as well
+    {"wgrad_fused", {0}, {0}},    // 0 = backward kernels store activations, separate weight-gradient GEMMs (identity reference)
+};
+Option* find_option(const char* key) {
+    if (!key) return nullptr;
+    for (Option& o : g_options)
+        if (strcmp(o.key, key) == 0) return &o;
+    return nullptr;
 }
+}  // namespace
+
+int nfx_option_int(const char* key, int dflt) {   // internal (hidden): the value of a set option, else dflt
+    Option* o = find_option(key);
+    return o && o->is_set.load(std::memory_order_acquire) ? o->value.load(std::memory_order_relaxed) : dflt;
+}
+int nfx_set_option(const char* key, int value) {
+    Option* o = find_option(key);
+    if (!o) return fail(NFX_EINVAL, "nfx_set_option: unknown option '%s'", key ? key : "(null)");
+    o->value.store(value, std::memory_order_relaxed);
+    o->is_set.store(1, std::memory_order_release);
+    return NFX_OK;
+}
+int nfx_unset_option(const char* key) {
+    Option* o = find_option(key);
+    if (!o) return fail(NFX_EINVAL, "nfx_unset_option: unknown option '%s'", key ? key : "(null)");
+    o->is_set.store(0, std::memory_order_release);
+    return NFX_OK;
+}
+int nfx_get_option(const char* key, int* value, int* is_set) {
+    Option* o = find_option(key);
+    if (!o || !value) return fail(NFX_EINVAL, "nfx_get_option: unknown option '%s' or null output", key ? key : "(null)");
+    *value = o->value.load(std::memory_order_relaxed);
+    if (is_set) *is_set = o->is_set.load(std::memory_order_acquire);
+    return NFX_OK;
+}
+#define env_int nfx_option_int
 
 // --------------------------------------------------------------------------- packing
 size_t nfx_nerf_packed_bytes(int prec) {
@@ -165,8 +216,9 @@ int nfx_scatter_rows(const float* src, const int32_t* row_of, int64_t n_all, int
     REQUIRE(n_all >= 0 && d >= 1, "nfx_scatter_rows: bad shape (%lld rows of %d)", (long long)n_all, d);
     if (n_all == 0) return NFX_OK;
     REQUIRE(row_of && dst, "nfx_scatter_rows: null pointer");   // (src may be null when no row is selected)
-    // at most 2^32 - 1 elements (or float4 groups) per launch: slice the rows
-    const long long per_row = d % 4 == 0 ? d / 4 : d, max_rows = ((1ll << 32) - 1) / per_row;
+    // at most 2^31 elements (or float4 groups) per launch: the kernel's 32-bit grid-stride index advances by at most
+    // 2^21 per step and must not wrap past 2^32; slice the rows
+    const long long per_row = d % 4 == 0 ? d / 4 : d, max_rows = (1ll << 31) / per_row > 0 ? (1ll << 31) / per_row : 1;
     for (long long r0 = 0; r0 < n_all; r0 += max_rows) {
         const long long nr = n_all - r0 < max_rows ? n_all - r0 : max_rows;
         const int rc = hip_result(nfx_launch_scatter_rows(src, row_of + r0, nr, d, dst + r0 * d, (hipStream_t)stream),
@@ -194,26 +246,26 @@ int nfx_nerf_mlp_fwd(const float* rayo, const float* rayd, const float* z, int64
     if (!ALIGNED(blob, 16) || !ALIGNED(rgbs, 16))
         return fail(NFX_EALIGN, "nfx_nerf_mlp_fwd: blob and rgbs must be 16-byte aligned");
     const long long n_pts = (long long)n_rays * n_samples;
-    const int blocks = env_int("NFX_NERF_BLOCKS", 256);
+    const int blocks = env_int("nerf_blocks", 256);
     if (prec == NFX_PREC_BF16) {
         // NFX_NERF_VARIANT: 7 (default) = one wave per SIMD, 64 points per wave, epilogue software-pipelined under the
         // next tile's MFMAs, weight stream by LDS-DMA into a 6-slot ring (nerf_mlp_v6.hip); 6 / 8 = the same kernel
         // with register-staged weights (one / two staging sets); 1 = the 8 waves x 32 points reference geometry with
         // two waves per SIMD, 0 = 4 x 64 plain (nerf_mlp.hip).  All bit-identical.  The intermediate variants 2, 3, 5
         // of r01 live in scripts/experiments/ (not built).
-        const int variant = env_int("NFX_NERF_VARIANT", 7);
+        const int variant = env_int("nerf_variant", 7);
         if (variant == 8)
-            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, -8,
+            return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks, 2,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v8)");
         if (variant == 7)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          env_int("NFX_ABLATE", 0) > 0 ? 100 + env_int("NFX_ABLATE", 0) : -7,
+                                                          1,
                                                           (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v7)");
         if (variant == 6)
             return hip_result(nfx_launch_nerf_mlp_bf16_v6(rayo, rayd, z, n_pts, n_samples, blob, rgbs, blocks,
-                                                          env_int("NFX_ABLATE", 0), (hipStream_t)stream),
+                                                          0, (hipStream_t)stream),
                               "nerf_mlp_fwd(bf16, v6)");
         if (variant != 0 && variant != 1)
             return fail(NFX_EINVAL, "nfx_nerf_mlp_fwd: NFX_NERF_VARIANT %d is not built (0, 1, 6, 7, 8)", variant);

@@ -11,7 +11,7 @@
 
 int nfx_fail(int code, const char* fmt, ...);
 int nfx_hip_result(int e, const char* what);
-extern "C" int nfx_env_int(const char* name, int dflt);
+extern "C" int nfx_option_int(const char* name, int dflt);
 
 #define REQUIRE(cond, ...) \
     do {                   \
@@ -137,10 +137,10 @@ int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_fwd: blob must be 16-byte aligned");
     if (prec == NFX_PREC_FP32)
         return nfx_hip_result(nfx_launch_nerf_sigma_x3(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
-                                                       sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                                                       sigma, nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                               "nerf_sigma_fwd(fp32)");
     return nfx_hip_result(nfx_launch_nerf_sigma_geo(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
-                                                    sigma, nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                                                    sigma, nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                           "nerf_sigma_fwd");
 }
 
@@ -155,10 +155,10 @@ int nfx_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, in
     if (prec == NFX_PREC_FP32)
         return nfx_hip_result(nfx_launch_nerf_sigma_grad_x3(rayo, rayd, z, (long long)n_rays * n_samples, n_samples,
                                                             geom_blob, normal_sigma,
-                                                            nfx_env_int("NFX_NERF_BLOCKS", 256), (hipStream_t)stream),
+                                                            nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                               "nerf_sigma_grad(fp32)");
     return nfx_hip_result(nfx_launch_nerf_sigma_grad(rayo, rayd, z, (long long)n_rays * n_samples, n_samples,
-                                                     geom_blob, normal_sigma, nfx_env_int("NFX_NERF_BLOCKS", 256),
+                                                     geom_blob, normal_sigma, nfx_option_int("nerf_blocks", 256),
                                                      (hipStream_t)stream),
                           "nerf_sigma_grad");
 }

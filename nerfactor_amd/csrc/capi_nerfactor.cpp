@@ -13,7 +13,7 @@
 
 int nfx_fail(int code, const char* fmt, ...);       // capi.cpp
 int nfx_hip_result(int e, const char* what);        // capi.cpp
-extern "C" int nfx_env_int(const char* name, int dflt);  // capi.cpp
+extern "C" int nfx_option_int(const char* name, int dflt);  // capi.cpp
 
 #define REQUIRE(cond, ...) \
     do {                   \
@@ -206,10 +206,10 @@ int nfx_mlp128_xyz_fwd(const float* xyz, int64_t n, float xyz_scale, const void*
     if (prec == NFX_PREC_FP32)
         return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_XYZ, xyz, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, 1,
                                                    xyz_scale, blob, out_dim, out_act, post_scale, post_bias, out,
-                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                   nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                               "mlp128_xyz_fwd(fp32)");
     return nfx_hip_result(nfx_launch_mlp128_xyz(xyz, n, xyz_scale, blob, out_dim, out_act, post_scale, post_bias,
-                                                out, nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                out, nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                           "mlp128_xyz_fwd");
 }
 
@@ -229,7 +229,7 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
         if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_lvis_fwd: blob must be 16-byte aligned");
         return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_XYZ_LDIR, xyz, xyz_dir ? xyz_dir : xyz, lxyz, nullptr, nullptr,
                                                    nullptr, 0, n, n_lights, xyz_scale, blob, 1, 2, 1.0f, 0.0f, lvis,
-                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                   nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                               "lvis_fwd(fp32)");
     }
     REQUIRE(xyz && lxyz && blob && lvis && workspace, "nfx_lvis_fwd: null pointer");
@@ -237,14 +237,14 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
             workspace_bytes, nfx_lvis_workspace_bytes(n));
     if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16))
         return nfx_fail(NFX_EALIGN, "nfx_lvis_fwd: blob and workspace must be 16-byte aligned");
-    const int blocks = nfx_env_int("NFX_M128_BLOCKS", 256);
+    const int blocks = nfx_option_int("m128_blocks", 256);
     const char* b = static_cast<const char*>(blob);
     float* pre = static_cast<float*>(workspace);
     int rc = nfx_hip_result(nfx_launch_lvis_pre(xyz, n, xyz_scale, b, pre, blocks, (hipStream_t)stream), "lvis_pre");
     if (rc) return rc;
-    // NFX_LVIS_VARIANT: 0 = 8 waves x 32 rows with streamed weights (mlp128.hip); 2 | 3 | 4 = network resident in LDS,
+    // option lvis_variant: 0 = 8 waves x 32 rows with streamed weights (mlp128.hip); 2 | 3 | 4 = network resident in LDS,
     // one wave per SIMD with that many 32-row column tiles (lvis_v2.hip)
-    const int variant = nfx_env_int("NFX_LVIS_VARIANT", 8);   // 8 (default) = 8 waves (two per SIMD) x 2 column tiles
+    const int variant = nfx_option_int("lvis_variant", 8);   // 8 (default) = 8 waves (two per SIMD) x 2 column tiles
     if ((variant >= 2 && variant <= 4) || variant == 8)
         return nfx_hip_result(nfx_launch_lvis_v2(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis,
                                                  variant, blocks, (hipStream_t)stream),
@@ -270,29 +270,35 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
     if (prec == NFX_PREC_FP32)
         return nfx_hip_result(nfx_launch_mlp128_x3(NFX_IN_Z_RUSINK, xyz, nullptr, lxyz, cam, normal, z, z_dim, n, n_lights,
                                                    1.0f, blob, 1, 3, 1.0f, 0.0f, spec,
-                                                   nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                   nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                               "brdf_spec_fwd(fp32)");
-    // NFX_BRDF_VARIANT: 0 / 2 / 3 / 4 as NFX_LVIS_VARIANT (every row evaluated, back-lit rows zeroed afterwards);
+    // option brdf_variant: 0 / 2 / 3 / 4 as lvis_variant (every row evaluated, back-lit rows zeroed afterwards);
     // 5 = front-lit rows only (LDS row queue per wave), per-row geometry as in the dense kernels (bit-identical);
-    // 6 (default) = 5 with closed-form Rusinkiewicz angles.  NFX_BRDF_CT of variants 5 / 6: 8 (default) = 8 waves x 2
-    // column tiles, two waves per SIMD (up to 640 lights); 2 | 3 | 4 column tiles per wave, one wave per SIMD.
-    int variant = nfx_env_int("NFX_BRDF_VARIANT", 6);
+    // 6 (default) = 5 with closed-form Rusinkiewicz angles.  Option brdf_ct of variants 5 / 6: 2 | 3 | 4 (default) column
+    // tiles per wave, one wave per SIMD.  8 = 8 waves x 2 column tiles, two waves per SIMD, variant 6 only and NOT the
+    // default: r03 shipped it (12 % faster), and its per-row-geometry sibling <2, 0, 8> then failed bit identity on a
+    // fresh MI355X for a reason that is still not established — a kernel form whose sibling's
+    // bits depend on the box is opt-in until the mechanism is known.
+    int variant = nfx_option_int("brdf_variant", 6);
     if (variant >= 5) {
-        const int ct = nfx_env_int("NFX_BRDF_CT", 8);
+        int ct = nfx_option_int("brdf_ct", 4);
+#ifndef NFX_EXPERIMENT_BUILD
+        if (ct == 8 && variant != 6) ct = 2;   // <2, 0, 8> is not built
+#endif
         int rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, ct, variant == 6,
-                                         nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
+                                         nfx_option_int("m128_blocks", 256), (hipStream_t)stream);
         if (rc == -1 && ct == 8)   // more lights than the 8-wave row queues hold: the 4-wave form
             rc = nfx_launch_brdf_spec_v3(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, 4, variant == 6,
-                                         nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream);
+                                         nfx_option_int("m128_blocks", 256), (hipStream_t)stream);
         if (rc != -1) return nfx_hip_result(rc, "brdf_spec_fwd(v3)");
         variant = 3;   // shape outside the row queue's limits: dense kernel
     }
     if (variant >= 2 && variant <= 4)
         return nfx_hip_result(nfx_launch_brdf_spec_v2(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec, variant,
-                                                      nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                                      nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                               "brdf_spec_fwd(v2)");
     return nfx_hip_result(nfx_launch_brdf_spec(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, spec,
-                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                               nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                           "brdf_spec_fwd");
 }
 

@@ -12,7 +12,7 @@
 
 int nfx_fail(int code, const char* fmt, ...);
 int nfx_hip_result(int e, const char* what);
-extern "C" int nfx_env_int(const char* name, int dflt);
+extern "C" int nfx_option_int(const char* name, int dflt);
 
 #define REQUIRE(cond, ...) \
     do {                   \
@@ -141,11 +141,13 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
         return nfx_fail(NFX_EALIGN, "nfx_mlp128_bwd: blob and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long ld = ld_for(in_kind, n, n_lights);
+    REQUIRE(12 * ld < (1ll << 32), "nfx_mlp128_bwd: at most %lld rows per call (got %lld; feat_store.hpp's 32-bit lane offsets)",
+            (1ll << 32) / 12 - 256, ld);
     const long long rows = in_kind == NFX_IN_XYZ ? n : n * (long long)n_lights;
     const long long rows16 = (rows + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in dZ
     int rc = nfx_hip_result(nfx_launch_mlp128_bwd(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights,
                                                   blob, out_dim, out_act, post_scale, dout, workspace, ld,
-                                                  nfx_env_int("NFX_M128_BLOCKS", 256), st),
+                                                  nfx_option_int("m128_blocks", 256), st),
                             "mlp128_bwd");
     if (rc) return rc;
     const int ind = in_dims(in_kind), kx = in_kind == NFX_IN_XYZ ? 64 : 96;
@@ -254,9 +256,10 @@ int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64
         return nfx_fail(NFX_EALIGN, "nfx_nerf_mlp_bwd: blob, workspace and d_rgbs must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long n_pts = (long long)n_rays * n_samples, ld = nerf_ld(n_pts);
-    REQUIRE(ld * 2 * 4 < (1ll << 32), "nfx_nerf_mlp_bwd: at most 2^28 points per call (got %lld)", n_pts);
+    // feat_store.hpp: a lane's 32-bit offset inside a feature-pair row reaches row * 4 + 4 * ld2 = up to 12 * ld
+    REQUIRE(12 * ld < (1ll << 32), "nfx_nerf_mlp_bwd: at most %lld points per call (got %lld)", (1ll << 32) / 12 - 256, n_pts);
     int rc = nfx_hip_result(nfx_launch_nerf_bwd(rayo, rayd, z, n_pts, n_samples, blob, d_rgbs, workspace, ld,
-                                                nfx_env_int("NFX_NERF_BLOCKS", 256), st),
+                                                nfx_option_int("nerf_blocks", 256), st),
                             "nerf_bwd");
     if (rc) return rc;
     const long long rows16 = (n_pts + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in every dZ
@@ -404,7 +407,7 @@ int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, c
     if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 8))
         return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd: blob must be 16-byte, workspace 8-byte aligned");
     return nfx_hip_result(nfx_launch_brdf_spec_bwd(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, dspec, d_z,
-                                                   d_normal, workspace, nfx_env_int("NFX_M128_BLOCKS", 256),
+                                                   d_normal, workspace, nfx_option_int("m128_blocks", 256),
                                                    (hipStream_t)stream),
                           "brdf_spec_bwd");
 }
@@ -433,7 +436,7 @@ int nfx_brdf_rows_fwd(const float* z, int z_dim, const float* rusink, int64_t n,
     REQUIRE(z && rusink && blob && out, "nfx_brdf_rows_fwd: null pointer");
     if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_rows_fwd: blob must be 16-byte aligned");
     return nfx_hip_result(nfx_launch_brdf_rows(0, z, z_dim, rusink, n, reci ? 2 * n : n, blob, nullptr, out, nullptr, 0,
-                                               nfx_env_int("NFX_M128_BLOCKS", 256), (hipStream_t)stream),
+                                               nfx_option_int("m128_blocks", 256), (hipStream_t)stream),
                           "brdf_rows_fwd");
 }
 
@@ -460,8 +463,9 @@ int nfx_brdf_rows_bwd(const float* z, int z_dim, const float* rusink, int64_t n,
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = reci ? 2 * n : n;
     const long long ld = brdf_rows_ld(rows), rows16 = (rows + 15) / 16 * 16;
+    REQUIRE(12 * ld < (1ll << 32), "nfx_brdf_rows_bwd: at most %lld rows per call (got %lld)", (1ll << 32) / 12 - 256, ld);
     int rc = nfx_hip_result(nfx_launch_brdf_rows(1, z, z_dim, rusink, n, rows, blob, dout, d_z, workspace, ld,
-                                                 nfx_env_int("NFX_M128_BLOCKS", 256), st), "brdf_rows_bwd");
+                                                 nfx_option_int("m128_blocks", 256), st), "brdf_rows_bwd");
     if (rc) return rc;
     const int ind = z_dim + 15;
     const char* ws = static_cast<const char*>(workspace);

@@ -13,9 +13,6 @@
 #include "mlp128_layout.hpp"
 #include "mlp_engine.hpp"
 
-#ifdef NFX_LV2_TIMING
-__device__ unsigned long long nfx_lv2_times[64];   // s_memtime before each tile of one wave (diagnostic build)
-#endif
 
 namespace nfx {
 namespace lv2 {
@@ -144,11 +141,6 @@ __device__ __forceinline__ void tile(const char* wlds, int lane, const bf16x8 (&
             const bf16x8 b = s < KS1 ? b1[s < KS1 ? s : 0][c] : b2[s >= KS1 ? s - KS1 : 0][c];
             acc.v[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc.v[c], 0, 0, 0);
         }
-#ifdef NFX_LV2_TIMING
-        if constexpr (K == 8 || K == 9) {
-            if (blockIdx.x == 7 && threadIdx.x == 0) nfx_lv2_times[(K == 8 ? 20 : 32) + s] = __builtin_readcyclecounter();
-        }
-#endif
         if constexpr (s < PIECES) prev.template run<16 * s / PIECES, 16 * (s + 1) / PIECES>();
         if constexpr (s == PIECES - 1) {
             // keep the next tile's initial loads BEHIND the epilogue that frees their destination registers (hoisted
@@ -332,15 +324,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
         }
         // chunk K accumulates in accs[K & 1]; layers: L0 K 0-3 (pl -> ha), L1 4-7 (ha -> hb), L2 8-11 (hb -> ha),
         // L3 12-15 ([ha ; pl] -> hb), out 16 (hb -> activation)
-#ifdef NFX_LV2_TIMING
-// cycle stamp per tile of one wave (scripts/lv2_timing.py; the r02 first-tile experiments are in DESIGN.md section 2c)
-#define NFX_LV2_STAMP(K) \
-    if (blockIdx.x == 7 && tid == 0 && tl == blockIdx.x + 4 * (long long)gridDim.x) nfx_lv2_times[K] = __builtin_readcyclecounter();
-#else
-#define NFX_LV2_STAMP(K)
-#endif
 #define NFX_LV2_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
-        NFX_LV2_STAMP(K) \
         tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
 #define NFX_LV2_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
         NFX_LV2_TILE(0, 2, 0, pl, pl, EpiNone{}, init03(32, 32));
@@ -363,7 +347,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
         NFX_LV2_TILE(16, 8, 0, hb, pl, NFX_LV2_EPI(15, hb, 3), [](int, Acc<CT>&) {});
 #undef NFX_LV2_TILE
 #undef NFX_LV2_EPI
-        NFX_LV2_STAMP(17)
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
@@ -639,14 +622,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
     constexpr int kPass = CT * 32;
     long long kfill = 0, k_head = 0;   // next point to fill; point of the oldest queued row
     int head = 0, cnt = 0;
-#ifdef NFX_LV2_TIMING
-    // phase cycles of wave 0 of block 7, summed over its passes (scripts/brdf_phases.py): [48] fill, [49] row gathers +
-    // geometry + operand build, [50] the 17 tiles + output, [51] passes
-    unsigned long long ph_fill = 0, ph_geo = 0, ph_net = 0, ph_n = 0, ph_t = __builtin_readcyclecounter();
-#define NFX_PHASE(ACC) { const unsigned long long now_ = __builtin_readcyclecounter(); ACC += now_ - ph_t; ph_t = now_; }
-#else
-#define NFX_PHASE(ACC)
-#endif
     for (;;) {
         // ---- fill: front-lit rows of the next points until a whole pass is queued (ring: kPass - 1 + L <= kRing)
         while (cnt < kPass) {
@@ -716,7 +691,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        NFX_PHASE(ph_fill)
         const int rows = cnt < kPass ? cnt : kPass;
         // ---- pass: CT column tiles of 32 queued rows
         bf16x8 pl[2][CT];
@@ -815,24 +789,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         bf16x8 ha[8][CT], hb[8][CT];
         Acc<CT> accs[2];
         Pre pre;
-#ifdef NFX_LV2_TIMING
-        asm volatile("" :: "v"(pl[0][0]), "v"(pl[1][CT - 1]));   // the operands exist before the stamp
-        __builtin_amdgcn_sched_barrier(0);
-        NFX_PHASE(ph_geo)
-#endif
         {
             const char* f0 = wlds + lane * 16;
             pre.a[0] = *reinterpret_cast<const bf16x8*>(f0);
             pre.a[1] = *reinterpret_cast<const bf16x8*>(f0 + kFragBytes);
             InitBias{bias_lds}(lane, accs[0]);
         }
-#ifdef NFX_LV2_TIMING
-#define NFX_LV3_STAMP(K) if (blockIdx.x == 7 && tid == 0 && ph_n == 40) nfx_lv2_times[K] = __builtin_readcyclecounter();
-#else
-#define NFX_LV3_STAMP(K)
-#endif
 #define NFX_LV3_TILE(K, KS1, KS2, B1, B2, PREV, NEXT) \
-        NFX_LV3_STAMP(K) \
         tile<K, (K + 1) % 17, KS1, KS2, CT>(wlds, lane, B1, B2, accs[(K) & 1], accs[((K) + 1) & 1], pre, PREV, NEXT)
 #define NFX_LV3_EPI(K, OUT, T) EpiB<CT>{accs[(K) & 1], OUT[2 * (T)], OUT[2 * (T) + 1]}
 #define NFX_LV3_BIAS(OFF) (InitBias{bias_lds + (OFF)})
@@ -853,9 +816,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         NFX_LV3_TILE(14, 8, 2, ha, pl, NFX_LV3_EPI(13, hb, 1), NFX_LV3_BIAS(384 + 96));
         NFX_LV3_TILE(15, 8, 2, ha, pl, NFX_LV3_EPI(14, hb, 2), NFX_LV3_BIAS(512));
         NFX_LV3_TILE(16, 8, 0, hb, pl, NFX_LV3_EPI(15, hb, 3), [](int, Acc<CT>&) {});
-        NFX_LV3_STAMP(17)
 #undef NFX_LV3_TILE
-#undef NFX_LV3_STAMP
 #undef NFX_LV3_EPI
 #undef NFX_LV3_BIAS
         if (h == 0) {
@@ -863,11 +824,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             for (int c = 0; c < CT; ++c)
                 if (orow[c] >= 0) a.out[orow[c]] = softplusf(accs[0].v[c][0]);   // brdf.py:65
         }
-#ifdef NFX_LV2_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        NFX_PHASE(ph_net)
-        ++ph_n;
-#endif
         head = ring_wrap(head + rows, kCap);
         cnt -= rows;
         if (cnt > 0) {
@@ -877,15 +833,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
             k_head = kfill;
         }
     }
-#ifdef NFX_LV2_TIMING
-    if (blockIdx.x == 7 && tid == 0) {
-        nfx_lv2_times[48] = ph_fill;
-        nfx_lv2_times[49] = ph_geo;
-        nfx_lv2_times[50] = ph_net;
-        nfx_lv2_times[51] = ph_n;
-    }
-#endif
-#undef NFX_PHASE
 }
 
 }  // namespace lv2
@@ -951,14 +898,12 @@ extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const
     const int tiles = ct == 8 ? 2 : ct;
     if (n_lights > 1024 || tiles * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;   // (launch_compact checks its own ring)
     nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
-    if (ct == 8) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 8>(a, max_blocks, st);
+#ifdef NFX_EXPERIMENT_BUILD   // the per-row-geometry form with two waves per SIMD: NOT deterministic on MI355X, soak builds only
+    if (ct == 8 && !geo) return launch_compact<2, 0, 8>(a, max_blocks, st);
+#endif
+    if (ct == 8) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 4>(a, max_blocks, st);
     if (ct == 2) return geo ? launch_compact<2, 1, 4>(a, max_blocks, st) : launch_compact<2, 0, 4>(a, max_blocks, st);
     if (ct == 3) return geo ? launch_compact<3, 1, 4>(a, max_blocks, st) : launch_compact<3, 0, 4>(a, max_blocks, st);
     return geo ? launch_compact<4, 1, 4>(a, max_blocks, st) : launch_compact<4, 0, 4>(a, max_blocks, st);
 }
 
-#ifdef NFX_LV2_TIMING
-extern "C" int nfx_debug_lv2_times(unsigned long long* host64) {
-    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(nfx_lv2_times), sizeof(unsigned long long) * 64);
-}
-#endif

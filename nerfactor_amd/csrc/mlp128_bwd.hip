@@ -39,6 +39,7 @@ struct Geo {
     static constexpr int kOffH = kXFeats;                   // h0..h3: 4 x 128
     static constexpr int kOffDZ = kXFeats + 512;            // dZ0..dZ3: 4 x 128
     static constexpr int kOffDZo = kXFeats + 1024;          // dZ_out: 8
+    static_assert(kXFeats % 2 == 0, "feature-pair-major storage (feat_store.hpp): every group starts on an even feature");
     static constexpr int kFeats = kXFeats + 1032;
 };
 
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < 4; ++s) xin[s][0] = pe[s][0];
             store_posenc<10, 4>(fs, 0, h, pe);
-            if (h == 1) st16(fs, 63, (__bf16)0.f);
+            // pad feature 63 — only where nothing else owns the slot: with IN_KIND == 1 feature 63 is ldir.x, written by
+            // store_posenc<4, 2>(fs, 63) below from the OTHER lane half; two stores of different lanes to one address
+            // have no defined order
+            if constexpr (IN_KIND == 0) { if (h == 1) st16(fs, 63, (__bf16)0.f); }
         }
         if constexpr (IN_KIND == 1) {
             const int l = (int)(rc % n_lights);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_ring_kernel(
         ring::end<KSX, 20>(cx);
         // ------------------------------------------------------------------ stores of the forward half
         store_posenc<10, 4>(fs, 0, h, pe);
-        if (h == 1) st16(fs, 63, (__bf16)0.f);
+        if constexpr (IN_KIND == 0) { if (h == 1) st16(fs, 63, (__bf16)0.f); }   // (IN_KIND == 1: the slot is ldir.x, see the streamed kernel)
         if constexpr (IN_KIND == 1) {
             store_posenc<4, 2>(fs, 63, h, pl);
             if (h == 1) {  // pad features 90..95
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_ring_kernel(
 }  // namespace bwd
 }  // namespace nfx
 
-extern "C" int nfx_env_int(const char* name, int dflt);   // capi.cpp
+extern "C" int nfx_option_int(const char* name, int dflt);   // capi.cpp
 
 extern "C" {
 int nfx_launch_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, long long n, float xyz_scale,
@@ -464,7 +468,7 @@ int nfx_launch_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, l
     const long long rows = in_kind == 0 ? n : n * n_lights;
     const long long tiles = (rows + bwd::kRows - 1) / bwd::kRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    const bool use_ring = nfx_env_int("NFX_M128_BWD", 1) != 0;   // (per call, like every knob: INTEGRATION.md)
+    const bool use_ring = nfx_option_int("m128_bwd", 1) != 0;   // (per call, like every knob: INTEGRATION.md)
     if (use_ring) {   // r03 default: dgrad weights resident in LDS, forward weights through a DMA ring
         const int rl = bwd::ring::kLds;
         auto launch = [&](auto k) {

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
 }  // namespace bwd
 }  // namespace nfx
 
-extern "C" int nfx_env_int(const char* name, int dflt);   // capi.cpp
+extern "C" int nfx_option_int(const char* name, int dflt);   // capi.cpp
 
 extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                                    const void* blob, const float* d_rgbs, void* wsp, long long ld, int max_blocks,
@@ -440,8 +440,8 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     const long long tiles = (n_pts + bwd::kNerfRows - 1) / bwd::kNerfRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     // r03 default: weights through the LDS-DMA ring; NFX_NERF_BWD=0 keeps the register-staged kernel (identity reference)
-    const bool use_ring = nfx_env_int("NFX_NERF_BWD", 1) != 0;            // (per call, like every knob: INTEGRATION.md)
-    const int ring_nw = nfx_env_int("NFX_NERF_BWD_NW", 8) == 4 ? 4 : 8;
+    const bool use_ring = nfx_option_int("nerf_bwd", 1) != 0;            // (per call, like every knob: INTEGRATION.md)
+    const int ring_nw = nfx_option_int("nerf_bwd_nw", 8) == 4 ? 4 : 8;
     auto k = !use_ring ? bwd::nerf_bwd_kernel : ring_nw == 8 ? bwd::nerf_bwd_ring_kernel<8> : bwd::nerf_bwd_ring_kernel<4>;
     const int nw = use_ring ? ring_nw : bwd::kNerfNW;
     const int lds = !use_ring ? bwd::kNerfBwdLds : ring_nw == 8 ? bwd::nring::Cfg<8>::kLds : bwd::nring::Cfg<4>::kLds;

@@ -17,29 +17,13 @@
 //   DMA = 2  variant 8   register-staged with two staging sets (chunk k+3 fetched during tile k, stored a tile later).
 // The r01 experiment switches (second bias read group, A-prefetch depth, epilogue start offset, DMA fetch distance,
 // DMA pieces spread over the k-steps) were all measured and left at the values now hard-wired here — DESIGN.md
-// section 2 has the numbers; what remains switchable is the timing build (NFX_V6_TIMING) and the ablation masks
-// (NFX_ABLATION_BUILD).
+// section 2 has the numbers.  The cycle-stamp build (NFX_V6_TIMING), its experiment masks (NFX_V6_XP, NFX_V6_FENCE)
+// and the ablation instantiations (NFX_ABLATION_BUILD) that produced the r01-r03 measurements of DESIGN.md sections
+// 2 / 2d left this file in r04 (git history: fdbd16f holds them): the shipped translation unit is the product kernel.
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"
 #include "nerf_layout.hpp"
 
-#ifdef NFX_V6_TIMING
-__device__ unsigned long long nfx_v6_times[4][128];   // cycle stamp before each tile, all four waves of one block
-__device__ int nfx_v6_idx = -1;
-#endif
-
-// Experiment mask of the cycle-stamp build (-DNFX_V6_XP=<bits>, never set in the product build; scripts/build_v6_xp.sh):
-//   2  the epilogue converts into a scratch register set instead of the next layer's B operands — same VALU work, the
-//      MFMAs never read a freshly converted register: how round 3 tied the slow first tile of every layer to the
-//      operands' last writer (mlp_engine.hpp); in the product schedule (no stamps) the same experiment is worth 3.5 %.
-#ifndef NFX_V6_XP
-#define NFX_V6_XP 0
-#endif
-// operand-fence experiments in the PRODUCT schedule (scripts/build_v6_variant.sh): 1 = v_mov_b32 behind every converted
-// pair, 2 = eight v_mov_b64 once a tile's epilogue is complete.  Both are slower than no fence.
-#ifndef NFX_V6_FENCE
-#define NFX_V6_FENCE 0
-#endif
 
 namespace nfx {
 namespace v6 {
@@ -79,9 +63,6 @@ __device__ __forceinline__ void cvt_pair(float v0, float v1, bf16x8& dst, int j)
         w = __builtin_elementwise_max(w, z);
         pr = __builtin_bit_cast(b2, w);
     }
-#if NFX_V6_FENCE == 1   // (mlp_engine.hpp, "MFMA operands written by packed ...": measured, not shipped)
-    pr = __builtin_bit_cast(b2, mfma_operand_dword(__builtin_bit_cast(unsigned, pr)));
-#endif
     dst[j] = pr[0];
     dst[j + 1] = pr[1];
 }
@@ -102,23 +83,6 @@ struct EpiB {
             }
     }
     __device__ __forceinline__ void finish() {
-#if NFX_V6_FENCE == 2
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int c = 0; c < kCT; ++c) {
-            u64x2 a = __builtin_bit_cast(u64x2, lo[c]), b = __builtin_bit_cast(u64x2, hi[c]);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                unsigned long long x = a[q], y = b[q];
-                asm("v_mov_b64 %0, %0" : "+v"(x));
-                asm("v_mov_b64 %0, %0" : "+v"(y));
-                a[q] = x;
-                b[q] = y;
-            }
-            lo[c] = __builtin_bit_cast(bf16x8, a);
-            hi[c] = __builtin_bit_cast(bf16x8, b);
-        }
-#endif
     }
 };
 struct EpiNone {
@@ -163,9 +127,6 @@ struct Regs {
 };
 
 struct Ctx {
-#if NFX_V6_XP & 2
-    bf16x8 (&scratch)[2][kCT];
-#endif
     char* smem;
     const char* blob;
     int tid;
@@ -211,9 +172,6 @@ __device__ __forceinline__ void tile(const Ctx& cx, Regs& rg, const float* next_
     constexpr int K1 = (K + 1) % kNChunks, K2 = (K + dist_of<DMA>) % kNChunks;   // K2: the chunk fetched during this tile
     constexpr int NL2 = nerf::chunk_frags(K2) / 4;
     const int lane = cx.tid & 63;
-#ifdef NFX_V6_TIMING
-    if (blockIdx.x == 7 && lane == 0 && nfx_v6_idx == 0) nfx_v6_times[cx.wave][K] = __builtin_readcyclecounter();
-#endif
     const char* f0 = cx.smem + (K % R) * kSlotBytes + lane * 16;
     Stage<DMA ? 1 : NL2, kNW> st;
     if constexpr (DMA == 1 && !(AB & 1)) {
@@ -301,19 +259,9 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
         const float* nb = t == NT - 1 ? next_bias : bias + 32 * (t + 1);
         if constexpr (t == 0) {
             tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, prev0);
-#if NFX_V6_XP & 2
-            asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
-#endif
         } else {
-#if NFX_V6_XP & 2
-            EpiB<RELU> e{accs[(K - 1) & 1], cx.scratch[0], cx.scratch[1]};
-#else
             EpiB<RELU> e{accs[(K - 1) & 1], bout[2 * (t - 1)], bout[2 * (t - 1) + 1]};
-#endif
             tile<K, KS1, KS2, AB, DMA>(cx, rg, nb, b1, b2, accs[K & 1], accs[(K + 1) & 1], pre, e);
-#if NFX_V6_XP & 2
-            asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
-#endif
         }
     });
 }
@@ -332,14 +280,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
         for (int i = tid; i < kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
     }
     typedef __attribute__((address_space(3))) char lds_char;
-#if NFX_V6_XP & 2
-    bf16x8 xp_scratch[2][kCT];
-    Ctx cx{xp_scratch, smem, blob, tid, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem),
-           __builtin_amdgcn_readfirstlane(tid >> 6)};
-#else
     Ctx cx{smem, blob, tid, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem),
            __builtin_amdgcn_readfirstlane(tid >> 6)};
-#endif
     Acc accs[2];
     Pre pre;
     Regs rg;
@@ -389,44 +331,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
             posenc<10, kCT>(x, h, c, pe);
             posenc<4, kCT>(d, h, c, pv);
         }
-#ifdef NFX_V6_TIMING
-        // (set by every lane-0 with the same value: no barrier needed, and a __syncthreads() here crashes the
-        //  'AMDGPU Rewrite AGPR-Copy-MFMA' pass of ROCm 7.2 in MFMA VGPR form)
-        if (blockIdx.x == 7 && lane == 0) nfx_v6_idx = (tl == blockIdx.x + 4 * (long long)gridDim.x) ? 0 : -1;
-#endif
         bf16x8 ha[16][kCT], hb[16][kCT], r0[8][kCT];
-#if NFX_V6_XP & 2   // never written in this experiment: distinct registers holding activation-like values (half of them
-                    // zero, the rest in [0, 1): the matrix pipe's power draw — and with it the clock DVFS grants —
-                    // depends on the operand data, all-zero operands ran 18 % "faster")
-#pragma unroll
-        for (int i_ = 0; i_ < 16; ++i_)
-#pragma unroll
-            for (int c_ = 0; c_ < kCT; ++c_) {
-                u32x4 w = __builtin_bit_cast(u32x4, pe[i_ & 3][c_]);
-#pragma unroll
-                for (int q_ = 0; q_ < 4; ++q_) {
-                    unsigned x = (w[q_] * (2654435761u + 977u * i_)) & 0x7fff0000u;   // one positive bf16 + one zero per dword
-                    x = (x & 0x00ff0000u) | 0x3f000000u;                             // [0.5, 1)
-                    asm volatile("" : "+v"(x));
-                    w[q_] = (i_ + q_) & 1 ? x : (x >> 16);
-                }
-                ha[i_][c_] = __builtin_bit_cast(bf16x8, w);
-                hb[i_][c_] = __builtin_bit_cast(bf16x8, w);
-                asm volatile("" : "+v"(hb[i_][c_]));
-                if (i_ < 8) {
-                    r0[i_][c_] = __builtin_bit_cast(bf16x8, w);
-                    asm volatile("" : "+v"(r0[i_][c_]));
-                }
-            }
-#endif
         float sigma[kCT];
         const float* bl = bias_lds + kBiasL0;
         auto pend = [&](auto relu_tag, const Acc& a, bf16x8(&lo)[kCT], bf16x8(&hi)[kCT]) {
-#if NFX_V6_XP & 2
-            return EpiB<decltype(relu_tag)::value>{a, cx.scratch[0], cx.scratch[1]};
-#else
             return EpiB<decltype(relu_tag)::value>{a, lo, hi};
-#endif
         };
         using T = std::true_type;
         using F = std::false_type;
@@ -445,18 +354,12 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
                                        pend(T{}, accs[1], hb[14], hb[15]));
         // sigma tile (K = 72 -> accs[0]); pending: last bottleneck tile (accs[1]); next: rgb_out[0] tile 0
         tile<72, 16, 0, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, hb, pe, accs[0], accs[1], pre, pend(F{}, accs[1], ha[14], ha[15]));
-#if NFX_V6_XP & 2
-        asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
-#endif
         {
             EpiSigma es{accs[0], sigma};
             layer<73, 16, 2, 4, true, AB, DMA>(cx, rg, bias_lds + kBiasRgb0, bias_lds + kBiasRgb1, ha, pv, r0, accs, pre, es);
         }
         // rgb_out[1] (K = 77 -> accs[1]); pending: last rgb_out[0] tile (K = 76 -> accs[0]); next: L0 tile 0
         tile<77, 8, 0, AB, DMA>(cx, rg, bl, r0, pe, accs[1], accs[0], pre, pend(T{}, accs[0], r0[6], r0[7]));
-#if NFX_V6_XP & 2
-        asm volatile("" ::"v"(cx.scratch[0][0]), "v"(cx.scratch[0][1]), "v"(cx.scratch[1][0]), "v"(cx.scratch[1][1]));
-#endif
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < kCT; ++c)
@@ -485,31 +388,11 @@ static int launch_v6(const float* rayo, const float* rayd, const float* z, long 
 }
 
 extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd, const float* z, long long n_pts,
-                                           int n_samples, const void* blob, float* out, int max_blocks, int ablate,
+                                           int n_samples, const void* blob, float* out, int max_blocks, int dma_mode,
                                            hipStream_t stream) {
     if (n_pts <= 0) return 0;
-#if defined(NFX_ABLATION_BUILD) && defined(NFX_V6_FEW)   // (experiment builds: the register-only tile alone)
-    if (ablate == 175) return launch_v6<75, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
-#elif defined(NFX_ABLATION_BUILD)
-    switch (ablate) {
-#define NFX_V6_CASE(m) case m: return launch_v6<m, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
-        NFX_V6_CASE(1) NFX_V6_CASE(2) NFX_V6_CASE(3) NFX_V6_CASE(4) NFX_V6_CASE(8) NFX_V6_CASE(64) NFX_V6_CASE(7)
-        NFX_V6_CASE(12) NFX_V6_CASE(75)
-#undef NFX_V6_CASE
-#define NFX_V7_CASE(m) case 100 + m: return launch_v6<m, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
-        NFX_V7_CASE(1) NFX_V7_CASE(2) NFX_V7_CASE(3) NFX_V7_CASE(4) NFX_V7_CASE(8) NFX_V7_CASE(64) NFX_V7_CASE(66)
-        NFX_V7_CASE(75)
-#undef NFX_V7_CASE
-        default: break;
-    }
-#endif
-    if (ablate == -7 || ablate >= 100) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
-    if (ablate == -8) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
-    return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);
+    if (dma_mode == 1) return launch_v6<0, 1>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 7
+    if (dma_mode == 2) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
+    return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);                      // variant 6
 }
 
-#ifdef NFX_V6_TIMING
-extern "C" int nfx_debug_v6_times(unsigned long long* host512) {
-    return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(nfx_v6_times), sizeof(unsigned long long) * 4 * 128);
-}
-#endif

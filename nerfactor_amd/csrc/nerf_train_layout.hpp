@@ -29,5 +29,8 @@ constexpr int kOffDSig = kOffDBott + 256;    // dZ of sigma_out: 1 (+7 pad)
 constexpr int kOffDR0 = kOffDSig + 8;        // dZ of rgb_out[0]: 128
 constexpr int kOffDRgb = kOffDR0 + 128;      // dZ of rgb_out[1]: 3 (+5 pad)
 constexpr int kTrainFeats = kOffDRgb + 8;    // 4976
+// feature-PAIR-major storage (feat_store.hpp): every group starts on an even feature
+static_assert((kOffPe | kOffPv | kOffA | kOffBott | kOffR0 | kOffDZ | kOffDBott | kOffDSig | kOffDR0 | kOffDRgb) % 2 == 0,
+              "feature offsets must be even");
 }  // namespace nerf
 }  // namespace nfx

@@ -419,7 +419,7 @@ extern "C" int nfx_launch_scatter_rows(const float* src, const int* row_of, long
     if (n_all <= 0 || d <= 0) return 0;
     const bool v4 = d % 4 == 0 && (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
     const long long per_row = v4 ? d / 4 : d, n_elems = n_all * per_row;
-    if (n_elems >= (1ll << 32)) return (int)hipErrorInvalidValue;   // (the C-ABI wrapper splits such calls)
+    if (n_elems > (1ll << 31) + (1ll << 20)) return (int)hipErrorInvalidValue;   // (the C-ABI wrapper splits such calls: the 32-bit loop index must not wrap)
     long long blocks = (n_elems + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (v4)

@@ -269,7 +269,7 @@ static nfx::ShadeArgs make_args(const float* xyz, const float* cam, const float*
     a.to_srgb = to_srgb; a.olat_inten = olat_inten; a.ambient = ambient; a.out = out;
     return a;
 }
-size_t nfx_shade_lds_bytes(int n_lights, int n_probes) {
+__attribute__((visibility("default"))) size_t nfx_shade_lds_bytes(int n_lights, int n_probes) {   // public: include/nfx.h
     return sizeof(float) * ((size_t)4 * n_lights + (size_t)n_probes * n_lights * 3 +
                             (size_t)nfx::kShadeWaves * n_probes * 3);
 }

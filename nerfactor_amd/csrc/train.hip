@@ -262,9 +262,13 @@ __device__ __forceinline__ void wgrad_lds_narrow(const WgBatch& bt, const WgCall
             const int pp = i * 256 + tid, pr = pp >> 5, part = pp & 31;
             unsigned e[2], o[2];
             wg_split(sx[i], e, o);
+            // odd feature counts (63, 27 inputs; 1 or 3 outputs): the odd half of the last pair is never written by the
+            // backward kernels — zero it here instead of feeding stale bits to the MFMAs
+            if (2 * pr + 1 >= k_in) o[0] = o[1] = 0u;
             *reinterpret_cast<u32x2*>(bx + (2 * pr) * kWnPitch + part * 8) = u32x2{e[0], e[1]};
             *reinterpret_cast<u32x2*>(bx + (2 * pr + 1) * kWnPitch + part * 8) = u32x2{o[0], o[1]};
             wg_split(sz[i], e, o);
+            if (2 * pr + 1 >= n_out) o[0] = o[1] = 0u;
             *reinterpret_cast<u32x2*>(bz + (2 * pr) * kWnPitch + part * 8) = u32x2{e[0], e[1]};
             *reinterpret_cast<u32x2*>(bz + (2 * pr + 1) * kWnPitch + part * 8) = u32x2{o[0], o[1]};
         }
@@ -415,9 +419,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(WgBatch bt) {
             const int pp = i * 256 + tid, pr = pp >> 4, part = pp & 15;
             unsigned e[2], o[2];
             wg_split(sx[i], e, o);
+            if (kb + 2 * pr + 1 >= k_in) o[0] = o[1] = 0u;   // (odd feature counts: see wgrad_lds_narrow_kernel)
             *reinterpret_cast<u32x2*>(bx + (2 * pr) * kWlPitch + part * 8) = u32x2{e[0], e[1]};
             *reinterpret_cast<u32x2*>(bx + (2 * pr + 1) * kWlPitch + part * 8) = u32x2{o[0], o[1]};
             wg_split(sz[i], e, o);
+            if (nb + 2 * pr + 1 >= n_out) o[0] = o[1] = 0u;
             *reinterpret_cast<u32x2*>(bz + (2 * pr) * kWlPitch + part * 8) = u32x2{e[0], e[1]};
             *reinterpret_cast<u32x2*>(bz + (2 * pr + 1) * kWlPitch + part * 8) = u32x2{o[0], o[1]};
         }
@@ -504,15 +510,17 @@ struct nfx_wgrad_call {
     float* db;
 };
 
+int nfx_option_int(const char* key, int dflt);   // capi.cpp
+
 static void wgrad_plan(long long rows, bool* use_lds, long long* slab, int* n_slabs) {
-    const char* env = getenv("NFX_WGRAD_LDS");
-    *use_lds = env ? atoi(env) != 0 : rows >= 16384;
-    const char* es = getenv("NFX_WGRAD_SLABS");
+    const int force_lds = nfx_option_int("wgrad_lds", -1);
+    *use_lds = force_lds >= 0 ? force_lds != 0 : rows >= 16384;
+    const int n_forced = nfx_option_int("wgrad_slabs", 0);
     long long sl;
     if (*use_lds) {
         // fewer, longer slabs = fewer partial blocks to write and sum; at least 64 slabs, at most one per CU
-        if (es && atoi(es) > 0) {
-            sl = rows / atoi(es);
+        if (n_forced > 0) {
+            sl = rows / n_forced;
         } else {
             sl = rows / 256 > 2048 ? rows / 256 : 2048;
             const long long cap = rows / 64 > 256 ? rows / 64 : 256;
@@ -522,7 +530,7 @@ static void wgrad_plan(long long rows, bool* use_lds, long long* slab, int* n_sl
         if (sl < 256) sl = 256;
     } else {
         // latency-bound regime (one wave per block walks its slab with dependent loads): short slabs in parallel
-        sl = es && atoi(es) > 0 ? rows / atoi(es) : 128;
+        sl = n_forced > 0 ? rows / n_forced : 128;
         sl = (sl + 15) / 16 * 16;
         if (sl < 16) sl = 16;
     }
@@ -557,10 +565,7 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
     bt.n_calls = n_calls;
     bt.ld = ld;
     bt.rows = rows;
-    {
-        const char* en = getenv("NFX_WGRAD_NARROW");
-        bt.wide_only = en && atoi(en) == 0;
-    }
+    bt.wide_only = nfx_option_int("wgrad_narrow", 1) == 0;
     const int bs = lds ? 256 : 128;
     float* p = static_cast<float*>(partial);
     int blocks = 0;

@@ -61,9 +61,9 @@ def test_normalize_and_gen_z(nfx_lib, cuda):
 
 @pytest.mark.parametrize("variant", ["0", "1", "6", "7", "8"])
 @pytest.mark.parametrize("n_rays,n_samples", [(1, 64), (300, 64), (77, 192), (4, 5)])
-def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monkeypatch):
+def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, nfx_opt):
     from nerfactor_amd import ops
-    monkeypatch.setenv("NFX_NERF_VARIANT", variant)
+    nfx_opt.set("nerf_variant", variant)
     rng = np.random.default_rng(10 + n_rays)
     net = common.nerf_nets(seed=7)[0]
     ks, bs = common.nerf_layers(net)
@@ -82,11 +82,11 @@ def test_nerf_mlp_bf16_vs_oracle(nfx_lib, cuda, variant, n_rays, n_samples, monk
 
 
 @pytest.mark.parametrize("variant", ["1", "6", "7", "8"])
-def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch, variant):
+def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, nfx_opt, variant):
     """More tiles than workgroups (persistent loop, wrapped weight stream) must equal tile-by-tile."""
     from nerfactor_amd import ops
-    monkeypatch.setenv("NFX_NERF_VARIANT", variant)
-    monkeypatch.setenv("NFX_NERF_BLOCKS", "3")
+    nfx_opt.set("nerf_variant", variant)
+    nfx_opt.set("nerf_blocks", "3")
     rng = np.random.default_rng(3)
     net = common.nerf_nets(seed=8)[1]
     blob = ops.pack_nerf_weights(*common.nerf_layers(net)).to(cuda)
@@ -95,7 +95,7 @@ def test_nerf_mlp_batch_independence_and_persistence(nfx_lib, cuda, monkeypatch,
     rayd = dev(nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12), cuda)
     z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
     full = ops.nerf_mlp_fwd(rayo, rayd, z, blob)
-    monkeypatch.setenv("NFX_NERF_BLOCKS", "256")
+    nfx_opt.set("nerf_blocks", "256")
     part = torch.cat([ops.nerf_mlp_fwd(rayo[i:i + 500], rayd[i:i + 500], z[i:i + 500], blob)
                       for i in range(0, n, 500)])
     assert torch.equal(full, part)
@@ -314,7 +314,8 @@ def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
     assert 0.05 < float(out['occu_f'].mean()) < 0.6
 
 
-def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
+@pytest.mark.determinism
+def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, nfx_opt):
     """Variants 1, 2 and 3 differ in weight pipeline and wave schedule only — same MFMA order, so the
     outputs must be bit-identical (a DMA/LDS race in variant 2 would show up here)."""
     from nerfactor_amd import ops
@@ -326,7 +327,7 @@ def test_nerf_mlp_variants_are_bit_identical(nfx_lib, cuda, monkeypatch):
     z = dev(np.sort(rng.uniform(2, 6, size=(n, 64)), -1), cuda)
     outs = {}
     for v in ("0", "1", "6", "7", "8"):
-        monkeypatch.setenv("NFX_NERF_VARIANT", v)
+        nfx_opt.set("nerf_variant", v)
         outs[v] = [ops.nerf_mlp_fwd(rayo, rayd, z, blob) for _ in range(3)]
     for t in outs["1"][1:] + outs["0"] + outs["6"] + outs["7"] + outs["8"]:
         assert torch.equal(outs["1"][0], t)

@@ -84,9 +84,9 @@ def test_mlp128_xyz_backward_vs_autograd(nfx_lib, cuda, out_dim, act, scale, n):
 
 
 @pytest.mark.parametrize("wgrad_lds", ["0", "1"])
-def test_lvis_backward_vs_autograd(nfx_lib, cuda, monkeypatch, wgrad_lds):
+def test_lvis_backward_vs_autograd(nfx_lib, cuda, nfx_opt, wgrad_lds):
     from nerfactor_amd import ops
-    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)   # both weight-gradient GEMM kernels (train.hip)
+    nfx_opt.set("wgrad_lds", wgrad_lds)   # both weight-gradient GEMM kernels (train.hip)
     layers, out = net128(90, 90, 1)
     n = 21
     rng, lxyz, _, xyz, _, _ = scene(n, 91)
@@ -473,9 +473,9 @@ def test_composite_backward_vs_autograd(nfx_lib, cuda, n, s, white_bg, use_noise
 
 @pytest.mark.parametrize("wgrad_lds", ["0", "1"])
 @pytest.mark.parametrize("n_rays,s", [(40, 7), (3, 192)])
-def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s, monkeypatch, wgrad_lds):
+def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s, nfx_opt, wgrad_lds):
     from nerfactor_amd import ops
-    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)
+    nfx_opt.set("wgrad_lds", wgrad_lds)
     from tests import common
     net = common.nerf_nets(seed=5, opaque=False)[0]
     ks_np, bs_np = common.nerf_layers(net)
@@ -639,13 +639,14 @@ def test_shade_backward_finite_for_vanishing_roughness_and_mirror_lights(nfx_lib
     assert torch.isfinite(rgb).all()
 
 
+@pytest.mark.determinism
 @pytest.mark.parametrize("wgrad_lds", ["0", "1"])
-def test_weight_gradients_are_bit_reproducible(nfx_lib, cuda, monkeypatch, wgrad_lds):
+def test_weight_gradients_are_bit_reproducible(nfx_lib, cuda, nfx_opt, wgrad_lds):
     """No float atomics in the weight-gradient path: every (row slab, dW block) stores its partial sum and a second
     kernel adds the slabs in slab order, so two runs of the same backward give identical bits — for the direct-load
     kernel (short slabs in parallel) and for the LDS-staged one, for the width-128 and the NeRF networks."""
     from nerfactor_amd import ops
-    monkeypatch.setenv("NFX_WGRAD_LDS", wgrad_lds)
+    nfx_opt.set("wgrad_lds", wgrad_lds)
     layers, out = net128(31, 90, 1)
     ks = [k for k, _ in layers] + [out[0][0]]
     bs = [b for _, b in layers] + [out[0][1]]
@@ -741,6 +742,7 @@ def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
     assert torch.equal(got, nfx_grad.PairLoss.apply(alpha, bg, spec, rgb_p, rgb_g, lv_p, lv_g, lv_j, r_p, r_j))
 
 
+@pytest.mark.determinism
 @pytest.mark.parametrize("name,jitter,steps", [("shape", "0.01", 200), ("nerfactor_microfacet", "0.01", 200),
                                                ("nerfactor", "0.01", 200), ("nerfactor_microfacet", "0", 12)])
 def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, steps):
@@ -809,6 +811,7 @@ def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, st
     assert not torch.equal(kept1[0][key], kept1[1][key])
 
 
+@pytest.mark.determinism
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor"])
 def test_whole_step_gradients_are_bit_reproducible(nfx_lib, cuda, name):
     """No floating-point atomics are left in the training path (ordered weight-gradient reduction, fixed-point sums
@@ -841,8 +844,9 @@ def test_whole_step_gradients_are_bit_reproducible(nfx_lib, cuda, name):
     assert float(model._light.grad.abs().max()) > 0
 
 
+@pytest.mark.determinism
 @pytest.mark.parametrize("name,n", [("nerf", 37), ("nerf", 1024), ("nerfactor_microfacet", 300), ("shape", 37)])
-def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, monkeypatch, name, n):
+def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, nfx_opt, name, n):
     """The r03 backward kernels (weights through an LDS-DMA ring with hand-counted vmcnt waits; NeRF: 4 or 8 waves per
     workgroup) run the same MFMAs on the same operands as the register-staged kernels of rounds 1-2: every gradient of
     a whole step is bit-identical.  A wait that is one count too generous shows up here as a changed bit."""
@@ -867,21 +871,21 @@ def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, mon
                  torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1), t(rng.uniform(size=(n, 512))))
 
     def grads(**env):
-        for k in ('NFX_NERF_BWD', 'NFX_NERF_BWD_NW', 'NFX_M128_BWD'):
-            monkeypatch.delenv(k, raising=False)
+        for k in ('nerf_bwd', 'nerf_bwd_nw', 'm128_bwd'):
+            nfx_opt.unset(k)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            nfx_opt.set(k, v)
         torch.manual_seed(13)   # the NeRF step draws its stratified samples and noise
         opt.zero_grad()
         pred, gt, kw, _ = model(batch, mode='train')
         (model.compute_loss(pred, gt, keep_batch=True, **kw).sum() / n).backward()
         return opt.bucket.flat.clone()
 
-    ref = grads(NFX_NERF_BWD='0', NFX_M128_BWD='0')
+    ref = grads(nerf_bwd=0, m128_bwd=0)
     assert float(ref.abs().max()) > 0
     assert torch.equal(grads(), ref)                                     # the defaults: rings, NeRF with 8 waves
     if name == 'nerf':
-        assert torch.equal(grads(NFX_NERF_BWD_NW='4'), ref)
+        assert torch.equal(grads(nerf_bwd_nw=4), ref)
 
 
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor", "nerf", "shape"])
