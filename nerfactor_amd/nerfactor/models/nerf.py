@@ -31,6 +31,15 @@ class Model(BaseModel):
             for k, v in self._init_net().items():
                 self.net[stage + '_' + k] = v
         self._check_fusable()
+        # The last sample of a ray has dist = 1e10 (nerf.py:186-191), so alpha_last = [sigma_last > 0] EXACTLY: a ray
+        # whose sigma_last sits within the bf16 kernel's rounding of 0 flips between "hits the far plane" and
+        # "background", and no tolerance on rgb can hold for it.  When rendering (autograd off) with precision = bf16
+        # the density of every ray's LAST sample is therefore re-evaluated by the fp32-class density kernel
+        # (nerf_geom_x3.hip: 1 of n_samples points at ~3x the cost; ini key `last_sample_precision`, default fp32).
+        # A training step keeps the bf16 forward its backward kernel re-computes.
+        self.last_sample_precision = self.config.get('DEFAULT', 'last_sample_precision', fallback='fp32')
+        if self.last_sample_precision not in ('bf16', 'fp32'):
+            raise ValueError("last_sample_precision = %s (bf16 | fp32)" % self.last_sample_precision)
         self.register_trainable()
 
     # ------------------------------------------------------------------ construction
@@ -143,7 +152,10 @@ class Model(BaseModel):
             ks, bs = self._nerf_params(pref)
             return autograd.NerfMlp.apply(rayo, rayd, z, self._nerf_blob(pref),
                                           lambda: self._nerf_train_blob(pref), self.precision, *(ks + bs))
-        return ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision)
+        rgbs = ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision)
+        if self.precision == 'bf16' and self.last_sample_precision == 'fp32' and z.shape[1] > 1:
+            ops.nerf_refine_last_sample(rayo, rayd, z, rgbs, self._nerf_geom_blob(pref, 'fp32'))
+        return rgbs
 
     def _render_rays(self, rayo, rayd, mode='train'):
         cfg = self.config
@@ -182,10 +194,11 @@ class Model(BaseModel):
         return ops.nerf_mlp_fwd(o, d, z, self._nerf_blob(pref), self.precision).reshape(n, s, 4)
 
     # ------------------------------------------------------------------ geometry extraction (geometry_from_nerf.py)
-    def _nerf_geom_blob(self, pref):
+    def _nerf_geom_blob(self, pref, precision=None):
+        precision = precision or self.precision
         ks, bs = self._nerf_params(pref)
-        return self._packed(pref + 'geom' + self.precision, ks + bs,
-                            lambda k, b: ops.pack_nerf_geom_weights(k, b, self.precision))
+        return self._packed(pref + 'geom' + precision, ks + bs,
+                            lambda k, b: ops.pack_nerf_geom_weights(k, b, precision))
 
     @staticmethod
     def _in_bounds(rayo, rayd, z, bbox):

@@ -476,6 +476,19 @@ def nerf_sigma_fwd(rayo, rayd, z, blob, prec='bf16'):
     return out
 
 
+def nerf_refine_last_sample(rayo, rayd, z, rgbs, geom_blob_fp32):
+    """Overwrites the density of every ray's LAST sample in rgbs[N,S,4] (in place) with the fp32-class density kernel's
+    value (nerf_geom_x3.hip through nfx_nerf_sigma_fwd, NFX_PREC_FP32).  That sample gets dist = 1e10 when compositing
+    (nerf.py:186-191): alpha_last = [sigma_last > 0] exactly, so its SIGN is the only bit of the ray that a bf16 kernel
+    can get wrong by a whole pixel value; 1 / S of the points at ~3x the cost."""
+    n, s = z.shape
+    if n == 0 or s < 2:
+        return rgbs
+    sig = nerf_sigma_fwd(rayo, rayd, z[:, -1:].contiguous(), geom_blob_fp32, 'fp32')
+    rgbs[:, -1, 3] = sig[:, 0]
+    return rgbs
+
+
 def nerf_sigma_grad(rayo, rayd, z, geom_blob, prec='bf16'):
     """(normal[N,S,3], sigma_raw[N,S]) with normal = -l2_normalize(d relu(sigma)/dx)."""
     rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, geom_blob)

@@ -143,15 +143,23 @@ def test_sample_fine_vs_oracle(nfx_lib, cuda, nc, nf):
         np.testing.assert_allclose(got, want, atol=1e-5)
 
 
-def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16'):
+def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16', refine=True):
+    """The render of models/nerf.py:_render_rays spelled out in ops calls; with precision = bf16 every ray's last sample
+    gets its density from the fp32-class kernel (ops.nerf_refine_last_sample; `refine=False` = the r03 render)."""
     from nerfactor_amd import ops
     blobs = [ops.pack_nerf_weights(*common.nerf_layers(n), prec=prec).to(cuda) for n in nets]
+    gblobs = [ops.pack_nerf_geom_weights(*common.nerf_layers(n), prec='fp32').to(cuda) for n in nets] \
+        if refine and prec == 'bf16' else None
     o, d = dev(rayo, cuda), ops.l2_normalize3(dev(rayd, cuda), 1e-12)
     z = ops.gen_z(2., 6., 64, o.shape[0], device=cuda)
     raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
+    if gblobs:
+        ops.nerf_refine_last_sample(o, d, z, raw, gblobs[0])
     rgb_c, occu_c, depth_c, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
     z_all = ops.sample_fine(z, w, n_fine)
     raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1], prec)
+    if gblobs:
+        ops.nerf_refine_last_sample(o, d, z_all, raw, gblobs[1])
     rgb_f, occu_f, depth_f, _, _ = ops.composite_fwd(raw, z_all, d, white_bg=True, want_weights=False)
     return dict(rgb_c=rgb_c, occu_c=occu_c, depth_c=depth_c, z_all=z_all, rgb_f=rgb_f,
                 occu_f=occu_f, depth_f=depth_f)
@@ -159,34 +167,37 @@ def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16'):
 
 def test_full_render_vs_fp32_oracle(nfx_lib, cuda):
     """32x32 view, 64+128 samples, opaque-variant weights: the stated end-to-end tolerance
-    (PSNR >= 40 dB on uint8 luma, max-abs <= 3e-2 on rgb).
+    (PSNR >= 40 dB on uint8 luma, max-abs <= 3e-2 on rgb) on EVERY ray (r04).
 
-    The reference's formula has a DISCONTINUITY that no other rounding can reproduce bit-wise: the
-    last sample of every ray gets dist = 1e10 (nerf.py:186-191), so alpha_last = [sigma_last > 0]
-    exactly and whatever transmittance is left flips between "hit" and "background" with the sign
-    of one logit.  Rays whose oracle |sigma_last| is inside the bf16 noise band (0.06; the measured
-    max |d sigma| is 0.035 with the x8 sigma gain) are excluded from the max-abs bound — and only
-    from that one: they stay in the PSNR, and they must be a small minority."""
+    The reference's formula has a DISCONTINUITY: the last sample of every ray gets dist = 1e10 (nerf.py:186-191), so
+    alpha_last = [sigma_last > 0] exactly and whatever transmittance is left flips between "hit" and "background" with
+    the sign of one logit.  Rounds 1-3 excused rays whose oracle |sigma_last| < 0.06 from the max-abs bound (the bf16
+    kernel's density error is up to 0.037 with the x8 sigma gain, profiles/r04/sigma_last_error.json).  The render now
+    evaluates that one sample with the fp32-class density kernel (ops.nerf_refine_last_sample), and no ray is excused;
+    without the refinement the same frame must show the flips (the test would otherwise prove nothing)."""
     nets = common.nerf_nets(seed=0)
     rayo, rayd = common.camera_rays(32, 32)
     got = {k: v.cpu().numpy() for k, v in _render_device(rayo, rayd, nets, cuda).items()}
     coarse, fine, aux = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1])
     assert float(np.mean(coarse['occu'])) > 0.05
-    ok_c = np.abs(aux['rgbs_coarse'][:, -1, 3]) > 0.06
-    ok_f = ok_c & (np.abs(aux['rgbs_fine'][:, -1, 3]) > 0.06)
-    assert ok_f.mean() > 0.75
-    for tag, ref, ok in (('c', coarse, ok_c), ('f', fine, ok_f)):
+    in_band = (np.abs(aux['rgbs_coarse'][:, -1, 3]) <= 0.06) | (np.abs(aux['rgbs_fine'][:, -1, 3]) <= 0.06)
+    assert in_band.sum() >= 20          # the frame does contain rays on the discontinuity
+    for tag, ref in (('c', coarse), ('f', fine)):
         err = np.abs(got['rgb_' + tag] - ref['rgb']).max(-1)
         psnr = nerf_ref.psnr_uint8_luma(got['rgb_' + tag].reshape(32, 32, 3),
                                         ref['rgb'].reshape(32, 32, 3))
         assert psnr >= 40., (tag, psnr)
-        assert err[ok].max() <= 3e-2, (tag, err[ok].max())
+        assert err.max() <= 3e-2, (tag, err.max(), int(np.argmax(err)))
         # occupancy integrates the (x8-gained) sigma error along the whole ray: looser than rgb
-        assert np.max(np.abs(got['occu_' + tag] - ref['occu'])[ok]) <= 8e-2
+        assert np.max(np.abs(got['occu_' + tag] - ref['occu'])) <= 8e-2
         assert np.quantile(err, 0.9) <= 5e-3  # the bulk is far inside the bound
-    # resampled depths: same discontinuity (weights of the last bin), compare the stable rays
-    dz = np.abs(got['z_all'] - aux['z_all'])[ok_c]
-    # a sample may hop one coarse bin (bin width (far-near)/63 = 0.0635)
+    plain = {k: v.cpu().numpy() for k, v in _render_device(rayo, rayd, nets, cuda, refine=False).items()}
+    flips = np.abs(plain['occu_f'] - fine['occu']) > 0.1
+    print("32 x 32 frame: %d rays in the |sigma_last| < 0.06 band; without the fp32-class last sample %d rays flip "
+          "occupancy, max |d rgb| %.3e; with it %.3e" % (int(in_band.sum()), int(flips.sum()),
+          np.abs(plain['rgb_f'] - fine['rgb']).max(), np.abs(got['rgb_f'] - fine['rgb']).max()))
+    # resampled depths: a sample may hop one coarse bin (bin width (far-near)/63 = 0.0635)
+    dz = np.abs(got['z_all'] - aux['z_all'])
     assert np.quantile(dz, 0.99) <= 0.07 and dz.mean() <= 5e-3
 
 
@@ -275,7 +286,7 @@ def test_full_frame_properties(nfx_lib, cuda):
     for k in ('rgb_c', 'rgb_f', 'z_all'):
         assert torch.equal(out[k][sel], sub[k]), k
     # ... and those 4096 rays OF THE FULL-SIZE FRAME against the CPU oracle (torch-CPU fp32 port of the reference op
-    # sequence): PSNR >= 40 dB; max-abs <= 3e-2 outside the last-sample discontinuity band, counted
+    # sequence): PSNR >= 40 dB; max-abs <= 3e-2 on every ray (the last sample's density is fp32-class)
     import torch as _t
     from oracle import torch_ref
     tn = [torch_ref.to_torch_net(n) for n in nets]
@@ -285,9 +296,9 @@ def test_full_frame_properties(nfx_lib, cuda):
     assert nerf_ref.psnr_uint8_luma(got, want) >= 40.
     stable = np.minimum(aux['sigma_last_coarse'].numpy(), aux['sigma_last_fine'].numpy()) > 0.06
     err = np.abs(got - want).max(1)
-    print("full frame subset: %d of 4096 rays in the discontinuity band, max-abs %.3e outside, %.3e overall" % (
-        int((~stable).sum()), err[stable].max(), err.max()))
-    assert err[stable].max() <= 4e-2 and np.quantile(err[stable], 0.99) <= 3e-2 and stable.mean() > 0.7
+    print("full frame subset: %d of 4096 rays in the |sigma_last| < 0.06 band (NOT excused since r04), max-abs %.3e "
+          "over all rays" % (int((~stable).sum()), err.max()))
+    assert err.max() <= 3e-2, (err.max(), int((err > 3e-2).sum()))
 
 
 def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):

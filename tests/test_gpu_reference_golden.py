@@ -51,14 +51,16 @@ def test_nerf_plugin_render_vs_reference_outputs(nfx_lib, cuda, prec):
     batch = (['x'] * n, torch.tensor([[8, 8]] * n), dev(rayo, cuda), dev(rayd, cuda), dev(gt, cuda))
     pred, gt_t, loss_kwargs, to_vis = model(batch, mode='test')
     # rays whose last-sample logit sits inside the rounding noise flip between "hit" and "background"
-    # (dist_last = 1e10, nerf.py:186-191): excluded from the max-abs bound only (see test_gpu_nerf.py)
+    # (dist_last = 1e10, nerf.py:186-191).  precision = bf16 (r04): the plugin evaluates that one sample fp32-class
+    # (models/nerf.py last_sample_precision), so ALL 64 rays are held to the bound — 8 of them sit inside the 0.06 band
+    # rounds 1-3 excused.  precision = fp32: the 1e-2 band of the fp32-class kernel itself (no ray of this fixture inside).
     _, _, aux = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1])
-    band = 0.06 if prec == 'bf16' else 1e-2
-    ok_c = np.abs(aux['rgbs_coarse'][:, -1, 3]) > band
-    ok_f = ok_c & (np.abs(aux['rgbs_fine'][:, -1, 3]) > band)
-    # 56 of the 64 rays of this glorot ("opaque variant") fixture are outside the band (8 inside, counted here; the fitted
-    # weights of test_trained_nerf_1024_rays_vs_reference_outputs have < 2 % inside) — an exact count, so a drift of the oracle shows
-    assert int(ok_f.sum()) == (56 if prec == 'bf16' else 64), int(ok_f.sum())
+    band = 0. if prec == 'bf16' else 1e-2
+    ok_c = np.abs(aux['rgbs_coarse'][:, -1, 3]) >= band
+    ok_f = ok_c & (np.abs(aux['rgbs_fine'][:, -1, 3]) >= band)
+    assert int(ok_f.sum()) == 64, int(ok_f.sum())
+    in_r03_band = (np.abs(aux['rgbs_coarse'][:, -1, 3]) <= 0.06) | (np.abs(aux['rgbs_fine'][:, -1, 3]) <= 0.06)
+    assert int(in_r03_band.sum()) == 8, int(in_r03_band.sum())     # an exact count, so a drift of the oracle shows
     tol_rgb, tol_occu, tol_med = (3e-2, 8e-2, 5e-3) if prec == 'bf16' else (2e-3, 2e-3, 1e-4)
     for lvl, ok in (('coarse', ok_c), ('fine', ok_f)):
         rgb = to_vis[lvl + '_rgb'].cpu().numpy()
