@@ -385,6 +385,11 @@ NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, co
  * lane maps documented in DESIGN.md; used by the GPU tests to pin the fragment layout. */
 NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
 /* out[i] = (which ? cos : sin)(in[i]) with the kernel's own range reduction.  */
+/* D[32][32] = H^T Z (fp32 in, bf16 operands, fp32 out) for two row-major [16 rows][32 slots] tiles, contracted over the
+ * ROW axis through LDS and ds_read_b64_tr_b16 exactly as the fused weight-gradient kernels do (csrc/tr16.hpp).
+ * mode 1: D[256] = the raw lane map of the instruction (lane l reads LDS bytes 8 l .. 8 l + 7 of a tile holding its own
+ * 16-bit element indices). */
+NFX_API int nfx_selftest_tr16(const float *dev_h, const float *dev_z, float *dev_d, int mode, void *stream);
 NFX_API int nfx_selftest_sincos(const float *dev_in, int64_t n, int which, float *dev_out, void *stream);
 
 #ifdef __cplusplus

@@ -89,6 +89,7 @@ SIGNATURES = {
     'nfx_nerf_sigma_grad': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
+    'nfx_selftest_tr16': (_i, [_p, _p, _p, _i, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -311,6 +311,11 @@ int nfx_selftest_mfma_bf16(const float* a, const float* b, float* d, void* strea
     REQUIRE(a && b && d, "nfx_selftest_mfma_bf16: null pointer");
     return hip_result(nfx_launch_selftest_mfma(a, b, d, (hipStream_t)stream), "selftest_mfma");
 }
+int nfx_launch_selftest_tr16(const float*, const float*, float*, int, hipStream_t);
+int nfx_selftest_tr16(const float* h, const float* z, float* d, int mode, void* stream) {
+    REQUIRE(d && (mode == 1 || (h && z)), "nfx_selftest_tr16: null pointer");
+    return hip_result(nfx_launch_selftest_tr16(h, z, d, mode, (hipStream_t)stream), "selftest_tr16");
+}
 int nfx_selftest_sincos(const float* in, int64_t n, int which, float* out, void* stream) {
     REQUIRE(n >= 0 && (n == 0 || (in && out)), "nfx_selftest_sincos: bad arguments");
     return hip_result(nfx_launch_selftest_sincos(in, n, which, out, (hipStream_t)stream), "selftest_sincos");

@@ -23,6 +23,10 @@ extern "C" int nfx_option_int(const char* name, int dflt);
 extern "C" {
 int nfx_launch_mlp128_bwd(int, const float*, const float*, long long, float, const float*, int, const void*, int,
                           int, float, const float*, void*, long long, int, hipStream_t);
+int nfx_launch_mlp128_bwd_fused(int, const float*, const float*, long long, float, const float*, int, const void*, int, int,
+                                float, const float*, float*, int, float* const*, float* const*, hipStream_t);
+size_t nfx_mlp128_fused_partial_floats(int in_kind, int grid);
+int nfx_mlp128_fused_grid(int in_kind, long long n, int n_lights, int max_blocks);
 int nfx_mlp128_train_feats(int in_kind);
 int nfx_mlp128_train_blob_bytes(int in_kind);
 struct nfx_wgrad_call {   // one weight-gradient GEMM of a batched launch (train.hip)
@@ -113,8 +117,15 @@ static size_t mlp128_feat_bytes(int in_kind, int64_t n, int n_lights) {
     return ((size_t)nfx_mlp128_train_feats(in_kind) * ld_for(in_kind, n, n_lights) * 2 + 255) / 256 * 256;
 }
 
+// option wgrad_fused (default 1): weight gradients accumulated inside the backward kernels (mlp128_bwd_fused.hip); the
+// workspace then holds only the per-workgroup partial sums.  0 = the round-3 path (activations stored, GEMM launches).
+static bool fused_wgrad() { return nfx_option_int("wgrad_fused", 1) != 0; }
+
 size_t nfx_mlp128_bwd_workspace_bytes(int in_kind, int64_t n, int n_lights) {
     if (!kind_ok(in_kind) || n <= 0) return 0;
+    if (fused_wgrad())
+        return nfx_mlp128_fused_partial_floats(in_kind, nfx_mlp128_fused_grid(in_kind, n, n_lights,
+                                                                            nfx_option_int("m128_blocks", 256))) * sizeof(float);
     nfx_wgrad_call calls[6];
     mlp128_wgrad_calls(in_kind, 8, calls);
     const long long rows = in_kind == NFX_IN_XYZ ? n : n * (long long)n_lights;
@@ -140,6 +151,13 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 16))
         return nfx_fail(NFX_EALIGN, "nfx_mlp128_bwd: blob and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (fused_wgrad()) {
+        const int grid = nfx_mlp128_fused_grid(in_kind, n, n_lights, nfx_option_int("m128_blocks", 256));
+        return nfx_hip_result(nfx_launch_mlp128_bwd_fused(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights,
+                                                          blob, out_dim, out_act, post_scale, dout,
+                                                          static_cast<float*>(workspace), grid, dkernels, dbiases, st),
+                              "mlp128_bwd(fused)");
+    }
     const long long ld = ld_for(in_kind, n, n_lights);
     REQUIRE(12 * ld < (1ll << 32), "nfx_mlp128_bwd: at most %lld rows per call (got %lld; feat_store.hpp's 32-bit lane offsets)",
             (1ll << 32) / 12 - 256, ld);

@@ -14,6 +14,7 @@
 #include "geom.hpp"
 #include "lds_dma.hpp"
 #include "mlp128_layout.hpp"
+#include "mlp128_train_layout.hpp"
 #include "mlp_engine.hpp"
 #include "feat_store.hpp"
 
@@ -22,35 +23,6 @@ namespace bwd {
 
 constexpr int kNW = 4;  // one wave per SIMD: the re-computed activations + gradients need > 256 registers
 constexpr int kRows = kNW * 32;
-
-// Train-blob chunk geometry, KSX = k-steps of the network input (4: posenc10(xyz); 6: + posenc4(ldir)).
-template <int KSX>
-struct Geo {
-    static constexpr int kP0 = KSX <= 4 ? 4 : 8;           // frags per L0 chunk
-    static constexpr int kP3 = KSX <= 4 ? 12 : 16;         // frags per L3 chunk (8 + KSX used)
-    static constexpr int kNL0 = kP0 / 4, kNLH = 2, kNL3 = kP3 / 4, kNLO = 2, kNLD = 1;
-    static constexpr int kFwdFrags = 4 * kP0 + 32 + 32 + 4 * kP3 + 8;
-    static constexpr int kBwdFrags = 4 * 4 + 3 * 32;
-    static constexpr int kWeightBytes = (kFwdFrags + kBwdFrags) * 1024;
-    static constexpr int kBiasFloats = m128::kMainBiasFloats;  // 544
-    static constexpr int kBlobBytes = kWeightBytes + kBiasFloats * 4;
-    static constexpr int kXFeats = KSX * 16;               // 64 or 96 stored input features
-    // feature-major workspace rows
-    static constexpr int kOffH = kXFeats;                   // h0..h3: 4 x 128
-    static constexpr int kOffDZ = kXFeats + 512;            // dZ0..dZ3: 4 x 128
-    static constexpr int kOffDZo = kXFeats + 1024;          // dZ_out: 8
-    static_assert(kXFeats % 2 == 0, "feature-pair-major storage (feat_store.hpp): every group starts on an even feature");
-    static constexpr int kFeats = kXFeats + 1032;
-};
-
-__device__ __forceinline__ float act_grad(float logit, int act) {
-    switch (act) {
-        case 1: return logit > 0.f ? 1.f : 0.f;
-        case 2: { const float s = sigmoidf(logit); return s * (1.f - s); }
-        case 3: return sigmoidf(logit);  // d softplus
-        default: return 1.f;
-    }
-}
 
 // dgrad layer: dH^T = W dZ^T (NT tiles of 32 input features), ReLU-masked by the activation `hact`
 // the features belong to; result = next dZ (bf16, B layout).

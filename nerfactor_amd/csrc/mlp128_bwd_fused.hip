@@ -1,0 +1,526 @@
+// mlp128_bwd_fused.hip — backward of the width-128 surface MLPs with the WEIGHT GRADIENTS ACCUMULATED ON CHIP
+// (round 4; tape.gradient of trainvali.py:284 through shape.py:196-237 / nerfactor.py:377-411).
+//
+// Round 3's backward (mlp128_bwd.hip) stores every layer's input and pre-activation gradient — 1130 bf16 features per
+// row, 2.37 GB for the 1 048 576 light-visibility rows of a 1024-ray step — and a separate GEMM launch reads them back:
+// 4.7 GB of HBM traffic for a few MB of algorithmic input / output, both kernels at the 64-requests-per-CU ceiling
+// (DESIGN.md section 3b).  Here nothing but the weight gradients leaves the CU:
+//
+//   * one workgroup = 4 waves x 32 rows, persistent over its 128-row tiles; per tile it re-computes the forward and
+//     runs the dgrad chain exactly like mlp128_bwd_ring_kernel (same MFMA order, same operand registers);
+//   * when dZ_l of a tile exists, each wave writes its 32 rows of dZ_l and of the layer's input H_{l-1} ROW-MAJOR into
+//     two LDS buffers ([128 rows][128 slots] bf16, one ds_write_b128 per B-operand register: a lane holds 8 slots of
+//     its row), and after one barrier reads them back with the TRANSPOSING LDS load of gfx950
+//     (ds_read_b64_tr_b16: a 16-lane group turns a [4 rows][16 slots] block into "4 rows of one slot per lane") as
+//     MFMA operands whose K dimension is the ROW axis:   dW[i, j] += sum_rows H[row, i] dZ[row, j];
+//   * wave w owns the 32 dZ slots [32 w, 32 w + 32) of every layer and ALL input slots: its dW blocks (32 x 32 fp32
+//     = 16 VGPRs each) stay in registers for the whole launch and are written once, at the end, to a per-workgroup
+//     slice of `partial`; mlp128_wgrad_reduce_kernel adds the slices IN WORKGROUP ORDER into dkernels / dbiases
+//     (deterministic: no atomics) and undoes the slot permutations (B-operand slot <-> logical feature);
+//   * bias gradients ride along: the positional-encoding operand has a zero pad slot, set to 1.0 here (its forward
+//     weights are zero), so the dW row of that slot IS db of layers 0 and 3; layers 1, 2 and `out` take one more
+//     MFMA per k-step with an all-ones A operand;
+//   * 19 + 3 blocks = 352 accumulator registers do not fit beside the chain's ~270: the layers are split over TWO
+//     launches (PART 0: layer 3, out, layer 0 — 12 blocks; PART 1: layers 2, 1 — 10 blocks), each re-running the chain.
+//     The chain costs 252 MFMAs per 32 rows, the weight gradients 176: 680 instead of 428 matrix instructions per
+//     32 rows, against 2.3 KB of HBM traffic per row removed.
+//   * ALL weights (forward + dgrad, 248-304 KiB per tile from L2) stream through the 5-slot LDS-DMA ring of
+//     mlp128_bwd.hip, extended by the 14 dgrad sub-chunks: with no store in the tile loop the counted vmcnt waits see
+//     DMA pieces (and the tile's few input loads, which only make a wait conservative).
+// LDS: ring 40 KiB | biases | X rows | H rows | dZ rows = 145 536 bytes (row pitch = slots x 2 + 32 bytes: the four
+// rows of a transposing read land on distinct banks, and so do the 16-byte row stores of 8 consecutive lanes).
+#include "mlp_engine.hpp"
+#include "lds_dma.hpp"
+#include "mlp128_train_layout.hpp"
+#include "tr16.hpp"
+
+namespace nfx {
+namespace bwd {
+namespace fused {
+
+constexpr int kNW = 4, kRows = kNW * 32;
+constexpr int kR = 5, kD = 4, kSlot = 8192;
+constexpr int kFwdSub = 21, kSubN = 35;   // sub-chunks per tile: forward 0-20, dgrad through `out` 21-22, W3 23-26, W2 27-30, W1 31-34
+constexpr int kHPitch = 128 * 2 + 32;     // bytes per row of the H / dZ buffers
+
+template <int KSX>
+struct Sub {
+    using G = Geo<KSX>;
+    static constexpr int frags(int k) {
+        return k < 4 ? G::kP0 : k < 12 ? 8 : k < 20 ? ((k - 12) % 2 == 0 ? 8 : G::kP3 - 8) : 8;
+    }
+    static constexpr int off(int k) {   // first fragment in the train blob
+        return k < 4 ? k * G::kP0 : k < 8 ? 4 * G::kP0 + (k - 4) * 8 : k < 12 ? 4 * G::kP0 + 32 + (k - 8) * 8
+             : k < 20 ? 4 * G::kP0 + 64 + ((k - 12) / 2) * G::kP3 + ((k - 12) % 2) * 8
+             : k == 20 ? 4 * G::kP0 + 64 + 4 * G::kP3
+             : G::kFwdFrags + (k - kFwdSub) * 8;   // the 112 dgrad fragments are contiguous: 14 sub-chunks of 8
+    }
+    static constexpr int pieces(int k) { return frags(k) / kNW; }   // 1-KiB pieces per wave: 1 | 2
+    static constexpr int allow(int k) {   // pieces that may still be in flight when sub-chunk k + 1 must have landed
+        int n = 0;
+        for (int j = 2; j <= kD; ++j) n += pieces((k + j) % kSubN);
+        return n;
+    }
+};
+static_assert(Sub<6>::off(kFwdSub) == Geo<6>::kFwdFrags && Sub<6>::off(kSubN - 1) + 8 == Geo<6>::kFwdFrags + Geo<6>::kBwdFrags, "blob");
+static_assert(Sub<4>::off(kFwdSub) == Geo<4>::kFwdFrags && Sub<4>::off(kSubN - 1) + 8 == Geo<4>::kFwdFrags + Geo<4>::kBwdFrags, "blob");
+
+template <int KSX>
+struct Lds {
+    static constexpr int kXPitch = KSX * 32 + 32;   // KSX k-steps x 16 slots x 2 B + pad
+    static constexpr int kBias = kR * kSlot;
+    static constexpr int kX = kBias + m128::kMainBiasFloats * 4;
+    static constexpr int kH = kX + kRows * kXPitch;
+    static constexpr int kDZ = kH + kRows * kHPitch;
+    static constexpr int kTotal = kDZ + kRows * kHPitch;
+    static_assert(kX % 16 == 0 && kH % 16 == 0 && kDZ % 16 == 0 && kXPitch % 16 == 0, "16-byte rows");
+    static_assert(kTotal <= 160 * 1024, "LDS");
+};
+
+// blocks of 32 x 32 weight-gradient accumulators per wave and launch
+template <int KSX, int PART>
+struct Blocks {
+    static constexpr int NX = KSX / 2;                      // 32-slot tiles of the network input
+    // PART 0: [0, 4) W3 rows of h2 | [4, 4 + NX) W3 rows of the input | out | out bias | [6 + NX, 6 + 2 NX) W0
+    // PART 1: [0, 4) W2 | 4 bias 2 | [5, 9) W1 | 9 bias 1
+    static constexpr int kW3h = 0, kW3x = 4, kOut = 4 + NX, kOutB = 5 + NX, kW0 = 6 + NX;
+    static constexpr int kW2 = 0, kB2 = 4, kW1 = 5, kB1 = 9;
+    static constexpr int N = PART == 0 ? 6 + 2 * NX : 10;
+};
+
+struct Ctx {
+    char* smem;
+    unsigned smem_lds;
+    const char* blob;
+    int lane, wave;   // wave: wave-uniform
+    int cur;          // ring slot of the sub-chunk being consumed (wave-uniform)
+};
+template <int KSX, int K>
+__device__ __forceinline__ void begin(const Ctx& cx) {
+    constexpr int F = (K + kD) % kSubN, n = Sub<KSX>::pieces(F);
+    unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
+    unsigned lds = cx.smem_lds;
+    asm volatile("" : "+s"(base), "+s"(lds));   // per sub-chunk: keeps the addresses out of the loop preheader
+    int slot = cx.cur + kD;
+    slot = slot >= kR ? slot - kR : slot;
+    const int piece0 = cx.wave * n;
+    lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX>::off(F) * 1024 + piece0 * 1024,
+                      lds + (unsigned)slot * kSlot + (unsigned)piece0 * 1024u);
+}
+template <int KSX, int K>
+__device__ __forceinline__ void end(Ctx& cx) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Sub<KSX>::allow(K)) : "memory");
+    cx.cur = cx.cur + 1 == kR ? 0 : cx.cur + 1;
+}
+// acc += A(current slot, fragments f0 .. f0 + KS - 1) x b[0 ...]
+template <int KS, int KSA>
+__device__ __forceinline__ void mma(const Ctx& cx, const bf16x8 (&b)[KSA][1], int f0, f32x16& acc) {
+    const char* p = cx.smem + cx.cur * kSlot + f0 * kFragBytes + cx.lane * 16;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][0], acc, 0, 0, 0);
+    }
+}
+// ReLU mask of a pre-activation tile as bits (word t >> 1, bit 16 (t & 1) + r <-> accumulator register r of tile t): a
+// layer whose activation this launch needs only as the dgrad mask keeps 2 registers instead of 32 (the launches differ
+// in which activations they multiply: PART 0 h3, h2, input; PART 1 h1, h0)
+__device__ __forceinline__ void mask_bits(const f32x16& acc, int t, unsigned (&m)[2]) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+    asm volatile("" : "+v"(bits));   // opaque: the backward reads the BIT, the compare results do not stay alive
+    if (t & 1) m[t >> 1] |= bits << 16;
+    else m[t >> 1] = bits;
+}
+// one forward layer of 4 tiles whose chunk is ONE sub-chunk each (K0 = its first sub-chunk)
+template <int KSX, int K0, int KS, bool BITS, int KSA>
+__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[2]) {
+    static_for<0, 4>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        begin<KSX, K0 + t>(cx);
+        f32x16 acc[1];
+        bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);
+        mma<KS>(cx, b, 0, acc[0]);
+        end<KSX, K0 + t>(cx);
+        if constexpr (BITS) mask_bits(acc[0], t, mk);
+        acc_to_b<true, 1>(acc, out[2 * t], out[2 * t + 1]);
+    });
+}
+__device__ __forceinline__ void zero_acc(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+// ReLU mask of tile t of a layer: from the re-computed activation (BITS = false) or from its mask bits
+template <bool BITS>
+__device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[2], int t,
+                                          bf16x8& olo, bf16x8& ohi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bool on;
+        if constexpr (BITS) on = (mk[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
+        else on = (float)hact[2 * t + (r >> 3)][0][r & 7] > 0.f;
+        const __bf16 v = (__bf16)(on ? acc[r] : 0.f);
+        if (r < 8) olo[r & 7] = v;
+        else ohi[r & 7] = v;
+    }
+    mfma_operand_fence(olo);
+    mfma_operand_fence(ohi);
+}
+// dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation `hact`
+template <int KSX, int K0, bool BITS>
+__device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
+                                      bf16x8 (&dout)[8][1]) {
+    static_for<0, 4>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        begin<KSX, K0 + t>(cx);
+        f32x16 acc[1];
+        zero_acc(acc[0]);
+        mma<8>(cx, dz, 0, acc[0]);
+        end<KSX, K0 + t>(cx);
+        relu_mask<BITS>(acc[0], hact, mk, t, dout[2 * t][0], dout[2 * t + 1][0]);
+    });
+}
+
+// ---- rows -> LDS, LDS -> row-contracting MFMA operands
+// lane (row p, half h) stores the 8 slots of k-step s at row * pitch + s * 32 + h * 16: slot index = 16 s + 8 h + j
+template <int KS, int KSA>
+__device__ __forceinline__ void store_rows(char* row_half, const bf16x8 (&v)[KSA][1]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(row_half + s * 32) = v[s][0];
+}
+// acc[i] += A(tile i of the buffer at `a`, pitch APITCH)^T-contracted-over-rows with B = this wave's dZ tile at `b`;
+// ONES: one more MFMA per k-step whose A operand is all ones (every row of bacc = the column sums = the bias gradient)
+template <int NI, int APITCH, int A0, int ONES, int NA>   // A0: first accumulator block; ONES: block of the all-ones product, or -1
+__device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc)[NA]) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    const b8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+#pragma unroll
+    for (int kk = 0; kk < kRows / 16; ++kk) {
+        const bf16x8 bf = tr_frag<kHPitch>(b + kk * 16 * kHPitch);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bf16x8 af = tr_frag<APITCH>(a + kk * 16 * APITCH + i * 64);
+            acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[A0 + i], 0, 0, 0);
+        }
+        if constexpr (ONES >= 0)
+            acc[ONES] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), bf, acc[ONES], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // one k-step's operands at a time: the scheduler otherwise hoists every read of the
+                                             // step (80 fragment registers) above the first MFMA and the accumulators spill
+    }
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// IN_KIND 0: posenc10(xyz_scale*xyz) ; 1: [posenc10(xyz_scale*xyz), posenc4(normalize(lxyz_l - xyz_dir))]
+template <int IN_KIND, int PART>
+__global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ xyz_dir, long long n, float xyz_scale,
+    const float* __restrict__ lxyz, int n_lights, const char* __restrict__ blob, int out_dim, int out_act,
+    float post_scale, const float* __restrict__ dout, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSX = IN_KIND == 0 ? 4 : 6;
+    using G = Geo<KSX>;
+    using S = Sub<KSX>;
+    using L = Lds<KSX>;
+    using B = Blocks<KSX, PART>;
+    constexpr int NX = B::NX;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* bias_lds = reinterpret_cast<float*>(smem + L::kBias);
+    {
+        const float* bsrc = reinterpret_cast<const float*>(blob + G::kWeightBytes);
+        for (int i = tid; i < G::kBiasFloats; i += kNW * 64) bias_lds[i] = bsrc[i];
+#pragma unroll
+        for (int k = 0; k < kD; ++k) {   // sub-chunks 0 .. kD-1 of the first tile -> slots 0 .. kD-1
+            const u32x4* src = reinterpret_cast<const u32x4*>(blob + (size_t)S::off(k) * 1024);
+            u32x4* dst = reinterpret_cast<u32x4*>(smem + k * kSlot);
+            for (int i = tid; i < S::frags(k) * 64; i += kNW * 64) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    typedef __attribute__((address_space(3))) char lds_char;
+    Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave, 0};
+    // this lane's row of the three row-major buffers (stores) and its gather origin (transposing reads)
+    const int row_local = wave * 32 + p;
+    char* xrow = smem + L::kX + row_local * L::kXPitch + h * 16;
+    char* hrow = smem + L::kH + row_local * kHPitch + h * 16;
+    char* zrow = smem + L::kDZ + row_local * kHPitch + h * 16;
+    const char* xa = smem + L::kX + tr_lane_off(lane, L::kXPitch);
+    const char* ha = smem + L::kH + tr_lane_off(lane, kHPitch);
+    const char* zb = smem + L::kDZ + tr_lane_off(lane, kHPitch) + wave * 64;   // dZ slots [32 wave, 32 wave + 32)
+    f32x16 acc[B::N];
+#pragma unroll
+    for (int i = 0; i < B::N; ++i) zero_acc(acc[i]);
+
+    const long long n_rows = IN_KIND == 0 ? n : n * n_lights;
+    const long long n_tiles = (n_rows + kRows - 1) / kRows;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row = tile * kRows + row_local;
+        const bool valid = row < n_rows;
+        const long long rc = valid ? row : n_rows - 1;
+        const long long pt = IN_KIND == 0 ? rc : rc / n_lights;
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = xyz_scale * xyz[pt * 3 + k];
+        float dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 4 * h + r;
+            dv[r] = (valid && f < out_dim) ? dout[row * out_dim + f] : 0.f;
+        }
+        bf16x8 xin[KSX][1];
+        {
+            bf16x8 pe[4][1];
+            posenc<10, 1>(x, h, 0, pe);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xin[s][0] = pe[s][0];
+            // the zero pad slot of the encoding (q = 31 of lane half 1; its forward weights are zero, pack.cpp
+            // seg_row) carries 1.0: the dW row of that slot is the bias gradient of layers 0 and 3
+            if (h == 1) xin[3][0][7] = (__bf16)1.0f;
+        }
+        if constexpr (IN_KIND == 1) {
+            const int l = (int)(rc % n_lights);
+            float d[3], xd[3], lp[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xd[k] = xyz_dir[pt * 3 + k];
+                lp[k] = lxyz[l * 3 + k];
+            }
+            dir_to(lp, xd, d);
+            bf16x8 pl[2][1];
+            posenc<4, 1>(d, h, 0, pl);
+            xin[4][0] = pl[0][0];
+            xin[5][0] = pl[1][0];
+        }
+        if constexpr (PART == 0) store_rows<KSX>(xrow, xin);   // read by the W3 and W0 steps of this tile
+        // ------------------------------------------------------------------ forward (re-computed)
+        bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
+        unsigned m0[2], m1[2], m2[2], m3[2];   // ReLU mask bits of the activations this launch does not multiply
+        constexpr bool kBits01 = PART == 0, kBits23 = PART == 1;
+        layer<KSX, 0, KSX, kBits01>(cx, bias_lds, xin, h0, m0);
+        layer<KSX, 4, 8, kBits01>(cx, bias_lds + 128, h0, h1, m1);
+        layer<KSX, 8, 8, kBits23>(cx, bias_lds + 256, h1, h2, m2);
+        static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
+            constexpr int t = decltype(T)::value;
+            begin<KSX, 12 + 2 * t>(cx);
+            f32x16 a3[1];
+            bias_init<1>(bias_lds + 384 + 32 * t, h, a3);
+            mma<8>(cx, h2, 0, a3[0]);
+            end<KSX, 12 + 2 * t>(cx);
+            begin<KSX, 13 + 2 * t>(cx);
+            mma<KSX>(cx, xin, 0, a3[0]);
+            end<KSX, 13 + 2 * t>(cx);
+            if constexpr (kBits23) mask_bits(a3[0], t, m3);
+            acc_to_b<true, 1>(a3, h3[2 * t], h3[2 * t + 1]);
+        });
+        f32x16 logit[1];
+        begin<KSX, 20>(cx);
+        bias_init<1>(bias_lds + 512, h, logit);
+        mma<8>(cx, h3, 0, logit[0]);
+        end<KSX, 20>(cx);
+        // ------------------------------------------------------------------ dZ_out
+        bf16x8 dzo[1][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float g = dv[r] * post_scale * act_grad(logit[0][r], out_act);
+            dzo[0][0][r] = (__bf16)((valid && 4 * h + r < out_dim) ? g : 0.f);
+            dzo[0][0][4 + r] = (__bf16)0.f;
+        }
+        if constexpr (PART == 0) {   // out layer: dWo[i, f] = sum h3[row, i] dZo[row, f]; wave w takes h3 slots [32 w, +32)
+            store_rows<8>(hrow, h3);
+            store_rows<1>(zrow, dzo);
+            lds_barrier();
+            wgrad<1, kHPitch, B::kOut, B::kOutB>(ha + wave * 64, zb - wave * 64, acc);
+        }
+        // ------------------------------------------------------------------ dgrad chain + weight gradients
+        bf16x8 dz3[8][1], dz2[8][1], dz1[8][1], dz0[8][1];
+        {   // through the out layer: one k-step (16 padded output slots); tiles 0, 1 in sub-chunk 21, tiles 2, 3 in 22
+            static_for<0, 2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                begin<KSX, 21 + u>(cx);
+                f32x16 a0[1], a1[1];
+                zero_acc(a0[0]);
+                zero_acc(a1[0]);
+                mma<1>(cx, dzo, 0, a0[0]);
+                mma<1>(cx, dzo, 4, a1[0]);
+                end<KSX, 21 + u>(cx);
+                relu_mask<kBits23>(a0[0], h3, m3, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
+                relu_mask<kBits23>(a1[0], h3, m3, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
+            });
+        }
+        if constexpr (PART == 0) {   // W3 = [h2 ; input]^T dZ3 (the two ring barriers above separate it from the out step)
+            store_rows<8>(hrow, h2);
+            store_rows<8>(zrow, dz3);
+            lds_barrier();
+            wgrad<4, kHPitch, B::kW3h, -1>(ha, zb, acc);
+            wgrad<NX, L::kXPitch, B::kW3x, -1>(xa, zb, acc);
+        }
+        dgrad<KSX, 23, kBits23>(cx, dz3, h2, m2, dz2);   // W3[:128, :]
+        if constexpr (PART == 1) {
+            store_rows<8>(hrow, h1);
+            store_rows<8>(zrow, dz2);
+            lds_barrier();
+            wgrad<4, kHPitch, B::kW2, B::kB2>(ha, zb, acc);
+        }
+        dgrad<KSX, 27, kBits01>(cx, dz2, h1, m1, dz1);   // W2
+        if constexpr (PART == 1) {
+            store_rows<8>(hrow, h0);
+            store_rows<8>(zrow, dz1);
+            lds_barrier();
+            wgrad<4, kHPitch, B::kW1, B::kB1>(ha, zb, acc);
+        }
+        dgrad<KSX, 31, kBits01>(cx, dz1, h0, m0, dz0);   // W1
+        if constexpr (PART == 0) {
+            store_rows<8>(zrow, dz0);
+            lds_barrier();
+            wgrad<NX, L::kXPitch, B::kW0, -1>(xa, zb, acc);
+            lds_barrier();   // the next tile's first statement rewrites the X rows
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sub-chunks fetched ahead for a tile that does not exist
+    // ------------------------------------------------------------------ accumulators -> this workgroup's slice
+    float* mine = partial + ((size_t)blockIdx.x * kNW + wave) * (size_t)(B::N * 1024) + lane;
+#pragma unroll
+    for (int b = 0; b < B::N; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(b * 16 + r) * 64] = acc[b][r];
+}
+
+// ---- slot <-> logical feature (pack.cpp seg_row): slot c = 16 s + 8 h + j of a B operand
+__device__ __forceinline__ int hidden_feature(int c) {
+    const int s = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+    return 32 * (s >> 1) + 16 * (s & 1) + (j & 3) + 8 * (j >> 2) + 4 * hh;
+}
+constexpr int kSlotPad = -1, kSlotOnes = -2;
+// network input: posenc10(xyz) in k-steps 0-3 (Embedder order, embedder.py:38-47), posenc4(ldir) in 4-5 (features 63 ..)
+__device__ __forceinline__ int input_feature(int c) {
+    const int s = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+    if (s < 4) {
+        const int q = 8 * s + j;
+        if (q < 30) return 3 + 6 * (q / 3) + (q % 3) + 3 * hh;
+        if (q == 30) return hh ? 2 : 0;
+        return hh ? kSlotOnes : 1;
+    }
+    const int q = 8 * (s - 4) + j;
+    if (q < 12) return 63 + 3 + 6 * (q / 3) + (q % 3) + 3 * hh;
+    if (q == 12) return 63 + (hh ? 2 : 0);
+    if (q == 13) return hh ? kSlotPad : 64;
+    return kSlotPad;
+}
+
+struct ReduceArgs {
+    const float* part[2];
+    int n_wg, out_dim, in_dims;
+    float* dk[5];
+    float* db[5];
+};
+// One thread per accumulator element (part, wave, block, register, lane): the sum over the workgroups, in workgroup
+// order, added to the gradient element it stands for.
+template <int KSX>
+__global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceArgs a) {
+    constexpr int N0 = Blocks<KSX, 0>::N, N1 = Blocks<KSX, 1>::N, NX = KSX / 2;
+    using B0 = Blocks<KSX, 0>;
+    using B1 = Blocks<KSX, 1>;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kNW * (N0 + N1) * 1024) return;
+    const int lane = e & 63, r = (e >> 6) & 15;
+    int blk = (e >> 10) % (N0 + N1);
+    const int wave = (e >> 10) / (N0 + N1);
+    const int part = blk >= N0 ? 1 : 0;
+    if (part) blk -= N0;
+    const int nb = part ? N1 : N0;
+    const int n = lane & 31, m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // D element (row m, column n)
+    float* dst = nullptr;
+    const int jl = hidden_feature(32 * wave + n);   // the dZ slot of this column, as an output feature of its layer
+    if (part == 0) {
+        if (blk < B0::kW3x) dst = a.dk[3] + hidden_feature(32 * blk + m) * 128 + jl;
+        else if (blk < B0::kOut || blk >= B0::kW0) {
+            const int layer = blk < B0::kOut ? 3 : 0;
+            const int xf = input_feature(32 * (blk - (layer == 3 ? B0::kW3x : B0::kW0)) + m);
+            if (xf >= 0 && xf < a.in_dims) dst = a.dk[layer] + ((layer == 3 ? 128 : 0) + xf) * 128 + jl;
+            else if (xf == kSlotOnes) dst = a.db[layer] + jl;
+        } else {   // out layer: column n = dZo slot (half n >> 3, element n & 7) <-> output 4 (n >> 3) + (n & 7)
+            const int f = 4 * (n >> 3) + (n & 7);
+            if (n < 16 && (n & 7) < 4 && f < a.out_dim) {
+                if (blk == B0::kOut) dst = a.dk[4] + hidden_feature(32 * wave + m) * a.out_dim + f;
+                else if (wave == 0 && m == 0) dst = a.db[4] + f;
+            }
+        }
+    } else {
+        if (blk < B1::kB2) dst = a.dk[2] + hidden_feature(32 * blk + m) * 128 + jl;
+        else if (blk == B1::kB2) dst = m == 0 ? a.db[2] + jl : nullptr;
+        else if (blk < B1::kB1) dst = a.dk[1] + hidden_feature(32 * (blk - B1::kW1) + m) * 128 + jl;
+        else dst = m == 0 ? a.db[1] + jl : nullptr;
+    }
+    (void)NX;
+    if (dst == nullptr) return;
+    const float* src = a.part[part] + ((size_t)wave * nb + blk) * 1024 + r * 64 + lane;
+    const size_t stride = (size_t)kNW * nb * 1024;
+    float s = 0.f;
+    for (int g = 0; g < a.n_wg; ++g) s += src[g * stride];
+    *dst += s;
+}
+
+}  // namespace fused
+}  // namespace bwd
+}  // namespace nfx
+
+template <int IN_KIND>
+static int launch_fused(const float* xyz, const float* xyz_dir, long long n, float xyz_scale, const float* lxyz, int n_lights,
+                        const void* blob, int out_dim, int out_act, float post_scale, const float* dout, float* partial,
+                        int grid, float* const dk[5], float* const db[5], hipStream_t st) {
+    using namespace nfx::bwd::fused;
+    constexpr int KSX = IN_KIND == 0 ? 4 : 6;
+    constexpr int lds = Lds<KSX>::kTotal;
+    float* part1 = partial + (size_t)grid * kNW * Blocks<KSX, 0>::N * 1024;
+    auto k0 = mlp128_bwd_fused_kernel<IN_KIND, 0>;
+    auto k1 = mlp128_bwd_fused_kernel<IN_KIND, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k0, dim3(grid), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights,
+                       (const char*)blob, out_dim, out_act, post_scale, dout, partial);
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights,
+                       (const char*)blob, out_dim, out_act, post_scale, dout, part1);
+    ReduceArgs ra;
+    ra.part[0] = partial;
+    ra.part[1] = part1;
+    ra.n_wg = grid;
+    ra.out_dim = out_dim;
+    ra.in_dims = IN_KIND == 0 ? 63 : 90;
+    for (int i = 0; i < 5; ++i) {
+        ra.dk[i] = dk[i];
+        ra.db[i] = db[i];
+    }
+    const int elems = kNW * (Blocks<KSX, 0>::N + Blocks<KSX, 1>::N) * 1024;
+    hipLaunchKernelGGL(mlp128_wgrad_reduce_kernel<KSX>, dim3((elems + 255) / 256), dim3(256), 0, st, ra);
+    return (int)hipGetLastError();
+}
+
+extern "C" {
+// floats of `partial` one launch pair needs for `grid` workgroups
+size_t nfx_mlp128_fused_partial_floats(int in_kind, int grid) {
+    using namespace nfx::bwd::fused;
+    const int nb = in_kind == 0 ? Blocks<4, 0>::N + Blocks<4, 1>::N : Blocks<6, 0>::N + Blocks<6, 1>::N;
+    return (size_t)grid * kNW * nb * 1024;
+}
+int nfx_mlp128_fused_grid(int in_kind, long long n, int n_lights, int max_blocks) {
+    const long long rows = in_kind == 0 ? n : n * n_lights;
+    const long long tiles = (rows + nfx::bwd::fused::kRows - 1) / nfx::bwd::fused::kRows;
+    return (int)(tiles < max_blocks ? tiles : max_blocks);
+}
+
+// Fused backward + weight gradients of one width-128 network call: two kernel launches (the layers split over them)
+// and one ordered reduction into dkernels / dbiases (accumulated into, like nfx_launch_wgrad_batch).
+int nfx_launch_mlp128_bwd_fused(int in_kind, const float* xyz, const float* xyz_dir, long long n, float xyz_scale,
+                                const float* lxyz, int n_lights, const void* blob, int out_dim, int out_act,
+                                float post_scale, const float* dout, float* partial, int grid, float* const dk[5],
+                                float* const db[5], hipStream_t st) {
+    if (n <= 0) return 0;
+    return in_kind == 0 ? launch_fused<0>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blob, out_dim, out_act, post_scale, dout,
+                                          partial, grid, dk, db, st)
+                        : launch_fused<1>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blob, out_dim, out_act, post_scale, dout,
+                                          partial, grid, dk, db, st);
+}
+}

@@ -254,6 +254,19 @@ def selftest_mfma_bf16(a, b):
     return d
 
 
+def selftest_tr16(h=None, z=None):
+    """h, z: [16, 32] row-major tiles -> D[32, 32] = h^T z through LDS + ds_read_b64_tr_b16 (csrc/tr16.hpp); no arguments:
+    the instruction's raw lane map, [64, 4]."""
+    if h is None:
+        d = torch.empty((64, 4), dtype=torch.float32, device='cuda')
+        check(lib.nfx_selftest_tr16(None, None, _ptr(d), 1, _stream()), 'nfx_selftest_tr16')
+        return d
+    h, z = _dev(h, 'h', (16, 32)), _dev(z, 'z', (16, 32))
+    d = torch.empty((32, 32), dtype=torch.float32, device=h.device)
+    check(lib.nfx_selftest_tr16(_ptr(h), _ptr(z), _ptr(d), 0, _stream()), 'nfx_selftest_tr16')
+    return d
+
+
 def selftest_sincos(x, which):
     x = _dev(x, 'x')
     out = torch.empty_like(x)

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nerfactor_amd import optim  # noqa: E402
+from nerfactor_amd import _capi, optim  # noqa: E402
 from nerfactor_amd.nerfactor.config import make_config  # noqa: E402
 from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground  # noqa: E402
 from nerfactor_amd.nerfactor.models import get_model_class  # noqa: E402
@@ -19,7 +19,8 @@ path = 'gpurun_out/grad_identity.pt'
 out = {}
 for name, n in (('nerfactor_microfacet', 1024), ('nerfactor', 300), ('shape', 37), ('nerf', 200), ('nerf', 1024)):
     for lds in ('0', '1'):
-        os.environ['NFX_WGRAD_LDS'] = lds
+        _capi.set_option('wgrad_lds', int(lds))
+        _capi.set_option('wgrad_fused', 0)   # this script compares the stored-activation kernels
         torch.manual_seed(3)
         rng = np.random.default_rng(5)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)

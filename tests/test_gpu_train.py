@@ -53,9 +53,30 @@ def _check_grads(got, want, what, tol=4e-2):
     assert all(e[1] < tol for e in errs), "%s: (max/scale, frobenius rel, argmax) per layer = %s" % (what, errs)
 
 
-@pytest.mark.parametrize("out_dim,act,scale,n", [(3, 'sigmoid', .77, 1000), (3, None, 1., 77), (1, 'sigmoid', 1., 300)])
-def test_mlp128_xyz_backward_vs_autograd(nfx_lib, cuda, out_dim, act, scale, n):
+def test_transposing_lds_read_contracts_over_rows(nfx_lib, cuda):
+    """csrc/tr16.hpp: two row-major [16 rows][32 slots] tiles -> LDS -> ds_read_b64_tr_b16 -> one MFMA whose K axis is
+    the ROW axis must give H^T Z (random, non-symmetric tiles: a transposed or permuted operand cannot pass), and the
+    instruction's raw lane map is the one the header documents."""
     from nerfactor_amd import ops
+    rng = np.random.default_rng(5)
+    h = rng.integers(-8, 9, size=(16, 32)).astype(np.float32)      # exact in bf16, products exact in fp32
+    z = rng.integers(-8, 9, size=(16, 32)).astype(np.float32)
+    got = ops.selftest_tr16(dev(h, cuda), dev(z, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got, h.T @ z)
+    raw = ops.selftest_tr16().cpu().numpy().astype(np.int64)           # lane l read elements 4 l .. 4 l + 3 of its block
+    want = np.zeros((64, 4), np.int64)
+    for l in range(64):
+        i, base = l & 15, 64 * (l >> 4)                                # 16-lane group = a [4 rows][16 slots] block
+        for j in range(4):
+            want[l, j] = base + 16 * j + i                             # slot i of row j
+    np.testing.assert_array_equal(raw, want)
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("out_dim,act,scale,n", [(3, 'sigmoid', .77, 1000), (3, None, 1., 77), (1, 'sigmoid', 1., 300)])
+def test_mlp128_xyz_backward_vs_autograd(nfx_lib, cuda, nfx_opt, out_dim, act, scale, n, fused):
+    from nerfactor_amd import ops
+    nfx_opt.set("wgrad_fused", fused)     # 1: weight gradients accumulated on chip (mlp128_bwd_fused.hip); 0: the r03 path
     layers, out = net128(80 + out_dim, 63, out_dim)
     rng = np.random.default_rng(81)
     xyz = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
@@ -83,12 +104,17 @@ def test_mlp128_xyz_backward_vs_autograd(nfx_lib, cuda, out_dim, act, scale, n):
     _check_grads([d / 2 for d in dks], [k.grad for k in ks], 'dkernel x2', 0.2)
 
 
-@pytest.mark.parametrize("wgrad_lds", ["0", "1"])
-def test_lvis_backward_vs_autograd(nfx_lib, cuda, nfx_opt, wgrad_lds):
+@pytest.mark.parametrize("path,n", [("fused", 21), ("fused3", 23), ("gemm0", 21), ("gemm1", 21)])
+def test_lvis_backward_vs_autograd(nfx_lib, cuda, nfx_opt, path, n):
     from nerfactor_amd import ops
-    nfx_opt.set("wgrad_lds", wgrad_lds)   # both weight-gradient GEMM kernels (train.hip)
+    if path.startswith("fused"):          # weight gradients accumulated on chip, two launches + one ordered reduction
+        nfx_opt.set("wgrad_fused", 1)
+        if path == "fused3":              # 3 persistent workgroups: 30 tiles each, the weight ring wraps, a tail tile
+            nfx_opt.set("m128_blocks", 3)
+    else:                                 # the r03 path: activations stored, both weight-gradient GEMM kernels (train.hip)
+        nfx_opt.set("wgrad_fused", 0)
+        nfx_opt.set("wgrad_lds", path[-1])
     layers, out = net128(90, 90, 1)
-    n = 21
     rng, lxyz, _, xyz, _, _ = scene(n, 91)
     xyz_j = xyz + rng.normal(size=xyz.shape).astype(np.float32) * 0.01
     dout = rng.normal(size=(n, 512)).astype(np.float32)
@@ -109,6 +135,43 @@ def test_lvis_backward_vs_autograd(nfx_lib, cuda, nfx_opt, wgrad_lds):
         y.backward(torch.tensor(dout, dtype=torch.float64))
         _check_grads(dks, [k.grad for k in ks], 'dkernel', tol)
         _check_grads(dbs, [b.grad for b in bs], 'dbias', tol)
+
+
+@pytest.mark.parametrize("in_kind,n", [("xyz", 1500), ("lvis", 37)])
+def test_fused_weight_gradients_match_the_gemm_path(nfx_lib, cuda, nfx_opt, in_kind, n):
+    """Same bf16 products, fp32 sums in a different order: the fused kernels (slot-permuted accumulators, two launches,
+    workgroup-ordered reduction) against the stored-activation path, every gradient tensor within 2e-4 relative
+    Frobenius — an operand permutation or a missing block would be off by O(1) — and twice the same bits."""
+    from nerfactor_amd import ops
+    lv = in_kind == "lvis"
+    layers, out = net128(95, 90 if lv else 63, 1 if lv else 3)
+    rng, lxyz, _, xyz, _, _ = scene(n, 96)
+    xyz_j = xyz + rng.normal(size=xyz.shape).astype(np.float32) * 0.01
+    dout = rng.normal(size=(n, 512 if lv else 3)).astype(np.float32)
+    ks_np = [k for k, _ in layers] + [out[0][0]]
+    bs_np = [b for _, b in layers] + [out[0][1]]
+    kind = nfx_lib.IN_XYZ_LDIR if lv else nfx_lib.IN_XYZ
+    blob = ops.pack_mlp128_train_weights(ks_np, bs_np, kind, 1 if lv else 3).to(cuda)
+
+    def run(fused, blocks=None):
+        nfx_opt.set("wgrad_fused", fused)
+        if blocks:
+            nfx_opt.set("m128_blocks", blocks)
+        else:
+            nfx_opt.unset("m128_blocks")
+        dks = [torch.zeros(k.shape, device=cuda) for k in ks_np]
+        dbs = [torch.zeros(b.shape, device=cuda) for b in bs_np]
+        kw = dict(lxyz=dev(lxyz, cuda), xyz_dir=dev(xyz, cuda)) if lv else {}
+        ops.mlp128_bwd(kind, dev(xyz_j, cuda), dev(dout, cuda), blob, dks, dbs, out_act='sigmoid', xyz_scale=0.9, **kw)
+        return dks + dbs
+    want = run(0)
+    for blocks in (None, 5):
+        got = run(1, blocks)
+        for i, (g, w) in enumerate(zip(got, want)):
+            rel = float((g - w).norm() / (w.norm() + 1e-20))
+            assert rel < 2e-4, (in_kind, blocks, 'tensor %d' % i, rel)
+        again = run(1, blocks)
+        assert all(torch.equal(a, b) for a, b in zip(got, again)), "fused weight gradients are not bit-reproducible"
 
 
 def test_amsgrad_matches_keras_semantics(nfx_lib, cuda):
@@ -640,13 +703,18 @@ def test_shade_backward_finite_for_vanishing_roughness_and_mirror_lights(nfx_lib
 
 
 @pytest.mark.determinism
-@pytest.mark.parametrize("wgrad_lds", ["0", "1"])
+@pytest.mark.parametrize("wgrad_lds", ["0", "1", "fused"])
 def test_weight_gradients_are_bit_reproducible(nfx_lib, cuda, nfx_opt, wgrad_lds):
     """No float atomics in the weight-gradient path: every (row slab, dW block) stores its partial sum and a second
     kernel adds the slabs in slab order, so two runs of the same backward give identical bits — for the direct-load
-    kernel (short slabs in parallel) and for the LDS-staged one, for the width-128 and the NeRF networks."""
+    kernel (short slabs in parallel) and for the LDS-staged one, for the width-128 and the NeRF networks; "fused" = the
+    r04 default of the width-128 networks (accumulators in registers, per-workgroup slices added in workgroup order)."""
     from nerfactor_amd import ops
-    nfx_opt.set("wgrad_lds", wgrad_lds)
+    if wgrad_lds == "fused":
+        nfx_opt.set("wgrad_fused", 1)
+    else:
+        nfx_opt.set("wgrad_fused", 0)
+        nfx_opt.set("wgrad_lds", wgrad_lds)
     layers, out = net128(31, 90, 1)
     ks = [k for k, _ in layers] + [out[0][0]]
     bs = [b for _, b in layers] + [out[0][1]]
@@ -869,6 +937,8 @@ def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, nfx
         batch = (None, None, cam, t(np.zeros((n, 3))), t(rng.uniform(size=(n, 3))),
                  mark_all_foreground(torch.ones(n, 1, device=cuda)), xyz,
                  torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1), t(rng.uniform(size=(n, 512))))
+
+    nfx_opt.set('wgrad_fused', 0)   # the stored-activation path: the kernels this test compares (the fused kernels have their own)
 
     def grads(**env):
         for k in ('nerf_bwd', 'nerf_bwd_nw', 'm128_bwd'):
