@@ -579,8 +579,16 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     calls = calls[:steps * per_step].reshape(steps, per_step)  # per step: the calls in launch order
     big = calls.max(1)                                          # the largest call of a step (light visibility / fine net)
     tf = flops / dt / 1e12
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the reference's own ten steps (tests/golden/reference_grads.npz) through the same train path: step-1
+        # gradients, loss trajectory, parameters after the steps (tests/reference_steps.py; CPU oracle outside the timing)
+        from tests import reference_steps
+        tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev)
+        parity = reference_steps.summary(tag, reference_steps.metrics(tag, rmodel, rlosses, rgrad1))
     return {
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),
+        "parity": parity,
         "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
         "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
         "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
@@ -643,6 +651,99 @@ def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     }
 
 
+
+# ------------------------------------------------------------------------------------------------ relighting sweep (configs[4])
+SWEEP_VIEWS = 4
+
+
+def relight_sweep_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
+    """BASELINE.json configs[4], probe half: 8 novel environment maps x 4 test views through
+    Model.call(mode='test', relight_probes=True) (test.py:163-204): one step = the 4 views (x world under weak scaling),
+    every view's rays in contiguous ranges over the ranks, all 8 probes on every rank (sharding by
+    probe would repeat the light-visibility MLP 8 times)."""
+    from nerfactor_amd import synth
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    name = 'nerfactor_microfacet'
+    torch.manual_seed(5)
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none',
+                      test_envmap_dir='', xyz_jitter_std='0', precision=args.precision)
+    model = get_model_class(name)(cfg).to(dev)
+    for i, p in enumerate(synth.probes(N_PROBES, seed=20)):
+        model.add_probe('p%d' % i, p)
+    n = H * W
+    sh = Shards(n, rank, world, args.scaling)
+    n_views = SWEEP_VIEWS * sh.n_views
+    batches = []
+    for v in range(n_views):
+        hb = synth.surface_batch(n, seed=10 + v, n_lights=N_LIGHTS)      # SURVEY.md section 8d C5: seeds 10-13
+        batches.append(tuple(None if a is None else torch.from_numpy(a[sh.lo:sh.hi]).to(dev) for a in hb))
+    steps = max(1, args.steps // 2)
+
+    def step(k):
+        out = None
+        for b in batches:
+            out = model(b, mode='test', relight_probes=True)[0]['rgb_probes']
+        return out
+    elapsed, out = timed(step, steps, min(args.warmup, 2), barrier)
+    elapsed = max_over_ranks(elapsed)
+    assert torch.isfinite(out).all() and out.shape[1] == N_PROBES
+    return {
+        "workload": "nerfactor_microfacet relighting sweep (BASELINE.json configs[4]): %d test views x %d novel "
+                    "environment maps per step, 800x800 surface points per view (60 %% foreground), 512 lights, "
+                    "Model.call(mode='test', relight_probes=True)" % (n_views, N_PROBES),
+        "steps": steps, "views_per_step": n_views, "probes": N_PROBES,
+        "ms_per_step": elapsed / steps * 1e3, "ms_per_view": elapsed / steps * 1e3 / n_views * world,
+        "relit_images_per_s": n_views * N_PROBES * steps / elapsed,
+        "points_per_s": n_views * n * steps / elapsed,
+    }
+
+
+def nerf_fp32_class_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
+    """The headline render at the reference's own arithmetic class (VERDICT r03 #6 i): precision = fp32 = every MLP
+    operand a bf16 hi / lo pair, three MFMAs per product (nerf_mlp_x3.hip); a few steps, its own parity."""
+    from nerfactor_amd import synth
+    nets = synth.nerf_nets(seed=0)
+    blobs = [ops.pack_nerf_weights(*synth.nerf_layers(n), prec='fp32').to(dev) for n in nets]
+    sh = Shards(H * W, rank, world, args.scaling)
+    views, host_views = [], []
+    for v in range(sh.n_views):
+        ang = 0.7 * v
+        rayo, rayd = synth.camera_rays(H, W, cam_loc=(4 * np.cos(ang) * 0.8, 4 * np.sin(ang) * 0.8 - 0.1, 4 * 0.6))
+        host_views.append((rayo, rayd))
+        views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
+    steps = max(1, min(3, args.steps))
+    elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None, 'fp32'), steps, 1, barrier)
+    elapsed = max_over_ranks(elapsed)
+    assert torch.isfinite(rgb).all()
+    n_local = sh.hi - sh.lo
+    tf = sh.n_views * n_local * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT * steps / elapsed / 1e12
+    out = {"workload": "the headline NeRF render with precision = fp32 (bf16 hi / lo operand pairs, 3 MFMAs per product)",
+           "dtype": "bf16x3 (fp32-class)", "steps": steps, "rays_per_s": sh.rays_per_step_all_ranks * steps / elapsed,
+           "ms_per_step": elapsed / steps * 1e3,
+           "roofline": {"bound": "mfma", "kernel": "nerf_mlp_x3_kernel (whole step; achieved counts the ALGORITHMIC FLOPs "
+                                                   "once, the kernel executes three MFMAs per product)",
+                        "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
+                        "executed_tflops": 3 * tf, "traffic": None}}
+    if rank == 0 and not args.no_cpu_baseline:
+        _, idx, ref = nerf_cpu_reference(nets, *host_views[0], budget_s=0, timed_run=False)   # 1024 rays, no timing
+        sel = idx[(idx >= sh.lo) & (idx < sh.hi)]
+        keep = np.isin(idx, sel)
+        o, d = (torch.from_numpy(a[sel]).to(dev) for a in host_views[0])
+        got = nerf_render_step(ops, [(o, d)], blobs, prec='fp32').cpu().numpy()
+        want = ref[1]['rgb'].numpy()[keep]
+        err = np.abs(got - want).max(1)
+        sig = np.minimum(ref[2]['sigma_last_coarse'].numpy()[keep], ref[2]['sigma_last_fine'].numpy()[keep])
+        out["parity"] = {"psnr_db": psnr_uint8_luma(got, want), "max_abs_all_rays": float(err.max()),
+                         "q99_abs": float(np.quantile(err, 0.99)), "rays_compared": int(len(sel)),
+                         "rays_excluded_from_max_abs": 0, "rays_above_2e-4": int((err > 2e-4).sum()),
+                         "rays_with_abs_sigma_last_below_0.01": int((sig <= 1e-2).sum()),
+                         "reference": "oracle/torch_ref.py (fp32) on the same rays; stated tolerance 2e-4 on rgb (SURVEY.md "
+                                      "section 8d) for rays off the two discontinuities of the formula (alpha_last = "
+                                      "[sigma_last > 0], inverse-CDF bin edges), which are COUNTED here, not excluded"}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -650,7 +751,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat')
+    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat,relight,fp32_class')
     ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
     ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -699,6 +800,9 @@ def main():
             # (a check_numerics failure comes back as {"error": ...}, agreed on by all ranks inside the leg)
             train[name] = train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
     olat = olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'olat' in legs else None
+    relight = relight_sweep_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'relight' in legs else None
+    fp32c = nerf_fp32_class_leg(args, ops, dev, rank, world, barrier, max_over_ranks) \
+        if 'fp32_class' in legs and args.precision == 'bf16' else None
     if rank == 0:
         out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -718,6 +822,10 @@ def main():
             out["train"] = train
         if olat is not None:
             out["olat"] = olat
+        if relight is not None:
+            out["relight"] = relight
+        if fp32c is not None:
+            out["fp32_class"] = fp32c
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -18,12 +18,15 @@
 //     slice of `partial`; mlp128_wgrad_reduce_kernel adds the slices IN WORKGROUP ORDER into dkernels / dbiases
 //     (deterministic: no atomics) and undoes the slot permutations (B-operand slot <-> logical feature);
 //   * bias gradients ride along: the positional-encoding operand has a zero pad slot, set to 1.0 here (its forward
-//     weights are zero), so the dW row of that slot IS db of layers 0 and 3; layers 1, 2 and `out` take one more
-//     MFMA per k-step with an all-ones A operand;
-//   * 19 + 3 blocks = 352 accumulator registers do not fit beside the chain's ~270: the layers are split over TWO
-//     launches (PART 0: layer 3, out, layer 0 — 12 blocks; PART 1: layers 2, 1 — 10 blocks), each re-running the chain.
-//     The chain costs 252 MFMAs per 32 rows, the weight gradients 176: 680 instead of 428 matrix instructions per
-//     32 rows, against 2.3 KB of HBM traffic per row removed.
+//     weights are zero), so the dW row of that slot IS db of layers 0 and 3; for layers 1, 2 and `out` every lane adds
+//     the rows of the dZ operand it holds anyway (v_dot2c_f32_bf16 with a (1, 1) operand: 4 VALU per k-step, one
+//     register per layer — an all-ones MFMA block would cost 16);
+//   * 19 blocks = 304 accumulator registers do not fit beside the chain's ~270: the layers are split over TWO launches.
+//     PART 0 takes layer 3 and `out` (8 blocks) and STOPS behind dZ3: forward + one dgrad step, 23 weight sub-chunks per
+//     tile.  PART 1 takes layers 2, 1, 0 (11 blocks) and runs the whole chain (35 sub-chunks), keeping h2 / h3 only as
+//     ReLU mask bits.  Per 32 rows: 156 + 72 and 252 + 104 matrix instructions = 584 against 428 for one pass, against
+//     2.3 KB of HBM traffic per row removed.  (The first split — layer 3, out, layer 0 | layers 2, 1, both running the
+//     whole chain, bias by all-ones MFMA blocks — measured 571 + 564 us per 1 048 576 rows: profiles/r04/call_c.)
 //   * ALL weights (forward + dgrad, 248-304 KiB per tile from L2) stream through the 5-slot LDS-DMA ring of
 //     mlp128_bwd.hip, extended by the 14 dgrad sub-chunks: with no store in the tile loop the counted vmcnt waits see
 //     DMA pieces (and the tile's few input loads, which only make a wait conservative).
@@ -40,10 +43,12 @@ namespace fused {
 
 constexpr int kNW = 4, kRows = kNW * 32;
 constexpr int kR = 5, kD = 4, kSlot = 8192;
-constexpr int kFwdSub = 21, kSubN = 35;   // sub-chunks per tile: forward 0-20, dgrad through `out` 21-22, W3 23-26, W2 27-30, W1 31-34
+constexpr int kFwdSub = 21;   // sub-chunks per tile: forward 0-20, dgrad through `out` 21-22, W3 23-26, W2 27-30, W1 31-34
+// PART 0 (layers 3 and out) stops behind dZ3: 23 sub-chunks per tile; PART 1 (layers 2, 1, 0) runs the whole chain: 35
+constexpr int sub_n(int part) { return part == 0 ? 23 : 35; }
 constexpr int kHPitch = 128 * 2 + 32;     // bytes per row of the H / dZ buffers
 
-template <int KSX>
+template <int KSX, int NS>
 struct Sub {
     using G = Geo<KSX>;
     static constexpr int frags(int k) {
@@ -58,12 +63,12 @@ struct Sub {
     static constexpr int pieces(int k) { return frags(k) / kNW; }   // 1-KiB pieces per wave: 1 | 2
     static constexpr int allow(int k) {   // pieces that may still be in flight when sub-chunk k + 1 must have landed
         int n = 0;
-        for (int j = 2; j <= kD; ++j) n += pieces((k + j) % kSubN);
+        for (int j = 2; j <= kD; ++j) n += pieces((k + j) % NS);
         return n;
     }
 };
-static_assert(Sub<6>::off(kFwdSub) == Geo<6>::kFwdFrags && Sub<6>::off(kSubN - 1) + 8 == Geo<6>::kFwdFrags + Geo<6>::kBwdFrags, "blob");
-static_assert(Sub<4>::off(kFwdSub) == Geo<4>::kFwdFrags && Sub<4>::off(kSubN - 1) + 8 == Geo<4>::kFwdFrags + Geo<4>::kBwdFrags, "blob");
+static_assert(Sub<6, 35>::off(kFwdSub) == Geo<6>::kFwdFrags && Sub<6, 35>::off(34) + 8 == Geo<6>::kFwdFrags + Geo<6>::kBwdFrags, "blob");
+static_assert(Sub<4, 35>::off(kFwdSub) == Geo<4>::kFwdFrags && Sub<4, 35>::off(34) + 8 == Geo<4>::kFwdFrags + Geo<4>::kBwdFrags, "blob");
 
 template <int KSX>
 struct Lds {
@@ -81,11 +86,13 @@ struct Lds {
 template <int KSX, int PART>
 struct Blocks {
     static constexpr int NX = KSX / 2;                      // 32-slot tiles of the network input
-    // PART 0: [0, 4) W3 rows of h2 | [4, 4 + NX) W3 rows of the input | out | out bias | [6 + NX, 6 + 2 NX) W0
-    // PART 1: [0, 4) W2 | 4 bias 2 | [5, 9) W1 | 9 bias 1
-    static constexpr int kW3h = 0, kW3x = 4, kOut = 4 + NX, kOutB = 5 + NX, kW0 = 6 + NX;
-    static constexpr int kW2 = 0, kB2 = 4, kW1 = 5, kB1 = 9;
-    static constexpr int N = PART == 0 ? 6 + 2 * NX : 10;
+    // PART 0: [0, 4) W3 rows of h2 | [4, 4 + NX) W3 rows of the input | out || bias rows
+    // PART 1: [0, 4) W2 | [4, 8) W1 | [8, 8 + NX) W0 || bias rows
+    // NACC accumulator blocks (16 registers each) + one block-sized slot of the workgroup's slice whose first rows hold
+    // the per-lane column sums of dZ (row 0: out | layer 2, row 1: layer 1): N slots in all
+    static constexpr int kW3h = 0, kW3x = 4, kOut = 4 + NX;
+    static constexpr int kW2 = 0, kW1 = 4, kW0 = 8;
+    static constexpr int NACC = PART == 0 ? 5 + NX : 8 + NX, kBias = NACC, N = NACC + 1;
 };
 
 struct Ctx {
@@ -95,21 +102,21 @@ struct Ctx {
     int lane, wave;   // wave: wave-uniform
     int cur;          // ring slot of the sub-chunk being consumed (wave-uniform)
 };
-template <int KSX, int K>
+template <int KSX, int NS, int K>
 __device__ __forceinline__ void begin(const Ctx& cx) {
-    constexpr int F = (K + kD) % kSubN, n = Sub<KSX>::pieces(F);
+    constexpr int F = (K + kD) % NS, n = Sub<KSX, NS>::pieces(F);
     unsigned long long base = reinterpret_cast<unsigned long long>(cx.blob);
     unsigned lds = cx.smem_lds;
     asm volatile("" : "+s"(base), "+s"(lds));   // per sub-chunk: keeps the addresses out of the loop preheader
     int slot = cx.cur + kD;
     slot = slot >= kR ? slot - kR : slot;
     const int piece0 = cx.wave * n;
-    lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX>::off(F) * 1024 + piece0 * 1024,
+    lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX, NS>::off(F) * 1024 + piece0 * 1024,
                       lds + (unsigned)slot * kSlot + (unsigned)piece0 * 1024u);
 }
-template <int KSX, int K>
+template <int KSX, int NS, int K>
 __device__ __forceinline__ void end(Ctx& cx) {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Sub<KSX>::allow(K)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Sub<KSX, NS>::allow(K)) : "memory");
     cx.cur = cx.cur + 1 == kR ? 0 : cx.cur + 1;
 }
 // acc += A(current slot, fragments f0 .. f0 + KS - 1) x b[0 ...]
@@ -134,15 +141,15 @@ __device__ __forceinline__ void mask_bits(const f32x16& acc, int t, unsigned (&m
     else m[t >> 1] = bits;
 }
 // one forward layer of 4 tiles whose chunk is ONE sub-chunk each (K0 = its first sub-chunk)
-template <int KSX, int K0, int KS, bool BITS, int KSA>
+template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
 __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[2]) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        begin<KSX, K0 + t>(cx);
+        begin<KSX, NS, K0 + t>(cx);
         f32x16 acc[1];
         bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);
         mma<KS>(cx, b, 0, acc[0]);
-        end<KSX, K0 + t>(cx);
+        end<KSX, NS, K0 + t>(cx);
         if constexpr (BITS) mask_bits(acc[0], t, mk);
         acc_to_b<true, 1>(acc, out[2 * t], out[2 * t + 1]);
     });
@@ -168,16 +175,16 @@ __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact
     mfma_operand_fence(ohi);
 }
 // dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation `hact`
-template <int KSX, int K0, bool BITS>
+template <int KSX, int NS, int K0, bool BITS>
 __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
                                       bf16x8 (&dout)[8][1]) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        begin<KSX, K0 + t>(cx);
+        begin<KSX, NS, K0 + t>(cx);
         f32x16 acc[1];
         zero_acc(acc[0]);
         mma<8>(cx, dz, 0, acc[0]);
-        end<KSX, K0 + t>(cx);
+        end<KSX, NS, K0 + t>(cx);
         relu_mask<BITS>(acc[0], hact, mk, t, dout[2 * t][0], dout[2 * t + 1][0]);
     });
 }
@@ -189,12 +196,14 @@ __device__ __forceinline__ void store_rows(char* row_half, const bf16x8 (&v)[KSA
 #pragma unroll
     for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(row_half + s * 32) = v[s][0];
 }
-// acc[i] += A(tile i of the buffer at `a`, pitch APITCH)^T-contracted-over-rows with B = this wave's dZ tile at `b`;
-// ONES: one more MFMA per k-step whose A operand is all ones (every row of bacc = the column sums = the bias gradient)
-template <int NI, int APITCH, int A0, int ONES, int NA>   // A0: first accumulator block; ONES: block of the all-ones product, or -1
-__device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc)[NA]) {
-    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-    const b8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+// acc[i] += A(tile i of the buffer at `a`, pitch APITCH)^T-contracted-over-rows with B = this wave's dZ tile at `b`.
+// bsum (optional): + the sum of the B operand's 8 rows — lane (slot n, k-group g) adds its rows of every k-step, so the
+// column sum of slot n (the bias gradient) is bsum of lane n + bsum of lane n + 32.  v_dot2c_f32_bf16 with a (1, 1)
+// operand adds two rows per instruction: 4 VALU per k-step instead of a 16-register all-ones MFMA block.
+template <int NI, int APITCH, int A0, int NA>
+__device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc)[NA], float* bsum) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 ones = {(__bf16)1.f, (__bf16)1.f};
 #pragma unroll
     for (int kk = 0; kk < kRows / 16; ++kk) {
         const bf16x8 bf = tr_frag<kHPitch>(b + kk * 16 * kHPitch);
@@ -203,8 +212,11 @@ __device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc
             const bf16x8 af = tr_frag<APITCH>(a + kk * 16 * APITCH + i * 64);
             acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[A0 + i], 0, 0, 0);
         }
-        if constexpr (ONES >= 0)
-            acc[ONES] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), bf, acc[ONES], 0, 0, 0);
+        if (bsum != nullptr) {
+            const u32x4 w = __builtin_bit_cast(u32x4, bf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w[q]), ones, *bsum, false);
+        }
         __builtin_amdgcn_sched_barrier(0);   // one k-step's operands at a time: the scheduler otherwise hoists every read of the
                                              // step (80 fragment registers) above the first MFMA and the accumulators spill
     }
@@ -220,7 +232,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSX = IN_KIND == 0 ? 4 : 6;
     using G = Geo<KSX>;
-    using S = Sub<KSX>;
+    constexpr int NS = sub_n(PART);
+    using S = Sub<KSX, NS>;
     using L = Lds<KSX>;
     using B = Blocks<KSX, PART>;
     constexpr int NX = B::NX;
@@ -248,26 +261,52 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     const char* xa = smem + L::kX + tr_lane_off(lane, L::kXPitch);
     const char* ha = smem + L::kH + tr_lane_off(lane, kHPitch);
     const char* zb = smem + L::kDZ + tr_lane_off(lane, kHPitch) + wave * 64;   // dZ slots [32 wave, 32 wave + 32)
-    f32x16 acc[B::N];
+    f32x16 acc[B::NACC];
 #pragma unroll
-    for (int i = 0; i < B::N; ++i) zero_acc(acc[i]);
+    for (int i = 0; i < B::NACC; ++i) zero_acc(acc[i]);
+    float bsum0 = 0.f, bsum1 = 0.f;   // column sums of dZ_out (PART 0) | dZ2, dZ1 (PART 1): the bias gradients
 
     const long long n_rows = IN_KIND == 0 ? n : n * n_lights;
     const long long n_tiles = (n_rows + kRows - 1) / kRows;
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long row = tile * kRows + row_local;
+    // the rows' inputs are fetched ONE TILE AHEAD: a lone wave per SIMD has nothing to put under the first touch of a
+    // point (an HBM miss) at the top of a tile; the loads ride in the DMA window, where they only make a counted wait
+    // conservative
+    float nx[3], ndv[4], nxd[3];   // (the light position comes from a 6-KiB table that stays in L1 / L2: loaded at the tile's top)
+    auto fetch = [&](long long tl) {
+        const long long row = tl * kRows + row_local;
         const bool valid = row < n_rows;
         const long long rc = valid ? row : n_rows - 1;
         const long long pt = IN_KIND == 0 ? rc : rc / n_lights;
-        float x[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) x[k] = xyz_scale * xyz[pt * 3 + k];
-        float dv[4];
+        for (int k = 0; k < 3; ++k) nx[k] = xyz[pt * 3 + k];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = 4 * h + r;
-            dv[r] = (valid && f < out_dim) ? dout[row * out_dim + f] : 0.f;
+            ndv[r] = (valid && f < out_dim) ? dout[row * out_dim + f] : 0.f;
         }
+        if constexpr (IN_KIND == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nxd[k] = xyz_dir[pt * 3 + k];
+        }
+    };
+    fetch(blockIdx.x);
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row = tile * kRows + row_local;
+        const bool valid = row < n_rows;
+        float x[3], dv[4], xd[3], lp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x[k] = xyz_scale * nx[k];
+            xd[k] = nxd[k];
+        }
+        if constexpr (IN_KIND == 1) {
+            const int l = (int)((valid ? row : n_rows - 1) % n_lights);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lp[k] = lxyz[l * 3 + k];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dv[r] = ndv[r];
+        fetch(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
         bf16x8 xin[KSX][1];
         {
             bf16x8 pe[4][1];
@@ -279,45 +318,41 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             if (h == 1) xin[3][0][7] = (__bf16)1.0f;
         }
         if constexpr (IN_KIND == 1) {
-            const int l = (int)(rc % n_lights);
-            float d[3], xd[3], lp[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                xd[k] = xyz_dir[pt * 3 + k];
-                lp[k] = lxyz[l * 3 + k];
-            }
+            float d[3];
             dir_to(lp, xd, d);
             bf16x8 pl[2][1];
             posenc<4, 1>(d, h, 0, pl);
             xin[4][0] = pl[0][0];
             xin[5][0] = pl[1][0];
         }
-        if constexpr (PART == 0) store_rows<KSX>(xrow, xin);   // read by the W3 and W0 steps of this tile
+        store_rows<KSX>(xrow, xin);   // the input rows: read by the W3 step (PART 0) / the W0 step (PART 1) of this tile
         // ------------------------------------------------------------------ forward (re-computed)
         bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
-        unsigned m0[2], m1[2], m2[2], m3[2];   // ReLU mask bits of the activations this launch does not multiply
-        constexpr bool kBits01 = PART == 0, kBits23 = PART == 1;
-        layer<KSX, 0, KSX, kBits01>(cx, bias_lds, xin, h0, m0);
-        layer<KSX, 4, 8, kBits01>(cx, bias_lds + 128, h0, h1, m1);
-        layer<KSX, 8, 8, kBits23>(cx, bias_lds + 256, h1, h2, m2);
+        // PART 1 multiplies h1, h0 and the input; h2 and h3 it needs only as the dgrad ReLU masks: 2 registers of bits
+        // instead of 32.  PART 0 stops behind dZ3 and needs no mask below h3.
+        unsigned m2[2], m3[2];
+        constexpr bool kBits = PART == 1;
+        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2);
+        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2);
+        layer<KSX, NS, 8, 8, kBits>(cx, bias_lds + 256, h1, h2, m2);
         static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
             constexpr int t = decltype(T)::value;
-            begin<KSX, 12 + 2 * t>(cx);
+            begin<KSX, NS, 12 + 2 * t>(cx);
             f32x16 a3[1];
             bias_init<1>(bias_lds + 384 + 32 * t, h, a3);
             mma<8>(cx, h2, 0, a3[0]);
-            end<KSX, 12 + 2 * t>(cx);
-            begin<KSX, 13 + 2 * t>(cx);
+            end<KSX, NS, 12 + 2 * t>(cx);
+            begin<KSX, NS, 13 + 2 * t>(cx);
             mma<KSX>(cx, xin, 0, a3[0]);
-            end<KSX, 13 + 2 * t>(cx);
-            if constexpr (kBits23) mask_bits(a3[0], t, m3);
+            end<KSX, NS, 13 + 2 * t>(cx);
+            if constexpr (kBits) mask_bits(a3[0], t, m3);
             acc_to_b<true, 1>(a3, h3[2 * t], h3[2 * t + 1]);
         });
         f32x16 logit[1];
-        begin<KSX, 20>(cx);
+        begin<KSX, NS, 20>(cx);
         bias_init<1>(bias_lds + 512, h, logit);
         mma<8>(cx, h3, 0, logit[0]);
-        end<KSX, 20>(cx);
+        end<KSX, NS, 20>(cx);
         // ------------------------------------------------------------------ dZ_out
         bf16x8 dzo[1][1];
 #pragma unroll
@@ -330,50 +365,47 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             store_rows<8>(hrow, h3);
             store_rows<1>(zrow, dzo);
             lds_barrier();
-            wgrad<1, kHPitch, B::kOut, B::kOutB>(ha + wave * 64, zb - wave * 64, acc);
+            wgrad<1, kHPitch, B::kOut>(ha + wave * 64, zb - wave * 64, acc, &bsum0);
         }
         // ------------------------------------------------------------------ dgrad chain + weight gradients
-        bf16x8 dz3[8][1], dz2[8][1], dz1[8][1], dz0[8][1];
+        bf16x8 dz3[8][1];
         {   // through the out layer: one k-step (16 padded output slots); tiles 0, 1 in sub-chunk 21, tiles 2, 3 in 22
             static_for<0, 2>([&](auto U) {
                 constexpr int u = decltype(U)::value;
-                begin<KSX, 21 + u>(cx);
+                begin<KSX, NS, 21 + u>(cx);
                 f32x16 a0[1], a1[1];
                 zero_acc(a0[0]);
                 zero_acc(a1[0]);
                 mma<1>(cx, dzo, 0, a0[0]);
                 mma<1>(cx, dzo, 4, a1[0]);
-                end<KSX, 21 + u>(cx);
-                relu_mask<kBits23>(a0[0], h3, m3, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
-                relu_mask<kBits23>(a1[0], h3, m3, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
+                end<KSX, NS, 21 + u>(cx);
+                relu_mask<kBits>(a0[0], h3, m3, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
+                relu_mask<kBits>(a1[0], h3, m3, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
             });
         }
         if constexpr (PART == 0) {   // W3 = [h2 ; input]^T dZ3 (the two ring barriers above separate it from the out step)
             store_rows<8>(hrow, h2);
             store_rows<8>(zrow, dz3);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW3h, -1>(ha, zb, acc);
-            wgrad<NX, L::kXPitch, B::kW3x, -1>(xa, zb, acc);
-        }
-        dgrad<KSX, 23, kBits23>(cx, dz3, h2, m2, dz2);   // W3[:128, :]
-        if constexpr (PART == 1) {
+            wgrad<4, kHPitch, B::kW3h>(ha, zb, acc, nullptr);
+            wgrad<NX, L::kXPitch, B::kW3x>(xa, zb, acc, nullptr);
+            lds_barrier();   // the next tile's first statement rewrites the X rows
+        } else {
+            bf16x8 dz2[8][1], dz1[8][1], dz0[8][1];
+            dgrad<KSX, NS, 23, true>(cx, dz3, h2, m2, dz2);    // W3[:128, :]
             store_rows<8>(hrow, h1);
             store_rows<8>(zrow, dz2);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW2, B::kB2>(ha, zb, acc);
-        }
-        dgrad<KSX, 27, kBits01>(cx, dz2, h1, m1, dz1);   // W2
-        if constexpr (PART == 1) {
+            wgrad<4, kHPitch, B::kW2>(ha, zb, acc, &bsum0);
+            dgrad<KSX, NS, 27, false>(cx, dz2, h1, m2, dz1);   // W2
             store_rows<8>(hrow, h0);
             store_rows<8>(zrow, dz1);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW1, B::kB1>(ha, zb, acc);
-        }
-        dgrad<KSX, 31, kBits01>(cx, dz1, h0, m0, dz0);   // W1
-        if constexpr (PART == 0) {
+            wgrad<4, kHPitch, B::kW1>(ha, zb, acc, &bsum1);
+            dgrad<KSX, NS, 31, false>(cx, dz1, h0, m2, dz0);   // W1
             store_rows<8>(zrow, dz0);
             lds_barrier();
-            wgrad<NX, L::kXPitch, B::kW0, -1>(xa, zb, acc);
+            wgrad<NX, L::kXPitch, B::kW0>(xa, zb, acc, nullptr);
             lds_barrier();   // the next tile's first statement rewrites the X rows
         }
     }
@@ -381,9 +413,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     // ------------------------------------------------------------------ accumulators -> this workgroup's slice
     float* mine = partial + ((size_t)blockIdx.x * kNW + wave) * (size_t)(B::N * 1024) + lane;
 #pragma unroll
-    for (int b = 0; b < B::N; ++b)
+    for (int b = 0; b < B::NACC; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[(b * 16 + r) * 64] = acc[b][r];
+    mine[(B::kBias * 16 + 0) * 64] = bsum0;
+    mine[(B::kBias * 16 + 1) * 64] = bsum1;
 }
 
 // ---- slot <-> logical feature (pack.cpp seg_row): slot c = 16 s + 8 h + j of a B operand
@@ -414,15 +448,16 @@ struct ReduceArgs {
     float* dk[5];
     float* db[5];
 };
-// One thread per accumulator element (part, wave, block, register, lane): the sum over the workgroups, in workgroup
-// order, added to the gradient element it stands for.
+// One WAVE-QUARTET per 64 accumulator elements (part, wave, block, register, lanes 0-63): wave q of a workgroup sums
+// the workgroups [q n/4, (q+1) n/4) of its 64 elements, the four partial sums are added in wave order through LDS
+// (fixed order: deterministic), and the total is added to the gradient element it stands for.
 template <int KSX>
 __global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceArgs a) {
     constexpr int N0 = Blocks<KSX, 0>::N, N1 = Blocks<KSX, 1>::N, NX = KSX / 2;
     using B0 = Blocks<KSX, 0>;
     using B1 = Blocks<KSX, 1>;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= kNW * (N0 + N1) * 1024) return;
+    __shared__ float quarter[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
     const int lane = e & 63, r = (e >> 6) & 15;
     int blk = (e >> 10) % (N0 + N1);
     const int wave = (e >> 10) / (N0 + N1);
@@ -432,33 +467,44 @@ __global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceArgs a) 
     const int n = lane & 31, m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // D element (row m, column n)
     float* dst = nullptr;
     const int jl = hidden_feature(32 * wave + n);   // the dZ slot of this column, as an output feature of its layer
+    bool bias_row = false;   // a row of the bias slot: the column sum of slot n = the values of lanes n and n + 32
     if (part == 0) {
         if (blk < B0::kW3x) dst = a.dk[3] + hidden_feature(32 * blk + m) * 128 + jl;
-        else if (blk < B0::kOut || blk >= B0::kW0) {
-            const int layer = blk < B0::kOut ? 3 : 0;
-            const int xf = input_feature(32 * (blk - (layer == 3 ? B0::kW3x : B0::kW0)) + m);
-            if (xf >= 0 && xf < a.in_dims) dst = a.dk[layer] + ((layer == 3 ? 128 : 0) + xf) * 128 + jl;
-            else if (xf == kSlotOnes) dst = a.db[layer] + jl;
+        else if (blk < B0::kOut) {
+            const int xf = input_feature(32 * (blk - B0::kW3x) + m);
+            if (xf >= 0 && xf < a.in_dims) dst = a.dk[3] + (128 + xf) * 128 + jl;
+            else if (xf == kSlotOnes) dst = a.db[3] + jl;
         } else {   // out layer: column n = dZo slot (half n >> 3, element n & 7) <-> output 4 (n >> 3) + (n & 7)
             const int f = 4 * (n >> 3) + (n & 7);
             if (n < 16 && (n & 7) < 4 && f < a.out_dim) {
                 if (blk == B0::kOut) dst = a.dk[4] + hidden_feature(32 * wave + m) * a.out_dim + f;
-                else if (wave == 0 && m == 0) dst = a.db[4] + f;
+                else if (wave == 0 && r == 0 && lane < 32) { dst = a.db[4] + f; bias_row = true; }
             }
         }
     } else {
-        if (blk < B1::kB2) dst = a.dk[2] + hidden_feature(32 * blk + m) * 128 + jl;
-        else if (blk == B1::kB2) dst = m == 0 ? a.db[2] + jl : nullptr;
-        else if (blk < B1::kB1) dst = a.dk[1] + hidden_feature(32 * (blk - B1::kW1) + m) * 128 + jl;
-        else dst = m == 0 ? a.db[1] + jl : nullptr;
+        if (blk < B1::kW1) dst = a.dk[2] + hidden_feature(32 * blk + m) * 128 + jl;
+        else if (blk < B1::kW0) dst = a.dk[1] + hidden_feature(32 * (blk - B1::kW1) + m) * 128 + jl;
+        else if (blk < B1::kBias) {
+            const int xf = input_feature(32 * (blk - B1::kW0) + m);
+            if (xf >= 0 && xf < a.in_dims) dst = a.dk[0] + xf * 128 + jl;
+            else if (xf == kSlotOnes) dst = a.db[0] + jl;
+        } else if (r < 2 && lane < 32) { dst = a.db[r == 0 ? 2 : 1] + jl; bias_row = true; }
     }
     (void)NX;
-    if (dst == nullptr) return;
     const float* src = a.part[part] + ((size_t)wave * nb + blk) * 1024 + r * 64 + lane;
     const size_t stride = (size_t)kNW * nb * 1024;
+    const int g0 = (int)((long long)a.n_wg * seg / 4), g1 = (int)((long long)a.n_wg * (seg + 1) / 4);
     float s = 0.f;
-    for (int g = 0; g < a.n_wg; ++g) s += src[g * stride];
-    *dst += s;
+    if (dst != nullptr) {   // (uniform per 64-element group except for the bias rows' upper lanes)
+        if (bias_row) for (int g = g0; g < g1; ++g) s += src[g * stride] + src[g * stride + 32];
+        else for (int g = g0; g < g1; ++g) s += src[g * stride];
+    }
+    quarter[seg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (seg == 0 && dst != nullptr) {
+        const int i = threadIdx.x;
+        *dst += (quarter[0][i] + quarter[1][i]) + (quarter[2][i] + quarter[3][i]);
+    }
 }
 
 }  // namespace fused
@@ -494,7 +540,7 @@ static int launch_fused(const float* xyz, const float* xyz_dir, long long n, flo
         ra.db[i] = db[i];
     }
     const int elems = kNW * (Blocks<KSX, 0>::N + Blocks<KSX, 1>::N) * 1024;
-    hipLaunchKernelGGL(mlp128_wgrad_reduce_kernel<KSX>, dim3((elems + 255) / 256), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(mlp128_wgrad_reduce_kernel<KSX>, dim3(elems / 64), dim3(256), 0, st, ra);
     return (int)hipGetLastError();
 }
 

@@ -89,9 +89,22 @@ class FlatBucket:
         self.flat[-1] = scalar
 
     def all_reduce(self, stream=None):
-        """Sum over ranks: ONE collective for all gradients and the loss."""
+        """Sum over ranks: ONE collective for all gradients and the loss.  `stream`: a torch.cuda.Stream to run the
+        collective on instead of the current one — it waits for the work already queued on the current stream (the
+        backward kernels that fill the bucket), and the current stream waits for it before anything queued later reads
+        the bucket, so whatever the caller enqueues on the current stream BETWEEN this call and its first read of the
+        bucket overlaps the collective.  optim.train_step has nothing to put there (the collective follows the last
+        backward kernel and the optimizer kernel needs its result), so it passes None."""
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if stream is None or not self.flat.is_cuda:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            else:
+                cur = torch.cuda.current_stream(self.flat.device)
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.record_stream(stream)
+                cur.wait_stream(stream)
         return self.views, self.flat[-1]
 
 

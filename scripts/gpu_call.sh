@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU-box call (via gpurun): runs the stages named on the command line, everything worth keeping goes to gpurun_out/<tag>/.
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
-# stages: pytest | pytest-x | smoke | bench | bench-norefine | soak | soak-xp | sigma | prof | pmc | train-prof
+# stages: pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
+#         soak | soak-xp | soak-xp2 | sigma | fitted | prof | train-prof
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -19,6 +20,23 @@ for st in "$@"; do
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-norefine) timeout 600 python bench.py --steps ${STEPS:-10} --warmup 3 --legs nerf --no-last-sample-refine > $OUT/bench_norefine.json 2> $OUT/bench_norefine.err; tail -c 1200 $OUT/bench_norefine.json ;;
     soak)     timeout 600 python scripts/soak_8wave.py > $OUT/soak_product.log 2>&1; tail -12 $OUT/soak_product.log ;;
+    pmc-train) for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_LDS" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+                 set -- $pass; name=$1; shift
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_train/$name -o p -- python $ROOT/bench.py --legs train --train-models ${PMC_MODELS:-nerfactor_microfacet} --steps 1 --warmup 1 --no-cpu-baseline > $ROOT/$OUT/pmc_train_$name.log 2>&1); echo "pmc pass $name rc=$?"
+               done
+               python scripts/pmc_digest.py $OUT/pmc_train > $OUT/pmc_train_digest.json; python - <<PYEOF
+import json
+d=json.load(open("$OUT/pmc_train_digest.json"))
+for k,v in d.items():
+    if 'bwd' in k or 'wgrad' in k:
+        print(k[:70], {a: (round(b,4) if isinstance(b,float) and b<10 else int(b)) for a,b in v.items() if a in ('dispatches','mfma_util','SQ_WAIT_INST_ANY_frac_of_wave_cycles','SQ_WAIT_INST_LDS_frac_of_wave_cycles','SQ_LDS_BANK_CONFLICT','SQ_LDS_IDX_ACTIVE','hbm_read_bytes_corrected','hbm_write_bytes','SQ_BUSY_CYCLES','GRBM_GUI_ACTIVE','SQ_INSTS_LDS')})
+PYEOF
+               ;;
+    soak-xp2) NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp2.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_fastdiv.log 2>&1; tail -8 $OUT/soak_experiment_fastdiv.log ;;
+    fitted)   timeout 600 python scripts/fitted_outliers.py > $OUT/fitted_outliers.json 2>&1; cat $OUT/fitted_outliers.json ;;
+    pytest-k) timeout 1500 python -m pytest tests -m gpu -q -k "$PYTEST_K" > $OUT/pytest_gpu_k.log 2>&1; tail -${TAILN:-30} $OUT/pytest_gpu_k.log ;;
+    bench-train) timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; tail -c 2500 $OUT/bench_train.json; tail -3 $OUT/bench_train.err ;;
+    bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
     soak-xp)  NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_build.log 2>&1; tail -16 $OUT/soak_experiment_build.log ;;
     sigma)    timeout 600 python scripts/sigma_last_error.py > $OUT/sigma_last_error.json 2>&1; cat $OUT/sigma_last_error.json ;;
     prof)     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs ${PROF_LEGS:-nerf,nerfactor_microfacet,nerfactor,olat} > $ROOT/$OUT/prof_run.log 2>&1); find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -25 ;;

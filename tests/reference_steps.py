@@ -1,0 +1,168 @@
+"""The reference's ten training steps (tests/golden/reference_grads.npz: trainvali.py:273-285 of the unmodified reference
+differentiated on the torch TF shim) re-run through the libnfx training step, and how far the result is from them.
+Shared by tests/test_gpu_reference_grads.py (which asserts the bounds) and bench.py's `train` leg (which prints the
+numbers as its `parity` block).  Test infrastructure: nothing in nerfactor_amd/ imports this."""
+import numpy as np
+import torch
+
+from tests import common
+from tests.golden import golden_inputs as gi
+from tests.test_cpu_reference_grads import FIX, N_STEPS, elements, oracle_first_step_grads
+
+# the NeRF fine network sees inverse-CDF samples that hop a bin under any rounding difference of the coarse weights
+TIGHT_TOL = {'nfm': 0.08, 'nfl': 0.08, 'nerf': 0.15, 'brdf': 0.01}   # measured 7e-4
+TAG_OF = {'nerfactor_microfacet': 'nfm', 'nerfactor': 'nfl', 'nerf': 'nerf', 'brdf': 'brdf'}
+LR = {'nfm': 5e-3, 'nfl': 5e-3, 'nerf': 1e-4, 'brdf': 1e-2}
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+
+
+def set_net(net, part, pairs):
+    for layer, (k, b) in zip(net[part].layers, pairs):
+        with torch.no_grad():
+            layer.kernel.copy_(torch.from_numpy(k))
+            layer.bias.copy_(torch.from_numpy(b))
+
+
+def metrics(tag, model, losses, grad1):
+    """Distances of a run from the reference fixture: loss of step 1 and the 10-step trajectory (relative), every
+    gradient tensor of step 1 (relative Frobenius against the oracle with the same bf16 operand rounding = the kernel
+    check, against the reference's fp32 gradient, and the bf16 oracle's own distance from the reference), parameters
+    after the 10 steps in units of lr x steps."""
+    want_losses = np.asarray(FIX[tag + '/loss'], dtype=np.float64)
+    losses = np.asarray(losses, dtype=np.float64)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    quant = oracle_first_step_grads(tag, quant=True, dtype=torch.float32 if tag == 'nerf' else torch.float64)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    report = {}
+    for name in names:
+        want, got = elements('%s/grad/%s' % (tag, name), grad1[name])
+        _, qv = elements('%s/grad/%s' % (tag, name), quant[name])
+        report[name] = (fro(got, qv), fro(got, want), fro(qv, want))
+    moved = []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            want, got = elements('%s/param_after_%d/%s' % (tag, N_STEPS, name), p.detach().cpu().numpy())
+            moved.append(np.abs(got - want) / (LR[tag] * N_STEPS))
+    return dict(names=names, grads=report, loss_step1_rel=float(abs(losses[0] / want_losses[0] - 1)),
+                loss_trajectory_max_rel=float(np.max(np.abs(losses / want_losses - 1))),
+                params_mean_dev_lr_steps=float(np.concatenate(moved).mean()))
+
+
+def summary(tag, m):
+    """The bench's `parity` block: the worst tensor of each comparison and the stated tolerances."""
+    g = m['grads']
+    worst = lambda i: max(g.items(), key=lambda kv: kv[1][i])
+    return {
+        "reference": "tests/golden/reference_grads.npz (trainvali.py:273-285 of the unmodified reference, 10 steps)",
+        "gradient_tensors": len(g),
+        "grad_rel_frobenius_vs_bf16_oracle_worst": round(worst(0)[1][0], 5), "worst_tensor": worst(0)[0],
+        "grad_rel_frobenius_vs_reference_worst": round(worst(1)[1][1], 5),
+        "bf16_oracle_vs_reference_worst": round(worst(2)[1][2], 5),
+        "loss_step1_rel_err": m['loss_step1_rel'], "loss_trajectory_max_rel_err": m['loss_trajectory_max_rel'],
+        "params_after_10_steps_mean_dev_in_lr_steps": m['params_mean_dev_lr_steps'],
+        "tolerance": {"grad_vs_bf16_oracle": TIGHT_TOL[tag], "grad_vs_reference": "1.3 x (bf16 oracle vs reference) + 0.05",
+                      "loss_step1": 2e-2, "loss_trajectory": 5e-2, "params_mean_dev": 0.15},
+    }
+
+
+def check(tag, model, losses, grad1):
+    """The bounds of tests/test_gpu_reference_grads.py."""
+    m = metrics(tag, model, losses, grad1)
+    assert m['loss_step1_rel'] < 2e-2, m['loss_step1_rel']
+    assert m['loss_trajectory_max_rel'] <= 5e-2, m['loss_trajectory_max_rel']
+    assert sorted(m['names']) == sorted(k.split('/', 2)[2].replace(':summary', '') for k in FIX.files
+                                        if k.startswith(tag + '/grad/'))
+    bad = {n: tuple(round(v, 4) for v in r) for n, r in m['grads'].items()
+           if r[0] > TIGHT_TOL[tag] or r[1] > 1.3 * r[2] + 0.05}
+    print(tag, 'gradient rel-Frobenius (HIP vs bf16 oracle, HIP vs reference, bf16 oracle vs reference), worst:',
+          sorted(((n, tuple(round(v, 4) for v in r)) for n, r in m['grads'].items()), key=lambda kv: -kv[1][0])[:4])
+    assert not bad, bad
+    assert m['params_mean_dev_lr_steps'] < 0.15, m['params_mean_dev_lr_steps']
+    return m
+
+
+def run_nerfactor(tag, cuda):
+    """-> (model, losses of the 10 steps, gradients of step 1) for 'nfm' (microfacet) | 'nfl' (learned BRDF)."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    learned = tag == 'nfl'
+    name = 'nerfactor' if learned else 'nerfactor_microfacet'
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='',
+                      light_tv_weight='2e-4', light_achro_weight='1e-4')
+    model = get_model_class(name)(cfg)
+    for part, pairs in gi.nerfactor_net(3 if learned else 1).items():
+        set_net(model.net, part, pairs)
+    if learned:
+        for part, pairs in gi.brdf_net().items():
+            set_net(model.brdf_model.net, part, pairs)
+    with torch.no_grad():
+        model._light.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE[tag])))
+    model = model.to(cuda)
+    model.register_trainable()
+    rayo, rgb, alpha, xyz, normal, lvis = (dev(a, cuda) for a in gi.surface_batch(512))
+    n = rayo.shape[0]
+    batch = (['x'] * n, torch.tensor([[4, n // 4]] * n, dtype=torch.int32, device=cuda), rayo, torch.zeros_like(rayo),
+             rgb, alpha, xyz, normal, lvis)
+    opt = optim.make_optimizer(model, cfg)
+    losses, grad1 = [], None
+    for step in range(N_STEPS):
+        opt.zero_grad()
+        noise = dev(FIX['%s/normal_%03d' % (tag, step)], cuda)
+        pred, gt, loss_kwargs, _ = model(batch, mode='train', xyz_noise=noise)
+        loss_kwargs['keep_batch'] = True
+        weighted = model.compute_loss(pred, gt, **loss_kwargs).sum() / n
+        weighted.backward()
+        if step == 0:
+            grad1 = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+        losses.append(float(opt.step(loss=weighted.detach())))
+    return model, losses, grad1
+
+
+def run_nerf(cuda):
+    """The NeRF step with the reference's tf.random.uniform draws (stratified coarse samples, inverse-CDF fine
+    samples) replayed through torch.rand."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    cfg = make_config('nerf')
+    assert cfg.getboolean('DEFAULT', 'perturb') and cfg.getfloat('DEFAULT', 'noise_std') == 0.
+    model = get_model_class('nerf')(cfg)
+    for pref, net in zip(('coarse_', 'fine_'), common.nerf_nets(seed=gi.NERF_SEED)):
+        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+            set_net(model.net, pref + part, net[part])
+    model = model.to(cuda)
+    model.register_trainable()
+    rayo, rayd, gt = (dev(a[:gi.GRAD_NERF_RAYS], cuda) for a in gi.nerf_rays())
+    n = rayo.shape[0]
+    batch = (['x'] * n, torch.tensor([[4, n // 4]] * n, dtype=torch.int32, device=cuda), rayo, rayd, gt)
+    draws = iter([FIX['nerf/uniform_%03d' % i] for i in range(2 * N_STEPS)])
+    real_rand = torch.rand
+
+    def replay(shape, device=None, **kw):
+        a = next(draws)
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
+        return torch.from_numpy(a).to(device)
+    torch.rand = replay
+    try:
+        opt = optim.make_optimizer(model, cfg)
+        losses, grad1 = [], None
+        for step in range(N_STEPS):
+            opt.zero_grad()
+            pred, gt_, loss_kwargs, _ = model(batch, mode='train')
+            weighted = model.compute_loss(pred, gt_, keep_batch=True).sum() / n
+            weighted.backward()
+            if step == 0:
+                grad1 = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+            losses.append(float(opt.step(loss=weighted.detach())))
+    finally:
+        torch.rand = real_rand
+    return model, losses, grad1
+
+
+def run(model_name, cuda):
+    tag = TAG_OF[model_name]
+    return (tag,) + (run_nerf(cuda) if tag == 'nerf' else run_nerfactor(tag, cuda))

@@ -15,130 +15,21 @@ import numpy as np
 import pytest
 import torch
 
-from tests import common
+from tests import reference_steps as RS
 from tests.golden import golden_inputs as gi
-from tests.test_cpu_reference_grads import FIX, N_STEPS, elements, fixture_tensor, oracle_first_step_grads
+from tests.reference_steps import dev, set_net
+from tests.test_cpu_reference_grads import FIX, N_STEPS
 
 pytestmark = pytest.mark.gpu
-# the NeRF fine network sees inverse-CDF samples that hop a bin under any rounding difference of the coarse weights
-TIGHT_TOL = {'nfm': 0.08, 'nfl': 0.08, 'nerf': 0.15, 'brdf': 0.01}   # measured 7e-4
-
-
-def dev(a, cuda):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
-
-
-def set_net(net, part, pairs):
-    for layer, (k, b) in zip(net[part].layers, pairs):
-        with torch.no_grad():
-            layer.kernel.copy_(torch.from_numpy(k))
-            layer.bias.copy_(torch.from_numpy(b))
-
-
-def compare(tag, model, losses, grad1, lr):
-    want_losses = FIX[tag + '/loss']
-    assert abs(losses[0] / want_losses[0] - 1) < 2e-2, (losses[0], want_losses[0])
-    np.testing.assert_allclose(losses, want_losses, rtol=5e-2)
-    names = [n for n, p in model.named_parameters() if p.requires_grad]
-    assert sorted(names) == sorted(k.split('/', 2)[2].replace(':summary', '') for k in FIX.files
-                                   if k.startswith(tag + '/grad/'))
-    quant = oracle_first_step_grads(tag, quant=True, dtype=torch.float32 if tag == 'nerf' else torch.float64)
-    report, bad = {}, {}
-    for name in names:
-        want, got = elements('%s/grad/%s' % (tag, name), grad1[name])
-        _, qv = elements('%s/grad/%s' % (tag, name), quant[name])
-        fro = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
-        vs_q, vs_ref, q_vs_ref = fro(got, qv), fro(got, want), fro(qv, want)
-        report[name] = (round(vs_q, 4), round(vs_ref, 4), round(q_vs_ref, 4))
-        if vs_q > TIGHT_TOL[tag] or vs_ref > 1.3 * q_vs_ref + 0.05:
-            bad[name] = report[name]
-    print(tag, 'gradient rel-Frobenius (HIP vs bf16 oracle, HIP vs reference, bf16 oracle vs reference), worst:',
-          sorted(report.items(), key=lambda kv: -kv[1][0])[:4])
-    assert not bad, bad
-    # parameters after 10 steps: the move from the reference's trajectory, in units of lr * steps
-    dev_ = []
-    for name, p in model.named_parameters():
-        if p.requires_grad:
-            want, got = elements('%s/param_after_%d/%s' % (tag, N_STEPS, name), p.detach().cpu().numpy())
-            dev_.append(np.abs(got - want) / (lr * N_STEPS))
-    dev_ = np.concatenate(dev_)
-    assert dev_.mean() < 0.15, dev_.mean()
 
 
 @pytest.mark.parametrize("tag", ['nfm', 'nfl'])
 def test_nerfactor_train_steps_vs_reference(nfx_lib, cuda, tag):
-    from nerfactor_amd import optim
-    from nerfactor_amd.nerfactor.config import make_config
-    from nerfactor_amd.nerfactor.models import get_model_class
-    learned = tag == 'nfl'
-    name = 'nerfactor' if learned else 'nerfactor_microfacet'
-    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='',
-                      light_tv_weight='2e-4', light_achro_weight='1e-4')
-    model = get_model_class(name)(cfg)
-    for part, pairs in gi.nerfactor_net(3 if learned else 1).items():
-        set_net(model.net, part, pairs)
-    if learned:
-        for part, pairs in gi.brdf_net().items():
-            set_net(model.brdf_model.net, part, pairs)
-    with torch.no_grad():
-        model._light.copy_(torch.from_numpy(gi.light_probe(gi.LIGHT_SCALE[tag])))
-    model = model.to(cuda)
-    model.register_trainable()
-    rayo, rgb, alpha, xyz, normal, lvis = (dev(a, cuda) for a in gi.surface_batch(512))
-    n = rayo.shape[0]
-    batch = (['x'] * n, torch.tensor([[4, n // 4]] * n, dtype=torch.int32, device=cuda), rayo, torch.zeros_like(rayo),
-             rgb, alpha, xyz, normal, lvis)
-    opt = optim.make_optimizer(model, cfg)
-    losses, grad1 = [], None
-    for step in range(N_STEPS):
-        opt.zero_grad()
-        noise = dev(FIX['%s/normal_%03d' % (tag, step)], cuda)
-        pred, gt, loss_kwargs, _ = model(batch, mode='train', xyz_noise=noise)
-        loss_kwargs['keep_batch'] = True
-        weighted = model.compute_loss(pred, gt, **loss_kwargs).sum() / n
-        weighted.backward()
-        if step == 0:
-            grad1 = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
-        losses.append(float(opt.step(loss=weighted.detach())))
-    compare(tag, model, losses, grad1, 5e-3)
+    RS.check(tag, *RS.run_nerfactor(tag, cuda))
 
 
-def test_nerf_train_steps_vs_reference(nfx_lib, cuda, monkeypatch):
-    from nerfactor_amd import optim
-    from nerfactor_amd.nerfactor.config import make_config
-    from nerfactor_amd.nerfactor.models import get_model_class
-    cfg = make_config('nerf')
-    assert cfg.getboolean('DEFAULT', 'perturb') and cfg.getfloat('DEFAULT', 'noise_std') == 0.
-    model = get_model_class('nerf')(cfg)
-    for pref, net in zip(('coarse_', 'fine_'), common.nerf_nets(seed=gi.NERF_SEED)):
-        for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
-            set_net(model.net, pref + part, net[part])
-    model = model.to(cuda)
-    model.register_trainable()
-    rayo, rayd, gt = (dev(a[:gi.GRAD_NERF_RAYS], cuda) for a in gi.nerf_rays())
-    n = rayo.shape[0]
-    batch = (['x'] * n, torch.tensor([[4, n // 4]] * n, dtype=torch.int32, device=cuda), rayo, rayd, gt)
-    # the reference's tf.random.uniform draws (stratified coarse samples, inverse-CDF fine samples), replayed
-    draws = iter([FIX['nerf/uniform_%03d' % i] for i in range(2 * N_STEPS)])
-    real_rand = torch.rand
-
-    def replay(shape, device=None, **kw):
-        a = next(draws)
-        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
-        return torch.from_numpy(a).to(device)
-    monkeypatch.setattr(torch, 'rand', replay)
-    opt = optim.make_optimizer(model, cfg)
-    losses, grad1 = [], None
-    for step in range(N_STEPS):
-        opt.zero_grad()
-        pred, gt_, loss_kwargs, _ = model(batch, mode='train')
-        weighted = model.compute_loss(pred, gt_, keep_batch=True).sum() / n
-        weighted.backward()
-        if step == 0:
-            grad1 = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
-        losses.append(float(opt.step(loss=weighted.detach())))
-    monkeypatch.setattr(torch, 'rand', real_rand)
-    compare('nerf', model, losses, grad1, 1e-4)
+def test_nerf_train_steps_vs_reference(nfx_lib, cuda):
+    RS.check('nerf', *RS.run_nerf(cuda))
 
 
 def test_brdf_prior_train_steps_vs_reference(nfx_lib, cuda, tmp_path):
@@ -172,7 +63,7 @@ def test_brdf_prior_train_steps_vs_reference(nfx_lib, cuda, tmp_path):
             np.testing.assert_allclose(model.compute_loss(pred, gt, keep_batch=True).detach().cpu().numpy(),
                                        FIX['brdf/per_example_loss'], rtol=0.1, atol=2e-2)
         losses.append(float(opt.step(loss=weighted.detach())))
-    compare('brdf', model, losses, grad1, 1e-2)
+    RS.check('brdf', model, losses, grad1)
     # bit-reproducible: the same step twice from the same state gives the same gradients
     g = []
     for _ in range(2):
