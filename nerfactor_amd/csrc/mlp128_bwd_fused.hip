@@ -74,8 +74,8 @@ template <int KSX>
 struct Lds {
     static constexpr int kXPitch = KSX * 32 + 32;   // KSX k-steps x 16 slots x 2 B + pad
     static constexpr int kBias = kR * kSlot;
-    static constexpr int kX = kBias + m128::kMainBiasFloats * 4;
-    static constexpr int kH = kX + kRows * kXPitch;
+    static constexpr int kX = kBias + m128::kMainBiasFloats * 4;   // PART 0: the input rows (pitch kXPitch); PART 1: h0 (pitch kHPitch)
+    static constexpr int kH = kX + kRows * kHPitch;
     static constexpr int kDZ = kH + kRows * kHPitch;
     static constexpr int kTotal = kDZ + kRows * kHPitch;
     static_assert(kX % 16 == 0 && kH % 16 == 0 && kDZ % 16 == 0 && kXPitch % 16 == 0, "16-byte rows");
@@ -141,8 +141,10 @@ __device__ __forceinline__ void mask_bits(const f32x16& acc, int t, unsigned (&m
     else m[t >> 1] = bits;
 }
 // one forward layer of 4 tiles whose chunk is ONE sub-chunk each (K0 = its first sub-chunk)
+// `park` (optional): the tile's two output k-steps go to this lane's parked row in LDS as soon as they exist
 template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
-__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[2]) {
+__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[2],
+                                      char* park = nullptr) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
@@ -152,20 +154,31 @@ __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (
         end<KSX, NS, K0 + t>(cx);
         if constexpr (BITS) mask_bits(acc[0], t, mk);
         acc_to_b<true, 1>(acc, out[2 * t], out[2 * t + 1]);
+        if (park != nullptr) {
+            *reinterpret_cast<bf16x8*>(park + (2 * t) * 32) = out[2 * t][0];
+            *reinterpret_cast<bf16x8*>(park + (2 * t + 1) * 32) = out[2 * t + 1][0];
+        }
     });
 }
 __device__ __forceinline__ void zero_acc(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
-// ReLU mask of tile t of a layer: from the re-computed activation (BITS = false) or from its mask bits
-template <bool BITS>
-__device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[2], int t,
-                                          bf16x8& olo, bf16x8& ohi) {
+// ReLU mask of tile t of a layer.  MODE 0: from the re-computed activation in registers; 1: from its mask bits; 2: from the
+// activation parked in LDS (`park` = this lane's row and half: k-step s at park + 32 s — exactly what store_rows wrote).
+template <int MODE>
+__device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
+                                          const char* park, int t, bf16x8& olo, bf16x8& ohi) {
+    bf16x8 plo, phi;
+    if constexpr (MODE == 2) {
+        plo = *reinterpret_cast<const bf16x8*>(park + (2 * t) * 32);
+        phi = *reinterpret_cast<const bf16x8*>(park + (2 * t + 1) * 32);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         bool on;
-        if constexpr (BITS) on = (mk[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
+        if constexpr (MODE == 1) on = (mk[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
+        else if constexpr (MODE == 2) on = (float)(r < 8 ? plo[r & 7] : phi[r & 7]) > 0.f;
         else on = (float)hact[2 * t + (r >> 3)][0][r & 7] > 0.f;
         const __bf16 v = (__bf16)(on ? acc[r] : 0.f);
         if (r < 8) olo[r & 7] = v;
@@ -174,10 +187,10 @@ __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact
     mfma_operand_fence(olo);
     mfma_operand_fence(ohi);
 }
-// dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation `hact`
-template <int KSX, int NS, int K0, bool BITS>
+// dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation
+template <int KSX, int NS, int K0, int MODE>
 __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
-                                      bf16x8 (&dout)[8][1]) {
+                                      const char* park, bf16x8 (&dout)[8][1]) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
@@ -185,7 +198,7 @@ __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const b
         zero_acc(acc[0]);
         mma<8>(cx, dz, 0, acc[0]);
         end<KSX, NS, K0 + t>(cx);
-        relu_mask<BITS>(acc[0], hact, mk, t, dout[2 * t][0], dout[2 * t + 1][0]);
+        relu_mask<MODE>(acc[0], hact, mk, park, t, dout[2 * t][0], dout[2 * t + 1][0]);
     });
 }
 
@@ -213,9 +226,15 @@ __device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc
             acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[A0 + i], 0, 0, 0);
         }
         if (bsum != nullptr) {
-            const u32x4 w = __builtin_bit_cast(u32x4, bf);
+            // (hipcc 7.2: four dot products of the dwords of a bit_cast u32x4 all read the FIRST dword — r04 call D, every
+            //  dot2-summed bias gradient wrong; element pairs spelled out read the right registers)
+            float t = *bsum;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w[q]), ones, *bsum, false);
+            for (int q = 0; q < 4; ++q) {
+                const b2 pr = {bf[2 * q], bf[2 * q + 1]};
+                t = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, t, false);
+            }
+            *bsum = t;
         }
         __builtin_amdgcn_sched_barrier(0);   // one k-step's operands at a time: the scheduler otherwise hoists every read of the
                                              // step (80 fragment registers) above the first MFMA and the accumulators spill
@@ -255,11 +274,13 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave, 0};
     // this lane's row of the three row-major buffers (stores) and its gather origin (transposing reads)
     const int row_local = wave * 32 + p;
-    char* xrow = smem + L::kX + row_local * L::kXPitch + h * 16;
+    char* xrow = smem + L::kX + row_local * L::kXPitch + h * 16;     // PART 0: input rows
+    char* h0row = smem + L::kX + row_local * kHPitch + h * 16;       // PART 1: h0 parked in the same region
     char* hrow = smem + L::kH + row_local * kHPitch + h * 16;
     char* zrow = smem + L::kDZ + row_local * kHPitch + h * 16;
     const char* xa = smem + L::kX + tr_lane_off(lane, L::kXPitch);
     const char* ha = smem + L::kH + tr_lane_off(lane, kHPitch);
+    const char* h0a = smem + L::kX + tr_lane_off(lane, kHPitch);
     const char* zb = smem + L::kDZ + tr_lane_off(lane, kHPitch) + wave * 64;   // dZ slots [32 wave, 32 wave + 32)
     f32x16 acc[B::NACC];
 #pragma unroll
@@ -325,15 +346,18 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             xin[4][0] = pl[0][0];
             xin[5][0] = pl[1][0];
         }
-        store_rows<KSX>(xrow, xin);   // the input rows: read by the W3 step (PART 0) / the W0 step (PART 1) of this tile
+        if constexpr (PART == 0) store_rows<KSX>(xrow, xin);   // the input rows: read by the W3 step of this tile
         // ------------------------------------------------------------------ forward (re-computed)
         bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
-        // PART 1 multiplies h1, h0 and the input; h2 and h3 it needs only as the dgrad ReLU masks: 2 registers of bits
-        // instead of 32.  PART 0 stops behind dZ3 and needs no mask below h3.
+        // PART 1 multiplies h1, h0 and the input.  h0 and h1 are PARKED in LDS the moment they exist (h0 in the region
+        // PART 0 uses for the input rows, h1 in the H buffer): the weight-gradient steps read them there, the dgrad masks
+        // re-read the lane's own row, and their 64 registers are free for the whole backward (kept live they spilled: 35
+        // registers, 730 us per 1 048 576 rows — r04 call D).  h2 and h3 it needs only as masks: 2 registers of bits.
+        // PART 0 stops behind dZ3 and needs no mask below h3.
         unsigned m2[2], m3[2];
         constexpr bool kBits = PART == 1;
-        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2);
-        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2);
+        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr);
+        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr);
         layer<KSX, NS, 8, 8, kBits>(cx, bias_lds + 256, h1, h2, m2);
         static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
             constexpr int t = decltype(T)::value;
@@ -379,8 +403,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
                 mma<1>(cx, dzo, 0, a0[0]);
                 mma<1>(cx, dzo, 4, a1[0]);
                 end<KSX, NS, 21 + u>(cx);
-                relu_mask<kBits>(a0[0], h3, m3, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
-                relu_mask<kBits>(a1[0], h3, m3, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
+                relu_mask<kBits ? 1 : 0>(a0[0], h3, m3, nullptr, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
+                relu_mask<kBits ? 1 : 0>(a1[0], h3, m3, nullptr, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
             });
         }
         if constexpr (PART == 0) {   // W3 = [h2 ; input]^T dZ3 (the two ring barriers above separate it from the out step)
@@ -392,21 +416,20 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             lds_barrier();   // the next tile's first statement rewrites the X rows
         } else {
             bf16x8 dz2[8][1], dz1[8][1], dz0[8][1];
-            dgrad<KSX, NS, 23, true>(cx, dz3, h2, m2, dz2);    // W3[:128, :]
-            store_rows<8>(hrow, h1);
+            dgrad<KSX, NS, 23, 1>(cx, dz3, h2, m2, nullptr, dz2);   // W3[:128, :]
             store_rows<8>(zrow, dz2);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW2>(ha, zb, acc, &bsum0);
-            dgrad<KSX, NS, 27, false>(cx, dz2, h1, m2, dz1);   // W2
-            store_rows<8>(hrow, h0);
+            wgrad<4, kHPitch, B::kW2>(ha, zb, acc, &bsum0);           // A = h1, parked in the H buffer by the forward
+            dgrad<KSX, NS, 27, 2>(cx, dz2, h1, m2, hrow, dz1);        // W2; mask = this lane's parked h1 row
             store_rows<8>(zrow, dz1);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW1>(ha, zb, acc, &bsum1);
-            dgrad<KSX, NS, 31, false>(cx, dz1, h0, m2, dz0);   // W1
+            wgrad<4, kHPitch, B::kW1>(h0a, zb, acc, &bsum1);          // A = h0, parked in the X region
+            dgrad<KSX, NS, 31, 2>(cx, dz1, h0, m2, h0row, dz0);       // W1; mask = the parked h0 row
+            store_rows<KSX>(hrow, xin);                               // the input rows take the H buffer (h1 is done with)
             store_rows<8>(zrow, dz0);
             lds_barrier();
-            wgrad<NX, L::kXPitch, B::kW0>(xa, zb, acc, nullptr);
-            lds_barrier();   // the next tile's first statement rewrites the X rows
+            wgrad<NX, kHPitch, B::kW0>(ha, zb, acc, nullptr);
+            lds_barrier();   // the next tile's forward parks h1 in the H buffer again
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sub-chunks fetched ahead for a tile that does not exist
