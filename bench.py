@@ -562,7 +562,32 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
             ": " + errors[0] if errors else " (not this one)")}
     losses = torch.stack(losses).cpu().numpy()
     assert np.isfinite(losses).all(), "non-finite training loss in the timed steps"
-    dt = elapsed / steps
+    dt_eager = elapsed / steps
+    # One process, foreground-tagged batch: the step as ONE hipGraph replay (optim.GraphedTrainStep = ini key
+    # `hip_graph = true`; bit-identical to the eager step, tests/test_gpu_train.py).  The eager NeRFactor step issues
+    # ~170 launches and sits at the host's issue time (2.2-2.8 ms depending on the box's CPU), whatever its kernels
+    # take: the replay is what shows the GPU time.  N > 1 ranks keep the eager step (the all-reduce is not captured).
+    graph_dt, graph_note = None, None
+    if world == 1 and not args.no_hip_graph and name != 'nerf':
+        gstep = optim.GraphedTrainStep(model, opt, global_bs)
+        glosses = []
+
+        def gs(k):
+            loss, _ = gstep(batch)
+            if k is not None:
+                glosses.append(loss)
+            return loss
+        try:
+            g_steps = min(steps, 60)       # (the leg is capped at TRAIN_STEPS_MAX optimizer steps on one noise batch)
+            elapsed_g, _ = timed(gs, g_steps, 6, barrier)
+            model.flush_numerics(block=True)
+            if np.isfinite(torch.stack(glosses).cpu().numpy()).all():
+                graph_dt = elapsed_g / g_steps
+            else:
+                graph_note = "non-finite loss in the replayed steps"
+        except FloatingPointError as e:
+            graph_note = "check_numerics raised in the replayed steps: %s" % e
+    dt = graph_dt if graph_dt is not None else dt_eager
     if name == 'nerf':
         # per ray 64 coarse + 192 fine points; forward + re-computed forward + dgrad + wgrad = 4 x the forward MACs
         flops = 4 * n * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT
@@ -590,6 +615,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),
         "parity": parity,
         "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
+        "step": ("one hipGraph replay per step (optim.GraphedTrainStep, ini hip_graph = true)" if graph_dt is not None
+                 else "eager optim.train_step" + (" (%s)" % graph_note if graph_note else "")),
+        "ms_per_step_eager": dt_eager * 1e3,
         "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
         "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
             torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if world > 1 else "none (one rank)",
@@ -755,6 +783,7 @@ def main():
     ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
     ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hip-graph', action='store_true', help="train leg: time the eager step only")
     ap.add_argument('--no-last-sample-refine', action='store_true',
                     help="A/B: skip the fp32-class re-evaluation of every ray's last sample (the r03 render)")
     ap.add_argument('--precision', choices=('bf16', 'fp32'), default='bf16',

@@ -33,8 +33,10 @@ VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # r01: lvis 21.16 -> 20.79 ms, NeRF render 1228 -> 1239 TFLOP/s (instruction count of the lvis kernel 5380 -> 4554),
 # variant 6 1293 -> 1330 TFLOP/s, density-gradient kernel 72.5 -> 68.4 ms per 256 x 256 view; no effect on the
 # backward kernels (nerf_bwd, mlp128_bwd, brdf_bwd)
+# r04: mlp128_bwd_fused.hip — 1113 of ~3850 VALU instructions per tile of its PART 1 kernel were v_accvgpr_read / _write
+# of the chain's accumulators (the persistent weight-gradient blocks still end up in AccVGPRs: only MFMAs touch them)
 PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
-                  'nerf_geom.hip': VGPR_FORM}
+                  'nerf_geom.hip': VGPR_FORM, 'mlp128_bwd_fused.hip': VGPR_FORM}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
     PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
 

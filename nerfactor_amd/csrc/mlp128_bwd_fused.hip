@@ -129,21 +129,55 @@ __device__ __forceinline__ void mma(const Ctx& cx, const bf16x8 (&b)[KSA][1], in
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][0], acc, 0, 0, 0);
     }
 }
-// ReLU mask of a pre-activation tile as bits (word t >> 1, bit 16 (t & 1) + r <-> accumulator register r of tile t): a
-// layer whose activation this launch needs only as the dgrad mask keeps 2 registers instead of 32 (the launches differ
-// in which activations they multiply: PART 0 h3, h2, input; PART 1 h1, h0)
-__device__ __forceinline__ void mask_bits(const f32x16& acc, int t, unsigned (&m)[2]) {
-    unsigned bits = 0;
+// ---- packed 16-bit epilogues (the kernels are VALU-bound beside their MFMAs: r04 call C counted ~3300 VALU instructions
+// per 128-row tile and wave against 340 matrix instructions; the scalar forms — v_med3 + v_cvt per value, bf16 -> f32 +
+// compare + select per masked value, compare + select + shift-or per mask bit — were a third of them)
+// Everything below works on DWORDS holding two bf16 (a B-operand register = 4 of them).  The two flag helpers are inline
+// asm on purpose: written as vector min / subtract, hipcc 7.2 turns "is this bf16 non-zero" back into shift + float
+// compare + select + permute per element (7 VALU per pair instead of 1).
+__device__ __forceinline__ unsigned cvt2(float a, float b) {   // v_cvt_pk_bf16_f32: low half = a
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ unsigned relu2(unsigned v) {        // v_pk_max_i16: a negative bf16 is a negative int16
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+__device__ __forceinline__ unsigned nonzero2(unsigned h) {     // 1 per half whose (non-negative) bf16 is not zero
+    unsigned o;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(o) : "v"(h), "s"(0x00010001u));
+    return o;
+}
+__device__ __forceinline__ unsigned keep2(unsigned v, unsigned flag01) {   // v where the half's flag is 1, +0 where it is 0
+    unsigned m;
+    asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(flag01));                 // 0 - 1 = 0xffff
+    return v & m;
+}
+// ReLU + bf16 of one accumulator tile (bias already in it) -> the next layer's two B-operand k-steps; BITS: also the
+// tile's ReLU mask, one word per tile: pair j (accumulator registers 2 j, 2 j + 1) at bit 7 - j of the low / high half
+template <bool BITS>
+__device__ __forceinline__ void relu_tile(const f32x16& acc, bf16x8& lo, bf16x8& hi, unsigned& bits) {
+    u32x4 wl, wh;
+    unsigned w = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.f ? 1u : 0u) << r;
-    asm volatile("" : "+v"(bits));   // opaque: the backward reads the BIT, the compare results do not stay alive
-    if (t & 1) m[t >> 1] |= bits << 16;
-    else m[t >> 1] = bits;
+    for (int j = 0; j < 8; ++j) {
+        const unsigned pr = relu2(cvt2(acc[2 * j], acc[2 * j + 1]));
+        if (j < 4) wl[j] = pr;
+        else wh[j - 4] = pr;
+        if constexpr (BITS) w = (w << 1) | nonzero2(pr);
+    }
+    if constexpr (BITS) bits = w;
+    lo = __builtin_bit_cast(bf16x8, wl);
+    hi = __builtin_bit_cast(bf16x8, wh);
+    mfma_operand_fence(lo);
+    mfma_operand_fence(hi);
 }
 // one forward layer of 4 tiles whose chunk is ONE sub-chunk each (K0 = its first sub-chunk)
 // `park` (optional): the tile's two output k-steps go to this lane's parked row in LDS as soon as they exist
 template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
-__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[2],
+__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[4],
                                       char* park = nullptr) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
@@ -152,8 +186,7 @@ __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (
         bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);
         mma<KS>(cx, b, 0, acc[0]);
         end<KSX, NS, K0 + t>(cx);
-        if constexpr (BITS) mask_bits(acc[0], t, mk);
-        acc_to_b<true, 1>(acc, out[2 * t], out[2 * t + 1]);
+        relu_tile<BITS>(acc[0], out[2 * t][0], out[2 * t + 1][0], mk[t]);
         if (park != nullptr) {
             *reinterpret_cast<bf16x8*>(park + (2 * t) * 32) = out[2 * t][0];
             *reinterpret_cast<bf16x8*>(park + (2 * t + 1) * 32) = out[2 * t + 1][0];
@@ -167,29 +200,34 @@ __device__ __forceinline__ void zero_acc(f32x16& a) {
 // ReLU mask of tile t of a layer.  MODE 0: from the re-computed activation in registers; 1: from its mask bits; 2: from the
 // activation parked in LDS (`park` = this lane's row and half: k-step s at park + 32 s — exactly what store_rows wrote).
 template <int MODE>
-__device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
+__device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
                                           const char* park, int t, bf16x8& olo, bf16x8& ohi) {
-    bf16x8 plo, phi;
+    u32x4 plo, phi;
     if constexpr (MODE == 2) {
-        plo = *reinterpret_cast<const bf16x8*>(park + (2 * t) * 32);
-        phi = *reinterpret_cast<const bf16x8*>(park + (2 * t + 1) * 32);
+        plo = *reinterpret_cast<const u32x4*>(park + (2 * t) * 32);
+        phi = *reinterpret_cast<const u32x4*>(park + (2 * t + 1) * 32);
+    } else if constexpr (MODE == 0) {
+        plo = __builtin_bit_cast(u32x4, hact[2 * t][0]);
+        phi = __builtin_bit_cast(u32x4, hact[2 * t + 1][0]);
     }
+    u32x4 wl, wh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        bool on;
-        if constexpr (MODE == 1) on = (mk[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
-        else if constexpr (MODE == 2) on = (float)(r < 8 ? plo[r & 7] : phi[r & 7]) > 0.f;
-        else on = (float)hact[2 * t + (r >> 3)][0][r & 7] > 0.f;
-        const __bf16 v = (__bf16)(on ? acc[r] : 0.f);
-        if (r < 8) olo[r & 7] = v;
-        else ohi[r & 7] = v;
+    for (int j = 0; j < 8; ++j) {
+        unsigned on;
+        if constexpr (MODE == 1) on = (mk[t] >> (7 - j)) & 0x00010001u;
+        else on = nonzero2(j < 4 ? plo[j] : phi[j - 4]);
+        const unsigned v = keep2(cvt2(acc[2 * j], acc[2 * j + 1]), on);
+        if (j < 4) wl[j] = v;
+        else wh[j - 4] = v;
     }
+    olo = __builtin_bit_cast(bf16x8, wl);
+    ohi = __builtin_bit_cast(bf16x8, wh);
     mfma_operand_fence(olo);
     mfma_operand_fence(ohi);
 }
 // dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation
 template <int KSX, int NS, int K0, int MODE>
-__device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[2],
+__device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
                                       const char* park, bf16x8 (&dout)[8][1]) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
@@ -354,7 +392,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         // re-read the lane's own row, and their 64 registers are free for the whole backward (kept live they spilled: 35
         // registers, 730 us per 1 048 576 rows — r04 call D).  h2 and h3 it needs only as masks: 2 registers of bits.
         // PART 0 stops behind dZ3 and needs no mask below h3.
-        unsigned m2[2], m3[2];
+        unsigned m2[4], m3[4];
         constexpr bool kBits = PART == 1;
         layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr);
         layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr);
@@ -369,8 +407,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             begin<KSX, NS, 13 + 2 * t>(cx);
             mma<KSX>(cx, xin, 0, a3[0]);
             end<KSX, NS, 13 + 2 * t>(cx);
-            if constexpr (kBits) mask_bits(a3[0], t, m3);
-            acc_to_b<true, 1>(a3, h3[2 * t], h3[2 * t + 1]);
+            relu_tile<kBits>(a3[0], h3[2 * t][0], h3[2 * t + 1][0], m3[t]);
         });
         f32x16 logit[1];
         begin<KSX, NS, 20>(cx);
