@@ -385,6 +385,33 @@ NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, co
  * lane maps documented in DESIGN.md; used by the GPU tests to pin the fragment layout. */
 NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
 /* out[i] = (which ? cos : sin)(in[i]) with the kernel's own range reduction.  */
+/* ------------------------------------------------------------------------ */
+/* Runtime-shaped MLP (csrc/mlp_generic.hip): every mlp.Network the reference */
+/* can build (nerfactor/networks/mlp.py:24-50: widths, activations, skip_at    */
+/* anywhere; nerfactor/models/nerf.py:53-90: mlp_width, enc_depth,             */
+/* use_views = False, pos_enc = False) that the tuned kernels above do not     */
+/* cover — one fused kernel, bf16 operands / fp32 accumulate, FORWARD ONLY.    */
+/* widths[i] = units of Dense layer i, acts[i] = NFX_ACT_*, skip_input[i] != 0  */
+/* <=> layer i reads concat(output of layer i - 1, network input) (i - 1 is in  */
+/* the reference's skip_at).  Limits: d_in <= 128, widths <= 256, <= 16 layers  */
+/* (NFX_ENOSUP beyond).  kernels[i]: Keras layout [in_i, widths[i]].            */
+/* x: [n, ld_x] fp32, first d_in columns; y: [n, ld_y], columns                 */
+/* [col0, col0 + widths[n_layers - 1]) are written (so that a caller can        */
+/* assemble concat(features, embedded view) without a copy).                    */
+/* ------------------------------------------------------------------------ */
+NFX_API size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input);
+NFX_API int nfx_mlp_generic_pack(const float *const *kernels, const float *const *biases, int d_in, int n_layers,
+                                 const int *widths, const int *skip_input, void *blob, size_t blob_bytes);
+NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_in, int n_layers, const int *widths,
+                                const int *acts, const int *skip_input, const void *dev_blob, float *dev_y, int ld_y,
+                                int col0, void *stream);
+/* Embedder (nerfactor/networks/embedder.py:23-47) as a kernel: out[row, col0 ...] = [v, sin(2^0 v), cos(2^0 v), ...]
+ * (incl_input, n_freqs log-sampled bands; n_freqs = 0 = identity) of a 3-vector v per row:
+ *   mode 0: v = x[row / per_ray]        mode 1: v = x[row / per_ray] + dir[row / per_ray] * z[row]  (points along rays,
+ *   nerfactor/models/nerf.py:162-164)    mode 2: v = dir[row / per_ray]. */
+NFX_API int nfx_embed(const float *dev_x, const float *dev_dir, const float *dev_z, int64_t n, int per_ray, int mode,
+                      int n_freqs, int incl_input, float *dev_out, int ld_out, int col0, void *stream);
+
 /* D[32][32] = H^T Z (fp32 in, bf16 operands, fp32 out) for two row-major [16 rows][32 slots] tiles, contracted over the
  * ROW axis through LDS and ds_read_b64_tr_b16 exactly as the fused weight-gradient kernels do (csrc/tr16.hpp).
  * mode 1: D[256] = the raw lane map of the instruction (lane l reads LDS bytes 8 l .. 8 l + 7 of a tile holding its own

@@ -90,6 +90,10 @@ SIGNATURES = {
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
     'nfx_selftest_tr16': (_i, [_p, _p, _p, _i, _p]),
+    'nfx_mlp_generic_packed_bytes': (_sz, [_i, _i, _p, _p]),
+    'nfx_mlp_generic_pack': (_i, [_pp, _pp, _i, _i, _p, _p, _p, _sz]),
+    'nfx_mlp_generic_fwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
+    'nfx_embed': (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -67,24 +67,35 @@ class Model(BaseModel):
 
     def _init_embedder(self):
         cfg = self.config
-        if not cfg.getboolean('DEFAULT', 'pos_enc'):
-            raise NotImplementedError("pos_enc=False is not supported by the fused kernels")
         lx = cfg.getint('DEFAULT', 'n_freqs_xyz')
         lv = cfg.getint('DEFAULT', 'n_freqs_view')
+        if not cfg.getboolean('DEFAULT', 'pos_enc'):   # tf.identity in the reference (nerf.py:81-85): n_freqs = 0
+            lx = lv = 0
+        elif not self.use_views:                        # nerf.py:103-104: the view embedder is the identity
+            lv = 0
         return {
-            'xyz': Embedder(incl_input=True, in_dims=3, log2_max_freq=lx - 1, n_freqs=lx),
-            'view': Embedder(incl_input=True, in_dims=3, log2_max_freq=lv - 1, n_freqs=lv)}
+            'xyz': Embedder(incl_input=True, in_dims=3, log2_max_freq=max(lx - 1, 0), n_freqs=lx),
+            'view': Embedder(incl_input=True, in_dims=3, log2_max_freq=max(lv - 1, 0), n_freqs=lv)}
 
     def _check_fusable(self):
+        """self.tuned: the shipped architecture (config/nerf.ini: mlp_width = 256, enc_depth = 8, relu, use_views,
+        n_freqs_xyz = 10, n_freqs_view = 4) runs on the tuned kernels, forward and backward.  Every other shape the
+        reference can build (nerf.py:53-90: other widths and depths, use_views = False, pos_enc = False, other band
+        counts) RENDERS through the runtime-shaped kernels (csrc/mlp_generic.hip: nfx_embed + nfx_mlp_generic_fwd, bf16
+        operands like the tuned path); there is no backward for those, so a training call raises."""
         cfg = self.config
-        ok = (self.use_views and cfg.getint('DEFAULT', 'mlp_width') == 256 and
-              cfg.getint('DEFAULT', 'enc_depth') == 8 and
-              cfg.get('DEFAULT', 'act', fallback='relu') == 'relu' and
-              self.embedder['xyz'].n_freqs == 10 and self.embedder['view'].n_freqs == 4)
-        if not ok:
+        width, depth = cfg.getint('DEFAULT', 'mlp_width'), cfg.getint('DEFAULT', 'enc_depth')
+        act = cfg.get('DEFAULT', 'act', fallback='relu')
+        self.tuned = (self.use_views and width == 256 and depth == 8 and act == 'relu' and
+                      self.embedder['xyz'].n_freqs == 10 and self.embedder['view'].n_freqs == 4)
+        if self.tuned:
+            return
+        if act not in (None, 'relu', 'sigmoid', 'softplus') or depth < 2 or depth > 12 or not 1 <= width <= 256:
             raise NotImplementedError(
-                "libnfx implements the shipped NeRF architecture (config/nerf.ini: mlp_width=256, "
-                "enc_depth=8, relu, use_views, n_freqs_xyz=10, n_freqs_view=4)")
+                "libnfx's runtime-shaped kernels take 2 <= enc_depth <= 12, mlp_width <= 256 and relu / sigmoid / softplus "
+                "/ linear activations (got enc_depth = %d, mlp_width = %d, act = %s)" % (depth, width, act))
+        if self.precision != 'bf16':
+            raise NotImplementedError("precision = fp32 exists for the shipped NeRF architecture only")
 
     # ------------------------------------------------------------------ weights -> device blob
     def _nerf_blob(self, pref):
@@ -146,8 +157,58 @@ class Model(BaseModel):
         return self._packed(pref + 'train' + nfx_grad.GRAD_PREC, ks + bs,
                             lambda k, b: ops.pack_nerf_train_weights(k, b, nfx_grad.GRAD_PREC))
 
+    # ------------------------------------------------------------------ non-shipped shapes: runtime-shaped kernels
+    def _generic_nets(self, pref):
+        """The stage's networks packed for nfx_mlp_generic_fwd (cached like the tuned blobs, re-packed when a parameter
+        changes)."""
+        def packed(name):
+            net = self.net[pref + name]
+            ks, bs = net.kernels_and_biases()
+            acts = [l.activation for l in net.layers]
+
+            def pack(k, b):
+                g = ops.GenericNet(k, b, acts, net.skip_at)
+                self.__dict__.setdefault('_generic_desc', {})[pref + name] = g
+                return g.blob
+            blob = self._packed(pref + name + 'generic', ks + bs, pack)
+            g = self._generic_desc[pref + name]
+            g.blob = blob
+            return g
+        names = ('enc', 'sigma_out', 'bottleneck', 'rgb_out') if self.use_views else ('enc', 'rgbs_out')
+        return {n: packed(n) for n in names}
+
+    def _eval_rays_generic(self, rayo, rayd, z, pref):
+        """_eval_nerf_at (nerf.py:256-290) on the runtime-shaped kernels, chunked by `mlp_chunk` points like the
+        reference: embed(o + d z) -> enc -> [sigma_out | bottleneck -> concat(embed(view)) -> rgb_out] or rgbs_out."""
+        nets = self._generic_nets(pref)
+        n, s = z.shape
+        lx, lv = self.embedder['xyz'].n_freqs, self.embedder['view'].n_freqs
+        rays_per_chunk = max(1, self.config.getint('DEFAULT', 'mlp_chunk') // s)
+        rgbs = torch.empty((n, s, 4), dtype=torch.float32, device=z.device)
+        for r0 in range(0, n, rays_per_chunk):
+            r1 = min(n, r0 + rays_per_chunk)
+            o, d, zz = rayo[r0:r1].contiguous(), rayd[r0:r1].contiguous(), z[r0:r1].contiguous()
+            feat = ops.mlp_generic_fwd(ops.embed(lx, rayo=o, rayd=d, z=zz), nets['enc'])
+            out = rgbs[r0:r1].view(-1, 4)
+            if not self.use_views:
+                ops.mlp_generic_fwd(feat, nets['rgbs_out'], out=out)
+                continue
+            w = nets['bottleneck'].d_out
+            cat = torch.empty((feat.shape[0], w + 3 + 6 * lv), dtype=torch.float32, device=z.device)
+            ops.mlp_generic_fwd(feat, nets['bottleneck'], out=cat)              # columns [0, w)
+            ops.embed(lv, rayd=d, per_ray=s, out=cat, col0=w)                   # columns [w, w + 3 + 6 lv)
+            ops.mlp_generic_fwd(cat, nets['rgb_out'], out=out)                  # rgb -> columns 0..2
+            ops.mlp_generic_fwd(feat, nets['sigma_out'], out=out, col0=3)       # sigma -> column 3
+        return rgbs
+
     def _eval_rays(self, rayo, rayd, z, pref):
         """rgbs[N,S,4]; differentiable w.r.t. the network weights while autograd is recording."""
+        if not self.tuned:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError(
+                    "training a NeRF of a non-shipped shape: libnfx has backward kernels for the shipped architecture "
+                    "only (mlp_width = 256, enc_depth = 8, use_views, n_freqs 10 / 4); this shape renders (mode = 'test')")
+            return self._eval_rays_generic(rayo, rayd, z, pref)
         if torch.is_grad_enabled():
             ks, bs = self._nerf_params(pref)
             return autograd.NerfMlp.apply(rayo, rayd, z, self._nerf_blob(pref),
@@ -191,10 +252,15 @@ class Model(BaseModel):
         d = views.reshape(-1, 3).contiguous()
         z = torch.zeros((n * s, 1), dtype=torch.float32, device=pts.device)
         pref = 'fine_' if use_fine else 'coarse_'
+        if not self.tuned:
+            return self._eval_rays_generic(o, d, z, pref).reshape(n, s, 4)
         return ops.nerf_mlp_fwd(o, d, z, self._nerf_blob(pref), self.precision).reshape(n, s, 4)
 
     # ------------------------------------------------------------------ geometry extraction (geometry_from_nerf.py)
     def _nerf_geom_blob(self, pref, precision=None):
+        if not self.tuned:
+            raise NotImplementedError("geometry extraction (density / density-gradient kernels) exists for the shipped NeRF "
+                                      "architecture only")
         precision = precision or self.precision
         ks, bs = self._nerf_params(pref)
         return self._packed(pref + 'geom' + precision, ks + bs,

@@ -254,6 +254,87 @@ def selftest_mfma_bf16(a, b):
     return d
 
 
+# ------------------------------------------------------------------------------ runtime-shaped MLP (mlp_generic.hip)
+class GenericNet:
+    """A packed mlp.Network of arbitrary shape for mlp_generic_fwd: blob (uint8 tensor, move it with .to(device)) + the
+    layer description the C-ABI takes.  skip_at: the reference's list (after layer i the input is re-concatenated,
+    y first: nerfactor/networks/mlp.py:47-48)."""
+
+    def __init__(self, kernels, biases, acts, skip_at=None):
+        ks = [_as_host_f32(k) for k in kernels]
+        bs = [_as_host_f32(b) for b in biases]
+        n = len(ks)
+        if n == 0 or len(bs) != n or len(acts) != n:
+            raise _capi.NfxError("GenericNet: kernels, biases and acts must have the same, non-zero length")
+        self.widths = [int(k.shape[1]) for k in ks]
+        skip_at = set(skip_at or [])
+        self.skip_input = [1 if (i - 1) in skip_at else 0 for i in range(n)]
+        self.d_in = int(ks[0].shape[0])
+        for i in range(n):
+            want = (self.d_in if i == 0 else self.widths[i - 1] + (self.d_in if self.skip_input[i] else 0))
+            if ks[i].shape[0] != want or bs[i].shape != (self.widths[i],):
+                raise _capi.NfxError("GenericNet: layer %d has kernel %s / bias %s, expected [%d, %d] / [%d]" % (
+                    i, ks[i].shape, bs[i].shape, want, self.widths[i], self.widths[i]))
+        self.acts = [_ACT[a] for a in acts]
+        self._w = (ctypes.c_int * n)(*self.widths)
+        self._s = (ctypes.c_int * n)(*self.skip_input)
+        self._a = (ctypes.c_int * n)(*self.acts)
+        nbytes = lib.nfx_mlp_generic_packed_bytes(self.d_in, n, self._w, self._s)
+        if nbytes == 0:
+            raise _capi.NfxError("GenericNet: shape outside the generic kernel's limits: " + _capi.last_error())
+        blob = np.zeros(nbytes, np.uint8)
+        karr = (ctypes.c_void_p * n)(*[k.ctypes.data for k in ks])
+        barr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+        check(lib.nfx_mlp_generic_pack(karr, barr, self.d_in, n, self._w, self._s, blob.ctypes.data, nbytes),
+              'nfx_mlp_generic_pack')
+        self.blob = torch.from_numpy(blob)
+        self.n_layers, self.d_out = n, self.widths[-1]
+
+    def to(self, device):
+        self.blob = self.blob.to(device)
+        return self
+
+
+def mlp_generic_fwd(x, net, out=None, col0=0):
+    """y[n, d_out] = net(x[n, >= d_in]) through the runtime-shaped fused kernel; `out` / `col0`: write into columns
+    [col0, col0 + d_out) of an existing [n, ld] matrix (assembling a concatenation without a copy)."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise _capi.NfxError("mlp_generic_fwd: x must be a CUDA fp32 matrix with unit column stride")
+    n = x.shape[0]
+    if x.shape[1] < net.d_in:
+        raise _capi.NfxError("mlp_generic_fwd: x has %d columns, the network reads %d" % (x.shape[1], net.d_in))
+    if out is None:
+        out = torch.empty((n, net.d_out), dtype=torch.float32, device=x.device)
+    if out.dim() != 2 or out.shape[0] != n or out.stride(1) != 1 or not out.is_cuda or out.dtype != torch.float32:
+        raise _capi.NfxError("mlp_generic_fwd: bad output matrix")
+    check(lib.nfx_mlp_generic_fwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
+                                  net._s, _ptr(net.blob), _ptr(out), out.stride(0) if n else out.shape[1], col0,
+                                  _stream()), 'nfx_mlp_generic_fwd')
+    return out
+
+
+def embed(n_freqs, incl_input=True, x=None, rayo=None, rayd=None, z=None, per_ray=1, out=None, col0=0):
+    """Embedder (embedder.py:23-47) on the device: of x[n, 3] (per_ray rows per vector), of the points rayo + rayd z
+    (z[n_rays, S] -> n_rays S rows), or of the ray directions (rayd with per_ray rows each).  Returns / fills
+    out[:, col0 : col0 + 3 incl_input + 6 n_freqs]."""
+    d_out = (3 if incl_input else 0) + 6 * n_freqs
+    if z is not None:
+        mode, n, per_ray = 1, z.numel(), z.shape[1]
+        a, b, c = _dev(rayo, 'rayo', (None, 3)), _dev(rayd, 'rayd', (None, 3)), _dev(z, 'z')
+    elif x is not None:
+        mode, a, b, c = 0, _dev(x, 'x', (None, 3)), None, None
+        n = a.shape[0] * per_ray
+    else:
+        mode, a, b, c = 2, None, _dev(rayd, 'rayd', (None, 3)), None
+        n = b.shape[0] * per_ray
+    dev_ = (a if a is not None else b).device
+    if out is None:
+        out = torch.empty((n, d_out), dtype=torch.float32, device=dev_)
+    check(lib.nfx_embed(_ptr(a), _ptr(b), _ptr(c), n, per_ray, mode, n_freqs, 1 if incl_input else 0, _ptr(out),
+                        out.stride(0) if n else d_out, col0, _stream()), 'nfx_embed')
+    return out
+
+
 def selftest_tr16(h=None, z=None):
     """h, z: [16, 32] row-major tiles -> D[32, 32] = h^T z through LDS + ds_read_b64_tr_b16 (csrc/tr16.hpp); no arguments:
     the instruction's raw lane map, [64, 4]."""

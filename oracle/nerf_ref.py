@@ -102,7 +102,7 @@ NERF_WIDTH, NERF_DEPTH = 256, 8
 
 
 def init_nerf_net(rng, n_freqs_xyz=10, n_freqs_view=4, width=NERF_WIDTH, depth=NERF_DEPTH,
-                  sigma_bias=0., sigma_gain=1., dtype=np.float32):
+                  sigma_bias=0., sigma_gain=1., dtype=np.float32, use_views=True):
     """Random weights with the shapes of Model._init_net (nerf.py:53-71): glorot-uniform
     kernels, zero biases (Keras defaults).  sigma_bias / sigma_gain make the "opaque"
     variant of SURVEY.md §8d (non-trivial opacity exercises compositing + resampling)."""
@@ -112,6 +112,10 @@ def init_nerf_net(rng, n_freqs_xyz=10, n_freqs_view=4, width=NERF_WIDTH, depth=N
     for i in range(depth):
         enc.append((glorot_uniform(rng, fan_in, width, dtype), np.zeros(width, dtype)))
         fan_in = width + dx if i == skip else width
+    if not use_views:   # nerf.py:62-66: one linear head for (rgb, sigma)
+        k = glorot_uniform(rng, width, 4, dtype)
+        k[:, 3] *= dtype(sigma_gain)
+        return {'enc': enc, 'rgbs_out': [(k, np.array([0., 0., 0., sigma_bias], dtype))]}
     net = {
         'enc': enc,
         'sigma_out': [(glorot_uniform(rng, width, 1, dtype) * dtype(sigma_gain),
@@ -134,7 +138,7 @@ def randomize_biases(net, rng, scale=0.1):
 
 def eval_nerf_at(pts, views, net, n_freqs_xyz=10, n_freqs_view=4, quant=None,
                  mlp_chunk=65536):
-    """Model._eval_nerf_at (nerf.py:256-290), use_views=True branch.
+    """Model._eval_nerf_at (nerf.py:256-290); a net with 'rgbs_out' takes the use_views = False branch.
     pts, views [N,S,3] -> rgbs [N,S,4] = concat(raw rgb, raw sigma)."""
     depth = len(net['enc'])
     pts_flat = pts.reshape(-1, 3)
@@ -144,6 +148,9 @@ def eval_nerf_at(pts, views, net, n_freqs_xyz=10, n_freqs_view=4, quant=None,
         pe = embed(pts_flat[i:i + mlp_chunk], n_freqs_xyz)
         ve = embed(views_flat[i:i + mlp_chunk], n_freqs_view)
         feat = mlp(pe, net['enc'], ['relu'] * depth, skip_at=[depth // 2], quant=quant)
+        if 'rgbs_out' in net:   # use_views = False (nerf.py:283-286)
+            chunks.append(mlp(feat, net['rgbs_out'], [None], quant=quant))
+            continue
         sigma = mlp(feat, net['sigma_out'], [None], quant=quant)
         feat = mlp(feat, net['bottleneck'], [None], quant=quant)
         rgb = mlp(np.concatenate((feat, ve), -1), net['rgb_out'], ['relu', None],

