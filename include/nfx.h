@@ -393,7 +393,7 @@ NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float
 /* cover — one fused kernel, bf16 operands / fp32 accumulate, FORWARD ONLY.    */
 /* widths[i] = units of Dense layer i, acts[i] = NFX_ACT_*, skip_input[i] != 0  */
 /* <=> layer i reads concat(output of layer i - 1, network input) (i - 1 is in  */
-/* the reference's skip_at).  Limits: d_in <= 128, widths <= 256, <= 16 layers  */
+/* the reference's skip_at).  Limits: d_in <= 320, widths <= 256, <= 16 layers  */
 /* (NFX_ENOSUP beyond).  kernels[i]: Keras layout [in_i, widths[i]].            */
 /* x: [n, ld_x] fp32, first d_in columns; y: [n, ld_y], columns                 */
 /* [col0, col0 + widths[n_layers - 1]) are written (so that a caller can        */

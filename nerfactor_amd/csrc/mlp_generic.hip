@@ -13,7 +13,7 @@
 //   * weights are packed on the host in LOGICAL feature order (no permutation is needed: the operand comes from LDS,
 //     not from the previous tile's accumulators) as 1-KiB A fragments, read straight from global memory / L2;
 //   * the layer table (input widths, tiles, activation, fragment and bias offsets) is a kernel argument.
-// Limits: network input <= 128 features, hidden widths <= 256, <= 16 layers, output <= 256.  No backward: a model
+// Limits: network input <= 320 features, hidden widths <= 256, <= 16 layers, output <= 256.  No backward: a model
 // with a non-shipped shape renders (test.py, nerf_test.py) but trainvali raises NotImplementedError for it.
 // nfx_embed is the Embedder (embedder.py:23-47) as its own kernel, with the point generation o + d z folded in.
 #include "mlp_engine.hpp"

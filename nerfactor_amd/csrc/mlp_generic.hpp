@@ -4,7 +4,7 @@
 namespace nfx {
 namespace generic {
 
-constexpr int kMaxLayers = 16, kMaxIn = 128, kMaxHidden = 256;
+constexpr int kMaxLayers = 16, kMaxIn = 320, kMaxHidden = 256;   // kMaxIn: concat(256 features, embedded view) = 283
 
 struct Layer {
     int ks_h;      // k-steps (16 features) taken from the previous layer's output (0 for the first layer)

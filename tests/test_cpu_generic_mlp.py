@@ -72,6 +72,6 @@ def test_generic_limits_are_reported(nfx_lib):
     with pytest.raises(nfx_lib.NfxError, match='units'):
         ops.GenericNet([z(3, 300)], [np.zeros(300, np.float32)], [None])
     with pytest.raises(nfx_lib.NfxError, match='network input'):
-        ops.GenericNet([z(200, 8)], [np.zeros(8, np.float32)], [None])
+        ops.GenericNet([z(400, 8)], [np.zeros(8, np.float32)], [None])
     with pytest.raises(nfx_lib.NfxError, match='expected'):
         ops.GenericNet([z(3, 8), z(9, 4)], [np.zeros(8, np.float32), np.zeros(4, np.float32)], ['relu', None])

@@ -20,7 +20,7 @@ def dev(a, cuda):
     (3, [64, 64, 4], ['relu', 'relu', None], None, 77),
     (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 333),
     (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
-    (128, [256], ['relu'], None, 1)])
+    (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200)])
 def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
     from nerfactor_amd import ops
     rng = np.random.default_rng(sum(widths))
