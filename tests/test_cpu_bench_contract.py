@@ -1,5 +1,5 @@
-"""The bench line the driver parses, checked on the line committed as this round's evidence (profiles/r03/bench.json =
-the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5` on an MI355X): keys and types of the contract, the
+"""The bench line the driver parses, checked on the line committed as this round's evidence (profiles/r04/bench.json =
+the stdout of `python bench.py --gpus 1 --steps 20 --warmup 3` on an MI355X): keys and types of the contract, the
 roofline / cpu_baseline objects, and the arithmetic a reader can redo from the line itself.  No GPU needed; a change of
 bench.py's output format that forgets the contract, or evidence that no longer matches it, fails here."""
 import json
@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, 'profiles', 'r03', 'bench.json')
+LINE = os.path.join(ROOT, 'profiles', 'r04', 'bench.json')
 
 
 @pytest.fixture(scope='module')
@@ -33,7 +33,7 @@ def test_top_level_contract(line):
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert line['metric'].split(' ')[0] == base['metric'].split(' ')[0] == 'rays/sec'
     assert line['unit'] == 'rays/s' and line['higher_is_better'] is True
-    assert (line['n_gpus'], line['steps'], line['warmup']) == (1, 20, 5)
+    assert (line['n_gpus'], line['steps'], line['warmup']) == (1, 20, 3)
     assert line['scaling'] == 'weak' and line['data'] == 'synthetic' and line['dtype'] == 'bf16'
     assert line['vs_baseline'] is None                 # BASELINE.md holds no published number for this metric
     assert line['world_size'] == 1 and 'collective_backend' in line
@@ -57,7 +57,9 @@ def test_roofline_and_cpu_baseline(line):
     assert c['kind'] in ('port', 'reference') and c['unit'] == 'rays/s' and c['cores'] >= 1 and c['value'] > 0
     assert 'sample' in c
     p = line['parity']
-    assert p['psnr_db'] >= 40 and p['max_abs'] <= 3e-2                             # north_star's tolerance
+    assert p['psnr_db'] >= 40 and p['max_abs'] <= 3e-2                             # north_star's tolerance ...
+    assert p['rays_excluded_from_max_abs'] == 0 and p['max_abs_all_rays'] == p['max_abs']   # ... on EVERY ray (r04)
+    assert p['frac_rays_above_3e-2'] == 0 and p['rays_compared'] >= 4096
     pf = line['parity_fitted_weights']
     assert pf['psnr_db'] >= 40 and pf['rays_excluded_from_max_abs'] == 0 and pf['frac_rays_above_3e-2'] <= 0.01
 
@@ -73,9 +75,23 @@ def test_every_leg_of_the_metric_is_on_the_line(line):
         leg = line['train'][name]
         check_roofline(leg['roofline'], 'mfma')
         assert leg['steps'] >= 20 and leg['final_loss'] < leg['first_loss'] and 'collective' in leg and 'error' not in leg
+        assert leg['ms_per_step'] <= leg['ms_per_step_eager'] * 1.02 and 'step' in leg
+        par = leg['parity']                          # the reference's own ten steps through the same train path (r04)
+        tol = par['tolerance']
+        assert par['grad_rel_frobenius_vs_bf16_oracle_worst'] <= tol['grad_vs_bf16_oracle']
+        assert par['loss_step1_rel_err'] <= tol['loss_step1'] and par['loss_trajectory_max_rel_err'] <= tol['loss_trajectory']
+        assert par['params_after_10_steps_mean_dev_in_lr_steps'] <= tol['params_mean_dev'] and par['gradient_tensors'] >= 10
+    assert line['train']['nerfactor_microfacet']['ms_per_step'] <= 1.9            # <= 1.8 on the driver's box
+    assert line['train']['nerfactor_microfacet']['roofline']['frac'] >= 0.10
     olat = line['olat']                                                           # configs[4], OLAT half
     check_roofline(olat['roofline'], 'hbm')
     assert olat['ms_per_step'] > 0
+    sweep = line['relight']                                                       # configs[4], probe half: 4 views x 8 probes
+    assert sweep['views_per_step'] == 4 and sweep['probes'] == 8 and sweep['ms_per_view'] > 0
+    f32 = line['fp32_class']                                                      # the headline at the reference's precision
+    check_roofline(f32['roofline'], 'mfma')
+    assert f32['parity']['rays_excluded_from_max_abs'] == 0 and f32['parity']['max_abs_all_rays'] <= 2e-3
+    assert f32['parity']['q99_abs'] <= 2e-4 and f32['parity']['psnr_db'] >= 55
 
 
 def test_bench_defaults_and_cpu_exit():
