@@ -169,8 +169,8 @@ def committed_traffic(kernel_substr, scale=1):
     scripts/pmc_digest.py: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the kernel's dispatches of
     this very command at N = 1).  rocprofv3 counter passes cannot run inside this process, so the figure is a committed
     constant and the line says so."""
-    for rnd, name in (('r03', 'pmc_digest.json'), ('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'),
-                      ('r01', 'pmc_nerfactor_digest.json')):
+    for rnd, name in (('r04', 'pmc_digest.json'), ('r04', 'pmc_train_digest.json'), ('r03', 'pmc_digest.json'),
+                      ('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'), ('r01', 'pmc_nerfactor_digest.json')):
         dig = os.path.join(ROOT, 'profiles', rnd, name)
         if not os.path.exists(dig):
             continue
@@ -604,6 +604,15 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     calls = calls[:steps * per_step].reshape(steps, per_step)  # per step: the calls in launch order
     big = calls.max(1)                                          # the largest call of a step (light visibility / fine net)
     tf = flops / dt / 1e12
+    # HBM traffic of the step's largest backward call from the committed PMC digest of the training legs (separate
+    # rocprofv3 --pmc passes of `bench.py --legs train`): per launch, averaged over the kernel's dispatches
+    traffic, traffic_source, traffic_kernels = None, None, (
+        ['nerf_bwd_ring_kernel', 'wgrad_lds_kernel', 'wgrad_reduce_kernel'] if name == 'nerf' else
+        ['mlp128_bwd_fused_kernel<1, 0>', 'mlp128_bwd_fused_kernel<1, 1>', 'mlp128_wgrad_reduce_kernel<6>'])
+    if args.precision == 'bf16':
+        parts = [committed_traffic(k) for k in traffic_kernels]
+        if all(p[0] is not None for p in parts):
+            traffic, traffic_source = sum(p[0] for p in parts), parts[0][1]
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
         # the reference's own ten steps (tests/golden/reference_grads.npz) through the same train path: step-1
@@ -624,7 +633,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         "roofline": {"bound": "mfma", "kernel": "whole step; largest backward call = ops.%s (fused backward + batched "
                                                 "weight-gradient launches)" % dom,
                      "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
-                     "flop_per_step_per_gpu": flops, "traffic": None,
+                     "flop_per_step_per_gpu": flops, "traffic": traffic,
+                     "traffic_unit": "GB per largest backward call (%s)" % " + ".join(traffic_kernels),
+                     "traffic_source": traffic_source,
                      "largest_backward_call_ms": float(big.mean()),
                      "backward_calls_ms_per_step": float(calls.sum(1).mean())},
     }
