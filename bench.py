@@ -607,7 +607,7 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     # HBM traffic of the step's largest backward call from the committed PMC digest of the training legs (separate
     # rocprofv3 --pmc passes of `bench.py --legs train`): per launch, averaged over the kernel's dispatches
     traffic, traffic_source, traffic_kernels = None, None, (
-        ['nerf_bwd_ring_kernel', 'wgrad_lds_kernel', 'wgrad_reduce_kernel'] if name == 'nerf' else
+        ['nerf_bwd_ring_kernel', 'nfx::wgrad_lds_kernel', 'nfx::wgrad_reduce_kernel'] if name == 'nerf' else
         ['mlp128_bwd_fused_kernel<1, 0>', 'mlp128_bwd_fused_kernel<1, 1>', 'mlp128_wgrad_reduce_kernel<6>'])
     if args.precision == 'bf16':
         parts = [committed_traffic(k) for k in traffic_kernels]

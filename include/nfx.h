@@ -408,7 +408,9 @@ NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_i
 /* Embedder (nerfactor/networks/embedder.py:23-47) as a kernel: out[row, col0 ...] = [v, sin(2^0 v), cos(2^0 v), ...]
  * (incl_input, n_freqs log-sampled bands; n_freqs = 0 = identity) of a 3-vector v per row:
  *   mode 0: v = x[row / per_ray]        mode 1: v = x[row / per_ray] + dir[row / per_ray] * z[row]  (points along rays,
- *   nerfactor/models/nerf.py:162-164)    mode 2: v = dir[row / per_ray]. */
+ *   nerfactor/models/nerf.py:162-164)    mode 2: v = dir[row / per_ray]
+ *   mode 3: v = safe_l2_normalize(dir[row % per_ray] - x[row / per_ray]): the unit direction from surface point
+ *   row / per_ray to light row % per_ray (nerfactor/models/shape.py:128-131; per_ray = number of lights). */
 NFX_API int nfx_embed(const float *dev_x, const float *dev_dir, const float *dev_z, int64_t n, int per_ray, int mode,
                       int n_freqs, int incl_input, float *dev_out, int ld_out, int col0, void *stream);
 

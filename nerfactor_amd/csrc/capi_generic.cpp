@@ -119,7 +119,7 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
 
 int nfx_embed(const float* x, const float* dir, const float* z, int64_t n, int per_ray, int mode, int n_freqs, int incl_input,
               float* out, int ld_out, int col0, void* stream) {
-    REQUIRE(n >= 0 && per_ray >= 1 && mode >= 0 && mode <= 2 && n_freqs >= 0 && n_freqs <= 16, "nfx_embed: bad arguments");
+    REQUIRE(n >= 0 && per_ray >= 1 && mode >= 0 && mode <= 3 && n_freqs >= 0 && n_freqs <= 16, "nfx_embed: bad arguments");
     REQUIRE(incl_input || n_freqs > 0, "nfx_embed: empty encoding");
     if (n == 0) return NFX_OK;
     REQUIRE(out && (mode == 2 || x) && (mode == 0 || dir) && (mode != 1 || z), "nfx_embed: null pointer");

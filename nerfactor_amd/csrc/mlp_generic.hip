@@ -126,7 +126,13 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     for (int k = 0; k < 3; ++k) {
         if (a.mode == 0) v[k] = a.x[src * 3 + k];
         else if (a.mode == 1) v[k] = a.x[src * 3 + k] + a.dir[src * 3 + k] * a.z[row];
-        else v[k] = a.dir[src * 3 + k];
+        else if (a.mode == 2) v[k] = a.dir[src * 3 + k];
+        else v[k] = a.dir[(row - src * a.per_ray) * 3 + k] - a.x[src * 3 + k];   // light (row % per_ray) - point
+    }
+    if (a.mode == 3) {   // shape.py:128-131: safe_l2_normalize(lxyz - x), eps 1e-6
+        const float inv = 1.0f / sqrtf(fmaxf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], 1e-6f));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] *= inv;
     }
     float* o = a.out + row * a.ld_out + a.col0;
     int c = 0;

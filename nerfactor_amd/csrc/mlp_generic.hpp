@@ -35,7 +35,7 @@ struct EmbedArgs {
     const float* z;      // [n] depths (mode 1)
     long long n;
     int per_ray;         // rows per source vector / ray
-    int mode;            // 0: x   1: o + d z   2: d
+    int mode;            // 0: x   1: o + d z   2: d   3: normalize(dir[row % per_ray] - x[row / per_ray]) (surface -> light)
     int n_freqs, incl_input;
     float* out;
     int ld_out, col0;

@@ -26,8 +26,11 @@ class Model(BaseModel):
         self.normal_precision = cfg.get('DEFAULT', 'normal_precision', fallback='fp32')
         if self.normal_precision not in ('bf16', 'fp32'):
             raise ValueError("normal_precision = %s (bf16 | fp32)" % self.normal_precision)
+        self.tuned = True
         self.embedder = self._init_embedder()
         self.net = self._init_net()
+        if not self.tuned and self.precision != 'bf16':
+            raise NotImplementedError("precision = fp32 exists for the shipped surface MLP shapes only")
         # big world-space coordinates (e.g. MVS reconstructions) are scaled before the MLPs
         self.xyz_scale = cfg.getfloat('DEFAULT', 'xyz_scale', fallback=1.)
         lxyz, lareas = self._gen_lights()
@@ -53,9 +56,17 @@ class Model(BaseModel):
         width = cfg.getint('DEFAULT', 'mlp_width')
         depth = cfg.getint('DEFAULT', 'mlp_depth')
         skip_at = cfg.getint('DEFAULT', 'mlp_skip_at')
+        # self.tuned: the shipped surface MLP (mlp_width = 128, mlp_depth = 4, mlp_skip_at = 2 on 10 / 4 encoding bands)
+        # runs on the tuned kernels, forward and backward.  Other shapes the reference can build (shape.py:79-94) RENDER
+        # through the runtime-shaped kernels (csrc/mlp_generic.hip); training them raises (no backward of that generality).
         if (width, depth, skip_at) != (128, 4, 2):
-            raise NotImplementedError(
-                "libnfx implements the shipped surface MLP (mlp_width=128, mlp_depth=4, mlp_skip_at=2)")
+            self.tuned = False
+            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth - 1):
+                raise NotImplementedError(
+                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and a skip before the last "
+                    "layer (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
+            if self.precision != 'bf16':
+                raise NotImplementedError("precision = fp32 exists for the shipped surface MLP only")
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
         body.build(in_dims)
         head = mlp.Network([out_dims], act=[out_act])
@@ -78,7 +89,7 @@ class Model(BaseModel):
         ll = cfg.getint('DEFAULT', 'n_freqs_ldir')
         lv = cfg.getint('DEFAULT', 'n_freqs_vdir')
         if (lx, ll) != (10, 4):
-            raise NotImplementedError("libnfx implements n_freqs_xyz=10, n_freqs_ldir=4")
+            self.tuned = False     # other band counts: the runtime-shaped path (nfx_embed takes any)
         return {name: Embedder(incl_input=True, in_dims=3, log2_max_freq=L - 1, n_freqs=L)
                 for name, L in (('xyz', lx), ('ldir', ll), ('vdir', lv))}
 
@@ -117,6 +128,11 @@ class Model(BaseModel):
         """One xyz-conditioned head; differentiable w.r.t. its weights when autograd is recording.  `infer_prec`:
         operand type of the forward-only evaluation (vali / test / render) when it differs from `precision`."""
         params = self._params128(body, head)
+        if not self._net_tuned(body):
+            self._no_generic_training(params)
+            enc = ops.embed(self.embedder['xyz'].n_freqs, x=(pts * self.xyz_scale).contiguous())
+            y = ops.mlp_generic_fwd(enc, self._generic_net(body, head, out_act))
+            return y if (post_scale == 1. and post_bias == 0.) else y * post_scale + post_bias
         if self._wants_grad(params):
             blob = self._blob128(body, head, _capi.IN_XYZ, out_dim)
             return nfx_grad.Mlp128Xyz.apply(
@@ -127,6 +143,57 @@ class Model(BaseModel):
         blob = self._blob128(body, head, _capi.IN_XYZ, out_dim, prec=prec)
         return ops.mlp128_xyz_fwd(pts, blob, out_dim, out_act=out_act, xyz_scale=self.xyz_scale,
                                   post_scale=post_scale, post_bias=post_bias, prec=prec)
+
+    # ------------------------------------------------------------------ non-shipped shapes: runtime-shaped kernels
+    def _net_tuned(self, body_name, nets=None):
+        """Does THIS network have the shape the tuned kernels implement?  (A NeRFactor model may mix shapes: its shape
+        networks come with the pre-trained shape model's configuration, its albedo / BRDF-code heads with its own.)"""
+        body = (self.net if nets is None else nets)[body_name]
+        return (self.embedder['xyz'].n_freqs == 10 and self.embedder['ldir'].n_freqs == 4 and len(body.layers) == 4 and
+                all(l.units == 128 and l.activation == 'relu' for l in body.layers) and list(body.skip_at or []) == [2])
+
+    def _no_generic_training(self, params):
+        if self._wants_grad(params):
+            raise NotImplementedError(
+                "training a surface MLP of a non-shipped shape: libnfx has backward kernels for mlp_width = 128, "
+                "mlp_depth = 4, mlp_skip_at = 2, n_freqs 10 / 4 only; this shape renders (mode = 'vali' | 'test')")
+
+    def _generic_net(self, body_name, head_name, out_act, nets=None):
+        """Body + head as ONE runtime-shaped network (cached and re-packed like the tuned blobs)."""
+        nets = self.net if nets is None else nets
+        body, head = nets[body_name], nets[head_name]
+        ks, bs = body.kernels_and_biases()
+        ko, bo = head.kernels_and_biases()
+        acts = [l.activation for l in body.layers] + [out_act]
+
+        def pack(k, b):
+            g = ops.GenericNet(k, b, acts, body.skip_at)
+            self.__dict__.setdefault('_generic_desc', {})[body_name] = g
+            return g.blob
+        blob = self._packed(body_name + 'generic', ks + ko + bs + bo, pack)
+        g = self._generic_desc[body_name]
+        g.blob = blob
+        return g
+
+    def _pred_lvis_generic(self, pts, dir_pts):
+        """_pred_lvis_at (shape.py:213-237) for a non-shipped shape: per chunk of points the rows [point x light] are
+        assembled as [embed(xyz_scale x) | embed(normalize(light - x_dir))] and pushed through the runtime-shaped MLP
+        (mlp_chunk rows at a time, like the reference's chunk_apply)."""
+        lxyz = self.lxyz.reshape(-1, 3).contiguous()
+        n, L = pts.shape[0], lxyz.shape[0]
+        lx, ll = self.embedder['xyz'].n_freqs, self.embedder['ldir'].n_freqs
+        dx, dl = 3 + 6 * lx, 3 + 6 * ll
+        net = self._generic_net('lvis_mlp', 'lvis_out', 'sigmoid')
+        out = torch.empty((n, L), dtype=torch.float32, device=pts.device)
+        per = max(1, self.mlp_chunk // L)
+        dir_pts = pts if dir_pts is None else dir_pts
+        for i in range(0, n, per):
+            x = (pts[i:i + per] * self.xyz_scale).contiguous()
+            rows = torch.empty((x.shape[0] * L, dx + dl), dtype=torch.float32, device=pts.device)
+            ops.embed(lx, x=x, per_ray=L, out=rows)
+            ops.embed(ll, x=dir_pts[i:i + per].contiguous(), lights=lxyz, out=rows, col0=dx)
+            ops.mlp_generic_fwd(rows, net, out=out[i:i + per].view(-1, 1))
+        return out
 
     # ------------------------------------------------------------------ geometry helpers
     def _calc_ldir(self, pts):
@@ -189,8 +256,11 @@ class Model(BaseModel):
         """[N,L] visibility of every light from every point.  Directions are recomputed in the
         kernel from `self.lxyz` and `dir_pts` (default `pts`); an explicit `surf2l` tensor is
         accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
-        blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
         params = self._params128('lvis_mlp', 'lvis_out')
+        if not self._net_tuned('lvis_mlp'):
+            self._no_generic_training(params)
+            return self.check_numerics(self._pred_lvis_generic(pts, dir_pts), "Light visibility")
+        blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
         lxyz = self.lxyz.reshape(-1, 3)
         if self._wants_grad(params):
             lvis = nfx_grad.Lvis.apply(

@@ -313,12 +313,17 @@ def mlp_generic_fwd(x, net, out=None, col0=0):
     return out
 
 
-def embed(n_freqs, incl_input=True, x=None, rayo=None, rayd=None, z=None, per_ray=1, out=None, col0=0):
+def embed(n_freqs, incl_input=True, x=None, rayo=None, rayd=None, z=None, per_ray=1, out=None, col0=0, lights=None):
     """Embedder (embedder.py:23-47) on the device: of x[n, 3] (per_ray rows per vector), of the points rayo + rayd z
-    (z[n_rays, S] -> n_rays S rows), or of the ray directions (rayd with per_ray rows each).  Returns / fills
+    (z[n_rays, S] -> n_rays S rows), of the ray directions (rayd with per_ray rows each), or — lights[L, 3] given — of the
+    unit directions from every point x[n] to every light (n L rows, shape.py:128-131).  Returns / fills
     out[:, col0 : col0 + 3 incl_input + 6 n_freqs]."""
     d_out = (3 if incl_input else 0) + 6 * n_freqs
-    if z is not None:
+    if lights is not None:
+        mode, a, b, c = 3, _dev(x, 'x', (None, 3)), _dev(lights, 'lights', (None, 3)), None
+        per_ray = b.shape[0]
+        n = a.shape[0] * per_ray
+    elif z is not None:
         mode, n, per_ray = 1, z.numel(), z.shape[1]
         a, b, c = _dev(rayo, 'rayo', (None, 3)), _dev(rayd, 'rayd', (None, 3)), _dev(z, 'z')
     elif x is not None:

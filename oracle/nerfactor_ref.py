@@ -55,8 +55,8 @@ def init_mlp128(rng, in_dims, out_dims, width=128, depth=4, skip_at=2, dtype=np.
     return layers, out
 
 
-def mlp128(x, layers, out, out_act, quant=None):
-    h = mlp(x, layers, ['relu'] * len(layers), skip_at=[2], quant=quant)
+def mlp128(x, layers, out, out_act, quant=None, skip_at=2):
+    h = mlp(x, layers, ['relu'] * len(layers), skip_at=[skip_at], quant=quant)
     return mlp(h, out, [out_act], quant=quant)
 
 
@@ -70,18 +70,18 @@ def calc_vdir(cam_loc, pts, eps=1e-6):
     return l2_normalize(cam_loc - pts, 1, eps)
 
 
-def pred_normal_at(pts, net, xyz_scale=1., eps=1e-6, quant=None):
-    """shape.py:196-211 (raw, un-normalised, +1e-6)."""
-    pe = embed((pts.dtype.type(xyz_scale) * pts), 10)
-    return mlp128(pe, net['normal_mlp'], net['normal_out'], None, quant) + pts.dtype.type(eps)
+def pred_normal_at(pts, net, xyz_scale=1., eps=1e-6, quant=None, n_freqs_xyz=10, skip_at=2):
+    """shape.py:196-211 (raw, un-normalised, +1e-6).  (n_freqs_xyz / skip_at: config/shape.ini values by default.)"""
+    pe = embed((pts.dtype.type(xyz_scale) * pts), n_freqs_xyz)
+    return mlp128(pe, net['normal_mlp'], net['normal_out'], None, quant, skip_at) + pts.dtype.type(eps)
 
 
-def pred_lvis_at(pts, surf2l, net, xyz_scale=1., quant=None):
+def pred_lvis_at(pts, surf2l, net, xyz_scale=1., quant=None, n_freqs_xyz=10, n_freqs_ldir=4, skip_at=2):
     """shape.py:213-237: sigmoid MLP on concat(posenc10(pts), posenc4(ldir)) per (point, light)."""
     n, nl = surf2l.shape[:2]
     surf = np.broadcast_to((pts.dtype.type(xyz_scale) * pts)[:, None, :], (n, nl, 3)).reshape(-1, 3)
-    x = np.concatenate((embed(surf, 10), embed(surf2l.reshape(-1, 3), 4)), -1)
-    return mlp128(x, net['lvis_mlp'], net['lvis_out'], 'sigmoid', quant).reshape(n, nl)
+    x = np.concatenate((embed(surf, n_freqs_xyz), embed(surf2l.reshape(-1, 3), n_freqs_ldir)), -1)
+    return mlp128(x, net['lvis_mlp'], net['lvis_out'], 'sigmoid', quant, skip_at).reshape(n, nl)
 
 
 def pred_albedo_at(pts, net, xyz_scale=1., slope=0.77, bias=0.03, quant=None):
