@@ -390,7 +390,7 @@ NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float
 /* can build (nerfactor/networks/mlp.py:24-50: widths, activations, skip_at    */
 /* anywhere; nerfactor/models/nerf.py:53-90: mlp_width, enc_depth,             */
 /* use_views = False, pos_enc = False) that the tuned kernels above do not     */
-/* cover — one fused kernel, bf16 operands / fp32 accumulate, FORWARD ONLY.    */
+/* cover — one fused kernel, bf16 operands / fp32 accumulate.                  */
 /* widths[i] = units of Dense layer i, acts[i] = NFX_ACT_*, skip_input[i] != 0  */
 /* <=> layer i reads concat(output of layer i - 1, network input) (i - 1 is in  */
 /* the reference's skip_at).  Limits: d_in <= 320, widths <= 256, <= 16 layers  */
@@ -405,6 +405,24 @@ NFX_API int nfx_mlp_generic_pack(const float *const *kernels, const float *const
 NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_in, int n_layers, const int *widths,
                                 const int *acts, const int *skip_input, const void *dev_blob, float *dev_y, int ld_y,
                                 int col0, void *stream);
+/* Backward of the same networks (what trainvali.py:278-285 needs for a non-shipped shape: tf.GradientTape over
+ * mlp.Network).  The train blob = the forward blob followed by the transposed (dgrad) fragments; nfx_mlp_generic_fwd
+ * accepts it too.  Given dy = dLoss / d(activated output) [n, ld_dy] (columns col0_dy ...), ADDS dLoss/dW into
+ * dkernels[i] ([in_i, widths[i]], Keras layout) and dLoss/db into dbiases[i], and — dx != NULL — writes
+ * dLoss / d(network input) to dx[n, ld_dx] (first d_in columns), for chaining networks (bottleneck -> rgb_out,
+ * nerfactor/models/nerf.py:277-287).  The kernels re-compute the forward in bf16 from x; activation derivatives of
+ * hidden layers are taken from their bf16 outputs.  Deterministic (no atomics; the row split of the weight-gradient
+ * contraction depends on the problem shape only).  Workspace: nfx_mlp_generic_bwd_workspace_bytes (about
+ * 2 bytes x n x (d_in + 2 x sum of widths)), 16-byte aligned device memory. */
+NFX_API size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input);
+NFX_API int nfx_mlp_generic_pack_train(const float *const *kernels, const float *const *biases, int d_in, int n_layers,
+                                       const int *widths, const int *skip_input, void *blob, size_t blob_bytes);
+NFX_API size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, const int *widths,
+                                                   const int *skip_input);
+NFX_API int nfx_mlp_generic_bwd(const float *dev_x, int64_t n, int ld_x, int d_in, int n_layers, const int *widths,
+                                const int *acts, const int *skip_input, const void *dev_train_blob, const float *dev_dy,
+                                int ld_dy, int col0_dy, float *dev_dx, int ld_dx, float *const *dev_dkernels,
+                                float *const *dev_dbiases, void *dev_workspace, size_t workspace_bytes, void *stream);
 /* Embedder (nerfactor/networks/embedder.py:23-47) as a kernel: out[row, col0 ...] = [v, sin(2^0 v), cos(2^0 v), ...]
  * (incl_input, n_freqs log-sampled bands; n_freqs = 0 = identity) of a 3-vector v per row:
  *   mode 0: v = x[row / per_ray]        mode 1: v = x[row / per_ray] + dir[row / per_ray] * z[row]  (points along rays,

@@ -181,6 +181,28 @@ class NerfMlp(torch.autograd.Function):
         return (None,) * 6 + tuple(rks) + tuple(rbs)
 
 
+class GenericMlp(torch.autograd.Function):
+    """y = net(x) for an mlp.Network of any shape (csrc/mlp_generic.hip); gradients for its kernels / biases and — when
+    x itself carries a gradient (bottleneck -> rgb_out, nerf.py:277-287) — for x.  `net_fn()` returns the
+    ops.GenericNet holding the current train blob."""
+
+    @staticmethod
+    def forward(ctx, x, net_fn, *params):
+        net = net_fn()
+        ctx.save_for_backward(x)
+        ctx.cfg = (net_fn, params)
+        return ops.mlp_generic_fwd(x, net)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        net_fn, params = ctx.cfg
+        nk = len(params) // 2
+        (dks, rks), (dbs, rbs) = _targets(params[:nk]), _targets(params[nk:])
+        dx = ops.mlp_generic_bwd(x, net_fn(), dy.contiguous(), dks, dbs, want_dx=ctx.needs_input_grad[0])
+        return (dx, None) + tuple(rks) + tuple(rbs)
+
+
 class Composite(torch.autograd.Function):
     """(rgb, occu, depth, disp, weights) of nerf.py:184-254; the loss reaches the networks through rgb only, so
     that is the one differentiable output (occu / depth / disp / weights are returned detached)."""

@@ -17,6 +17,7 @@ extern "C" int nfx_option_int(const char* key, int dflt);        // capi.cpp
 extern "C" {
 int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipStream_t st);
 int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st);
+int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st);
 }
 
 // the layer table of a network: mlp.Network(widths, skip_at) semantics (nerfactor/networks/mlp.py:38-50) —
@@ -115,6 +116,161 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     a.col0 = col0;
     a.n_layers = n_layers;
     return nfx_hip_result(nfx_launch_mlp_generic(&a, 4 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// train blob = [forward fragments][biases][transposed fragments]: its head IS the forward blob
+namespace {
+struct BwdPlan {
+    nfx::generic::Layer layer[nfx::generic::kMaxLayers];
+    nfx::generic::BwdLayer b[nfx::generic::kMaxLayers];
+    int n_frags, n_bias, n_tfrags, feat_rows, n_jobs;
+    long long slice;
+};
+int bwd_plan(int d_in, int n_layers, const int* widths, const int* skip_input, const int* acts, BwdPlan* p) {
+    int rc = layer_table(d_in, n_layers, widths, skip_input, acts, p->layer, &p->n_frags, &p->n_bias);
+    if (rc) return rc;
+    const int mx = (d_in + 31) / 32;
+    int wt = 0, rows = 32 * mx, jobs = 0;
+    long long dw = 0;
+    for (int i = 0; i + 1 < n_layers; ++i) {
+        p->b[i].h_row = rows;
+        rows += 32 * p->layer[i].n_tiles;
+    }
+    p->b[n_layers - 1].h_row = -1;
+    for (int i = 0; i < n_layers; ++i) {
+        const nfx::generic::Layer& L = p->layer[i];
+        const int mh = i ? p->layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0);
+        p->b[i].wt_off = wt;
+        p->b[i].dz_row = rows;
+        p->b[i].dw_off = (int)dw;
+        p->b[i].job0 = jobs;
+        wt += m_in * 2 * L.n_tiles;
+        rows += 32 * L.n_tiles;
+        jobs += m_in * L.n_tiles;
+        dw += (long long)((i ? widths[i - 1] : 0) + (L.ks_x ? d_in : 0)) * L.n_out;
+    }
+    p->n_tfrags = wt;
+    p->feat_rows = rows;
+    p->n_jobs = jobs;
+    p->slice = dw;
+    return NFX_OK;
+}
+// row splits of the weight-gradient contraction: enough waves to fill the chip, a function of the problem shape only
+int wgrad_splits(long long tiles, int n_jobs) {
+    long long s = (4096 + n_jobs - 1) / n_jobs;
+    if (s > tiles / 4) s = tiles / 4;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input) {
+    BwdPlan p;
+    if (!widths || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
+    return (size_t)(p.n_frags + p.n_tfrags) * 1024 + (size_t)p.n_bias * 4;
+}
+
+int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* biases, int d_in, int n_layers,
+                               const int* widths, const int* skip_input, void* blob, size_t blob_bytes) {
+    REQUIRE(kernels && biases && widths && blob, "nfx_mlp_generic_pack_train: null argument");
+    BwdPlan p;
+    int rc = bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p);
+    if (rc) return rc;
+    const size_t head = (size_t)p.n_frags * 1024 + (size_t)p.n_bias * 4, need = head + (size_t)p.n_tfrags * 1024;
+    REQUIRE(blob_bytes >= need, "nfx_mlp_generic_pack_train: blob too small (%zu < %zu)", blob_bytes, need);
+    rc = nfx_mlp_generic_pack(kernels, biases, d_in, n_layers, widths, skip_input, blob, head);
+    if (rc) return rc;
+    uint16_t* wt = reinterpret_cast<uint16_t*>(static_cast<char*>(blob) + head);
+    memset(wt, 0, (size_t)p.n_tfrags * 1024);
+    const int mx = (d_in + 31) / 32;
+    for (int i = 0; i < n_layers; ++i) {
+        const nfx::generic::Layer& L = p.layer[i];
+        const int prev = i ? widths[i - 1] : 0, mh = i ? p.layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0), ks_o = 2 * L.n_tiles;
+        for (int mt = 0; mt < m_in; ++mt)
+            for (int s = 0; s < ks_o; ++s) {
+                uint16_t* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o + s) * 512;
+                const bool from_x = mt >= mh;
+                const int base = from_x ? prev : 0, feat0 = 32 * (from_x ? mt - mh : mt), limit = from_x ? d_in : prev;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int f = feat0 + (lane & 31), g = lane >> 5;       // A row = input feature, k = output feature
+                    if (f >= limit) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = 16 * s + 8 * g + j;
+                        if (o < L.n_out) frag[lane * 8 + j] = nfx::pack::f32_to_bf16_rne(kernels[i][(size_t)(base + f) * L.n_out + o]);
+                    }
+                }
+            }
+    }
+    return NFX_OK;
+}
+
+size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, const int* widths, const int* skip_input) {
+    BwdPlan p;
+    if (n < 0 || !widths || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
+    const long long tiles = (n + 31) / 32;
+    return align256((size_t)tiles * p.feat_rows * 64) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
+}
+
+int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_layers, const int* widths, const int* acts,
+                        const int* skip_input, const void* train_blob, const float* dy, int ld_dy, int col0_dy, float* dx,
+                        int ld_dx, float* const* dkernels, float* const* dbiases, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    REQUIRE(n >= 0, "nfx_mlp_generic_bwd: n < 0");
+    REQUIRE(widths && acts && dkernels && dbiases, "nfx_mlp_generic_bwd: null layer description");
+    BwdPlan p;
+    int rc = bwd_plan(d_in, n_layers, widths, skip_input, acts, &p);
+    if (rc) return rc;
+    for (int i = 0; i < n_layers; ++i) {
+        REQUIRE(acts[i] >= 0 && acts[i] <= 3, "nfx_mlp_generic_bwd: activation %d of layer %d", acts[i], i);
+        REQUIRE(dkernels[i] && dbiases[i], "nfx_mlp_generic_bwd: gradient buffer of layer %d is null", i);
+    }
+    if (n == 0) return NFX_OK;
+    REQUIRE(x && train_blob && dy && workspace, "nfx_mlp_generic_bwd: null pointer");
+    REQUIRE(ld_x >= d_in && ld_dy >= col0_dy + widths[n_layers - 1] && col0_dy >= 0 && (!dx || ld_dx >= d_in),
+            "nfx_mlp_generic_bwd: bad leading dimensions");
+    if (((uintptr_t)train_blob | (uintptr_t)workspace) & 15) return nfx_fail(NFX_EALIGN, "nfx_mlp_generic_bwd: blob / workspace must be 16-byte aligned");
+    const size_t need = nfx_mlp_generic_bwd_workspace_bytes(n, d_in, n_layers, widths, skip_input);
+    REQUIRE(workspace_bytes >= need, "nfx_mlp_generic_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    nfx::generic::BwdArgs ba;
+    nfx::generic::WgradArgs wa;
+    memset(&ba, 0, sizeof ba);
+    memset(&wa, 0, sizeof wa);
+    const long long tiles = (n + 31) / 32;
+    ba.f.x = x;
+    ba.f.n = n;
+    ba.f.ld_x = ld_x;
+    ba.f.d_in = d_in;
+    ba.f.weights = static_cast<const char*>(train_blob);
+    ba.f.biases = reinterpret_cast<const float*>(ba.f.weights + (size_t)p.n_frags * 1024);
+    ba.f.n_layers = n_layers;
+    ba.wt = ba.f.weights + (size_t)p.n_frags * 1024 + (size_t)p.n_bias * 4;
+    ba.dy = dy;
+    ba.ld_dy = ld_dy;
+    ba.col0_dy = col0_dy;
+    ba.dx = dx;
+    ba.ld_dx = ld_dx;
+    ba.ws = static_cast<char*>(workspace);
+    ba.tiles = tiles;
+    ba.feat_rows = p.feat_rows;
+    wa.ws = ba.ws;
+    wa.tiles = tiles;
+    wa.feat_rows = p.feat_rows;
+    wa.n_layers = n_layers;
+    wa.d_in = d_in;
+    wa.splits = wgrad_splits(tiles, p.n_jobs);
+    wa.n_jobs = p.n_jobs;
+    wa.slice = p.slice;
+    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * 64));
+    for (int i = 0; i < n_layers; ++i) {
+        ba.f.layer[i] = wa.layer[i] = p.layer[i];
+        ba.b[i] = wa.b[i] = p.b[i];
+        wa.dw[i] = dkernels[i];
+        wa.db[i] = dbiases[i];
+    }
+    return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 4 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
+                          "mlp_generic_bwd");
 }
 
 int nfx_embed(const float* x, const float* dir, const float* z, int64_t n, int per_ray, int mode, int n_freqs, int incl_input,

@@ -41,5 +41,43 @@ struct EmbedArgs {
     int ld_out, col0;
 };
 
+// ---- backward (round 4): one kernel re-computes the forward, runs the dgrad chain and leaves every layer's input
+// and output gradient in the workspace as TILE-BLOCKED, FEATURE-MAJOR bf16 — ws[row tile t][feature row f][32 rows],
+// every matrix (network input, hidden outputs, gradients) a range of feature rows padded to a multiple of 32 — the
+// layout in which a weight-gradient MFMA operand (one feature, 8 consecutive rows) is one 16-byte load, and in which
+// everything a wave writes and reads back lies in cache lines no other wave touches.  A second kernel contracts the
+// pairs over the rows, a third and fourth reduce its row splits and the bias gradients in a fixed order.
+struct BwdLayer {
+    int wt_off;    // first TRANSPOSED fragment of this layer (1 KiB units, relative to Args::weights): M tiles over the
+                   // previous layer's outputs, then over the network input, each x 2 n_tiles k-steps over this layer's outputs
+    int h_row;     // feature row (F units) of this layer's OUTPUT activations in the workspace (hidden layers only)
+    int dz_row;    // feature row of this layer's output gradient
+    int dw_off;    // float offset of this layer's kernel gradient in a partial slice
+    int job0;      // first weight-gradient job (32 x 32 tile of dW) of this layer
+};
+struct BwdArgs {
+    Args f;                  // the forward's arguments; f.y unused
+    const char* wt;          // transposed fragments (dgrad)
+    const float* dy;         // [n, ld_dy] gradient w.r.t. the activated outputs, columns [col0_dy, ...)
+    int ld_dy, col0_dy;
+    float* dx;               // [n, ld_dx] gradient w.r.t. the network input, or null
+    int ld_dx;
+    char* ws;                // workspace: bf16 [tiles][feat_rows][32]
+    long long tiles;         // row tiles (32 rows)
+    int feat_rows;           // sum of all padded feature counts (x at feature row 0, hidden outputs, gradients)
+    BwdLayer b[kMaxLayers];
+};
+struct WgradArgs {
+    const char* ws;
+    long long tiles;
+    int feat_rows, n_layers, d_in, splits, n_jobs;
+    long long slice;         // floats per partial slice
+    float* partial;          // [splits][slice]
+    Layer layer[kMaxLayers];
+    BwdLayer b[kMaxLayers];
+    float* dw[kMaxLayers];   // [n_in, n_out] fp32, ADDED into
+    float* db[kMaxLayers];   // [n_out]
+};
+
 }  // namespace generic
 }  // namespace nfx

@@ -81,8 +81,8 @@ class Model(BaseModel):
         """self.tuned: the shipped architecture (config/nerf.ini: mlp_width = 256, enc_depth = 8, relu, use_views,
         n_freqs_xyz = 10, n_freqs_view = 4) runs on the tuned kernels, forward and backward.  Every other shape the
         reference can build (nerf.py:53-90: other widths and depths, use_views = False, pos_enc = False, other band
-        counts) RENDERS through the runtime-shaped kernels (csrc/mlp_generic.hip: nfx_embed + nfx_mlp_generic_fwd, bf16
-        operands like the tuned path); there is no backward for those, so a training call raises."""
+        counts) renders AND trains through the runtime-shaped kernels (csrc/mlp_generic.hip: nfx_embed,
+        nfx_mlp_generic_fwd / _bwd, bf16 operands like the tuned path), one autograd node per network."""
         cfg = self.config
         width, depth = cfg.getint('DEFAULT', 'mlp_width'), cfg.getint('DEFAULT', 'enc_depth')
         act = cfg.get('DEFAULT', 'act', fallback='relu')
@@ -158,24 +158,46 @@ class Model(BaseModel):
                             lambda k, b: ops.pack_nerf_train_weights(k, b, nfx_grad.GRAD_PREC))
 
     # ------------------------------------------------------------------ non-shipped shapes: runtime-shaped kernels
-    def _generic_nets(self, pref):
-        """The stage's networks packed for nfx_mlp_generic_fwd (cached like the tuned blobs, re-packed when a parameter
-        changes)."""
-        def packed(name):
-            net = self.net[pref + name]
-            ks, bs = net.kernels_and_biases()
-            acts = [l.activation for l in net.layers]
+    def _generic_net(self, key, train=False):
+        """self.net[key] packed for nfx_mlp_generic_fwd / _bwd (cached like the tuned blobs, re-packed — on the device —
+        when a parameter changes); train = True: with the backward's transposed fragments."""
+        net = self.net[key]
+        ks, bs = net.kernels_and_biases()
+        acts = [l.activation for l in net.layers]
+        tag = key + ('generic_train' if train else 'generic')
+        descs = self.__dict__.setdefault('_generic_desc', {})
 
-            def pack(k, b):
-                g = ops.GenericNet(k, b, acts, net.skip_at)
-                self.__dict__.setdefault('_generic_desc', {})[pref + name] = g
-                return g.blob
-            blob = self._packed(pref + name + 'generic', ks + bs, pack)
-            g = self._generic_desc[pref + name]
-            g.blob = blob
-            return g
+        def pack(k, b):
+            g = ops.GenericNet(k, b, acts, net.skip_at, train=train)
+            descs.setdefault(tag, g)
+            return g.blob
+        blob = self._packed(tag, ks + bs, pack)
+        g = descs[tag]
+        g.blob = blob
+        return g
+
+    def _generic_nets(self, pref, train=False):
         names = ('enc', 'sigma_out', 'bottleneck', 'rgb_out') if self.use_views else ('enc', 'rgbs_out')
-        return {n: packed(n) for n in names}
+        return {n: self._generic_net(pref + n, train) for n in names}
+
+    def _generic_apply(self, key, x):
+        """net(x) recorded for autograd: forward and backward on the runtime-shaped kernels."""
+        ks, bs = self.net[key].kernels_and_biases()
+        return autograd.GenericMlp.apply(x, lambda: self._generic_net(key, train=True), *(ks + bs))
+
+    def _eval_rays_generic_train(self, rayo, rayd, z, pref):
+        """_eval_rays_generic with every network an autograd node (the embeddings are data): what trainvali.py's
+        GradientTape differentiates for a non-shipped shape."""
+        n, s = z.shape
+        lx, lv = self.embedder['xyz'].n_freqs, self.embedder['view'].n_freqs
+        feat = self._generic_apply(pref + 'enc', ops.embed(lx, rayo=rayo, rayd=rayd, z=z))
+        if not self.use_views:
+            return self._generic_apply(pref + 'rgbs_out', feat).view(n, s, 4)
+        sigma = self._generic_apply(pref + 'sigma_out', feat)
+        bott = self._generic_apply(pref + 'bottleneck', feat)
+        cat = torch.cat((bott, ops.embed(lv, rayd=rayd, per_ray=s)), 1)
+        rgb = self._generic_apply(pref + 'rgb_out', cat)
+        return torch.cat((rgb, sigma), 1).view(n, s, 4)
 
     def _eval_rays_generic(self, rayo, rayd, z, pref):
         """_eval_nerf_at (nerf.py:256-290) on the runtime-shaped kernels, chunked by `mlp_chunk` points like the
@@ -205,9 +227,7 @@ class Model(BaseModel):
         """rgbs[N,S,4]; differentiable w.r.t. the network weights while autograd is recording."""
         if not self.tuned:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError(
-                    "training a NeRF of a non-shipped shape: libnfx has backward kernels for the shipped architecture "
-                    "only (mlp_width = 256, enc_depth = 8, use_views, n_freqs 10 / 4); this shape renders (mode = 'test')")
+                return self._eval_rays_generic_train(rayo, rayd, z, pref)
             return self._eval_rays_generic(rayo, rayd, z, pref)
         if torch.is_grad_enabled():
             ks, bs = self._nerf_params(pref)

@@ -57,8 +57,8 @@ class Model(BaseModel):
         depth = cfg.getint('DEFAULT', 'mlp_depth')
         skip_at = cfg.getint('DEFAULT', 'mlp_skip_at')
         # self.tuned: the shipped surface MLP (mlp_width = 128, mlp_depth = 4, mlp_skip_at = 2 on 10 / 4 encoding bands)
-        # runs on the tuned kernels, forward and backward.  Other shapes the reference can build (shape.py:79-94) RENDER
-        # through the runtime-shaped kernels (csrc/mlp_generic.hip); training them raises (no backward of that generality).
+        # runs on the tuned kernels, forward and backward.  Other shapes the reference can build (shape.py:79-94) render
+        # and train through the runtime-shaped kernels (csrc/mlp_generic.hip), one autograd node per network.
         if (width, depth, skip_at) != (128, 4, 2):
             self.tuned = False
             if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth - 1):
@@ -129,9 +129,8 @@ class Model(BaseModel):
         operand type of the forward-only evaluation (vali / test / render) when it differs from `precision`."""
         params = self._params128(body, head)
         if not self._net_tuned(body):
-            self._no_generic_training(params)
-            enc = ops.embed(self.embedder['xyz'].n_freqs, x=(pts * self.xyz_scale).contiguous())
-            y = ops.mlp_generic_fwd(enc, self._generic_net(body, head, out_act))
+            enc = ops.embed(self.embedder['xyz'].n_freqs, x=(pts.detach() * self.xyz_scale).contiguous())
+            y = self._generic_apply(enc, body, head, out_act, params)
             return y if (post_scale == 1. and post_bias == 0.) else y * post_scale + post_bias
         if self._wants_grad(params):
             blob = self._blob128(body, head, _capi.IN_XYZ, out_dim)
@@ -152,28 +151,33 @@ class Model(BaseModel):
         return (self.embedder['xyz'].n_freqs == 10 and self.embedder['ldir'].n_freqs == 4 and len(body.layers) == 4 and
                 all(l.units == 128 and l.activation == 'relu' for l in body.layers) and list(body.skip_at or []) == [2])
 
-    def _no_generic_training(self, params):
-        if self._wants_grad(params):
-            raise NotImplementedError(
-                "training a surface MLP of a non-shipped shape: libnfx has backward kernels for mlp_width = 128, "
-                "mlp_depth = 4, mlp_skip_at = 2, n_freqs 10 / 4 only; this shape renders (mode = 'vali' | 'test')")
-
-    def _generic_net(self, body_name, head_name, out_act, nets=None):
-        """Body + head as ONE runtime-shaped network (cached and re-packed like the tuned blobs)."""
+    def _generic_net(self, body_name, head_name, out_act, nets=None, train=False):
+        """Body + head as ONE runtime-shaped network (cached and re-packed like the tuned blobs); train = True: with the
+        backward's transposed fragments."""
         nets = self.net if nets is None else nets
         body, head = nets[body_name], nets[head_name]
         ks, bs = body.kernels_and_biases()
         ko, bo = head.kernels_and_biases()
         acts = [l.activation for l in body.layers] + [out_act]
+        tag = body_name + ('generic_train' if train else 'generic')
+        descs = self.__dict__.setdefault('_generic_desc', {})
 
         def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at)
-            self.__dict__.setdefault('_generic_desc', {})[body_name] = g
+            g = ops.GenericNet(k, b, acts, body.skip_at, train=train)
+            descs.setdefault(tag, g)
             return g.blob
-        blob = self._packed(body_name + 'generic', ks + ko + bs + bo, pack)
-        g = self._generic_desc[body_name]
+        blob = self._packed(tag, ks + ko + bs + bo, pack)
+        g = descs[tag]
         g.blob = blob
         return g
+
+    def _generic_apply(self, rows, body_name, head_name, out_act, params, out=None):
+        """net(rows): an autograd node (runtime-shaped forward + backward kernels) while the weights are being trained,
+        the bare forward kernel otherwise."""
+        if self._wants_grad(params):
+            return nfx_grad.GenericMlp.apply(
+                rows, lambda: self._generic_net(body_name, head_name, out_act, train=True), *params)
+        return ops.mlp_generic_fwd(rows, self._generic_net(body_name, head_name, out_act), out=out)
 
     def _pred_lvis_generic(self, pts, dir_pts):
         """_pred_lvis_at (shape.py:213-237) for a non-shipped shape: per chunk of points the rows [point x light] are
@@ -183,17 +187,21 @@ class Model(BaseModel):
         n, L = pts.shape[0], lxyz.shape[0]
         lx, ll = self.embedder['xyz'].n_freqs, self.embedder['ldir'].n_freqs
         dx, dl = 3 + 6 * lx, 3 + 6 * ll
-        net = self._generic_net('lvis_mlp', 'lvis_out', 'sigmoid')
-        out = torch.empty((n, L), dtype=torch.float32, device=pts.device)
+        params = self._params128('lvis_mlp', 'lvis_out')
+        training = self._wants_grad(params)
+        out = None if training else torch.empty((n, L), dtype=torch.float32, device=pts.device)
         per = max(1, self.mlp_chunk // L)
-        dir_pts = pts if dir_pts is None else dir_pts
+        pts = pts.detach()
+        dir_pts = pts if dir_pts is None else dir_pts.detach()
+        parts = []
         for i in range(0, n, per):
             x = (pts[i:i + per] * self.xyz_scale).contiguous()
             rows = torch.empty((x.shape[0] * L, dx + dl), dtype=torch.float32, device=pts.device)
             ops.embed(lx, x=x, per_ray=L, out=rows)
             ops.embed(ll, x=dir_pts[i:i + per].contiguous(), lights=lxyz, out=rows, col0=dx)
-            ops.mlp_generic_fwd(rows, net, out=out[i:i + per].view(-1, 1))
-        return out
+            parts.append(self._generic_apply(rows, 'lvis_mlp', 'lvis_out', 'sigmoid', params,
+                                             out=None if training else out[i:i + per].view(-1, 1)))
+        return torch.cat(parts, 0).view(n, L) if training else out
 
     # ------------------------------------------------------------------ geometry helpers
     def _calc_ldir(self, pts):
@@ -258,7 +266,6 @@ class Model(BaseModel):
         accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
         params = self._params128('lvis_mlp', 'lvis_out')
         if not self._net_tuned('lvis_mlp'):
-            self._no_generic_training(params)
             return self.check_numerics(self._pred_lvis_generic(pts, dir_pts), "Light visibility")
         blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
         lxyz = self.lxyz.reshape(-1, 3)

@@ -256,11 +256,12 @@ def selftest_mfma_bf16(a, b):
 
 # ------------------------------------------------------------------------------ runtime-shaped MLP (mlp_generic.hip)
 class GenericNet:
-    """A packed mlp.Network of arbitrary shape for mlp_generic_fwd: blob (uint8 tensor, move it with .to(device)) + the
-    layer description the C-ABI takes.  skip_at: the reference's list (after layer i the input is re-concatenated,
-    y first: nerfactor/networks/mlp.py:47-48)."""
+    """A packed mlp.Network of arbitrary shape for mlp_generic_fwd / mlp_generic_bwd: blob (uint8 tensor, move it with
+    .to(device)) + the layer description the C-ABI takes.  skip_at: the reference's list (after layer i the input is
+    re-concatenated, y first: nerfactor/networks/mlp.py:47-48).  train = True packs the train blob (forward fragments +
+    transposed fragments for the backward); the forward accepts either."""
 
-    def __init__(self, kernels, biases, acts, skip_at=None):
+    def __init__(self, kernels, biases, acts, skip_at=None, train=False):
         ks = [_as_host_f32(k) for k in kernels]
         bs = [_as_host_f32(b) for b in biases]
         n = len(ks)
@@ -279,16 +280,19 @@ class GenericNet:
         self._w = (ctypes.c_int * n)(*self.widths)
         self._s = (ctypes.c_int * n)(*self.skip_input)
         self._a = (ctypes.c_int * n)(*self.acts)
-        nbytes = lib.nfx_mlp_generic_packed_bytes(self.d_in, n, self._w, self._s)
+        size_fn, pack_fn = ((lib.nfx_mlp_generic_train_packed_bytes, lib.nfx_mlp_generic_pack_train) if train else
+                            (lib.nfx_mlp_generic_packed_bytes, lib.nfx_mlp_generic_pack))
+        nbytes = size_fn(self.d_in, n, self._w, self._s)
         if nbytes == 0:
             raise _capi.NfxError("GenericNet: shape outside the generic kernel's limits: " + _capi.last_error())
         blob = np.zeros(nbytes, np.uint8)
         karr = (ctypes.c_void_p * n)(*[k.ctypes.data for k in ks])
         barr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
-        check(lib.nfx_mlp_generic_pack(karr, barr, self.d_in, n, self._w, self._s, blob.ctypes.data, nbytes),
-              'nfx_mlp_generic_pack')
+        check(pack_fn(karr, barr, self.d_in, n, self._w, self._s, blob.ctypes.data, nbytes), 'nfx_mlp_generic_pack')
         self.blob = torch.from_numpy(blob)
-        self.n_layers, self.d_out = n, self.widths[-1]
+        self.n_layers, self.d_out, self.train = n, self.widths[-1], bool(train)
+        self.in_dims = [self.d_in if i == 0 else self.widths[i - 1] + (self.d_in if self.skip_input[i] else 0)
+                        for i in range(n)]
 
     def to(self, device):
         self.blob = self.blob.to(device)
@@ -311,6 +315,33 @@ def mlp_generic_fwd(x, net, out=None, col0=0):
                                   net._s, _ptr(net.blob), _ptr(out), out.stride(0) if n else out.shape[1], col0,
                                   _stream()), 'nfx_mlp_generic_fwd')
     return out
+
+
+def mlp_generic_bwd(x, net, dy, dkernels, dbiases, want_dx=False):
+    """Backward of mlp_generic_fwd(x, net): ADDS dLoss/dW into dkernels[i] ([in_i, widths[i]]) and dLoss/db into
+    dbiases[i] given dy[n, d_out] = dLoss/d y; returns dLoss/dx [n, d_in] when want_dx (chained networks), else None.
+    `net` must carry a train blob (GenericNet(..., train=True))."""
+    if not net.train:
+        raise _capi.NfxError("mlp_generic_bwd: the network was packed without the backward fragments (train=True)")
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise _capi.NfxError("mlp_generic_bwd: x must be a CUDA fp32 matrix with unit column stride")
+    n = x.shape[0]
+    dy = _dev(dy, 'dy', (n, net.d_out))
+    if len(dkernels) != net.n_layers or len(dbiases) != net.n_layers:
+        raise _capi.NfxError("mlp_generic_bwd: need %d kernel and bias gradient buffers" % net.n_layers)
+    for i in range(net.n_layers):
+        for t, name, shape in ((dkernels[i], 'dkernels', (net.in_dims[i], net.widths[i])), (dbiases[i], 'dbiases', (net.widths[i],))):
+            if _dev(t, '%s[%d]' % (name, i), shape) is not t:
+                raise _capi.NfxError("mlp_generic_bwd: %s[%d] must be contiguous (it is accumulated into)" % (name, i))
+    dx = torch.empty((n, net.d_in), dtype=torch.float32, device=x.device) if want_dx else None
+    nbytes = lib.nfx_mlp_generic_bwd_workspace_bytes(n, net.d_in, net.n_layers, net._w, net._s)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    karr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dkernels])
+    barr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dbiases])
+    check(lib.nfx_mlp_generic_bwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
+                                  net._s, _ptr(net.blob), _ptr(dy), net.d_out, 0, _ptr(dx), net.d_in, karr, barr,
+                                  _ptr(ws), ws.numel(), _stream()), 'nfx_mlp_generic_bwd')
+    return dx
 
 
 def embed(n_freqs, incl_input=True, x=None, rayo=None, rayd=None, z=None, per_ray=1, out=None, col0=0, lights=None):

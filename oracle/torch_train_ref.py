@@ -67,9 +67,14 @@ def mlp128(x, P, name, out_act):
 
 
 # ------------------------------------------------------------------------------------------------ NeRF
-def _nerf_net(pts, views, P, pref):
-    pe, ve = embed(pts.reshape(-1, 3), 10), embed(views.reshape(-1, 3), 4)
-    feat = mlp(pe, P, pref + 'enc', 8, ['relu'] * 8, skip_at=[4])
+def _nerf_net(pts, views, P, pref, arch=None):
+    """arch = (n_freqs_xyz, n_freqs_view, enc_depth, use_views), default config/nerf.ini's; the widths are the
+    parameters' (models/nerf.py:53-90)."""
+    lx, lv, depth, use_views = arch or (10, 4, 8, True)
+    pe, ve = embed(pts.reshape(-1, 3), lx), embed(views.reshape(-1, 3), lv)
+    feat = mlp(pe, P, pref + 'enc', depth, ['relu'] * depth, skip_at=[depth // 2])
+    if not use_views:
+        return mlp(feat, P, pref + 'rgbs_out', 1, [None]).reshape(pts.shape[:2] + (4,))
     sigma = mlp(feat, P, pref + 'sigma_out', 1, [None])
     feat = mlp(feat, P, pref + 'bottleneck', 1, [None])
     rgb = mlp(torch.cat((feat, ve), -1), P, pref + 'rgb_out', 2, ['relu', None])
@@ -92,7 +97,7 @@ def _accumulate(rgbs, z, rayd, noise, white_bg):
 
 
 def nerf_loss(P, rayo, rayd, gt, u_coarse, n_coarse_noise, u_fine, n_fine_noise, near=2., far=6., n_coarse=64,
-              n_fine=128, white_bg=True, noise_std=0.):
+              n_fine=128, white_bg=True, noise_std=0., arch=None):
     """Per-ray training loss of models/nerf.py (loss = l2, keep_batch): the draws are the tf.random tensors in the order
     the reference makes them (uniform [n, 64], normal [n, 64], uniform [n, 128], normal [n, 192])."""
     dt = rayo.dtype
@@ -105,7 +110,7 @@ def nerf_loss(P, rayo, rayd, gt, u_coarse, n_coarse_noise, u_fine, n_fine_noise,
     upper, lower = torch.cat((mid, z[:, -1:]), -1), torch.cat((z[:, :1], mid), -1)
     z = lower + (upper - lower) * u_coarse
     pts = rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]
-    rgbs = _nerf_net(pts, rayd[:, None, :].expand(pts.shape), P, 'coarse_')
+    rgbs = _nerf_net(pts, rayd[:, None, :].expand(pts.shape), P, 'coarse_', arch)
     rgb_c, w = _accumulate(rgbs, z, rayd, n_coarse_noise * noise_std, white_bg)
     # gen_z_fine: inverse-transform sampling of the coarse weights, no gradient (nerf.py:143)
     with torch.no_grad():
@@ -122,7 +127,7 @@ def nerf_loss(P, rayo, rayd, gt, u_coarse, n_coarse_noise, u_fine, n_fine_noise,
         z_fine = val_b + (u_fine - cdf_b) / den * (val_a - val_b)
     z_all = torch.sort(torch.cat((z, z_fine), -1), -1).values
     pts = rayo[:, None, :] + rayd[:, None, :] * z_all[:, :, None]
-    rgbs = _nerf_net(pts, rayd[:, None, :].expand(pts.shape), P, 'fine_')
+    rgbs = _nerf_net(pts, rayd[:, None, :].expand(pts.shape), P, 'fine_', arch)
     rgb_f, _ = _accumulate(rgbs, z_all, rayd, n_fine_noise * noise_std, white_bg)
     return ((gt - rgb_c) ** 2).mean(-1) + ((gt - rgb_f) ** 2).mean(-1)
 

@@ -75,3 +75,46 @@ def test_generic_limits_are_reported(nfx_lib):
         ops.GenericNet([z(400, 8)], [np.zeros(8, np.float32)], [None])
     with pytest.raises(nfx_lib.NfxError, match='expected'):
         ops.GenericNet([z(3, 8), z(9, 4)], [np.zeros(8, np.float32), np.zeros(4, np.float32)], ['relu', None])
+
+
+@pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 5], [0]), (27, [40, 200, 33], [0, 1]), (130, [256], None)])
+def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in, widths, skip_at):
+    """nfx_mlp_generic_pack_train: [forward fragments | biases | transposed fragments].  A transposed fragment of layer i
+    (M tile over the layer's inputs — previous outputs first, then the network input —, k-step s over its outputs) holds
+    bf16(W_i[input 32 mt + (lane & 31)][output 16 s + 8 (lane >> 5) + j]); the dgrad product over them is dZ W^T."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(d_in)
+    ks, bs, prev = [], [], d_in
+    for i, w in enumerate(widths):
+        ks.append((rng.normal(size=(prev, w)) * 0.2).astype(np.float32))
+        bs.append((rng.normal(size=w) * 0.1).astype(np.float32))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    acts = ['relu'] * (len(widths) - 1) + [None]
+    fwd = ops.GenericNet(ks, bs, acts, skip_at).blob.numpy()
+    net = ops.GenericNet(ks, bs, acts, skip_at, train=True)
+    blob = net.blob.numpy()
+    assert net.train and np.array_equal(blob[:len(fwd)], fwd) and (len(blob) - len(fwd)) % 1024 == 0
+    frags = (blob[len(fwd):].view(np.uint16).reshape(-1, 64, 8).astype(np.uint32) << 16).view(np.float32)
+    mx, off = (d_in + 31) // 32, 0
+    for i, w in enumerate(widths):
+        nt = (w + 31) // 32
+        prev_w = widths[i - 1] if i else 0
+        mh = (prev_w + 31) // 32 if i else 0
+        m_in = mh + (mx if (i == 0 or net.skip_input[i]) else 0)
+        dz = bf(rng.normal(size=(5, w)))
+        dzp = np.pad(dz, ((0, 0), (0, nt * 32 - w)))
+        got = np.zeros((5, m_in * 32), np.float32)
+        for mt in range(m_in):
+            for s in range(2 * nt):
+                fr = frags[off + mt * 2 * nt + s]
+                for g in range(2):
+                    got[:, 32 * mt:32 * mt + 32] += dzp[:, 16 * s + 8 * g:16 * s + 8 * g + 8] @ fr[32 * g:32 * g + 32].T
+        want = dz @ bf(ks[i]).T                                   # [5, n_in]: previous outputs, then the network input
+        np.testing.assert_allclose(got[:, :prev_w], want[:, :prev_w], rtol=2e-5, atol=2e-5)
+        assert np.all(got[:, prev_w:32 * mh] == 0)
+        if m_in > mh:
+            np.testing.assert_allclose(got[:, 32 * mh:32 * mh + d_in], want[:, prev_w:], rtol=2e-5, atol=2e-5)
+            assert np.all(got[:, 32 * mh + d_in:] == 0)
+        off += m_in * 2 * nt
+    assert off == len(frags)
+    assert nfx_lib.lib.nfx_mlp_generic_bwd_workspace_bytes(1000, d_in, len(widths), net._w, net._s) > 0

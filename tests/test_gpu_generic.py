@@ -76,8 +76,7 @@ def test_embed_kernel_is_the_embedder(nfx_lib, cuda):
     (dict(pos_enc='False', mlp_width='128'), dict(width=128, n_freqs_xyz=0, n_freqs_view=0))])
 def test_nerf_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
     """Model.call(mode='test') of NeRF configurations outside config/nerf.ini's architecture against the oracle's render
-    of the same weights: the stated tolerance (max-abs 3e-2 outside the alpha_last band, PSNR >= 40 dB); training such a
-    model raises NotImplementedError (no backward kernels for it) instead of silently doing something else."""
+    of the same weights: the stated tolerance (max-abs 3e-2 outside the alpha_last band, PSNR >= 40 dB)."""
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.models import get_model_class
     cfg = make_config('nerf', **overrides)
@@ -109,9 +108,6 @@ def test_nerf_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
         assert err[ok].max() <= 3e-2, (tag, err[ok].max())
         # (rays inside the alpha_last band flip without the tuned path's fp32-class last sample: PSNR over the stable rays)
         assert nerf_ref.psnr_uint8_luma(got[ok].reshape(-1, 1, 3), ref['rgb'][ok].reshape(-1, 1, 3)) >= 40.
-    model.register_trainable()
-    with pytest.raises(NotImplementedError, match='non-shipped shape'):
-        model(batch, mode='train')
 
 
 @pytest.mark.parametrize("overrides,width,depth,skip,lx,ll", [
@@ -121,7 +117,7 @@ def test_nerf_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
 def test_shape_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, width, depth, skip, lx, ll):
     """Surface MLPs outside mlp_width = 128 / mlp_depth = 4 / mlp_skip_at = 2 / bands 10, 4 (reference shape.py:79-94 builds
     them from the ini): normals and the [points x 512 lights] visibilities of Model.call(mode='test') against the oracle
-    (bf16 bound 3e-2, same-rounding bound 1e-2); a training call raises NotImplementedError."""
+    (bf16 bound 3e-2, same-rounding bound 1e-2)."""
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.models import get_model_class
     from oracle import nerfactor_ref as R
@@ -157,6 +153,210 @@ def test_shape_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, width
     want_q = R.pred_lvis_at(xyz, surf2l, net, xyz_scale=scale, quant=nerf_ref.bf16_round, n_freqs_xyz=lx, n_freqs_ldir=ll, skip_at=skip)
     got_l = pred['lvis'].cpu().numpy()
     assert got_l.shape == want_l.shape and np.abs(got_l - want_l).max() < 3e-2 and np.abs(got_l - want_q).max() < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------- backward
+def _rel(got, want):
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def _oracle_grads(x, layers, acts, skip_at, dy, want_dx):
+    """d sum(y * dy) / d (kernels, biases, x) by torch.autograd over oracle/torch_train_ref.mlp in float64, operands of
+    every Dense layer rounded to bf16 with a straight-through gradient (what the MFMA path computes)."""
+    from oracle import torch_train_ref as T
+    P = {}
+    for i, (k, b) in enumerate(layers):
+        P['net_m_layer%d.kernel' % i] = torch.tensor(k, dtype=torch.float64, requires_grad=True)
+        P['net_m_layer%d.bias' % i] = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=want_dx)
+    T.QUANT = T.bf16_ste
+    try:
+        y = T.mlp(xt, P, 'm', len(layers), acts, skip_at)
+    finally:
+        T.QUANT = None
+    if skip_at and (len(layers) - 1) in skip_at:
+        raise AssertionError
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    n = len(layers)
+    return ([P['net_m_layer%d.kernel' % i].grad.numpy() for i in range(n)],
+            [P['net_m_layer%d.bias' % i].grad.numpy() for i in range(n)], xt.grad.numpy() if want_dx else None)
+
+
+@pytest.mark.parametrize("d_in,widths,acts,skip_at,n", [
+    (63, [96, 96, 96, 96, 5], ['relu'] * 4 + [None], [1], 1000),
+    (3, [64, 64, 4], ['relu', 'relu', None], None, 77),
+    (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 3333),
+    (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
+    (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200),
+    (39, [128, 128, 128, 1], ['relu'] * 3 + ['sigmoid'], [1], 20000)])
+def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
+    """nfx_mlp_generic_bwd: weight, bias and input gradients of arbitrary mlp.Network shapes against torch.autograd of
+    the oracle with the same bf16 operand rounding.  Bound: 2 % of each tensor's norm — the kernels round the
+    propagated gradient and the transposed weights to bf16 as well (two more 2^-9 roundings per layer), the oracle's
+    straight-through backward does not.  Bit-identical between calls; ADDS into the gradient buffers."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(sum(widths) + n)
+    layers, prev = [], d_in
+    for i, w in enumerate(widths):
+        layers.append((nerf_ref.glorot_uniform(rng, prev, w), rng.uniform(-.2, .2, size=w).astype(np.float32)))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, train=True).to(cuda)
+    x = rng.normal(size=(n, d_in)).astype(np.float32)
+    dy = rng.normal(size=(n, widths[-1])).astype(np.float32)
+    # the train blob's head is the forward blob
+    fwd = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at).to(cuda)
+    assert torch.equal(ops.mlp_generic_fwd(dev(x, cuda), net), ops.mlp_generic_fwd(dev(x, cuda), fwd))
+
+    def run(fill):
+        dks = [torch.full(k.shape, fill, device=cuda) for k, _ in layers]
+        dbs = [torch.full(b.shape, fill, device=cuda) for _, b in layers]
+        dx = ops.mlp_generic_bwd(dev(x, cuda), net, dev(dy, cuda), dks, dbs, want_dx=True)
+        return dks, dbs, dx
+    dks, dbs, dx = run(0.)
+    wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True)
+    for i in range(len(layers)):
+        assert _rel(dks[i].cpu().numpy(), wk[i]) < 2e-2, ('kernel', i, _rel(dks[i].cpu().numpy(), wk[i]))
+        assert _rel(dbs[i].cpu().numpy(), wb[i]) < 2e-2, ('bias', i, _rel(dbs[i].cpu().numpy(), wb[i]))
+    assert dx.shape == (n, d_in) and _rel(dx.cpu().numpy(), wx) < 2e-2, _rel(dx.cpu().numpy(), wx)
+    dks2, dbs2, dx2 = run(1.)
+    for a, b in zip(dks + dbs, dks2 + dbs2):
+        assert torch.allclose(a + 1., b, rtol=0, atol=1e-6 * max(1., float(a.abs().max())))     # accumulates
+    dks3, dbs3, dx3 = run(0.)
+    for a, b in zip(dks + dbs + [dx], dks3 + dbs3 + [dx3]):
+        assert torch.equal(a, b)                                                               # deterministic
+    # no input gradient requested: the same weight gradients
+    dks4 = [torch.zeros_like(t) for t in dks]
+    assert ops.mlp_generic_bwd(dev(x, cuda), net, dev(dy, cuda), dks4, [torch.zeros_like(t) for t in dbs]) is None
+    for a, b in zip(dks, dks4):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception, match='train'):
+        ops.mlp_generic_bwd(dev(x, cuda), fwd, dev(dy, cuda), dks4, dbs)
+
+
+def test_nerf_plugin_trains_non_shipped_shapes(nfx_lib, cuda):
+    """models.nerf.Model of a non-shipped shape under autograd (one GenericMlp node per network, Composite, the l2
+    loss): the first step's gradients against torch.autograd of oracle/torch_train_ref.nerf_loss with the same uniform
+    draws, then 40 AMSGrad steps on the fixed batch reduce the loss."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from oracle import torch_train_ref as T
+    nc, nf = 16, 32
+    cfg = make_config('nerf', mlp_width='64', enc_depth='4', n_freqs_xyz='6', n_freqs_view='2',
+                      n_samples_coarse=str(nc), n_samples_fine=str(nf), lr='1e-3')
+    assert cfg.getboolean('DEFAULT', 'perturb') and cfg.getfloat('DEFAULT', 'noise_std') == 0.
+    torch.manual_seed(11)
+    model = get_model_class('nerf')(cfg)
+    rng = np.random.default_rng(12)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('.bias'):
+                p.copy_(torch.from_numpy(rng.uniform(-.1, .1, size=tuple(p.shape)).astype(np.float32)))
+            if 'sigma_out' in name and name.endswith('.kernel'):
+                p.mul_(8.)
+    model = model.to(cuda)
+    assert not model.tuned
     model.register_trainable()
-    with pytest.raises(NotImplementedError, match='non-shipped shape'):
-        model(batch, mode='train')
+    rayo, rayd = common.camera_rays(16, 16)
+    n = rayo.shape[0]
+    gt = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
+    batch = (['x'] * n, torch.tensor([[16, 16]] * n), dev(rayo, cuda), dev(rayd, cuda), dev(gt, cuda))
+    u_c, u_f = rng.uniform(size=(n, nc)).astype(np.float32), rng.uniform(size=(n, nf)).astype(np.float32)
+    draws = iter([u_c, u_f])
+    real_rand = torch.rand
+
+    def replay(shape, device=None, **kw):
+        a = next(draws)
+        assert tuple(a.shape) == tuple(shape)
+        return torch.from_numpy(a).to(device)
+    torch.rand = replay
+    try:
+        pred, gt_, loss_kwargs, _ = model(batch, mode='train')
+        loss = model.compute_loss(pred, gt_, keep_batch=True).sum() / n
+        loss.backward()
+    finally:
+        torch.rand = real_rand
+    got = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+    P = {k: p.detach().cpu().double().requires_grad_(True) for k, p in model.named_parameters()}
+    t64 = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+    T.QUANT = T.bf16_ste
+    try:
+        ref = T.nerf_loss(P, t64(rayo), t64(rayd), t64(gt), t64(u_c), torch.zeros(n, nc, dtype=torch.float64), t64(u_f),
+                          torch.zeros(n, nc + nf, dtype=torch.float64), near=cfg.getfloat('DEFAULT', 'near'),
+                          far=cfg.getfloat('DEFAULT', 'far'), n_coarse=nc, n_fine=nf,
+                          white_bg=cfg.getboolean('DEFAULT', 'white_bg'), arch=(6, 2, 4, True)).sum() / n
+    finally:
+        T.QUANT = None
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-2 * float(ref.detach()), (float(loss.detach()), float(ref.detach()))
+    assert set(got) == set(P)
+    worst = max((_rel(got[k], P[k].grad.numpy()), k) for k in got)
+    assert worst[0] < 5e-2, worst
+    opt = optim.make_optimizer(model, cfg)
+    losses = []
+    for step in range(40):
+        opt.zero_grad()
+        pred, gt_, _, _ = model(batch, mode='train')
+        l = model.compute_loss(pred, gt_, keep_batch=True).sum() / n
+        l.backward()
+        losses.append(float(opt.step(loss=l.detach())))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+
+def test_shape_plugin_trains_non_shipped_shapes(nfx_lib, cuda):
+    """models.shape.Model with 64-wide, 3-deep surface MLPs: the gradients of one training call against
+    torch.autograd of the oracle's networks (float64, bf16 operand rounding), then the loss falls under AMSGrad."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from oracle import torch_train_ref as T
+    cfg = make_config('shape', xyz_jitter_std='0', mlp_width='64', mlp_depth='3', mlp_skip_at='1', lr='1e-3')
+    torch.manual_seed(3)
+    model = get_model_class('shape')(cfg).to(cuda)
+    assert not model._net_tuned('normal_mlp')
+    model.register_trainable()
+    rng = np.random.default_rng(4)
+    n = 96
+    xyz = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    normal = nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12)
+    L = model.lxyz.reshape(-1, 3).shape[0]
+    lvis = rng.uniform(size=(n, L)).astype(np.float32)
+    z3 = np.zeros((n, 3), np.float32)
+    batch = (['x'] * n, torch.tensor([[1, n]] * n), dev(z3, cuda), dev(z3, cuda), dev(z3, cuda),
+             torch.ones(n, 1, device=cuda), dev(xyz, cuda), dev(normal, cuda), dev(lvis, cuda))
+    pred, gt, kw, _ = model(batch, mode='train')
+    loss = model.compute_loss(pred, gt, **kw).mean()
+    loss.backward()
+    got = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+    assert len(got) == 16 and all(np.abs(g).max() > 0 for g in got.values())
+    # oracle: the same two networks and loss (shape.py:239-277 with alpha = 1: MSE over the last axis of both heads)
+    P = {k: p.detach().cpu().double().requires_grad_(True) for k, p in model.named_parameters()}
+    lxyz = model.lxyz.reshape(-1, 3).cpu().double()
+    x64 = torch.from_numpy(xyz.astype(np.float64)) * model.xyz_scale
+    T.QUANT = T.bf16_ste
+    try:
+        pe = T.embed(x64, 10)
+        nrm = T.mlp(T.mlp(pe, P, 'normal_mlp', 3, ['relu'] * 3, [1]), P, 'normal_out', 1, [None]) + 1e-6
+        nrm = T.l2n(nrm, 1, 1e-6)
+        d = lxyz[None] - torch.from_numpy(xyz.astype(np.float64))[:, None]
+        le = T.embed(T.l2n(d, 2, 1e-6), 4)
+        rows = torch.cat((pe[:, None].expand(n, L, pe.shape[1]), le), -1).reshape(n * L, -1)
+        vis = T.mlp(T.mlp(rows, P, 'lvis_mlp', 3, ['relu'] * 3, [1]), P, 'lvis_out', 1, ['sigmoid']).reshape(n, L)
+    finally:
+        T.QUANT = None
+    w_n, w_l = cfg.getfloat('DEFAULT', 'normal_loss_weight'), cfg.getfloat('DEFAULT', 'lvis_loss_weight')
+    ref = (w_n * ((nrm - torch.from_numpy(normal.astype(np.float64))) ** 2).mean(-1) +
+           w_l * ((vis - torch.from_numpy(lvis.astype(np.float64))) ** 2).mean(-1)).mean()
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-2 * float(ref.detach()), (float(loss.detach()), float(ref.detach()))
+    worst = max((_rel(got[k], P[k].grad.numpy()), k) for k in got)
+    assert worst[0] < 5e-2, worst
+    opt = optim.make_optimizer(model, cfg)
+    losses = []
+    for step in range(40):
+        opt.zero_grad()
+        pred, gt, kw, _ = model(batch, mode='train')
+        l = model.compute_loss(pred, gt, **kw).mean()
+        l.backward()
+        losses.append(float(opt.step(loss=l.detach())))
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
