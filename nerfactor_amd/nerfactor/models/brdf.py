@@ -37,8 +37,15 @@ class Model(BaseModel):
         width = cfg.getint('DEFAULT', 'mlp_width')
         depth = cfg.getint('DEFAULT', 'mlp_depth')
         skip_at = cfg.getint('DEFAULT', 'mlp_skip_at')
-        if (width, depth, skip_at) != (128, 4, 2):
-            raise NotImplementedError("libnfx implements mlp_width=128, mlp_depth=4, mlp_skip_at=2")
+        # self.tuned: the shipped prior (config/brdf.ini: 128 x 4, skip at 2, 2 encoding bands) runs on the fused
+        # width-128 template, forward and backward; every other shape the reference can build (brdf.py:57-86) on the
+        # runtime-shaped kernels (csrc/mlp_generic.hip), rows = [z | embed(rusink)] assembled explicitly.
+        self.tuned = (width, depth, skip_at) == (128, 4, 2) and self.embedder['rusink'].n_freqs == 2
+        if not self.tuned:
+            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth - 1):
+                raise NotImplementedError(
+                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and a skip before the last "
+                    "layer (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
         body.build(self.z_dim + self.embedder['rusink'].out_dims)
         head = mlp.Network([1], act=['softplus'])  # reflectance > 0
@@ -47,13 +54,10 @@ class Model(BaseModel):
 
     def _init_embedder(self):
         cfg = self.config
-        if not cfg.getboolean('DEFAULT', 'pos_enc'):
-            raise NotImplementedError("pos_enc=False is not supported by the fused kernels")
         n_freqs = cfg.getint('DEFAULT', 'n_freqs')
-        if n_freqs != 2:
-            raise NotImplementedError("libnfx implements the shipped Rusinkiewicz encoder (n_freqs=2)")
-        return {'rusink': Embedder(incl_input=True, in_dims=3, log2_max_freq=n_freqs - 1,
-                                   n_freqs=n_freqs)}
+        if not cfg.getboolean('DEFAULT', 'pos_enc'):   # tf.identity in the reference (brdf.py:72-74): no bands
+            n_freqs = 0
+        return {'rusink': Embedder(incl_input=True, in_dims=3, log2_max_freq=max(n_freqs - 1, 0), n_freqs=n_freqs)}
 
     def _train_blob(self):
         """Forward + dgrad + input-gradient fragments of the prior (cached, re-packed on the device after a step)."""
@@ -71,12 +75,45 @@ class Model(BaseModel):
         ko, bo = self.net['brdf_out'].kernels_and_biases()
         params = tuple(ks + ko) + tuple(bs + bo)
         z, rusink = z.float().contiguous(), rusink.float().contiguous()
+        if not self.tuned:
+            return self._eval_brdf_generic(z, rusink, params)
         if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params)):
             brdf, reci = nfx_grad.BrdfRows.apply(z, rusink, self._train_blob, self.precision, *params)
         else:
             out = ops.brdf_rows_fwd(z, rusink, self._train_blob(), reci=True, prec=nfx_grad.GRAD_PREC)   # rows kernels: bf16 only
             brdf, reci = out[:z.shape[0]], out[z.shape[0]:]
         return brdf[:, None], reci[:, None]
+
+    def _generic_net(self, train=False):
+        ks, bs = self.net['brdf_mlp'].kernels_and_biases()
+        ko, bo = self.net['brdf_out'].kernels_and_biases()
+        body = self.net['brdf_mlp']
+        acts = [l.activation for l in body.layers] + ['softplus']
+        tag = 'brdf_generic_train' if train else 'brdf_generic'
+        descs = self.__dict__.setdefault('_generic_desc', {})
+
+        def pack(k, b):
+            g = ops.GenericNet(k, b, acts, body.skip_at, train=train)
+            descs.setdefault(tag, g)
+            return g.blob
+        blob = self._packed(tag, ks + ko + bs + bo, pack)
+        g = descs[tag]
+        g.blob = blob
+        return g
+
+    def _eval_brdf_generic(self, z, rusink, params):
+        """_eval_brdf_at for a non-shipped shape: the 2 M rows [z | embed(rusink)], [z | embed(rusink with phi_d + pi)]
+        through the runtime-shaped MLP — an autograd node (weights, and z through the concatenation) when recording."""
+        import math
+        nf, m = self.embedder['rusink'].n_freqs, z.shape[0]
+        reci = torch.cat((rusink[:, :1] + math.pi, rusink[:, 1:]), 1)
+        enc = ops.embed(nf, x=torch.cat((rusink, reci), 0).contiguous())
+        rows = torch.cat((torch.cat((z, z), 0), enc), 1)
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params)):
+            y = nfx_grad.GenericMlp.apply(rows, lambda: self._generic_net(train=True), *params)
+        else:
+            y = ops.mlp_generic_fwd(rows, self._generic_net())
+        return y[:m], y[m:]
 
     # ------------------------------------------------------------------ training of the prior (brdf.py:87-136)
     def call(self, batch, mode='train'):

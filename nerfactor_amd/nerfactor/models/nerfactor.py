@@ -56,6 +56,11 @@ class Model(ShapeModel):
 
     def _init_brdf_model(self):
         self.brdf_model = BRDFModel(self.config_brdf)
+        if not self.brdf_model.tuned:
+            raise NotImplementedError(
+                "NeRFactor evaluates the BRDF prior inside the fused shading kernels (nfx_brdf_spec_fwd / _bwd), which "
+                "implement the shipped prior (mlp_width = 128, mlp_depth = 4, mlp_skip_at = 2, n_freqs = 2); a prior of "
+                "another shape trains and tests on its own (models.brdf) but cannot be plugged in here")
         if configutil.ckpt_available(self._brdf_ckpt):
             configutil.restore_model(self.brdf_model, self._brdf_ckpt)
         for p in self.brdf_model.parameters():

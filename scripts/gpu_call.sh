@@ -2,7 +2,7 @@
 # One GPU-box call (via gpurun): runs the stages named on the command line, everything worth keeping goes to gpurun_out/<tag>/.
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
 # stages: pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
-#         soak | soak-xp | soak-xp2 | sigma | fitted | prof | train-prof
+#         soak | soak-xp | soak-xp2 | sigma | fitted | generic | prof | train-prof | pmc | pmc-train
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -46,6 +46,7 @@ PYEOF
     bench-train) timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; tail -c 2500 $OUT/bench_train.json; tail -3 $OUT/bench_train.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
     soak-xp)  NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_build.log 2>&1; tail -16 $OUT/soak_experiment_build.log ;;
+    generic)  timeout 600 python scripts/generic_rates.py > $OUT/generic_rates.json 2> $OUT/generic_rates.err; cat $OUT/generic_rates.json; tail -3 $OUT/generic_rates.err ;;
     sigma)    timeout 600 python scripts/sigma_last_error.py > $OUT/sigma_last_error.json 2>&1; cat $OUT/sigma_last_error.json ;;
     prof)     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs ${PROF_LEGS:-nerf,nerfactor_microfacet,nerfactor,olat} > $ROOT/$OUT/prof_run.log 2>&1); find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -25 ;;
     train-prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_train -o train -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs train > $ROOT/$OUT/prof_train_run.log 2>&1); find $OUT/prof_train -name "*kernel_stats*" | head -1 | xargs -r head -30 ;;

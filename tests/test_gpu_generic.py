@@ -360,3 +360,70 @@ def test_shape_plugin_trains_non_shipped_shapes(nfx_lib, cuda):
         l.backward()
         losses.append(float(opt.step(loss=l.detach())))
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize("overrides,width,depth,skip,nf", [
+    (dict(mlp_width='64', mlp_depth='3', mlp_skip_at='1'), 64, 3, 1, 2),
+    (dict(n_freqs='4', z_dim='5'), 128, 4, 2, 4), (dict(pos_enc='False', mlp_width='96'), 96, 4, 2, 0)])
+def test_brdf_plugin_non_shipped_shapes(nfx_lib, cuda, overrides, width, depth, skip, nf):
+    """models.brdf.Model outside config/brdf.ini's architecture (reference brdf.py:57-86 builds width / depth / skip / bands
+    from the ini, pos_enc = False = identity): both reciprocal halves against the oracle, the gradients of one training
+    call — weights AND latent codes — against torch.autograd of the oracle, and AMSGrad reduces the loss."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from oracle import torch_train_ref as T
+    cfg = make_config('brdf', lr='1e-3', **overrides)
+    torch.manual_seed(5)
+    model = get_model_class('brdf')(cfg)
+    rng = np.random.default_rng(6)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('.bias'):
+                p.copy_(torch.from_numpy(rng.uniform(-.1, .1, size=tuple(p.shape)).astype(np.float32)))
+    model = model.to(cuda)
+    assert not model.tuned
+    model.register_trainable()
+    m = 700
+    rusink = rng.uniform(0, np.pi / 2, size=(m, 3)).astype(np.float32)
+    refl = rng.uniform(0.05, 2., size=(m, 1)).astype(np.float32)
+    i = torch.zeros(m, dtype=torch.long, device=cuda)
+    batch = (['a'] * m, i, None, None, None, dev(rusink, cuda), dev(refl, cuda))
+    pred, gt, kw, _ = model(batch, mode='train')
+    loss = model.compute_loss(pred, gt, **kw).mean()
+    loss.backward()
+    got = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+    P = {k: p.detach().cpu().double().requires_grad_(True) for k, p in model.named_parameters()}
+    zkey = [k for k in P if 'latent' in k or k.endswith('z') or 'code' in k]
+    assert len(zkey) == 1, list(P)
+    r64 = torch.from_numpy(rusink.astype(np.float64))
+    z = P[zkey[0]][0:1].expand(m, -1)
+    if cfg.getboolean('DEFAULT', 'normalize_z'):
+        z = T.l2n(z, 1, 1e-12)
+    T.QUANT = T.bf16_ste
+    try:
+        def run(r):
+            h = T.mlp(torch.cat((z, T.embed(r, nf)), 1), P, 'brdf_mlp', depth, ['relu'] * depth, [skip])
+            return T.mlp(h, P, 'brdf_out', 1, ['softplus'])
+        brdf, reci = run(r64), run(torch.cat((r64[:, :1] + np.pi, r64[:, 1:]), 1))
+    finally:
+        T.QUANT = None
+    assert np.abs(pred['brdf'].detach().cpu().numpy() - brdf.detach().numpy()).max() < 1e-2
+    assert np.abs(pred['brdf_reci'].detach().cpu().numpy() - reci.detach().numpy()).max() < 1e-2
+    f = {'log': torch.log, 'none': lambda v: v, 'divide': lambda v: v / (v + 1.)}[cfg.get('DEFAULT', 'loss_transform').lower()]
+    g64 = torch.from_numpy(refl.astype(np.float64))
+    ref = (((f(g64) - f(brdf)) ** 2).mean(-1) + ((f(g64) - f(reci)) ** 2).mean(-1)).mean()
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-2 * float(ref.detach())
+    assert set(got) == set(P)
+    worst = max((_rel(got[k], P[k].grad.numpy()), k) for k in got)
+    assert worst[0] < 5e-2, worst
+    opt = optim.make_optimizer(model, cfg)
+    losses = []
+    for step in range(40):
+        opt.zero_grad()
+        pred, gt, kw, _ = model(batch, mode='train')
+        l = model.compute_loss(pred, gt, **kw).mean()
+        l.backward()
+        losses.append(float(opt.step(loss=l.detach())))
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
