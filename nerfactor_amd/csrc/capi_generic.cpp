@@ -32,19 +32,27 @@ static int layer_table(int d_in, int n_layers, const int* widths, const int* ski
         if (widths[i] < 1 || widths[i] > kMaxHidden)
             return nfx_fail(NFX_ENOSUP, "generic MLP: layer %d has %d units (1 .. %d)", i, widths[i], kMaxHidden);
         Layer& L = out[i];
-        L.ks_h = i == 0 ? 0 : (widths[i - 1] + 15) / 16;
-        L.ks_x = (i == 0 || (skip_input && skip_input[i])) ? (d_in + 15) / 16 : 0;
+        // both operand sources padded to whole groups: a group never mixes the previous layer's output with the input
+        L.ks_h = i == 0 ? 0 : nfx::generic::pad_group((widths[i - 1] + 15) / 16);
+        L.ks_x = (i == 0 || (skip_input && skip_input[i])) ? nfx::generic::pad_group((d_in + 15) / 16) : 0;
+        L.ks_pad = L.ks_h + L.ks_x;
         L.n_tiles = (widths[i] + 31) / 32;
         L.n_out = widths[i];
         L.act = acts ? acts[i] : 0;
         L.w_off = w;
         L.b_off = b;
-        w += L.n_tiles * (L.ks_h + L.ks_x);
+        w += L.n_tiles * L.ks_pad;
         b += L.n_tiles * 32;
     }
     *n_frags = w;
     *n_bias = b;
     return NFX_OK;
+}
+static void set_pitches(nfx::generic::Args* a) {
+    int widest = 1;
+    for (int i = 0; i < a->n_layers; ++i) widest = a->layer[i].n_tiles > widest ? a->layer[i].n_tiles : widest;
+    a->x_pitch = (a->d_in + 63) / 64 * 128 + 16;       // whole k-groups (64 features) per row
+    a->h_pitch = (widest + 1) / 2 * 128 + 16;
 }
 
 size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input) {
@@ -64,8 +72,8 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
     const size_t need = (size_t)nf * 1024 + (size_t)nb * 4;
     REQUIRE(blob_bytes >= need, "nfx_mlp_generic_pack: blob too small (%zu < %zu)", blob_bytes, need);
     memset(blob, 0, need);
-    uint16_t* w = static_cast<uint16_t*>(blob);
-    float* b = reinterpret_cast<float*>(static_cast<char*>(blob) + (size_t)nf * 1024);
+    float* b = static_cast<float*>(blob);                                           // [biases | fragments]
+    uint16_t* w = reinterpret_cast<uint16_t*>(static_cast<char*>(blob) + (size_t)nb * 4);
     for (int i = 0; i < n_layers; ++i) {
         REQUIRE(kernels[i] && biases[i], "nfx_mlp_generic_pack: layer %d null", i);
         const nfx::generic::Layer& L = t[i];
@@ -74,7 +82,7 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
         (void)n_in;
         for (int tl = 0; tl < L.n_tiles; ++tl)
             for (int s = 0; s < L.ks_h + L.ks_x; ++s) {
-                uint16_t* frag = w + ((size_t)L.w_off + (size_t)tl * (L.ks_h + L.ks_x) + s) * 512;
+                uint16_t* frag = w + ((size_t)L.w_off + (size_t)tl * L.ks_pad + s) * 512;
                 const bool from_x = s >= L.ks_h;
                 const int base = from_x ? prev : 0, feat0 = 16 * (from_x ? s - L.ks_h : s), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -109,17 +117,19 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     a.n = n;
     a.ld_x = ld_x;
     a.d_in = d_in;
-    a.weights = static_cast<const char*>(blob);
-    a.biases = reinterpret_cast<const float*>(a.weights + (size_t)nf * 1024);
+    a.biases = static_cast<const float*>(blob);
+    a.weights = static_cast<const char*>(blob) + (size_t)nb * 4;
     a.y = y;
     a.ld_y = ld_y;
     a.col0 = col0;
     a.n_layers = n_layers;
-    return nfx_hip_result(nfx_launch_mlp_generic(&a, 4 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
+    a.n_frags = nf;
+    set_pitches(&a);
+    return nfx_hip_result(nfx_launch_mlp_generic(&a, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
-// train blob = [forward fragments][biases][transposed fragments]: its head IS the forward blob
+// train blob = [biases][forward fragments][transposed fragments]: its head IS the forward blob, the fragments one stream
 namespace {
 struct BwdPlan {
     nfx::generic::Layer layer[nfx::generic::kMaxLayers];
@@ -141,14 +151,18 @@ int bwd_plan(int d_in, int n_layers, const int* widths, const int* skip_input, c
     for (int i = 0; i < n_layers; ++i) {
         const nfx::generic::Layer& L = p->layer[i];
         const int mh = i ? p->layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0);
-        p->b[i].wt_off = wt;
         p->b[i].dz_row = rows;
         p->b[i].dw_off = (int)dw;
         p->b[i].job0 = jobs;
-        wt += m_in * 2 * L.n_tiles;
         rows += 32 * L.n_tiles;
-        jobs += m_in * L.n_tiles;
+        jobs += ((m_in + 1) / 2) * ((L.n_tiles + 1) / 2);        // 64 x 64 blocks of dW
         dw += (long long)((i ? widths[i - 1] : 0) + (L.ks_x ? d_in : 0)) * L.n_out;
+    }
+    for (int i = n_layers - 1; i >= 0; --i) {                     // the transposed stream: last layer first, as the backward walks
+        const nfx::generic::Layer& L = p->layer[i];
+        const int mh = i ? p->layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0);
+        p->b[i].wt_off = wt;
+        wt += m_in * nfx::generic::pad_group(2 * L.n_tiles);
     }
     p->n_tfrags = wt;
     p->feat_rows = rows;
@@ -188,9 +202,10 @@ int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* 
     for (int i = 0; i < n_layers; ++i) {
         const nfx::generic::Layer& L = p.layer[i];
         const int prev = i ? widths[i - 1] : 0, mh = i ? p.layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0), ks_o = 2 * L.n_tiles;
+        const int ks_o_pad = nfx::generic::pad_group(ks_o);
         for (int mt = 0; mt < m_in; ++mt)
             for (int s = 0; s < ks_o; ++s) {
-                uint16_t* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o + s) * 512;
+                uint16_t* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o_pad + s) * 512;
                 const bool from_x = mt >= mh;
                 const int base = from_x ? prev : 0, feat0 = 32 * (from_x ? mt - mh : mt), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -242,10 +257,12 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     ba.f.n = n;
     ba.f.ld_x = ld_x;
     ba.f.d_in = d_in;
-    ba.f.weights = static_cast<const char*>(train_blob);
-    ba.f.biases = reinterpret_cast<const float*>(ba.f.weights + (size_t)p.n_frags * 1024);
+    ba.f.biases = static_cast<const float*>(train_blob);
+    ba.f.weights = static_cast<const char*>(train_blob) + (size_t)p.n_bias * 4;
     ba.f.n_layers = n_layers;
-    ba.wt = ba.f.weights + (size_t)p.n_frags * 1024 + (size_t)p.n_bias * 4;
+    ba.f.n_frags = p.n_frags;
+    // layer 0's transposed tiles (all of them input-gradient tiles) end the stream: not walked when dx is not wanted
+    ba.stream_frags = p.n_frags + p.n_tfrags - (dx ? 0 : (d_in + 31) / 32 * nfx::generic::pad_group(2 * p.layer[0].n_tiles));
     ba.dy = dy;
     ba.ld_dy = ld_dy;
     ba.col0_dy = col0_dy;
@@ -269,7 +286,8 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
         wa.dw[i] = dkernels[i];
         wa.db[i] = dbiases[i];
     }
-    return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 4 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
+    set_pitches(&ba.f);
+    return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                           "mlp_generic_bwd");
 }
 

@@ -7,11 +7,12 @@
 // their arithmetic class: bf16 operands, fp32 accumulation and bias, one v_mfma_f32_32x32x16_bf16 per
 // (32 outputs x 32 rows x 16 inputs), transposed formulation H^T = W^T X^T (mlp_engine.hpp):
 //   * one wave = 32 rows, no workgroup-level synchronisation at all (waves are independent);
-//   * activations live in the wave's own LDS area as ROW-MAJOR bf16 — the network input (kept for the skip
+//   * activations live in the wave's own LDS area (sized from the network's real widths) as ROW-MAJOR bf16 — the network input (kept for the skip
 //     concatenations) and two ping-pong hidden buffers — so the B operand of any layer is a plain ds_read_b128 of the
 //     lane's row, whatever the width, and a layer's output tile goes back with four 8-byte stores per lane;
 //   * weights are packed on the host in LOGICAL feature order (no permutation is needed: the operand comes from LDS,
-//     not from the previous tile's accumulators) as 1-KiB A fragments, read straight from global memory / L2;
+//     not from the previous tile's accumulators) as 1-KiB A fragments, ONE stream in consumption order that each wave
+//     pulls through its own LDS ring with the DMA path, three groups of four fragments ahead of its MFMAs;
 //   * the layer table (input widths, tiles, activation, fragment and bias offsets) is a kernel argument.
 // Limits: network input <= 320 features, hidden widths <= 256, <= 16 layers, output <= 256.
 // nfx_embed is the Embedder (embedder.py:23-47) as its own kernel, with the point generation o + d z folded in.
@@ -21,134 +22,239 @@
 // walks the layers back with the TRANSPOSED weight fragments — dH^T = W dZ^T is the forward's loop with another weight
 // stream — multiplying by the activation's derivative taken from the stored bf16 outputs.  Every layer's input and
 // gradient go to the workspace through the transposing LDS read (tr16.hpp), 1 KiB contiguous per 16 features; the
-// weight-gradient kernel then needs no LDS at all: one wave per (32 x 32 tile of dW, row split), both MFMA operands
+// weight-gradient kernel then needs no LDS at all: one wave per (64 x 64 block of dW, row split), all MFMA operands
 // 16-byte loads.  Deterministic: fixed split count per problem shape, ordered reductions, no atomics.
 #include "mlp_engine.hpp"
+#include "lds_dma.hpp"
 #include "mlp_generic.hpp"
 #include "tr16.hpp"
 
 namespace nfx {
 namespace generic {
 
-constexpr int kWavesPerBlock = 2;
-constexpr int kXPitch = kMaxIn * 2 + 16, kHPitch = kMaxHidden * 2 + 16;   // bytes per row (+16: rows 4 banks apart)
-constexpr int kWaveLds = 32 * (kXPitch + 2 * kHPitch);
-constexpr int kLds = kWavesPerBlock * kWaveLds;
-static_assert(kLds <= 160 * 1024, "LDS");
+// One wave per workgroup (waves are independent: no barrier anywhere).  LDS of a wave: the weight ring, then 32 rows x
+// (x_pitch + 2 h_pitch) bytes of activations, the pitches sized by the HOST from the network's real widths
+// (Args::x_pitch / h_pitch: features x 2 + 16, rows 4 banks apart) — a 256-wide network keeps 3 waves per CU resident,
+// a 128-wide one 5, a 64-wide one 6.
+// LDS is addressed through address_space(3) pointers THROUGHOUT: a generic pointer that the compiler cannot trace back to
+// the shared array (a select between two buffers is enough) becomes a flat load, which waits on vmcnt — i.e. on the
+// weight ring's look-ahead — before every MFMA.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+constexpr int kRingGroups = 3, kGroupBytes = kGroup * kFragBytes, kRingBytes = kRingGroups * kGroupBytes;
+static_assert(kRingBytes + 32 * ((kMaxIn * 2 + 16) + 2 * (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
+static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8) = (kRingGroups - 1) kGroup pieces in flight");
 
-__device__ __forceinline__ float activate(float v, int act) {
-    switch (act) {
-        case 1: return fmaxf(v, 0.f);
-        case 2: return sigmoidf(v);
-        case 3: return softplusf(v);
-        default: return v;
+// The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
+// to whole groups of kGroup), copied global -> LDS by the DMA path (lds_dma.hpp) kRingGroups groups ahead of the MFMAs —
+// a register-staged prefetch cannot rotate its buffers without waiting for the loads it just issued; an LDS slot is
+// only an address.  The stream is circular: behind its last group the ring already fetches the next row tile's first.
+// vmcnt is in order, so "at most 8 pieces outstanding" = the oldest group has landed; the wave's other VMEM operations
+// can only make that wait stricter.
+struct Ring {
+    const char* next;    // next group to fetch (wave-uniform)
+    const char* begin;
+    const char* end;
+    const lds_char* lds_ptr; // the ring, as a pointer (reads) ...
+    unsigned lds;            // ... and as the LDS address M0 takes
+    unsigned lane_off;
+    int slot;            // oldest group = the one the MFMAs read next = the one refilled after them
+    __device__ __forceinline__ void issue() {
+        lds_dma_pieces<kGroup>(lane_off, next, lds + (unsigned)slot * kGroupBytes);
+        next += kGroupBytes;
+        if (next == end) next = begin;
+        slot = slot == kRingGroups - 1 ? 0 : slot + 1;
+    }
+    __device__ __forceinline__ void start(lds_char* ring, const char* stream, int n_frags, int lane) {
+        lds_ptr = ring;
+        lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+        lane_off = (unsigned)lane * 16u;
+        begin = next = stream;
+        end = stream + (size_t)n_frags * kFragBytes;
+        slot = 0;
+#pragma unroll
+        for (int i = 0; i < kRingGroups; ++i) issue();
+    }
+};
+// One 32 x 32 output tile: acc += W_tile^T [h | x], kg_h groups of four k-steps over the previous layer's output, then
+// kg_x over the network input.  A: the ring; B: 64 consecutive features of the lane's own row in LDS.  Nothing in the
+// loop depends on the k-step but immediate offsets: pad steps multiply zero fragments with whatever finite bf16 the
+// row holds there (the activation area is zeroed once, then only ever holds activations).
+__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
+    for (int gi = 0; gi < kg_h + kg_x; ++gi) {
+        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * 32) : xsrc + (gi - kg_h) * (kGroup * 32);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const lds_char* grp = w.lds_ptr + w.slot * kGroupBytes + w.lane_off;
+        bf16x8 af[kGroup], bf[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * kFragBytes);
+            bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc, 0, 0, 0);
+        // the slot is refilled only after every read of it has RETURNED (the compiler may sink MFMAs below this point,
+        // not memory operations above it); the wait overlaps the first MFMAs of the group
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        w.issue();
+    }
+    return acc;
+}
+// the wave's activation area starts as zeros: every feature a pad k-step can touch is a finite number
+__device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    for (int o = lane * 16; o < bytes; o += 64 * 16) *reinterpret_cast<lds_f32x4*>(p + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// the lane's row of the network input -> bf16, zero padded to whole k-steps; lane half g takes every other 8 features
+__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g) {
+    for (int c0 = 8 * g; c0 < feats; c0 += 16) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = src[c0 + j < d_in ? c0 + j : d_in - 1];     // (unconditional: eight loads in flight)
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c0 + j < d_in ? f[j] : 0.f);
+        *reinterpret_cast<lds_bf16x8*>(dst + c0 * 2) = v;
+    }
+}
+// bias of the lane's 16 outputs of a tile (D row of register q: (q&3) + 8 (q>>2) + 4 g) through wave-uniform (scalar)
+// loads: a vector load here would put a compiler-placed vmcnt(0) — a drain of the weight ring — into every tile
+__device__ __forceinline__ void load_bias(const float* __restrict__ bt, int g, float* v) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = (q & 3) + 8 * (q >> 2);
+        const float lo = bt[c], hi = bt[c + 4];
+        v[q] = g ? hi : lo;
     }
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64) void mlp_generic_kernel(Args a) {
+// The activation code is wave-uniform: ONE branch per tile around sixteen straight-line evaluations — a switch inside
+// the per-element loop is if-converted into "evaluate relu, sigmoid and softplus, select", ~50 VALU per element.
+__device__ __forceinline__ void activate16(float* v, int act) {
+    if (act == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
+    } else if (act == 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = sigmoidf(v[q]);
+    } else if (act == 3) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = softplusf(v[q]);
+    }
+}
+// features beyond the layer's width (last tile only) are exact zeros
+__device__ __forceinline__ void zero_pad16(float* v, int t, int g, int n_out) {
+    if (32 * t + 32 > n_out) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (32 * t + (q & 3) + 8 * (q >> 2) + 4 * g >= n_out) v[q] = 0.f;
+    }
+}
+// 16 floats (register q = feature (q&3) + 8 (q>>2) + 4 g of the tile) -> the lane's row in LDS as four 8-byte stores
+__device__ __forceinline__ void store_row16(lds_char* row_tile, int g, const float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[4 * q + j];
+        *reinterpret_cast<lds_bf16x4*>(row_tile + (8 * q + 4 * g) * 2) = o;
+    }
+}
+
+__global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, p = lane & 31;
-    char* xb = smem + wave * kWaveLds;                 // [32][kXPitch]  network input
-    char* hb[2] = {xb + 32 * kXPitch, xb + 32 * kXPitch + 32 * kHPitch};
+    const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
+    const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
+    lds_char* ring = (lds_char*)smem;
+    lds_char* xb = ring + kRingBytes;                   // [32][x_pitch]  network input
+    lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
     const long long n_tiles_rows = (a.n + 31) / 32;
-    for (long long rt = (long long)blockIdx.x * kWavesPerBlock + wave; rt < n_tiles_rows; rt += (long long)gridDim.x * kWavesPerBlock) {
+    Ring w;
+    w.start(ring, a.weights, a.n_frags, lane);
+    zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
+    for (long long rt = blockIdx.x; rt < n_tiles_rows; rt += gridDim.x) {
         const long long row0 = rt * 32;
-        // ---- network input -> bf16 rows (zero padded to a multiple of 16 features); lane half g takes the odd / even 16-byte groups
-        const int ks_in = (a.d_in + 15) / 16;
         {
             const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
-            const float* src = a.x + r * a.ld_x;
-            for (int c0 = 8 * g; c0 < ks_in * 16; c0 += 16) {
-                bf16x8 v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c0 + j < a.d_in ? src[c0 + j] : 0.f);
-                *reinterpret_cast<bf16x8*>(xb + p * kXPitch + c0 * 2) = v;
-            }
+            load_x(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
         }
         int cur = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-            const char* hsrc = hb[cur] + p * kHPitch + g * 16;      // this lane's row, its 8 of every 16 features
-            const char* xsrc = xb + p * kXPitch + g * 16;
-            char* hdst = hb[cur ^ 1] + p * kHPitch;
+            const lds_char* hsrc = hb[cur] + p * h_pitch + g * 16;      // this lane's row, its 8 of every 16 features
+            const lds_char* xsrc = xb + p * x_pitch + g * 16;
+            lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
             for (int t = 0; t < L.n_tiles; ++t) {
+                float bias[16];
+                load_bias(a.biases + L.b_off + 32 * t, g, bias);
                 f32x16 acc;
-                {
-                    const float* bt = a.biases + L.b_off + 32 * t + 4 * g;   // D row of register r: (r&3) + 8 (r>>2) + 4 g
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * q);
-                        acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
-                    }
-                }
-                const char* w = a.weights + ((size_t)L.w_off + (size_t)t * (L.ks_h + L.ks_x)) * kFragBytes + lane * 16;
-#pragma unroll 4
-                for (int s = 0; s < L.ks_h; ++s) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(w + (size_t)s * kFragBytes);
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hsrc + s * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
-                }
-                w += (size_t)L.ks_h * kFragBytes;
-#pragma unroll 4
-                for (int s = 0; s < L.ks_x; ++s) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(w + (size_t)s * kFragBytes);
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(xsrc + s * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
-                }
-                // D: lane = row p (+ half g), register r = output feature 32 t + (r&3) + 8 (r>>2) + 4 g
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+                acc = tile_mma(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
+                // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
+                activate16(v, L.act);
                 if (last) {
                     if (row0 + p < a.n) {
-                        float* dst = a.y + (row0 + p) * a.ld_y + a.col0;
+                        float* dst = a.y + (row0 + p) * a.ld_y + a.col0 + 32 * t + 4 * g;
+                        if (32 * t + 32 <= L.n_out) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
-                            if (f < L.n_out) dst[f] = activate(acc[r], L.act);
+                            for (int q = 0; q < 16; ++q) dst[(q & 3) + 8 * (q >> 2)] = v[q];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q)
+                                if (32 * t + (q & 3) + 8 * (q >> 2) + 4 * g < L.n_out) dst[(q & 3) + 8 * (q >> 2)] = v[q];
                         }
                     }
                 } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {   // registers 4 q .. 4 q + 3 = four consecutive features: one 8-byte store
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        bf16x4 v;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int f = 32 * t + j + 8 * q + 4 * g;
-                            v[j] = (__bf16)(f < L.n_out ? activate(acc[4 * q + j], L.act) : 0.f);   // pad features: exact zeros
-                        }
-                        *reinterpret_cast<bf16x4*>(hdst + (32 * t + 8 * q + 4 * g) * 2) = v;
-                    }
+                    zero_pad16(v, t, g, L.n_out);
+                    store_row16(hdst + 64 * t, g, v);
                 }
             }
             cur ^= 1;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead must not outlive the wave's LDS
 }
-
 
 // ------------------------------------------------------------------------------------------------ backward
-__device__ __forceinline__ float act_grad_logit(float v, int act) {     // d act / d logit
-    switch (act) {
-        case 1: return v > 0.f ? 1.f : 0.f;
-        case 2: { const float s = sigmoidf(v); return s * (1.f - s); }
-        case 3: return sigmoidf(v);
-        default: return 1.f;
+// d[q] *= d act / d logit at logit z[q]  (the output layer) ...
+__device__ __forceinline__ void scale_by_act_grad_logit16(float* d, const float* z, int act) {
+    if (act == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = z[q] > 0.f ? d[q] : 0.f;
+    } else if (act == 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float s = sigmoidf(z[q]); d[q] *= s * (1.f - s); }
+    } else if (act == 3) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] *= sigmoidf(z[q]);
     }
 }
-__device__ __forceinline__ float act_grad_output(float y, int act) {    // the same from the activated output
-    switch (act) {
-        case 1: return y > 0.f ? 1.f : 0.f;
-        case 2: return y * (1.f - y);
-        case 3: return 1.f - expf(-y);
-        default: return 1.f;
+// ... and the same from the activated output y[q] (hidden layers: what the workspace holds)
+__device__ __forceinline__ void scale_by_act_grad_output16(float* d, const float* y, int act) {
+    if (act == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = y[q] > 0.f ? d[q] : 0.f;
+    } else if (act == 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] *= y[q] * (1.f - y[q]);
+    } else if (act == 3) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] *= 1.f - expf(-y[q]);
     }
 }
 // [32 rows][F features] row-major bf16 in the wave's LDS -> feature rows [frow, frow + F) of the wave's workspace tile.
 // 16-lane group q takes rows 4 q .. 4 q + 3 (then + 16): lane i supplies row 4 q + (i >> 2), features f0 + 4 (i & 3) ..,
 // receives feature f0 + i of the four rows = one 8-byte store.
-__device__ __forceinline__ void store_blocked(const char* lds, int pitch, int F, char* wst, int frow, int lane) {
+__device__ __forceinline__ void store_blocked(const lds_char* lds, int pitch, int F, char* wst, int frow, int lane) {
     const int i = lane & 15, q = lane >> 4;
-    const char* src = lds + (4 * q + (i >> 2)) * pitch + 8 * (i & 3);
+    const lds_char* src = lds + (4 * q + (i >> 2)) * pitch + 8 * (i & 3);
     char* dst = wst + ((size_t)(frow + i) * 32 + 4 * q) * 2;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int f0 = 0; f0 < F; f0 += 16) {
@@ -159,112 +265,95 @@ __device__ __forceinline__ void store_blocked(const char* lds, int pitch, int F,
     }
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64) void mlp_generic_bwd_kernel(BwdArgs ba) {
+__global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, p = lane & 31;
-    char* xb = smem + wave * kWaveLds;
-    char* hb[2] = {xb + 32 * kXPitch, xb + 32 * kXPitch + 32 * kHPitch};
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    const int fx = (a.d_in + 31) / 32 * 32, ks_in = (a.d_in + 15) / 16, mx = fx / 32;
-    for (long long rt = (long long)blockIdx.x * kWavesPerBlock + wave; rt < ba.tiles; rt += (long long)gridDim.x * kWavesPerBlock) {
+    const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
+    const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
+    lds_char* ring = (lds_char*)smem;
+    lds_char* xb = ring + kRingBytes;
+    lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
+    const int fx = (a.d_in + 31) / 32 * 32, mx = fx / 32;
+    Ring w;
+    w.start(ring, a.weights, ba.stream_frags, lane);   // forward fragments, then the transposed ones, as one stream
+    zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
+    for (long long rt = blockIdx.x; rt < ba.tiles; rt += gridDim.x) {
         const long long row0 = rt * 32;
         const bool live = row0 + p < a.n;
         const long long r = live ? row0 + p : a.n - 1;
         char* wst = ba.ws + (size_t)rt * ba.feat_rows * 64;
-        {
-            const float* src = a.x + r * a.ld_x;
-            for (int c0 = 8 * g; c0 < fx; c0 += 16) {
-                bf16x8 v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c0 + j < a.d_in ? src[c0 + j] : 0.f);
-                *reinterpret_cast<bf16x8*>(xb + p * kXPitch + c0 * 2) = v;
-            }
-            store_blocked(xb, kXPitch, fx, wst, 0, lane);
-        }
+        load_x(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g);
+        store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         int cur = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-            const char* hsrc = hb[cur] + p * kHPitch + g * 16;
-            const char* xsrc = xb + p * kXPitch + g * 16;
-            char* hdst = hb[cur ^ 1] + p * kHPitch;
+            const lds_char* hsrc = hb[cur] + p * h_pitch + g * 16;
+            const lds_char* xsrc = xb + p * x_pitch + g * 16;
+            lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
             for (int t = 0; t < L.n_tiles; ++t) {
+                float bias[16];
+                load_bias(a.biases + L.b_off + 32 * t, g, bias);
                 f32x16 acc;
-                {
-                    const float* bt = a.biases + L.b_off + 32 * t + 4 * g;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 8 * q);
-                        acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+                acc = tile_mma(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
+                if (last) {      // dZ = dy * act'(logit); rows past n and features past the width contribute nothing
+                    const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy + 32 * t + 4 * g;
+                    float d[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = (q & 3) + 8 * (q >> 2);
+                        d[q] = dyr[32 * t + 4 * g + c < L.n_out ? c : 0];
                     }
-                }
-                const char* w = a.weights + ((size_t)L.w_off + (size_t)t * (L.ks_h + L.ks_x)) * kFragBytes + lane * 16;
-#pragma unroll 4
-                for (int s = 0; s < L.ks_h; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w + (size_t)s * kFragBytes),
-                                                                  *reinterpret_cast<const bf16x8*>(hsrc + s * 32), acc, 0, 0, 0);
-                w += (size_t)L.ks_h * kFragBytes;
-#pragma unroll 4
-                for (int s = 0; s < L.ks_x; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w + (size_t)s * kFragBytes),
-                                                                  *reinterpret_cast<const bf16x8*>(xsrc + s * 32), acc, 0, 0, 0);
-                const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
+                    scale_by_act_grad_logit16(d, v, L.act);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int f = 32 * t + j + 8 * q + 4 * g;
-                        float o = 0.f;
-                        if (f < L.n_out) o = last ? (live ? dyr[f] * act_grad_logit(acc[4 * q + j], L.act) : 0.f) : activate(acc[4 * q + j], L.act);
-                        v[j] = (__bf16)o;
-                    }
-                    *reinterpret_cast<bf16x4*>(hdst + (32 * t + 8 * q + 4 * g) * 2) = v;
+                    for (int q = 0; q < 16; ++q) v[q] = live ? d[q] : 0.f;
+                } else {
+                    activate16(v, L.act);
                 }
+                zero_pad16(v, t, g, L.n_out);
+                store_row16(hdst + 64 * t, g, v);
             }
-            if (!last) store_blocked(hb[cur ^ 1], kHPitch, L.n_tiles * 32, wst, ba.b[l].h_row, lane);
+            if (!last) store_blocked(hb[cur ^ 1], h_pitch, L.n_tiles * 32, wst, ba.b[l].h_row, lane);
             cur ^= 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stored activations are read back below (same wave, own lines)
-        // ---- backward: hb[cur] holds dZ of layer l
+        // ---- backward: hb[cur] holds dZ of layer l.  The transposed fragments follow the forward ones in the stream, last
+        // layer first; the tiles that produce dLoss/d(network input) are always computed (the stream does not skip) and
+        // stored only when dx is wanted — except layer 0's, which end the stream and are cut off it by the host.
         bool dx_written = false;
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const Layer L = a.layer[l];
-            store_blocked(hb[cur], kHPitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
-            const int ks_o = 2 * L.n_tiles, mh = l > 0 ? a.layer[l - 1].n_tiles : 0;
-            const char* zsrc = hb[cur] + p * kHPitch + g * 16;
-            const char* w = ba.wt + (size_t)ba.b[l].wt_off * kFragBytes + lane * 16;
+            store_blocked(hb[cur], h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
+            const int kg_o = pad_group(2 * L.n_tiles) / kGroup, mh = l > 0 ? a.layer[l - 1].n_tiles : 0;
+            const lds_char* zsrc = hb[cur] + p * h_pitch + g * 16;
             for (int mt = 0; mt < mh; ++mt) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 4
-                for (int s = 0; s < ks_o; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w + ((size_t)mt * ks_o + s) * kFragBytes),
-                                                                  *reinterpret_cast<const bf16x8*>(zsrc + s * 32), acc, 0, 0, 0);
-                const int pact = a.layer[l - 1].act;
+                acc = tile_mma(acc, w, kg_o, 0, zsrc, zsrc);
+                // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
                 const __bf16* hy = reinterpret_cast<const __bf16*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
-                char* zdst = hb[cur ^ 1] + p * kHPitch;
+                float d[16], y[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (__bf16)(acc[4 * q + j] * act_grad_output((float)hy[(8 * q + j) * 32], pact));
-                    *reinterpret_cast<bf16x4*>(zdst + (32 * mt + 8 * q + 4 * g) * 2) = v;
+                for (int q = 0; q < 16; ++q) {
+                    d[q] = acc[q];
+                    y[q] = (float)hy[((q & 3) + 8 * (q >> 2)) * 32];
                 }
+                scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
+                store_row16(hb[cur ^ 1] + p * h_pitch + 64 * mt, g, d);
             }
-            if (ba.dx && L.ks_x > 0) {
+            if (L.ks_x > 0 && (ba.dx || l > 0)) {
                 for (int mt = 0; mt < mx; ++mt) {
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 4
-                    for (int s = 0; s < ks_o; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w + ((size_t)(mh + mt) * ks_o + s) * kFragBytes),
-                                                                      *reinterpret_cast<const bf16x8*>(zsrc + s * 32), acc, 0, 0, 0);
-                    if (live) {
+                    acc = tile_mma(acc, w, kg_o, 0, zsrc, zsrc);
+                    if (live && ba.dx) {
                         float* dst = ba.dx + (row0 + p) * ba.ld_dx;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
@@ -278,9 +367,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void mlp_generic_bwd_kernel(Bw
             cur ^= 1;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// one wave per (32 x 32 tile of one layer's dW, row split): dW[i, o] = sum over rows of IN[row, i] dZ[row, o]
+// one wave per (64 x 64 block of one layer's dW = 2 x 2 MFMA tiles, row split): dW[i, o] = sum over rows of IN[row, i] dZ[row, o].
+// Four 16-byte loads feed four MFMAs (1 KiB of operands per MFMA and wave instead of 2); a block's second input / output
+// tile may not exist (odd tile counts) — it then aliases the first and is not stored.
+struct InTile { int frow, n_valid, i_base; };
+__device__ __forceinline__ InTile in_tile(const WgradArgs& a, int l, int it) {
+    const int mh = l > 0 ? a.layer[l - 1].n_tiles : 0, prev = l > 0 ? a.layer[l - 1].n_out : 0;
+    if (it < mh) return {a.b[l - (l > 0)].h_row + 32 * it, prev - 32 * it, 32 * it};
+    return {32 * (it - mh), a.d_in - 32 * (it - mh), prev + 32 * (it - mh)};
+}
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, g = lane >> 5;
     const long long wid = (long long)blockIdx.x * 4 + wave;
@@ -289,34 +387,45 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     int l = 0;
     while (l + 1 < a.n_layers && a.b[l + 1].job0 <= job) ++l;
     const Layer L = a.layer[l];
-    const int mh = l > 0 ? a.layer[l - 1].n_tiles : 0, prev = l > 0 ? a.layer[l - 1].n_out : 0;
-    const int local = job - a.b[l].job0, it = local / L.n_tiles, ot = local - it * L.n_tiles;
-    const bool from_x = it >= mh;
-    const int fa = from_x ? 32 * (it - mh) : a.b[l - (l > 0)].h_row + 32 * it;
-    const int fb = a.b[l].dz_row + 32 * ot;
+    const int m_in = (l > 0 ? a.layer[l - 1].n_tiles : 0) + (L.ks_x ? (a.d_in + 31) / 32 : 0);
+    const int o_pairs = (L.n_tiles + 1) / 2, local = job - a.b[l].job0, ip = local / o_pairs, op = local - ip * o_pairs;
+    const bool two_i = 2 * ip + 1 < m_in, two_o = 2 * op + 1 < L.n_tiles;
+    const InTile ti[2] = {in_tile(a, l, 2 * ip), in_tile(a, l, two_i ? 2 * ip + 1 : 2 * ip)};
+    const int fb[2] = {a.b[l].dz_row + 64 * op, a.b[l].dz_row + 64 * op + (two_o ? 32 : 0)};
     const long long t0 = a.tiles * sp / a.splits, t1 = a.tiles * (sp + 1) / a.splits;
-    const char* pa = a.ws + ((size_t)(fa + m) * 32 + 8 * g) * 2;
-    const char* pb = a.ws + ((size_t)(fb + m) * 32 + 8 * g) * 2;
+    const char* pa[2] = {a.ws + ((size_t)(ti[0].frow + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(ti[1].frow + m) * 32 + 8 * g) * 2};
+    const char* pb[2] = {a.ws + ((size_t)(fb[0] + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(fb[1] + m) * 32 + 8 * g) * 2};
     const size_t tile_bytes = (size_t)a.feat_rows * 64;
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 2
+    for (int q = 0; q < 16; ++q) acc[0][0][q] = acc[0][1][q] = acc[1][0][q] = acc[1][1][q] = 0.f;
     for (long long t = t0; t < t1; ++t) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + t * tile_bytes), a1 = *reinterpret_cast<const bf16x8*>(pa + t * tile_bytes + 32);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + t * tile_bytes), b1 = *reinterpret_cast<const bf16x8*>(pb + t * tile_bytes + 32);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const size_t off = t * tile_bytes + 32 * kk;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa[0] + off), a1 = *reinterpret_cast<const bf16x8*>(pa[1] + off);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb[0] + off), b1 = *reinterpret_cast<const bf16x8*>(pb[1] + off);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
     // D: column (lane & 31) = o, row (q&3) + 8 (q>>2) + 4 g = i
-    const int n_i = from_x ? a.d_in - 32 * (it - mh) : prev - 32 * it, i_base = from_x ? prev + 32 * (it - mh) : 32 * it;
-    const int o = 32 * ot + m;
     float* dst = a.partial + (size_t)sp * a.slice + a.b[l].dw_off;
-    if (o < L.n_out) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i = (q & 3) + 8 * (q >> 2) + 4 * g;
-            if (i < n_i) dst[(size_t)(i_base + i) * L.n_out + o] = acc[q];
+    for (int x = 0; x < 2; ++x) {
+        if (x && !two_i) break;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            if (y && !two_o) break;
+            const int o = 64 * op + 32 * y + m;
+            if (o >= L.n_out) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * g;
+                if (i < ti[x].n_valid) dst[(size_t)(ti[x].i_base + i) * L.n_out + o] = acc[x][y][q];
+            }
         }
     }
 }
@@ -399,23 +508,24 @@ extern "C" {
 int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (args->n <= 0) return 0;
-    const long long tiles = (args->n + 31) / 32, want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)(want < max_blocks ? want : max_blocks);
+    const long long tiles = (args->n + 31) / 32;
+    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
+    const int lds = kRingBytes + 32 * (args->x_pitch + 2 * args->h_pitch);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mlp_generic_kernel, dim3(grid), dim3(kWavesPerBlock * 64), kLds, st, *args);
+    hipLaunchKernelGGL(mlp_generic_kernel, dim3(grid), dim3(64), lds, st, *args);
     return (int)hipGetLastError();
 }
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (ba->f.n <= 0) return 0;
-    const long long want = (ba->tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int grid = (int)(want < max_blocks ? want : max_blocks);
+    const int grid = (int)(ba->tiles < max_blocks ? ba->tiles : max_blocks);
+    const int lds = kRingBytes + 32 * (ba->f.x_pitch + 2 * ba->f.h_pitch);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(kWavesPerBlock * 64), kLds, st, *ba);
+    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(64), lds, st, *ba);
     const long long waves = (long long)wa->n_jobs * wa->splits;
     hipLaunchKernelGGL(mlp_generic_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
     hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);

@@ -5,10 +5,16 @@ namespace nfx {
 namespace generic {
 
 constexpr int kMaxLayers = 16, kMaxIn = 320, kMaxHidden = 256;   // kMaxIn: concat(256 features, embedded view) = 283
+// Fragments are fetched kGroup at a time, two groups ahead, as ONE stream through the whole network: every tile's
+// k-steps are padded to a multiple of kGroup with zero fragments, tiles and layers follow each other without gaps.
+constexpr int kGroup = 4;
+constexpr int pad_group(int ks) { return (ks + kGroup - 1) / kGroup * kGroup; }
 
 struct Layer {
-    int ks_h;      // k-steps (16 features) taken from the previous layer's output (0 for the first layer)
-    int ks_x;      // k-steps taken from the network input (first layer, and layers behind a skip concatenation)
+    int ks_h;      // k-steps (16 features) taken from the previous layer's output (0 for the first layer) ...
+    int ks_x;      // ... and from the network input (first layer, and layers behind a skip concatenation): each padded
+                   // to whole groups (zero fragments), so that a group reads ONE source
+    int ks_pad;    // fragments per output tile in the blob: ks_h + ks_x
     int n_tiles;   // 32-wide output tiles
     int n_out;     // true output width
     int act;       // NFX_ACT_*
@@ -20,10 +26,12 @@ struct Args {
     long long n;
     int ld_x, d_in;
     const char* weights;   // fragments
+    int n_frags;           // in the forward stream (the prefetch never reads past it)
     const float* biases;
     float* y;         // [n, ld_y] output, columns [col0, col0 + n_out of the last layer)
     int ld_y, col0;
     int n_layers;
+    int x_pitch, h_pitch;   // LDS row pitches in bytes: (features padded to 64) x 2 + 16 of the input / the widest layer
     Layer layer[kMaxLayers];
 };
 // Embedder (embedder.py:23-47): out[:, col0 ...] = [x, sin(f_0 x), cos(f_0 x), sin(f_1 x), cos(f_1 x), ...], f_k = 2^k,
@@ -48,16 +56,17 @@ struct EmbedArgs {
 // everything a wave writes and reads back lies in cache lines no other wave touches.  A second kernel contracts the
 // pairs over the rows, a third and fourth reduce its row splits and the bias gradients in a fixed order.
 struct BwdLayer {
-    int wt_off;    // first TRANSPOSED fragment of this layer (1 KiB units, relative to Args::weights): M tiles over the
-                   // previous layer's outputs, then over the network input, each x 2 n_tiles k-steps over this layer's outputs
+    int wt_off;    // first TRANSPOSED fragment of this layer (1 KiB units): M tiles over the previous layer's outputs, then
+                   // over the network input, each pad_group(2 n_tiles) k-steps over this layer's outputs
     int h_row;     // feature row (F units) of this layer's OUTPUT activations in the workspace (hidden layers only)
     int dz_row;    // feature row of this layer's output gradient
     int dw_off;    // float offset of this layer's kernel gradient in a partial slice
-    int job0;      // first weight-gradient job (32 x 32 tile of dW) of this layer
+    int job0;      // first weight-gradient job (64 x 64 block of dW) of this layer
 };
 struct BwdArgs {
     Args f;                  // the forward's arguments; f.y unused
-    const char* wt;          // transposed fragments (dgrad)
+    int stream_frags;        // forward + transposed fragments the kernel walks per row tile (without layer 0's
+                             // input-gradient tiles, the stream's tail, when dx is null)
     const float* dy;         // [n, ld_dy] gradient w.r.t. the activated outputs, columns [col0_dy, ...)
     int ld_dy, col0_dy;
     float* dx;               // [n, ld_dx] gradient w.r.t. the network input, or null

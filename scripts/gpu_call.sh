@@ -47,6 +47,18 @@ PYEOF
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
     soak-xp)  NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_build.log 2>&1; tail -16 $OUT/soak_experiment_build.log ;;
     generic)  timeout 600 python scripts/generic_rates.py > $OUT/generic_rates.json 2> $OUT/generic_rates.err; cat $OUT/generic_rates.json; tail -3 $OUT/generic_rates.err ;;
+    generic-prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_generic -o g -- python $ROOT/scripts/generic_rates.py > $ROOT/$OUT/prof_generic_run.log 2>&1); find $OUT/prof_generic -name "*kernel_stats*" | head -1 | xargs -r head -12 ;;
+    generic-pmc) for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS" "sq2 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_MFMA"; do
+                 set -- $pass; name=$1; shift
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_generic/$name -o p -- python $ROOT/scripts/generic_rates.py > $ROOT/$OUT/pmc_generic_$name.log 2>&1); echo "pmc pass $name rc=$?"
+               done
+               python scripts/pmc_digest.py $OUT/pmc_generic > $OUT/pmc_generic_digest.json; python - <<PYEOF
+import json
+d=json.load(open("$OUT/pmc_generic_digest.json"))
+for k,v in d.items():
+    if 'generic' in k: print(k[:60], {a: (round(b,4) if isinstance(b,float) and b<10 else int(b)) for a,b in v.items()})
+PYEOF
+               ;;
     sigma)    timeout 600 python scripts/sigma_last_error.py > $OUT/sigma_last_error.json 2>&1; cat $OUT/sigma_last_error.json ;;
     prof)     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs ${PROF_LEGS:-nerf,nerfactor_microfacet,nerfactor,olat} > $ROOT/$OUT/prof_run.log 2>&1); find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -25 ;;
     train-prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_train -o train -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs train > $ROOT/$OUT/prof_train_run.log 2>&1); find $OUT/prof_train -name "*kernel_stats*" | head -1 | xargs -r head -30 ;;

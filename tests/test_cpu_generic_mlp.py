@@ -12,17 +12,21 @@ def bf(a):
     return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
 
 
+def pad4(ks):
+    return (ks + 3) // 4 * 4    # mlp_generic.hpp: kGroup — every tile's fragments are padded to whole prefetch groups
+
+
 def emulate(net, x, widths, d_in):
     blob = net.blob.numpy()
     n_bias = sum(((w + 31) // 32) * 32 for w in widths)
     n_frag = (len(blob) - 4 * n_bias) // 1024
-    frags = (blob[:n_frag * 1024].view(np.uint16).reshape(n_frag, 64, 8).astype(np.uint32) << 16).view(np.float32)
-    bias = blob[n_frag * 1024:].view(np.float32)
-    ks_in = (d_in + 15) // 16
+    bias = blob[:4 * n_bias].view(np.float32)                 # [biases | fragments]
+    frags = (blob[4 * n_bias:].view(np.uint16).reshape(n_frag, 64, 8).astype(np.uint32) << 16).view(np.float32)
+    ks_in = pad4((d_in + 15) // 16)                           # both operand sources are padded to whole groups
     xp = np.pad(bf(x), ((0, 0), (0, ks_in * 16 - d_in)))
     h, w_off, b_off = None, 0, 0
     for i, w in enumerate(widths):
-        ks_h = 0 if i == 0 else (widths[i - 1] + 15) // 16
+        ks_h = 0 if i == 0 else pad4((widths[i - 1] + 15) // 16)
         ks_x = ks_in if (i == 0 or net.skip_input[i]) else 0
         nt = (w + 31) // 32
         hp = None if h is None else np.pad(h, ((0, 0), (0, ks_h * 16 - h.shape[1])))
@@ -79,9 +83,10 @@ def test_generic_limits_are_reported(nfx_lib):
 
 @pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 5], [0]), (27, [40, 200, 33], [0, 1]), (130, [256], None)])
 def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in, widths, skip_at):
-    """nfx_mlp_generic_pack_train: [forward fragments | biases | transposed fragments].  A transposed fragment of layer i
+    """nfx_mlp_generic_pack_train: [biases | forward fragments | transposed fragments].  A transposed fragment of layer i
     (M tile over the layer's inputs — previous outputs first, then the network input —, k-step s over its outputs) holds
-    bf16(W_i[input 32 mt + (lane & 31)][output 16 s + 8 (lane >> 5) + j]); the dgrad product over them is dZ W^T."""
+    bf16(W_i[input 32 mt + (lane & 31)][output 16 s + 8 (lane >> 5) + j]); the dgrad product over them is dZ W^T.  The
+    layers follow each other LAST FIRST (the order the backward consumes them), every tile padded to whole groups."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(d_in)
     ks, bs, prev = [], [], d_in
@@ -96,7 +101,7 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
     assert net.train and np.array_equal(blob[:len(fwd)], fwd) and (len(blob) - len(fwd)) % 1024 == 0
     frags = (blob[len(fwd):].view(np.uint16).reshape(-1, 64, 8).astype(np.uint32) << 16).view(np.float32)
     mx, off = (d_in + 31) // 32, 0
-    for i, w in enumerate(widths):
+    for i, w in reversed(list(enumerate(widths))):
         nt = (w + 31) // 32
         prev_w = widths[i - 1] if i else 0
         mh = (prev_w + 31) // 32 if i else 0
@@ -106,7 +111,7 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
         got = np.zeros((5, m_in * 32), np.float32)
         for mt in range(m_in):
             for s in range(2 * nt):
-                fr = frags[off + mt * 2 * nt + s]
+                fr = frags[off + mt * pad4(2 * nt) + s]
                 for g in range(2):
                     got[:, 32 * mt:32 * mt + 32] += dzp[:, 16 * s + 8 * g:16 * s + 8 * g + 8] @ fr[32 * g:32 * g + 32].T
         want = dz @ bf(ks[i]).T                                   # [5, n_in]: previous outputs, then the network input
@@ -115,6 +120,6 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
         if m_in > mh:
             np.testing.assert_allclose(got[:, 32 * mh:32 * mh + d_in], want[:, prev_w:], rtol=2e-5, atol=2e-5)
             assert np.all(got[:, 32 * mh + d_in:] == 0)
-        off += m_in * 2 * nt
+        off += m_in * pad4(2 * nt)
     assert off == len(frags)
     assert nfx_lib.lib.nfx_mlp_generic_bwd_workspace_bytes(1000, d_in, len(widths), net._w, net._s) > 0
