@@ -410,7 +410,7 @@ NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_i
  * accepts it too.  Given dy = dLoss / d(activated output) [n, ld_dy] (columns col0_dy ...), ADDS dLoss/dW into
  * dkernels[i] ([in_i, widths[i]], Keras layout) and dLoss/db into dbiases[i], and — dx != NULL — writes
  * dLoss / d(network input) to dx[n, ld_dx] (first d_in columns), for chaining networks (bottleneck -> rgb_out,
- * nerfactor/models/nerf.py:277-287).  The kernels re-compute the forward in bf16 from x; activation derivatives of
+ * nerfactor/models/nerf.py:277-287).  dkernels = dbiases = NULL: only dx is computed (input gradients of a frozen network).  The kernels re-compute the forward in bf16 from x; activation derivatives of
  * hidden layers are taken from their bf16 outputs.  Deterministic (no atomics; the row split of the weight-gradient
  * contraction depends on the problem shape only).  Workspace: nfx_mlp_generic_bwd_workspace_bytes (about
  * 2 bytes x n x (d_in + 2 x sum of widths)), 16-byte aligned device memory. */
@@ -429,6 +429,11 @@ NFX_API int nfx_mlp_generic_bwd(const float *dev_x, int64_t n, int ld_x, int d_i
  *   nerfactor/models/nerf.py:162-164)    mode 2: v = dir[row / per_ray]
  *   mode 3: v = safe_l2_normalize(dir[row % per_ray] - x[row / per_ray]): the unit direction from surface point
  *   row / per_ray to light row % per_ray (nerfactor/models/shape.py:128-131; per_ray = number of lights). */
+/* The embedding's pull-back for explicit vectors (mode 0): dv[n, 3] = (d embedding / d v)^T d_out[row, col0 ...] — with
+ * nfx_mlp_generic_bwd's dx it gives d(network output)/d(point), the density gradient geometry_from_nerf.py:288-297 takes
+ * by tf.GradientTape, for a NeRF of any shape. */
+NFX_API int nfx_embed_bwd(const float *dev_v, int64_t n, int n_freqs, int incl_input, const float *dev_d_out, int ld_out,
+                          int col0, float *dev_dv, void *stream);
 NFX_API int nfx_embed(const float *dev_x, const float *dev_dir, const float *dev_z, int64_t n, int per_ray, int mode,
                       int n_freqs, int incl_input, float *dev_out, int ld_out, int col0, void *stream);
 

@@ -17,6 +17,7 @@ extern "C" int nfx_option_int(const char* key, int dflt);        // capi.cpp
 extern "C" {
 int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipStream_t st);
 int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st);
+int nfx_launch_embed_bwd(const nfx::generic::EmbedArgs* a, const float* d_out, float* dv, hipStream_t st);
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st);
 }
 
@@ -135,7 +136,7 @@ struct BwdPlan {
     nfx::generic::Layer layer[nfx::generic::kMaxLayers];
     nfx::generic::BwdLayer b[nfx::generic::kMaxLayers];
     int n_frags, n_bias, n_tfrags, feat_rows, n_jobs;
-    long long slice;
+    long long slice, dw_total;
 };
 int bwd_plan(int d_in, int n_layers, const int* widths, const int* skip_input, const int* acts, BwdPlan* p) {
     int rc = layer_table(d_in, n_layers, widths, skip_input, acts, p->layer, &p->n_frags, &p->n_bias);
@@ -167,12 +168,17 @@ int bwd_plan(int d_in, int n_layers, const int* widths, const int* skip_input, c
     p->n_tfrags = wt;
     p->feat_rows = rows;
     p->n_jobs = jobs;
+    p->dw_total = dw;
+    for (int i = 0; i < n_layers; ++i) {
+        p->b[i].db_off = (int)dw;
+        dw += p->layer[i].n_out;
+    }
     p->slice = dw;
     return NFX_OK;
 }
 // row splits of the weight-gradient contraction: enough waves to fill the chip, a function of the problem shape only
 int wgrad_splits(long long tiles, int n_jobs) {
-    long long s = (4096 + n_jobs - 1) / n_jobs;
+    long long s = (8192 + n_jobs - 1) / n_jobs;
     if (s > tiles / 4) s = tiles / 4;
     if (s > 64) s = 64;
     return s < 1 ? 1 : (int)s;
@@ -233,13 +239,15 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
                         int ld_dx, float* const* dkernels, float* const* dbiases, void* workspace, size_t workspace_bytes,
                         void* stream) {
     REQUIRE(n >= 0, "nfx_mlp_generic_bwd: n < 0");
-    REQUIRE(widths && acts && dkernels && dbiases, "nfx_mlp_generic_bwd: null layer description");
+    REQUIRE(widths && acts, "nfx_mlp_generic_bwd: null layer description");
+    REQUIRE((dkernels && dbiases) || (!dkernels && !dbiases && dx), "nfx_mlp_generic_bwd: gradient buffers for both kernels and "
+            "biases, or neither (then dx is the only result and must not be null)");
     BwdPlan p;
     int rc = bwd_plan(d_in, n_layers, widths, skip_input, acts, &p);
     if (rc) return rc;
     for (int i = 0; i < n_layers; ++i) {
         REQUIRE(acts[i] >= 0 && acts[i] <= 3, "nfx_mlp_generic_bwd: activation %d of layer %d", acts[i], i);
-        REQUIRE(dkernels[i] && dbiases[i], "nfx_mlp_generic_bwd: gradient buffer of layer %d is null", i);
+        REQUIRE(!dkernels || (dkernels[i] && dbiases[i]), "nfx_mlp_generic_bwd: gradient buffer of layer %d is null", i);
     }
     if (n == 0) return NFX_OK;
     REQUIRE(x && train_blob && dy && workspace, "nfx_mlp_generic_bwd: null pointer");
@@ -279,12 +287,13 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     wa.splits = wgrad_splits(tiles, p.n_jobs);
     wa.n_jobs = p.n_jobs;
     wa.slice = p.slice;
+    wa.dw_total = p.dw_total;
     wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * 64));
     for (int i = 0; i < n_layers; ++i) {
         ba.f.layer[i] = wa.layer[i] = p.layer[i];
         ba.b[i] = wa.b[i] = p.b[i];
-        wa.dw[i] = dkernels[i];
-        wa.db[i] = dbiases[i];
+        wa.dw[i] = dkernels ? dkernels[i] : nullptr;
+        wa.db[i] = dkernels ? dbiases[i] : nullptr;
     }
     set_pitches(&ba.f);
     return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
@@ -300,4 +309,14 @@ int nfx_embed(const float* x, const float* dir, const float* z, int64_t n, int p
     REQUIRE(ld_out >= col0 + (incl_input ? 3 : 0) + 6 * n_freqs && col0 >= 0, "nfx_embed: output row too short");
     nfx::generic::EmbedArgs a{x, dir, z, n, per_ray, mode, n_freqs, incl_input, out, ld_out, col0};
     return nfx_hip_result(nfx_launch_embed(&a, (hipStream_t)stream), "embed");
+}
+
+int nfx_embed_bwd(const float* v, int64_t n, int n_freqs, int incl_input, const float* d_out, int ld_out, int col0, float* dv,
+                  void* stream) {
+    REQUIRE(n >= 0 && n_freqs >= 0 && n_freqs <= 16 && (incl_input || n_freqs > 0), "nfx_embed_bwd: bad arguments");
+    if (n == 0) return NFX_OK;
+    REQUIRE(v && d_out && dv, "nfx_embed_bwd: null pointer");
+    REQUIRE(ld_out >= col0 + (incl_input ? 3 : 0) + 6 * n_freqs && col0 >= 0, "nfx_embed_bwd: gradient row too short");
+    nfx::generic::EmbedArgs a{v, nullptr, nullptr, n, 1, 0, n_freqs, incl_input, nullptr, ld_out, col0};
+    return nfx_hip_result(nfx_launch_embed_bwd(&a, d_out, dv, (hipStream_t)stream), "embed_bwd");
 }

@@ -17,7 +17,7 @@
 // Limits: network input <= 320 features, hidden widths <= 256, <= 16 layers, output <= 256.
 // nfx_embed is the Embedder (embedder.py:23-47) as its own kernel, with the point generation o + d z folded in.
 //
-// Backward (mlp_generic_bwd_kernel + mlp_generic_wgrad_kernel + two ordered reductions; mlp_generic.hpp has the
+// Backward (mlp_generic_bwd_kernel + mlp_generic_wgrad_kernel + one ordered reduction; mlp_generic.hpp has the
 // workspace layout): the same wave re-computes its 32 rows' forward, turns dLoss/dy into the output-layer gradient and
 // walks the layers back with the TRANSPOSED weight fragments — dH^T = W dZ^T is the forward's loop with another weight
 // stream — multiplying by the activation's derivative taken from the stored bf16 outputs.  Every layer's input and
@@ -396,9 +396,15 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     const char* pa[2] = {a.ws + ((size_t)(ti[0].frow + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(ti[1].frow + m) * 32 + 8 * g) * 2};
     const char* pb[2] = {a.ws + ((size_t)(fb[0] + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(fb[1] + m) * 32 + 8 * g) * 2};
     const size_t tile_bytes = (size_t)a.feat_rows * 64;
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], accb[2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[0][0][q] = acc[0][1][q] = acc[1][0][q] = acc[1][1][q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[0][0][q] = acc[0][1][q] = acc[1][0][q] = acc[1][1][q] = accb[0][q] = accb[1][q] = 0.f;
+    // the jobs of a layer's first input pair also sum their dZ columns: db[o] = sum over rows of 1 x dZ[row, o]
+    const bool with_bias = ip == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+#pragma unroll 2
     for (long long t = t0; t < t1; ++t) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -409,9 +415,18 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (with_bias) {
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b0, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b1, accb[1], 0, 0, 0);
+            }
         }
     }
     // D: column (lane & 31) = o, row (q&3) + 8 (q>>2) + 4 g = i
+    if (with_bias && g == 0) {      // every row of accb holds the column sums: row 0 = register 0 of lanes 0..31
+        float* db = a.partial + (size_t)sp * a.slice + a.b[l].db_off;
+        if (64 * op + m < L.n_out) db[64 * op + m] = accb[0][0];
+        if (two_o && 64 * op + 32 + m < L.n_out) db[64 * op + 32 + m] = accb[1][0];
+    }
     float* dst = a.partial + (size_t)sp * a.slice + a.b[l].dw_off;
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
@@ -433,36 +448,16 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_reduce_kernel(WgradArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.slice) return;
+    float s = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) s += a.partial[(size_t)sp * a.slice + idx];     // fixed order
     int l = 0;
-    while (l + 1 < a.n_layers && a.b[l + 1].dw_off <= idx) ++l;
-    float s = 0.f;
-    for (int sp = 0; sp < a.splits; ++sp) s += a.partial[(size_t)sp * a.slice + idx];
-    a.dw[l][idx - a.b[l].dw_off] += s;
-}
-
-// one block per (layer, output): db[o] += sum over rows of dZ[row, o], a fixed-shape tree
-__global__ __launch_bounds__(256) void mlp_generic_bias_kernel(WgradArgs a) {
-    __shared__ float red[256];
-    int l = 0, o = blockIdx.x;
-    while (o >= a.layer[l].n_out) o -= a.layer[l++].n_out;
-    const char* src = a.ws + (size_t)(a.b[l].dz_row + o) * 64;
-    const size_t tile_bytes = (size_t)a.feat_rows * 64;
-    float s = 0.f;
-    for (long long t = threadIdx.x; t < a.tiles; t += 256) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + t * tile_bytes + 16 * c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[j];
-        }
+    if (idx < a.dw_total) {
+        while (l + 1 < a.n_layers && a.b[l + 1].dw_off <= idx) ++l;
+        a.dw[l][idx - a.b[l].dw_off] += s;
+    } else {
+        while (l + 1 < a.n_layers && a.b[l + 1].db_off <= idx) ++l;
+        a.db[l][idx - a.b[l].db_off] += s;
     }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.db[l][o] += red[0];
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
@@ -501,6 +496,34 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     }
 }
 
+// d (embedding) / d v pulled back: dv = d[identity block] + sum over bands of 2^k (cos(2^k v) d[sin block] - sin(2^k v) d[cos block])
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float* d_out, float* dv) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.n) return;
+    const float* d = d_out + row * a.ld_out + a.col0;
+    float v[3], g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = a.x[row * 3 + k];
+    int c = 0;
+    if (a.incl_input) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = d[k];
+        c = 3;
+    }
+    for (int f = 0; f < a.n_freqs; ++f) {
+        const float s = (float)(1 << f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float sn, cs;
+            sincos_cw(v[k] * s, sn, cs);
+            g[k] += s * (cs * d[c + k] - sn * d[c + 3 + k]);
+        }
+        c += 6;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dv[row * 3 + k] = g[k];
+}
+
 }  // namespace generic
 }  // namespace nfx
 
@@ -526,12 +549,16 @@ int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::gener
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(64), lds, st, *ba);
-    const long long waves = (long long)wa->n_jobs * wa->splits;
-    hipLaunchKernelGGL(mlp_generic_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
-    hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
-    int n_bias = 0;
-    for (int l = 0; l < wa->n_layers; ++l) n_bias += wa->layer[l].n_out;
-    hipLaunchKernelGGL(mlp_generic_bias_kernel, dim3(n_bias), dim3(256), 0, st, *wa);
+    if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
+        const long long waves = (long long)wa->n_jobs * wa->splits;
+        hipLaunchKernelGGL(mlp_generic_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
+        hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
+    }
+    return (int)hipGetLastError();
+}
+int nfx_launch_embed_bwd(const nfx::generic::EmbedArgs* a, const float* d_out, float* dv, hipStream_t st) {
+    if (a->n <= 0) return 0;
+    hipLaunchKernelGGL(nfx::generic::embed_bwd_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, st, *a, d_out, dv);
     return (int)hipGetLastError();
 }
 int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st) {

@@ -5,8 +5,9 @@ namespace nfx {
 namespace generic {
 
 constexpr int kMaxLayers = 16, kMaxIn = 320, kMaxHidden = 256;   // kMaxIn: concat(256 features, embedded view) = 283
-// Fragments are fetched kGroup at a time, two groups ahead, as ONE stream through the whole network: every tile's
-// k-steps are padded to a multiple of kGroup with zero fragments, tiles and layers follow each other without gaps.
+// A wave pulls the network's fragments through its LDS ring kGroup at a time as ONE stream (mlp_generic.hip: Ring): both
+// operand sources of every tile are padded to whole groups with zero fragments, tiles and layers follow each other
+// without gaps, the transposed (backward) fragments follow the forward ones, last layer first.
 constexpr int kGroup = 4;
 constexpr int pad_group(int ks) { return (ks + kGroup - 1) / kGroup * kGroup; }
 
@@ -54,13 +55,15 @@ struct EmbedArgs {
 // every matrix (network input, hidden outputs, gradients) a range of feature rows padded to a multiple of 32 — the
 // layout in which a weight-gradient MFMA operand (one feature, 8 consecutive rows) is one 16-byte load, and in which
 // everything a wave writes and reads back lies in cache lines no other wave touches.  A second kernel contracts the
-// pairs over the rows, a third and fourth reduce its row splits and the bias gradients in a fixed order.
+// pairs over the rows (the bias gradients ride along as a product with a fragment of ones), a third reduces its row
+// splits in a fixed order.
 struct BwdLayer {
     int wt_off;    // first TRANSPOSED fragment of this layer (1 KiB units): M tiles over the previous layer's outputs, then
                    // over the network input, each pad_group(2 n_tiles) k-steps over this layer's outputs
     int h_row;     // feature row (F units) of this layer's OUTPUT activations in the workspace (hidden layers only)
     int dz_row;    // feature row of this layer's output gradient
-    int dw_off;    // float offset of this layer's kernel gradient in a partial slice
+    int dw_off;    // float offset of this layer's kernel gradient in a partial slice ...
+    int db_off;    // ... and of its bias gradient (behind all kernel gradients)
     int job0;      // first weight-gradient job (64 x 64 block of dW) of this layer
 };
 struct BwdArgs {
@@ -80,7 +83,8 @@ struct WgradArgs {
     const char* ws;
     long long tiles;
     int feat_rows, n_layers, d_in, splits, n_jobs;
-    long long slice;         // floats per partial slice
+    long long slice;         // floats per partial slice: all kernel gradients, then all bias gradients
+    long long dw_total;      // floats of kernel gradients in a slice
     float* partial;          // [splits][slice]
     Layer layer[kMaxLayers];
     BwdLayer b[kMaxLayers];

@@ -81,8 +81,9 @@ class Model(BaseModel):
         """self.tuned: the shipped architecture (config/nerf.ini: mlp_width = 256, enc_depth = 8, relu, use_views,
         n_freqs_xyz = 10, n_freqs_view = 4) runs on the tuned kernels, forward and backward.  Every other shape the
         reference can build (nerf.py:53-90: other widths and depths, use_views = False, pos_enc = False, other band
-        counts) renders AND trains through the runtime-shaped kernels (csrc/mlp_generic.hip: nfx_embed,
-        nfx_mlp_generic_fwd / _bwd, bf16 operands like the tuned path), one autograd node per network."""
+        counts) renders, trains and yields its geometry (eval_sigma / eval_sigma_normal) through the runtime-shaped
+        kernels (csrc/mlp_generic.hip: nfx_embed, nfx_mlp_generic_fwd / _bwd, bf16 operands like the tuned path), one
+        autograd node per network."""
         cfg = self.config
         width, depth = cfg.getint('DEFAULT', 'mlp_width'), cfg.getint('DEFAULT', 'enc_depth')
         act = cfg.get('DEFAULT', 'act', fallback='relu')
@@ -277,10 +278,35 @@ class Model(BaseModel):
         return ops.nerf_mlp_fwd(o, d, z, self._nerf_blob(pref), self.precision).reshape(n, s, 4)
 
     # ------------------------------------------------------------------ geometry extraction (geometry_from_nerf.py)
+    def _sigma_generic(self, rayo, rayd, z, pref, want_normal=False):
+        """(sigma_raw[N,S], normal[N,S,3] | None) of a non-shipped shape on the runtime-shaped kernels, `mlp_chunk` points at
+        a time: the density through enc -> sigma_out (or column 3 of rgbs_out); the normal -l2_normalize(d relu(sigma)/dx)
+        (geometry_from_nerf.py:288-297) by the input-gradient mode of nfx_mlp_generic_bwd through both networks and
+        nfx_embed_bwd through the positional encoding — bf16 operands (the fp32-class density-gradient kernel exists
+        for the shipped shape only)."""
+        n, s = z.shape
+        lx = self.embedder['xyz'].n_freqs
+        pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3).contiguous()
+        head = pref + ('sigma_out' if self.use_views else 'rgbs_out')
+        enc, out = self._generic_net(pref + 'enc', train=want_normal), self._generic_net(head, train=want_normal)
+        chunk = self.config.getint('DEFAULT', 'mlp_chunk')
+        sigma = torch.empty(n * s, dtype=torch.float32, device=z.device)
+        normal = torch.empty((n * s, 3), dtype=torch.float32, device=z.device) if want_normal else None
+        for i in range(0, n * s, chunk):
+            p = pts[i:i + chunk]
+            emb = ops.embed(lx, x=p)
+            feat = ops.mlp_generic_fwd(emb, enc)
+            raw = ops.mlp_generic_fwd(feat, out)               # [m, 1] or [m, 4] (use_views = False: rgb + sigma)
+            sigma[i:i + chunk] = raw[:, -1]
+            if want_normal:
+                dy = torch.zeros_like(raw)
+                dy[:, -1] = (raw[:, -1] > 0).float()           # d relu(sigma) / d sigma
+                d_feat = ops.mlp_generic_bwd(feat, out, dy, None, None, want_dx=True)
+                d_emb = ops.mlp_generic_bwd(emb, enc, d_feat, None, None, want_dx=True)
+                normal[i:i + chunk] = -ops.l2_normalize3(ops.embed_bwd(lx, p, d_emb), 1e-12)
+        return sigma.view(n, s), (normal.view(n, s, 3) if want_normal else None)
+
     def _nerf_geom_blob(self, pref, precision=None):
-        if not self.tuned:
-            raise NotImplementedError("geometry extraction (density / density-gradient kernels) exists for the shipped NeRF "
-                                      "architecture only")
         precision = precision or self.precision
         ks, bs = self._nerf_params(pref)
         return self._packed(pref + 'geom' + precision, ks + bs,
@@ -297,7 +323,10 @@ class Model(BaseModel):
         """relu(sigma)[N,S] at rayo + rayd z (eval_sigma_mlp, geometry_from_nerf.py:322-350); outside the optional
         bounding box (x_min, x_max, y_min, y_max, z_min, z_max) the density is 0."""
         pref = 'fine_' if use_fine else 'coarse_'
-        sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_geom_blob(pref), self.precision))
+        if not self.tuned:
+            sigma = torch.relu(self._sigma_generic(rayo, rayd, z, pref)[0])
+        else:
+            sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_geom_blob(pref), self.precision))
         if bbox is not None:
             sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)
         return sigma
@@ -305,7 +334,10 @@ class Model(BaseModel):
     def eval_sigma_normal(self, rayo, rayd, z, bbox=None):
         """(relu(sigma)[N,S], normal[N,S,3]) of the FINE network, normal = -l2_normalize(d sigma / dx)
         (geometry_from_nerf.py:280-306: the bounding box zeroes sigma, not the normal)."""
-        normal, sigma = ops.nerf_sigma_grad(rayo, rayd, z, self._nerf_geom_blob('fine_'), self.precision)
+        if not self.tuned:
+            sigma, normal = self._sigma_generic(rayo, rayd, z, 'fine_', want_normal=True)
+        else:
+            normal, sigma = ops.nerf_sigma_grad(rayo, rayd, z, self._nerf_geom_blob('fine_'), self.precision)
         sigma = torch.relu(sigma)
         if bbox is not None:
             sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)

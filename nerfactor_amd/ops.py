@@ -327,20 +327,36 @@ def mlp_generic_bwd(x, net, dy, dkernels, dbiases, want_dx=False):
         raise _capi.NfxError("mlp_generic_bwd: x must be a CUDA fp32 matrix with unit column stride")
     n = x.shape[0]
     dy = _dev(dy, 'dy', (n, net.d_out))
-    if len(dkernels) != net.n_layers or len(dbiases) != net.n_layers:
+    if dkernels is None and dbiases is None:          # input gradient of a frozen network
+        if not want_dx:
+            raise _capi.NfxError("mlp_generic_bwd: nothing to compute (no gradient buffers, want_dx = False)")
+        dkernels = dbiases = ()
+    elif len(dkernels) != net.n_layers or len(dbiases) != net.n_layers:
         raise _capi.NfxError("mlp_generic_bwd: need %d kernel and bias gradient buffers" % net.n_layers)
-    for i in range(net.n_layers):
+    for i in range(len(dkernels)):
         for t, name, shape in ((dkernels[i], 'dkernels', (net.in_dims[i], net.widths[i])), (dbiases[i], 'dbiases', (net.widths[i],))):
             if _dev(t, '%s[%d]' % (name, i), shape) is not t:
                 raise _capi.NfxError("mlp_generic_bwd: %s[%d] must be contiguous (it is accumulated into)" % (name, i))
     dx = torch.empty((n, net.d_in), dtype=torch.float32, device=x.device) if want_dx else None
     nbytes = lib.nfx_mlp_generic_bwd_workspace_bytes(n, net.d_in, net.n_layers, net._w, net._s)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-    karr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dkernels])
-    barr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dbiases])
+    karr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dkernels]) if dkernels else None
+    barr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dbiases]) if dbiases else None
     check(lib.nfx_mlp_generic_bwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
                                   net._s, _ptr(net.blob), _ptr(dy), net.d_out, 0, _ptr(dx), net.d_in, karr, barr,
                                   _ptr(ws), ws.numel(), _stream()), 'nfx_mlp_generic_bwd')
+    return dx
+
+
+def embed_bwd(n_freqs, x, d_out, incl_input=True, col0=0):
+    """dx[n, 3] = (d embed(x) / d x)^T d_out[:, col0 : col0 + 3 incl_input + 6 n_freqs] for explicit vectors x[n, 3]."""
+    x = _dev(x, 'x', (None, 3))
+    if not isinstance(d_out, torch.Tensor) or not d_out.is_cuda or d_out.dtype != torch.float32 or d_out.dim() != 2 \
+            or d_out.stride(1) != 1 or d_out.shape[0] != x.shape[0]:
+        raise _capi.NfxError("embed_bwd: d_out must be a CUDA fp32 matrix with one row per vector")
+    dx = torch.empty_like(x)
+    check(lib.nfx_embed_bwd(_ptr(x), x.shape[0], n_freqs, int(incl_input), _ptr(d_out), d_out.stride(0) if x.shape[0] else 0,
+                            col0, _ptr(dx), _stream()), 'nfx_embed_bwd')
     return dx
 
 

@@ -427,3 +427,91 @@ def test_brdf_plugin_non_shipped_shapes(nfx_lib, cuda, overrides, width, depth, 
         l.backward()
         losses.append(float(opt.step(loss=l.detach())))
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize("overrides,kw", [
+    (dict(mlp_width='128', enc_depth='4', n_freqs_xyz='6'), dict(width=128, depth=4, n_freqs_xyz=6)),
+    (dict(use_views='False', mlp_width='64'), dict(width=64, use_views=False, n_freqs_view=0))])
+def test_nerf_geometry_of_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
+    """Model.eval_sigma / eval_sigma_normal (what geometry_from_nerf.py:280-350 evaluates) for NeRFs outside the shipped
+    architecture: density against the oracle's network, normals -l2_normalize(d relu(sigma)/dx) against torch.autograd
+    in float64 with the kernels' bf16 operand rounding (straight-through) — the bounds of the tuned bf16 kernel's test
+    (median cosine > 0.999, 10 % quantile > 0.98) — and loosely against plain float64."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from oracle import torch_train_ref as T
+    cfg = make_config('nerf', **overrides)
+    model = get_model_class('nerf')(cfg).to(cuda)
+    assert not model.tuned
+    rng = np.random.default_rng(21)
+    lx, depth = kw.get('n_freqs_xyz', 10), kw.get('depth', 8)
+    for pref in ('coarse_', 'fine_'):
+        net = nerf_ref.init_nerf_net(rng, n_freqs_xyz=lx, n_freqs_view=kw.get('n_freqs_view', 4), width=kw.get('width', 256),
+                                     depth=depth, sigma_bias=0.5, sigma_gain=8., use_views=kw.get('use_views', True))
+        nerf_ref.randomize_biases(net, rng)
+        for part, pairs in net.items():
+            for layer, (k, b) in zip(model.net[pref + part].layers, pairs):
+                with torch.no_grad():
+                    layer.kernel.copy_(torch.from_numpy(k))
+                    layer.bias.copy_(torch.from_numpy(b))
+    n, s = 60, 11
+    rayo = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    rayd = nerf_ref.l2_normalize(rng.normal(size=(n, 3)).astype(np.float32), 1, 1e-12)
+    z = np.sort(rng.uniform(0.5, 3., size=(n, s)).astype(np.float32), 1)
+    sig, normal = model.eval_sigma_normal(dev(rayo, cuda), dev(rayd, cuda), dev(z, cuda))
+    sig_c = model.eval_sigma(dev(rayo, cuda), dev(rayd, cuda), dev(z, cuda), use_fine=True)
+    assert torch.equal(sig, sig_c) and sig.shape == (n, s) and normal.shape == (n, s, 3)
+    sig, normal = sig.cpu().numpy().reshape(-1), normal.cpu().numpy().reshape(-1, 3)
+    pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3)
+    P = {k: p.detach().cpu().double() for k, p in model.named_parameters()}
+    head = ('sigma_out', 1) if kw.get('use_views', True) else ('rgbs_out', 1)
+
+    def reference(quant):
+        T.QUANT = T.bf16_ste if quant else None
+        try:
+            x = torch.tensor(pts, dtype=torch.float64, requires_grad=True)
+            feat = T.mlp(T.embed(x, lx), P, 'fine_enc', depth, ['relu'] * depth, [depth // 2])
+            raw = T.mlp(feat, P, 'fine_' + head[0], 1, [None])[:, -1]
+        finally:
+            T.QUANT = None
+        (g,) = torch.autograd.grad(torch.relu(raw).sum(), x)
+        return raw.detach().numpy(), g.numpy()
+    raw_q, _ = reference(True)
+    assert np.abs(np.maximum(raw_q, 0) - sig).max() < 2e-2 * max(1., np.abs(raw_q).max())
+    on = sig > 0
+    assert 0.2 < on.mean() < 1.0
+    assert np.abs(normal[~on]).max() == 0.
+    np.testing.assert_allclose(np.linalg.norm(normal[on], axis=1), 1., atol=1e-5)
+    for quant, (p50, p10) in ((True, (0.999, 0.98)), (False, (0.99, 0.8))):
+        raw, g = reference(quant)
+        want = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+        both = on & (raw > 0)
+        cos = (want[both] * normal[both]).sum(1)
+        assert np.median(cos) > p50 and np.quantile(cos, 0.1) > p10, (quant, np.median(cos), np.quantile(cos, 0.1))
+
+
+def test_embed_backward_and_input_gradient_only_mode(nfx_lib, cuda):
+    """nfx_embed_bwd against the analytic pull-back; nfx_mlp_generic_bwd without gradient buffers returns the same dx as
+    with them and touches nothing else."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-2, 2, size=(300, 3))
+    for L in (0, 3, 10):
+        d = rng.normal(size=(300, 3 + 6 * L + 5))
+        got = ops.embed_bwd(L, dev(x, cuda), dev(d, cuda), col0=2).cpu().numpy()
+        want = d[:, 2:5].copy()
+        for k in range(L):
+            c = 5 + 6 * k
+            want += 2. ** k * (np.cos(2. ** k * x) * d[:, c:c + 3] - np.sin(2. ** k * x) * d[:, c + 3:c + 6])
+        # (fp32 arguments: the 2^9 band alone turns the rounding of x into 1e-4 rad, weighted 2^9 again)
+        assert np.abs(got - want).max() < 1e-4 * np.abs(want).max(), (L, np.abs(got - want).max(), np.abs(want).max())
+    ks = [nerf_ref.glorot_uniform(rng, 20, 48), nerf_ref.glorot_uniform(rng, 48, 2)]
+    bs = [np.zeros(48, np.float32), np.zeros(2, np.float32)]
+    net = ops.GenericNet(ks, bs, ['relu', None], train=True).to(cuda)
+    xin, dy = dev(rng.normal(size=(500, 20)), cuda), dev(rng.normal(size=(500, 2)), cuda)
+    dks, dbs = [torch.zeros(k.shape, device=cuda) for k in ks], [torch.zeros(b.shape, device=cuda) for b in bs]
+    a = ops.mlp_generic_bwd(xin, net, dy, dks, dbs, want_dx=True)
+    b = ops.mlp_generic_bwd(xin, net, dy, None, None, want_dx=True)
+    assert torch.equal(a, b)
+    with pytest.raises(Exception, match='nothing to compute'):
+        ops.mlp_generic_bwd(xin, net, dy, None, None)
