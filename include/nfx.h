@@ -399,12 +399,15 @@ NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float
 /* [col0, col0 + widths[n_layers - 1]) are written (so that a caller can        */
 /* assemble concat(features, embedded view) without a copy).                    */
 /* ------------------------------------------------------------------------ */
-NFX_API size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input);
+/* prec here: NFX_PREC_BF16 as above; NFX_PREC_FP32 = fp32 operands and the native fp32 matrix instruction        */
+/* (v_mfma_f32_32x32x2_f32) — the reference's own arithmetic, forward AND backward, for any shape (2-KiB fragments;  */
+/* a blob is packed for one prec).                                                                                  */
+NFX_API size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input, int prec);
 NFX_API int nfx_mlp_generic_pack(const float *const *kernels, const float *const *biases, int d_in, int n_layers,
-                                 const int *widths, const int *skip_input, void *blob, size_t blob_bytes);
+                                 const int *widths, const int *skip_input, int prec, void *blob, size_t blob_bytes);
 NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_in, int n_layers, const int *widths,
-                                const int *acts, const int *skip_input, const void *dev_blob, float *dev_y, int ld_y,
-                                int col0, void *stream);
+                                const int *acts, const int *skip_input, const void *dev_blob, int prec, float *dev_y,
+                                int ld_y, int col0, void *stream);
 /* Backward of the same networks (what trainvali.py:278-285 needs for a non-shipped shape: tf.GradientTape over
  * mlp.Network).  The train blob = the forward blob followed by the transposed (dgrad) fragments; nfx_mlp_generic_fwd
  * accepts it too.  Given dy = dLoss / d(activated output) [n, ld_dy] (columns col0_dy ...), ADDS dLoss/dW into
@@ -413,16 +416,20 @@ NFX_API int nfx_mlp_generic_fwd(const float *dev_x, int64_t n, int ld_x, int d_i
  * nerfactor/models/nerf.py:277-287).  dkernels = dbiases = NULL: only dx is computed (input gradients of a frozen network).  The kernels re-compute the forward in bf16 from x; activation derivatives of
  * hidden layers are taken from their bf16 outputs.  Deterministic (no atomics; the row split of the weight-gradient
  * contraction depends on the problem shape only).  Workspace: nfx_mlp_generic_bwd_workspace_bytes (about
- * 2 bytes x n x (d_in + 2 x sum of widths)), 16-byte aligned device memory. */
-NFX_API size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input);
+ * 2 (bf16) or 4 (fp32) bytes x n x (d_in + 2 x sum of widths)), 16-byte aligned device memory.  With NFX_PREC_FP32
+ * nothing is rounded to bf16 anywhere: this is the backward at the reference's arithmetic (trainvali.py:273-285). */
+NFX_API size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input,
+                                                  int prec);
 NFX_API int nfx_mlp_generic_pack_train(const float *const *kernels, const float *const *biases, int d_in, int n_layers,
-                                       const int *widths, const int *skip_input, void *blob, size_t blob_bytes);
+                                       const int *widths, const int *skip_input, int prec, void *blob,
+                                       size_t blob_bytes);
 NFX_API size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, const int *widths,
-                                                   const int *skip_input);
+                                                   const int *skip_input, int prec);
 NFX_API int nfx_mlp_generic_bwd(const float *dev_x, int64_t n, int ld_x, int d_in, int n_layers, const int *widths,
-                                const int *acts, const int *skip_input, const void *dev_train_blob, const float *dev_dy,
-                                int ld_dy, int col0_dy, float *dev_dx, int ld_dx, float *const *dev_dkernels,
-                                float *const *dev_dbiases, void *dev_workspace, size_t workspace_bytes, void *stream);
+                                const int *acts, const int *skip_input, const void *dev_train_blob, int prec,
+                                const float *dev_dy, int ld_dy, int col0_dy, float *dev_dx, int ld_dx,
+                                float *const *dev_dkernels, float *const *dev_dbiases, void *dev_workspace,
+                                size_t workspace_bytes, void *stream);
 /* Embedder (nerfactor/networks/embedder.py:23-47) as a kernel: out[row, col0 ...] = [v, sin(2^0 v), cos(2^0 v), ...]
  * (incl_input, n_freqs log-sampled bands; n_freqs = 0 = identity) of a 3-vector v per row:
  *   mode 0: v = x[row / per_ray]        mode 1: v = x[row / per_ray] + dir[row / per_ray] * z[row]  (points along rays,

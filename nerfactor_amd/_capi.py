@@ -90,14 +90,14 @@ SIGNATURES = {
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
     'nfx_selftest_tr16': (_i, [_p, _p, _p, _i, _p]),
-    'nfx_mlp_generic_packed_bytes': (_sz, [_i, _i, _p, _p]),
-    'nfx_mlp_generic_pack': (_i, [_pp, _pp, _i, _i, _p, _p, _p, _sz]),
-    'nfx_mlp_generic_fwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
-    'nfx_mlp_generic_train_packed_bytes': (_sz, [_i, _i, _p, _p]),
-    'nfx_mlp_generic_pack_train': (_i, [_pp, _pp, _i, _i, _p, _p, _p, _sz]),
-    'nfx_mlp_generic_bwd_workspace_bytes': (_sz, [_i64, _i, _i, _p, _p]),
+    'nfx_mlp_generic_packed_bytes': (_sz, [_i, _i, _p, _p, _i]),
+    'nfx_mlp_generic_pack': (_i, [_pp, _pp, _i, _i, _p, _p, _i, _p, _sz]),
+    'nfx_mlp_generic_fwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p]),
+    'nfx_mlp_generic_train_packed_bytes': (_sz, [_i, _i, _p, _p, _i]),
+    'nfx_mlp_generic_pack_train': (_i, [_pp, _pp, _i, _i, _p, _p, _i, _p, _sz]),
+    'nfx_mlp_generic_bwd_workspace_bytes': (_sz, [_i64, _i, _i, _p, _p, _i]),
     'nfx_embed_bwd': (_i, [_p, _i64, _i, _i, _p, _i, _i, _p, _p]),
-    'nfx_mlp_generic_bwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _pp, _pp, _p, _sz, _p]),
+    'nfx_mlp_generic_bwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p, _i, _pp, _pp, _p, _sz, _p]),
     'nfx_embed': (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i, _p]),
 }
 

@@ -52,29 +52,42 @@ static int layer_table(int d_in, int n_layers, const int* widths, const int* ski
 static void set_pitches(nfx::generic::Args* a) {
     int widest = 1;
     for (int i = 0; i < a->n_layers; ++i) widest = a->layer[i].n_tiles > widest ? a->layer[i].n_tiles : widest;
-    a->x_pitch = (a->d_in + 63) / 64 * 128 + 16;       // whole k-groups (64 features) per row
-    a->h_pitch = (widest + 1) / 2 * 128 + 16;
+    const int elem = a->f32 ? 4 : 2;
+    a->x_pitch = (a->d_in + 63) / 64 * 64 * elem + 16;       // whole k-groups (64 features) per row
+    a->h_pitch = (widest + 1) / 2 * 64 * elem + 16;
+}
+static int check_prec(int prec, const char* who) {
+    if (prec != NFX_PREC_BF16 && prec != NFX_PREC_FP32) return nfx_fail(NFX_EINVAL, "%s: prec %d (NFX_PREC_BF16 | NFX_PREC_FP32)", who, prec);
+    return NFX_OK;
+}
+static size_t frag_bytes(int prec) { return prec == NFX_PREC_FP32 ? 2048 : 1024; }
+// element (lane, i) of a fragment: bf16: [lane][8]; fp32: [half = i / 4][lane][4] (one DMA piece per half)
+static void put(void* frag, int prec, int lane, int i, float v) {
+    if (prec == NFX_PREC_FP32) static_cast<float*>(frag)[(i >> 2) * 256 + lane * 4 + (i & 3)] = v;
+    else static_cast<uint16_t*>(frag)[lane * 8 + i] = nfx::pack::f32_to_bf16_rne(v);
 }
 
-size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input) {
+size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input, int prec) {
     nfx::generic::Layer t[nfx::generic::kMaxLayers];
     int nf, nb;
-    if (!widths || layer_table(d_in, n_layers, widths, skip_input, nullptr, t, &nf, &nb)) return 0;
-    return (size_t)nf * 1024 + (size_t)nb * 4;
+    if (!widths || check_prec(prec, "nfx_mlp_generic_packed_bytes") || layer_table(d_in, n_layers, widths, skip_input, nullptr, t, &nf, &nb)) return 0;
+    return (size_t)nf * frag_bytes(prec) + (size_t)nb * 4;
 }
 
 int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases, int d_in, int n_layers, const int* widths,
-                         const int* skip_input, void* blob, size_t blob_bytes) {
+                         const int* skip_input, int prec, void* blob, size_t blob_bytes) {
     REQUIRE(kernels && biases && widths && blob, "nfx_mlp_generic_pack: null argument");
+    if (int e = check_prec(prec, "nfx_mlp_generic_pack")) return e;
+    const size_t fb = frag_bytes(prec);
     nfx::generic::Layer t[nfx::generic::kMaxLayers];
     int nf, nb;
     int rc = layer_table(d_in, n_layers, widths, skip_input, nullptr, t, &nf, &nb);
     if (rc) return rc;
-    const size_t need = (size_t)nf * 1024 + (size_t)nb * 4;
+    const size_t need = (size_t)nf * fb + (size_t)nb * 4;
     REQUIRE(blob_bytes >= need, "nfx_mlp_generic_pack: blob too small (%zu < %zu)", blob_bytes, need);
     memset(blob, 0, need);
     float* b = static_cast<float*>(blob);                                           // [biases | fragments]
-    uint16_t* w = reinterpret_cast<uint16_t*>(static_cast<char*>(blob) + (size_t)nb * 4);
+    char* w = static_cast<char*>(blob) + (size_t)nb * 4;
     for (int i = 0; i < n_layers; ++i) {
         REQUIRE(kernels[i] && biases[i], "nfx_mlp_generic_pack: layer %d null", i);
         const nfx::generic::Layer& L = t[i];
@@ -83,7 +96,7 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
         (void)n_in;
         for (int tl = 0; tl < L.n_tiles; ++tl)
             for (int s = 0; s < L.ks_h + L.ks_x; ++s) {
-                uint16_t* frag = w + ((size_t)L.w_off + (size_t)tl * L.ks_pad + s) * 512;
+                char* frag = w + ((size_t)L.w_off + (size_t)tl * L.ks_pad + s) * fb;
                 const bool from_x = s >= L.ks_h;
                 const int base = from_x ? prev : 0, feat0 = 16 * (from_x ? s - L.ks_h : s), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -92,7 +105,7 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
                     for (int j = 0; j < 8; ++j) {
                         const int f = feat0 + 8 * g + j;
                         if (f >= limit) continue;
-                        frag[lane * 8 + j] = nfx::pack::f32_to_bf16_rne(kernels[i][(size_t)(base + f) * L.n_out + col]);
+                        put(frag, prec, lane, j, kernels[i][(size_t)(base + f) * L.n_out + col]);
                     }
                 }
             }
@@ -102,8 +115,9 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
 }
 
 int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_layers, const int* widths, const int* acts,
-                        const int* skip_input, const void* blob, float* y, int ld_y, int col0, void* stream) {
+                        const int* skip_input, const void* blob, int prec, float* y, int ld_y, int col0, void* stream) {
     REQUIRE(n >= 0, "nfx_mlp_generic_fwd: n < 0");
+    if (int e = check_prec(prec, "nfx_mlp_generic_fwd")) return e;
     REQUIRE(widths && acts, "nfx_mlp_generic_fwd: null layer description");
     nfx::generic::Args a;
     int nf, nb;
@@ -125,6 +139,7 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     a.col0 = col0;
     a.n_layers = n_layers;
     a.n_frags = nf;
+    a.f32 = prec == NFX_PREC_FP32;
     set_pitches(&a);
     return nfx_hip_result(nfx_launch_mlp_generic(&a, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
 }
@@ -186,24 +201,26 @@ int wgrad_splits(long long tiles, int n_jobs) {
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace
 
-size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input) {
+size_t nfx_mlp_generic_train_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input, int prec) {
     BwdPlan p;
-    if (!widths || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
-    return (size_t)(p.n_frags + p.n_tfrags) * 1024 + (size_t)p.n_bias * 4;
+    if (!widths || check_prec(prec, "nfx_mlp_generic_train_packed_bytes") || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
+    return (size_t)(p.n_frags + p.n_tfrags) * frag_bytes(prec) + (size_t)p.n_bias * 4;
 }
 
 int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* biases, int d_in, int n_layers,
-                               const int* widths, const int* skip_input, void* blob, size_t blob_bytes) {
+                               const int* widths, const int* skip_input, int prec, void* blob, size_t blob_bytes) {
     REQUIRE(kernels && biases && widths && blob, "nfx_mlp_generic_pack_train: null argument");
+    if (int e = check_prec(prec, "nfx_mlp_generic_pack_train")) return e;
+    const size_t fb = frag_bytes(prec);
     BwdPlan p;
     int rc = bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p);
     if (rc) return rc;
-    const size_t head = (size_t)p.n_frags * 1024 + (size_t)p.n_bias * 4, need = head + (size_t)p.n_tfrags * 1024;
+    const size_t head = (size_t)p.n_frags * fb + (size_t)p.n_bias * 4, need = head + (size_t)p.n_tfrags * fb;
     REQUIRE(blob_bytes >= need, "nfx_mlp_generic_pack_train: blob too small (%zu < %zu)", blob_bytes, need);
-    rc = nfx_mlp_generic_pack(kernels, biases, d_in, n_layers, widths, skip_input, blob, head);
+    rc = nfx_mlp_generic_pack(kernels, biases, d_in, n_layers, widths, skip_input, prec, blob, head);
     if (rc) return rc;
-    uint16_t* wt = reinterpret_cast<uint16_t*>(static_cast<char*>(blob) + head);
-    memset(wt, 0, (size_t)p.n_tfrags * 1024);
+    char* wt = static_cast<char*>(blob) + head;
+    memset(wt, 0, (size_t)p.n_tfrags * fb);
     const int mx = (d_in + 31) / 32;
     for (int i = 0; i < n_layers; ++i) {
         const nfx::generic::Layer& L = p.layer[i];
@@ -211,7 +228,7 @@ int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* 
         const int ks_o_pad = nfx::generic::pad_group(ks_o);
         for (int mt = 0; mt < m_in; ++mt)
             for (int s = 0; s < ks_o; ++s) {
-                uint16_t* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o_pad + s) * 512;
+                char* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o_pad + s) * fb;
                 const bool from_x = mt >= mh;
                 const int base = from_x ? prev : 0, feat0 = 32 * (from_x ? mt - mh : mt), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -219,7 +236,7 @@ int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* 
                     if (f >= limit) continue;
                     for (int j = 0; j < 8; ++j) {
                         const int o = 16 * s + 8 * g + j;
-                        if (o < L.n_out) frag[lane * 8 + j] = nfx::pack::f32_to_bf16_rne(kernels[i][(size_t)(base + f) * L.n_out + o]);
+                        if (o < L.n_out) put(frag, prec, lane, j, kernels[i][(size_t)(base + f) * L.n_out + o]);
                     }
                 }
             }
@@ -227,18 +244,19 @@ int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* 
     return NFX_OK;
 }
 
-size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, const int* widths, const int* skip_input) {
+size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, const int* widths, const int* skip_input, int prec) {
     BwdPlan p;
-    if (n < 0 || !widths || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
+    if (n < 0 || !widths || check_prec(prec, "nfx_mlp_generic_bwd_workspace_bytes") || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
     const long long tiles = (n + 31) / 32;
-    return align256((size_t)tiles * p.feat_rows * 64) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
+    return align256((size_t)tiles * p.feat_rows * (prec == NFX_PREC_FP32 ? 128 : 64)) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
 }
 
 int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_layers, const int* widths, const int* acts,
-                        const int* skip_input, const void* train_blob, const float* dy, int ld_dy, int col0_dy, float* dx,
-                        int ld_dx, float* const* dkernels, float* const* dbiases, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+                        const int* skip_input, const void* train_blob, int prec, const float* dy, int ld_dy, int col0_dy,
+                        float* dx, int ld_dx, float* const* dkernels, float* const* dbiases, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     REQUIRE(n >= 0, "nfx_mlp_generic_bwd: n < 0");
+    if (int e = check_prec(prec, "nfx_mlp_generic_bwd")) return e;
     REQUIRE(widths && acts, "nfx_mlp_generic_bwd: null layer description");
     REQUIRE((dkernels && dbiases) || (!dkernels && !dbiases && dx), "nfx_mlp_generic_bwd: gradient buffers for both kernels and "
             "biases, or neither (then dx is the only result and must not be null)");
@@ -254,7 +272,7 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     REQUIRE(ld_x >= d_in && ld_dy >= col0_dy + widths[n_layers - 1] && col0_dy >= 0 && (!dx || ld_dx >= d_in),
             "nfx_mlp_generic_bwd: bad leading dimensions");
     if (((uintptr_t)train_blob | (uintptr_t)workspace) & 15) return nfx_fail(NFX_EALIGN, "nfx_mlp_generic_bwd: blob / workspace must be 16-byte aligned");
-    const size_t need = nfx_mlp_generic_bwd_workspace_bytes(n, d_in, n_layers, widths, skip_input);
+    const size_t need = nfx_mlp_generic_bwd_workspace_bytes(n, d_in, n_layers, widths, skip_input, prec);
     REQUIRE(workspace_bytes >= need, "nfx_mlp_generic_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
     nfx::generic::BwdArgs ba;
     nfx::generic::WgradArgs wa;
@@ -288,13 +306,14 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     wa.n_jobs = p.n_jobs;
     wa.slice = p.slice;
     wa.dw_total = p.dw_total;
-    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * 64));
+    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * (prec == NFX_PREC_FP32 ? 128 : 64)));
     for (int i = 0; i < n_layers; ++i) {
         ba.f.layer[i] = wa.layer[i] = p.layer[i];
         ba.b[i] = wa.b[i] = p.b[i];
         wa.dw[i] = dkernels ? dkernels[i] : nullptr;
         wa.db[i] = dkernels ? dbiases[i] : nullptr;
     }
+    ba.f.f32 = prec == NFX_PREC_FP32;
     set_pitches(&ba.f);
     return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                           "mlp_generic_bwd");

@@ -24,6 +24,12 @@
 // gradient go to the workspace through the transposing LDS read (tr16.hpp), 1 KiB contiguous per 16 features; the
 // weight-gradient kernel then needs no LDS at all: one wave per (64 x 64 block of dW, row split), all MFMA operands
 // 16-byte loads.  Deterministic: fixed split count per problem shape, ordered reductions, no atomics.
+//
+// precision = fp32 (NFX_PREC_FP32): the same kernels instantiated with fp32 activations in LDS, fp32 fragments (2 KiB per
+// k-step) and the native fp32 matrix instruction v_mfma_f32_32x32x2_f32 — eight per k-step, k = 8 g + i on both
+// operands — i.e. the reference's own arithmetic (trainvali.py:273-285 differentiates in fp32), forward AND backward,
+// for any shape including the shipped ones.  163 TFLOP/s is that instruction's peak; at one wave per SIMD its 64-cycle
+// issue hides the loop's scalar work, so this path is MFMA-bound where the bf16 one is issue-bound.
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"
 #include "mlp_generic.hpp"
@@ -34,8 +40,8 @@ namespace generic {
 
 // One wave per workgroup (waves are independent: no barrier anywhere).  LDS of a wave: the weight ring, then 32 rows x
 // (x_pitch + 2 h_pitch) bytes of activations, the pitches sized by the HOST from the network's real widths
-// (Args::x_pitch / h_pitch: features x 2 + 16, rows 4 banks apart) — a 256-wide network keeps 3 waves per CU resident,
-// a 128-wide one 5, a 64-wide one 6.
+// (Args::x_pitch / h_pitch: features x element size + 16, rows 4 banks apart) — bf16: a 256-wide network keeps 3 waves
+// per CU resident, a 128-wide one 5, a 64-wide one 6.
 // LDS is addressed through address_space(3) pointers THROUGHOUT: a generic pointer that the compiler cannot trace back to
 // the shared array (a select between two buffers is enough) becomes a flat load, which waits on vmcnt — i.e. on the
 // weight ring's look-ahead — before every MFMA.
@@ -43,16 +49,33 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-constexpr int kRingGroups = 3, kGroupBytes = kGroup * kFragBytes, kRingBytes = kRingGroups * kGroupBytes;
-static_assert(kRingBytes + 32 * ((kMaxIn * 2 + 16) + 2 * (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
-static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8) = (kRingGroups - 1) kGroup pieces in flight");
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+constexpr int kRingGroups = 3;
+
+// What differs between the two operand types: F32 = false: bf16 operands, v_mfma_f32_32x32x16_bf16; true: fp32 operands,
+// 8 x v_mfma_f32_32x32x2_f32 per k-step.
+template <bool F32>
+struct P {
+    static constexpr int kElem = F32 ? 4 : 2;                 // bytes per activation / weight
+    static constexpr int kFrag = 32 * 16 * kElem;             // one k-step's A fragment (32 outputs x 16 inputs): 1 or 2 KiB
+    static constexpr int kGroupBytes = kGroup * kFrag;
+    static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
+    static constexpr int kRingBytes = kRingGroups * kGroupBytes;
+    static constexpr int kStep = 16 * kElem;                  // bytes of one k-step in a row: 32 or 64
+    static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
+    static constexpr int kWsFeat = 32 * kElem;                // workspace bytes per (feature, row tile)
+};
+static_assert(P<false>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + 2 * (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<true>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + 2 * (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
+static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8 | 16) = (kRingGroups - 1) groups of pieces in flight");
 
 // The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
 // to whole groups of kGroup), copied global -> LDS by the DMA path (lds_dma.hpp) kRingGroups groups ahead of the MFMAs —
 // a register-staged prefetch cannot rotate its buffers without waiting for the loads it just issued; an LDS slot is
 // only an address.  The stream is circular: behind its last group the ring already fetches the next row tile's first.
-// vmcnt is in order, so "at most 8 pieces outstanding" = the oldest group has landed; the wave's other VMEM operations
-// can only make that wait stricter.
+// vmcnt is in order, so "at most two groups of pieces outstanding" = the oldest group has landed; the wave's other VMEM
+// operations can only make that wait stricter.
+template <bool F32>
 struct Ring {
     const char* next;    // next group to fetch (wave-uniform)
     const char* begin;
@@ -62,8 +85,10 @@ struct Ring {
     unsigned lane_off;
     int slot;            // oldest group = the one the MFMAs read next = the one refilled after them
     __device__ __forceinline__ void issue() {
-        lds_dma_pieces<kGroup>(lane_off, next, lds + (unsigned)slot * kGroupBytes);
-        next += kGroupBytes;
+        const unsigned dst = lds + (unsigned)slot * P<F32>::kGroupBytes;
+        lds_dma_pieces<4>(lane_off, next, dst);
+        if constexpr (F32) lds_dma_pieces<4>(lane_off, next + 4096, dst + 4096u);
+        next += P<F32>::kGroupBytes;
         if (next == end) next = begin;
         slot = slot == kRingGroups - 1 ? 0 : slot + 1;
     }
@@ -72,29 +97,48 @@ struct Ring {
         lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
         lane_off = (unsigned)lane * 16u;
         begin = next = stream;
-        end = stream + (size_t)n_frags * kFragBytes;
+        end = stream + (size_t)n_frags * P<F32>::kFrag;
         slot = 0;
 #pragma unroll
         for (int i = 0; i < kRingGroups; ++i) issue();
     }
+    __device__ __forceinline__ void wait_oldest() {
+        if constexpr (F32) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
 };
 // One 32 x 32 output tile: acc += W_tile^T [h | x], kg_h groups of four k-steps over the previous layer's output, then
 // kg_x over the network input.  A: the ring; B: 64 consecutive features of the lane's own row in LDS.  Nothing in the
-// loop depends on the k-step but immediate offsets: pad steps multiply zero fragments with whatever finite bf16 the
+// loop depends on the k-step but immediate offsets: pad steps multiply zero fragments with whatever finite number the
 // row holds there (the activation area is zeroed once, then only ever holds activations).
-__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
+// fp32: a fragment is [half][lane][4 floats] — lane (m, g) holds W[16 s + 8 g + 4 half + r][m] — and MFMA i of a k-step
+// contracts k = 8 g + i on both operands.
+template <bool F32>
+__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<F32>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
     for (int gi = 0; gi < kg_h + kg_x; ++gi) {
-        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * 32) : xsrc + (gi - kg_h) * (kGroup * 32);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        const lds_char* grp = w.lds_ptr + w.slot * kGroupBytes + w.lane_off;
-        bf16x8 af[kGroup], bf[kGroup];
+        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<F32>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<F32>::kStep);
+        w.wait_oldest();
+        const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
+        if constexpr (!F32) {
+            bf16x8 af[kGroup], bf[kGroup];
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * kFragBytes);
-            bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
+            for (int j = 0; j < kGroup; ++j) {
+                af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 1024);
+                bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const f32x4 a0 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048), a1 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048 + 1024);
+                const f32x4 b0 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64), b1 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64 + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc, 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc, 0, 0, 0);
         // the slot is refilled only after every read of it has RETURNED (the compiler may sink MFMAs below this point,
         // not memory operations above it); the wait overlaps the first MFMAs of the group
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -104,19 +148,31 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring& w, int kg_h, int kg
 }
 // the wave's activation area starts as zeros: every feature a pad k-step can touch is a finite number
 __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
-    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     for (int o = lane * 16; o < bytes; o += 64 * 16) *reinterpret_cast<lds_f32x4*>(p + o) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-// the lane's row of the network input -> bf16, zero padded to whole k-steps; lane half g takes every other 8 features
-__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g) {
+// the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features; `ws`
+// (backward, fp32 only): also to the workspace, feature-major (the bf16 path transposes through store_blocked instead)
+template <bool F32>
+__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g, float* ws_col = nullptr) {
     for (int c0 = 8 * g; c0 < feats; c0 += 16) {
         float f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = src[c0 + j < d_in ? c0 + j : d_in - 1];     // (unconditional: eight loads in flight)
-        bf16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c0 + j < d_in ? f[j] : 0.f);
-        *reinterpret_cast<lds_bf16x8*>(dst + c0 * 2) = v;
+        for (int j = 0; j < 8; ++j) f[j] = c0 + j < d_in ? f[j] : 0.f;
+        if constexpr (F32) {
+            *reinterpret_cast<lds_f32x4*>(dst + c0 * 4) = f32x4{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<lds_f32x4*>(dst + c0 * 4 + 16) = f32x4{f[4], f[5], f[6], f[7]};
+            if (ws_col) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ws_col[(size_t)(c0 + j) * 32] = f[j];
+            }
+        } else {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+            *reinterpret_cast<lds_bf16x8*>(dst + c0 * 2) = v;
+        }
     }
 }
 // bias of the lane's 16 outputs of a tile (D row of register q: (q&3) + 8 (q>>2) + 4 g) through wave-uniform (scalar)
@@ -152,40 +208,46 @@ __device__ __forceinline__ void zero_pad16(float* v, int t, int g, int n_out) {
             if (32 * t + (q & 3) + 8 * (q >> 2) + 4 * g >= n_out) v[q] = 0.f;
     }
 }
-// 16 floats (register q = feature (q&3) + 8 (q>>2) + 4 g of the tile) -> the lane's row in LDS as four 8-byte stores
+// 16 floats (register q = feature (q&3) + 8 (q>>2) + 4 g of the tile) -> the lane's row in LDS: four 8- or 16-byte stores
+template <bool F32>
 __device__ __forceinline__ void store_row16(lds_char* row_tile, int g, const float* v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        bf16x4 o;
+        if constexpr (F32) {
+            *reinterpret_cast<lds_f32x4*>(row_tile + (8 * q + 4 * g) * 4) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        } else {
+            bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[4 * q + j];
-        *reinterpret_cast<lds_bf16x4*>(row_tile + (8 * q + 4 * g) * 2) = o;
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[4 * q + j];
+            *reinterpret_cast<lds_bf16x4*>(row_tile + (8 * q + 4 * g) * 2) = o;
+        }
     }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + kRingBytes;                   // [32][x_pitch]  network input
+    lds_char* xb = ring + P<F32>::kRingBytes;           // [32][x_pitch]  network input
     lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
     const long long n_tiles_rows = (a.n + 31) / 32;
-    Ring w;
+    Ring<F32> w;
     w.start(ring, a.weights, a.n_frags, lane);
     zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
     for (long long rt = blockIdx.x; rt < n_tiles_rows; rt += gridDim.x) {
         const long long row0 = rt * 32;
         {
             const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
-            load_x(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
+            load_x<F32>(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
         }
         int cur = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-            const lds_char* hsrc = hb[cur] + p * h_pitch + g * 16;      // this lane's row, its 8 of every 16 features
-            const lds_char* xsrc = xb + p * x_pitch + g * 16;
+            const lds_char* hsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);   // this lane's row, its 8 of every 16 features
+            const lds_char* xsrc = xb + p * x_pitch + g * (P<F32>::kStep / 2);
             lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
             for (int t = 0; t < L.n_tiles; ++t) {
                 float bias[16];
@@ -193,7 +255,7 @@ __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
+                acc = tile_mma<F32>(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
                 // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
                 float v[16];
 #pragma unroll
@@ -213,7 +275,7 @@ __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
                     }
                 } else {
                     zero_pad16(v, t, g, L.n_out);
-                    store_row16(hdst + 64 * t, g, v);
+                    store_row16<F32>(hdst + P<F32>::kTile * t, g, v);
                 }
             }
             cur ^= 1;
@@ -249,7 +311,7 @@ __device__ __forceinline__ void scale_by_act_grad_output16(float* d, const float
         for (int q = 0; q < 16; ++q) d[q] *= 1.f - expf(-y[q]);
     }
 }
-// [32 rows][F features] row-major bf16 in the wave's LDS -> feature rows [frow, frow + F) of the wave's workspace tile.
+// bf16: [32 rows][F features] row-major in the wave's LDS -> feature rows [frow, frow + F) of the wave's workspace tile.
 // 16-lane group q takes rows 4 q .. 4 q + 3 (then + 16): lane i supplies row 4 q + (i >> 2), features f0 + 4 (i & 3) ..,
 // receives feature f0 + i of the four rows = one 8-byte store.
 __device__ __forceinline__ void store_blocked(const lds_char* lds, int pitch, int F, char* wst, int frow, int lane) {
@@ -264,33 +326,40 @@ __device__ __forceinline__ void store_blocked(const lds_char* lds, int pitch, in
         *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64 + 32) = hi;
     }
 }
+// fp32: the lane's 16 values of a tile straight from registers, one coalesced 128-byte line per feature and half
+__device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int g, const float* v) {
+    float* dst = reinterpret_cast<float*>(wst) + (size_t)(frow_tile + 4 * g) * 32 + p;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * 32] = v[q];
+}
 
+template <bool F32>
 __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
     const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + kRingBytes;
+    lds_char* xb = ring + P<F32>::kRingBytes;
     lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
     const int fx = (a.d_in + 31) / 32 * 32, mx = fx / 32;
-    Ring w;
+    Ring<F32> w;
     w.start(ring, a.weights, ba.stream_frags, lane);   // forward fragments, then the transposed ones, as one stream
     zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
     for (long long rt = blockIdx.x; rt < ba.tiles; rt += gridDim.x) {
         const long long row0 = rt * 32;
         const bool live = row0 + p < a.n;
         const long long r = live ? row0 + p : a.n - 1;
-        char* wst = ba.ws + (size_t)rt * ba.feat_rows * 64;
-        load_x(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g);
-        store_blocked(xb, x_pitch, fx, wst, 0, lane);
+        char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<F32>::kWsFeat;
+        load_x<F32>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
+        if constexpr (!F32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         int cur = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-            const lds_char* hsrc = hb[cur] + p * h_pitch + g * 16;
-            const lds_char* xsrc = xb + p * x_pitch + g * 16;
+            const lds_char* hsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);
+            const lds_char* xsrc = xb + p * x_pitch + g * (P<F32>::kStep / 2);
             lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
             for (int t = 0; t < L.n_tiles; ++t) {
                 float bias[16];
@@ -298,7 +367,7 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
+                acc = tile_mma<F32>(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
                 float v[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
@@ -317,42 +386,52 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                     activate16(v, L.act);
                 }
                 zero_pad16(v, t, g, L.n_out);
-                store_row16(hdst + 64 * t, g, v);
+                store_row16<F32>(hdst + P<F32>::kTile * t, g, v);
+                if constexpr (F32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
             }
-            if (!last) store_blocked(hb[cur ^ 1], h_pitch, L.n_tiles * 32, wst, ba.b[l].h_row, lane);
+            if constexpr (!F32) {
+                if (!last) store_blocked(hb[cur ^ 1], h_pitch, L.n_tiles * 32, wst, ba.b[l].h_row, lane);
+            }
             cur ^= 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stored activations are read back below (same wave, own lines)
         // ---- backward: hb[cur] holds dZ of layer l.  The transposed fragments follow the forward ones in the stream, last
         // layer first; the tiles that produce dLoss/d(network input) are always computed (the stream does not skip) and
         // stored only when dx is wanted — except layer 0's, which end the stream and are cut off it by the host.
         bool dx_written = false;
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const Layer L = a.layer[l];
-            store_blocked(hb[cur], h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
+            if constexpr (!F32) store_blocked(hb[cur], h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
             const int kg_o = pad_group(2 * L.n_tiles) / kGroup, mh = l > 0 ? a.layer[l - 1].n_tiles : 0;
-            const lds_char* zsrc = hb[cur] + p * h_pitch + g * 16;
+            const lds_char* zsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);
             for (int mt = 0; mt < mh; ++mt) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma(acc, w, kg_o, 0, zsrc, zsrc);
+                acc = tile_mma<F32>(acc, w, kg_o, 0, zsrc, zsrc);
                 // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
-                const __bf16* hy = reinterpret_cast<const __bf16*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
                 float d[16], y[16];
+                if constexpr (F32) {
+                    const float* hy = reinterpret_cast<const float*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    d[q] = acc[q];
-                    y[q] = (float)hy[((q & 3) + 8 * (q >> 2)) * 32];
+                    for (int q = 0; q < 16; ++q) y[q] = hy[((q & 3) + 8 * (q >> 2)) * 32];
+                } else {
+                    const __bf16* hy = reinterpret_cast<const __bf16*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) y[q] = (float)hy[((q & 3) + 8 * (q >> 2)) * 32];
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d[q] = acc[q];
                 scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
-                store_row16(hb[cur ^ 1] + p * h_pitch + 64 * mt, g, d);
+                store_row16<F32>(hb[cur ^ 1] + p * h_pitch + P<F32>::kTile * mt, g, d);
+                if constexpr (F32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
             }
             if (L.ks_x > 0 && (ba.dx || l > 0)) {
                 for (int mt = 0; mt < mx; ++mt) {
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                    acc = tile_mma(acc, w, kg_o, 0, zsrc, zsrc);
+                    acc = tile_mma<F32>(acc, w, kg_o, 0, zsrc, zsrc);
                     if (live && ba.dx) {
                         float* dst = ba.dx + (row0 + p) * ba.ld_dx;
 #pragma unroll
@@ -372,14 +451,39 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
 
 // one wave per (64 x 64 block of one layer's dW = 2 x 2 MFMA tiles, row split): dW[i, o] = sum over rows of IN[row, i] dZ[row, o].
 // Four 16-byte loads feed four MFMAs (1 KiB of operands per MFMA and wave instead of 2); a block's second input / output
-// tile may not exist (odd tile counts) — it then aliases the first and is not stored.
+// tile may not exist (odd tile counts) — it then aliases the first and is not stored.  fp32: the same with 32-byte
+// operands (8 rows) and eight v_mfma_f32_32x32x2_f32 per tile pair and 16 rows.
 struct InTile { int frow, n_valid, i_base; };
 __device__ __forceinline__ InTile in_tile(const WgradArgs& a, int l, int it) {
     const int mh = l > 0 ? a.layer[l - 1].n_tiles : 0, prev = l > 0 ? a.layer[l - 1].n_out : 0;
     if (it < mh) return {a.b[l - (l > 0)].h_row + 32 * it, prev - 32 * it, 32 * it};
     return {32 * (it - mh), a.d_in - 32 * (it - mh), prev + 32 * (it - mh)};
 }
+template <bool F32> struct Frag;
+template <> struct Frag<false> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const char* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void ones() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)1.0f;
+    }
+    static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0); }
+};
+template <> struct Frag<true> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ void load(const char* p) { lo = *reinterpret_cast<const f32x4*>(p); hi = *reinterpret_cast<const f32x4*>(p + 16); }
+    __device__ __forceinline__ void ones() { lo = hi = f32x4{1.f, 1.f, 1.f, 1.f}; }
+    static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[i], b.lo[i], c, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[i], b.hi[i], c, 0, 0, 0);
+        return c;
+    }
+};
+template <bool F32>
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
+    constexpr int E = P<F32>::kElem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, g = lane >> 5;
     const long long wid = (long long)blockIdx.x * 4 + wave;
     if (wid >= (long long)a.n_jobs * a.splits) return;
@@ -393,31 +497,30 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     const InTile ti[2] = {in_tile(a, l, 2 * ip), in_tile(a, l, two_i ? 2 * ip + 1 : 2 * ip)};
     const int fb[2] = {a.b[l].dz_row + 64 * op, a.b[l].dz_row + 64 * op + (two_o ? 32 : 0)};
     const long long t0 = a.tiles * sp / a.splits, t1 = a.tiles * (sp + 1) / a.splits;
-    const char* pa[2] = {a.ws + ((size_t)(ti[0].frow + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(ti[1].frow + m) * 32 + 8 * g) * 2};
-    const char* pb[2] = {a.ws + ((size_t)(fb[0] + m) * 32 + 8 * g) * 2, a.ws + ((size_t)(fb[1] + m) * 32 + 8 * g) * 2};
-    const size_t tile_bytes = (size_t)a.feat_rows * 64;
+    const char* pa[2] = {a.ws + ((size_t)(ti[0].frow + m) * 32 + 8 * g) * E, a.ws + ((size_t)(ti[1].frow + m) * 32 + 8 * g) * E};
+    const char* pb[2] = {a.ws + ((size_t)(fb[0] + m) * 32 + 8 * g) * E, a.ws + ((size_t)(fb[1] + m) * 32 + 8 * g) * E};
+    const size_t tile_bytes = (size_t)a.feat_rows * 32 * E;
     f32x16 acc[2][2], accb[2];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[0][0][q] = acc[0][1][q] = acc[1][0][q] = acc[1][1][q] = accb[0][q] = accb[1][q] = 0.f;
     // the jobs of a layer's first input pair also sum their dZ columns: db[o] = sum over rows of 1 x dZ[row, o]
     const bool with_bias = ip == 0;
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    Frag<F32> ones;
+    ones.ones();
 #pragma unroll 2
     for (long long t = t0; t < t1; ++t) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const size_t off = t * tile_bytes + 32 * kk;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa[0] + off), a1 = *reinterpret_cast<const bf16x8*>(pa[1] + off);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb[0] + off), b1 = *reinterpret_cast<const bf16x8*>(pb[1] + off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            const size_t off = t * tile_bytes + 16 * E * kk;
+            Frag<F32> a0, a1, b0, b1;
+            a0.load(pa[0] + off); a1.load(pa[1] + off); b0.load(pb[0] + off); b1.load(pb[1] + off);
+            acc[0][0] = Frag<F32>::mma(a0, b0, acc[0][0]);
+            acc[0][1] = Frag<F32>::mma(a0, b1, acc[0][1]);
+            acc[1][0] = Frag<F32>::mma(a1, b0, acc[1][0]);
+            acc[1][1] = Frag<F32>::mma(a1, b1, acc[1][1]);
             if (with_bias) {
-                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b0, accb[0], 0, 0, 0);
-                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b1, accb[1], 0, 0, 0);
+                accb[0] = Frag<F32>::mma(ones, b0, accb[0]);
+                accb[1] = Frag<F32>::mma(ones, b1, accb[1]);
             }
         }
     }
@@ -533,25 +636,30 @@ int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipSt
     if (args->n <= 0) return 0;
     const long long tiles = (args->n + 31) / 32;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    const int lds = kRingBytes + 32 * (args->x_pitch + 2 * args->h_pitch);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const bool f32 = args->f32 != 0;
+    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (args->x_pitch + 2 * args->h_pitch);
+    const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mlp_generic_kernel, dim3(grid), dim3(64), lds, st, *args);
+    if (f32) hipLaunchKernelGGL(mlp_generic_kernel<true>, dim3(grid), dim3(64), lds, st, *args);
+    else hipLaunchKernelGGL(mlp_generic_kernel<false>, dim3(grid), dim3(64), lds, st, *args);
     return (int)hipGetLastError();
 }
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (ba->f.n <= 0) return 0;
     const int grid = (int)(ba->tiles < max_blocks ? ba->tiles : max_blocks);
-    const int lds = kRingBytes + 32 * (ba->f.x_pitch + 2 * ba->f.h_pitch);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const bool f32 = ba->f.f32 != 0;
+    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (ba->f.x_pitch + 2 * ba->f.h_pitch);
+    const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_bwd_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_bwd_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(64), lds, st, *ba);
+    if (f32) hipLaunchKernelGGL(mlp_generic_bwd_kernel<true>, dim3(grid), dim3(64), lds, st, *ba);
+    else hipLaunchKernelGGL(mlp_generic_bwd_kernel<false>, dim3(grid), dim3(64), lds, st, *ba);
     if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
         const long long waves = (long long)wa->n_jobs * wa->splits;
-        hipLaunchKernelGGL(mlp_generic_wgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
+        if (f32) hipLaunchKernelGGL(mlp_generic_wgrad_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
+        else hipLaunchKernelGGL(mlp_generic_wgrad_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
         hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
     }
     return (int)hipGetLastError();

@@ -32,7 +32,8 @@ struct Args {
     float* y;         // [n, ld_y] output, columns [col0, col0 + n_out of the last layer)
     int ld_y, col0;
     int n_layers;
-    int x_pitch, h_pitch;   // LDS row pitches in bytes: (features padded to 64) x 2 + 16 of the input / the widest layer
+    int x_pitch, h_pitch;   // LDS row pitches in bytes: (features padded to 64) x element size + 16 of the input / the widest layer
+    int f32;                // operands: 0 bf16 (1-KiB fragments), 1 fp32 (2-KiB fragments, v_mfma_f32_32x32x2_f32)
     Layer layer[kMaxLayers];
 };
 // Embedder (embedder.py:23-47): out[:, col0 ...] = [x, sin(f_0 x), cos(f_0 x), sin(f_1 x), cos(f_1 x), ...], f_k = 2^k,
@@ -74,7 +75,7 @@ struct BwdArgs {
     int ld_dy, col0_dy;
     float* dx;               // [n, ld_dx] gradient w.r.t. the network input, or null
     int ld_dx;
-    char* ws;                // workspace: bf16 [tiles][feat_rows][32]
+    char* ws;                // workspace: bf16 | fp32 [tiles][feat_rows][32]
     long long tiles;         // row tiles (32 rows)
     int feat_rows;           // sum of all padded feature counts (x at feature row 0, hidden outputs, gradients)
     BwdLayer b[kMaxLayers];
@@ -82,7 +83,7 @@ struct BwdArgs {
 struct WgradArgs {
     const char* ws;
     long long tiles;
-    int feat_rows, n_layers, d_in, splits, n_jobs;
+    int feat_rows, n_layers, d_in, splits, n_jobs;   // (the element type of ws is the kernel's template argument)
     long long slice;         // floats per partial slice: all kernel gradients, then all bias gradients
     long long dw_total;      // floats of kernel gradients in a slice
     float* partial;          // [splits][slice]

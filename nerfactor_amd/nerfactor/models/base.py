@@ -47,6 +47,15 @@ class Model(torch.nn.Module):
         self.trainable_registered = False
         self.wloss = self._init_loss()
         self.precision = config.get('DEFAULT', 'precision', fallback='bf16')  # MFMA operand type
+        # Operand type of the BACKWARD.  precision = fp32 trains at the reference's own arithmetic (trainvali.py:273-285
+        # differentiates in fp32) by default: forward and backward of every network through the fp32 instantiation of
+        # the runtime-shaped kernels (csrc/mlp_generic.hip: fp32 operands, native fp32 matrix instruction) — about 15x
+        # the bf16 step.  grad_precision = bf16 keeps round 3's mixed mode (fp32-class forward kernels, bf16-operand
+        # backward kernels), which is what precision = bf16 always uses.
+        self.grad_precision = config.get('DEFAULT', 'grad_precision', fallback=self.precision)
+        if self.grad_precision not in ('bf16', 'fp32') or (self.precision == 'bf16' and self.grad_precision == 'fp32'):
+            raise ValueError("grad_precision = %s with precision = %s (bf16 | fp32; fp32 gradients need precision = fp32)"
+                             % (self.grad_precision, self.precision))
         self._blobs = {}  # packed-weight cache: key -> (versions, device blob)
         self._packers = {}  # key -> ops.DevicePacker
 

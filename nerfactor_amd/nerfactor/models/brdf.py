@@ -75,7 +75,8 @@ class Model(BaseModel):
         ko, bo = self.net['brdf_out'].kernels_and_biases()
         params = tuple(ks + ko) + tuple(bs + bo)
         z, rusink = z.float().contiguous(), rusink.float().contiguous()
-        if not self.tuned:
+        recording = torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params))
+        if not self.tuned or (recording and self.grad_precision == 'fp32'):
             return self._eval_brdf_generic(z, rusink, params)
         if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in params)):
             brdf, reci = nfx_grad.BrdfRows.apply(z, rusink, self._train_blob, self.precision, *params)
@@ -89,11 +90,11 @@ class Model(BaseModel):
         ko, bo = self.net['brdf_out'].kernels_and_biases()
         body = self.net['brdf_mlp']
         acts = [l.activation for l in body.layers] + ['softplus']
-        tag = 'brdf_generic_train' if train else 'brdf_generic'
+        tag = ('brdf_generic_train' if train else 'brdf_generic') + self.precision
         descs = self.__dict__.setdefault('_generic_desc', {})
 
         def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at, train=train)
+            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=self.precision)
             descs.setdefault(tag, g)
             return g.blob
         blob = self._packed(tag, ks + ko + bs + bo, pack)

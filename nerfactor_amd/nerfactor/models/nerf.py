@@ -95,8 +95,6 @@ class Model(BaseModel):
             raise NotImplementedError(
                 "libnfx's runtime-shaped kernels take 2 <= enc_depth <= 12, mlp_width <= 256 and relu / sigmoid / softplus "
                 "/ linear activations (got enc_depth = %d, mlp_width = %d, act = %s)" % (depth, width, act))
-        if self.precision != 'bf16':
-            raise NotImplementedError("precision = fp32 exists for the shipped NeRF architecture only")
 
     # ------------------------------------------------------------------ weights -> device blob
     def _nerf_blob(self, pref):
@@ -161,15 +159,15 @@ class Model(BaseModel):
     # ------------------------------------------------------------------ non-shipped shapes: runtime-shaped kernels
     def _generic_net(self, key, train=False):
         """self.net[key] packed for nfx_mlp_generic_fwd / _bwd (cached like the tuned blobs, re-packed — on the device —
-        when a parameter changes); train = True: with the backward's transposed fragments."""
+        when a parameter changes); train = True: with the backward's transposed fragments.  Operand type = `precision`."""
         net = self.net[key]
         ks, bs = net.kernels_and_biases()
         acts = [l.activation for l in net.layers]
-        tag = key + ('generic_train' if train else 'generic')
+        tag = key + ('generic_train' if train else 'generic') + self.precision
         descs = self.__dict__.setdefault('_generic_desc', {})
 
         def pack(k, b):
-            g = ops.GenericNet(k, b, acts, net.skip_at, train=train)
+            g = ops.GenericNet(k, b, acts, net.skip_at, train=train, prec=self.precision)
             descs.setdefault(tag, g)
             return g.blob
         blob = self._packed(tag, ks + bs, pack)
@@ -226,9 +224,10 @@ class Model(BaseModel):
 
     def _eval_rays(self, rayo, rayd, z, pref):
         """rgbs[N,S,4]; differentiable w.r.t. the network weights while autograd is recording."""
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if training and (not self.tuned or self.grad_precision == 'fp32'):
+            return self._eval_rays_generic_train(rayo, rayd, z, pref)     # (fp32 gradients: the fp32 runtime-shaped kernels)
         if not self.tuned:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                return self._eval_rays_generic_train(rayo, rayd, z, pref)
             return self._eval_rays_generic(rayo, rayd, z, pref)
         if torch.is_grad_enabled():
             ks, bs = self._nerf_params(pref)

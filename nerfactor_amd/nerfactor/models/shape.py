@@ -29,8 +29,6 @@ class Model(BaseModel):
         self.tuned = True
         self.embedder = self._init_embedder()
         self.net = self._init_net()
-        if not self.tuned and self.precision != 'bf16':
-            raise NotImplementedError("precision = fp32 exists for the shipped surface MLP shapes only")
         # big world-space coordinates (e.g. MVS reconstructions) are scaled before the MLPs
         self.xyz_scale = cfg.getfloat('DEFAULT', 'xyz_scale', fallback=1.)
         lxyz, lareas = self._gen_lights()
@@ -65,8 +63,6 @@ class Model(BaseModel):
                 raise NotImplementedError(
                     "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and a skip before the last "
                     "layer (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
-            if self.precision != 'bf16':
-                raise NotImplementedError("precision = fp32 exists for the shipped surface MLP only")
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
         body.build(in_dims)
         head = mlp.Network([out_dims], act=[out_act])
@@ -128,7 +124,7 @@ class Model(BaseModel):
         """One xyz-conditioned head; differentiable w.r.t. its weights when autograd is recording.  `infer_prec`:
         operand type of the forward-only evaluation (vali / test / render) when it differs from `precision`."""
         params = self._params128(body, head)
-        if not self._net_tuned(body):
+        if not self._net_tuned(body) or self._fp32_grads(params):
             enc = ops.embed(self.embedder['xyz'].n_freqs, x=(pts.detach() * self.xyz_scale).contiguous())
             y = self._generic_apply(enc, body, head, out_act, params)
             return y if (post_scale == 1. and post_bias == 0.) else y * post_scale + post_bias
@@ -151,6 +147,11 @@ class Model(BaseModel):
         return (self.embedder['xyz'].n_freqs == 10 and self.embedder['ldir'].n_freqs == 4 and len(body.layers) == 4 and
                 all(l.units == 128 and l.activation == 'relu' for l in body.layers) and list(body.skip_at or []) == [2])
 
+    def _fp32_grads(self, params):
+        """A training call at grad_precision = fp32: every network, the shipped shapes included, runs forward and
+        backward on the fp32 runtime-shaped kernels."""
+        return self.grad_precision == 'fp32' and self._wants_grad(params)
+
     def _generic_net(self, body_name, head_name, out_act, nets=None, train=False):
         """Body + head as ONE runtime-shaped network (cached and re-packed like the tuned blobs); train = True: with the
         backward's transposed fragments."""
@@ -159,11 +160,11 @@ class Model(BaseModel):
         ks, bs = body.kernels_and_biases()
         ko, bo = head.kernels_and_biases()
         acts = [l.activation for l in body.layers] + [out_act]
-        tag = body_name + ('generic_train' if train else 'generic')
+        tag = body_name + ('generic_train' if train else 'generic') + self.precision
         descs = self.__dict__.setdefault('_generic_desc', {})
 
         def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at, train=train)
+            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=self.precision)
             descs.setdefault(tag, g)
             return g.blob
         blob = self._packed(tag, ks + ko + bs + bo, pack)
@@ -265,7 +266,7 @@ class Model(BaseModel):
         kernel from `self.lxyz` and `dir_pts` (default `pts`); an explicit `surf2l` tensor is
         accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
         params = self._params128('lvis_mlp', 'lvis_out')
-        if not self._net_tuned('lvis_mlp'):
+        if not self._net_tuned('lvis_mlp') or self._fp32_grads(params):
             return self.check_numerics(self._pred_lvis_generic(pts, dir_pts), "Light visibility")
         blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
         lxyz = self.lxyz.reshape(-1, 3)

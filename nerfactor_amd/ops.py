@@ -259,9 +259,10 @@ class GenericNet:
     """A packed mlp.Network of arbitrary shape for mlp_generic_fwd / mlp_generic_bwd: blob (uint8 tensor, move it with
     .to(device)) + the layer description the C-ABI takes.  skip_at: the reference's list (after layer i the input is
     re-concatenated, y first: nerfactor/networks/mlp.py:47-48).  train = True packs the train blob (forward fragments +
-    transposed fragments for the backward); the forward accepts either."""
+    transposed fragments for the backward); the forward accepts either.  prec = 'fp32': fp32 fragments for the kernels'
+    fp32 instantiation (native fp32 matrix instruction, nothing rounded to bf16)."""
 
-    def __init__(self, kernels, biases, acts, skip_at=None, train=False):
+    def __init__(self, kernels, biases, acts, skip_at=None, train=False, prec='bf16'):
         ks = [_as_host_f32(k) for k in kernels]
         bs = [_as_host_f32(b) for b in biases]
         n = len(ks)
@@ -282,13 +283,14 @@ class GenericNet:
         self._a = (ctypes.c_int * n)(*self.acts)
         size_fn, pack_fn = ((lib.nfx_mlp_generic_train_packed_bytes, lib.nfx_mlp_generic_pack_train) if train else
                             (lib.nfx_mlp_generic_packed_bytes, lib.nfx_mlp_generic_pack))
-        nbytes = size_fn(self.d_in, n, self._w, self._s)
+        self.prec = _PREC[prec]
+        nbytes = size_fn(self.d_in, n, self._w, self._s, self.prec)
         if nbytes == 0:
             raise _capi.NfxError("GenericNet: shape outside the generic kernel's limits: " + _capi.last_error())
         blob = np.zeros(nbytes, np.uint8)
         karr = (ctypes.c_void_p * n)(*[k.ctypes.data for k in ks])
         barr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
-        check(pack_fn(karr, barr, self.d_in, n, self._w, self._s, blob.ctypes.data, nbytes), 'nfx_mlp_generic_pack')
+        check(pack_fn(karr, barr, self.d_in, n, self._w, self._s, self.prec, blob.ctypes.data, nbytes), 'nfx_mlp_generic_pack')
         self.blob = torch.from_numpy(blob)
         self.n_layers, self.d_out, self.train = n, self.widths[-1], bool(train)
         self.in_dims = [self.d_in if i == 0 else self.widths[i - 1] + (self.d_in if self.skip_input[i] else 0)
@@ -312,8 +314,8 @@ def mlp_generic_fwd(x, net, out=None, col0=0):
     if out.dim() != 2 or out.shape[0] != n or out.stride(1) != 1 or not out.is_cuda or out.dtype != torch.float32:
         raise _capi.NfxError("mlp_generic_fwd: bad output matrix")
     check(lib.nfx_mlp_generic_fwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
-                                  net._s, _ptr(net.blob), _ptr(out), out.stride(0) if n else out.shape[1], col0,
-                                  _stream()), 'nfx_mlp_generic_fwd')
+                                  net._s, _ptr(net.blob), net.prec, _ptr(out), out.stride(0) if n else out.shape[1],
+                                  col0, _stream()), 'nfx_mlp_generic_fwd')
     return out
 
 
@@ -338,13 +340,13 @@ def mlp_generic_bwd(x, net, dy, dkernels, dbiases, want_dx=False):
             if _dev(t, '%s[%d]' % (name, i), shape) is not t:
                 raise _capi.NfxError("mlp_generic_bwd: %s[%d] must be contiguous (it is accumulated into)" % (name, i))
     dx = torch.empty((n, net.d_in), dtype=torch.float32, device=x.device) if want_dx else None
-    nbytes = lib.nfx_mlp_generic_bwd_workspace_bytes(n, net.d_in, net.n_layers, net._w, net._s)
+    nbytes = lib.nfx_mlp_generic_bwd_workspace_bytes(n, net.d_in, net.n_layers, net._w, net._s, net.prec)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     karr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dkernels]) if dkernels else None
     barr = (ctypes.c_void_p * net.n_layers)(*[t.data_ptr() for t in dbiases]) if dbiases else None
     check(lib.nfx_mlp_generic_bwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
-                                  net._s, _ptr(net.blob), _ptr(dy), net.d_out, 0, _ptr(dx), net.d_in, karr, barr,
-                                  _ptr(ws), ws.numel(), _stream()), 'nfx_mlp_generic_bwd')
+                                  net._s, _ptr(net.blob), net.prec, _ptr(dy), net.d_out, 0, _ptr(dx), net.d_in, karr,
+                                  barr, _ptr(ws), ws.numel(), _stream()), 'nfx_mlp_generic_bwd')
     return dx
 
 

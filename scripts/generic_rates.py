@@ -24,7 +24,7 @@ def timed(fn, reps=5):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-def net(d_in, widths, acts, skip_at, rng):
+def net(d_in, widths, acts, skip_at, rng, prec='bf16'):
     ks, bs, prev = [], [], d_in
     for i, w in enumerate(widths):
         lim = np.sqrt(6. / (prev + w))
@@ -32,17 +32,19 @@ def net(d_in, widths, acts, skip_at, rng):
         bs.append(np.zeros(w, np.float32))
         prev = w + (d_in if skip_at and i in skip_at else 0)
     macs = sum(k.size for k in ks)
-    return ops.GenericNet(ks, bs, acts, skip_at, train=True).to(cuda), ks, bs, macs
+    return ops.GenericNet(ks, bs, acts, skip_at, train=True, prec=prec).to(cuda), ks, bs, macs
 
 
 def main():
     rng = np.random.default_rng(0)
     out = {}
-    for name, d_in, widths, acts, skip, n in (
-            ('nerf_enc_256x8', 63, [256] * 8, ['relu'] * 8, [4], 1 << 18),
-            ('surface_128x4_lvis', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 21),
-            ('narrow_64x4', 39, [64] * 4 + [4], ['relu'] * 4 + [None], [1], 1 << 20)):
-        g, ks, bs, macs = net(d_in, widths, acts, skip, rng)
+    for name, d_in, widths, acts, skip, n, prec in (
+            ('nerf_enc_256x8', 63, [256] * 8, ['relu'] * 8, [4], 1 << 18, 'bf16'),
+            ('surface_128x4_lvis', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 21, 'bf16'),
+            ('narrow_64x4', 39, [64] * 4 + [4], ['relu'] * 4 + [None], [1], 1 << 20, 'bf16'),
+            ('nerf_enc_256x8_fp32', 63, [256] * 8, ['relu'] * 8, [4], 1 << 17, 'fp32'),
+            ('surface_128x4_lvis_fp32', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 19, 'fp32')):
+        g, ks, bs, macs = net(d_in, widths, acts, skip, rng, prec)
         x = torch.randn((n, d_in), device=cuda)
         dy = torch.randn((n, widths[-1]), device=cuda)
         dks = [torch.zeros(k.shape, device=cuda) for k in ks]
@@ -53,7 +55,7 @@ def main():
         out[name] = {'rows': n, 'macs_per_row': macs, 'fwd_ms': round(f, 3), 'fwd_tflops': round(2 * macs * n / f / 1e9, 1),
                      'bwd_ms': round(b, 3), 'bwd_tflops': round(6 * macs * n / b / 1e9, 1),     # fwd recompute + dgrad + wgrad
                      'bwd_with_dx_ms': round(bx, 3),
-                     'workspace_mb': round(ops.lib.nfx_mlp_generic_bwd_workspace_bytes(n, g.d_in, g.n_layers, g._w, g._s) / 2 ** 20, 1)}
+                     'workspace_mb': round(ops.lib.nfx_mlp_generic_bwd_workspace_bytes(n, g.d_in, g.n_layers, g._w, g._s, g.prec) / 2 ** 20, 1)}
     print(json.dumps(out))
 
 

@@ -84,7 +84,7 @@ def check(tag, model, losses, grad1):
     return m
 
 
-def run_nerfactor(tag, cuda):
+def run_nerfactor(tag, cuda, precision='bf16'):
     """-> (model, losses of the 10 steps, gradients of step 1) for 'nfm' (microfacet) | 'nfl' (learned BRDF)."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
@@ -92,7 +92,7 @@ def run_nerfactor(tag, cuda):
     learned = tag == 'nfl'
     name = 'nerfactor' if learned else 'nerfactor_microfacet'
     cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='',
-                      light_tv_weight='2e-4', light_achro_weight='1e-4')
+                      light_tv_weight='2e-4', light_achro_weight='1e-4', precision=precision)
     model = get_model_class(name)(cfg)
     for part, pairs in gi.nerfactor_net(3 if learned else 1).items():
         set_net(model.net, part, pairs)
@@ -122,13 +122,13 @@ def run_nerfactor(tag, cuda):
     return model, losses, grad1
 
 
-def run_nerf(cuda):
+def run_nerf(cuda, precision='bf16'):
     """The NeRF step with the reference's tf.random.uniform draws (stratified coarse samples, inverse-CDF fine
     samples) replayed through torch.rand."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.models import get_model_class
-    cfg = make_config('nerf')
+    cfg = make_config('nerf', precision=precision)
     assert cfg.getboolean('DEFAULT', 'perturb') and cfg.getfloat('DEFAULT', 'noise_std') == 0.
     model = get_model_class('nerf')(cfg)
     for pref, net in zip(('coarse_', 'fine_'), common.nerf_nets(seed=gi.NERF_SEED)):
@@ -161,6 +161,32 @@ def run_nerf(cuda):
     finally:
         torch.rand = real_rand
     return model, losses, grad1
+
+
+# precision = fp32 (grad_precision = fp32: every network forward and backward on the fp32 runtime-shaped kernels): each
+# gradient tensor of step 1 against the REFERENCE's fp32 gradient itself, no bf16-oracle detour.  What is left is fp32
+# summation order plus the ReLU masks / inverse-CDF bins that flip under it.  'nfl': the learned BRDF inside the shading
+# kernels (nfx_brdf_spec_fwd / _bwd) keeps bf16 operands — its z and normal gradients carry that rounding.
+FP32_TOL = {'nfm': 1e-3, 'nerf': 1e-3, 'brdf': 1e-3, 'nfl': 5e-2}
+
+
+def check_fp32(tag, model, losses, grad1):
+    want_losses = np.asarray(FIX[tag + '/loss'], dtype=np.float64)
+    losses = np.asarray(losses, dtype=np.float64)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    report = {}
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            want, got = elements('%s/grad/%s' % (tag, name), grad1[name])
+            report[name] = fro(got, want)
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:4]
+    rel1, traj = abs(losses[0] / want_losses[0] - 1), float(np.max(np.abs(losses / want_losses - 1)))
+    print(tag, 'fp32: gradient rel-Frobenius vs the reference, worst:', [(n, round(v, 6)) for n, v in worst],
+          'loss step 1 rel', rel1, 'trajectory', traj)
+    assert worst[0][1] < FP32_TOL[tag], worst
+    loose = tag == 'nfl'
+    assert rel1 < (2e-3 if loose else 1e-4) and traj < (5e-3 if loose else 1e-3), (rel1, traj)
+    return report
 
 
 def run(model_name, cuda):

@@ -122,4 +122,29 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
             assert np.all(got[:, 32 * mh + d_in:] == 0)
         off += m_in * pad4(2 * nt)
     assert off == len(frags)
-    assert nfx_lib.lib.nfx_mlp_generic_bwd_workspace_bytes(1000, d_in, len(widths), net._w, net._s) > 0
+    assert nfx_lib.lib.nfx_mlp_generic_bwd_workspace_bytes(1000, d_in, len(widths), net._w, net._s, net.prec) > 0
+
+
+@pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 5], [0]), (27, [40, 200, 33], [0, 1])])
+def test_fp32_blob_has_the_same_stream_with_two_kib_fragments(nfx_lib, d_in, widths, skip_at):
+    """prec = 'fp32': [biases | forward | transposed] with fp32 fragments laid out [half][lane][4 floats] — element
+    (lane, i) is the one the bf16 blob holds at [lane][i], unrounded; same fragment order, same zero padding."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(d_in + 1)
+    ks, bs, prev = [], [], d_in
+    for i, w in enumerate(widths):
+        ks.append((rng.normal(size=(prev, w)) * 0.2).astype(np.float32))
+        bs.append((rng.normal(size=w) * 0.1).astype(np.float32))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    acts = ['relu'] * (len(widths) - 1) + [None]
+    n_bias = sum(((w + 31) // 32) * 32 for w in widths)
+    for train in (False, True):
+        b16 = ops.GenericNet(ks, bs, acts, skip_at, train=train).blob.numpy()
+        b32 = ops.GenericNet(ks, bs, acts, skip_at, train=train, prec='fp32').blob.numpy()
+        assert np.array_equal(b16[:4 * n_bias], b32[:4 * n_bias])
+        f16 = (b16[4 * n_bias:].view(np.uint16).reshape(-1, 64, 8).astype(np.uint32) << 16).view(np.float32)
+        f32 = b32[4 * n_bias:].view(np.float32).reshape(-1, 2, 64, 4).transpose(0, 2, 1, 3).reshape(-1, 64, 8)
+        assert f16.shape == f32.shape
+        assert np.array_equal(bf(f32), f16)                       # the bf16 blob is the fp32 one, rounded
+        flat = np.concatenate([k.ravel() for k in ks])
+        assert np.isin(f32[f32 != 0], flat).all()                 # and the fp32 one holds the parameters themselves

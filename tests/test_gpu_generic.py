@@ -21,7 +21,10 @@ def dev(a, cuda):
     (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 333),
     (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
     (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200)])
-def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
+@pytest.mark.parametrize("prec", ['bf16', 'fp32'])
+def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n, prec):
+    """bf16: same-rounding bound 4e-3, float64 bound 3e-2; prec = 'fp32' (fp32 operands, native fp32 matrix instruction):
+    1e-5 of the float64 network, relative to its largest output."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(sum(widths))
     layers, prev = [], d_in
@@ -30,15 +33,18 @@ def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
         prev = w + (d_in if skip_at and i in skip_at else 0)
     if skip_at and (len(widths) - 1) in skip_at:
         pytest.skip("a skip behind the last layer changes the output width")
-    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at).to(cuda)
+    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, prec=prec).to(cuda)
     x = rng.normal(size=(n, d_in)).astype(np.float32)
     got = ops.mlp_generic_fwd(dev(x, cuda), net).cpu().numpy()
     want = nerf_ref.mlp(x.astype(np.float64), [(k.astype(np.float64), b.astype(np.float64)) for k, b in layers], acts, skip_at)
     want_q = nerf_ref.mlp(x, layers, acts, skip_at, quant=nerf_ref.bf16_round)
     scale = max(1., np.abs(want).max())
     assert got.shape == (n, widths[-1])
-    assert np.abs(got - want_q).max() < 4e-3 * scale, np.abs(got - want_q).max()      # same bf16 operand rounding
-    assert np.abs(got - want).max() < 3e-2 * scale
+    if prec == 'fp32':
+        assert np.abs(got - want).max() < 1e-5 * scale, np.abs(got - want).max()
+    else:
+        assert np.abs(got - want_q).max() < 4e-3 * scale, np.abs(got - want_q).max()      # same bf16 operand rounding
+        assert np.abs(got - want).max() < 3e-2 * scale
     # writing into a column range of a wider matrix; a strided input
     wide = torch.full((n, widths[-1] + 7), -5., device=cuda)
     xs = torch.zeros((n, d_in + 3), device=cuda)
@@ -160,7 +166,7 @@ def _rel(got, want):
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
-def _oracle_grads(x, layers, acts, skip_at, dy, want_dx):
+def _oracle_grads(x, layers, acts, skip_at, dy, want_dx, quant=True):
     """d sum(y * dy) / d (kernels, biases, x) by torch.autograd over oracle/torch_train_ref.mlp in float64, operands of
     every Dense layer rounded to bf16 with a straight-through gradient (what the MFMA path computes)."""
     from oracle import torch_train_ref as T
@@ -169,13 +175,11 @@ def _oracle_grads(x, layers, acts, skip_at, dy, want_dx):
         P['net_m_layer%d.kernel' % i] = torch.tensor(k, dtype=torch.float64, requires_grad=True)
         P['net_m_layer%d.bias' % i] = torch.tensor(b, dtype=torch.float64, requires_grad=True)
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=want_dx)
-    T.QUANT = T.bf16_ste
+    T.QUANT = T.bf16_ste if quant else None
     try:
         y = T.mlp(xt, P, 'm', len(layers), acts, skip_at)
     finally:
         T.QUANT = None
-    if skip_at and (len(layers) - 1) in skip_at:
-        raise AssertionError
     (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
     n = len(layers)
     return ([P['net_m_layer%d.kernel' % i].grad.numpy() for i in range(n)],
@@ -189,22 +193,24 @@ def _oracle_grads(x, layers, acts, skip_at, dy, want_dx):
     (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
     (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200),
     (39, [128, 128, 128, 1], ['relu'] * 3 + ['sigmoid'], [1], 20000)])
-def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n):
+@pytest.mark.parametrize("prec", ['bf16', 'fp32'])
+def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n, prec):
     """nfx_mlp_generic_bwd: weight, bias and input gradients of arbitrary mlp.Network shapes against torch.autograd of
     the oracle with the same bf16 operand rounding.  Bound: 2 % of each tensor's norm — the kernels round the
     propagated gradient and the transposed weights to bf16 as well (two more 2^-9 roundings per layer), the oracle's
-    straight-through backward does not.  Bit-identical between calls; ADDS into the gradient buffers."""
+    straight-through backward does not.  prec = 'fp32': against the PLAIN float64 autograd, 2e-5 of each tensor's norm
+    (nothing is rounded to bf16; the sums are fp32).  Bit-identical between calls; ADDS into the gradient buffers."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(sum(widths) + n)
     layers, prev = [], d_in
     for i, w in enumerate(widths):
         layers.append((nerf_ref.glorot_uniform(rng, prev, w), rng.uniform(-.2, .2, size=w).astype(np.float32)))
         prev = w + (d_in if skip_at and i in skip_at else 0)
-    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, train=True).to(cuda)
+    net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, train=True, prec=prec).to(cuda)
     x = rng.normal(size=(n, d_in)).astype(np.float32)
     dy = rng.normal(size=(n, widths[-1])).astype(np.float32)
     # the train blob's head is the forward blob
-    fwd = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at).to(cuda)
+    fwd = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, prec=prec).to(cuda)
     assert torch.equal(ops.mlp_generic_fwd(dev(x, cuda), net), ops.mlp_generic_fwd(dev(x, cuda), fwd))
 
     def run(fill):
@@ -213,14 +219,16 @@ def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_
         dx = ops.mlp_generic_bwd(dev(x, cuda), net, dev(dy, cuda), dks, dbs, want_dx=True)
         return dks, dbs, dx
     dks, dbs, dx = run(0.)
-    wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True)
+    wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True, quant=prec == 'bf16')
+    # (fp32, nine layers deep: fp32 against float64 pre-activations flips a few ReLU masks at 0 — 2.3e-4 measured)
+    tol = 2e-2 if prec == 'bf16' else (2e-5 if len(widths) <= 5 else 5e-4)
     for i in range(len(layers)):
-        assert _rel(dks[i].cpu().numpy(), wk[i]) < 2e-2, ('kernel', i, _rel(dks[i].cpu().numpy(), wk[i]))
-        assert _rel(dbs[i].cpu().numpy(), wb[i]) < 2e-2, ('bias', i, _rel(dbs[i].cpu().numpy(), wb[i]))
-    assert dx.shape == (n, d_in) and _rel(dx.cpu().numpy(), wx) < 2e-2, _rel(dx.cpu().numpy(), wx)
+        assert _rel(dks[i].cpu().numpy(), wk[i]) < tol, ('kernel', i, _rel(dks[i].cpu().numpy(), wk[i]))
+        assert _rel(dbs[i].cpu().numpy(), wb[i]) < tol, ('bias', i, _rel(dbs[i].cpu().numpy(), wb[i]))
+    assert dx.shape == (n, d_in) and _rel(dx.cpu().numpy(), wx) < tol, _rel(dx.cpu().numpy(), wx)
     dks2, dbs2, dx2 = run(1.)
     for a, b in zip(dks + dbs, dks2 + dbs2):
-        assert torch.allclose(a + 1., b, rtol=0, atol=1e-6 * max(1., float(a.abs().max())))     # accumulates
+        assert torch.allclose(a + 1., b, rtol=0, atol=2e-6 * max(1., float(a.abs().max())))     # accumulates
     dks3, dbs3, dx3 = run(0.)
     for a, b in zip(dks + dbs + [dx], dks3 + dbs3 + [dx3]):
         assert torch.equal(a, b)                                                               # deterministic
