@@ -620,9 +620,33 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         from tests import reference_steps
         tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev)
         parity = reference_steps.summary(tag, reference_steps.metrics(tag, rmodel, rlosses, rgrad1))
+    fp32_block = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.precision == 'bf16':
+        # the same step at the reference's own arithmetic (precision = fp32 -> grad_precision = fp32: fp32 operands, native
+        # fp32 matrix instruction, forward and backward: csrc/mlp_generic.hip) — its time, and its gradients held to the
+        # reference's fp32 gradients directly
+        torch.manual_seed(5)
+        m32 = get_model_class(name)(make_config(name, precision='fp32', **extra)).to(dev)
+        o32 = optim.make_optimizer(m32, m32.config)
+        for _ in range(3):
+            optim.train_step(m32, batch, o32, global_bs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            optim.train_step(m32, batch, o32, global_bs)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / 10
+        m32.flush_numerics(block=True)
+        tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev, 'fp32')
+        p32 = reference_steps.metrics_fp32(tag, rmodel, rlosses, rgrad1)
+        p32.pop('grads')
+        fp32_block = {"what": "the same step with precision = fp32: every network forward and backward in fp32 "
+                              "(v_mfma_f32_32x32x2_f32, nfx_mlp_generic_fwd / _bwd)" + (
+                                  "; the learned BRDF inside the shading kernels keeps bf16 operands" if name == 'nerfactor' else ""),
+                      "ms_per_step": dt32 * 1e3, "parity": p32}
     return {
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),
-        "parity": parity,
+        "parity": parity, "fp32": fp32_block,
         "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
         "step": ("one hipGraph replay per step (optim.GraphedTrainStep, ini hip_graph = true)" if graph_dt is not None
                  else "eager optim.train_step" + (" (%s)" % graph_note if graph_note else "")),

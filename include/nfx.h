@@ -22,7 +22,9 @@
  *     forward kernels: nfx_nerf_pack_weights / nfx_nerf_mlp_fwd and nfx_mlp128_pack_weights /
  *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd, and the
  *     geometry pair nfx_nerf_pack_geom_weights / nfx_nerf_sigma_fwd / nfx_nerf_sigma_grad; the
- *     training-blob and backward entry points return NFX_ENOSUP for it.
+ *     tuned training-blob and backward entry points return NFX_ENOSUP for it.  The runtime-shaped
+ *     family (nfx_mlp_generic_*) takes NFX_PREC_FP32 as TRUE fp32 operands on the fp32 matrix
+ *     instruction, forward and backward: that is the backward at the reference's arithmetic.
  *   - re-entrant: no global mutable state besides the option table of nfx_set_option
  *     (atomic integers); concurrent calls on different streams are legal.
  */

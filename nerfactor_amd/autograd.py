@@ -6,7 +6,9 @@ import torch
 
 from . import _capi, ops
 
-# Operand type of every BACKWARD kernel (fused dgrad chains, weight-gradient GEMMs) and of the train blobs they read.
+# Operand type of every TUNED backward kernel (fused dgrad chains, weight-gradient GEMMs) and of the train blobs they read.
+# (grad_precision = fp32 — the default of precision = fp32 — does not come here: the models route every network's
+# training call through GenericMlp below on the fp32 runtime-shaped kernels, csrc/mlp_generic.hip.)
 # `precision = fp32` selects the fp32-class forward kernels (bf16 hi / lo operand pairs, three MFMAs per product); its
 # gradients are still formed by the bf16-operand backward kernels, which re-compute their own bf16 forward for the ReLU
 # masks — mixed precision in the usual sense: fp32-class values and losses, gradients with bf16 operand rounding
