@@ -372,12 +372,12 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
                 if (last) {      // dZ = dy * act'(logit); rows past n and features past the width contribute nothing
-                    const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy + 32 * t + 4 * g;
-                    float d[16];
+                    const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;      // (every index clamped INTO the row: the last
+                    float d[16];                                                //  row's pad columns lie past the buffer)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const int c = (q & 3) + 8 * (q >> 2);
-                        d[q] = dyr[32 * t + 4 * g + c < L.n_out ? c : 0];
+                        const int f = 32 * t + 4 * g + (q & 3) + 8 * (q >> 2);
+                        d[q] = dyr[f < L.n_out ? f : 0];
                     }
                     scale_by_act_grad_logit16(d, v, L.act);
 #pragma unroll

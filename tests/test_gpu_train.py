@@ -811,16 +811,18 @@ def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
 
 
 @pytest.mark.determinism
-@pytest.mark.parametrize("name,jitter,steps", [("shape", "0.01", 200), ("nerfactor_microfacet", "0.01", 200),
-                                               ("nerfactor", "0.01", 200), ("nerfactor_microfacet", "0", 12)])
-def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, steps):
+@pytest.mark.parametrize("name,jitter,steps,precision", [
+    ("shape", "0.01", 200, "bf16"), ("nerfactor_microfacet", "0.01", 200, "bf16"), ("nerfactor", "0.01", 200, "bf16"),
+    ("nerfactor_microfacet", "0", 12, "bf16"), ("nerfactor_microfacet", "0.01", 12, "fp32")])
+def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, steps, precision):
     """optim.GraphedTrainStep (the step captured in a hipGraph and replayed) against optim.train_step: the two are the
     same kernels in the same order and torch's generator hands a replay the noise the eager step would have drawn, so
     losses, parameters and optimizer state after 200 steps on changing batches — xyz jitter ON, as the shipped configs
     train — must agree bit for bit and stay finite (round 2's six-step, jitter-off form missed that its benchmark ended
     in NaN; scripts/diag_graph_diverge.py is the step-by-step version of this test).  The version counters move, so an
     eager vali call afterwards sees the trained weights; the `to_vis` a replay returns belongs to the caller (clones of
-    the graph's static outputs, `id` of the live batch)."""
+    the graph's static outputs, `id` of the live batch).  precision = fp32: the step on the fp32 runtime-shaped kernels
+    (workspaces from torch's allocator inside the capture) replays the same way."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.datasets.nerf_shape import mark_all_foreground
@@ -842,7 +844,7 @@ def test_graphed_train_step_equals_the_eager_one(nfx_lib, cuda, name, jitter, st
 
     def run(graph):
         torch.manual_seed(11)
-        cfg = make_config(name, xyz_jitter_std=jitter, **extra)
+        cfg = make_config(name, xyz_jitter_std=jitter, precision=precision, **extra)
         model = get_model_class(name)(cfg).to(cuda)
         opt = optim.make_optimizer(model, cfg)
         step = optim.GraphedTrainStep(model, opt, n, warmup=2) if graph else (lambda b: optim.train_step(model, b, opt, n))
