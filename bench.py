@@ -642,7 +642,8 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         p32.pop('grads')
         fp32_block = {"what": "the same step with precision = fp32: every network forward and backward in fp32 "
                               "(v_mfma_f32_32x32x2_f32, nfx_mlp_generic_fwd / _bwd)" + (
-                                  "; the learned BRDF inside the shading kernels keeps bf16 operands" if name == 'nerfactor' else ""),
+                                  "; the frozen learned BRDF on explicit fp32 rows (local frames and Rusinkiewicz angles "
+                                  "in fp32 torch operations) instead of inside the bf16 shading kernels" if name == 'nerfactor' else ""),
                       "ms_per_step": dt32 * 1e3, "parity": p32}
     return {
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),

@@ -199,10 +199,29 @@ class GenericMlp(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         net_fn, params = ctx.cfg
+        if not any(ctx.needs_input_grad[2:]):      # a frozen network (NeRFactor's BRDF prior): the input gradient only
+            dx = ops.mlp_generic_bwd(x, net_fn(), dy.contiguous(), None, None, want_dx=True)
+            return (dx, None) + (None,) * len(params)
         nk = len(params) // 2
         (dks, rks), (dbs, rbs) = _targets(params[:nk]), _targets(params[nk:])
         dx = ops.mlp_generic_bwd(x, net_fn(), dy.contiguous(), dks, dbs, want_dx=ctx.needs_input_grad[0])
         return (dx, None) + tuple(rks) + tuple(rbs)
+
+
+class Embed(torch.autograd.Function):
+    """embedder(x) for explicit vectors x[n, 3] (nfx_embed) with its pull-back (nfx_embed_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, n_freqs):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.n_freqs = n_freqs
+        return ops.embed(n_freqs, x=x)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        return ops.embed_bwd(ctx.n_freqs, x, d_out.contiguous()), None
 
 
 class Composite(torch.autograd.Function):

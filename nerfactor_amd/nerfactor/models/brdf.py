@@ -85,16 +85,17 @@ class Model(BaseModel):
             brdf, reci = out[:z.shape[0]], out[z.shape[0]:]
         return brdf[:, None], reci[:, None]
 
-    def _generic_net(self, train=False):
+    def _generic_net(self, train=False, prec=None):
+        prec = self.precision if prec is None else prec
         ks, bs = self.net['brdf_mlp'].kernels_and_biases()
         ko, bo = self.net['brdf_out'].kernels_and_biases()
         body = self.net['brdf_mlp']
         acts = [l.activation for l in body.layers] + ['softplus']
-        tag = ('brdf_generic_train' if train else 'brdf_generic') + self.precision
+        tag = ('brdf_generic_train' if train else 'brdf_generic') + prec
         descs = self.__dict__.setdefault('_generic_desc', {})
 
         def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=self.precision)
+            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=prec)
             descs.setdefault(tag, g)
             return g.blob
         blob = self._packed(tag, ks + ko + bs + bo, pack)

@@ -354,6 +354,12 @@ class Model(ShapeModel):
         """Differentiable render under the trained light: frozen learned BRDF (gradients reach the
         latent z and the normal through nfx_brdf_spec_bwd) + the shading integral."""
         from nerfactor_amd import autograd as nfx_grad
+        lxyz = self.lxyz.reshape(-1, 3)
+        if self.grad_precision == 'fp32':
+            spec = self._brdf_spec_fp32(xyz, cam, normal, brdf_prop)
+            return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,
+                                            self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
+                                            albedo, spec, light_vis, light)
         nets = self.brdf_model.net
         fwd_blob = self._blob128('brdf_mlp', 'brdf_out', _capi.IN_Z_RUSINK, 1, z_dim=self.z_dim, nets=nets)
 
@@ -368,6 +374,33 @@ class Model(ShapeModel):
         return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,
                                         self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
                                         albedo, spec, light_vis, light)
+
+    def _brdf_spec_fp32(self, xyz, cam, normal, brdf_prop):
+        """spec[N, L] of the frozen prior at grad_precision = fp32 (nerfactor.py:413-461): the fused bf16 kernels
+        (nfx_brdf_spec_fwd / _bwd) have no fp32 instantiation, so the rows are assembled explicitly — local frames and
+        Rusinkiewicz angles in differentiable fp32 torch operations with the reference's custom gradients
+        (util/geom.py), the embedding and the prior's MLP on the fp32 runtime-shaped kernels (input gradients only: the
+        prior is frozen).  Gradients reach the normal (through the local frame) and the BRDF code z."""
+        from nerfactor_amd import autograd as nfx_grad
+        from ..util import geom as geomutil
+        lxyz = self.lxyz.reshape(-1, 3)
+        n, nl = xyz.shape[0], lxyz.shape[0]
+        pts2l = mathutil.safe_l2_normalize(lxyz[None, :, :] - xyz[:, None, :], axis=2)
+        pts2c = mathutil.safe_l2_normalize(cam - xyz, axis=1)
+        rot = geomutil.gen_world2local(normal)
+        vdir = torch.einsum('jkl,jl->jk', rot, pts2c)
+        ldir = torch.einsum('jkl,jnl->jnk', rot, pts2l).reshape(-1, 3)
+        front = torch.nonzero(ldir[:, 2] > 0)[:, 0]
+        vrep = vdir[:, None, :].expand(n, nl, 3).reshape(-1, 3)
+        rusink = geomutil.dir2rusink_autograd(ldir[front], vrep[front])
+        z = brdf_prop[:, None, :].expand(n, nl, brdf_prop.shape[1]).reshape(-1, brdf_prop.shape[1])[front]
+        prior = self.brdf_model
+        rows = torch.cat((z, nfx_grad.Embed.apply(rusink, prior.embedder['rusink'].n_freqs)), 1)
+        ks, bs = prior.net['brdf_mlp'].kernels_and_biases()
+        ko, bo = prior.net['brdf_out'].kernels_and_biases()
+        y = nfx_grad.GenericMlp.apply(rows, lambda: prior._generic_net(train=True, prec='fp32'), *(ks + ko + bs + bo))
+        spec = torch.zeros(n * nl, dtype=torch.float32, device=xyz.device).index_put((front,), y[:, 0])
+        return spec.reshape(n, nl)
 
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):

@@ -4,7 +4,9 @@ import torch
 
 from nerfactor_amd import ops
 
-from .math import safe_l2_normalize
+import math
+
+from .math import safe_acos, safe_atan2, safe_l2_normalize
 
 
 def gen_world2local(normal, eps=1e-6):
@@ -20,3 +22,24 @@ def dir2rusink(a, b):
     """(phi_d, theta_h, theta_d) of direction pairs a (light), b (view), both [N,3] in the local
     frame — evaluated by libnfx (nfx_dir2rusink)."""
     return ops.dir2rusink(a, b)
+
+
+def _rot_vec(v, axis, ang):
+    """Rodrigues rotation of the rows of v about the unit `axis` (a 3-tuple) by the angles `ang`."""
+    ax = v.new_tensor(axis).reshape(1, 3)
+    c, s = torch.cos(ang)[:, None], torch.sin(ang)[:, None]
+    return v * c + ax * (v @ ax.t()) * (1. - c) + torch.cross(ax.expand_as(v), v, dim=1) * s
+
+
+def dir2rusink_autograd(a, b):
+    """dir2rusink in differentiable torch operations with the reference's custom gradients (safe_acos / safe_atan2) —
+    what a training call at grad_precision = fp32 differentiates; the fused kernels carry the same formulas."""
+    a = safe_l2_normalize(a, axis=1)
+    b = safe_l2_normalize(b, axis=1)
+    h = safe_l2_normalize((a + b) / 2, axis=1)
+    theta_h = safe_acos(h[:, 2])
+    phi_h = safe_atan2(h[:, 1], h[:, 0])
+    diff = _rot_vec(_rot_vec(b, (0., 0., 1.), -phi_h), (0., 1., 0.), -theta_h)
+    theta_d = safe_acos(diff[:, 2])
+    phi_d = torch.remainder(safe_atan2(diff[:, 1], diff[:, 0]), math.pi)
+    return torch.stack((phi_d, theta_h, theta_d), 1)

@@ -165,9 +165,11 @@ def run_nerf(cuda, precision='bf16'):
 
 # precision = fp32 (grad_precision = fp32: every network forward and backward on the fp32 runtime-shaped kernels): each
 # gradient tensor of step 1 against the REFERENCE's fp32 gradient itself, no bf16-oracle detour.  What is left is fp32
-# summation order plus the ReLU masks / inverse-CDF bins that flip under it.  'nfl': the learned BRDF inside the shading
-# kernels (nfx_brdf_spec_fwd / _bwd) keeps bf16 operands — its z and normal gradients carry that rounding.
-FP32_TOL = {'nfm': 1e-3, 'nerf': 1e-3, 'brdf': 1e-3, 'nfl': 5e-2}
+# summation order plus the ReLU masks / inverse-CDF bins that flip under it.  'nfl': the frozen learned BRDF is evaluated
+# on explicit fp32 rows there (models/nerfactor.py:_brdf_spec_fp32) instead of inside the bf16 shading kernels; its
+# 10-step trajectory is the loosest of the four (1.7e-3: AMSGrad normalises every element's gradient, so elements whose
+# gradient sits at the optimizer's epsilon move by up to lr whichever way their last bit falls).
+FP32_TOL = {'nfm': 1e-3, 'nerf': 1e-3, 'brdf': 1e-3, 'nfl': 1e-3}
 
 
 def metrics_fp32(tag, model, losses, grad1):
