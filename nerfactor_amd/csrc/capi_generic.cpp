@@ -96,7 +96,10 @@ int nfx_mlp_generic_pack(const float* const* kernels, const float* const* biases
         (void)n_in;
         for (int tl = 0; tl < L.n_tiles; ++tl)
             for (int s = 0; s < L.ks_h + L.ks_x; ++s) {
-                char* frag = w + ((size_t)L.w_off + (size_t)tl * L.ks_pad + s) * fb;
+                // stream order of a layer: k-GROUP outer, output tile inner (the kernel reads a group's B operand once
+                // and sweeps the tiles' accumulators): group (s / kGroup) of tile tl, step s % kGroup
+                const int kg = s / nfx::generic::kGroup, j4 = s % nfx::generic::kGroup;
+                char* frag = w + ((size_t)L.w_off + ((size_t)kg * L.n_tiles + tl) * nfx::generic::kGroup + j4) * fb;
                 const bool from_x = s >= L.ks_h;
                 const int base = from_x ? prev : 0, feat0 = 16 * (from_x ? s - L.ks_h : s), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -226,10 +229,17 @@ int nfx_mlp_generic_pack_train(const float* const* kernels, const float* const* 
         const nfx::generic::Layer& L = p.layer[i];
         const int prev = i ? widths[i - 1] : 0, mh = i ? p.layer[i - 1].n_tiles : 0, m_in = mh + (L.ks_x ? mx : 0), ks_o = 2 * L.n_tiles;
         const int ks_o_pad = nfx::generic::pad_group(ks_o);
+        // a layer's transposed fragments: the input-gradient tiles FIRST (tile-major: they read dZ before the hidden
+        // tiles overwrite it in place), then the hidden tiles k-group outer / tile inner like the forward
+        const int nx = m_in - mh, kgo = ks_o_pad / nfx::generic::kGroup;
+        (void)kgo;
         for (int mt = 0; mt < m_in; ++mt)
             for (int s = 0; s < ks_o; ++s) {
-                char* frag = wt + ((size_t)p.b[i].wt_off + (size_t)mt * ks_o_pad + s) * fb;
                 const bool from_x = mt >= mh;
+                const int kg = s / nfx::generic::kGroup, j4 = s % nfx::generic::kGroup;
+                const size_t idx = from_x ? (size_t)(mt - mh) * ks_o_pad + s
+                                          : (size_t)nx * ks_o_pad + ((size_t)kg * mh + mt) * nfx::generic::kGroup + j4;
+                char* frag = wt + ((size_t)p.b[i].wt_off + idx) * fb;
                 const int base = from_x ? prev : 0, feat0 = 32 * (from_x ? mt - mh : mt), limit = from_x ? d_in : prev;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int f = feat0 + (lane & 31), g = lane >> 5;       // A row = input feature, k = output feature

@@ -7,9 +7,10 @@
 // their arithmetic class: bf16 operands, fp32 accumulation and bias, one v_mfma_f32_32x32x16_bf16 per
 // (32 outputs x 32 rows x 16 inputs), transposed formulation H^T = W^T X^T (mlp_engine.hpp):
 //   * one wave = 32 rows, no workgroup-level synchronisation at all (waves are independent);
-//   * activations live in the wave's own LDS area (sized from the network's real widths) as ROW-MAJOR bf16 — the network input (kept for the skip
-//     concatenations) and two ping-pong hidden buffers — so the B operand of any layer is a plain ds_read_b128 of the
-//     lane's row, whatever the width, and a layer's output tile goes back with four 8-byte stores per lane;
+//   * activations live in the wave's own LDS area (sized from the network's real widths) as ROW-MAJOR bf16 — the network
+//     input (kept for the skip concatenations) and ONE hidden buffer: a layer accumulates ALL its output tiles in
+//     registers (k-group outer, tile inner: the B operand of a group — a plain ds_read_b128 of the lane's row — is read
+//     once for all tiles) and only then overwrites its input with its output, four 8-byte stores per lane and tile;
 //   * weights are packed on the host in LOGICAL feature order (no permutation is needed: the operand comes from LDS,
 //     not from the previous tile's accumulators) as 1-KiB A fragments, ONE stream in consumption order that each wave
 //     pulls through its own LDS ring with the DMA path, three groups of four fragments ahead of its MFMAs;
@@ -39,9 +40,9 @@ namespace nfx {
 namespace generic {
 
 // One wave per workgroup (waves are independent: no barrier anywhere).  LDS of a wave: the weight ring, then 32 rows x
-// (x_pitch + 2 h_pitch) bytes of activations, the pitches sized by the HOST from the network's real widths
-// (Args::x_pitch / h_pitch: features x element size + 16, rows 4 banks apart) — bf16: a 256-wide network keeps 3 waves
-// per CU resident, a 128-wide one 5, a 64-wide one 6.
+// (x_pitch + h_pitch) bytes — the network input and ONE hidden buffer that every layer updates in place — the pitches
+// sized by the HOST from the network's real widths (Args::x_pitch / h_pitch: features x element size + 16, rows 4 banks
+// apart) — bf16: a 256-wide network keeps 4 waves per CU resident (33.5 KiB each), fp32: 2 (66 KiB).
 // LDS is addressed through address_space(3) pointers THROUGHOUT: a generic pointer that the compiler cannot trace back to
 // the shared array (a select between two buffers is enough) becomes a flat load, which waits on vmcnt — i.e. on the
 // weight ring's look-ahead — before every MFMA.
@@ -65,8 +66,8 @@ struct P {
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
     static constexpr int kWsFeat = 32 * kElem;                // workspace bytes per (feature, row tile)
 };
-static_assert(P<false>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + 2 * (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
-static_assert(P<true>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + 2 * (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<false>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<true>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
 static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8 | 16) = (kRingGroups - 1) groups of pieces in flight");
 
 // The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
@@ -146,6 +147,101 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<F32>& w, int kg_h, i
     }
     return acc;
 }
+// A whole layer, k-group OUTER and output tile INNER: the four B operands of a group are read from LDS once and swept
+// over the NT tiles' accumulators (the stream holds a layer's fragments in exactly this order), so a hidden layer costs
+// 1 + 1/NT LDS reads per MFMA instead of 2 — and because every output tile is complete before any is written, the layer's
+// output can overwrite its input IN PLACE: one hidden buffer per wave instead of two.
+// `tile_done(t, acc)` is called once per output tile after the last k-group (the accumulators never leave this function:
+// handed out by reference they end up in scratch memory).
+template <bool F32, int NT, bool ROLLED, class TileDone>
+__device__ __forceinline__ void layer_mma(Ring<F32>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc, TileDone tile_done) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    for (int gi = 0; gi < kg_h + kg_x; ++gi) {
+        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<F32>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<F32>::kStep);
+        if constexpr (!F32) {
+            bf16x8 bf[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w.wait_oldest();
+                const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
+                bf16x8 af[kGroup];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 1024);
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc[t], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every read of the slot has returned: refill it)
+                w.issue();
+            }
+        } else {
+            f32x4 b0[kGroup], b1[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                b0[j] = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64);
+                b1[j] = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64 + 16);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w.wait_oldest();
+                const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                    const f32x4 a0 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048), a1 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048 + 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j][i], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j][i], acc[t], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                w.issue();
+            }
+        }
+    }
+    if constexpr (!ROLLED) {      // forward kernel: the epilogues unrolled (measured faster there: 378 vs 365 TFLOP/s on 256 x 8)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" ::: "memory");     // (one tile's epilogue at a time: hoisted together, eight tiles' bias loads spill)
+            tile_done(t, acc[t]);
+        }
+    } else {
+        // backward kernel: ONE copy of the epilogue code, looped over the tiles (unrolled it is ~25 K instructions per row
+        // tile of a 256 x 8 backward, and the instruction cache, not the matrix pipe, sets the pace: 4.5 ms against
+        // 2.8); the tile's accumulator is picked by a wave-uniform branch, 16 register moves
+#pragma nounroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 c;
+#define NFX_PICK(K)                        \
+    if constexpr (NT > K) {                \
+        if (t == K) {                      \
+            c = acc[K];                    \
+            asm volatile("" : "+v"(c));    \
+        }                                  \
+    }
+            NFX_PICK(0) NFX_PICK(1) NFX_PICK(2) NFX_PICK(3) NFX_PICK(4) NFX_PICK(5) NFX_PICK(6) NFX_PICK(7)
+#undef NFX_PICK
+            tile_done(t, c);
+        }
+    }
+}
+// (1 <= n <= kMaxHidden / 32 output tiles: one instantiation each, chosen by a wave-uniform branch)
+#define NFX_FOR_TILE_COUNT(n, CALL) \
+    switch (n) {                     \
+        case 1: CALL(1); break;      \
+        case 2: CALL(2); break;      \
+        case 3: CALL(3); break;      \
+        case 4: CALL(4); break;      \
+        case 5: CALL(5); break;      \
+        case 6: CALL(6); break;      \
+        case 7: CALL(7); break;      \
+        default: CALL(8); break;     \
+    }
+static_assert(kMaxHidden == 256, "NFX_FOR_TILE_COUNT covers 1 .. 8 tiles");
+
 // the wave's activation area starts as zeros: every feature a pad k-step can touch is a finite number
 __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
     for (int o = lane * 16; o < bytes; o += 64 * 16) *reinterpret_cast<lds_f32x4*>(p + o) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -224,6 +320,38 @@ __device__ __forceinline__ void store_row16(lds_char* row_tile, int g, const flo
     }
 }
 
+// forward of one layer with NT output tiles; `hrow` = the lane's row of THE hidden buffer: read (k-steps over the previous
+// layer's output) and, once all tiles are accumulated, overwritten with this layer's output
+template <bool F32, int NT>
+__device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<F32>& w, lds_char* hrow, const lds_char* xrow,
+                                              int g, float* yrow) {
+    layer_mma<F32, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<F32>::kStep / 2), xrow + g * (P<F32>::kStep / 2),
+                              [&](int t, const f32x16& acc) {
+        // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
+        float bias[16], v[16];
+        load_bias(a.biases + L.b_off + 32 * t, g, bias);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
+        activate16(v, L.act);
+        if (last) {
+            if (yrow) {
+                float* dst = yrow + 32 * t + 4 * g;
+                if (32 * t + 32 <= L.n_out) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dst[(q & 3) + 8 * (q >> 2)] = v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (32 * t + (q & 3) + 8 * (q >> 2) + 4 * g < L.n_out) dst[(q & 3) + 8 * (q >> 2)] = v[q];
+                }
+            }
+        } else {
+            zero_pad16(v, t, g, L.n_out);
+            store_row16<F32>(hrow + P<F32>::kTile * t, g, v);
+        }
+    });
+}
+
 template <bool F32>
 __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,54 +359,24 @@ __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
     lds_char* xb = ring + P<F32>::kRingBytes;           // [32][x_pitch]  network input
-    lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
+    lds_char* hb = xb + 32 * x_pitch;                   // [32][h_pitch]  THE hidden buffer (updated in place)
     const long long n_tiles_rows = (a.n + 31) / 32;
     Ring<F32> w;
     w.start(ring, a.weights, a.n_frags, lane);
-    zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
+    zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
     for (long long rt = blockIdx.x; rt < n_tiles_rows; rt += gridDim.x) {
         const long long row0 = rt * 32;
         {
             const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
             load_x<F32>(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
         }
-        int cur = 0;
+        float* yrow = row0 + p < a.n ? a.y + (row0 + p) * a.ld_y + a.col0 : nullptr;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-            const lds_char* hsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);   // this lane's row, its 8 of every 16 features
-            const lds_char* xsrc = xb + p * x_pitch + g * (P<F32>::kStep / 2);
-            lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
-            for (int t = 0; t < L.n_tiles; ++t) {
-                float bias[16];
-                load_bias(a.biases + L.b_off + 32 * t, g, bias);
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma<F32>(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
-                // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
-                float v[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
-                activate16(v, L.act);
-                if (last) {
-                    if (row0 + p < a.n) {
-                        float* dst = a.y + (row0 + p) * a.ld_y + a.col0 + 32 * t + 4 * g;
-                        if (32 * t + 32 <= L.n_out) {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) dst[(q & 3) + 8 * (q >> 2)] = v[q];
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q)
-                                if (32 * t + (q & 3) + 8 * (q >> 2) + 4 * g < L.n_out) dst[(q & 3) + 8 * (q >> 2)] = v[q];
-                        }
-                    }
-                } else {
-                    zero_pad16(v, t, g, L.n_out);
-                    store_row16<F32>(hdst + P<F32>::kTile * t, g, v);
-                }
-            }
-            cur ^= 1;
+#define NFX_FWD(NT) forward_layer<F32, NT>(a, L, last, w, hb + p * h_pitch, xb + p * x_pitch, g, yrow)
+            NFX_FOR_TILE_COUNT(L.n_tiles, NFX_FWD)
+#undef NFX_FWD
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead must not outlive the wave's LDS
@@ -333,6 +431,63 @@ __device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int 
     for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * 32] = v[q];
 }
 
+// the backward kernel's forward of one layer: as forward_layer, plus the workspace copies (fp32: straight from the
+// registers) and, for the output layer, dZ = dy * act'(logit) in place of the activation
+template <bool F32, int NT>
+__device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<F32>& w, lds_char* hrow, const lds_char* xrow, int g, int p,
+                                                bool live, const float* dyr, char* wst) {
+    const Args& a = ba.f;
+    const Layer L = a.layer[l];
+    const bool last = l == a.n_layers - 1;
+    layer_mma<F32, NT, true>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<F32>::kStep / 2), xrow + g * (P<F32>::kStep / 2),
+                             [&](int t, const f32x16& acc) {
+        float bias[16], v[16];
+        load_bias(a.biases + L.b_off + 32 * t, g, bias);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
+        if (last) {      // dZ = dy * act'(logit); rows past n and features past the width contribute nothing
+            float d[16];                     // (every index clamped INTO the row: the last row's pad columns lie past the buffer)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int f = 32 * t + 4 * g + (q & 3) + 8 * (q >> 2);
+                d[q] = dyr[f < L.n_out ? f : 0];
+            }
+            scale_by_act_grad_logit16(d, v, L.act);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = live ? d[q] : 0.f;
+        } else {
+            activate16(v, L.act);
+        }
+        zero_pad16(v, t, g, L.n_out);
+        store_row16<F32>(hrow + P<F32>::kTile * t, g, v);
+        if constexpr (F32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
+    });
+}
+// dZ_{l-1} = (dZ_l W_l^T over the previous layer's NT output tiles) * act'(H_{l-1}), written over dZ_l in place
+template <bool F32, int NT>
+__device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<F32>& w, lds_char* hrow, int g, int p, char* wst) {
+    const Args& a = ba.f;
+    const int kg_o = pad_group(2 * a.layer[l].n_tiles) / kGroup;
+    layer_mma<F32, NT, true>(w, kg_o, 0, hrow + g * (P<F32>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
+        // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
+        float d[16], y[16];
+        if constexpr (F32) {
+            const float* hy = reinterpret_cast<const float*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[q] = hy[((q & 3) + 8 * (q >> 2)) * 32];
+        } else {
+            const __bf16* hy = reinterpret_cast<const __bf16*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[q] = (float)hy[((q & 3) + 8 * (q >> 2)) * 32];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = acc[q];
+        scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
+        store_row16<F32>(hrow + P<F32>::kTile * mt, g, d);
+        if constexpr (F32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
+    });
+}
+
 template <bool F32>
 __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -341,11 +496,12 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
     lds_char* xb = ring + P<F32>::kRingBytes;
-    lds_char* hb[2] = {xb + 32 * x_pitch, xb + 32 * x_pitch + 32 * h_pitch};
+    lds_char* hb = xb + 32 * x_pitch;                   // THE hidden buffer: activations forward, gradients backward
+    lds_char* hrow = hb + p * h_pitch;
     const int fx = (a.d_in + 31) / 32 * 32, mx = fx / 32;
     Ring<F32> w;
     w.start(ring, a.weights, ba.stream_frags, lane);   // forward fragments, then the transposed ones, as one stream
-    zero_lds(xb, 32 * (x_pitch + 2 * h_pitch), lane);
+    zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
     for (long long rt = blockIdx.x; rt < ba.tiles; rt += gridDim.x) {
         const long long row0 = rt * 32;
         const bool live = row0 + p < a.n;
@@ -354,78 +510,26 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
         load_x<F32>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
         if constexpr (!F32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
-        int cur = 0;
+        const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
         for (int l = 0; l < a.n_layers; ++l) {
-            const Layer L = a.layer[l];
-            const bool last = l == a.n_layers - 1;
-            const lds_char* hsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);
-            const lds_char* xsrc = xb + p * x_pitch + g * (P<F32>::kStep / 2);
-            lds_char* hdst = hb[cur ^ 1] + p * h_pitch;
-            for (int t = 0; t < L.n_tiles; ++t) {
-                float bias[16];
-                load_bias(a.biases + L.b_off + 32 * t, g, bias);
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma<F32>(acc, w, L.ks_h / kGroup, L.ks_x / kGroup, hsrc, xsrc);
-                float v[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = acc[q] + bias[q];
-                if (last) {      // dZ = dy * act'(logit); rows past n and features past the width contribute nothing
-                    const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;      // (every index clamped INTO the row: the last
-                    float d[16];                                                //  row's pad columns lie past the buffer)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int f = 32 * t + 4 * g + (q & 3) + 8 * (q >> 2);
-                        d[q] = dyr[f < L.n_out ? f : 0];
-                    }
-                    scale_by_act_grad_logit16(d, v, L.act);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = live ? d[q] : 0.f;
-                } else {
-                    activate16(v, L.act);
-                }
-                zero_pad16(v, t, g, L.n_out);
-                store_row16<F32>(hdst + P<F32>::kTile * t, g, v);
-                if constexpr (F32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
-            }
+#define NFX_RECOMPUTE(NT) recompute_layer<F32, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
+            NFX_FOR_TILE_COUNT(a.layer[l].n_tiles, NFX_RECOMPUTE)
+#undef NFX_RECOMPUTE
             if constexpr (!F32) {
-                if (!last) store_blocked(hb[cur ^ 1], h_pitch, L.n_tiles * 32, wst, ba.b[l].h_row, lane);
+                if (l + 1 < a.n_layers) store_blocked(hb, h_pitch, a.layer[l].n_tiles * 32, wst, ba.b[l].h_row, lane);
             }
-            cur ^= 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stored activations are read back below (same wave, own lines)
-        // ---- backward: hb[cur] holds dZ of layer l.  The transposed fragments follow the forward ones in the stream, last
-        // layer first; the tiles that produce dLoss/d(network input) are always computed (the stream does not skip) and
-        // stored only when dx is wanted — except layer 0's, which end the stream and are cut off it by the host.
+        // ---- backward: the hidden buffer holds dZ of layer l.  The transposed fragments follow the forward ones in the
+        // stream, last layer first, per layer the input-gradient tiles (tile-major) then the hidden tiles (k-group outer);
+        // the input-gradient tiles are always computed (the stream does not skip) and stored only when dx is wanted —
+        // except layer 0's, which end the stream and are cut off it by the host.
         bool dx_written = false;
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const Layer L = a.layer[l];
-            if constexpr (!F32) store_blocked(hb[cur], h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
-            const int kg_o = pad_group(2 * L.n_tiles) / kGroup, mh = l > 0 ? a.layer[l - 1].n_tiles : 0;
-            const lds_char* zsrc = hb[cur] + p * h_pitch + g * (P<F32>::kStep / 2);
-            for (int mt = 0; mt < mh; ++mt) {
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = tile_mma<F32>(acc, w, kg_o, 0, zsrc, zsrc);
-                // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
-                float d[16], y[16];
-                if constexpr (F32) {
-                    const float* hy = reinterpret_cast<const float*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) y[q] = hy[((q & 3) + 8 * (q >> 2)) * 32];
-                } else {
-                    const __bf16* hy = reinterpret_cast<const __bf16*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) y[q] = (float)hy[((q & 3) + 8 * (q >> 2)) * 32];
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) d[q] = acc[q];
-                scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
-                store_row16<F32>(hb[cur ^ 1] + p * h_pitch + P<F32>::kTile * mt, g, d);
-                if constexpr (F32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
-            }
+            if constexpr (!F32) store_blocked(hb, h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
+            const int kg_o = pad_group(2 * L.n_tiles) / kGroup;
+            const lds_char* zsrc = hrow + g * (P<F32>::kStep / 2);
             if (L.ks_x > 0 && (ba.dx || l > 0)) {
                 for (int mt = 0; mt < mx; ++mt) {
                     f32x16 acc;
@@ -443,7 +547,11 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                 }
                 dx_written = true;
             }
-            cur ^= 1;
+            if (l > 0) {
+#define NFX_DGRAD(NT) dgrad_layer<F32, NT>(ba, l, w, hrow, g, p, wst)
+                NFX_FOR_TILE_COUNT(a.layer[l - 1].n_tiles, NFX_DGRAD)
+#undef NFX_DGRAD
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -637,7 +745,7 @@ int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipSt
     const long long tiles = (args->n + 31) / 32;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     const bool f32 = args->f32 != 0;
-    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (args->x_pitch + 2 * args->h_pitch);
+    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (args->x_pitch + args->h_pitch);
     const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -650,7 +758,7 @@ int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::gener
     if (ba->f.n <= 0) return 0;
     const int grid = (int)(ba->tiles < max_blocks ? ba->tiles : max_blocks);
     const bool f32 = ba->f.f32 != 0;
-    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (ba->f.x_pitch + 2 * ba->f.h_pitch);
+    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (ba->f.x_pitch + ba->f.h_pitch);
     const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_bwd_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_bwd_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;

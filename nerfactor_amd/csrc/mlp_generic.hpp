@@ -6,8 +6,10 @@ namespace generic {
 
 constexpr int kMaxLayers = 16, kMaxIn = 320, kMaxHidden = 256;   // kMaxIn: concat(256 features, embedded view) = 283
 // A wave pulls the network's fragments through its LDS ring kGroup at a time as ONE stream (mlp_generic.hip: Ring): both
-// operand sources of every tile are padded to whole groups with zero fragments, tiles and layers follow each other
-// without gaps, the transposed (backward) fragments follow the forward ones, last layer first.
+// operand sources of every tile are padded to whole groups with zero fragments; within a layer the groups run k-group
+// outer, output tile inner (the kernel reads a group's B operand once for all tiles); layers follow each other without
+// gaps, the transposed (backward) fragments follow the forward ones, last layer first, per layer the input-gradient tiles
+// (tile-major) before the hidden tiles.
 constexpr int kGroup = 4;
 constexpr int pad_group(int ks) { return (ks + kGroup - 1) / kGroup * kGroup; }
 
@@ -19,7 +21,7 @@ struct Layer {
     int n_tiles;   // 32-wide output tiles
     int n_out;     // true output width
     int act;       // NFX_ACT_*
-    int w_off;     // first fragment (1 KiB units) of this layer in the blob
+    int w_off;     // first fragment of this layer in the blob: fragment ((kg n_tiles + tile) kGroup + j) = k-step 4 kg + j of tile
     int b_off;     // first bias float (32 per tile)
 };
 struct Args {
@@ -59,8 +61,9 @@ struct EmbedArgs {
 // pairs over the rows (the bias gradients ride along as a product with a fragment of ones), a third reduces its row
 // splits in a fixed order.
 struct BwdLayer {
-    int wt_off;    // first TRANSPOSED fragment of this layer (1 KiB units): M tiles over the previous layer's outputs, then
-                   // over the network input, each pad_group(2 n_tiles) k-steps over this layer's outputs
+    int wt_off;    // first TRANSPOSED fragment of this layer: the M tiles over the network input first (tile-major,
+                   // pad_group(2 n_tiles) k-steps over this layer's outputs each), then those over the previous layer's
+                   // outputs (k-group outer, tile inner)
     int h_row;     // feature row (F units) of this layer's OUTPUT activations in the workspace (hidden layers only)
     int dz_row;    // feature row of this layer's output gradient
     int dw_off;    // float offset of this layer's kernel gradient in a partial slice ...

@@ -34,7 +34,7 @@ def emulate(net, x, widths, d_in):
         for t in range(nt):
             acc = np.tile(bias[b_off + 32 * t:b_off + 32 * t + 32], (x.shape[0], 1)).astype(np.float32)
             for s in range(ks_h + ks_x):
-                fr = frags[w_off + t * (ks_h + ks_x) + s]
+                fr = frags[w_off + ((s // 4) * nt + t) * 4 + s % 4]       # a layer's stream: k-group outer, tile inner
                 src, s0 = (hp, s) if s < ks_h else (xp, s - ks_h)
                 for g in range(2):   # lane = m + 32 g holds W[16 s + 8 g + j][32 t + m]
                     acc += src[:, 16 * s0 + 8 * g:16 * s0 + 8 * g + 8] @ fr[32 * g:32 * g + 32].T
@@ -109,9 +109,12 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
         dz = bf(rng.normal(size=(5, w)))
         dzp = np.pad(dz, ((0, 0), (0, nt * 32 - w)))
         got = np.zeros((5, m_in * 32), np.float32)
+        nx = m_in - mh
         for mt in range(m_in):
             for s in range(2 * nt):
-                fr = frags[off + mt * pad4(2 * nt) + s]
+                # input-gradient tiles first (tile-major), then the hidden tiles k-group outer / tile inner
+                idx = (mt - mh) * pad4(2 * nt) + s if mt >= mh else nx * pad4(2 * nt) + ((s // 4) * mh + mt) * 4 + s % 4
+                fr = frags[off + idx]
                 for g in range(2):
                     got[:, 32 * mt:32 * mt + 32] += dzp[:, 16 * s + 8 * g:16 * s + 8 * g + 8] @ fr[32 * g:32 * g + 32].T
         want = dz @ bf(ks[i]).T                                   # [5, n_in]: previous outputs, then the network input
