@@ -151,3 +151,39 @@ def test_fp32_blob_has_the_same_stream_with_two_kib_fragments(nfx_lib, d_in, wid
         assert np.array_equal(bf(f32), f16)                       # the bf16 blob is the fp32 one, rounded
         flat = np.concatenate([k.ravel() for k in ks])
         assert np.isin(f32[f32 != 0], flat).all()                 # and the fp32 one holds the parameters themselves
+
+
+@pytest.mark.parametrize("prec,train", [('bf16', False), ('bf16', True), ('fp32', True)])
+def test_generic_blobs_are_gathers_the_device_repacks(nfx_lib, prec, train):
+    """A training step never re-packs on the host: ops.DevicePacker derives an index map from the host packer and the
+    device gathers (nfx_pack_gather).  That needs the blob to be a pure gather of the parameters — bf16 halves or fp32
+    words; unlike the hi / lo blobs of the tuned fp32-class kernels, the fp32 runtime-shaped blob is one.  Here the map
+    is applied with NumPy: it must reproduce the host packer on fresh random parameters."""
+    from nerfactor_amd import ops
+    d_in, widths, skip_at = 27, [40, 72, 5], [0]
+    acts = ['relu', 'relu', None]
+    shapes_k, prev = [], d_in
+    for i, w in enumerate(widths):
+        shapes_k.append((prev, w))
+        prev = w + (d_in if i in skip_at else 0)
+    shapes_b = [(w,) for w in widths]
+    pack_fn = lambda k, b: ops.GenericNet(k, b, acts, skip_at, train=train, prec=prec).blob
+    packer = ops.DevicePacker(pack_fn, shapes_k, shapes_b)
+    rng = np.random.default_rng(3)
+    ks = [rng.normal(size=s).astype(np.float32) for s in shapes_k]
+    bs = [rng.normal(size=s).astype(np.float32) for s in shapes_b]
+    want = pack_fn(ks, bs).numpy().view(np.uint32)
+    src = np.concatenate([a.ravel() for a in ks + bs])
+    m = packer.map_host
+    got = np.zeros(packer.n_words, np.uint32)
+    f32 = m[:, 1] == -2                                           # an fp32 word: source index in column 0 (-1 = padding)
+    idx = m[f32, 0]
+    got[f32] = np.where(idx >= 0, src[np.maximum(idx, 0)].view(np.uint32), 0)
+    def half(col):                                                # a bf16 half (round to nearest even), -1 = padding
+        i = m[~f32, col]
+        return np.where(i >= 0, (torch.from_numpy(src[np.maximum(i, 0)]).to(torch.bfloat16).view(torch.int16).numpy()
+                                 .astype(np.uint32) & 0xffff), 0)
+    got[~f32] = half(0) | (half(1) << 16)
+    assert np.array_equal(got, want)
+    if prec == 'fp32':                                            # fp32 blob: every word a whole parameter, or padding
+        assert (m[~f32] == -1).all()
