@@ -281,8 +281,8 @@ class Model(BaseModel):
         """(sigma_raw[N,S], normal[N,S,3] | None) of a non-shipped shape on the runtime-shaped kernels, `mlp_chunk` points at
         a time: the density through enc -> sigma_out (or column 3 of rgbs_out); the normal -l2_normalize(d relu(sigma)/dx)
         (geometry_from_nerf.py:288-297) by the input-gradient mode of nfx_mlp_generic_bwd through both networks and
-        nfx_embed_bwd through the positional encoding — bf16 operands (the fp32-class density-gradient kernel exists
-        for the shipped shape only)."""
+        nfx_embed_bwd through the positional encoding — operands = `precision` (bf16, or the kernels' fp32 instantiation;
+        the hi / lo density-gradient kernel is the shipped shape's)."""
         n, s = z.shape
         lx = self.embedder['xyz'].n_freqs
         pts = (rayo[:, None, :] + rayd[:, None, :] * z[:, :, None]).reshape(-1, 3).contiguous()
