@@ -1,0 +1,52 @@
+"""Host logic of the precision / shape routing (no GPU): which models count as the shipped ("tuned") shapes, what
+`precision` / `grad_precision` combinations exist, and that nothing but the documented cases raises at construction
+(INTEGRATION.md "Shapes"; reference nerfactor/models/{nerf,shape,brdf}.py build their networks from the ini)."""
+import pytest
+
+from nerfactor_amd.nerfactor.config import make_config
+from nerfactor_amd.nerfactor.models import get_model_class
+
+
+def build(name, **ov):
+    return get_model_class(name)(make_config(name, **ov))
+
+
+def test_shipped_configurations_are_tuned():
+    assert build('nerf').tuned and build('brdf').tuned
+    shape = build('shape')
+    assert shape._net_tuned('normal_mlp') and shape._net_tuned('lvis_mlp')
+
+
+@pytest.mark.parametrize("name,ov", [
+    ('nerf', dict(mlp_width='128')), ('nerf', dict(enc_depth='6')), ('nerf', dict(use_views='False')),
+    ('nerf', dict(pos_enc='False')), ('nerf', dict(n_freqs_xyz='8')),
+    ('brdf', dict(mlp_width='64')), ('brdf', dict(n_freqs='3')), ('brdf', dict(pos_enc='False')), ('brdf', dict(mlp_skip_at='1'))])
+def test_other_shapes_construct_and_take_the_runtime_shaped_path(name, ov):
+    for prec in ('bf16', 'fp32'):
+        assert not build(name, precision=prec, **ov).tuned
+
+
+@pytest.mark.parametrize("ov", [dict(mlp_width='64'), dict(mlp_depth='3', mlp_skip_at='1'), dict(n_freqs_xyz='6'),
+                                dict(n_freqs_ldir='2')])
+def test_surface_model_shapes_are_checked_per_network(ov):
+    m = build('shape', **ov)
+    assert not m._net_tuned('normal_mlp') or not m._net_tuned('lvis_mlp')
+
+
+def test_limits_of_the_runtime_shaped_kernels_raise_with_the_numbers():
+    with pytest.raises(NotImplementedError, match='mlp_width'):
+        build('nerf', mlp_width='512')
+    with pytest.raises(NotImplementedError, match='mlp_width'):
+        build('shape', mlp_width='300')
+    with pytest.raises(NotImplementedError, match='skip'):
+        build('brdf', mlp_depth='4', mlp_skip_at='3')
+
+
+def test_grad_precision_follows_precision_and_rejects_the_impossible_pair():
+    assert build('nerf').grad_precision == 'bf16'
+    assert build('nerf', precision='fp32').grad_precision == 'fp32'
+    assert build('nerf', precision='fp32', grad_precision='bf16').grad_precision == 'bf16'
+    with pytest.raises(ValueError, match='grad_precision'):
+        build('nerf', grad_precision='fp32')
+    with pytest.raises(ValueError, match='grad_precision'):
+        build('shape', precision='fp32', grad_precision='fp16')
