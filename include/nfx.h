@@ -23,8 +23,9 @@
  *     nfx_mlp128_xyz_fwd / nfx_lvis_fwd (workspace unused) / nfx_brdf_spec_fwd, and the
  *     geometry pair nfx_nerf_pack_geom_weights / nfx_nerf_sigma_fwd / nfx_nerf_sigma_grad; the
  *     tuned training-blob and backward entry points return NFX_ENOSUP for it.  The runtime-shaped
- *     family (nfx_mlp_generic_*) takes NFX_PREC_FP32 as TRUE fp32 operands on the fp32 matrix
- *     instruction, forward and backward: that is the backward at the reference's arithmetic.
+ *     family (nfx_mlp_generic_*) takes it forward AND backward (fp32 activations, gradients and
+ *     workspace; hi/lo pairs only as MFMA operands) — the backward of `precision = fp32` — and
+ *     additionally NFX_PREC_FP32_NATIVE: true fp32 operands on the fp32 matrix instruction.
  *   - re-entrant: no global mutable state besides the option table of nfx_set_option
  *     (atomic integers); concurrent calls on different streams are legal.
  */
@@ -54,6 +55,7 @@ extern "C" {
 
 #define NFX_PREC_BF16 0
 #define NFX_PREC_FP32 1
+#define NFX_PREC_FP32_NATIVE 2 /* nfx_mlp_generic_* only: fp32 operands, v_mfma_f32_32x32x2_f32 */
 
 #define NFX_ACT_NONE 0
 #define NFX_ACT_RELU 1
@@ -223,6 +225,22 @@ NFX_API int nfx_brdf_spec_fwd(const float *dev_xyz, const float *dev_cam, const 
 /* Rusinkiewicz coordinates (phi_d, theta_h, theta_d), util/geom.py:152-192. a,b [n,3]. */
 NFX_API int nfx_dir2rusink(const float *dev_a, const float *dev_b, int64_t n, float *dev_rusink,
                    void *stream);
+
+/* The learned BRDF's input rows made explicit, in fp32 (nerfactor/models/nerfactor.py:413-436 + embedder.py:23-47):
+ * for every (point, light): rows[(i n_lights + l) ld_rows ...] = [z[i] | rusink | sin(2^k rusink), cos(2^k rusink) k < n_freqs]
+ * with rusink = dir2rusink(R_i l, R_i v) in the local frame R_i = gen_world2local(normal[i]) and front[i n_lights + l] =
+ * 1.0 where the light is in front of the surface (local l.z > 0), else 0.0 — what `precision = fp32` feeds to
+ * nfx_mlp_generic_fwd for the frozen BRDF prior (spec = front * softplus(...)).  EVERY row is written (no compaction:
+ * no data-dependent size, the step stays capturable).  _bwd: given dLoss/d rows (from nfx_mlp_generic_bwd's dx) writes
+ * d_normal[n, 3] (through the local frame and the Rusinkiewicz angles, with the reference's custom gradients of
+ * safe_acos / safe_atan2, util/math.py:24-60) and d_z[n, z_dim], each summed over the point's FRONT-LIT lights in a fixed
+ * order (bit-reproducible, no atomics).  z_dim <= 8, n_freqs <= 8 (NFX_ENOSUP beyond).                                  */
+NFX_API int nfx_brdf_rows_geom_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal, const float *dev_z,
+                                   int z_dim, const float *dev_lxyz, int n_lights, int64_t n, int n_freqs, float *dev_rows,
+                                   int ld_rows, float *dev_front, void *stream);
+NFX_API int nfx_brdf_rows_geom_bwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal, int z_dim,
+                                   const float *dev_lxyz, int n_lights, int64_t n, int n_freqs, const float *dev_d_rows,
+                                   int ld_rows, float *dev_d_normal, float *dev_d_z, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Training (replaces tape.gradient / optimizer.apply_gradients,             */
@@ -401,9 +419,15 @@ NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float
 /* [col0, col0 + widths[n_layers - 1]) are written (so that a caller can        */
 /* assemble concat(features, embedded view) without a copy).                    */
 /* ------------------------------------------------------------------------ */
-/* prec here: NFX_PREC_BF16 as above; NFX_PREC_FP32 = fp32 operands and the native fp32 matrix instruction        */
-/* (v_mfma_f32_32x32x2_f32) — the reference's own arithmetic, forward AND backward, for any shape (2-KiB fragments;  */
-/* a blob is packed for one prec).                                                                                  */
+/* prec here: NFX_PREC_BF16 as above; NFX_PREC_FP32 = fp32-class as in the tuned kernels (every MFMA operand a    */
+/* bf16 hi / lo pair, three v_mfma_f32_32x32x16_bf16 per product) with fp32 activations, gradients and workspace,     */
+/* forward AND backward, for any shape; NFX_PREC_FP32_NATIVE = fp32 operands on the native fp32 matrix instruction    */
+/* (v_mfma_f32_32x32x2_f32: the reference's own arithmetic bit class, ~5x the matrix time).  2-KiB fragments in both  */
+/* fp32 modes; a blob is packed for one prec.  nfx_mlp_generic_split_hilo turns the fragments of a                    */
+/* NFX_PREC_FP32_NATIVE blob (a pure gather of the parameters: nfx_pack_gather can rebuild it on the device) into     */
+/* NFX_PREC_FP32 fragments IN PLACE on `stream` (train != 0: a train blob, forward + transposed fragments).           */
+NFX_API int nfx_mlp_generic_split_hilo(void *dev_blob, int d_in, int n_layers, const int *widths, const int *skip_input,
+                                       int train, void *stream);
 NFX_API size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int *widths, const int *skip_input, int prec);
 NFX_API int nfx_mlp_generic_pack(const float *const *kernels, const float *const *biases, int d_in, int n_layers,
                                  const int *widths, const int *skip_input, int prec, void *blob, size_t blob_bytes);

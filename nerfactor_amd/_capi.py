@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libnfx.so')
 if os.environ.get('NFX_LIB_PATH'):   # experiment builds (python -m nerfactor_amd.build --out ...)
     LIB_PATH = os.environ['NFX_LIB_PATH']
 
-PREC_BF16, PREC_FP32 = 0, 1
+PREC_BF16, PREC_FP32, PREC_FP32_NATIVE = 0, 1, 2    # (PREC_FP32_NATIVE: the runtime-shaped kernels only)
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3
 IN_XYZ, IN_XYZ_LDIR, IN_Z_RUSINK = 0, 1, 2
 
@@ -96,6 +96,9 @@ SIGNATURES = {
     'nfx_mlp_generic_train_packed_bytes': (_sz, [_i, _i, _p, _p, _i]),
     'nfx_mlp_generic_pack_train': (_i, [_pp, _pp, _i, _i, _p, _p, _i, _p, _sz]),
     'nfx_mlp_generic_bwd_workspace_bytes': (_sz, [_i64, _i, _i, _p, _p, _i]),
+    'nfx_mlp_generic_split_hilo': (_i, [_p, _i, _i, _p, _p, _i, _p]),
+    'nfx_brdf_rows_geom_fwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _i64, _i, _p, _i, _p, _p]),
+    'nfx_brdf_rows_geom_bwd': (_i, [_p, _p, _p, _i, _p, _i, _i64, _i, _p, _i, _p, _p, _p]),
     'nfx_embed_bwd': (_i, [_p, _i64, _i, _i, _p, _i, _i, _p, _p]),
     'nfx_mlp_generic_bwd': (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p, _i, _pp, _pp, _p, _sz, _p]),
     'nfx_embed': (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i, _p]),

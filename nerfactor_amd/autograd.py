@@ -208,6 +208,27 @@ class GenericMlp(torch.autograd.Function):
         return (dx, None) + tuple(rks) + tuple(rbs)
 
 
+class BrdfRowsGeom(torch.autograd.Function):
+    """(rows, front) = the learned BRDF's explicit fp32 input rows [z | embed(rusink)] per (point, light) and the front-lit
+    flags (nerfactor.py:413-436); differentiable w.r.t. the normal (local frame + Rusinkiewicz angles, the reference's
+    custom gradients) and the BRDF code z — one libnfx kernel each way (csrc/brdf_rows_geom.hip)."""
+
+    @staticmethod
+    def forward(ctx, xyz, cam, lxyz, n_freqs, normal, z):
+        ctx.save_for_backward(xyz, cam, lxyz, normal)
+        ctx.cfg = (n_freqs, z.shape[1])
+        rows, front = ops.brdf_rows_geom_fwd(xyz, cam, normal, z, lxyz, n_freqs)
+        ctx.mark_non_differentiable(front)
+        return rows, front
+
+    @staticmethod
+    def backward(ctx, d_rows, _unused):
+        xyz, cam, lxyz, normal = ctx.saved_tensors
+        n_freqs, z_dim = ctx.cfg
+        d_normal, d_z = ops.brdf_rows_geom_bwd(xyz, cam, normal, z_dim, lxyz, n_freqs, d_rows.contiguous())
+        return None, None, None, None, d_normal, d_z
+
+
 class Embed(torch.autograd.Function):
     """embedder(x) for explicit vectors x[n, 3] (nfx_embed) with its pull-back (nfx_embed_bwd)."""
 

@@ -19,6 +19,7 @@ int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipSt
 int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st);
 int nfx_launch_embed_bwd(const nfx::generic::EmbedArgs* a, const float* d_out, float* dv, hipStream_t st);
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st);
+int nfx_launch_split_hilo(void* frags, long long n_frags, hipStream_t st);
 }
 
 // the layer table of a network: mlp.Network(widths, skip_at) semantics (nerfactor/networks/mlp.py:38-50) —
@@ -52,19 +53,33 @@ static int layer_table(int d_in, int n_layers, const int* widths, const int* ski
 static void set_pitches(nfx::generic::Args* a) {
     int widest = 1;
     for (int i = 0; i < a->n_layers; ++i) widest = a->layer[i].n_tiles > widest ? a->layer[i].n_tiles : widest;
-    const int elem = a->f32 ? 4 : 2;
+    const int elem = a->f32 ? 4 : 2;                         // (f32 = the prec: 0 bf16, else fp32 activations)
     a->x_pitch = (a->d_in + 63) / 64 * 64 * elem + 16;       // whole k-groups (64 features) per row
     a->h_pitch = (widest + 1) / 2 * 64 * elem + 16;
 }
 static int check_prec(int prec, const char* who) {
-    if (prec != NFX_PREC_BF16 && prec != NFX_PREC_FP32) return nfx_fail(NFX_EINVAL, "%s: prec %d (NFX_PREC_BF16 | NFX_PREC_FP32)", who, prec);
+    if (prec != NFX_PREC_BF16 && prec != NFX_PREC_FP32 && prec != NFX_PREC_FP32_NATIVE)
+        return nfx_fail(NFX_EINVAL, "%s: prec %d (NFX_PREC_BF16 | NFX_PREC_FP32 | NFX_PREC_FP32_NATIVE)", who, prec);
     return NFX_OK;
 }
-static size_t frag_bytes(int prec) { return prec == NFX_PREC_FP32 ? 2048 : 1024; }
-// element (lane, i) of a fragment: bf16: [lane][8]; fp32: [half = i / 4][lane][4] (one DMA piece per half)
+static_assert(NFX_PREC_BF16 == 0 && NFX_PREC_FP32 == 1 && NFX_PREC_FP32_NATIVE == 2, "= nfx::generic::kBf16 / kX3 / kNative (mlp_generic.hip)");
+static bool wide(int prec) { return prec != NFX_PREC_BF16; }      // fp32 activations / workspace, 2-KiB fragments
+static size_t frag_bytes(int prec) { return wide(prec) ? 2048 : 1024; }
+static float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// element (lane, i) of a fragment: bf16: [lane][8]; fp32 native: [half = i / 4][lane][4] (one DMA piece per half);
+// fp32-class: [hi plane | lo plane], each [lane][8] bf16 — hi = bf16(v), lo = bf16(v - hi) (csrc/mlp_x3.hpp)
 static void put(void* frag, int prec, int lane, int i, float v) {
-    if (prec == NFX_PREC_FP32) static_cast<float*>(frag)[(i >> 2) * 256 + lane * 4 + (i & 3)] = v;
-    else static_cast<uint16_t*>(frag)[lane * 8 + i] = nfx::pack::f32_to_bf16_rne(v);
+    if (prec == NFX_PREC_FP32_NATIVE) static_cast<float*>(frag)[(i >> 2) * 256 + lane * 4 + (i & 3)] = v;
+    else if (prec == NFX_PREC_FP32) {
+        const uint16_t hi = nfx::pack::f32_to_bf16_rne(v);
+        static_cast<uint16_t*>(frag)[lane * 8 + i] = hi;
+        static_cast<uint16_t*>(frag)[512 + lane * 8 + i] = nfx::pack::f32_to_bf16_rne(v - bf16_to_f32(hi));
+    } else static_cast<uint16_t*>(frag)[lane * 8 + i] = nfx::pack::f32_to_bf16_rne(v);
 }
 
 size_t nfx_mlp_generic_packed_bytes(int d_in, int n_layers, const int* widths, const int* skip_input, int prec) {
@@ -142,7 +157,7 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     a.col0 = col0;
     a.n_layers = n_layers;
     a.n_frags = nf;
-    a.f32 = prec == NFX_PREC_FP32;
+    a.f32 = prec;
     set_pitches(&a);
     return nfx_hip_result(nfx_launch_mlp_generic(&a, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
 }
@@ -258,7 +273,7 @@ size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, co
     BwdPlan p;
     if (n < 0 || !widths || check_prec(prec, "nfx_mlp_generic_bwd_workspace_bytes") || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
     const long long tiles = (n + 31) / 32;
-    return align256((size_t)tiles * p.feat_rows * (prec == NFX_PREC_FP32 ? 128 : 64)) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
+    return align256((size_t)tiles * p.feat_rows * (wide(prec) ? 128 : 64)) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
 }
 
 int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_layers, const int* widths, const int* acts,
@@ -316,17 +331,27 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     wa.n_jobs = p.n_jobs;
     wa.slice = p.slice;
     wa.dw_total = p.dw_total;
-    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * (prec == NFX_PREC_FP32 ? 128 : 64)));
+    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * (wide(prec) ? 128 : 64)));
     for (int i = 0; i < n_layers; ++i) {
         ba.f.layer[i] = wa.layer[i] = p.layer[i];
         ba.b[i] = wa.b[i] = p.b[i];
         wa.dw[i] = dkernels ? dkernels[i] : nullptr;
         wa.db[i] = dkernels ? dbiases[i] : nullptr;
     }
-    ba.f.f32 = prec == NFX_PREC_FP32;
+    ba.f.f32 = prec;
     set_pitches(&ba.f);
     return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                           "mlp_generic_bwd");
+}
+
+int nfx_mlp_generic_split_hilo(void* blob, int d_in, int n_layers, const int* widths, const int* skip_input, int train, void* stream) {
+    REQUIRE(blob && widths, "nfx_mlp_generic_split_hilo: null argument");
+    if ((uintptr_t)blob & 15) return nfx_fail(NFX_EALIGN, "nfx_mlp_generic_split_hilo: blob must be 16-byte aligned");
+    BwdPlan p;
+    int rc = bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p);
+    if (rc) return rc;
+    char* frags = static_cast<char*>(blob) + (size_t)p.n_bias * 4;
+    return nfx_hip_result(nfx_launch_split_hilo(frags, p.n_frags + (train ? p.n_tfrags : 0), (hipStream_t)stream), "split_hilo");
 }
 
 int nfx_embed(const float* x, const float* dir, const float* z, int64_t n, int per_ray, int mode, int n_freqs, int incl_input,

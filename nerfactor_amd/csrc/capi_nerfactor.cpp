@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/nfx.h"
+#include "brdf_rows_geom.hpp"
 #include "mlp128_layout.hpp"
 #include "pack.hpp"
 
@@ -22,6 +23,7 @@ extern "C" int nfx_option_int(const char* name, int dflt);  // capi.cpp
 #define ALIGNED(p, a) ((((uintptr_t)(p)) & ((a)-1)) == 0)
 
 extern "C" {
+int nfx_launch_brdf_rows_geom(const nfx::rowsgeom::Args*, int, hipStream_t);
 int nfx_launch_mlp128_xyz(const float*, long long, float, const void*, int, int, float, float, float*, int,
                           hipStream_t);
 int nfx_launch_lvis_pre(const float*, long long, float, const void*, float*, int, hipStream_t);
@@ -346,6 +348,30 @@ int nfx_shade_olat_fwd(const float* xyz, const float* cam, const float* normal, 
                                                 lareas, olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat,
                                                 (hipStream_t)stream),
                           "shade_olat_fwd");
+}
+
+static int rows_geom_check(const char* who, int64_t n, int n_lights, int z_dim, int n_freqs, int ld) {
+    REQUIRE(n >= 0 && n_lights >= 1, "%s: bad sizes", who);
+    if (z_dim < 1 || z_dim > nfx::rowsgeom::kMaxZ) return nfx_fail(NFX_ENOSUP, "%s: z_dim %d (1 .. %d)", who, z_dim, nfx::rowsgeom::kMaxZ);
+    if (n_freqs < 0 || n_freqs > nfx::rowsgeom::kMaxFreqs) return nfx_fail(NFX_ENOSUP, "%s: %d bands (0 .. %d)", who, n_freqs, nfx::rowsgeom::kMaxFreqs);
+    REQUIRE(ld >= z_dim + 3 + 6 * n_freqs, "%s: rows of %d floats, %d needed", who, ld, z_dim + 3 + 6 * n_freqs);
+    return NFX_OK;
+}
+int nfx_brdf_rows_geom_fwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim, const float* lxyz,
+                           int n_lights, int64_t n, int n_freqs, float* rows, int ld_rows, float* front, void* stream) {
+    if (int e = rows_geom_check("nfx_brdf_rows_geom_fwd", n, n_lights, z_dim, n_freqs, ld_rows)) return e;
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && z && lxyz && rows && front, "nfx_brdf_rows_geom_fwd: null pointer");
+    nfx::rowsgeom::Args a{xyz, cam, normal, z, lxyz, n, n_lights, z_dim, n_freqs, rows, front, nullptr, ld_rows, nullptr, nullptr};
+    return nfx_hip_result(nfx_launch_brdf_rows_geom(&a, 0, (hipStream_t)stream), "brdf_rows_geom_fwd");
+}
+int nfx_brdf_rows_geom_bwd(const float* xyz, const float* cam, const float* normal, int z_dim, const float* lxyz, int n_lights,
+                           int64_t n, int n_freqs, const float* d_rows, int ld_rows, float* d_normal, float* d_z, void* stream) {
+    if (int e = rows_geom_check("nfx_brdf_rows_geom_bwd", n, n_lights, z_dim, n_freqs, ld_rows)) return e;
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && cam && normal && lxyz && d_rows && d_normal && d_z, "nfx_brdf_rows_geom_bwd: null pointer");
+    nfx::rowsgeom::Args a{xyz, cam, normal, nullptr, lxyz, n, n_lights, z_dim, n_freqs, nullptr, nullptr, d_rows, ld_rows, d_normal, d_z};
+    return nfx_hip_result(nfx_launch_brdf_rows_geom(&a, 1, (hipStream_t)stream), "brdf_rows_geom_bwd");
 }
 
 int nfx_dir2rusink(const float* a, const float* b, int64_t n, float* rusink, void* stream) {

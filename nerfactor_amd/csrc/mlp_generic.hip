@@ -26,11 +26,20 @@
 // weight-gradient kernel then needs no LDS at all: one wave per (64 x 64 block of dW, row split), all MFMA operands
 // 16-byte loads.  Deterministic: fixed split count per problem shape, ordered reductions, no atomics.
 //
-// precision = fp32 (NFX_PREC_FP32): the same kernels instantiated with fp32 activations in LDS, fp32 fragments (2 KiB per
+// NFX_PREC_FP32_NATIVE: the same kernels instantiated with fp32 activations in LDS, fp32 fragments (2 KiB per
 // k-step) and the native fp32 matrix instruction v_mfma_f32_32x32x2_f32 — eight per k-step, k = 8 g + i on both
 // operands — i.e. the reference's own arithmetic (trainvali.py:273-285 differentiates in fp32), forward AND backward,
-// for any shape including the shipped ones.  163 TFLOP/s is that instruction's peak; at one wave per SIMD its 64-cycle
+// for any shape including the shipped ones.  157 TFLOP/s is that instruction's peak; at one wave per SIMD its 64-cycle
 // issue hides the loop's scalar work, so this path is MFMA-bound where the bf16 one is issue-bound.
+//
+// NFX_PREC_FP32 (round 5): fp32-class arithmetic on the bf16 matrix pipe, the hi / lo operand pairs of mlp_x3.hpp in
+// the runtime-shaped kernels.  Activations, gradients and the workspace stay fp32 exactly as in the native mode; a
+// weight fragment is the same 2 KiB, pre-split by the packer into [hi plane | lo plane] (hi = bf16(w), lo = bf16(w - hi),
+// lane order of the bf16 fragment: the 8 consecutive k of a lane are the same in both instructions), the B operand — 8
+// consecutive fp32 features of the lane's row — is split in registers once per k-group for all output tiles, and a
+// k-step is three v_mfma_f32_32x32x16_bf16 (a_lo b_hi + a_hi b_lo + a_hi b_hi) = 96 matrix-pipe cycles instead of the
+// 512 of eight fp32 instructions.  Operands carry 16 significant bits: gradients within 1e-3 of the reference's
+// (tests/test_gpu_reference_grads.py), at a fifth of the native mode's matrix time.
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"
 #include "mlp_generic.hpp"
@@ -53,11 +62,14 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 constexpr int kRingGroups = 3;
 
-// What differs between the two operand types: F32 = false: bf16 operands, v_mfma_f32_32x32x16_bf16; true: fp32 operands,
-// 8 x v_mfma_f32_32x32x2_f32 per k-step.
-template <bool F32>
+// What differs between the operand modes M: kBf16: bf16 operands, v_mfma_f32_32x32x16_bf16; kNative: fp32 operands,
+// 8 x v_mfma_f32_32x32x2_f32 per k-step; kX3: the fp32 DATA layout (LDS, workspace, fragment size) of kNative with
+// hi / lo bf16 pairs as MFMA operands, 3 x v_mfma_f32_32x32x16_bf16 per k-step.
+enum : int { kBf16 = 0, kX3 = 1, kNative = 2 };        // = Args::f32 = the C-ABI's NFX_PREC_BF16 / _FP32 / _FP32_NATIVE
+template <int M>
 struct P {
-    static constexpr int kElem = F32 ? 4 : 2;                 // bytes per activation / weight
+    static constexpr bool kF32 = M != kBf16;                  // fp32 activations / workspace / 2-KiB fragments
+    static constexpr int kElem = kF32 ? 4 : 2;                // bytes per activation / weight
     static constexpr int kFrag = 32 * 16 * kElem;             // one k-step's A fragment (32 outputs x 16 inputs): 1 or 2 KiB
     static constexpr int kGroupBytes = kGroup * kFrag;
     static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
@@ -66,8 +78,8 @@ struct P {
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
     static constexpr int kWsFeat = 32 * kElem;                // workspace bytes per (feature, row tile)
 };
-static_assert(P<false>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
-static_assert(P<true>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<kBf16>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
 static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8 | 16) = (kRingGroups - 1) groups of pieces in flight");
 
 // The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
@@ -76,7 +88,7 @@ static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8 | 1
 // only an address.  The stream is circular: behind its last group the ring already fetches the next row tile's first.
 // vmcnt is in order, so "at most two groups of pieces outstanding" = the oldest group has landed; the wave's other VMEM
 // operations can only make that wait stricter.
-template <bool F32>
+template <int M>
 struct Ring {
     const char* next;    // next group to fetch (wave-uniform)
     const char* begin;
@@ -86,10 +98,10 @@ struct Ring {
     unsigned lane_off;
     int slot;            // oldest group = the one the MFMAs read next = the one refilled after them
     __device__ __forceinline__ void issue() {
-        const unsigned dst = lds + (unsigned)slot * P<F32>::kGroupBytes;
+        const unsigned dst = lds + (unsigned)slot * P<M>::kGroupBytes;
         lds_dma_pieces<4>(lane_off, next, dst);
-        if constexpr (F32) lds_dma_pieces<4>(lane_off, next + 4096, dst + 4096u);
-        next += P<F32>::kGroupBytes;
+        if constexpr (P<M>::kF32) lds_dma_pieces<4>(lane_off, next + 4096, dst + 4096u);
+        next += P<M>::kGroupBytes;
         if (next == end) next = begin;
         slot = slot == kRingGroups - 1 ? 0 : slot + 1;
     }
@@ -98,29 +110,50 @@ struct Ring {
         lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
         lane_off = (unsigned)lane * 16u;
         begin = next = stream;
-        end = stream + (size_t)n_frags * P<F32>::kFrag;
+        end = stream + (size_t)n_frags * P<M>::kFrag;
         slot = 0;
 #pragma unroll
         for (int i = 0; i < kRingGroups; ++i) issue();
     }
     __device__ __forceinline__ void wait_oldest() {
-        if constexpr (F32) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (P<M>::kF32) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
 };
+// kX3: eight consecutive fp32 features of a row -> the bf16 pair (mlp_x3.hpp: hi = bf16(v), lo = bf16(v - hi); v - hi is exact)
+struct HiLo {
+    bf16x8 hi, lo;
+};
+__device__ __forceinline__ HiLo split8(f32x4 a, f32x4 b) {
+    HiLo r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.hi[j] = (__bf16)a[j];
+        r.lo[j] = (__bf16)(a[j] - (float)r.hi[j]);
+        r.hi[4 + j] = (__bf16)b[j];
+        r.lo[4 + j] = (__bf16)(b[j] - (float)r.hi[4 + j]);
+    }
+    return r;
+}
+// acc += a b with both operands as pairs: small terms first, the a_lo b_lo term (2^-18 relative) dropped
+__device__ __forceinline__ f32x16 mma_x3(const bf16x8& ah, const bf16x8& al, const HiLo& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi, acc, 0, 0, 0);
+}
 // One 32 x 32 output tile: acc += W_tile^T [h | x], kg_h groups of four k-steps over the previous layer's output, then
 // kg_x over the network input.  A: the ring; B: 64 consecutive features of the lane's own row in LDS.  Nothing in the
 // loop depends on the k-step but immediate offsets: pad steps multiply zero fragments with whatever finite number the
 // row holds there (the activation area is zeroed once, then only ever holds activations).
 // fp32: a fragment is [half][lane][4 floats] — lane (m, g) holds W[16 s + 8 g + 4 half + r][m] — and MFMA i of a k-step
 // contracts k = 8 g + i on both operands.
-template <bool F32>
-__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<F32>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
+template <int M>
+__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<M>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
     for (int gi = 0; gi < kg_h + kg_x; ++gi) {
-        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<F32>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<F32>::kStep);
+        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<M>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<M>::kStep);
         w.wait_oldest();
-        const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
-        if constexpr (!F32) {
+        const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+        if constexpr (M == kBf16) {
             bf16x8 af[kGroup], bf[kGroup];
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
@@ -129,6 +162,20 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<F32>& w, int kg_h, i
             }
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc, 0, 0, 0);
+        } else if constexpr (M == kX3) {      // fragment = [hi plane | lo plane], 1 KiB each, bf16 lane order
+            bf16x8 ah[kGroup], al[kGroup];
+            HiLo b[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                ah[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 2048);
+                al[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 2048 + 1024);
+                {
+                    const f32x4 f0 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64), f1 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64 + 16);
+                    b[j] = split8(f0, f1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) acc = mma_x3(ah[j], al[j], b[j], acc);
         } else {
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
@@ -153,29 +200,52 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<F32>& w, int kg_h, i
 // output can overwrite its input IN PLACE: one hidden buffer per wave instead of two.
 // `tile_done(t, acc)` is called once per output tile after the last k-group (the accumulators never leave this function:
 // handed out by reference they end up in scratch memory).
-template <bool F32, int NT, bool ROLLED, class TileDone>
-__device__ __forceinline__ void layer_mma(Ring<F32>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc, TileDone tile_done) {
+template <int M, int NT, bool ROLLED, class TileDone>
+__device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc, TileDone tile_done) {
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     for (int gi = 0; gi < kg_h + kg_x; ++gi) {
-        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<F32>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<F32>::kStep);
-        if constexpr (!F32) {
+        const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<M>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<M>::kStep);
+        if constexpr (M == kBf16) {
             bf16x8 bf[kGroup];
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 w.wait_oldest();
-                const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
+                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
                 bf16x8 af[kGroup];
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 1024);
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc[t], 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every read of the slot has returned: refill it)
+                w.issue();
+            }
+        } else if constexpr (M == kX3) {
+            // the group's B operand is split ONCE (24 VALU per k-step) for all NT tiles; the A pairs come split from the blob
+            HiLo b[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const f32x4 f0 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64), f1 = *reinterpret_cast<const lds_f32x4*>(bsrc + j * 64 + 16);
+                b[j] = split8(f0, f1);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w.wait_oldest();
+                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+                bf16x8 ah[kGroup], al[kGroup];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                    ah[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 2048);
+                    al[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 2048 + 1024);
+                }
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) acc[t] = mma_x3(ah[j], al[j], b[j], acc[t]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 w.issue();
             }
         } else {
@@ -188,7 +258,7 @@ __device__ __forceinline__ void layer_mma(Ring<F32>& w, int kg_h, int kg_x, cons
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 w.wait_oldest();
-                const lds_char* grp = w.lds_ptr + w.slot * P<F32>::kGroupBytes + w.lane_off;
+                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) {
                     const f32x4 a0 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048), a1 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048 + 1024);
@@ -248,7 +318,7 @@ __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
 }
 // the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features; `ws`
 // (backward, fp32 only): also to the workspace, feature-major (the bf16 path transposes through store_blocked instead)
-template <bool F32>
+template <int M>
 __device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g, float* ws_col = nullptr) {
     for (int c0 = 8 * g; c0 < feats; c0 += 16) {
         float f[8];
@@ -256,7 +326,7 @@ __device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, 
         for (int j = 0; j < 8; ++j) f[j] = src[c0 + j < d_in ? c0 + j : d_in - 1];     // (unconditional: eight loads in flight)
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = c0 + j < d_in ? f[j] : 0.f;
-        if constexpr (F32) {
+        if constexpr (P<M>::kF32) {
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4) = f32x4{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4 + 16) = f32x4{f[4], f[5], f[6], f[7]};
             if (ws_col) {
@@ -305,11 +375,11 @@ __device__ __forceinline__ void zero_pad16(float* v, int t, int g, int n_out) {
     }
 }
 // 16 floats (register q = feature (q&3) + 8 (q>>2) + 4 g of the tile) -> the lane's row in LDS: four 8- or 16-byte stores
-template <bool F32>
+template <int M>
 __device__ __forceinline__ void store_row16(lds_char* row_tile, int g, const float* v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if constexpr (F32) {
+        if constexpr (P<M>::kF32) {
             *reinterpret_cast<lds_f32x4*>(row_tile + (8 * q + 4 * g) * 4) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
         } else {
             bf16x4 o;
@@ -320,12 +390,22 @@ __device__ __forceinline__ void store_row16(lds_char* row_tile, int g, const flo
     }
 }
 
+// A layer with an odd tile count leaves features [32 NT, 32 NT + 32) of its last k-group to the next layer's pad k-steps
+// (zero fragments): they must be finite — a stale Inf / NaN of a wider layer or an earlier row tile times zero is NaN.
+template <int M, int NT>
+__device__ __forceinline__ void zero_pad_tile(lds_char* hrow, int g) {
+    if constexpr (NT & 1) {
+        const float z[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        store_row16<M>(hrow + P<M>::kTile * NT, g, z);
+    }
+}
+
 // forward of one layer with NT output tiles; `hrow` = the lane's row of THE hidden buffer: read (k-steps over the previous
 // layer's output) and, once all tiles are accumulated, overwritten with this layer's output
-template <bool F32, int NT>
-__device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<F32>& w, lds_char* hrow, const lds_char* xrow,
+template <int M, int NT>
+__device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<M>& w, lds_char* hrow, const lds_char* xrow,
                                               int g, float* yrow) {
-    layer_mma<F32, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<F32>::kStep / 2), xrow + g * (P<F32>::kStep / 2),
+    layer_mma<M, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
                               [&](int t, const f32x16& acc) {
         // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
         float bias[16], v[16];
@@ -347,34 +427,35 @@ __device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, boo
             }
         } else {
             zero_pad16(v, t, g, L.n_out);
-            store_row16<F32>(hrow + P<F32>::kTile * t, g, v);
+            store_row16<M>(hrow + P<M>::kTile * t, g, v);
         }
     });
+    if (!last) zero_pad_tile<M, NT>(hrow, g);
 }
 
-template <bool F32>
+template <int M>
 __global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + P<F32>::kRingBytes;           // [32][x_pitch]  network input
+    lds_char* xb = ring + P<M>::kRingBytes;           // [32][x_pitch]  network input
     lds_char* hb = xb + 32 * x_pitch;                   // [32][h_pitch]  THE hidden buffer (updated in place)
     const long long n_tiles_rows = (a.n + 31) / 32;
-    Ring<F32> w;
+    Ring<M> w;
     w.start(ring, a.weights, a.n_frags, lane);
     zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
     for (long long rt = blockIdx.x; rt < n_tiles_rows; rt += gridDim.x) {
         const long long row0 = rt * 32;
         {
             const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
-            load_x<F32>(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
+            load_x<M>(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
         }
         float* yrow = row0 + p < a.n ? a.y + (row0 + p) * a.ld_y + a.col0 : nullptr;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-#define NFX_FWD(NT) forward_layer<F32, NT>(a, L, last, w, hb + p * h_pitch, xb + p * x_pitch, g, yrow)
+#define NFX_FWD(NT) forward_layer<M, NT>(a, L, last, w, hb + p * h_pitch, xb + p * x_pitch, g, yrow)
             NFX_FOR_TILE_COUNT(L.n_tiles, NFX_FWD)
 #undef NFX_FWD
         }
@@ -433,13 +514,13 @@ __device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int 
 
 // the backward kernel's forward of one layer: as forward_layer, plus the workspace copies (fp32: straight from the
 // registers) and, for the output layer, dZ = dy * act'(logit) in place of the activation
-template <bool F32, int NT>
-__device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<F32>& w, lds_char* hrow, const lds_char* xrow, int g, int p,
+template <int M, int NT>
+__device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M>& w, lds_char* hrow, const lds_char* xrow, int g, int p,
                                                 bool live, const float* dyr, char* wst) {
     const Args& a = ba.f;
     const Layer L = a.layer[l];
     const bool last = l == a.n_layers - 1;
-    layer_mma<F32, NT, true>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<F32>::kStep / 2), xrow + g * (P<F32>::kStep / 2),
+    layer_mma<M, NT, true>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
                              [&](int t, const f32x16& acc) {
         float bias[16], v[16];
         load_bias(a.biases + L.b_off + 32 * t, g, bias);
@@ -459,19 +540,20 @@ __device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<F
             activate16(v, L.act);
         }
         zero_pad16(v, t, g, L.n_out);
-        store_row16<F32>(hrow + P<F32>::kTile * t, g, v);
-        if constexpr (F32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
+        store_row16<M>(hrow + P<M>::kTile * t, g, v);
+        if constexpr (P<M>::kF32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
     });
+    zero_pad_tile<M, NT>(hrow, g);
 }
 // dZ_{l-1} = (dZ_l W_l^T over the previous layer's NT output tiles) * act'(H_{l-1}), written over dZ_l in place
-template <bool F32, int NT>
-__device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<F32>& w, lds_char* hrow, int g, int p, char* wst) {
+template <int M, int NT>
+__device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M>& w, lds_char* hrow, int g, int p, char* wst) {
     const Args& a = ba.f;
     const int kg_o = pad_group(2 * a.layer[l].n_tiles) / kGroup;
-    layer_mma<F32, NT, true>(w, kg_o, 0, hrow + g * (P<F32>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
+    layer_mma<M, NT, true>(w, kg_o, 0, hrow + g * (P<M>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
         // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
         float d[16], y[16];
-        if constexpr (F32) {
+        if constexpr (P<M>::kF32) {
             const float* hy = reinterpret_cast<const float*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
 #pragma unroll
             for (int q = 0; q < 16; ++q) y[q] = hy[((q & 3) + 8 * (q >> 2)) * 32];
@@ -483,39 +565,40 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<F32>&
 #pragma unroll
         for (int q = 0; q < 16; ++q) d[q] = acc[q];
         scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
-        store_row16<F32>(hrow + P<F32>::kTile * mt, g, d);
-        if constexpr (F32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
+        store_row16<M>(hrow + P<M>::kTile * mt, g, d);
+        if constexpr (P<M>::kF32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
     });
+    zero_pad_tile<M, NT>(hrow, g);
 }
 
-template <bool F32>
+template <int M>
 __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
     const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + P<F32>::kRingBytes;
+    lds_char* xb = ring + P<M>::kRingBytes;
     lds_char* hb = xb + 32 * x_pitch;                   // THE hidden buffer: activations forward, gradients backward
     lds_char* hrow = hb + p * h_pitch;
     const int fx = (a.d_in + 31) / 32 * 32, mx = fx / 32;
-    Ring<F32> w;
+    Ring<M> w;
     w.start(ring, a.weights, ba.stream_frags, lane);   // forward fragments, then the transposed ones, as one stream
     zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
     for (long long rt = blockIdx.x; rt < ba.tiles; rt += gridDim.x) {
         const long long row0 = rt * 32;
         const bool live = row0 + p < a.n;
         const long long r = live ? row0 + p : a.n - 1;
-        char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<F32>::kWsFeat;
-        load_x<F32>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
-        if constexpr (!F32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
+        char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<M>::kWsFeat;
+        load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
+        if constexpr (!P<M>::kF32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
         for (int l = 0; l < a.n_layers; ++l) {
-#define NFX_RECOMPUTE(NT) recompute_layer<F32, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
+#define NFX_RECOMPUTE(NT) recompute_layer<M, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
             NFX_FOR_TILE_COUNT(a.layer[l].n_tiles, NFX_RECOMPUTE)
 #undef NFX_RECOMPUTE
-            if constexpr (!F32) {
+            if constexpr (!P<M>::kF32) {
                 if (l + 1 < a.n_layers) store_blocked(hb, h_pitch, a.layer[l].n_tiles * 32, wst, ba.b[l].h_row, lane);
             }
         }
@@ -527,15 +610,15 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
         bool dx_written = false;
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const Layer L = a.layer[l];
-            if constexpr (!F32) store_blocked(hb, h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
+            if constexpr (!P<M>::kF32) store_blocked(hb, h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
             const int kg_o = pad_group(2 * L.n_tiles) / kGroup;
-            const lds_char* zsrc = hrow + g * (P<F32>::kStep / 2);
+            const lds_char* zsrc = hrow + g * (P<M>::kStep / 2);
             if (L.ks_x > 0 && (ba.dx || l > 0)) {
                 for (int mt = 0; mt < mx; ++mt) {
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                    acc = tile_mma<F32>(acc, w, kg_o, 0, zsrc, zsrc);
+                    acc = tile_mma<M>(acc, w, kg_o, 0, zsrc, zsrc);
                     if (live && ba.dx) {
                         float* dst = ba.dx + (row0 + p) * ba.ld_dx;
 #pragma unroll
@@ -548,7 +631,7 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                 dx_written = true;
             }
             if (l > 0) {
-#define NFX_DGRAD(NT) dgrad_layer<F32, NT>(ba, l, w, hrow, g, p, wst)
+#define NFX_DGRAD(NT) dgrad_layer<M, NT>(ba, l, w, hrow, g, p, wst)
                 NFX_FOR_TILE_COUNT(a.layer[l - 1].n_tiles, NFX_DGRAD)
 #undef NFX_DGRAD
             }
@@ -567,8 +650,8 @@ __device__ __forceinline__ InTile in_tile(const WgradArgs& a, int l, int it) {
     if (it < mh) return {a.b[l - (l > 0)].h_row + 32 * it, prev - 32 * it, 32 * it};
     return {32 * (it - mh), a.d_in - 32 * (it - mh), prev + 32 * (it - mh)};
 }
-template <bool F32> struct Frag;
-template <> struct Frag<false> {
+template <int M> struct Frag;
+template <> struct Frag<kBf16> {
     bf16x8 v;
     __device__ __forceinline__ void load(const char* p) { v = *reinterpret_cast<const bf16x8*>(p); }
     __device__ __forceinline__ void ones() {
@@ -576,8 +659,22 @@ template <> struct Frag<false> {
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)1.0f;
     }
     static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mma_ones(const Frag& one, const Frag& b, f32x16 c) { return mma(one, b, c); }
 };
-template <> struct Frag<true> {
+template <> struct Frag<kX3> {      // 8 consecutive fp32 rows of one feature, split in registers (both operands are activations)
+    HiLo v;
+    __device__ __forceinline__ void load(const char* p) { v = split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 16)); }
+    __device__ __forceinline__ void ones() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v.hi[j] = (__bf16)1.0f; v.lo[j] = (__bf16)0.0f; }
+    }
+    static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return mma_x3(a.v.hi, a.v.lo, b.v, c); }
+    static __device__ __forceinline__ f32x16 mma_ones(const Frag& one, const Frag& b, f32x16 c) {      // (1 has no lo half)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.v.hi, b.v.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.v.hi, b.v.hi, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<kNative> {
     f32x4 lo, hi;
     __device__ __forceinline__ void load(const char* p) { lo = *reinterpret_cast<const f32x4*>(p); hi = *reinterpret_cast<const f32x4*>(p + 16); }
     __device__ __forceinline__ void ones() { lo = hi = f32x4{1.f, 1.f, 1.f, 1.f}; }
@@ -588,10 +685,11 @@ template <> struct Frag<true> {
         for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[i], b.hi[i], c, 0, 0, 0);
         return c;
     }
+    static __device__ __forceinline__ f32x16 mma_ones(const Frag& one, const Frag& b, f32x16 c) { return mma(one, b, c); }
 };
-template <bool F32>
+template <int M>
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
-    constexpr int E = P<F32>::kElem;
+    constexpr int E = P<M>::kElem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, g = lane >> 5;
     const long long wid = (long long)blockIdx.x * 4 + wave;
     if (wid >= (long long)a.n_jobs * a.splits) return;
@@ -613,22 +711,22 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     for (int q = 0; q < 16; ++q) acc[0][0][q] = acc[0][1][q] = acc[1][0][q] = acc[1][1][q] = accb[0][q] = accb[1][q] = 0.f;
     // the jobs of a layer's first input pair also sum their dZ columns: db[o] = sum over rows of 1 x dZ[row, o]
     const bool with_bias = ip == 0;
-    Frag<F32> ones;
+    Frag<M> ones;
     ones.ones();
 #pragma unroll 2
     for (long long t = t0; t < t1; ++t) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const size_t off = t * tile_bytes + 16 * E * kk;
-            Frag<F32> a0, a1, b0, b1;
+            Frag<M> a0, a1, b0, b1;
             a0.load(pa[0] + off); a1.load(pa[1] + off); b0.load(pb[0] + off); b1.load(pb[1] + off);
-            acc[0][0] = Frag<F32>::mma(a0, b0, acc[0][0]);
-            acc[0][1] = Frag<F32>::mma(a0, b1, acc[0][1]);
-            acc[1][0] = Frag<F32>::mma(a1, b0, acc[1][0]);
-            acc[1][1] = Frag<F32>::mma(a1, b1, acc[1][1]);
+            acc[0][0] = Frag<M>::mma(a0, b0, acc[0][0]);
+            acc[0][1] = Frag<M>::mma(a0, b1, acc[0][1]);
+            acc[1][0] = Frag<M>::mma(a1, b0, acc[1][0]);
+            acc[1][1] = Frag<M>::mma(a1, b1, acc[1][1]);
             if (with_bias) {
-                accb[0] = Frag<F32>::mma(ones, b0, accb[0]);
-                accb[1] = Frag<F32>::mma(ones, b1, accb[1]);
+                accb[0] = Frag<M>::mma_ones(ones, b0, accb[0]);
+                accb[1] = Frag<M>::mma_ones(ones, b1, accb[1]);
             }
         }
     }
@@ -669,6 +767,19 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_reduce_kernel(WgradArgs
         while (l + 1 < a.n_layers && a.b[l + 1].db_off <= idx) ++l;
         a.db[l][idx - a.b[l].db_off] += s;
     }
+}
+
+// NFX_PREC_FP32_NATIVE fragments ([half][lane][4 floats]) -> NFX_PREC_FP32 fragments ([hi plane | lo plane] of [lane][8 bf16]),
+// IN PLACE: thread (fragment, lane) reads exactly the 32 bytes it writes.  The device re-pack of an fp32-class blob is the
+// native blob's gather (ops.DevicePacker) followed by this.
+__global__ __launch_bounds__(256) void split_hilo_kernel(char* frags, long long n_frags) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((t >> 6) >= n_frags) return;
+    char* f = frags + (t >> 6) * 2048 + (t & 63) * 16;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(f), b = *reinterpret_cast<const f32x4*>(f + 1024);
+    const HiLo r = split8(a, b);
+    *reinterpret_cast<bf16x8*>(f) = r.hi;
+    *reinterpret_cast<bf16x8*>(f + 1024) = r.lo;
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
@@ -738,38 +849,54 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
 }  // namespace generic
 }  // namespace nfx
 
+// (one instantiation per operand mode, picked by Args::f32)
+#define NFX_FOR_MODE(mode, CALL)                 \
+    switch (mode) {                              \
+        case nfx::generic::kBf16: CALL(nfx::generic::kBf16); break;     \
+        case nfx::generic::kX3: CALL(nfx::generic::kX3); break;         \
+        default: CALL(nfx::generic::kNative); break;                    \
+    }
 extern "C" {
 int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (args->n <= 0) return 0;
     const long long tiles = (args->n + 31) / 32;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    const bool f32 = args->f32 != 0;
-    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (args->x_pitch + args->h_pitch);
-    const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    if (f32) hipLaunchKernelGGL(mlp_generic_kernel<true>, dim3(grid), dim3(64), lds, st, *args);
-    else hipLaunchKernelGGL(mlp_generic_kernel<false>, dim3(grid), dim3(64), lds, st, *args);
+    const int lds = (args->f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + 32 * (args->x_pitch + args->h_pitch);
+#define NFX_LAUNCH(MODE)                                                                                                 \
+    {                                                                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<MODE>),                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+        if (e != hipSuccess) return (int)e;                                                                              \
+        hipLaunchKernelGGL(mlp_generic_kernel<MODE>, dim3(grid), dim3(64), lds, st, *args);                              \
+    }
+    NFX_FOR_MODE(args->f32, NFX_LAUNCH)
+#undef NFX_LAUNCH
     return (int)hipGetLastError();
 }
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (ba->f.n <= 0) return 0;
     const int grid = (int)(ba->tiles < max_blocks ? ba->tiles : max_blocks);
-    const bool f32 = ba->f.f32 != 0;
-    const int lds = (f32 ? P<true>::kRingBytes : P<false>::kRingBytes) + 32 * (ba->f.x_pitch + ba->f.h_pitch);
-    const void* fn = f32 ? reinterpret_cast<const void*>(mlp_generic_bwd_kernel<true>) : reinterpret_cast<const void*>(mlp_generic_bwd_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    if (f32) hipLaunchKernelGGL(mlp_generic_bwd_kernel<true>, dim3(grid), dim3(64), lds, st, *ba);
-    else hipLaunchKernelGGL(mlp_generic_bwd_kernel<false>, dim3(grid), dim3(64), lds, st, *ba);
-    if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
-        const long long waves = (long long)wa->n_jobs * wa->splits;
-        if (f32) hipLaunchKernelGGL(mlp_generic_wgrad_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
-        else hipLaunchKernelGGL(mlp_generic_wgrad_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
-        hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
+    const int lds = (ba->f.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + 32 * (ba->f.x_pitch + ba->f.h_pitch);
+    const long long waves = (long long)wa->n_jobs * wa->splits;
+#define NFX_LAUNCH(MODE)                                                                                                 \
+    {                                                                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<MODE>),                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+        if (e != hipSuccess) return (int)e;                                                                              \
+        hipLaunchKernelGGL(mlp_generic_bwd_kernel<MODE>, dim3(grid), dim3(64), lds, st, *ba);                            \
+        if (wa->dw[0]) /* (no gradient buffers: the caller wants dLoss/dx only) */                                       \
+            hipLaunchKernelGGL(mlp_generic_wgrad_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa); \
     }
+    NFX_FOR_MODE(ba->f.f32, NFX_LAUNCH)
+#undef NFX_LAUNCH
+    if (wa->dw[0]) hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
+    return (int)hipGetLastError();
+}
+int nfx_launch_split_hilo(void* frags, long long n_frags, hipStream_t st) {
+    if (n_frags <= 0) return 0;
+    hipLaunchKernelGGL(nfx::generic::split_hilo_kernel, dim3((unsigned)((n_frags * 64 + 255) / 256)), dim3(256), 0, st, static_cast<char*>(frags), n_frags);
     return (int)hipGetLastError();
 }
 int nfx_launch_embed_bwd(const nfx::generic::EmbedArgs* a, const float* d_out, float* dv, hipStream_t st) {

@@ -56,6 +56,13 @@ class Model(torch.nn.Module):
         if self.grad_precision not in ('bf16', 'fp32') or (self.precision == 'bf16' and self.grad_precision == 'fp32'):
             raise ValueError("grad_precision = %s with precision = %s (bf16 | fp32; fp32 gradients need precision = fp32)"
                              % (self.grad_precision, self.precision))
+        # Which fp32 instantiation of the runtime-shaped kernels `precision = fp32` runs (csrc/mlp_generic.hip): `pairs`
+        # (default, round 5) = fp32 activations / gradients with bf16 hi / lo operand pairs on the bf16 matrix pipe — the
+        # arithmetic class of the tuned fp32 render kernels; `native` = fp32 operands on v_mfma_f32_32x32x2_f32.
+        self.fp32_matrix = config.get('DEFAULT', 'fp32_matrix', fallback='pairs')
+        if self.fp32_matrix not in ('pairs', 'native'):
+            raise ValueError("fp32_matrix = %s (pairs | native)" % self.fp32_matrix)
+        self.generic_prec = 'bf16' if self.precision == 'bf16' else ('fp32' if self.fp32_matrix == 'pairs' else 'fp32_native')
         self._blobs = {}  # packed-weight cache: key -> (versions, device blob)
         self._packers = {}  # key -> ops.DevicePacker
 

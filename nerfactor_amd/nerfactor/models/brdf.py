@@ -86,7 +86,7 @@ class Model(BaseModel):
         return brdf[:, None], reci[:, None]
 
     def _generic_net(self, train=False, prec=None):
-        prec = self.precision if prec is None else prec
+        prec = self.generic_prec if prec is None else prec
         ks, bs = self.net['brdf_mlp'].kernels_and_biases()
         ko, bo = self.net['brdf_out'].kernels_and_biases()
         body = self.net['brdf_mlp']
@@ -94,11 +94,7 @@ class Model(BaseModel):
         tag = ('brdf_generic_train' if train else 'brdf_generic') + prec
         descs = self.__dict__.setdefault('_generic_desc', {})
 
-        def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=prec)
-            descs.setdefault(tag, g)
-            return g.blob
-        blob = self._packed(tag, ks + ko + bs + bo, pack)
+        blob = self._packed(tag, ks + ko + bs + bo, ops.generic_pack_fn(acts, body.skip_at, train, prec, descs, tag))
         g = descs[tag]
         g.blob = blob
         return g

@@ -163,14 +163,10 @@ class Model(BaseModel):
         net = self.net[key]
         ks, bs = net.kernels_and_biases()
         acts = [l.activation for l in net.layers]
-        tag = key + ('generic_train' if train else 'generic') + self.precision
+        tag = key + ('generic_train' if train else 'generic') + self.generic_prec
         descs = self.__dict__.setdefault('_generic_desc', {})
 
-        def pack(k, b):
-            g = ops.GenericNet(k, b, acts, net.skip_at, train=train, prec=self.precision)
-            descs.setdefault(tag, g)
-            return g.blob
-        blob = self._packed(tag, ks + bs, pack)
+        blob = self._packed(tag, ks + bs, ops.generic_pack_fn(acts, net.skip_at, train, self.generic_prec, descs, tag))
         g = descs[tag]
         g.blob = blob
         return g

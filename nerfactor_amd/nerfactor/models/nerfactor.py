@@ -57,10 +57,15 @@ class Model(ShapeModel):
     def _init_brdf_model(self):
         self.brdf_model = BRDFModel(self.config_brdf)
         if not self.brdf_model.tuned:
-            raise NotImplementedError(
-                "NeRFactor evaluates the BRDF prior inside the fused shading kernels (nfx_brdf_spec_fwd / _bwd), which "
-                "implement the shipped prior (mlp_width = 128, mlp_depth = 4, mlp_skip_at = 2, n_freqs = 2); a prior of "
-                "another shape trains and tests on its own (models.brdf) but cannot be plugged in here")
+            # A prior of another shape than the shipped one (the reference builds whatever brdf.ini says,
+            # nerfactor.py:45-60) is evaluated on explicit rows: nfx_brdf_rows_geom_fwd / _bwd + the runtime-shaped MLP
+            # kernels (`_brdf_spec_rows`) instead of the fused shading kernels.  What that path needs:
+            emb = self.brdf_model.embedder['rusink']
+            zd = self.config_brdf.getint('DEFAULT', 'z_dim')
+            if not (getattr(emb, 'fusable', False) or (emb.incl_input and emb.n_freqs == 0)) or emb.n_freqs > 8 or zd > 8:
+                raise NotImplementedError(
+                    "a non-shipped BRDF prior inside NeRFactor needs z_dim <= 8 and a standard Rusinkiewicz embedder "
+                    "(input included, bands 2^k with k < n_freqs <= 8, sin / cos): nfx_brdf_rows_geom_fwd builds its rows")
         if configutil.ckpt_available(self._brdf_ckpt):
             configutil.restore_model(self.brdf_model, self._brdf_ckpt)
         for p in self.brdf_model.parameters():
@@ -289,6 +294,9 @@ class Model(ShapeModel):
     # ------------------------------------------------------------------ BRDF + rendering
     def _brdf_terms(self, xyz, cam, normal, brdf_prop):
         """kwargs for the shading kernels describing the BRDF: learned specular term [N, L]."""
+        if not self.brdf_model.tuned:      # a prior of a non-shipped shape: explicit rows + the runtime-shaped kernels
+            spec = self._brdf_spec_rows(xyz, cam, normal, brdf_prop)
+            return {'spec': spec, 'spec_scale': self.config.getfloat('DEFAULT', 'learned_brdf_scale')}
         blob = self._blob128('brdf_mlp', 'brdf_out', _capi.IN_Z_RUSINK, 1, z_dim=self.z_dim,
                              nets=self.brdf_model.net)
         spec = ops.brdf_spec_fwd(xyz, cam, normal, brdf_prop, self.lxyz.reshape(-1, 3), blob,
@@ -355,8 +363,8 @@ class Model(ShapeModel):
         latent z and the normal through nfx_brdf_spec_bwd) + the shading integral."""
         from nerfactor_amd import autograd as nfx_grad
         lxyz = self.lxyz.reshape(-1, 3)
-        if self.grad_precision == 'fp32':
-            spec = self._brdf_spec_fp32(xyz, cam, normal, brdf_prop)
+        if self.grad_precision == 'fp32' or not self.brdf_model.tuned:
+            spec = self._brdf_spec_rows(xyz, cam, normal, brdf_prop)
             return nfx_grad.ShadeSpec.apply(xyz, cam, lxyz, self.lareas,
                                             self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
                                             albedo, spec, light_vis, light)
@@ -375,32 +383,37 @@ class Model(ShapeModel):
                                         self.config.getfloat('DEFAULT', 'learned_brdf_scale'), to_srgb, normal,
                                         albedo, spec, light_vis, light)
 
-    def _brdf_spec_fp32(self, xyz, cam, normal, brdf_prop):
-        """spec[N, L] of the frozen prior at grad_precision = fp32 (nerfactor.py:413-461): the fused bf16 kernels
-        (nfx_brdf_spec_fwd / _bwd) have no fp32 instantiation, so the rows are assembled explicitly — local frames and
-        Rusinkiewicz angles in differentiable fp32 torch operations with the reference's custom gradients
-        (util/geom.py), the embedding and the prior's MLP on the fp32 runtime-shaped kernels (input gradients only: the
-        prior is frozen).  Gradients reach the normal (through the local frame) and the BRDF code z."""
+    def _brdf_spec_rows(self, xyz, cam, normal, brdf_prop):
+        """spec[N, L] of the frozen prior on EXPLICIT rows (nerfactor.py:413-461) — the path of grad_precision = fp32 (the
+        fused bf16 kernels nfx_brdf_spec_fwd / _bwd have no fp32 instantiation) and of a prior whose shape those kernels do
+        not implement.  The prior's input rows [z | embed(rusink)] of every (point, light) pair are made by ONE libnfx
+        kernel (local frames, Rusinkiewicz angles and the Embedder in fp32, csrc/brdf_rows_geom.hip) and the prior's MLP
+        runs on the runtime-shaped kernels (operands = `precision`; in a training call in their input-gradient mode: the
+        prior is frozen); the pull-back to the normal (with the reference's custom gradients of safe_acos / safe_atan2)
+        and to the BRDF code z is the twin kernel.  Back-lit rows are evaluated and multiplied by 0 instead of being
+        compacted away (nerfactor.py:429-434 masks them "for speed"): no data-dependent shape, no host round trip, so the
+        step can be captured in a hipGraph."""
         from nerfactor_amd import autograd as nfx_grad
-        from ..util import geom as geomutil
-        lxyz = self.lxyz.reshape(-1, 3)
+        lxyz = self.lxyz.reshape(-1, 3).contiguous()
         n, nl = xyz.shape[0], lxyz.shape[0]
-        pts2l = mathutil.safe_l2_normalize(lxyz[None, :, :] - xyz[:, None, :], axis=2)
-        pts2c = mathutil.safe_l2_normalize(cam - xyz, axis=1)
-        rot = geomutil.gen_world2local(normal)
-        vdir = torch.einsum('jkl,jl->jk', rot, pts2c)
-        ldir = torch.einsum('jkl,jnl->jnk', rot, pts2l).reshape(-1, 3)
-        front = torch.nonzero(ldir[:, 2] > 0)[:, 0]
-        vrep = vdir[:, None, :].expand(n, nl, 3).reshape(-1, 3)
-        rusink = geomutil.dir2rusink_autograd(ldir[front], vrep[front])
-        z = brdf_prop[:, None, :].expand(n, nl, brdf_prop.shape[1]).reshape(-1, brdf_prop.shape[1])[front]
         prior = self.brdf_model
-        rows = torch.cat((z, nfx_grad.Embed.apply(rusink, prior.embedder['rusink'].n_freqs)), 1)
-        ks, bs = prior.net['brdf_mlp'].kernels_and_biases()
-        ko, bo = prior.net['brdf_out'].kernels_and_biases()
-        y = nfx_grad.GenericMlp.apply(rows, lambda: prior._generic_net(train=True, prec='fp32'), *(ks + ko + bs + bo))
-        spec = torch.zeros(n * nl, dtype=torch.float32, device=xyz.device).index_put((front,), y[:, 0])
-        return spec.reshape(n, nl)
+        nf = prior.embedder['rusink'].n_freqs
+        if torch.is_grad_enabled() and (normal.requires_grad or brdf_prop.requires_grad):
+            rows, front = nfx_grad.BrdfRowsGeom.apply(xyz, cam, lxyz, nf, normal, brdf_prop)
+            ks, bs = prior.net['brdf_mlp'].kernels_and_biases()
+            ko, bo = prior.net['brdf_out'].kernels_and_biases()
+            y = nfx_grad.GenericMlp.apply(rows, lambda: prior._generic_net(train=True, prec=self.generic_prec),
+                                          *(ks + ko + bs + bo))
+            return (y[:, 0] * front).reshape(n, nl)
+        spec = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
+        per = max(1, self.mlp_chunk // nl)          # (rows of mlp_chunk / L points at a time, like chunk_apply)
+        net = prior._generic_net(prec=self.generic_prec)
+        for i in range(0, n, per):
+            sl = slice(i, i + per)
+            rows, front = ops.brdf_rows_geom_fwd(xyz[sl], cam[sl], normal[sl].detach(), brdf_prop[sl].detach(), lxyz, nf)
+            y = ops.mlp_generic_fwd(rows, net)
+            spec[sl] = (y[:, 0] * front).reshape(-1, nl)
+        return spec
 
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):

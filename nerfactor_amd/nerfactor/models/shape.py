@@ -160,14 +160,10 @@ class Model(BaseModel):
         ks, bs = body.kernels_and_biases()
         ko, bo = head.kernels_and_biases()
         acts = [l.activation for l in body.layers] + [out_act]
-        tag = body_name + ('generic_train' if train else 'generic') + self.precision
+        tag = body_name + ('generic_train' if train else 'generic') + self.generic_prec
         descs = self.__dict__.setdefault('_generic_desc', {})
 
-        def pack(k, b):
-            g = ops.GenericNet(k, b, acts, body.skip_at, train=train, prec=self.precision)
-            descs.setdefault(tag, g)
-            return g.blob
-        blob = self._packed(tag, ks + ko + bs + bo, pack)
+        blob = self._packed(tag, ks + ko + bs + bo, ops.generic_pack_fn(acts, body.skip_at, train, self.generic_prec, descs, tag))
         g = descs[tag]
         g.blob = blob
         return g

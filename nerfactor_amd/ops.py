@@ -8,9 +8,12 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import PREC_BF16, PREC_FP32, check, lib
+from ._capi import PREC_BF16, PREC_FP32, PREC_FP32_NATIVE, check, lib
 
-_PREC = {'bf16': PREC_BF16, 'fp32': PREC_FP32, PREC_BF16: PREC_BF16, PREC_FP32: PREC_FP32}
+# 'fp32' = fp32-class (bf16 hi / lo operand pairs on the bf16 matrix pipe); 'fp32_native' (runtime-shaped kernels only) = fp32
+# operands on the native fp32 matrix instruction
+_PREC = {'bf16': PREC_BF16, 'fp32': PREC_FP32, 'fp32_native': PREC_FP32_NATIVE, PREC_BF16: PREC_BF16, PREC_FP32: PREC_FP32,
+         PREC_FP32_NATIVE: PREC_FP32_NATIVE}
 _ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2, 'softplus': 3}
 
 
@@ -70,7 +73,13 @@ class DevicePacker:
     (0 = padding).  A probe with every parameter = 1 + 2^-20 tells fp32 words from bf16 pairs."""
 
     def __init__(self, pack_fn, shapes_k, shapes_b):
+        # a packer whose blob is NOT a gather (the hi / lo fragments of the runtime-shaped kernels' fp32-class mode) may
+        # name one that is (`pack_fn.gather_fn`: the same blob with fp32 fragments) plus the device pass that turns the
+        # gathered blob into its own (`pack_fn.post(blob)`, in place): the map is derived from gather_fn, the one-time
+        # bit-for-bit check still runs against pack_fn itself
         self.pack_fn = pack_fn
+        self.post = getattr(pack_fn, 'post', None)
+        map_fn = getattr(pack_fn, 'gather_fn', pack_fn)
         self.shapes = [tuple(s) for s in list(shapes_k) + list(shapes_b)]
         self.nk = len(shapes_k)
         sizes = [int(np.prod(s)) for s in self.shapes]
@@ -79,7 +88,7 @@ class DevicePacker:
         offs = np.cumsum([0] + sizes)
 
         def run(arrays):
-            return pack_fn(arrays[:self.nk], arrays[self.nk:]).numpy()
+            return map_fn(arrays[:self.nk], arrays[self.nk:]).numpy()
 
         # probe: every parameter = 1 + 2^-20 -> an fp32 word reads 0x3f800008, a bf16 half 0x3f80 (or 0 = padding)
         probe = run([np.full(s, 1. + 2. ** -20, np.float32) for s in self.shapes]).view(np.uint32)
@@ -122,6 +131,8 @@ class DevicePacker:
         blob = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
         check(lib.nfx_pack_gather(_ptr(src), _ptr(self._dev[dev]), self.n_words, _ptr(blob), _stream()),
               'nfx_pack_gather')
+        if self.post is not None:
+            self.post(blob)
         if not self._checked:   # once per network: the device gather must reproduce the host packer bit for bit
             want = self.pack_fn(list(tensors[:self.nk]), list(tensors[self.nk:]))
             if not torch.equal(blob.cpu(), want):
@@ -259,8 +270,9 @@ class GenericNet:
     """A packed mlp.Network of arbitrary shape for mlp_generic_fwd / mlp_generic_bwd: blob (uint8 tensor, move it with
     .to(device)) + the layer description the C-ABI takes.  skip_at: the reference's list (after layer i the input is
     re-concatenated, y first: nerfactor/networks/mlp.py:47-48).  train = True packs the train blob (forward fragments +
-    transposed fragments for the backward); the forward accepts either.  prec = 'fp32': fp32 fragments for the kernels'
-    fp32 instantiation (native fp32 matrix instruction, nothing rounded to bf16)."""
+    transposed fragments for the backward); the forward accepts either.  prec = 'fp32': fp32-class — fp32 activations and
+    gradients, every MFMA operand a bf16 hi / lo pair (fragments pre-split by the packer); prec = 'fp32_native': fp32
+    fragments for the native fp32 matrix instruction (nothing rounded to bf16, ~5x the matrix time)."""
 
     def __init__(self, kernels, biases, acts, skip_at=None, train=False, prec='bf16'):
         ks = [_as_host_f32(k) for k in kernels]
@@ -299,6 +311,30 @@ class GenericNet:
     def to(self, device):
         self.blob = self.blob.to(device)
         return self
+
+
+def generic_split_hilo(blob, net):
+    """In place, on the device: the fragments of a prec = 'fp32_native' blob of `net`'s shape -> prec = 'fp32' (hi / lo pairs)."""
+    if not blob.is_cuda or blob.dtype != torch.uint8:
+        raise _capi.NfxError("generic_split_hilo: blob must be a CUDA uint8 tensor")
+    check(lib.nfx_mlp_generic_split_hilo(_ptr(blob), net.d_in, net.n_layers, net._w, net._s, int(net.train), _stream()),
+          'nfx_mlp_generic_split_hilo')
+    return blob
+
+
+def generic_pack_fn(acts, skip_at, train, prec, descs, tag):
+    """The `pack_fn(kernels, biases) -> host blob` the models hand to their blob cache (models/base.py:_packed) for a
+    runtime-shaped network; the first call leaves the GenericNet (layer description) in descs[tag].  fp32-class blobs
+    carry what ops.DevicePacker needs to rebuild them on the device: the native-fp32 packer (a pure gather) and the
+    in-place hi / lo split."""
+    def pack(k, b):
+        g = GenericNet(k, b, acts, skip_at, train=train, prec=prec)
+        descs.setdefault(tag, g)
+        return g.blob
+    if _PREC[prec] == PREC_FP32:
+        pack.gather_fn = lambda k, b: GenericNet(k, b, acts, skip_at, train=train, prec='fp32_native').blob
+        pack.post = lambda blob: generic_split_hilo(blob, descs[tag])
+    return pack
 
 
 def mlp_generic_fwd(x, net, out=None, col0=0):
@@ -499,6 +535,37 @@ def shade_olat_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, olat_inten, amb
                                  spec_scale, f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
                                  n, nl, int(linear2srgb), _ptr(out), _stream()), 'nfx_shade_olat_fwd')
     return out
+
+
+def brdf_rows_geom_fwd(xyz, cam, normal, z, lxyz, n_freqs):
+    """(rows [n L, z_dim + 3 + 6 n_freqs], front [n L]) of the learned BRDF in fp32: rows = [z | embed(rusink)] per (point,
+    light), front = 1.0 where the light is in front of the surface (nerfactor.py:413-436)."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    cam, normal = _dev(cam, 'cam', (n, 3)), _dev(normal, 'normal', (n, 3))
+    z = _dev(z, 'z', (n, None))
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    nl, zd = lxyz.shape[0], z.shape[1]
+    rows = torch.empty((n * nl, zd + 3 + 6 * n_freqs), dtype=torch.float32, device=xyz.device)
+    front = torch.empty((n * nl,), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_brdf_rows_geom_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(z), zd, _ptr(lxyz), nl, n, n_freqs, _ptr(rows),
+                                     rows.shape[1], _ptr(front), _stream()), 'nfx_brdf_rows_geom_fwd')
+    return rows, front
+
+
+def brdf_rows_geom_bwd(xyz, cam, normal, z_dim, lxyz, n_freqs, d_rows):
+    """(d_normal [n, 3], d_z [n, z_dim]) from dLoss/d rows of brdf_rows_geom_fwd, summed over each point's front-lit lights."""
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    cam, normal = _dev(cam, 'cam', (n, 3)), _dev(normal, 'normal', (n, 3))
+    lxyz = _dev(lxyz, 'lxyz', (None, 3))
+    nl = lxyz.shape[0]
+    d_rows = _dev(d_rows, 'd_rows', (n * nl, z_dim + 3 + 6 * n_freqs))
+    d_normal = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
+    d_z = torch.empty((n, z_dim), dtype=torch.float32, device=xyz.device)
+    check(lib.nfx_brdf_rows_geom_bwd(_ptr(xyz), _ptr(cam), _ptr(normal), z_dim, _ptr(lxyz), nl, n, n_freqs, _ptr(d_rows),
+                                     d_rows.shape[1], _ptr(d_normal), _ptr(d_z), _stream()), 'nfx_brdf_rows_geom_bwd')
+    return d_normal, d_z
 
 
 def dir2rusink(a, b):

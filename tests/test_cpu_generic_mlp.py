@@ -130,7 +130,7 @@ def test_train_blob_is_the_forward_blob_plus_transposed_fragments(nfx_lib, d_in,
 
 @pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 5], [0]), (27, [40, 200, 33], [0, 1])])
 def test_fp32_blob_has_the_same_stream_with_two_kib_fragments(nfx_lib, d_in, widths, skip_at):
-    """prec = 'fp32': [biases | forward | transposed] with fp32 fragments laid out [half][lane][4 floats] — element
+    """prec = 'fp32_native': [biases | forward | transposed] with fp32 fragments laid out [half][lane][4 floats] — element
     (lane, i) is the one the bf16 blob holds at [lane][i], unrounded; same fragment order, same zero padding."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(d_in + 1)
@@ -143,7 +143,7 @@ def test_fp32_blob_has_the_same_stream_with_two_kib_fragments(nfx_lib, d_in, wid
     n_bias = sum(((w + 31) // 32) * 32 for w in widths)
     for train in (False, True):
         b16 = ops.GenericNet(ks, bs, acts, skip_at, train=train).blob.numpy()
-        b32 = ops.GenericNet(ks, bs, acts, skip_at, train=train, prec='fp32').blob.numpy()
+        b32 = ops.GenericNet(ks, bs, acts, skip_at, train=train, prec='fp32_native').blob.numpy()
         assert np.array_equal(b16[:4 * n_bias], b32[:4 * n_bias])
         f16 = (b16[4 * n_bias:].view(np.uint16).reshape(-1, 64, 8).astype(np.uint32) << 16).view(np.float32)
         f32 = b32[4 * n_bias:].view(np.float32).reshape(-1, 2, 64, 4).transpose(0, 2, 1, 3).reshape(-1, 64, 8)
@@ -153,12 +153,13 @@ def test_fp32_blob_has_the_same_stream_with_two_kib_fragments(nfx_lib, d_in, wid
         assert np.isin(f32[f32 != 0], flat).all()                 # and the fp32 one holds the parameters themselves
 
 
-@pytest.mark.parametrize("prec,train", [('bf16', False), ('bf16', True), ('fp32', True)])
+@pytest.mark.parametrize("prec,train", [('bf16', False), ('bf16', True), ('fp32_native', True), ('fp32', True)])
 def test_generic_blobs_are_gathers_the_device_repacks(nfx_lib, prec, train):
     """A training step never re-packs on the host: ops.DevicePacker derives an index map from the host packer and the
     device gathers (nfx_pack_gather).  That needs the blob to be a pure gather of the parameters — bf16 halves or fp32
-    words; unlike the hi / lo blobs of the tuned fp32-class kernels, the fp32 runtime-shaped blob is one.  Here the map
-    is applied with NumPy: it must reproduce the host packer on fresh random parameters."""
+    words; unlike the hi / lo blobs of the tuned fp32-class kernels, the native-fp32 runtime-shaped blob is one, and the
+    fp32-class blob (prec = 'fp32') is that gather followed by the in-place hi / lo split.  Here the map is applied with
+    NumPy: it must reproduce the host packer on fresh random parameters."""
     from nerfactor_amd import ops
     d_in, widths, skip_at = 27, [40, 72, 5], [0]
     acts = ['relu', 'relu', None]
@@ -167,8 +168,9 @@ def test_generic_blobs_are_gathers_the_device_repacks(nfx_lib, prec, train):
         shapes_k.append((prev, w))
         prev = w + (d_in if i in skip_at else 0)
     shapes_b = [(w,) for w in widths]
-    pack_fn = lambda k, b: ops.GenericNet(k, b, acts, skip_at, train=train, prec=prec).blob
+    pack_fn = ops.generic_pack_fn(acts, skip_at, train, prec, {}, 't')
     packer = ops.DevicePacker(pack_fn, shapes_k, shapes_b)
+    assert (packer.post is not None) == (prec == 'fp32')
     rng = np.random.default_rng(3)
     ks = [rng.normal(size=s).astype(np.float32) for s in shapes_k]
     bs = [rng.normal(size=s).astype(np.float32) for s in shapes_b]
@@ -184,6 +186,49 @@ def test_generic_blobs_are_gathers_the_device_repacks(nfx_lib, prec, train):
         return np.where(i >= 0, (torch.from_numpy(src[np.maximum(i, 0)]).to(torch.bfloat16).view(torch.int16).numpy()
                                  .astype(np.uint32) & 0xffff), 0)
     got[~f32] = half(0) | (half(1) << 16)
+    if prec == 'fp32':                                            # (the device pass behind the gather, restated below)
+        got = _split_native(got.view(np.uint8), 4 * sum(((w + 31) // 32) * 32 for w in widths))[0].view(np.uint32)
     assert np.array_equal(got, want)
-    if prec == 'fp32':                                            # fp32 blob: every word a whole parameter, or padding
+    if prec != 'bf16':                                            # fp32 blob: every word a whole parameter, or padding
         assert (m[~f32] == -1).all()
+
+
+def _split_native(native, n_bias_bytes):
+    """NumPy restatement of csrc/mlp_generic.hip:split_hilo_kernel: fp32 fragments [half][lane][4] -> [hi plane | lo plane]
+    of [lane][8] bf16, hi = bf16(w) (round to nearest even), lo = bf16(w - hi)."""
+    out = native.copy()
+    fr = native[n_bias_bytes:].view(np.float32).reshape(-1, 2, 64, 4)                 # [frag][half][lane][r]
+    w = fr.transpose(0, 2, 1, 3).reshape(-1, 64, 8)                                   # [frag][lane][i = 4 half + r]
+    hi = bf(w)
+    lo = bf(w - hi)
+    planes = np.stack([hi, lo], 1)                                                    # [frag][plane][lane][8]
+    out[n_bias_bytes:] = (planes.view(np.uint32) >> 16).astype(np.uint16).reshape(-1).view(np.uint8)
+    return out, w, hi, lo
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("d_in,widths,skip_at", [(63, [96, 96, 96, 96, 5], [1]), (90, [128, 128, 128, 128, 1], [2]), (27, [40, 200, 33], [0, 1])])
+def test_fp32_class_blob_is_the_split_native_blob(nfx_lib, d_in, widths, skip_at, train):
+    """prec = 'fp32' (bf16 hi / lo operand pairs, round 5) packs the SAME fragments as prec = 'fp32_native', each split
+    into a hi and a lo plane in the bf16 fragment's lane order: that identity is what lets the device re-pack be the
+    native blob's gather followed by one in-place pass (ops.generic_pack_fn), and hi + lo carries 16 significant bits."""
+    from nerfactor_amd import ops
+    rng = np.random.default_rng(len(widths) + d_in)
+    ks, bs, prev = [], [], d_in
+    for i, w in enumerate(widths):
+        ks.append((rng.normal(size=(prev, w)) * 0.2).astype(np.float32))
+        bs.append((rng.normal(size=w) * 0.1).astype(np.float32))
+        prev = w + (d_in if skip_at and i in skip_at else 0)
+    acts = ['relu'] * (len(widths) - 1) + [None]
+    pairs = ops.GenericNet(ks, bs, acts, skip_at, train=train, prec='fp32').blob.numpy()
+    native = ops.GenericNet(ks, bs, acts, skip_at, train=train, prec='fp32_native').blob.numpy()
+    assert pairs.shape == native.shape
+    n_bias = 4 * sum(((w + 31) // 32) * 32 for w in widths)
+    want, w, hi, lo = _split_native(native, n_bias)
+    assert np.array_equal(pairs, want)
+    assert np.array_equal(pairs[:n_bias], native[:n_bias])                # biases stay fp32
+    assert np.abs(hi + lo - w).max() <= 2. ** -16 * np.abs(w).max()
+    # the map ops.DevicePacker derives comes from the native packer; the fp32-class packer names it
+    fn = ops.generic_pack_fn(acts, skip_at, train, 'fp32', {}, 't')
+    assert np.array_equal(fn.gather_fn(ks, bs).numpy(), native) and callable(fn.post)
+    assert not hasattr(ops.generic_pack_fn(acts, skip_at, train, 'bf16', {}, 't'), 'post')
