@@ -622,29 +622,41 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         parity = reference_steps.summary(tag, reference_steps.metrics(tag, rmodel, rlosses, rgrad1))
     fp32_block = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.precision == 'bf16':
-        # the same step at the reference's own arithmetic (precision = fp32 -> grad_precision = fp32: fp32 operands, native
-        # fp32 matrix instruction, forward and backward: csrc/mlp_generic.hip) — its time, and its gradients held to the
-        # reference's fp32 gradients directly
-        torch.manual_seed(5)
-        m32 = get_model_class(name)(make_config(name, precision='fp32', **extra)).to(dev)
-        o32 = optim.make_optimizer(m32, m32.config)
-        for _ in range(3):
-            optim.train_step(m32, batch, o32, global_bs)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            optim.train_step(m32, batch, o32, global_bs)
-        torch.cuda.synchronize()
-        dt32 = (time.perf_counter() - t0) / 10
-        m32.flush_numerics(block=True)
+        # the same step at the reference's arithmetic class (precision = fp32 -> grad_precision = fp32: fp32 activations and
+        # gradients, every MFMA operand a bf16 hi / lo pair, forward and backward: csrc/mlp_generic.hip, round 5) — its
+        # time, its gradients held to the reference's fp32 gradients directly, and the time of the same step on the native
+        # fp32 matrix instruction (fp32_matrix = native, round 4's path) beside it
+        def time_fp32(fp32_matrix, graph):
+            torch.manual_seed(5)
+            m32 = get_model_class(name)(make_config(name, precision='fp32', fp32_matrix=fp32_matrix, **extra)).to(dev)
+            o32 = optim.make_optimizer(m32, m32.config)
+            step32 = optim.GraphedTrainStep(m32, o32, global_bs) if graph else (lambda b: optim.train_step(m32, b, o32, global_bs))
+            for _ in range(6 if graph else 3):
+                step32(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step32(batch)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t0) / 10
+            m32.flush_numerics(block=True)
+            return dt32 * 1e3
+        ms32 = {"eager": time_fp32('pairs', False), "native_fp32_mfma_eager": time_fp32('native', False)}
+        if name != 'nerf' and not args.no_hip_graph:
+            try:
+                ms32["hip_graph"] = time_fp32('pairs', True)
+            except Exception as e:      # (a capture failure must not take the whole line down)
+                ms32["hip_graph_error"] = str(e)[:200]
         tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev, 'fp32')
         p32 = reference_steps.metrics_fp32(tag, rmodel, rlosses, rgrad1)
         p32.pop('grads')
-        fp32_block = {"what": "the same step with precision = fp32: every network forward and backward in fp32 "
-                              "(v_mfma_f32_32x32x2_f32, nfx_mlp_generic_fwd / _bwd)" + (
-                                  "; the frozen learned BRDF on explicit fp32 rows (local frames and Rusinkiewicz angles "
-                                  "in fp32 torch operations) instead of inside the bf16 shading kernels" if name == 'nerfactor' else ""),
-                      "ms_per_step": dt32 * 1e3, "parity": p32}
+        fp32_block = {"what": "the same step with precision = fp32: every network forward and backward with fp32 activations / "
+                              "gradients and bf16 hi / lo operand pairs (3 x v_mfma_f32_32x32x16_bf16 per product, "
+                              "nfx_mlp_generic_fwd / _bwd with NFX_PREC_FP32)" + (
+                                  "; the frozen learned BRDF on explicit fp32 rows (nfx_brdf_rows_geom_fwd / _bwd) instead of "
+                                  "inside the bf16 shading kernels" if name == 'nerfactor' else ""),
+                      "ms_per_step": min(v for k, v in ms32.items() if k in ('eager', 'hip_graph')),
+                      "ms_per_step_by_mode": ms32, "parity": p32}
     return {
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),
         "parity": parity, "fp32": fp32_block,

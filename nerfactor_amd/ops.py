@@ -332,8 +332,14 @@ def generic_pack_fn(acts, skip_at, train, prec, descs, tag):
         descs.setdefault(tag, g)
         return g.blob
     if _PREC[prec] == PREC_FP32:
-        pack.gather_fn = lambda k, b: GenericNet(k, b, acts, skip_at, train=train, prec='fp32_native').blob
-        pack.post = lambda blob: generic_split_hilo(blob, descs[tag])
+        shape = {}       # (the layer description nfx_mlp_generic_split_hilo takes: the same for both fp32 layouts)
+
+        def gather(k, b):
+            g = GenericNet(k, b, acts, skip_at, train=train, prec='fp32_native')
+            shape.setdefault('net', g)
+            return g.blob
+        pack.gather_fn = gather
+        pack.post = lambda blob: generic_split_hilo(blob, shape['net'])
     return pack
 
 

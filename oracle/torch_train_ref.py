@@ -51,6 +51,15 @@ def bf16_ste(t):
     return t + (t.detach().float().to(torch.bfloat16).to(t.dtype) - t.detach())
 
 
+def pairs_ste(t):
+    """The fp32-class operand of csrc/mlp_x3.hpp / mlp_generic.hip (NFX_PREC_FP32): the fp32 value as a bf16 hi / lo pair —
+    hi = bf16(v), lo = bf16(v - hi), 16 significant bits — with a straight-through gradient."""
+    v = t.detach().float()
+    hi = v.to(torch.bfloat16).float()
+    lo = (v - hi).to(torch.bfloat16).float()
+    return t + ((hi + lo).to(t.dtype) - t.detach())
+
+
 def mlp(x, P, name, n_layers, acts, skip_at=None):
     q = QUANT if QUANT is not None else (lambda t: t)
     h = x

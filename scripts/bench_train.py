@@ -30,6 +30,8 @@ def main():
                          'reach the weights: operand data changes the clock)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'],
                     help="fp32: grad_precision = fp32, every network forward and backward on the fp32 runtime-shaped kernels")
+    ap.add_argument('--fp32-matrix', default='pairs', choices=['pairs', 'native'],
+                    help="precision = fp32: bf16 hi / lo operand pairs (default, round 5) or the native fp32 matrix instruction")
     ap.add_argument('--model', default='nerfactor_microfacet',
                     choices=['nerfactor_microfacet', 'nerfactor', 'shape', 'nerf'])
     args = ap.parse_args()
@@ -44,7 +46,7 @@ def main():
     rank, world = nfx_dist.init_from_env(backend='nccl', device=dev)
     torch.manual_seed(5)  # identical initial weights on every rank (MirroredStrategy semantics)
     extra = dict(shape_mode='finetune', shape_model_ckpt='none', test_envmap_dir='') if 'nerfactor' in args.model else {}
-    cfg = make_config(args.model, precision=args.precision, **extra)
+    cfg = make_config(args.model, precision=args.precision, fp32_matrix=args.fp32_matrix, **extra)
     model = get_model_class(args.model)(cfg).to(dev)
     opt = optim.make_optimizer(model, cfg)
     rng = np.random.default_rng(100 + rank)
@@ -94,7 +96,7 @@ def main():
             flops, what = 3 * 2 * (rows * 72320 + 2 * 3 * n * 65664), "512 lights, jitter on"
         print(json.dumps({
             "workload": "%s train step, %d rays/GPU (weak), %s%s, precision = %s" % (
-                args.model, n, what, ", hipGraph" if args.graph else "", args.precision),
+                args.model, n, what, ", hipGraph" if args.graph else "", args.precision + ("" if args.precision == 'bf16' else " (%s)" % args.fp32_matrix)),
             "n_gpus": world, "ms_per_step": dt * 1e3, "rays_per_s": n * world / dt,
             "mlp_flops_per_step_per_gpu": flops, "mlp_tflops": flops / dt / 1e12,
             "final_loss": float(loss)}))

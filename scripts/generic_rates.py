@@ -42,8 +42,12 @@ def main():
             ('nerf_enc_256x8', 63, [256] * 8, ['relu'] * 8, [4], 1 << 18, 'bf16'),
             ('surface_128x4_lvis', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 21, 'bf16'),
             ('narrow_64x4', 39, [64] * 4 + [4], ['relu'] * 4 + [None], [1], 1 << 20, 'bf16'),
+            # 'fp32' = fp32-class: bf16 hi / lo operand pairs (round 5); 'fp32_native' = v_mfma_f32_32x32x2_f32
             ('nerf_enc_256x8_fp32', 63, [256] * 8, ['relu'] * 8, [4], 1 << 17, 'fp32'),
-            ('surface_128x4_lvis_fp32', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 19, 'fp32')):
+            ('surface_128x4_lvis_fp32', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 19, 'fp32'),
+            ('brdf_prior_128x4_fp32', 18, [128] * 4 + [1], ['relu'] * 4 + ['softplus'], [2], 1 << 19, 'fp32'),
+            ('nerf_enc_256x8_fp32_native', 63, [256] * 8, ['relu'] * 8, [4], 1 << 17, 'fp32_native'),
+            ('surface_128x4_lvis_fp32_native', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 19, 'fp32_native')):
         g, ks, bs, macs = net(d_in, widths, acts, skip, rng, prec)
         x = torch.randn((n, d_in), device=cuda)
         dy = torch.randn((n, widths[-1]), device=cuda)

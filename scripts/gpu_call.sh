@@ -44,7 +44,7 @@ PYEOF
     fitted)   timeout 600 python scripts/fitted_outliers.py > $OUT/fitted_outliers.json 2>&1; cat $OUT/fitted_outliers.json ;;
     pytest-k) timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_FLAGS:-} -k "$PYTEST_K" > $OUT/pytest_gpu_k.log 2>&1; tail -${TAILN:-30} $OUT/pytest_gpu_k.log ;;
     bench-train) timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; tail -c 2500 $OUT/bench_train.json; tail -3 $OUT/bench_train.err ;;
-    bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
+    bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do for fm in "pairs" "pairs --graph" "native"; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --fp32-matrix $fm --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
     soak-xp)  NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_build.log 2>&1; tail -16 $OUT/soak_experiment_build.log ;;
     generic)  timeout 600 python scripts/generic_rates.py > $OUT/generic_rates.json 2> $OUT/generic_rates.err; cat $OUT/generic_rates.json; tail -3 $OUT/generic_rates.err ;;

@@ -84,7 +84,7 @@ def check(tag, model, losses, grad1):
     return m
 
 
-def run_nerfactor(tag, cuda, precision='bf16'):
+def run_nerfactor(tag, cuda, precision='bf16', **cfg_overrides):
     """-> (model, losses of the 10 steps, gradients of step 1) for 'nfm' (microfacet) | 'nfl' (learned BRDF)."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
@@ -92,7 +92,7 @@ def run_nerfactor(tag, cuda, precision='bf16'):
     learned = tag == 'nfl'
     name = 'nerfactor' if learned else 'nerfactor_microfacet'
     cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='',
-                      light_tv_weight='2e-4', light_achro_weight='1e-4', precision=precision)
+                      light_tv_weight='2e-4', light_achro_weight='1e-4', precision=precision, **cfg_overrides)
     model = get_model_class(name)(cfg)
     for part, pairs in gi.nerfactor_net(3 if learned else 1).items():
         set_net(model.net, part, pairs)
@@ -122,13 +122,13 @@ def run_nerfactor(tag, cuda, precision='bf16'):
     return model, losses, grad1
 
 
-def run_nerf(cuda, precision='bf16'):
+def run_nerf(cuda, precision='bf16', **cfg_overrides):
     """The NeRF step with the reference's tf.random.uniform draws (stratified coarse samples, inverse-CDF fine
     samples) replayed through torch.rand."""
     from nerfactor_amd import optim
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.models import get_model_class
-    cfg = make_config('nerf', precision=precision)
+    cfg = make_config('nerf', precision=precision, **cfg_overrides)
     assert cfg.getboolean('DEFAULT', 'perturb') and cfg.getfloat('DEFAULT', 'noise_std') == 0.
     model = get_model_class('nerf')(cfg)
     for pref, net in zip(('coarse_', 'fine_'), common.nerf_nets(seed=gi.NERF_SEED)):
@@ -164,15 +164,22 @@ def run_nerf(cuda, precision='bf16'):
 
 
 # precision = fp32 (grad_precision = fp32: every network forward and backward on the fp32 runtime-shaped kernels): each
-# gradient tensor of step 1 against the REFERENCE's fp32 gradient itself, no bf16-oracle detour.  What is left is fp32
-# summation order plus the ReLU masks / inverse-CDF bins that flip under it.  'nfl': the frozen learned BRDF is evaluated
-# on explicit fp32 rows there (models/nerfactor.py:_brdf_spec_fp32) instead of inside the bf16 shading kernels; its
-# 10-step trajectory is the loosest of the four (1.7e-3: AMSGrad normalises every element's gradient, so elements whose
-# gradient sits at the optimizer's epsilon move by up to lr whichever way their last bit falls).
+# gradient tensor of step 1 against the REFERENCE's fp32 gradient itself, no bf16-oracle detour.
+# fp32_matrix = native (fp32 operands, v_mfma_f32_32x32x2_f32): what is left is fp32 summation order plus the ReLU masks /
+# inverse-CDF bins that flip under it.  'nfl': the frozen learned BRDF is evaluated on explicit fp32 rows there
+# (models/nerfactor.py:_brdf_spec_rows) instead of inside the bf16 shading kernels; its 10-step trajectory is the loosest of
+# the four (1.7e-3: AMSGrad normalises every element's gradient, so elements whose gradient sits at the optimizer's epsilon
+# move by up to lr whichever way their last bit falls).
+# fp32_matrix = pairs (the default since round 5: fp32 activations / gradients, bf16 hi / lo operand pairs = 16 significant
+# bits per operand): every product is good to ~1e-5, but pre-activations that far from float32's flip ~1e-5 of the ReLU
+# masks, and a flipped mask moves its whole path (tests/test_gpu_generic.py::test_generic_mlp_backward_vs_oracle measures
+# the effect in isolation) — its bound is PAIRS_TOL.
 FP32_TOL = {'nfm': 1e-3, 'nerf': 1e-3, 'brdf': 1e-3, 'nfl': 1e-3}
+PAIRS_TOL = {'nfm': 1e-2, 'nerf': 1e-2, 'brdf': 1e-2, 'nfl': 1e-2}
 
 
 def metrics_fp32(tag, model, losses, grad1):
+    tol = (PAIRS_TOL if getattr(model, 'fp32_matrix', 'native') == 'pairs' else FP32_TOL)[tag]
     want_losses = np.asarray(FIX[tag + '/loss'], dtype=np.float64)
     losses = np.asarray(losses, dtype=np.float64)
     fro = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
@@ -186,15 +193,15 @@ def metrics_fp32(tag, model, losses, grad1):
             "gradient_tensors": len(report), "grad_rel_frobenius_vs_reference_worst": worst[1], "worst_tensor": worst[0],
             "loss_step1_rel_err": float(abs(losses[0] / want_losses[0] - 1)),
             "loss_trajectory_max_rel_err": float(np.max(np.abs(losses / want_losses - 1))),
-            "tolerance": {"grad_vs_reference": FP32_TOL[tag]}, "grads": report}
+            "fp32_matrix": getattr(model, 'fp32_matrix', 'native'), "tolerance": {"grad_vs_reference": tol}, "grads": report}
 
 
 def check_fp32(tag, model, losses, grad1):
     m = metrics_fp32(tag, model, losses, grad1)
     top = sorted(m['grads'].items(), key=lambda kv: -kv[1])[:4]
-    print(tag, 'fp32: gradient rel-Frobenius vs the reference, worst:', [(n, float('%.2e' % v)) for n, v in top],
+    print(tag, 'fp32 (%s): gradient rel-Frobenius vs the reference, worst:' % m['fp32_matrix'], [(n, float('%.2e' % v)) for n, v in top],
           'loss step 1 rel', m['loss_step1_rel_err'], 'trajectory', m['loss_trajectory_max_rel_err'])
-    assert m['grad_rel_frobenius_vs_reference_worst'] < FP32_TOL[tag], top
+    assert m['grad_rel_frobenius_vs_reference_worst'] < m['tolerance']['grad_vs_reference'], top
     loose = tag == 'nfl'
     assert m['loss_step1_rel_err'] < (2e-3 if loose else 1e-4), m['loss_step1_rel_err']
     assert m['loss_trajectory_max_rel_err'] < (5e-3 if loose else 1e-3), m['loss_trajectory_max_rel_err']

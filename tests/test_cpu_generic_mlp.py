@@ -171,6 +171,14 @@ def test_generic_blobs_are_gathers_the_device_repacks(nfx_lib, prec, train):
     pack_fn = ops.generic_pack_fn(acts, skip_at, train, prec, {}, 't')
     packer = ops.DevicePacker(pack_fn, shapes_k, shapes_b)
     assert (packer.post is not None) == (prec == 'fp32')
+    if prec == 'fp32':     # the split pass gets the layer description from the gather packer's own run (no GPU: a stand-in)
+        seen = []
+        real, ops.generic_split_hilo = ops.generic_split_hilo, lambda blob, net: seen.append((net.d_in, net.widths, net.train))
+        try:
+            packer.post(None)
+        finally:
+            ops.generic_split_hilo = real
+        assert seen == [(d_in, widths, train)]
     rng = np.random.default_rng(3)
     ks = [rng.normal(size=s).astype(np.float32) for s in shapes_k]
     bs = [rng.normal(size=s).astype(np.float32) for s in shapes_b]

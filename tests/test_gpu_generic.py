@@ -176,7 +176,7 @@ def _oracle_grads(x, layers, acts, skip_at, dy, want_dx, quant=True):
         P['net_m_layer%d.kernel' % i] = torch.tensor(k, dtype=torch.float64, requires_grad=True)
         P['net_m_layer%d.bias' % i] = torch.tensor(b, dtype=torch.float64, requires_grad=True)
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=want_dx)
-    T.QUANT = T.bf16_ste if quant else None
+    T.QUANT = {True: T.bf16_ste, 'bf16': T.bf16_ste, 'pairs': T.pairs_ste, False: None, None: None}[quant]
     try:
         y = T.mlp(xt, P, 'm', len(layers), acts, skip_at)
     finally:
@@ -222,9 +222,17 @@ def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_
         dx = ops.mlp_generic_bwd(dev(x, cuda), net, dev(dy, cuda), dks, dbs, want_dx=True)
         return dks, dbs, dx
     dks, dbs, dx = run(0.)
-    wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True, quant=prec == 'bf16')
-    # (fp32, nine layers deep: fp32 against float64 pre-activations flips a few ReLU masks at 0 — 2.3e-4 measured)
+    # prec = 'fp32' is held to the float64 network evaluated on the SAME 16-bit operands (oracle pairs_ste): against the plain
+    # float64 network its pre-activations sit ~1e-5 off, so ~1e-5 of the ReLU masks of a large batch differ, and a differing
+    # mask moves its whole path: relative Frobenius ~ sqrt(fraction) = 4e-3 (128 x 3, 20 000 rows) and 9e-3 (256 x 8) measured
+    # (r05 call A) where the products themselves are good to 1e-5 — asserted loosely below.  The native fp32 instruction shows
+    # the same effect at its own rounding (nine layers: 2.3e-4 measured).
+    wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True, quant={'bf16': 'bf16', 'fp32': 'pairs', 'fp32_native': None}[prec])
     tol = 2e-2 if prec == 'bf16' else ((2e-5 if prec == 'fp32_native' else 2e-4) if len(widths) <= 5 else (5e-4 if prec == 'fp32_native' else 1e-3))
+    if prec == 'fp32':
+        pk, pb, px = _oracle_grads(x, layers, acts, skip_at, dy, True, quant=None)
+        for got, want in list(zip(dks, pk)) + list(zip(dbs, pb)) + [(dx, px)]:
+            assert _rel(got.cpu().numpy(), want) < 3e-2, _rel(got.cpu().numpy(), want)
     for i in range(len(layers)):
         assert _rel(dks[i].cpu().numpy(), wk[i]) < tol, ('kernel', i, _rel(dks[i].cpu().numpy(), wk[i]))
         assert _rel(dbs[i].cpu().numpy(), wb[i]) < tol, ('bias', i, _rel(dbs[i].cpu().numpy(), wb[i]))
@@ -479,7 +487,7 @@ def test_nerf_geometry_of_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
     head = ('sigma_out', 1) if kw.get('use_views', True) else ('rgbs_out', 1)
 
     def reference(quant):
-        T.QUANT = T.bf16_ste if quant else None
+        T.QUANT = {True: T.bf16_ste, 'bf16': T.bf16_ste, 'pairs': T.pairs_ste, False: None, None: None}[quant]
         try:
             x = torch.tensor(pts, dtype=torch.float64, requires_grad=True)
             feat = T.mlp(T.embed(x, lx), P, 'fine_enc', depth, ['relu'] * depth, [depth // 2])
