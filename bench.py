@@ -641,21 +641,23 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
             dt32 = (time.perf_counter() - t0) / 10
             m32.flush_numerics(block=True)
             return dt32 * 1e3
-        ms32 = {"eager": time_fp32('pairs', False), "native_fp32_mfma_eager": time_fp32('native', False)}
+        default_mode = get_model_class(name).DEFAULT_FP32_MATRIX      # pairs for the surface models, native for NeRF
+        ms32 = {"pairs_eager": time_fp32('pairs', False), "native_eager": time_fp32('native', False)}
         if name != 'nerf' and not args.no_hip_graph:
             try:
-                ms32["hip_graph"] = time_fp32('pairs', True)
+                ms32["pairs_hip_graph"] = time_fp32('pairs', True)
             except Exception as e:      # (a capture failure must not take the whole line down)
-                ms32["hip_graph_error"] = str(e)[:200]
+                ms32["pairs_hip_graph_error"] = str(e)[:200]
         tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev, 'fp32')
         p32 = reference_steps.metrics_fp32(tag, rmodel, rlosses, rgrad1)
         p32.pop('grads')
-        fp32_block = {"what": "the same step with precision = fp32: every network forward and backward with fp32 activations / "
-                              "gradients and bf16 hi / lo operand pairs (3 x v_mfma_f32_32x32x16_bf16 per product, "
-                              "nfx_mlp_generic_fwd / _bwd with NFX_PREC_FP32)" + (
+        fp32_block = {"what": "the same step with precision = fp32: every network forward and backward through nfx_mlp_generic_fwd / "
+                              "_bwd with fp32 activations, gradients and workspace; fp32_matrix = pairs: bf16 hi / lo operand "
+                              "pairs, 3 x v_mfma_f32_32x32x16_bf16 per product; native: v_mfma_f32_32x32x2_f32" + (
                                   "; the frozen learned BRDF on explicit fp32 rows (nfx_brdf_rows_geom_fwd / _bwd) instead of "
                                   "inside the bf16 shading kernels" if name == 'nerfactor' else ""),
-                      "ms_per_step": min(v for k, v in ms32.items() if k in ('eager', 'hip_graph')),
+                      "fp32_matrix_default": default_mode,
+                      "ms_per_step": min(v for k, v in ms32.items() if k.startswith(default_mode) and isinstance(v, float)),
                       "ms_per_step_by_mode": ms32, "parity": p32}
     return {
         "workload": "%s optim.train_step, %d rays per GPU and step (weak), %s" % (name, n, what),

@@ -30,8 +30,13 @@
 //   * ALL weights (forward + dgrad, 248-304 KiB per tile from L2) stream through the 5-slot LDS-DMA ring of
 //     mlp128_bwd.hip, extended by the 14 dgrad sub-chunks: with no store in the tile loop the counted vmcnt waits see
 //     DMA pieces (and the tile's few input loads, which only make a wait conservative).
-// LDS: ring 40 KiB | biases | X rows | H rows | dZ rows = 145 536 bytes (row pitch = slots x 2 + 32 bytes: the four
-// rows of a transposing read land on distinct banks, and so do the 16-byte row stores of 8 consecutive lanes).
+// LDS: ring 40 KiB | biases | X rows | H rows | dZ rows = 141 568 bytes.  The three row buffers are [128 rows][64 dwords]
+// with NO padding and an XOR swizzle of the dword index by the row (swz_bytes below, round 5).  Round 4 padded the rows to
+// 72 dwords: under the LDS's banking rules (MI355X_MICROARCH.md: ds_write_b128 = 8 lanes x 4 dwords over 32 banks,
+// ds_read_b64_tr_b16 = 32 lanes x 2 dwords over 64 banks, ds_read_b128 = 16 lanes x 4 dwords over 64 banks) that pitch makes
+// every row store AND every transposing read a 2-way conflict — 816 of the 2640 LDS cycles of a PART-1 tile by that model,
+// 29 % by the counters (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r04/pmc_train_digest.json).  No pitch serves
+// both (stores want the row stride = 4 mod 8 dwords, the transposing reads = 16 mod 64); the swizzle does.
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"
 #include "mlp128_train_layout.hpp"
@@ -46,7 +51,33 @@ constexpr int kR = 5, kD = 4, kSlot = 8192;
 constexpr int kFwdSub = 21;   // sub-chunks per tile: forward 0-20, dgrad through `out` 21-22, W3 23-26, W2 27-30, W1 31-34
 // PART 0 (layers 3 and out) stops behind dZ3: 23 sub-chunks per tile; PART 1 (layers 2, 1, 0) runs the whole chain: 35
 constexpr int sub_n(int part) { return part == 0 ? 23 : 35; }
-constexpr int kHPitch = 128 * 2 + 32;     // bytes per row of the H / dZ buffers
+constexpr int kHPitch = 128 * 2;          // bytes per row of the X / H / dZ buffers (64 dwords, swizzled)
+// Physical byte offset inside a row = logical offset ^ swz_bytes(row) (bits 4-7 = dword bits 2-5):
+//   dword bits 4-5 ^= row bits 0-1   -> the 4 consecutive rows of a transposing read (16 contiguous dwords each) fall into
+//                                       the four 16-dword quarters of the 64 banks;
+//   dword bits 2-3 ^= (row bits 1, 2) ^ row bit 3 -> with bit 4 the 8 consecutive rows of a ds_write_b128 lane group get 8
+//                                       distinct 4-dword spans of the 32 store banks, and the 16 rows of a ds_read_b128 lane
+//                                       group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) 16 distinct spans of the 64.
+__device__ __forceinline__ int swz_bytes(int row) {
+    const int b0 = row & 1, b1 = (row >> 1) & 1, b2 = (row >> 2) & 1, b3 = (row >> 3) & 1;
+    return ((b1 ^ b3) << 4) | ((b2 ^ b3) << 5) | (b0 << 6) | (b1 << 7);
+}
+// this lane's byte offset (from the buffer's start) of a transposing read: rows 8 (q >> 1) + 4 hi + (i >> 2) (+ 16 kk: not
+// in the swizzle), slots [32 tile + 16 (q & 1) + 4 (i & 3), + 4) — tr16.hpp:tr_lane_off with the swizzle applied
+__device__ __forceinline__ int tr_swz_off(int lane, int tile, int hi) {
+    const int i = lane & 15, q = lane >> 4;
+    const int row = 8 * (q >> 1) + 4 * hi + (i >> 2);
+    return row * kHPitch + ((tile * 64 + 32 * (q & 1) + 8 * (i & 3)) ^ swz_bytes(row));
+}
+struct TrOff {      // per lane: offsets of the lo / hi half of an operand for column tiles 0..3 and for this wave's own tile
+    int lo[4], hi[4], mylo[1], myhi[1];
+};
+__device__ __forceinline__ bf16x8 tr_frag2(const char* lo_p, const char* hi_p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo_p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi_p));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 template <int KSX, int NS>
 struct Sub {
@@ -72,13 +103,12 @@ static_assert(Sub<4, 35>::off(kFwdSub) == Geo<4>::kFwdFrags && Sub<4, 35>::off(3
 
 template <int KSX>
 struct Lds {
-    static constexpr int kXPitch = KSX * 32 + 32;   // KSX k-steps x 16 slots x 2 B + pad
     static constexpr int kBias = kR * kSlot;
-    static constexpr int kX = kBias + m128::kMainBiasFloats * 4;   // PART 0: the input rows (pitch kXPitch); PART 1: h0 (pitch kHPitch)
+    static constexpr int kX = (kBias + m128::kMainBiasFloats * 4 + 255) / 256 * 256;   // PART 0: the input rows (KSX k-steps of the 8 a row holds); PART 1: h0
     static constexpr int kH = kX + kRows * kHPitch;
     static constexpr int kDZ = kH + kRows * kHPitch;
     static constexpr int kTotal = kDZ + kRows * kHPitch;
-    static_assert(kX % 16 == 0 && kH % 16 == 0 && kDZ % 16 == 0 && kXPitch % 16 == 0, "16-byte rows");
+    static_assert(kX % 256 == 0 && kH % 256 == 0 && kDZ % 256 == 0, "rows start on bank 0");
     static_assert(kTotal <= 160 * 1024, "LDS");
 };
 
@@ -178,7 +208,7 @@ __device__ __forceinline__ void relu_tile(const f32x16& acc, bf16x8& lo, bf16x8&
 // `park` (optional): the tile's two output k-steps go to this lane's parked row in LDS as soon as they exist
 template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
 __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[4],
-                                      char* park = nullptr) {
+                                      char* park = nullptr, int lx = 0) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
@@ -187,9 +217,9 @@ __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (
         mma<KS>(cx, b, 0, acc[0]);
         end<KSX, NS, K0 + t>(cx);
         relu_tile<BITS>(acc[0], out[2 * t][0], out[2 * t + 1][0], mk[t]);
-        if (park != nullptr) {
-            *reinterpret_cast<bf16x8*>(park + (2 * t) * 32) = out[2 * t][0];
-            *reinterpret_cast<bf16x8*>(park + (2 * t + 1) * 32) = out[2 * t + 1][0];
+        if (park != nullptr) {      // (the lane's swizzled row: k-step s at park + ((32 s) ^ lx), see store_rows)
+            *reinterpret_cast<bf16x8*>(park + (((2 * t) * 32) ^ lx)) = out[2 * t][0];
+            *reinterpret_cast<bf16x8*>(park + (((2 * t + 1) * 32) ^ lx)) = out[2 * t + 1][0];
         }
     });
 }
@@ -198,14 +228,15 @@ __device__ __forceinline__ void zero_acc(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 // ReLU mask of tile t of a layer.  MODE 0: from the re-computed activation in registers; 1: from its mask bits; 2: from the
-// activation parked in LDS (`park` = this lane's row and half: k-step s at park + 32 s — exactly what store_rows wrote).
+// activation parked in LDS (`park` = this lane's row, `lx` its swizzled half: k-step s at park + ((32 s) ^ lx) — exactly
+// what store_rows wrote).
 template <int MODE>
 __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
-                                          const char* park, int t, bf16x8& olo, bf16x8& ohi) {
+                                          const char* park, int lx, int t, bf16x8& olo, bf16x8& ohi) {
     u32x4 plo, phi;
     if constexpr (MODE == 2) {
-        plo = *reinterpret_cast<const u32x4*>(park + (2 * t) * 32);
-        phi = *reinterpret_cast<const u32x4*>(park + (2 * t + 1) * 32);
+        plo = *reinterpret_cast<const u32x4*>(park + (((2 * t) * 32) ^ lx));
+        phi = *reinterpret_cast<const u32x4*>(park + (((2 * t + 1) * 32) ^ lx));
     } else if constexpr (MODE == 0) {
         plo = __builtin_bit_cast(u32x4, hact[2 * t][0]);
         phi = __builtin_bit_cast(u32x4, hact[2 * t + 1][0]);
@@ -228,7 +259,7 @@ __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact
 // dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation
 template <int KSX, int NS, int K0, int MODE>
 __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
-                                      const char* park, bf16x8 (&dout)[8][1]) {
+                                      const char* park, int lx, bf16x8 (&dout)[8][1]) {
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
@@ -236,31 +267,36 @@ __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const b
         zero_acc(acc[0]);
         mma<8>(cx, dz, 0, acc[0]);
         end<KSX, NS, K0 + t>(cx);
-        relu_mask<MODE>(acc[0], hact, mk, park, t, dout[2 * t][0], dout[2 * t + 1][0]);
+        relu_mask<MODE>(acc[0], hact, mk, park, lx, t, dout[2 * t][0], dout[2 * t + 1][0]);
     });
 }
 
 // ---- rows -> LDS, LDS -> row-contracting MFMA operands
-// lane (row p, half h) stores the 8 slots of k-step s at row * pitch + s * 32 + h * 16: slot index = 16 s + 8 h + j
+// lane (row p, half h) stores the 8 slots of k-step s (slot index = 16 s + 8 h + j) at logical byte s * 32 + h * 16 of its
+// row, physical (s * 32) ^ lx with lx = (h * 16) ^ swz_bytes(row): one v_xor per store instead of an immediate offset
 template <int KS, int KSA>
-__device__ __forceinline__ void store_rows(char* row_half, const bf16x8 (&v)[KSA][1]) {
+__device__ __forceinline__ void store_rows(char* row, int lx, const bf16x8 (&v)[KSA][1]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(row_half + s * 32) = v[s][0];
+    for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(row + ((s * 32) ^ lx)) = v[s][0];
 }
 // acc[i] += A(tile i of the buffer at `a`, pitch APITCH)^T-contracted-over-rows with B = this wave's dZ tile at `b`.
 // bsum (optional): + the sum of the B operand's 8 rows — lane (slot n, k-group g) adds its rows of every k-step, so the
 // column sum of slot n (the bias gradient) is bsum of lane n + bsum of lane n + 32.  v_dot2c_f32_bf16 with a (1, 1)
 // operand adds two rows per instruction: 4 VALU per k-step instead of a 16-register all-ones MFMA block.
-template <int NI, int APITCH, int A0, int NA>
-__device__ __forceinline__ void wgrad(const char* a, const char* b, f32x16 (&acc)[NA], float* bsum) {
+// `a`, `b`: the buffers' starts; A tiles i < NI at the lane's offsets alo[i] / ahi[i] (MINE: the wave's own tile), B at
+// blo / bhi; the 16 rows of k-step kk are an immediate offset (kk * 4 KiB: outside the swizzle).
+template <int NI, int A0, int NA, int NO>
+__device__ __forceinline__ void wgrad(const char* a, const int (&alo)[NO], const int (&ahi)[NO], const char* b, int blo, int bhi,
+                                      f32x16 (&acc)[NA], float* bsum) {
+    static_assert(NI <= NO, "offsets");
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     const b2 ones = {(__bf16)1.f, (__bf16)1.f};
 #pragma unroll
     for (int kk = 0; kk < kRows / 16; ++kk) {
-        const bf16x8 bf = tr_frag<kHPitch>(b + kk * 16 * kHPitch);
+        const bf16x8 bf = tr_frag2(b + blo + kk * 16 * kHPitch, b + bhi + kk * 16 * kHPitch);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const bf16x8 af = tr_frag<APITCH>(a + kk * 16 * APITCH + i * 64);
+            const bf16x8 af = tr_frag2(a + alo[i] + kk * 16 * kHPitch, a + ahi[i] + kk * 16 * kHPitch);
             acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[A0 + i], 0, 0, 0);
         }
         if (bsum != nullptr) {
@@ -312,14 +348,22 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave, 0};
     // this lane's row of the three row-major buffers (stores) and its gather origin (transposing reads)
     const int row_local = wave * 32 + p;
-    char* xrow = smem + L::kX + row_local * L::kXPitch + h * 16;     // PART 0: input rows
-    char* h0row = smem + L::kX + row_local * kHPitch + h * 16;       // PART 1: h0 parked in the same region
-    char* hrow = smem + L::kH + row_local * kHPitch + h * 16;
-    char* zrow = smem + L::kDZ + row_local * kHPitch + h * 16;
-    const char* xa = smem + L::kX + tr_lane_off(lane, L::kXPitch);
-    const char* ha = smem + L::kH + tr_lane_off(lane, kHPitch);
-    const char* h0a = smem + L::kX + tr_lane_off(lane, kHPitch);
-    const char* zb = smem + L::kDZ + tr_lane_off(lane, kHPitch) + wave * 64;   // dZ slots [32 wave, 32 wave + 32)
+    const int lx = (h * 16) ^ swz_bytes(row_local);                  // this lane's half of its (swizzled) row
+    char* xrow = smem + L::kX + row_local * kHPitch;                 // PART 0: input rows; PART 1: h0 parked in the same region
+    char* hrow = smem + L::kH + row_local * kHPitch;
+    char* zrow = smem + L::kDZ + row_local * kHPitch;
+    char* const h0row = xrow;
+    const char* const xa = smem + L::kX;
+    const char* const ha = smem + L::kH;
+    const char* const za = smem + L::kDZ;
+    TrOff tr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tr.lo[i] = tr_swz_off(lane, i, 0);
+        tr.hi[i] = tr_swz_off(lane, i, 1);
+    }
+    tr.mylo[0] = tr_swz_off(lane, wave, 0);                             // the wave's own tile: dZ slots [32 wave, 32 wave + 32)
+    tr.myhi[0] = tr_swz_off(lane, wave, 1);
     f32x16 acc[B::NACC];
 #pragma unroll
     for (int i = 0; i < B::NACC; ++i) zero_acc(acc[i]);
@@ -384,7 +428,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             xin[4][0] = pl[0][0];
             xin[5][0] = pl[1][0];
         }
-        if constexpr (PART == 0) store_rows<KSX>(xrow, xin);   // the input rows: read by the W3 step of this tile
+        if constexpr (PART == 0) store_rows<KSX>(xrow, lx, xin);   // the input rows: read by the W3 step of this tile
         // ------------------------------------------------------------------ forward (re-computed)
         bf16x8 h0[8][1], h1[8][1], h2[8][1], h3[8][1];
         // PART 1 multiplies h1, h0 and the input.  h0 and h1 are PARKED in LDS the moment they exist (h0 in the region
@@ -394,8 +438,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         // PART 0 stops behind dZ3 and needs no mask below h3.
         unsigned m2[4], m3[4];
         constexpr bool kBits = PART == 1;
-        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr);
-        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr);
+        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr, lx);
+        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr, lx);
         layer<KSX, NS, 8, 8, kBits>(cx, bias_lds + 256, h1, h2, m2);
         static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
             constexpr int t = decltype(T)::value;
@@ -423,10 +467,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             dzo[0][0][4 + r] = (__bf16)0.f;
         }
         if constexpr (PART == 0) {   // out layer: dWo[i, f] = sum h3[row, i] dZo[row, f]; wave w takes h3 slots [32 w, +32)
-            store_rows<8>(hrow, h3);
-            store_rows<1>(zrow, dzo);
+            store_rows<8>(hrow, lx, h3);
+            store_rows<1>(zrow, lx, dzo);
             lds_barrier();
-            wgrad<1, kHPitch, B::kOut>(ha + wave * 64, zb - wave * 64, acc, &bsum0);
+            wgrad<1, B::kOut>(ha, tr.mylo, tr.myhi, za, tr.lo[0], tr.hi[0], acc, &bsum0);
         }
         // ------------------------------------------------------------------ dgrad chain + weight gradients
         bf16x8 dz3[8][1];
@@ -440,32 +484,32 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
                 mma<1>(cx, dzo, 0, a0[0]);
                 mma<1>(cx, dzo, 4, a1[0]);
                 end<KSX, NS, 21 + u>(cx);
-                relu_mask<kBits ? 1 : 0>(a0[0], h3, m3, nullptr, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
-                relu_mask<kBits ? 1 : 0>(a1[0], h3, m3, nullptr, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
+                relu_mask<kBits ? 1 : 0>(a0[0], h3, m3, nullptr, 0, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
+                relu_mask<kBits ? 1 : 0>(a1[0], h3, m3, nullptr, 0, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
             });
         }
         if constexpr (PART == 0) {   // W3 = [h2 ; input]^T dZ3 (the two ring barriers above separate it from the out step)
-            store_rows<8>(hrow, h2);
-            store_rows<8>(zrow, dz3);
+            store_rows<8>(hrow, lx, h2);
+            store_rows<8>(zrow, lx, dz3);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW3h>(ha, zb, acc, nullptr);
-            wgrad<NX, L::kXPitch, B::kW3x>(xa, zb, acc, nullptr);
+            wgrad<4, B::kW3h>(ha, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, nullptr);
+            wgrad<NX, B::kW3x>(xa, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, nullptr);
             lds_barrier();   // the next tile's first statement rewrites the X rows
         } else {
             bf16x8 dz2[8][1], dz1[8][1], dz0[8][1];
-            dgrad<KSX, NS, 23, 1>(cx, dz3, h2, m2, nullptr, dz2);   // W3[:128, :]
-            store_rows<8>(zrow, dz2);
+            dgrad<KSX, NS, 23, 1>(cx, dz3, h2, m2, nullptr, 0, dz2);   // W3[:128, :]
+            store_rows<8>(zrow, lx, dz2);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW2>(ha, zb, acc, &bsum0);           // A = h1, parked in the H buffer by the forward
-            dgrad<KSX, NS, 27, 2>(cx, dz2, h1, m2, hrow, dz1);        // W2; mask = this lane's parked h1 row
-            store_rows<8>(zrow, dz1);
+            wgrad<4, B::kW2>(ha, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, &bsum0);   // A = h1, parked in the H buffer by the forward
+            dgrad<KSX, NS, 27, 2>(cx, dz2, h1, m2, hrow, lx, dz1);     // W2; mask = this lane's parked h1 row
+            store_rows<8>(zrow, lx, dz1);
             lds_barrier();
-            wgrad<4, kHPitch, B::kW1>(h0a, zb, acc, &bsum1);          // A = h0, parked in the X region
-            dgrad<KSX, NS, 31, 2>(cx, dz1, h0, m2, h0row, dz0);       // W1; mask = the parked h0 row
-            store_rows<KSX>(hrow, xin);                               // the input rows take the H buffer (h1 is done with)
-            store_rows<8>(zrow, dz0);
+            wgrad<4, B::kW1>(xa, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, &bsum1);   // A = h0, parked in the X region
+            dgrad<KSX, NS, 31, 2>(cx, dz1, h0, m2, h0row, lx, dz0);    // W1; mask = the parked h0 row
+            store_rows<KSX>(hrow, lx, xin);                            // the input rows take the H buffer (h1 is done with)
+            store_rows<8>(zrow, lx, dz0);
             lds_barrier();
-            wgrad<NX, kHPitch, B::kW0>(ha, zb, acc, nullptr);
+            wgrad<NX, B::kW0>(ha, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, nullptr);
             lds_barrier();   // the next tile's forward parks h1 in the H buffer again
         }
     }

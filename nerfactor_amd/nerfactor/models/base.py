@@ -39,6 +39,8 @@ def _png_pool():
 
 
 class Model(torch.nn.Module):
+    DEFAULT_FP32_MATRIX = 'pairs'
+
     def __init__(self, config, debug=False):
         super().__init__()
         self.config = config
@@ -57,9 +59,13 @@ class Model(torch.nn.Module):
             raise ValueError("grad_precision = %s with precision = %s (bf16 | fp32; fp32 gradients need precision = fp32)"
                              % (self.grad_precision, self.precision))
         # Which fp32 instantiation of the runtime-shaped kernels `precision = fp32` runs (csrc/mlp_generic.hip): `pairs`
-        # (default, round 5) = fp32 activations / gradients with bf16 hi / lo operand pairs on the bf16 matrix pipe — the
-        # arithmetic class of the tuned fp32 render kernels; `native` = fp32 operands on v_mfma_f32_32x32x2_f32.
-        self.fp32_matrix = config.get('DEFAULT', 'fp32_matrix', fallback='pairs')
+        # (round 5) = fp32 activations / gradients with bf16 hi / lo operand pairs on the bf16 matrix pipe — the arithmetic
+        # class of the tuned fp32 render kernels, 1.7-1.9x the step rate of `native` = fp32 operands on
+        # v_mfma_f32_32x32x2_f32.  The default is per model (DEFAULT_FP32_MATRIX): `pairs` where its gradients stay within
+        # the 1e-3 of the reference's that tests/reference_steps.py:FP32_TOL states (the surface models and the BRDF prior:
+        # <= 4.9e-4 measured), `native` for NeRF, whose 8 x 256 network and inverse-CDF sampler turn pre-activations 1e-6
+        # off into 1.8e-2 on its worst gradient tensor (ReLU masks and sample bins that hang on the last bits).
+        self.fp32_matrix = config.get('DEFAULT', 'fp32_matrix', fallback=self.DEFAULT_FP32_MATRIX)
         if self.fp32_matrix not in ('pairs', 'native'):
             raise ValueError("fp32_matrix = %s (pairs | native)" % self.fp32_matrix)
         self.generic_prec = 'bf16' if self.precision == 'bf16' else ('fp32' if self.fp32_matrix == 'pairs' else 'fp32_native')

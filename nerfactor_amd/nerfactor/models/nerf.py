@@ -16,6 +16,8 @@ from .base import Model as BaseModel
 
 
 class Model(BaseModel):
+    DEFAULT_FP32_MATRIX = 'native'      # (models/base.py: where `pairs` leaves the stated 1e-3 of the reference's gradients)
+
     def __init__(self, config, debug=False):
         super().__init__(config, debug=debug)
         cfg = self.config

@@ -170,12 +170,14 @@ def run_nerf(cuda, precision='bf16', **cfg_overrides):
 # (models/nerfactor.py:_brdf_spec_rows) instead of inside the bf16 shading kernels; its 10-step trajectory is the loosest of
 # the four (1.7e-3: AMSGrad normalises every element's gradient, so elements whose gradient sits at the optimizer's epsilon
 # move by up to lr whichever way their last bit falls).
-# fp32_matrix = pairs (the default since round 5: fp32 activations / gradients, bf16 hi / lo operand pairs = 16 significant
-# bits per operand): every product is good to ~1e-5, but pre-activations that far from float32's flip ~1e-5 of the ReLU
-# masks, and a flipped mask moves its whole path (tests/test_gpu_generic.py::test_generic_mlp_backward_vs_oracle measures
-# the effect in isolation) — its bound is PAIRS_TOL.
+# fp32_matrix = pairs (round 5: fp32 activations / gradients, bf16 hi / lo operand pairs = 16 significant bits per operand;
+# the default of the surface models and the BRDF prior): every product is good to ~1e-5, but pre-activations ~1e-6 from
+# float32's flip a few of the ReLU masks of a batch, and a flipped mask moves its whole path
+# (tests/test_gpu_generic.py::test_generic_mlp_backward_vs_oracle isolates the effect).  Measured (r05 call B): nfm 4.9e-4,
+# nfl 3.2e-4, brdf 4.8e-6 — inside the SAME 1e-3 — and NeRF 1.8e-2 (8 x 256 layers, plus fine samples that hop an
+# inverse-CDF bin), which is why NeRF's default stays `native`; PAIRS_TOL states what the opt-in costs there.
 FP32_TOL = {'nfm': 1e-3, 'nerf': 1e-3, 'brdf': 1e-3, 'nfl': 1e-3}
-PAIRS_TOL = {'nfm': 1e-2, 'nerf': 1e-2, 'brdf': 1e-2, 'nfl': 1e-2}
+PAIRS_TOL = {'nfm': 1e-3, 'nerf': 5e-2, 'brdf': 1e-3, 'nfl': 1e-3}
 
 
 def metrics_fp32(tag, model, losses, grad1):

@@ -50,3 +50,18 @@ def test_grad_precision_follows_precision_and_rejects_the_impossible_pair():
         build('nerf', grad_precision='fp32')
     with pytest.raises(ValueError, match='grad_precision'):
         build('shape', precision='fp32', grad_precision='fp16')
+
+
+def test_fp32_matrix_defaults_per_model_and_is_an_ini_key():
+    """precision = fp32 runs the runtime-shaped kernels with bf16 hi / lo operand pairs where that keeps the gradients
+    within the stated 1e-3 of the reference's (surface models, BRDF prior) and with the native fp32 matrix instruction for
+    NeRF; `fp32_matrix` overrides either way; precision = bf16 never reaches an fp32 instantiation."""
+    assert build('nerf', precision='fp32').fp32_matrix == 'native' and build('nerf', precision='fp32').generic_prec == 'fp32_native'
+    for name in ('shape', 'brdf'):
+        m = build(name, precision='fp32')
+        assert m.fp32_matrix == 'pairs' and m.generic_prec == 'fp32'
+    assert build('nerf', precision='fp32', fp32_matrix='pairs').generic_prec == 'fp32'
+    assert build('shape', precision='fp32', fp32_matrix='native').generic_prec == 'fp32_native'
+    assert build('shape').generic_prec == 'bf16' and build('nerf', fp32_matrix='native').generic_prec == 'bf16'
+    with pytest.raises(ValueError, match='fp32_matrix'):
+        build('shape', precision='fp32', fp32_matrix='tf32')

@@ -201,8 +201,9 @@ def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_
     propagated gradient and the transposed weights to bf16 as well (two more 2^-9 roundings per layer), the oracle's
     straight-through backward does not.  prec = 'fp32_native': against the PLAIN float64 autograd, 2e-5 of each tensor's
     norm (nothing is rounded to bf16; the sums are fp32); prec = 'fp32' (hi / lo operand pairs in all three products —
-    forward, dgrad, weight gradients): 2e-4, a hundredth of the bf16 bound.  Bit-identical between calls; ADDS into the
-    gradient buffers."""
+    forward, dgrad, weight gradients): 2e-4, a hundredth of the bf16 bound, against the float64 network on the same
+    16-bit operands.  Both fp32 modes are compared on the rows whose ReLU masks do not hang on the last bits (below).
+    Bit-identical between calls; ADDS into the gradient buffers."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(sum(widths) + n)
     layers, prev = [], d_in
@@ -211,28 +212,44 @@ def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_
         prev = w + (d_in if skip_at and i in skip_at else 0)
     net = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, train=True, prec=prec).to(cuda)
     x = rng.normal(size=(n, d_in)).astype(np.float32)
-    dy = rng.normal(size=(n, widths[-1])).astype(np.float32)
+    dy_all = rng.normal(size=(n, widths[-1])).astype(np.float32)
+    dy = dy_all
+    if prec != 'bf16':
+        # A pre-activation within rounding of 0 decides a ReLU mask, and a mask that differs from the oracle's moves its
+        # row's whole path: with pre-activations ~1e-6 (pairs) / ~1e-7 (native) from float64's, a few of the 1e7 (row, unit)
+        # masks of a large batch differ and the relative Frobenius distance of a weight gradient is 2e-3 ... 9e-3 (r05 calls
+        # A / B: 128 x 3 on 20 000 rows, 256 x 8 on 3 333) however exact the products are.  The arithmetic is therefore
+        # compared on the rows with no pre-activation inside 1e-4 of its layer's scale (dy = 0 elsewhere), every row
+        # loosely at the end.
+        h, x64, fragile = x.astype(np.float64), x.astype(np.float64), np.zeros(n, bool)
+        for i, (k, b) in enumerate(layers):
+            zpre = h @ k.astype(np.float64) + b
+            if acts[i] == 'relu':
+                fragile |= (np.abs(zpre) < 1e-4 * np.sqrt((zpre ** 2).mean())).any(1)
+            h = {'relu': lambda t: np.maximum(t, 0), 'sigmoid': lambda t: 1. / (1. + np.exp(-t)), 'softplus': lambda t: np.logaddexp(t, 0),
+                 None: lambda t: t}[acts[i]](zpre)
+            if skip_at and i in skip_at:
+                h = np.concatenate([h, x64], 1)
+        assert fragile.mean() < 0.5
+        dy = np.where(fragile[:, None], 0., dy_all).astype(np.float32)
     # the train blob's head is the forward blob
     fwd = ops.GenericNet([k for k, _ in layers], [b for _, b in layers], acts, skip_at, prec=prec).to(cuda)
     assert torch.equal(ops.mlp_generic_fwd(dev(x, cuda), net), ops.mlp_generic_fwd(dev(x, cuda), fwd))
 
-    def run(fill):
+    def run(fill, dy=dy):
         dks = [torch.full(k.shape, fill, device=cuda) for k, _ in layers]
         dbs = [torch.full(b.shape, fill, device=cuda) for _, b in layers]
         dx = ops.mlp_generic_bwd(dev(x, cuda), net, dev(dy, cuda), dks, dbs, want_dx=True)
         return dks, dbs, dx
     dks, dbs, dx = run(0.)
-    # prec = 'fp32' is held to the float64 network evaluated on the SAME 16-bit operands (oracle pairs_ste): against the plain
-    # float64 network its pre-activations sit ~1e-5 off, so ~1e-5 of the ReLU masks of a large batch differ, and a differing
-    # mask moves its whole path: relative Frobenius ~ sqrt(fraction) = 4e-3 (128 x 3, 20 000 rows) and 9e-3 (256 x 8) measured
-    # (r05 call A) where the products themselves are good to 1e-5 — asserted loosely below.  The native fp32 instruction shows
-    # the same effect at its own rounding (nine layers: 2.3e-4 measured).
     wk, wb, wx = _oracle_grads(x, layers, acts, skip_at, dy, True, quant={'bf16': 'bf16', 'fp32': 'pairs', 'fp32_native': None}[prec])
     tol = 2e-2 if prec == 'bf16' else ((2e-5 if prec == 'fp32_native' else 2e-4) if len(widths) <= 5 else (5e-4 if prec == 'fp32_native' else 1e-3))
-    if prec == 'fp32':
-        pk, pb, px = _oracle_grads(x, layers, acts, skip_at, dy, True, quant=None)
-        for got, want in list(zip(dks, pk)) + list(zip(dbs, pb)) + [(dx, px)]:
-            assert _rel(got.cpu().numpy(), want) < 3e-2, _rel(got.cpu().numpy(), want)
+    if prec != 'bf16':      # every row, plain float64: the ReLU-mask effect included
+        ak, ab, ax = run(0., dy_all)
+        pk, pb, px = _oracle_grads(x, layers, acts, skip_at, dy_all, True, quant=None)
+        worst = max(_rel(got.cpu().numpy(), want) for got, want in list(zip(ak, pk)) + list(zip(ab, pb)) + [(ax, px)])
+        print("generic bwd %s, %d rows x %s: all rows vs plain float64, worst tensor %.2e" % (prec, n, widths, worst))
+        assert worst < 3e-2, worst
     for i in range(len(layers)):
         assert _rel(dks[i].cpu().numpy(), wk[i]) < tol, ('kernel', i, _rel(dks[i].cpu().numpy(), wk[i]))
         assert _rel(dbs[i].cpu().numpy(), wb[i]) < tol, ('bias', i, _rel(dbs[i].cpu().numpy(), wb[i]))

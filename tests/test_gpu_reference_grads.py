@@ -38,8 +38,9 @@ def test_fp32_train_steps_vs_reference(nfx_lib, cuda, tag, fp32_matrix):
     """precision = fp32 (VERDICT r03 missing #1: training at the reference's own arithmetic): the step differentiates
     every network in fp32 — forward and backward through csrc/mlp_generic.hip with fp32 activations, gradients and
     workspace — and each gradient tensor is held to the reference's fp32 gradient directly (tests/reference_steps.py).
-    fp32_matrix = native: fp32 operands on the native fp32 matrix instruction, FP32_TOL = 1e-3 (unchanged since round 4);
-    fp32_matrix = pairs (round 5): bf16 hi / lo operand pairs on the bf16 matrix pipe, PAIRS_TOL."""
+    fp32_matrix = native (NeRF's default): fp32 operands on the native fp32 matrix instruction, FP32_TOL = 1e-3 (unchanged
+    since round 4); fp32_matrix = pairs (round 5, the surface models' default): bf16 hi / lo operand pairs on the bf16 matrix
+    pipe, PAIRS_TOL — the same 1e-3 for the NeRFactor models, 5e-2 for NeRF (opt-in there)."""
     run = RS.run_nerf(cuda, 'fp32', fp32_matrix=fp32_matrix) if tag == 'nerf' else RS.run_nerfactor(tag, cuda, 'fp32', fp32_matrix=fp32_matrix)
     assert run[0].grad_precision == 'fp32' and run[0].fp32_matrix == fp32_matrix
     RS.check_fp32(tag, *run)
