@@ -42,14 +42,14 @@ class Model(BaseModel):
         # runtime-shaped kernels (csrc/mlp_generic.hip), rows = [z | embed(rusink)] assembled explicitly.
         self.tuned = (width, depth, skip_at) == (128, 4, 2) and self.embedder['rusink'].n_freqs == 2
         if not self.tuned:
-            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth - 1):
+            # (a skip behind the body's last layer is an inner skip of the body + head network the kernels evaluate)
+            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth):
                 raise NotImplementedError(
-                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and a skip before the last "
-                    "layer (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
+                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
+                    "mlp_depth (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
-        body.build(self.z_dim + self.embedder['rusink'].out_dims)
         head = mlp.Network([1], act=['softplus'])  # reflectance > 0
-        head.build(width)
+        head.build(body.build(self.z_dim + self.embedder['rusink'].out_dims))
         return {'brdf_mlp': body, 'brdf_out': head}
 
     def _init_embedder(self):

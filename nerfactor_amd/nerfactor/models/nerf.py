@@ -52,18 +52,20 @@ class Model(BaseModel):
         act = cfg.get('DEFAULT', 'act', fallback='relu')
         dx = self.embedder['xyz'].out_dims
         enc = mlp.Network([width] * depth, act=[act] * depth, skip_at=[depth // 2])
-        enc.build(dx)
+        # (enc_depth = 2: the skip sits behind the LAST layer, so the encoder's output is concat(y, embed(x)) and every head
+        # reads width + dx features — nerf.py:53-71 with mlp.py:47-48; Keras infers the heads' input width)
+        d_enc = enc.build(dx)
         net = {'enc': enc}
         if not self.use_views:
             net['rgbs_out'] = mlp.Network([4], act=[None])
-            net['rgbs_out'].build(width)
+            net['rgbs_out'].build(d_enc)
             return net
         dv = self.embedder['view'].out_dims
         net['sigma_out'] = mlp.Network([1], act=[None])       # relu applied when compositing
         net['bottleneck'] = mlp.Network([width], act=[None])
         net['rgb_out'] = mlp.Network([width // 2, 3], act=[act, None])  # sigmoid when compositing
-        net['sigma_out'].build(width)
-        net['bottleneck'].build(width)
+        net['sigma_out'].build(d_enc)
+        net['bottleneck'].build(d_enc)
         net['rgb_out'].build(width + dv)
         return net
 
@@ -135,14 +137,21 @@ class Model(BaseModel):
     @staticmethod
     def accumulate_sigma(sigma, z, rayd, noise_std=0., inf=1e10, accu_chunk=65536):
         """weights[N,S] from densities; `accu_chunk` is accepted for signature compatibility —
-        the kernel needs no chunking."""
-        if inf != 1e10:
-            raise NotImplementedError("inf is fixed to 1e10 in the fused kernel")
+        the kernel needs no chunking.  `inf` (nerf.py:186-191: the distance the LAST sample is given) is 1e10 inside the
+        compositing kernel; another value is evaluated through the same kernel on S + 1 samples: an empty sample
+        (density 0: alpha = 0, weight 0) placed `inf` behind the last one gives that one dist = inf, and is dropped."""
         n, s = sigma.shape
-        rgbs = torch.zeros((n, s, 4), dtype=torch.float32, device=sigma.device)
-        rgbs[:, :, 3] = sigma
         noise = torch.randn_like(sigma) * noise_std if noise_std > 0 else None
-        return ops.composite_fwd(rgbs, z, rayd, white_bg=False, noise=noise)[4]
+        extra = inf != 1e10
+        if extra:
+            z = torch.cat((z, z[:, -1:] + float(inf)), 1)
+            sigma = torch.cat((sigma, torch.zeros_like(sigma[:, :1])), 1)
+            if noise is not None:
+                noise = torch.cat((noise, torch.zeros_like(noise[:, :1])), 1)
+        rgbs = torch.zeros((n, s + extra, 4), dtype=torch.float32, device=sigma.device)
+        rgbs[:, :, 3] = sigma
+        w = ops.composite_fwd(rgbs, z.contiguous(), rayd, white_bg=False, noise=noise)[4]
+        return w[:, :s].contiguous() if extra else w
 
     def _nerf_params(self, pref):
         nets = [self.net[pref + k] for k in ('enc', 'sigma_out', 'bottleneck', 'rgb_out')]
@@ -168,10 +177,19 @@ class Model(BaseModel):
         tag = key + ('generic_train' if train else 'generic') + self.generic_prec
         descs = self.__dict__.setdefault('_generic_desc', {})
 
-        blob = self._packed(tag, ks + bs, ops.generic_pack_fn(acts, net.skip_at, train, self.generic_prec, descs, tag))
+        inner_skips = None if net.skip_at is None else [i for i in net.skip_at if i < len(net.layers) - 1]    # (a trailing one: _enc_out)
+        blob = self._packed(tag, ks + bs, ops.generic_pack_fn(acts, inner_skips, train, self.generic_prec, descs, tag))
         g = descs[tag]
         g.blob = blob
         return g
+
+    def _enc_out(self, pref, feat, emb):
+        """The encoder's output given its last layer's: a skip behind the LAST layer (enc_depth = 2: skip_at = [1]) appends the
+        embedded input, y first (mlp.py:47-48)."""
+        enc = self.net[pref + 'enc']
+        if enc.skip_at is not None and len(enc.layers) - 1 in enc.skip_at:
+            return torch.cat((feat, emb), 1)
+        return feat
 
     def _generic_nets(self, pref, train=False):
         names = ('enc', 'sigma_out', 'bottleneck', 'rgb_out') if self.use_views else ('enc', 'rgbs_out')
@@ -187,7 +205,8 @@ class Model(BaseModel):
         GradientTape differentiates for a non-shipped shape."""
         n, s = z.shape
         lx, lv = self.embedder['xyz'].n_freqs, self.embedder['view'].n_freqs
-        feat = self._generic_apply(pref + 'enc', ops.embed(lx, rayo=rayo, rayd=rayd, z=z))
+        emb = ops.embed(lx, rayo=rayo, rayd=rayd, z=z)
+        feat = self._enc_out(pref, self._generic_apply(pref + 'enc', emb), emb)
         if not self.use_views:
             return self._generic_apply(pref + 'rgbs_out', feat).view(n, s, 4)
         sigma = self._generic_apply(pref + 'sigma_out', feat)
@@ -207,7 +226,8 @@ class Model(BaseModel):
         for r0 in range(0, n, rays_per_chunk):
             r1 = min(n, r0 + rays_per_chunk)
             o, d, zz = rayo[r0:r1].contiguous(), rayd[r0:r1].contiguous(), z[r0:r1].contiguous()
-            feat = ops.mlp_generic_fwd(ops.embed(lx, rayo=o, rayd=d, z=zz), nets['enc'])
+            emb = ops.embed(lx, rayo=o, rayd=d, z=zz)
+            feat = self._enc_out(pref, ops.mlp_generic_fwd(emb, nets['enc']), emb)
             out = rgbs[r0:r1].view(-1, 4)
             if not self.use_views:
                 ops.mlp_generic_fwd(feat, nets['rgbs_out'], out=out)
@@ -292,14 +312,16 @@ class Model(BaseModel):
         for i in range(0, n * s, chunk):
             p = pts[i:i + chunk]
             emb = ops.embed(lx, x=p)
-            feat = ops.mlp_generic_fwd(emb, enc)
+            feat = self._enc_out(pref, ops.mlp_generic_fwd(emb, enc), emb)
             raw = ops.mlp_generic_fwd(feat, out)               # [m, 1] or [m, 4] (use_views = False: rgb + sigma)
             sigma[i:i + chunk] = raw[:, -1]
             if want_normal:
                 dy = torch.zeros_like(raw)
                 dy[:, -1] = (raw[:, -1] > 0).float()           # d relu(sigma) / d sigma
                 d_feat = ops.mlp_generic_bwd(feat, out, dy, None, None, want_dx=True)
-                d_emb = ops.mlp_generic_bwd(emb, enc, d_feat, None, None, want_dx=True)
+                d_emb = ops.mlp_generic_bwd(emb, enc, d_feat[:, :enc.d_out].contiguous(), None, None, want_dx=True)
+                if d_feat.shape[1] > enc.d_out:                # (a trailing skip hands the embedding to the head directly)
+                    d_emb = d_emb + d_feat[:, enc.d_out:]
                 normal[i:i + chunk] = -ops.l2_normalize3(ops.embed_bwd(lx, p, d_emb), 1e-12)
         return sigma.view(n, s), (normal.view(n, s, 3) if want_normal else None)
 

@@ -59,14 +59,15 @@ class Model(BaseModel):
         # and train through the runtime-shaped kernels (csrc/mlp_generic.hip), one autograd node per network.
         if (width, depth, skip_at) != (128, 4, 2):
             self.tuned = False
-            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth - 1):
+            # (a skip behind the body's LAST layer is an inner skip of the body + head network the kernels evaluate: the
+            # head then reads concat(y, x), which is what body.build returns)
+            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth):
                 raise NotImplementedError(
-                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and a skip before the last "
-                    "layer (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
+                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
+                    "mlp_depth (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
-        body.build(in_dims)
         head = mlp.Network([out_dims], act=[out_act])
-        head.build(width)
+        head.build(body.build(in_dims))
         return body, head
 
     def _init_net(self):
@@ -79,14 +80,14 @@ class Model(BaseModel):
 
     def _init_embedder(self):
         cfg = self.config
-        if not cfg.getboolean('DEFAULT', 'pos_enc'):
-            raise NotImplementedError("pos_enc=False is not supported by the fused kernels")
         lx = cfg.getint('DEFAULT', 'n_freqs_xyz')
         ll = cfg.getint('DEFAULT', 'n_freqs_ldir')
         lv = cfg.getint('DEFAULT', 'n_freqs_vdir')
+        if not cfg.getboolean('DEFAULT', 'pos_enc'):   # tf.identity in the reference (shape.py:97-106): no bands, the input itself
+            lx = ll = lv = 0
         if (lx, ll) != (10, 4):
-            self.tuned = False     # other band counts: the runtime-shaped path (nfx_embed takes any)
-        return {name: Embedder(incl_input=True, in_dims=3, log2_max_freq=L - 1, n_freqs=L)
+            self.tuned = False     # other band counts (0 included): the runtime-shaped path (nfx_embed takes any)
+        return {name: Embedder(incl_input=True, in_dims=3, log2_max_freq=max(L - 1, 0), n_freqs=L)
                 for name, L in (('xyz', lx), ('ldir', ll), ('vdir', lv))}
 
     # ------------------------------------------------------------------ packed weights

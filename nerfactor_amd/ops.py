@@ -282,6 +282,10 @@ class GenericNet:
             raise _capi.NfxError("GenericNet: kernels, biases and acts must have the same, non-zero length")
         self.widths = [int(k.shape[1]) for k in ks]
         skip_at = set(skip_at or [])
+        if any(i < 0 or i >= n - 1 for i in skip_at):
+            # (a skip behind the last layer widens the network's OUTPUT to concat(y, x): the kernel has no such mode, and
+            # dropping it silently would evaluate another function — the caller appends x itself, models/nerf.py:_enc_out)
+            raise _capi.NfxError("GenericNet: skip_at %s — a skip must sit behind one of the layers 0 .. %d" % (sorted(skip_at), n - 2))
         self.skip_input = [1 if (i - 1) in skip_at else 0 for i in range(n)]
         self.d_in = int(ks[0].shape[0])
         for i in range(n):

@@ -112,15 +112,16 @@ def init_nerf_net(rng, n_freqs_xyz=10, n_freqs_view=4, width=NERF_WIDTH, depth=N
     for i in range(depth):
         enc.append((glorot_uniform(rng, fan_in, width, dtype), np.zeros(width, dtype)))
         fan_in = width + dx if i == skip else width
+    d_enc = fan_in      # (enc_depth = 2: the skip sits behind the last layer and the heads read concat(y, embed(x)), mlp.py:47-48)
     if not use_views:   # nerf.py:62-66: one linear head for (rgb, sigma)
-        k = glorot_uniform(rng, width, 4, dtype)
+        k = glorot_uniform(rng, d_enc, 4, dtype)
         k[:, 3] *= dtype(sigma_gain)
         return {'enc': enc, 'rgbs_out': [(k, np.array([0., 0., 0., sigma_bias], dtype))]}
     net = {
         'enc': enc,
-        'sigma_out': [(glorot_uniform(rng, width, 1, dtype) * dtype(sigma_gain),
+        'sigma_out': [(glorot_uniform(rng, d_enc, 1, dtype) * dtype(sigma_gain),
                        np.full(1, sigma_bias, dtype))],
-        'bottleneck': [(glorot_uniform(rng, width, width, dtype), np.zeros(width, dtype))],
+        'bottleneck': [(glorot_uniform(rng, d_enc, width, dtype), np.zeros(width, dtype))],
         'rgb_out': [(glorot_uniform(rng, width + dv, width // 2, dtype),
                      np.zeros(width // 2, dtype)),
                     (glorot_uniform(rng, width // 2, 3, dtype), np.zeros(3, dtype))],

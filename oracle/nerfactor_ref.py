@@ -51,7 +51,8 @@ def init_mlp128(rng, in_dims, out_dims, width=128, depth=4, skip_at=2, dtype=np.
     for i in range(depth):
         layers.append((glorot_uniform(rng, fan_in, width, dtype), np.zeros(width, dtype)))
         fan_in = width + in_dims if i == skip_at else width
-    out = [(glorot_uniform(rng, width, out_dims, dtype), np.zeros(out_dims, dtype))]
+    # (a skip behind the LAST body layer: the head reads concat(y, x), mlp.py:47-48 — Keras infers its input width)
+    out = [(glorot_uniform(rng, fan_in, out_dims, dtype), np.zeros(out_dims, dtype))]
     return layers, out
 
 

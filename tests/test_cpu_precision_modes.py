@@ -38,8 +38,12 @@ def test_limits_of_the_runtime_shaped_kernels_raise_with_the_numbers():
         build('nerf', mlp_width='512')
     with pytest.raises(NotImplementedError, match='mlp_width'):
         build('shape', mlp_width='300')
+    assert not build('brdf', mlp_depth='4', mlp_skip_at='3').tuned      # (a skip behind the body's last layer: the head reads concat(y, x))
     with pytest.raises(NotImplementedError, match='skip'):
-        build('brdf', mlp_depth='4', mlp_skip_at='3')
+        build('brdf', mlp_depth='4', mlp_skip_at='4')
+    assert not build('shape', pos_enc='False').tuned and build('shape', pos_enc='False').embedder['xyz'].n_freqs == 0
+    enc2 = build('nerf', enc_depth='2', mlp_width='64')                # the skip sits behind the last encoder layer
+    assert tuple(enc2.net['coarse_sigma_out'].layers[0].kernel.shape) == (64 + 63, 1)
 
 
 def test_grad_precision_follows_precision_and_rejects_the_impossible_pair():
