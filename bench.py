@@ -680,6 +680,139 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     }
 
 
+# ------------------------------------------------------------------------------------------------ geometry leg
+GEO_MAC = 63 * 256 + 6 * 256 * 256 + 319 * 256 + 256      # encoder (8 x 256, skip behind layer 4) + sigma_out: MAC per density sample
+GEO_LVIS_POINTS = 8192                                    # surface points of the shadow-ray stage's bounded sample
+
+
+def geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
+    """geometry_from_nerf.py:93-246 on the driver line: the timed 800 x 800 view of the bench through
+    `compute_depth_and_normal` (64 + 64 coarse samples of the coarse density, 64 + 64 + 128 + 64 = 320 samples of the fine
+    density WITH its gradient: expected depth and normal per ray) on the NeRF weights fitted to a scene, then
+    `compute_light_visibility` (the same 128 + 320 density march along the shadow ray to every front-lit one of 512 lights)
+    on a bounded sample of that view's surface points — the reference's heaviest offline stage, N x L x 448 density
+    evaluations per view.  Rays of the view are split over the ranks.  Roofline: MFMA, from the HIP-event time of the
+    density kernels; FLOPs = 2 x GEO_MAC per density sample, twice that where the gradient is taken (forward + reverse sweep)."""
+    from nerfactor_amd import synth
+    from nerfactor_amd.nerfactor import geometry_from_nerf as G
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from tests.golden import golden_inputs as gi
+    cfg = make_config('nerf', precision=args.precision)
+    model = get_model_class('nerf')(cfg)
+    nets = gi.trained_nerf_nets()
+    with torch.no_grad():
+        for pref, net in zip(('coarse_', 'fine_'), nets):
+            for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+                for layer, (k, b) in zip(model.net[pref + part].layers, net[part]):
+                    layer.kernel.copy_(torch.from_numpy(np.asarray(k, np.float32)))
+                    layer.bias.copy_(torch.from_numpy(np.asarray(b, np.float32)))
+    model = model.to(dev)
+    rayo_h, rayd_h = synth.camera_rays(H, W)
+    rayd_h = rayd_h / np.maximum(np.linalg.norm(rayd_h, axis=1, keepdims=True), 1e-12)
+    sh = Shards(H * W, rank, world, 'strong')
+    rayo, rayd = torch.from_numpy(rayo_h[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd_h[sh.lo:sh.hi].astype(np.float32)).to(dev)
+    n_c, n_f, _ = G._sample_counts(cfg)          # 128, 192: 320 fine-network samples per ray
+    steps = max(1, min(args.steps, 3))
+    state = {}
+    with torch.no_grad(), KernelTimer(ops, ['nerf_sigma_fwd', 'nerf_sigma_grad']) as kt:
+        def march(k):
+            kt.on = k is not None
+            state['out'] = G.compute_depth_and_normal(model, rayo, rayd, cfg)
+            return state['out'][0]
+        elapsed, _ = timed(march, steps, 1, barrier)
+        kt.on = False
+        elapsed = max_over_ranks(elapsed)
+        occu, depth, normal = state['out']
+        fwd_ms, grad_ms = kt.all_ms('nerf_sigma_fwd'), kt.all_ms('nerf_sigma_grad')
+    kernel_ms = (sum(fwd_ms) + sum(grad_ms)) / steps
+    n_local = sh.hi - sh.lo
+    flop_dn = n_local * (n_c + 2 * (n_c + n_f)) * 2 * GEO_MAC
+    # ---- shadow rays: a bounded sample of this rank's surface points (foreground: occupancy > 0.5) x 512 lights
+    fg = torch.nonzero(occu > 0.5)[:, 0]
+    n_pts = min(GEO_LVIS_POINTS // world, int(fg.numel()))
+    pick = fg[torch.linspace(0, fg.numel() - 1, n_pts, device=dev).long()] if n_pts else fg[:0]
+    surf = (rayo[pick] + rayd[pick] * depth[pick, None]).contiguous()
+    nrm = torch.nn.functional.normalize(normal[pick], dim=1).contiguous()
+    lv = {}
+    with torch.no_grad(), KernelTimer(ops, ['nerf_sigma_fwd']) as kt:
+        def shadow(k):
+            kt.on = k is not None
+            lv['lvis'] = G.compute_light_visibility(model, surf, nrm, cfg)
+            return lv['lvis']
+        elapsed_l, _ = timed(shadow, 1, 1, barrier)
+        kt.on = False
+        elapsed_l = max_over_ranks(elapsed_l)
+        lvis_kernel_ms = sum(kt.all_ms('nerf_sigma_fwd'))
+    lxyz, _ = G.gen_light_xyz(16, 32)
+    lx = torch.as_tensor(lxyz.reshape(-1, 3).astype(np.float32), device=dev)
+    s2l = torch.nn.functional.normalize(lx[None] - surf[:, None], dim=2, eps=1e-12)
+    pairs = int(((s2l * nrm[:, None]).sum(-1) > 0).sum())
+    flop_lv = pairs * (n_c + n_c + n_f) * 2 * GEO_MAC
+    finite = bool(torch.isfinite(normal).all() and torch.isfinite(lv['lvis']).all())
+    out = {
+        "workload": "geometry_from_nerf of one %d x %d view on the fitted NeRF (tests/golden/nerf_trained_fp16.npz): depth + normal "
+                    "march with %d coarse + %d fine-network samples per ray (density gradient on the %d), then the shadow-ray march "
+                    "to the front-lit ones of 512 lights for a sample of %d surface points per GPU" % (
+                        H, W, n_c, n_c + n_f, n_c + n_f, n_pts),
+        "precision": args.precision, "steps": steps, "finite": finite,
+        "depth_normal": {
+            "ms_per_view": elapsed / steps * 1e3, "rays_per_s": H * W * steps / elapsed,
+            "foreground_rays_this_rank": int(fg.numel()),
+            "roofline": {"bound": "mfma", "kernel": "nerf_sigma_geo_kernel (coarse density) + nerf_sigma_grad_kernel (fine density "
+                                                    "and its gradient: forward + reverse sweep), all launches of a view",
+                         "achieved": flop_dn / (kernel_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop_dn / (kernel_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                         "flop_per_view_per_gpu": flop_dn, "kernels_ms_per_view": kernel_ms,
+                         "mac_per_density_sample": GEO_MAC,
+                         "share_of_stage": kernel_ms / (elapsed / steps * 1e3)}},
+        "light_visibility": {
+            "surface_points_per_gpu": n_pts, "front_lit_pairs_per_gpu": pairs, "ms": elapsed_l * 1e3,
+            "pairs_per_s": pairs * world / elapsed_l if elapsed_l > 0 else None,      # (this rank's rate x ranks)
+            "full_view_estimate_s": (float(fg.numel()) * world / max(n_pts * world, 1)) * elapsed_l,
+            "roofline": {"bound": "mfma", "kernel": "nerf_sigma_geo_kernel (density only: the encoder + sigma tile), every launch of the stage",
+                         "achieved": flop_lv / max(lvis_kernel_ms * 1e-3, 1e-9) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop_lv / max(lvis_kernel_ms * 1e-3, 1e-9) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                         "flop_per_gpu": flop_lv, "kernels_ms": lvis_kernel_ms,
+                         "share_of_stage": lvis_kernel_ms / (elapsed_l * 1e3) if elapsed_l > 0 else None}}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lv['lvis'], lxyz))
+    return out
+
+
+def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lvis, lxyz, n_rays=48, n_pts=2):
+    """oracle/geometry_ref.py (NumPy / torch-CPU restatement of geometry_from_nerf.py:93-246) on a bounded sample: the CPU
+    baseline of both stages and the parity of the timed outputs on those rays / points."""
+    from oracle import geometry_ref as GR
+    torch.set_num_threads(host_cores())
+    fgi = torch.nonzero(occu > 0.5)[:, 0].cpu().numpy()
+    idx = np.sort(np.concatenate([fgi[np.linspace(0, len(fgi) - 1, n_rays // 2).astype(int)] if len(fgi) else np.zeros(0, int),
+                                  np.linspace(0, rayo_h.shape[0] - 1, n_rays - n_rays // 2).astype(int)]))
+    t0 = time.perf_counter()
+    r_occu, r_depth, r_normal = GR.compute_depth_and_normal(rayo_h[idx], rayd_h[idx].astype(np.float32), nets[0], nets[1])
+    t_dn = time.perf_counter() - t0
+    g_occu, g_depth, g_normal = occu[idx].cpu().numpy(), depth[idx].cpu().numpy(), normal[idx].cpu().numpy()
+    hit = r_occu > 0.5
+    cos = (g_normal[hit] * r_normal[hit]).sum(1) / np.maximum(np.linalg.norm(g_normal[hit], axis=1) * np.linalg.norm(r_normal[hit], axis=1), 1e-12)
+    sp, sn = surf[:n_pts].cpu().numpy(), nrm[:n_pts].cpu().numpy()
+    t0 = time.perf_counter()
+    r_lvis = GR.compute_light_visibility(sp, sn, lxyz.reshape(-1, 3).astype(np.float32), nets[0], nets[1])
+    t_lv = time.perf_counter() - t0
+    g_lvis = lvis[:n_pts].cpu().numpy()
+    pairs = int((r_lvis > 0).sum() + ((r_lvis == 0) & (g_lvis > 0)).sum())
+    return {
+        "cpu_baseline": {"kind": "port", "cores": host_cores(), "unit": "rays/s (depth + normal) | pairs/s (light visibility)",
+                         "value": len(idx) / t_dn, "light_visibility_pairs_per_s": max(pairs, 1) / t_lv,
+                         "sample": "oracle/geometry_ref.py on %d rays of the view (%.1f s) and %d surface points x 512 lights (%.1f s)" % (
+                             len(idx), t_dn, n_pts, t_lv)},
+        "parity": {"rays_compared": int(len(idx)), "occu_max_abs": float(np.abs(g_occu - r_occu).max()),
+                   "depth_max_abs_on_hits": float(np.abs(g_depth - r_depth)[hit].max()) if hit.any() else None,
+                   "normal_cos_min_on_hits": float(cos.min()) if hit.any() else None,
+                   "normal_cos_median_on_hits": float(np.median(cos)) if hit.any() else None,
+                   "lvis_points_compared": int(n_pts), "lvis_max_abs": float(np.abs(g_lvis - r_lvis).max()),
+                   "reference": "oracle/geometry_ref.py (fp32 / float64 autograd) on the same rays and points"}}
+
+
 # ------------------------------------------------------------------------------------------------ OLAT leg (configs[4])
 def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     """One-light-at-a-time relighting of an 800 x 800 view (test.py:182, nerfactor.py:348-364): the render of the
@@ -829,7 +962,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat,relight,fp32_class')
+    ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat,relight,fp32_class,geometry')
     ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
     ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -882,6 +1015,7 @@ def main():
     relight = relight_sweep_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'relight' in legs else None
     fp32c = nerf_fp32_class_leg(args, ops, dev, rank, world, barrier, max_over_ranks) \
         if 'fp32_class' in legs and args.precision == 'bf16' else None
+    geometry = geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'geometry' in legs else None
     if rank == 0:
         out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -905,6 +1039,8 @@ def main():
             out["relight"] = relight
         if fp32c is not None:
             out["fp32_class"] = fp32c
+        if geometry is not None:
+            out["geometry"] = geometry
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -35,8 +35,14 @@ VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # backward kernels (nerf_bwd, mlp128_bwd, brdf_bwd)
 # r04: mlp128_bwd_fused.hip — 1113 of ~3850 VALU instructions per tile of its PART 1 kernel were v_accvgpr_read / _write
 # of the chain's accumulators (the persistent weight-gradient blocks still end up in AccVGPRs: only MFMAs touch them)
+# r05: shade.hip — the shading kernels are VALU-bound by the per-light GGX term, not HBM-bound (static count: 4364 / 3070 VALU
+# instructions in shade_kernel / shade_olat_kernel, ~3000 executed per point and wave); a quarter of them were the IEEE
+# division / square-root sequences (v_div_scale, v_div_fmas, v_div_fixup around v_rcp / v_rsq: 528 v_div_scale in the file).
+# The 2.5-ulp forms (v_rcp_f32 + one Newton step) leave the render inside its 3e-4 of the fp32 oracle
+# (tests/test_gpu_nerfactor.py::test_shade_microfacet_vs_oracle): 4364 -> 3263 and 3070 -> 2348 instructions.
+FAST_DIV = ['-fno-hip-fp32-correctly-rounded-divide-sqrt']
 PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
-                  'nerf_geom.hip': VGPR_FORM, 'mlp128_bwd_fused.hip': VGPR_FORM}
+                  'nerf_geom.hip': VGPR_FORM, 'mlp128_bwd_fused.hip': VGPR_FORM, 'shade.hip': FAST_DIV}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
     PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
 

@@ -2,10 +2,11 @@
 # One GPU-box call (via gpurun): runs the stages named on the command line, everything worth keeping goes to gpurun_out/<tag>/.
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
 # stages: pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
-#         soak | soak-xp | soak-xp2 | sigma | fitted | generic | prof | train-prof | pmc | pmc-train
+#         soak | soak-xp | soak-xp2 | sigma | fitted | generic | prof | train-prof | pmc | pmc-train | bench-legs (LEGS=..., LEGS_TAG=...)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
+export NFX_CONVERGENCE_OUT=${NFX_CONVERGENCE_OUT:-$PWD/gpurun_out/$1/convergence.json}
 TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -18,6 +19,7 @@ for st in "$@"; do
     pytest-x) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_x.log 2>&1; tail -8 $OUT/pytest_gpu_x.log ;;
     smoke)    timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -6 $OUT/smoke.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
     bench-norefine) timeout 600 python bench.py --steps ${STEPS:-10} --warmup 3 --legs nerf --no-last-sample-refine > $OUT/bench_norefine.json 2> $OUT/bench_norefine.err; tail -c 1200 $OUT/bench_norefine.json ;;
     soak)     timeout 600 python scripts/soak_8wave.py > $OUT/soak_product.log 2>&1; tail -12 $OUT/soak_product.log ;;
     pmc)      for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
