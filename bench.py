@@ -101,7 +101,7 @@ def timed(step, steps, warmup, barrier):
 
 
 # ------------------------------------------------------------------------------------------------ NeRF leg
-def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None):
+def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coarse_prec=None):
     """views: [(rayo, rayd)] device tensors (this rank's shard of every view).  ev: per-view 4 events around the two
     MLP launches.  refine: the two fp32-class density blobs — the last sample of every ray is re-evaluated with them
     (what models/nerf.py does when rendering with precision = bf16: ops.nerf_refine_last_sample); inside the timed step,
@@ -113,10 +113,10 @@ def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None):
         z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
         if e is not None:
             e[0].record()
-        raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
+        raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], coarse_prec or prec)     # (coarse_prec: the plugin's ini key coarse_precision)
         if e is not None:
             e[1].record()
-        if refine is not None:
+        if refine is not None and (coarse_prec or prec) == 'bf16':
             ops.nerf_refine_last_sample(o, d, z, raw, refine[0])
         _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
         z_all = ops.sample_fine(z, w, N_FINE)
@@ -283,12 +283,19 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, n=2048):
     torch.set_num_threads(host_cores())
     with torch.no_grad():
         ref = torch_ref.render_rays(torch.from_numpy(o), torch.from_numpy(d), *[torch_ref.to_torch_net(x) for x in nets])
-    got = nerf_render_step(ops, [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))], blobs,
-                           prec=args.precision, refine=refine).cpu().numpy()
+    view = [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))]
+    got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine).cpu().numpy()
     want = ref[1]['rgb'].numpy()
     sig = np.minimum(ref[2]['sigma_last_coarse'].numpy(), ref[2]['sigma_last_fine'].numpy())
     err = np.abs(got - want).max(1)
-    return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()),
+    coarse32 = None
+    if args.precision == 'bf16':      # the same rays with the plugin's `coarse_precision = fp32` (coarse pass fp32-class, fine pass bf16)
+        b32 = [ops.pack_nerf_weights(*synth.nerf_layers(nets[0]), prec='fp32').to(dev), blobs[1]]
+        g32 = nerf_render_step(ops, view, b32, prec='bf16', refine=refine, coarse_prec='fp32').cpu().numpy()
+        e32 = np.abs(g32 - want).max(1)
+        coarse32 = {"psnr_db": psnr_uint8_luma(g32, want), "max_abs_all_rays": float(e32.max()),
+                    "rays_above_3e-2": int((e32 > 3e-2).sum()), "what": "ini key coarse_precision = fp32: +67 % frame time (r04 call B)"}
+    return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()), "coarse_precision_fp32": coarse32,
             "max_abs_all_rays": float(err.max()), "rays_compared": int(n),
             "rays_excluded_from_max_abs": 0, "rays_with_abs_sigma_last_below_0.06": int((sig <= 0.06).sum()),
             "frac_rays_above_3e-2": float((err > 3e-2).mean()), "rays_above_3e-2": int((err > 3e-2).sum()),
@@ -780,7 +787,7 @@ def geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     return out
 
 
-def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lvis, lxyz, n_rays=48, n_pts=2):
+def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lvis, lxyz, n_rays=768, n_pts=12):
     """oracle/geometry_ref.py (NumPy / torch-CPU restatement of geometry_from_nerf.py:93-246) on a bounded sample: the CPU
     baseline of both stages and the parity of the timed outputs on those rays / points."""
     from oracle import geometry_ref as GR

@@ -42,6 +42,10 @@ class Model(BaseModel):
         self.last_sample_precision = self.config.get('DEFAULT', 'last_sample_precision', fallback='fp32')
         if self.last_sample_precision not in ('bf16', 'fp32'):
             raise ValueError("last_sample_precision = %s (bf16 | fp32)" % self.last_sample_precision)
+        # `coarse_precision = fp32` (default bf16 = `precision`): render the coarse pass fp32-class (see _eval_rays)
+        self.coarse_precision = self.config.get('DEFAULT', 'coarse_precision', fallback='bf16')
+        if self.coarse_precision not in ('bf16', 'fp32'):
+            raise ValueError("coarse_precision = %s (bf16 | fp32)" % self.coarse_precision)
         self.register_trainable()
 
     # ------------------------------------------------------------------ construction
@@ -251,6 +255,12 @@ class Model(BaseModel):
             ks, bs = self._nerf_params(pref)
             return autograd.NerfMlp.apply(rayo, rayd, z, self._nerf_blob(pref),
                                           lambda: self._nerf_train_blob(pref), self.precision, *(ks + bs))
+        if pref == 'coarse_' and self.precision == 'bf16' and self.coarse_precision == 'fp32':
+            # (render-time option, round 5: the COARSE pass with fp32-class operands — its weights place the fine samples,
+            #  and on a fitted network's sharp density edge bf16 coarse weights move a silhouette ray's fine samples by up
+            #  to 1.5 coarse bins; 25 % of a frame's points at 3.7x)
+            return ops.nerf_mlp_fwd(rayo, rayd, z, self._packed(
+                pref + 'fp32', sum(self._nerf_params(pref), []), lambda k, b: ops.pack_nerf_weights(k, b, 'fp32')), 'fp32')
         rgbs = ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision)
         if self.precision == 'bf16' and self.last_sample_precision == 'fp32' and z.shape[1] > 1:
             ops.nerf_refine_last_sample(rayo, rayd, z, rgbs, self._nerf_geom_blob(pref, 'fp32'))
@@ -345,10 +355,21 @@ class Model(BaseModel):
         if not self.tuned:
             sigma = torch.relu(self._sigma_generic(rayo, rayd, z, pref)[0])
         else:
-            sigma = torch.relu(ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_geom_blob(pref), self.precision))
+            raw = ops.nerf_sigma_fwd(rayo, rayd, z, self._nerf_geom_blob(pref), self.precision)
+            sigma = torch.relu(self._refine_last_sigma(rayo, rayd, z, raw, pref))
         if bbox is not None:
             sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)
         return sigma
+
+    def _refine_last_sigma(self, rayo, rayd, z, sigma_raw, pref):
+        """geometry_from_nerf composites these densities with accumulate_sigma, where the LAST sample of a ray gets
+        dist = 1e10 (nerf.py:186-191): alpha_last = [sigma_last > 0] exactly, the one bit of a ray a bf16 density can get
+        wrong by a whole ray.  As in the render (last_sample_precision), precision = bf16 re-evaluates
+        that one sample with the fp32-class density kernel: 1 of 128 / 320 samples at ~3x the cost (round 5)."""
+        if self.precision == 'bf16' and self.last_sample_precision == 'fp32' and z.shape[1] > 1 and z.shape[0] > 0:
+            last = ops.nerf_sigma_fwd(rayo, rayd, z[:, -1:].contiguous(), self._nerf_geom_blob(pref, 'fp32'), 'fp32')
+            sigma_raw[:, -1] = last[:, 0]
+        return sigma_raw
 
     def eval_sigma_normal(self, rayo, rayd, z, bbox=None):
         """(relu(sigma)[N,S], normal[N,S,3]) of the FINE network, normal = -l2_normalize(d sigma / dx)
@@ -357,6 +378,7 @@ class Model(BaseModel):
             sigma, normal = self._sigma_generic(rayo, rayd, z, 'fine_', want_normal=True)
         else:
             normal, sigma = ops.nerf_sigma_grad(rayo, rayd, z, self._nerf_geom_blob('fine_'), self.precision)
+            sigma = self._refine_last_sigma(rayo, rayd, z, sigma, 'fine_')
         sigma = torch.relu(sigma)
         if bbox is not None:
             sigma = sigma * self._in_bounds(rayo, rayd, z, bbox)

@@ -488,8 +488,14 @@ def test_geometry_extraction_vs_oracle(nfx_lib, cuda, precision):
     stable = np.abs(w_occu - 0.5) > 0.0        # every ray; the last-sample discontinuity shows up as isolated outliers
     # bounds: bf16 operands | fp32-class kernels (measured: occupancy 5e-7, depth 4e-5, normal median 5e-4 / q90 2e-3)
     b_occu, b_depth, b_nq90, b_nmed = (3e-2, 5e-2, 8e-2, 4e-2) if precision == 'bf16' else (1e-3, 1e-3, 1e-2, 3e-3)
-    assert np.quantile(np.abs(occu - w_occu)[stable], 0.9) <= b_occu
-    assert np.quantile(np.abs(depth - w_depth), 0.9) <= b_depth
+    # (r05: every ray — the last sample is evaluated fp32-class in the geometry march, models/nerf.py:_refine_last_sigma;
+    #  counted exclusions of at most 2 % instead of the 0.9-quantile bounds of rounds 1-4)
+    def counted(err, tol, what):
+        bad = np.flatnonzero(err > tol)
+        print("%s %s: %d of %d above %.0e (max %.3e) %s" % (precision, what, len(bad), err.size, tol, err.max(), bad[:12].tolist()))
+        assert len(bad) <= 0.02 * err.size, (what, len(bad), float(err.max()))
+    counted(np.abs(occu - w_occu)[stable], b_occu, 'occupancy')
+    counted(np.abs(depth - w_depth), b_depth, 'depth')
     hit = w_occu > 0.5
     assert hit.sum() > 20
     # expected normals of a random-weight NeRF are short (per-sample normals cancel along the ray), so the test is on
@@ -497,7 +503,8 @@ def test_geometry_extraction_vs_oracle(nfx_lib, cuda, precision):
     dn = np.abs(normal - w_normal).max(1)
     # (bf16 against fp64 on a random-weight field: a sample whose ReLU pattern differs contributes a different unit
     #  vector, weighted by its compositing weight)
-    assert np.quantile(dn[hit], 0.9) <= b_nq90 and np.median(dn[hit]) <= b_nmed, (np.quantile(dn[hit], 0.9), np.median(dn[hit]))
+    counted(dn[hit], b_nq90, 'normal (as a vector)')
+    assert np.median(dn[hit]) <= b_nmed, np.median(dn[hit])
     print(precision, 'geometry vs oracle: occupancy q90 %.2e, depth q90 %.2e, normal median %.2e q90 %.2e' % (
         np.quantile(np.abs(occu - w_occu), 0.9), np.quantile(np.abs(depth - w_depth), 0.9), np.median(dn[hit]),
         np.quantile(dn[hit], 0.9)))
@@ -511,4 +518,5 @@ def test_geometry_extraction_vs_oracle(nfx_lib, cuda, precision):
     w_lvis = geometry_ref.compute_light_visibility(surf, nrm, lxyz, nets[0], nets[1])
     assert lvis.shape == w_lvis.shape == (12, 32)
     assert np.array_equal(lvis == 0, w_lvis == 0) or np.mean((lvis == 0) != (w_lvis == 0)) < 0.02   # same front-lit set
-    assert np.quantile(np.abs(lvis - w_lvis), 0.9) <= 4e-2 and np.abs(lvis - w_lvis).mean() <= 2e-2
+    counted(np.abs(lvis - w_lvis).reshape(-1), 4e-2, 'light visibility')
+    assert np.abs(lvis - w_lvis).mean() <= 2e-2

@@ -62,13 +62,22 @@ def test_nerf_plugin_render_vs_reference_outputs(nfx_lib, cuda, prec):
     in_r03_band = (np.abs(aux['rgbs_coarse'][:, -1, 3]) <= 0.06) | (np.abs(aux['rgbs_fine'][:, -1, 3]) <= 0.06)
     assert int(in_r03_band.sum()) == 8, int(in_r03_band.sum())     # an exact count, so a drift of the oracle shows
     tol_rgb, tol_occu, tol_med = (3e-2, 8e-2, 5e-3) if prec == 'bf16' else (2e-3, 2e-3, 1e-4)
-    for lvl, ok in (('coarse', ok_c), ('fine', ok_f)):
+    # what bf16 operands alone do to this input: the ORACLE with bf16-rounded operands (fp32 everywhere else)
+    cq, fq, _ = nerf_ref.render_rays(rayo, rayd, nets[0], nets[1], quant=nerf_ref.bf16_round)
+    for lvl, ok, oq in (('coarse', ok_c, cq), ('fine', ok_f, fq)):
         rgb = to_vis[lvl + '_rgb'].cpu().numpy()
         want = GOLD['nerf_%s_rgb' % lvl]
         err = np.abs(rgb - want).max(-1)
-        # bf16: the oracle with bf16-rounded operands (quant=bf16_round) is itself 3.03e-2 away from float32 on one
-        # ray of this input, so the 3e-2 bound holds for >= 95 % of the stable rays and 4e-2 for all of them
-        assert np.quantile(err[ok], 0.95) <= tol_rgb and err[ok].max() <= tol_rgb * 4 / 3, (lvl, err[ok].max())
+        # The stated tolerance on every ray; a ray above it is excused only — counted, at most 2 % = one ray of the 64 —
+        # when the ORACLE with bf16 operands is itself beyond the tolerance on that very ray (measured: one ray, 3.03e-2:
+        # the bound is a statement about bf16 operands, which no kernel can beat).  r01-r04 allowed 4/3 of the tolerance
+        # on all rays instead.
+        oracle_q = np.abs(oq['rgb'] - want).max(-1)
+        over = np.flatnonzero(ok & (err > tol_rgb))
+        print(prec, lvl, "rays above %.0e: %s (kernel %s, bf16-operand oracle %s)" % (
+            tol_rgb, over.tolist(), err[over].round(4).tolist(), oracle_q[over].round(4).tolist()))
+        assert len(over) <= 0.02 * ok.sum() and np.all(oracle_q[over] > tol_rgb * 0.95) and np.all(err[over] <= 1.2 * oracle_q[over]), (
+            lvl, over.tolist(), err[over].tolist(), oracle_q[over].tolist())
         assert np.median(err) <= tol_med, (lvl, np.median(err))
         occu = to_vis[lvl + '_occu'].cpu().numpy()
         assert np.abs(occu - GOLD['nerf_%s_occu' % lvl])[ok].max() <= tol_occu
@@ -208,6 +217,15 @@ def test_nerfactor_plugin_shape_mode_nerf_vs_reference_outputs(nfx_lib, cuda):
     assert np.abs(pred['rgb'].cpu().numpy() - GOLD['nfm_shapenerf_rgb']).max() < 3e-2
 
 
+def _excluded(err, tol, what, max_frac=0.02):
+    """Counted exclusion list: every element must be within `tol` except an explicit, reported set of at most
+    `max_frac` of them (VERDICT r01: max-abs bounds on >= 98 % of the elements, no quantile bounds)."""
+    bad = np.flatnonzero(err > tol)
+    print("%s: %d of %d elements above %.0e (max %.3e): %s" % (what, len(bad), err.size, tol, err.max(), bad[:16].tolist()))
+    assert len(bad) <= max_frac * err.size, (what, len(bad), err.size, float(err.max()))
+    return bad
+
+
 # ---------------------------------------------------------------------------------------------- geometry_from_nerf
 @pytest.mark.parametrize('bbox', [False, True])
 def test_geometry_extraction_vs_reference_outputs(nfx_lib, cuda, bbox):
@@ -229,10 +247,13 @@ def test_geometry_extraction_vs_reference_outputs(nfx_lib, cuda, bbox):
     with torch.no_grad():
         occu, depth, normal = (t.cpu().numpy() for t in
                                G.compute_depth_and_normal(model, dev(rayo, cuda), dev(rayd, cuda), cfg, bbox=box))
-    assert np.quantile(np.abs(occu - GOLD[tag + 'occu']), 0.9) <= 3e-2
-    assert np.quantile(np.abs(depth - GOLD[tag + 'depth']), 0.9) <= 5e-2
+    # (r05: max-abs on every ray — the last sample of a ray, whose sign decides the ray, is evaluated fp32-class in the
+    #  geometry march too (models/nerf.py:_refine_last_sigma); rounds 1-4 bounded the 0.9-quantile here)
+    _excluded(np.abs(occu - GOLD[tag + 'occu']), 3e-2, tag + 'occupancy')
+    _excluded(np.abs(depth - GOLD[tag + 'depth']), 0.16, tag + 'depth')            # 4 % of the [2, 6] depth range
     dn = np.abs(normal - GOLD[tag + 'normal']).max(1)
-    assert np.quantile(dn, 0.9) <= 8e-2 and np.median(dn) <= 4e-2, (np.quantile(dn, 0.9), np.median(dn))
+    _excluded(dn, 8e-2, tag + 'normal (as a vector)')
+    assert np.median(dn) <= 4e-2, np.median(dn)
     if bbox:
         surf, nrm = gi.geom_bbox_points()
     else:
@@ -243,24 +264,20 @@ def test_geometry_extraction_vs_reference_outputs(nfx_lib, cuda, bbox):
     want = GOLD[tag + 'lvis']
     assert lvis.shape == want.shape
     assert np.mean((lvis == 0) != (want == 0)) < 0.02                       # same front-lit set
-    assert np.quantile(np.abs(lvis - want), 0.9) <= 4e-2 and np.abs(lvis - want).mean() <= 2e-2
+    _excluded(np.abs(lvis - want).reshape(-1), 4e-2, tag + 'light visibility')
+    assert np.abs(lvis - want).mean() <= 2e-2
 
 
 # ---------------------------------------------------------------------------------------------- larger fixtures (r02)
-def _excluded(err, tol, what, max_frac=0.02):
-    """Counted exclusion list: every element must be within `tol` except an explicit, reported set of at most
-    `max_frac` of them (VERDICT r01: max-abs bounds on >= 98 % of the elements, no quantile bounds)."""
-    bad = np.flatnonzero(err > tol)
-    print("%s: %d of %d elements above %.0e (max %.3e): %s" % (what, len(bad), err.size, tol, err.max(), bad[:16].tolist()))
-    assert len(bad) <= max_frac * err.size, (what, len(bad), err.size, float(err.max()))
-    return bad
-
-
-def test_trained_nerf_1024_rays_vs_reference_outputs(nfx_lib, cuda):
+@pytest.mark.parametrize('coarse_precision', ['bf16', 'fp32'])
+def test_trained_nerf_1024_rays_vs_reference_outputs(nfx_lib, cuda, coarse_precision):
     """1024 rays of a 32 x 32 view through the trained networks against the reference's own render: max-abs 3e-2 on
     rgb / occupancy (4 % of the depth range on depth) for at least 98 % of the rays — silhouette rays, where a bf16-sized
-    change of the density moves the accumulated opacity, are the counted exceptions — and PSNR >= 40 dB."""
-    model = make('nerf', cuda)
+    change of the density moves the accumulated opacity, are the counted exceptions — and PSNR >= 40 dB.
+    coarse_precision = fp32 (ini key, r05): the coarse pass fp32-class — the rays above the tolerance are a coarse-pass
+    effect (bf16 coarse weights move a silhouette ray's fine samples across the fitted density edge):
+    with it EVERY ray's rgb is within 3e-2, no exclusion."""
+    model = make('nerf', cuda, coarse_precision=coarse_precision)
     nets = gi.trained_nerf_nets()
     np.testing.assert_allclose(gi.checksum_nerf(nets), GOLD['nerf1k_weight_checksum'], rtol=1e-6)
     for pref, net in zip(('coarse_', 'fine_'), nets):
@@ -273,7 +290,7 @@ def test_trained_nerf_1024_rays_vs_reference_outputs(nfx_lib, cuda):
     for lvl in ('coarse', 'fine'):
         rgb = to_vis[lvl + '_rgb'].cpu().numpy()
         want = GOLD['nerf1k_%s_rgb' % lvl]
-        _excluded(np.abs(rgb - want).max(-1), 3e-2, lvl + ' rgb')
+        _excluded(np.abs(rgb - want).max(-1), 3e-2, lvl + ' rgb', max_frac=0. if coarse_precision == 'fp32' else 0.02)
         _excluded(np.abs(to_vis[lvl + '_occu'].cpu().numpy() - GOLD['nerf1k_%s_occu' % lvl]), 3e-2, lvl + ' occu')
         _excluded(np.abs(to_vis[lvl + '_depth'].cpu().numpy() - GOLD['nerf1k_%s_depth' % lvl]), 0.16, lvl + ' depth')
         assert np.median(np.abs(rgb - want).max(-1)) < 3e-3
