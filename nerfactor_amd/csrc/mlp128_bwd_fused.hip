@@ -37,6 +37,8 @@
 // every row store AND every transposing read a 2-way conflict — 816 of the 2640 LDS cycles of a PART-1 tile by that model,
 // 29 % by the counters (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r04/pmc_train_digest.json).  No pitch serves
 // both (stores want the row stride = 4 mod 8 dwords, the transposing reads = 16 mod 64); the swizzle does.
+#include <type_traits>
+
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"
 #include "mlp128_train_layout.hpp"
@@ -159,6 +161,22 @@ __device__ __forceinline__ void mma(const Ctx& cx, const bf16x8 (&b)[KSA][1], in
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][0], acc, 0, 0, 0);
     }
 }
+// The same in two halves (round 5): the fragment reads of a sub-chunk are ISSUED first, the epilogue of the PREVIOUS tile
+// (30-70 VALU instructions: conversions, ReLU masks, the parked-row stores) runs while they are in flight, then the MFMAs.
+// With one wave per SIMD nothing else hides the ~130 cycles between a ds_read_b128 and its first use, and the ring's
+// barrier sits in front of every sub-chunk's reads: 35 exposed LDS latencies per 128-row tile before.
+template <int KS>
+__device__ __forceinline__ void load_frags(const Ctx& cx, int f0, bf16x8 (&a)[KS]) {
+    const char* p = cx.smem + cx.cur * kSlot + f0 * kFragBytes + cx.lane * 16;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
+    __builtin_amdgcn_sched_barrier(0);      // (the reads stay in front of what follows)
+}
+template <int KS, int KSA>
+__device__ __forceinline__ void mma_regs(const bf16x8 (&a)[KS], const bf16x8 (&b)[KSA][1], f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s][0], acc, 0, 0, 0);
+}
 // ---- packed 16-bit epilogues (the kernels are VALU-bound beside their MFMAs: r04 call C counted ~3300 VALU instructions
 // per 128-row tile and wave against 340 matrix instructions; the scalar forms — v_med3 + v_cvt per value, bf16 -> f32 +
 // compare + select per masked value, compare + select + shift-or per mask bit — were a third of them)
@@ -209,19 +227,29 @@ __device__ __forceinline__ void relu_tile(const f32x16& acc, bf16x8& lo, bf16x8&
 template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
 __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[4],
                                       char* park = nullptr, int lx = 0) {
-    static_for<0, 4>([&](auto T) {
+    f32x16 prev;      // tile t - 1's accumulators: its epilogue runs under tile t's fragment reads
+    auto epilogue = [&](auto T) {
         constexpr int t = decltype(T)::value;
-        begin<KSX, NS, K0 + t>(cx);
-        f32x16 acc[1];
-        bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);
-        mma<KS>(cx, b, 0, acc[0]);
-        end<KSX, NS, K0 + t>(cx);
-        relu_tile<BITS>(acc[0], out[2 * t][0], out[2 * t + 1][0], mk[t]);
+        relu_tile<BITS>(prev, out[2 * t][0], out[2 * t + 1][0], mk[t]);
         if (park != nullptr) {      // (the lane's swizzled row: k-step s at park + ((32 s) ^ lx), see store_rows)
             *reinterpret_cast<bf16x8*>(park + (((2 * t) * 32) ^ lx)) = out[2 * t][0];
             *reinterpret_cast<bf16x8*>(park + (((2 * t + 1) * 32) ^ lx)) = out[2 * t + 1][0];
         }
+    };
+    static_for<0, 4>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        begin<KSX, NS, K0 + t>(cx);
+        bf16x8 a[KS];
+        load_frags<KS>(cx, 0, a);
+        f32x16 acc[1];
+        bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);      // (broadcast reads: in flight under the epilogue as well)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (t > 0) epilogue(std::integral_constant<int, t - 1>{});
+        mma_regs<KS>(a, b, acc[0]);
+        end<KSX, NS, K0 + t>(cx);
+        prev = acc[0];
     });
+    epilogue(std::integral_constant<int, 3>{});
 }
 __device__ __forceinline__ void zero_acc(f32x16& a) {
 #pragma unroll
@@ -260,15 +288,20 @@ __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact
 template <int KSX, int NS, int K0, int MODE>
 __device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
                                       const char* park, int lx, bf16x8 (&dout)[8][1]) {
+    f32x16 prev;
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
+        bf16x8 a[8];
+        load_frags<8>(cx, 0, a);
+        if constexpr (t > 0) relu_mask<MODE>(prev, hact, mk, park, lx, t - 1, dout[2 * t - 2][0], dout[2 * t - 1][0]);
         f32x16 acc[1];
         zero_acc(acc[0]);
-        mma<8>(cx, dz, 0, acc[0]);
+        mma_regs<8>(a, dz, acc[0]);
         end<KSX, NS, K0 + t>(cx);
-        relu_mask<MODE>(acc[0], hact, mk, park, lx, t, dout[2 * t][0], dout[2 * t + 1][0]);
+        prev = acc[0];
     });
+    relu_mask<MODE>(prev, hact, mk, park, lx, 3, dout[6][0], dout[7][0]);
 }
 
 // ---- rows -> LDS, LDS -> row-contracting MFMA operands
@@ -441,18 +474,26 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr, lx);
         layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr, lx);
         layer<KSX, NS, 8, 8, kBits>(cx, bias_lds + 256, h1, h2, m2);
-        static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
-            constexpr int t = decltype(T)::value;
-            begin<KSX, NS, 12 + 2 * t>(cx);
-            f32x16 a3[1];
-            bias_init<1>(bias_lds + 384 + 32 * t, h, a3);
-            mma<8>(cx, h2, 0, a3[0]);
-            end<KSX, NS, 12 + 2 * t>(cx);
-            begin<KSX, NS, 13 + 2 * t>(cx);
-            mma<KSX>(cx, xin, 0, a3[0]);
-            end<KSX, NS, 13 + 2 * t>(cx);
-            relu_tile<kBits>(a3[0], h3[2 * t][0], h3[2 * t + 1][0], m3[t]);
-        });
+        {
+            f32x16 prev3;
+            static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
+                constexpr int t = decltype(T)::value;
+                begin<KSX, NS, 12 + 2 * t>(cx);
+                bf16x8 af[8];
+                load_frags<8>(cx, 0, af);
+                f32x16 a3[1];
+                bias_init<1>(bias_lds + 384 + 32 * t, h, a3);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (t > 0) relu_tile<kBits>(prev3, h3[2 * t - 2][0], h3[2 * t - 1][0], m3[t - 1]);   // (under the reads)
+                mma_regs<8>(af, h2, a3[0]);
+                end<KSX, NS, 12 + 2 * t>(cx);
+                begin<KSX, NS, 13 + 2 * t>(cx);
+                mma<KSX>(cx, xin, 0, a3[0]);
+                end<KSX, NS, 13 + 2 * t>(cx);
+                prev3 = a3[0];
+            });
+            relu_tile<kBits>(prev3, h3[6][0], h3[7][0], m3[3]);
+        }
         f32x16 logit[1];
         begin<KSX, NS, 20>(cx);
         bias_init<1>(bias_lds + 512, h, logit);
