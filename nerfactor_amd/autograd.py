@@ -78,6 +78,40 @@ class Lvis(torch.autograd.Function):
         return (None,) * 7 + tuple(rks) + tuple(rbs)
 
 
+class LvisFp32Class(torch.autograd.Function):
+    """lvis[n, L] of the SHIPPED light-visibility network at grad_precision = fp32 with fp32_matrix = pairs (round 5): the
+    forward is the tuned fp32-class kernel (mlp128_x3.hip: 339 TFLOP/s algorithmic against ~95 of the runtime-shaped one),
+    the backward the fp32-class runtime-shaped kernel on explicit rows [posenc(xyz_scale x) | posenc(dir(light - x_dir))]
+    — rebuilt chunk by chunk in the backward, so nothing of size rows x 90 lives between the two (the runtime-shaped
+    forward kept 377 MB of rows per 1024-ray step for autograd).  Both evaluate the same function with 16-bit operand
+    pairs; the backward re-computes its own forward for the ReLU masks."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_dir, lxyz, fwd_blob, net_fn, xyz_scale, n_freqs, chunk_rows, *params):
+        ctx.save_for_backward(xyz, xyz_dir, lxyz)
+        ctx.cfg = (net_fn, xyz_scale, n_freqs, chunk_rows, params)
+        return ops.lvis_fwd(xyz, lxyz, fwd_blob, xyz_scale=xyz_scale, xyz_dir=xyz_dir, prec='fp32')
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, xyz_dir, lxyz = ctx.saved_tensors
+        net_fn, xyz_scale, (lx, ll), chunk_rows, params = ctx.cfg
+        nk = len(params) // 2
+        (dks, rks), (dbs, rbs) = _targets(params[:nk]), _targets(params[nk:])
+        n, nl = xyz.shape[0], lxyz.shape[0]
+        dx_cols = 3 + 6 * lx
+        per = max(1, chunk_rows // nl)
+        dout = dout.contiguous()
+        net = net_fn()
+        for i in range(0, n, per):
+            x = (xyz[i:i + per] * xyz_scale).contiguous()
+            rows = torch.empty((x.shape[0] * nl, dx_cols + 3 + 6 * ll), dtype=torch.float32, device=xyz.device)
+            ops.embed(lx, x=x, per_ray=nl, out=rows)
+            ops.embed(ll, x=xyz_dir[i:i + per].contiguous(), lights=lxyz, out=rows, col0=dx_cols)
+            ops.mlp_generic_bwd(rows, net, dout[i:i + per].reshape(-1, 1), dks, dbs)
+        return (None,) * 8 + tuple(rks) + tuple(rbs)
+
+
 class ShadeMicrofacet(torch.autograd.Function):
     """rgb[n,3] under the trained light with the GGX microfacet BRDF (nerfactor.py:315-342)."""
 

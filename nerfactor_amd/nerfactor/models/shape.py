@@ -263,6 +263,15 @@ class Model(BaseModel):
         kernel from `self.lxyz` and `dir_pts` (default `pts`); an explicit `surf2l` tensor is
         accepted for signature compatibility only when it equals _calc_ldir(dir_pts)."""
         params = self._params128('lvis_mlp', 'lvis_out')
+        if self._net_tuned('lvis_mlp') and self._fp32_grads(params) and self.generic_prec == 'fp32':
+            # the shipped network at grad_precision = fp32 / fp32_matrix = pairs: tuned fp32-class forward kernel, runtime-shaped
+            # fp32-class backward on rows rebuilt in the backward (autograd.LvisFp32Class)
+            lvis = nfx_grad.LvisFp32Class.apply(
+                pts.detach(), (pts if dir_pts is None else dir_pts).detach(), self.lxyz.reshape(-1, 3).contiguous(),
+                self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1, prec='fp32'),
+                lambda: self._generic_net('lvis_mlp', 'lvis_out', 'sigmoid', train=True), self.xyz_scale,
+                (self.embedder['xyz'].n_freqs, self.embedder['ldir'].n_freqs), max(self.mlp_chunk, 1 << 18), *params)
+            return self.check_numerics(lvis, "Light visibility")
         if not self._net_tuned('lvis_mlp') or self._fp32_grads(params):
             return self.check_numerics(self._pred_lvis_generic(pts, dir_pts), "Light visibility")
         blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)

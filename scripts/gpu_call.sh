@@ -20,6 +20,7 @@ for st in "$@"; do
     smoke)    timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -6 $OUT/smoke.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
+    ubench-pair) (cd scripts/ubench && timeout 600 ./two_wave_valu_pair.bin > $ROOT/$OUT/two_wave_valu_pair.jsonl 2>&1); cat $OUT/two_wave_valu_pair.jsonl ;;
     bench-norefine) timeout 600 python bench.py --steps ${STEPS:-10} --warmup 3 --legs nerf --no-last-sample-refine > $OUT/bench_norefine.json 2> $OUT/bench_norefine.err; tail -c 1200 $OUT/bench_norefine.json ;;
     soak)     timeout 600 python scripts/soak_8wave.py > $OUT/soak_product.log 2>&1; tail -12 $OUT/soak_product.log ;;
     pmc)      for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
