@@ -54,6 +54,7 @@ HEAD_MAC = 65664 + 65664             # normal + albedo heads per point (+ 65 408
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 N_LIGHTS, N_PROBES = 512, 8
 PEAK_HBM_GBS = 8000.0                # MI355X HBM3E (MI355X_MICROARCH.md)
+PMC_RENDER_LEGS = 'nerf,nerfactor_microfacet,olat'      # the legs of measure_traffic's counter run (one pair of passes)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -164,12 +165,66 @@ def nerf_cpu_reference(nets, rayo, rayd, budget_s, timed_run=True):
 
 
 
+_LIVE_TRAFFIC = {}     # legs -> digest of a counter run of THIS command (measure_traffic)
+
+
+def measure_traffic(legs, extra=()):
+    """HBM traffic per launch of every nfx kernel of `legs`, MEASURED by this run: two child runs of
+    this very script (1 step, no CPU work) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` — separate passes,
+    kernel trace only, as MI355X_MICROARCH.md prescribes (the two counters do not fit one pass) — digested by
+    scripts/pmc_digest.py (FETCH_SIZE x 2: the gfx950 correction for wide coalesced reads).  Returns {} when rocprofv3 is
+    not on PATH, when this process is itself a child or already runs under a profiler, or when a pass fails or times out:
+    the caller then falls back to the committed constant and the line says which it is."""
+    import shutil
+    import subprocess
+    import tempfile
+    key = (legs,) + tuple(extra)
+    if key in _LIVE_TRAFFIC:
+        return _LIVE_TRAFFIC[key]
+    _LIVE_TRAFFIC[key] = {}
+    if (os.environ.get('NFX_BENCH_CHILD') or os.environ.get('NFX_BENCH_NO_PMC') or not shutil.which('rocprofv3')
+            or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)):
+        return {}
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    try:
+        import pmc_digest
+        with tempfile.TemporaryDirectory(prefix='nfx_pmc_', dir='/tmp') as tmp:
+            env = dict(os.environ, NFX_BENCH_CHILD='1', TMPDIR='/tmp')
+            for name, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+                cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', os.path.join(tmp, name),
+                       '-o', 'p', '--', sys.executable, os.path.join(ROOT, 'bench.py'), '--legs', legs, '--steps', '1',
+                       '--warmup', '1', '--no-cpu-baseline', '--no-hip-graph'] + list(extra)
+                res = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                if res.returncode != 0:
+                    return {}
+                # rocprofv3 writes <dir>/<host>/<pid>_... : hand pmc_digest one directory per pass
+                found = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, name)) for f in fs if f.endswith('counter_collection.csv')]
+                if not found:
+                    return {}
+                os.makedirs(os.path.join(tmp, 'digest', name), exist_ok=True)
+                shutil.copy(found[0], os.path.join(tmp, 'digest', name, 'p_counter_collection.csv'))
+            _LIVE_TRAFFIC[key] = pmc_digest.digest(os.path.join(tmp, 'digest'))
+    except Exception:        # (a profiler problem must never take the bench line down)
+        _LIVE_TRAFFIC[key] = {}
+    return _LIVE_TRAFFIC[key]
+
+
+def live_traffic(legs, kernel_substr, scale=1, extra=()):
+    """(GB per launch, source) from measure_traffic, or (None, None)."""
+    for k, v in measure_traffic(legs, extra).items():
+        if kernel_substr in k and 'hbm_write_bytes' in v and 'hbm_read_bytes_corrected' in v:
+            return (scale * (v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']) / 1e9,
+                    "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a 1-step child of this command "
+                    "(FETCH_SIZE x 2 for gfx950), average of %d dispatches" % int(v.get('dispatches', 0)))
+    return None, None
+
+
 def committed_traffic(kernel_substr, scale=1):
     """(GB per launch, source) of a kernel from the newest committed PMC digest (scripts/gpu_r03_final.sh ->
     scripts/pmc_digest.py: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the kernel's dispatches of
     this very command at N = 1).  rocprofv3 counter passes cannot run inside this process, so the figure is a committed
     constant and the line says so."""
-    for rnd, name in (('r04', 'pmc_digest.json'), ('r04', 'pmc_train_digest.json'), ('r03', 'pmc_digest.json'),
+    for rnd, name in (('r05', 'pmc_digest.json'), ('r05', 'pmc_train_digest.json'), ('r04', 'pmc_digest.json'), ('r04', 'pmc_train_digest.json'), ('r03', 'pmc_digest.json'),
                       ('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'), ('r01', 'pmc_nerfactor_digest.json')):
         dig = os.path.join(ROOT, 'profiles', rnd, name)
         if not os.path.exists(dig):
@@ -217,8 +272,12 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     variant = str(ops._capi.get_option("nerf_variant") or 7)
     # digest = average over the coarse and the fine dispatch; a launch pair = both
     fp32 = args.precision == 'fp32'
-    traffic, traffic_source = committed_traffic('nerf_mlp', scale=2) if n_local == H * W and variant == "7" and not fp32 \
-        else (None, None)
+    traffic, traffic_source = (None, None)
+    if n_local == H * W and variant == "7" and not fp32:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:      # measured by a counter run of this very command
+            traffic, traffic_source = live_traffic(PMC_RENDER_LEGS, 'nerf_mlp_bf16_v6', scale=2)
+        if traffic is None:
+            traffic, traffic_source = committed_traffic('nerf_mlp', scale=2)
     out = {
         "value": sh.rays_per_step_all_ranks * args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -425,8 +484,13 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     # lvis_pre and read once by the main kernel, the position read
     lv_traffic, lv_source = None, None
     if world == 1 and args.precision == 'bf16':
-        a, src = committed_traffic('resident128_kernel')
-        b, _ = committed_traffic('lvis_pre_kernel')
+        a, src, b = None, None, None
+        if rank == 0 and not args.no_cpu_baseline:
+            a, src = live_traffic(PMC_RENDER_LEGS, 'resident128_kernel')
+            b, _ = live_traffic(PMC_RENDER_LEGS, 'lvis_pre_kernel')
+        if a is None or b is None:
+            a, src = committed_traffic('resident128_kernel')
+            b, _ = committed_traffic('lvis_pre_kernel')
         if a is not None and b is not None:
             lv_traffic, lv_source = a + b, src
     out = {
@@ -633,9 +697,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         # gradients, every MFMA operand a bf16 hi / lo pair, forward and backward: csrc/mlp_generic.hip, round 5) — its
         # time, its gradients held to the reference's fp32 gradients directly, and the time of the same step on the native
         # fp32 matrix instruction (fp32_matrix = native, round 4's path) beside it
-        def time_fp32(fp32_matrix, graph):
+        def time_fp32(fp32_matrix, graph, **more):
             torch.manual_seed(5)
-            m32 = get_model_class(name)(make_config(name, precision='fp32', fp32_matrix=fp32_matrix, **extra)).to(dev)
+            m32 = get_model_class(name)(make_config(name, precision='fp32', fp32_matrix=fp32_matrix, **extra, **more)).to(dev)
             o32 = optim.make_optimizer(m32, m32.config)
             step32 = optim.GraphedTrainStep(m32, o32, global_bs) if graph else (lambda b: optim.train_step(m32, b, o32, global_bs))
             for _ in range(6 if graph else 3):
@@ -650,6 +714,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
             return dt32 * 1e3
         default_mode = get_model_class(name).DEFAULT_FP32_MATRIX      # pairs for the surface models, native for NeRF
         ms32 = {"pairs_eager": time_fp32('pairs', False), "native_eager": time_fp32('native', False)}
+        # (tests/test_gpu_convergence.py: the floor of bf16 training comes from the bf16 FORWARD; fp32-class forward kernels with
+        #  the bf16-operand backward kernels — precision = fp32, grad_precision = bf16 — recover most of it)
+        ms32["fp32_forward_bf16_grads_eager"] = time_fp32('pairs', False, grad_precision='bf16')
         if name != 'nerf' and not args.no_hip_graph:
             try:
                 ms32["pairs_hip_graph"] = time_fp32('pairs', True)
@@ -855,6 +922,10 @@ def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     # algorithmic bytes: 512 x 12 B written per foreground point; read: the point's visibility row (2 KiB) + 52 B
     alg = fg_per_call * (N_LIGHTS * 12 + N_LIGHTS * 4 + 52)
     gbs = alg / k_s / 1e9
+    o_traffic, o_source = live_traffic(PMC_RENDER_LEGS, 'shade_olat_kernel') if (rank == 0 and world == 1 and not args.no_cpu_baseline) \
+        else (None, None)
+    if o_traffic is None:
+        o_traffic, o_source = committed_traffic('shade_olat_kernel')
     return {
         "workload": "nerfactor_microfacet OLAT relighting (BASELINE.json configs[4], OLAT half): 800x800 surface points "
                     "per view (60 % foreground), 512 one-light renders per point, Model.call(mode='test', relight_olat=True)",
@@ -864,7 +935,11 @@ def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         "roofline": {"bound": "hbm", "kernel": "shade_olat_kernel (%d foreground points x 512 lights x 3 floats written)"
                                                % int(fg_per_call),
                      "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                     "avg_launch_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                     "avg_launch_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg, "traffic": o_traffic,
+                     "traffic_unit": "GB per launch", "traffic_source": o_source,
+                     # (static count of the kernel: 2348 VALU instructions, ~2000 executed per point and wave — the per-light GGX
+                     #  term, 512 of them per point: the kernel sits at its VALU issue rate, not at the HBM roof)
+                     "note": "VALU-bound by the per-light microfacet term: the HBM roofline is the bound by bytes, not the binding one",
                      "share_of_step": k_s * sh.n_views / (elapsed / args.steps)},
     }
 

@@ -70,7 +70,8 @@ class DevicePacker:
     """Re-packs one network's blob ON THE DEVICE (nfx_pack_gather) from an index map derived once from the host
     packer `pack_fn(kernels, biases) -> uint8 blob`: the packer is run on arrays holding the base-256 digits (+1)
     of each parameter's flat index — exactly representable in bf16 — so the blobs it returns ARE the gather map
-    (0 = padding).  A probe with every parameter = 1 + 2^-20 tells fp32 words from bf16 pairs."""
+    (0 = padding).  A probe with every parameter = 1 + 2^-20 tells fp32 words from bf16 pairs, and the LO halves of the
+    fp32-class kernels' hi / lo operand pairs from the hi ones (round 5: those blobs are re-packed on the device too)."""
 
     def __init__(self, pack_fn, shapes_k, shapes_b):
         # a packer whose blob is NOT a gather (the hi / lo fragments of the runtime-shaped kernels' fp32-class mode) may
@@ -83,37 +84,48 @@ class DevicePacker:
         self.shapes = [tuple(s) for s in list(shapes_k) + list(shapes_b)]
         self.nk = len(shapes_k)
         sizes = [int(np.prod(s)) for s in self.shapes]
-        if sum(sizes) >= 1 << 24:
+        if sum(sizes) >= 1 << 24:      # (bit 30 of a map entry is the residual flag)
             raise _capi.NfxError("DevicePacker: network too large for the 3-digit index map")
         offs = np.cumsum([0] + sizes)
 
         def run(arrays):
             return map_fn(arrays[:self.nk], arrays[self.nk:]).numpy()
 
-        # probe: every parameter = 1 + 2^-20 -> an fp32 word reads 0x3f800008, a bf16 half 0x3f80 (or 0 = padding)
+        # probe: every parameter = 1 + 2^-20 -> an fp32 word reads 0x3f800008, a bf16 half 0x3f80 (or 0 = padding); the LO
+        # half of an fp32-class operand pair (mlp_x3.hpp: bf16(v - bf16(v))) reads bf16(2^-20) = 0x3580
         probe = run([np.full(s, 1. + 2. ** -20, np.float32) for s in self.shapes]).view(np.uint32)
         is_bias = probe == np.uint32(0x3f800008)                  # "bias" = any parameter stored as fp32
-        halves_ok = np.isin(probe & np.uint32(0xffff), (0, 0x3f80)) & np.isin(probe >> np.uint32(16), (0, 0x3f80))
+        kinds = (0, 0x3f80, 0x3580)
+        halves_ok = np.isin(probe & np.uint32(0xffff), kinds) & np.isin(probe >> np.uint32(16), kinds)
         if not (is_bias | halves_ok).all() or not is_bias.any():
             raise NotAGather("DevicePacker: cannot separate the fp32 and bf16 regions of the blob")
+        res_lo = ~is_bias & ((probe & np.uint32(0xffff)) == 0x3580)       # this half holds a residual (lo) value
+        res_hi = ~is_bias & ((probe >> np.uint32(16)) == 0x3580)
         self.n_words = int(is_bias.size)
         self.nbytes = self.n_words * 4
         lo = np.zeros(self.n_words, np.int64)
         hi = np.zeros(self.n_words, np.int64)
         fb = np.zeros(self.n_words, np.int64)
         pad_lo = pad_hi = pad_b = None
+        # digit passes: parameter i = (digit_d(i) + 1) (1 + 2^-10).  bf16 of it is digit + 1 exactly (the 2^-10 part is under
+        # half an ulp of any 8-bit integer), its residual is (digit + 1) 2^-10 exactly, an fp32 word holds the product
+        eps = np.float32(2. ** -10)
         for d in range(3):
-            arrays = [(((np.arange(offs[i], offs[i + 1]) >> (8 * d)) & 255) + 1).astype(np.float32).reshape(s)
+            arrays = [((((np.arange(offs[i], offs[i + 1]) >> (8 * d)) & 255) + 1).astype(np.float32) * (np.float32(1.) + eps)).reshape(s)
                       for i, s in enumerate(self.shapes)]
             words = run(arrays).view(np.uint32)
-            vlo = (words << 16).view(np.float32).astype(np.int64)              # low bf16 of every word
-            vhi = (words & np.uint32(0xffff0000)).view(np.float32).astype(np.int64)
-            vb = np.where(is_bias, words.view(np.float32), 0.).astype(np.int64)
+            vlo = (words << 16).view(np.float32).astype(np.float64)              # low bf16 of every word
+            vhi = (words & np.uint32(0xffff0000)).view(np.float32).astype(np.float64)
+            vlo = np.rint(np.where(res_lo, vlo * 1024., vlo)).astype(np.int64)
+            vhi = np.rint(np.where(res_hi, vhi * 1024., vhi)).astype(np.int64)
+            vb = np.rint(np.where(is_bias, words.view(np.float32).astype(np.float64) / (1. + 2. ** -10), 0.)).astype(np.int64)
             if d == 0:
                 pad_lo, pad_hi, pad_b = vlo == 0, vhi == 0, vb == 0
             lo += np.maximum(vlo - 1, 0) << (8 * d)
             hi += np.maximum(vhi - 1, 0) << (8 * d)
             fb += np.maximum(vb - 1, 0) << (8 * d)
+        lo = np.where(res_lo, lo | (1 << 30), lo)
+        hi = np.where(res_hi, hi | (1 << 30), hi)
         lo[pad_lo], hi[pad_hi], fb[pad_b] = -1, -1, -1
         m = np.empty((self.n_words, 2), np.int32)
         m[:, 0] = np.where(is_bias, fb, lo)

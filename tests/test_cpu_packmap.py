@@ -12,9 +12,14 @@ def _bf16_bits(x):
 def _emulate_gather(packer, arrays):
     src = np.concatenate([a.reshape(-1) for a in arrays]).astype(np.float32)
     m = packer.map_host.astype(np.int64)
-    take = lambda idx: np.where(idx >= 0, src[np.maximum(idx, 0)], 0.).astype(np.float32)
+    take = lambda idx: np.where(idx >= 0, src[np.maximum(idx, 0) & 0x3fffffff], 0.).astype(np.float32)
     fp32 = m[:, 1] == -2
-    pair = _bf16_bits(take(m[:, 0])).astype(np.uint32) | (_bf16_bits(take(np.where(fp32, -1, m[:, 1]))).astype(np.uint32) << 16)
+
+    def half(idx):      # pack_gather.hip: bit 30 of an index = the LO half of the fp32-class pair, bf16(v - bf16(v))
+        v = take(idx)
+        hi = (_bf16_bits(v).astype(np.uint32) << 16).view(np.float32)
+        return np.where((idx >= 0) & ((idx & (1 << 30)) != 0), _bf16_bits(v - hi), _bf16_bits(v))
+    pair = half(m[:, 0]).astype(np.uint32) | (half(np.where(fp32, -1, m[:, 1])).astype(np.uint32) << 16)
     return np.where(fp32, take(m[:, 0]).view(np.uint32), pair).astype(np.uint32).view(np.uint8)
 
 
@@ -34,11 +39,17 @@ def _cases(nfx):
         'normal_train': (lambda k, b: ops.pack_mlp128_train_weights(k, b, nfx.IN_XYZ, 3), m128(63, 3)),
         'lvis_train': (lambda k, b: ops.pack_mlp128_train_weights(k, b, nfx.IN_XYZ_LDIR, 1), m128(90, 1)),
         'brdf_train': (lambda k, b: ops.pack_brdf_train_weights(k, b, 3), m128(18, 1)),
+        # precision = fp32: the split hi / lo fragments of the tuned fp32-class kernels (round 5: gathers of (hi, lo) halves)
+        'nerf_fp32': (lambda k, b: ops.pack_nerf_weights(k, b, 'fp32'), nerf_k),
+        'nerf_geom_fp32': (lambda k, b: ops.pack_nerf_geom_weights(k, b, 'fp32'), nerf_k),
+        'normal_fp32': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ, 3, prec='fp32'), m128(63, 3)),
+        'lvis_fp32': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_XYZ_LDIR, 1, prec='fp32'), m128(90, 1)),
+        'brdf_fp32': (lambda k, b: ops.pack_mlp128_weights(k, b, nfx.IN_Z_RUSINK, 1, z_dim=3, prec='fp32'), m128(18, 1)),
     }
 
 
 @pytest.mark.parametrize('name', ['nerf', 'nerf_train', 'nerf_geom', 'normal', 'lvis', 'brdf', 'normal_train', 'lvis_train',
-                                  'brdf_train'])
+                                  'brdf_train', 'nerf_fp32', 'nerf_geom_fp32', 'normal_fp32', 'lvis_fp32', 'brdf_fp32'])
 def test_gather_map_reproduces_host_packer(nfx_lib, name):
     from nerfactor_amd import ops
     pack_fn, shapes_k = _cases(nfx_lib)[name]
@@ -53,13 +64,16 @@ def test_gather_map_reproduces_host_packer(nfx_lib, name):
     n_kernel = sum(int(np.prod(s)) for s in shapes_k)
     m = packer.map_host
     fp32 = m[:, 1] == -2
-    if name != 'nerf_geom':   # (its fp32 region also carries the sigma_out kernel)
+    if not name.startswith('nerf_geom'):   # (its fp32 region also carries the sigma_out kernel)
         assert (m[fp32, 0][m[fp32, 0] >= 0] >= n_kernel).all()         # fp32 words gather biases only
-    assert m[~fp32].max() < n_kernel                                   # bf16 pairs gather kernels only
+    idx = m[~fp32]
+    assert (idx[idx >= 0] & 0x3fffffff).max() < n_kernel               # bf16 halves gather kernels only
+    assert bool(((idx >= 0) & ((idx & (1 << 30)) != 0)).any()) == name.endswith('_fp32')     # residual halves: fp32-class blobs only
 
 
 def test_fp32_split_blob_is_hi_lo_of_the_bf16_blob(nfx_lib):
-    """NFX_PREC_FP32 blob = [bf16(W) fragments | bf16(W - bf16(W)) fragments | fp32 biases]; not a gather."""
+    """NFX_PREC_FP32 blob = [bf16(W) fragments | bf16(W - bf16(W)) fragments | fp32 biases]: a gather of (hi, lo) halves
+    (round 5: ops.DevicePacker maps it, test_gather_map_reproduces_host_packer[*_fp32])."""
     from nerfactor_amd import ops
     rng = np.random.default_rng(5)
     ks = [rng.normal(size=s).astype(np.float32) for s in ops.NERF_LAYER_SHAPES]
@@ -76,9 +90,6 @@ def test_fp32_split_blob_is_hi_lo_of_the_bf16_blob(nfx_lib):
     want_lo = ops.pack_nerf_weights(ks_lo, bs, 'bf16').numpy()[:nw]
     assert np.array_equal(f32[nw:2 * nw], want_lo)
     assert np.abs(lo).max() <= 2. ** -8 * np.abs(hi).max()
-    with pytest.raises(ops.NotAGather):
-        ops.DevicePacker(lambda k, b: ops.pack_nerf_weights(k, b, 'fp32'), ops.NERF_LAYER_SHAPES,
-                         [(s[1],) for s in ops.NERF_LAYER_SHAPES])
 
 
 def test_fp32_split_blobs_of_the_width128_networks(nfx_lib):
@@ -110,9 +121,6 @@ def test_fp32_split_blobs_of_the_width128_networks(nfx_lib):
             assert np.array_equal(np.sort(lo[lo != 0]), np.sort(want_lo[want_lo != 0]))
             biases = f32[2 * nw:].view(np.float32)
             assert np.array_equal(biases[:512], np.concatenate(bs[:4])) and biases[512] == bs[4][0]
-        with pytest.raises(ops.NotAGather):
-            ops.DevicePacker(lambda k, b: ops.pack_mlp128_weights(k, b, kind, 1, z_dim=zd, prec='fp32'), shapes,
-                             [(s[1],) for s in shapes])
 
 
 def test_fp32_split_blob_of_the_density_gradient_kernel(nfx_lib):
