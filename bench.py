@@ -639,7 +639,7 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     # ~170 launches and sits at the host's issue time (2.2-2.8 ms depending on the box's CPU), whatever its kernels
     # take: the replay is what shows the GPU time.  N > 1 ranks keep the eager step (the all-reduce is not captured).
     graph_dt, graph_note = None, None
-    if world == 1 and not args.no_hip_graph and name != 'nerf':
+    if world == 1 and not args.no_hip_graph:      # (NeRF too since r05: torch's generator hands a replay the stratified draws of an eager step)
         gstep = optim.GraphedTrainStep(model, opt, global_bs)
         glosses = []
 
@@ -717,7 +717,7 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         # (tests/test_gpu_convergence.py: the floor of bf16 training comes from the bf16 FORWARD; fp32-class forward kernels with
         #  the bf16-operand backward kernels — precision = fp32, grad_precision = bf16 — recover most of it)
         ms32["fp32_forward_bf16_grads_eager"] = time_fp32('pairs', False, grad_precision='bf16')
-        if name != 'nerf' and not args.no_hip_graph:
+        if not args.no_hip_graph:
             try:
                 ms32["pairs_hip_graph"] = time_fp32('pairs', True)
             except Exception as e:      # (a capture failure must not take the whole line down)

@@ -60,7 +60,6 @@ typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-constexpr int kRingGroups = 3;
 
 // What differs between the operand modes M: kBf16: bf16 operands, v_mfma_f32_32x32x16_bf16; kNative: fp32 operands,
 // 8 x v_mfma_f32_32x32x2_f32 per k-step; kX3: the fp32 DATA layout (LDS, workspace, fragment size) of kNative with
@@ -73,6 +72,11 @@ struct P {
     static constexpr int kFrag = 32 * 16 * kElem;             // one k-step's A fragment (32 outputs x 16 inputs): 1 or 2 KiB
     static constexpr int kGroupBytes = kGroup * kFrag;
     static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
+    // ring depth in groups.  bf16: 3 (12 KiB: a 256-wide network keeps 4 waves per CU).  fp32 modes (8-KiB groups): 2 — a
+    // group is 12 (pairs) or 32 (native) MFMAs per output tile, two groups ahead are > 700 matrix-pipe cycles of cover
+    // for an L2 fetch, and 16 instead of 24 KiB of ring is what lets a width-128 network (33.8 KiB of fp32 activations per
+    // wave: the surface MLPs, the BRDF prior) keep THREE waves per CU instead of two (round 5)
+    static constexpr int kRingGroups = kF32 ? 2 : 3;
     static constexpr int kRingBytes = kRingGroups * kGroupBytes;
     static constexpr int kStep = 16 * kElem;                  // bytes of one k-step in a row: 32 or 64
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
@@ -80,7 +84,8 @@ struct P {
 };
 static_assert(P<kBf16>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
 static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
-static_assert(kGroup == 4 && kRingGroups == 3, "tile_mma's s_waitcnt vmcnt(8 | 16) = (kRingGroups - 1) groups of pieces in flight");
+static_assert(kGroup == 4 && P<kBf16>::kRingGroups == 3 && P<kNative>::kRingGroups == 2 && P<kX3>::kRingGroups == 2,
+              "wait_oldest: s_waitcnt vmcnt(8) = (kRingGroups - 1) groups of pieces in flight: 2 x 4 (bf16) | 1 x 8 (fp32 modes)");
 
 // The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
 // to whole groups of kGroup), copied global -> LDS by the DMA path (lds_dma.hpp) kRingGroups groups ahead of the MFMAs —
@@ -103,7 +108,7 @@ struct Ring {
         if constexpr (P<M>::kF32) lds_dma_pieces<4>(lane_off, next + 4096, dst + 4096u);
         next += P<M>::kGroupBytes;
         if (next == end) next = begin;
-        slot = slot == kRingGroups - 1 ? 0 : slot + 1;
+        slot = slot == P<M>::kRingGroups - 1 ? 0 : slot + 1;
     }
     __device__ __forceinline__ void start(lds_char* ring, const char* stream, int n_frags, int lane) {
         lds_ptr = ring;
@@ -113,11 +118,10 @@ struct Ring {
         end = stream + (size_t)n_frags * P<M>::kFrag;
         slot = 0;
 #pragma unroll
-        for (int i = 0; i < kRingGroups; ++i) issue();
+        for (int i = 0; i < P<M>::kRingGroups; ++i) issue();
     }
-    __device__ __forceinline__ void wait_oldest() {
-        if constexpr (P<M>::kF32) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __device__ __forceinline__ void wait_oldest() {      // (kRingGroups - 1) groups x pieces per group = 8 in both layouts
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
 };
 // kX3: eight consecutive fp32 features of a row -> the bf16 pair (mlp_x3.hpp: hi = bf16(v), lo = bf16(v - hi); v - hi is exact)

@@ -811,6 +811,38 @@ def test_fused_pair_loss_vs_torch(nfx_lib, cuda, kind):
 
 
 @pytest.mark.determinism
+def test_graphed_nerf_train_step_equals_the_eager_one(nfx_lib, cuda):
+    """The NeRF step (stratified coarse samples and inverse-CDF fine samples drawn with torch.rand INSIDE the step, perturb =
+    True as nerf.ini trains) captured in a hipGraph: torch's generator hands every replay the draws the eager step would have
+    made, so 40 steps on changing batches agree bit for bit with the eager run (the bench's NeRF training leg
+    was timed eager)."""
+    from nerfactor_amd import optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    n = 128
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    bs = []
+    for i in range(4):
+        cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+        bs.append((None, None, cam, t(rng.uniform(-1, 1, size=(n, 3))) - cam, t(rng.uniform(size=(n, 3)))))
+
+    def run(graph):
+        torch.manual_seed(11)
+        cfg = make_config('nerf', n_samples_coarse='16', n_samples_fine='32')
+        assert cfg.getboolean('DEFAULT', 'perturb')
+        model = get_model_class('nerf')(cfg).to(cuda)
+        opt = optim.make_optimizer(model, cfg)
+        step = optim.GraphedTrainStep(model, opt, n, warmup=2) if graph else (lambda b: optim.train_step(model, b, opt, n))
+        losses = [step(bs[i % len(bs)])[0] for i in range(40)]
+        return torch.stack(losses), opt.flat.clone(), step
+    le, pe, _ = run(False)
+    lg, pg, step = run(True)
+    assert len(step.graphs) == 1, "the step was not captured"
+    assert torch.isfinite(le).all() and torch.equal(le, lg) and torch.equal(pe, pg)
+
+
+@pytest.mark.determinism
 @pytest.mark.parametrize("name,jitter,steps,precision", [
     ("shape", "0.01", 200, "bf16"), ("nerfactor_microfacet", "0.01", 200, "bf16"), ("nerfactor", "0.01", 200, "bf16"),
     ("nerfactor_microfacet", "0", 12, "bf16"), ("nerfactor_microfacet", "0.01", 12, "fp32")])
