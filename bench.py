@@ -658,6 +658,8 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                 graph_note = "non-finite loss in the replayed steps"
         except FloatingPointError as e:
             graph_note = "check_numerics raised in the replayed steps: %s" % e
+    if graph_dt is not None and graph_dt > dt_eager:      # (a GPU-bound step — NeRF: ~60 launches — gains nothing from the replay)
+        graph_dt, graph_note = None, "the hipGraph replay was not faster: %.3f ms" % (graph_dt * 1e3)
     dt = graph_dt if graph_dt is not None else dt_eager
     if name == 'nerf':
         # per ray 64 coarse + 192 fine points; forward + re-computed forward + dgrad + wgrad = 4 x the forward MACs
