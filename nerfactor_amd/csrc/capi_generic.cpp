@@ -273,7 +273,8 @@ size_t nfx_mlp_generic_bwd_workspace_bytes(int64_t n, int d_in, int n_layers, co
     BwdPlan p;
     if (n < 0 || !widths || check_prec(prec, "nfx_mlp_generic_bwd_workspace_bytes") || bwd_plan(d_in, n_layers, widths, skip_input, nullptr, &p)) return 0;
     const long long tiles = (n + 31) / 32;
-    return align256((size_t)tiles * p.feat_rows * (wide(prec) ? 128 : 64)) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
+    // (tiles + 1: a spare tile for the waves of the last workgroup that have no row tile of their own, mlp_generic.hip)
+    return align256((size_t)(tiles + 1) * p.feat_rows * (wide(prec) ? 128 : 64)) + (size_t)wgrad_splits(tiles, p.n_jobs) * p.slice * 4 + 256;
 }
 
 int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_layers, const int* widths, const int* acts,
@@ -331,7 +332,7 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     wa.n_jobs = p.n_jobs;
     wa.slice = p.slice;
     wa.dw_total = p.dw_total;
-    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)tiles * p.feat_rows * (wide(prec) ? 128 : 64)));
+    wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)(tiles + 1) * p.feat_rows * (wide(prec) ? 128 : 64)));
     for (int i = 0; i < n_layers; ++i) {
         ba.f.layer[i] = wa.layer[i] = p.layer[i];
         ba.b[i] = wa.b[i] = p.b[i];

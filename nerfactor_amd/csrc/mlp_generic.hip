@@ -72,11 +72,10 @@ struct P {
     static constexpr int kFrag = 32 * 16 * kElem;             // one k-step's A fragment (32 outputs x 16 inputs): 1 or 2 KiB
     static constexpr int kGroupBytes = kGroup * kFrag;
     static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
-    // ring depth in groups.  bf16: 3 (12 KiB: a 256-wide network keeps 4 waves per CU).  fp32 modes (8-KiB groups): 2 — a
-    // group is 12 (pairs) or 32 (native) MFMAs per output tile, two groups ahead are > 700 matrix-pipe cycles of cover
-    // for an L2 fetch, and 16 instead of 24 KiB of ring is what lets a width-128 network (33.8 KiB of fp32 activations per
-    // wave: the surface MLPs, the BRDF prior) keep THREE waves per CU instead of two (round 5)
-    static constexpr int kRingGroups = kF32 ? 2 : 3;
+    // ring depth in groups (round 5: the ring is SHARED by the NW waves of a workgroup, below): a slot is refilled one
+    // group after it was read, so the fetch runs kRingGroups - 1 groups ahead.  bf16: 4 slots of 4 KiB; fp32 modes: 3 of
+    // 8 KiB (a group is 12 (pairs) or 32 (native) MFMAs per output tile there: two groups ahead are > 700 matrix-pipe cycles)
+    static constexpr int kRingGroups = kF32 ? 3 : 4;
     static constexpr int kRingBytes = kRingGroups * kGroupBytes;
     static constexpr int kStep = 16 * kElem;                  // bytes of one k-step in a row: 32 or 64
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
@@ -84,44 +83,73 @@ struct P {
 };
 static_assert(P<kBf16>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
 static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
-static_assert(kGroup == 4 && P<kBf16>::kRingGroups == 3 && P<kNative>::kRingGroups == 2 && P<kX3>::kRingGroups == 2,
-              "wait_oldest: s_waitcnt vmcnt(8) = (kRingGroups - 1) groups of pieces in flight: 2 x 4 (bf16) | 1 x 8 (fp32 modes)");
+static_assert(kGroup == 4, "a group = 4 fragments = 4 (bf16) or 8 (fp32 modes) 1-KiB DMA pieces");
 
-// The weight stream of one wave: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded
-// to whole groups of kGroup), copied global -> LDS by the DMA path (lds_dma.hpp) kRingGroups groups ahead of the MFMAs —
-// a register-staged prefetch cannot rotate its buffers without waiting for the loads it just issued; an LDS slot is
-// only an address.  The stream is circular: behind its last group the ring already fetches the next row tile's first.
-// vmcnt is in order, so "at most two groups of pieces outstanding" = the oldest group has landed; the wave's other VMEM
-// operations can only make that wait stricter.
-template <int M>
+// The weight stream: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded to whole
+// groups of kGroup), copied global -> LDS by the DMA path (lds_dma.hpp) ahead of the MFMAs — a register-staged prefetch
+// cannot rotate its buffers without waiting for the loads it just issued; an LDS slot is only an address.  The stream is
+// circular: behind its last group the ring already fetches the next row tile's first.
+//
+// Round 5: ONE ring per workgroup of NW waves (NW = 4, 2 or 1: what fits the LDS beside NW activation areas).  Round 4 gave
+// every wave its own ring: each wave then issues every 1-KiB DMA piece of the network itself, 4 (bf16) or 8 (fp32 modes)
+// global_load_lds per 4 (12, 32) MFMAs, and at 60-180 cycles of issue per piece (MI355X_MICROARCH.md) the DMA issue, not
+// the matrix pipe, set the pace (bf16: 13 % matrix-pipe busy at 384 TFLOP/s).  The NW waves of a workgroup run the same
+// network on NW different 32-row tiles in lock step — identical control flow, since every trip count comes from the layer
+// table — so a group is fetched ONCE, each wave issuing pieces / NW of it, and consumed by all:
+//   acquire(g): s_waitcnt vmcnt(my pieces of the groups behind g still allowed in flight) ; s_barrier   -> every wave's
+//               pieces of group g have landed AND every wave has finished reading group g - 1 (release below) -> the
+//               slot of g - 1 is refilled right here, with group g - 1 + kRingGroups;
+//   ... A fragments of group g from its slot, MFMAs ...
+//   release():  s_waitcnt lgkmcnt(0)   (this wave's reads of the slot have returned before it can reach the next barrier).
+// vmcnt is in order, so "at most k pieces outstanding" = the older ones have landed; the wave's other VMEM operations
+// can only make that wait stricter.  Every instantiation computes the same sums in the same order: bit-identical to r04.
+template <int M, int NW>
 struct Ring {
+    static constexpr int kMine = P<M>::kPieces / NW;     // DMA pieces of every group this wave issues: 8, 4, 2 or 1
+    static constexpr int kR = P<M>::kRingGroups;
+    static_assert(P<M>::kPieces % NW == 0 && kMine >= 1, "pieces per wave");
     const char* next;    // next group to fetch (wave-uniform)
     const char* begin;
     const char* end;
     const lds_char* lds_ptr; // the ring, as a pointer (reads) ...
     unsigned lds;            // ... and as the LDS address M0 takes
     unsigned lane_off;
-    int slot;            // oldest group = the one the MFMAs read next = the one refilled after them
-    __device__ __forceinline__ void issue() {
-        const unsigned dst = lds + (unsigned)slot * P<M>::kGroupBytes;
-        lds_dma_pieces<4>(lane_off, next, dst);
-        if constexpr (P<M>::kF32) lds_dma_pieces<4>(lane_off, next + 4096, dst + 4096u);
+    unsigned mine;       // byte offset of this wave's pieces inside a group
+    int slot;            // the group the MFMAs read next
+    int fill;            // the slot the next fetched group goes to
+    __device__ __forceinline__ void fetch() {
+        const unsigned dst = lds + (unsigned)fill * P<M>::kGroupBytes + mine;
+        if constexpr (kMine == 8) {
+            lds_dma_pieces<4>(lane_off, next + mine, dst);
+            lds_dma_pieces<4>(lane_off, next + mine + 4096, dst + 4096u);
+        } else {
+            lds_dma_pieces<kMine>(lane_off, next + mine, dst);
+        }
         next += P<M>::kGroupBytes;
         if (next == end) next = begin;
-        slot = slot == P<M>::kRingGroups - 1 ? 0 : slot + 1;
+        fill = fill == kR - 1 ? 0 : fill + 1;
     }
-    __device__ __forceinline__ void start(lds_char* ring, const char* stream, int n_frags, int lane) {
+    __device__ __forceinline__ void start(lds_char* ring, const char* stream, int n_frags, int lane, int wave) {
         lds_ptr = ring;
         lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
         lane_off = (unsigned)lane * 16u;
+        mine = (unsigned)wave * (kMine * 1024u);
         begin = next = stream;
         end = stream + (size_t)n_frags * P<M>::kFrag;
-        slot = 0;
+        slot = fill = 0;
 #pragma unroll
-        for (int i = 0; i < P<M>::kRingGroups; ++i) issue();
+        for (int i = 0; i < kR - 1; ++i) fetch();
     }
-    __device__ __forceinline__ void wait_oldest() {      // (kRingGroups - 1) groups x pieces per group = 8 in both layouts
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // group `slot` is ready for every wave of the workgroup; fetches one more group into the slot read before it
+    __device__ __forceinline__ void acquire() {
+        if constexpr (NW > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kR - 2) * kMine) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kR - 2) * kMine) : "memory");
+        fetch();
+    }
+    __device__ __forceinline__ const lds_char* group() const { return lds_ptr + slot * P<M>::kGroupBytes + lane_off; }
+    __device__ __forceinline__ void release() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = slot == kR - 1 ? 0 : slot + 1;
     }
 };
 // kX3: eight consecutive fp32 features of a row -> the bf16 pair (mlp_x3.hpp: hi = bf16(v), lo = bf16(v - hi); v - hi is exact)
@@ -151,12 +179,12 @@ __device__ __forceinline__ f32x16 mma_x3(const bf16x8& ah, const bf16x8& al, con
 // row holds there (the activation area is zeroed once, then only ever holds activations).
 // fp32: a fragment is [half][lane][4 floats] — lane (m, g) holds W[16 s + 8 g + 4 half + r][m] — and MFMA i of a k-step
 // contracts k = 8 g + i on both operands.
-template <int M>
-__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<M>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
+template <int M, int NW>
+__device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<M, NW>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc) {
     for (int gi = 0; gi < kg_h + kg_x; ++gi) {
         const lds_char* bsrc = gi < kg_h ? hsrc + gi * (kGroup * P<M>::kStep) : xsrc + (gi - kg_h) * (kGroup * P<M>::kStep);
-        w.wait_oldest();
-        const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+        w.acquire();
+        const lds_char* grp = w.group();
         if constexpr (M == kBf16) {
             bf16x8 af[kGroup], bf[kGroup];
 #pragma unroll
@@ -193,8 +221,7 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<M>& w, int kg_h, int
         }
         // the slot is refilled only after every read of it has RETURNED (the compiler may sink MFMAs below this point,
         // not memory operations above it); the wait overlaps the first MFMAs of the group
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        w.issue();
+        w.release();
     }
     return acc;
 }
@@ -204,8 +231,8 @@ __device__ __forceinline__ f32x16 tile_mma(f32x16 acc, Ring<M>& w, int kg_h, int
 // output can overwrite its input IN PLACE: one hidden buffer per wave instead of two.
 // `tile_done(t, acc)` is called once per output tile after the last k-group (the accumulators never leave this function:
 // handed out by reference they end up in scratch memory).
-template <int M, int NT, bool ROLLED, class TileDone>
-__device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc, TileDone tile_done) {
+template <int M, int NW, int NT, bool ROLLED, class TileDone>
+__device__ __forceinline__ void layer_mma(Ring<M, NW>& w, int kg_h, int kg_x, const lds_char* hsrc, const lds_char* xsrc, TileDone tile_done) {
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -219,15 +246,14 @@ __device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const 
             for (int j = 0; j < kGroup; ++j) bf[j] = *reinterpret_cast<const lds_bf16x8*>(bsrc + j * 32);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                w.wait_oldest();
-                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+                w.acquire();
+                const lds_char* grp = w.group();
                 bf16x8 af[kGroup];
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) af[j] = *reinterpret_cast<const lds_bf16x8*>(grp + j * 1024);
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[j], acc[t], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every read of the slot has returned: refill it)
-                w.issue();
+                w.release();     // (every read of the slot has returned)
             }
         } else if constexpr (M == kX3) {
             // the group's B operand is split ONCE (24 VALU per k-step) for all NT tiles; the A pairs come split from the blob
@@ -239,8 +265,8 @@ __device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const 
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                w.wait_oldest();
-                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+                w.acquire();
+                const lds_char* grp = w.group();
                 bf16x8 ah[kGroup], al[kGroup];
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) {
@@ -249,8 +275,7 @@ __device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const 
                 }
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) acc[t] = mma_x3(ah[j], al[j], b[j], acc[t]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                w.issue();
+                w.release();
             }
         } else {
             f32x4 b0[kGroup], b1[kGroup];
@@ -261,8 +286,8 @@ __device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const 
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                w.wait_oldest();
-                const lds_char* grp = w.lds_ptr + w.slot * P<M>::kGroupBytes + w.lane_off;
+                w.acquire();
+                const lds_char* grp = w.group();
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) {
                     const f32x4 a0 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048), a1 = *reinterpret_cast<const lds_f32x4*>(grp + j * 2048 + 1024);
@@ -271,8 +296,7 @@ __device__ __forceinline__ void layer_mma(Ring<M>& w, int kg_h, int kg_x, const 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j][i], acc[t], 0, 0, 0);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                w.issue();
+                w.release();
             }
         }
     }
@@ -406,10 +430,10 @@ __device__ __forceinline__ void zero_pad_tile(lds_char* hrow, int g) {
 
 // forward of one layer with NT output tiles; `hrow` = the lane's row of THE hidden buffer: read (k-steps over the previous
 // layer's output) and, once all tiles are accumulated, overwritten with this layer's output
-template <int M, int NT>
-__device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<M>& w, lds_char* hrow, const lds_char* xrow,
+template <int M, int NW, int NT>
+__device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<M, NW>& w, lds_char* hrow, const lds_char* xrow,
                                               int g, float* yrow) {
-    layer_mma<M, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
+    layer_mma<M, NW, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
                               [&](int t, const f32x16& acc) {
         // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
         float bias[16], v[16];
@@ -437,34 +461,39 @@ __device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, boo
     if (!last) zero_pad_tile<M, NT>(hrow, g);
 }
 
-template <int M>
-__global__ __launch_bounds__(64) void mlp_generic_kernel(Args a) {
+// One workgroup = NW waves, each with its own 32-row tile and its own activation area in LDS, ONE weight ring (Ring above).
+// Every wave runs the same number of row-tile iterations (the ring's barriers are workgroup barriers): a wave whose tile
+// lies past the end re-computes the last tile and stores nothing.
+template <int M, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
+    const int lane = threadIdx.x & 63, g = lane >> 5, p = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + P<M>::kRingBytes;           // [32][x_pitch]  network input
+    lds_char* xb = ring + P<M>::kRingBytes + wave * 32 * (x_pitch + h_pitch);   // [32][x_pitch]  network input
     lds_char* hb = xb + 32 * x_pitch;                   // [32][h_pitch]  THE hidden buffer (updated in place)
     const long long n_tiles_rows = (a.n + 31) / 32;
-    Ring<M> w;
-    w.start(ring, a.weights, a.n_frags, lane);
+    Ring<M, NW> w;
+    w.start(ring, a.weights, a.n_frags, lane, wave);
     zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
-    for (long long rt = blockIdx.x; rt < n_tiles_rows; rt += gridDim.x) {
-        const long long row0 = rt * 32;
+    for (long long base = (long long)blockIdx.x * NW; base < n_tiles_rows; base += (long long)gridDim.x * NW) {
+        const bool mine = base + wave < n_tiles_rows;
+        const long long row0 = (mine ? base + wave : n_tiles_rows - 1) * 32;
         {
             const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
             load_x<M>(a.x + r * a.ld_x, a.d_in, (a.d_in + 15) / 16 * 16, xb + p * x_pitch, g);
         }
-        float* yrow = row0 + p < a.n ? a.y + (row0 + p) * a.ld_y + a.col0 : nullptr;
+        float* yrow = (mine && row0 + p < a.n) ? a.y + (row0 + p) * a.ld_y + a.col0 : nullptr;
         for (int l = 0; l < a.n_layers; ++l) {
             const Layer L = a.layer[l];
             const bool last = l == a.n_layers - 1;
-#define NFX_FWD(NT) forward_layer<M, NT>(a, L, last, w, hb + p * h_pitch, xb + p * x_pitch, g, yrow)
+#define NFX_FWD(NT) forward_layer<M, NW, NT>(a, L, last, w, hb + p * h_pitch, xb + p * x_pitch, g, yrow)
             NFX_FOR_TILE_COUNT(L.n_tiles, NFX_FWD)
 #undef NFX_FWD
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead must not outlive the wave's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead must not outlive the workgroup's LDS
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -518,13 +547,13 @@ __device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int 
 
 // the backward kernel's forward of one layer: as forward_layer, plus the workspace copies (fp32: straight from the
 // registers) and, for the output layer, dZ = dy * act'(logit) in place of the activation
-template <int M, int NT>
-__device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M>& w, lds_char* hrow, const lds_char* xrow, int g, int p,
+template <int M, int NW, int NT>
+__device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M, NW>& w, lds_char* hrow, const lds_char* xrow, int g, int p,
                                                 bool live, const float* dyr, char* wst) {
     const Args& a = ba.f;
     const Layer L = a.layer[l];
     const bool last = l == a.n_layers - 1;
-    layer_mma<M, NT, true>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
+    layer_mma<M, NW, NT, true>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
                              [&](int t, const f32x16& acc) {
         float bias[16], v[16];
         load_bias(a.biases + L.b_off + 32 * t, g, bias);
@@ -550,11 +579,11 @@ __device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M
     zero_pad_tile<M, NT>(hrow, g);
 }
 // dZ_{l-1} = (dZ_l W_l^T over the previous layer's NT output tiles) * act'(H_{l-1}), written over dZ_l in place
-template <int M, int NT>
-__device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M>& w, lds_char* hrow, int g, int p, char* wst) {
+template <int M, int NW, int NT>
+__device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M, NW>& w, lds_char* hrow, int g, int p, char* wst) {
     const Args& a = ba.f;
     const int kg_o = pad_group(2 * a.layer[l].n_tiles) / kGroup;
-    layer_mma<M, NT, true>(w, kg_o, 0, hrow + g * (P<M>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
+    layer_mma<M, NW, NT, true>(w, kg_o, 0, hrow + g * (P<M>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
         // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
         float d[16], y[16];
         if constexpr (P<M>::kF32) {
@@ -575,31 +604,36 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M>& w
     zero_pad_tile<M, NT>(hrow, g);
 }
 
-template <int M>
-__global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
+template <int M, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
-    const int lane = threadIdx.x, g = lane >> 5, p = lane & 31;
+    const int lane = threadIdx.x & 63, g = lane >> 5, p = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
-    lds_char* xb = ring + P<M>::kRingBytes;
+    lds_char* xb = ring + P<M>::kRingBytes + wave * 32 * (x_pitch + h_pitch);
     lds_char* hb = xb + 32 * x_pitch;                   // THE hidden buffer: activations forward, gradients backward
     lds_char* hrow = hb + p * h_pitch;
     const int fx = (a.d_in + 31) / 32 * 32, mx = fx / 32;
-    Ring<M> w;
-    w.start(ring, a.weights, ba.stream_frags, lane);   // forward fragments, then the transposed ones, as one stream
+    Ring<M, NW> w;
+    w.start(ring, a.weights, ba.stream_frags, lane, wave);   // forward fragments, then the transposed ones, as one stream
     zero_lds(xb, 32 * (x_pitch + h_pitch), lane);
-    for (long long rt = blockIdx.x; rt < ba.tiles; rt += gridDim.x) {
-        const long long row0 = rt * 32;
-        const bool live = row0 + p < a.n;
-        const long long r = live ? row0 + p : a.n - 1;
+    for (long long base = (long long)blockIdx.x * NW; base < ba.tiles; base += (long long)gridDim.x * NW) {
+        // a wave past the last tile keeps step with its workgroup (the ring's barriers) on the last tile's rows; everything it
+        // would store goes nowhere (live = false) or to the workspace's spare tile (index ba.tiles), which nothing reads
+        const bool mine = base + wave < ba.tiles;
+        const long long rt = mine ? base + wave : ba.tiles;
+        const long long row0 = (mine ? rt : ba.tiles - 1) * 32;
+        const bool live = mine && row0 + p < a.n;
+        const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
         char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<M>::kWsFeat;
         load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
         if constexpr (!P<M>::kF32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
         for (int l = 0; l < a.n_layers; ++l) {
-#define NFX_RECOMPUTE(NT) recompute_layer<M, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
+#define NFX_RECOMPUTE(NT) recompute_layer<M, NW, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
             NFX_FOR_TILE_COUNT(a.layer[l].n_tiles, NFX_RECOMPUTE)
 #undef NFX_RECOMPUTE
             if constexpr (!P<M>::kF32) {
@@ -622,7 +656,7 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                    acc = tile_mma<M>(acc, w, kg_o, 0, zsrc, zsrc);
+                    acc = tile_mma<M, NW>(acc, w, kg_o, 0, zsrc, zsrc);
                     if (live && ba.dx) {
                         float* dst = ba.dx + (row0 + p) * ba.ld_dx;
 #pragma unroll
@@ -635,7 +669,7 @@ __global__ __launch_bounds__(64) void mlp_generic_bwd_kernel(BwdArgs ba) {
                 dx_written = true;
             }
             if (l > 0) {
-#define NFX_DGRAD(NT) dgrad_layer<M, NT>(ba, l, w, hrow, g, p, wst)
+#define NFX_DGRAD(NT) dgrad_layer<M, NW, NT>(ba, l, w, hrow, g, p, wst)
                 NFX_FOR_TILE_COUNT(a.layer[l - 1].n_tiles, NFX_DGRAD)
 #undef NFX_DGRAD
             }
@@ -853,49 +887,70 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
 }  // namespace generic
 }  // namespace nfx
 
-// (one instantiation per operand mode, picked by Args::f32)
-#define NFX_FOR_MODE(mode, CALL)                 \
-    switch (mode) {                              \
-        case nfx::generic::kBf16: CALL(nfx::generic::kBf16); break;     \
-        case nfx::generic::kX3: CALL(nfx::generic::kX3); break;         \
-        default: CALL(nfx::generic::kNative); break;                    \
+// (one instantiation per operand mode, picked by Args::f32, and per workgroup size NW)
+#define NFX_FOR_MODE(mode, NWV, CALL)                                        \
+    switch (mode) {                                                          \
+        case nfx::generic::kBf16: CALL(nfx::generic::kBf16, NWV); break;     \
+        case nfx::generic::kX3: CALL(nfx::generic::kX3, NWV); break;         \
+        default: CALL(nfx::generic::kNative, NWV); break;                    \
     }
+#define NFX_FOR_MODE_AND_NW(mode, nw, CALL)            \
+    switch (nw) {                                      \
+        case 4: NFX_FOR_MODE(mode, 4, CALL) break;     \
+        case 2: NFX_FOR_MODE(mode, 2, CALL) break;     \
+        default: NFX_FOR_MODE(mode, 1, CALL) break;    \
+    }
+// waves per workgroup: as many (4, 2, 1) as fit the 160 KiB of LDS beside the shared ring
+static int generic_waves(const nfx::generic::Args& a, long long tiles) {
+    using namespace nfx::generic;
+    const int ring = a.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes, act = 32 * (a.x_pitch + a.h_pitch);
+    int nw = 4;
+    while (nw > 1 && (ring + nw * act > 160 * 1024 || tiles < nw)) nw /= 2;
+    return nw;
+}
 extern "C" {
 int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (args->n <= 0) return 0;
     const long long tiles = (args->n + 31) / 32;
-    const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    const int lds = (args->f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + 32 * (args->x_pitch + args->h_pitch);
-#define NFX_LAUNCH(MODE)                                                                                                 \
+    const int nw = generic_waves(*args, tiles);
+    const long long wgs = (tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
+    const int grid = (int)(wgs < cap ? wgs : cap);
+    const int lds = (args->f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (args->x_pitch + args->h_pitch);
+#define NFX_LAUNCH(MODE, NWV)                                                                                            \
     {                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<MODE>),                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<MODE, NWV>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
         if (e != hipSuccess) return (int)e;                                                                              \
-        hipLaunchKernelGGL(mlp_generic_kernel<MODE>, dim3(grid), dim3(64), lds, st, *args);                              \
+        hipLaunchKernelGGL((mlp_generic_kernel<MODE, NWV>), dim3(grid), dim3(64 * NWV), lds, st, *args);                 \
     }
-    NFX_FOR_MODE(args->f32, NFX_LAUNCH)
+    NFX_FOR_MODE_AND_NW(args->f32, nw, NFX_LAUNCH)
 #undef NFX_LAUNCH
     return (int)hipGetLastError();
 }
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
     if (ba->f.n <= 0) return 0;
-    const int grid = (int)(ba->tiles < max_blocks ? ba->tiles : max_blocks);
-    const int lds = (ba->f.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + 32 * (ba->f.x_pitch + ba->f.h_pitch);
+    const int nw = generic_waves(ba->f, ba->tiles);
+    const long long wgs = (ba->tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
+    const int grid = (int)(wgs < cap ? wgs : cap);
+    const int lds = (ba->f.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (ba->f.x_pitch + ba->f.h_pitch);
     const long long waves = (long long)wa->n_jobs * wa->splits;
-#define NFX_LAUNCH(MODE)                                                                                                 \
+#define NFX_LAUNCH(MODE, NWV)                                                                                            \
     {                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<MODE>),                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<MODE, NWV>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
         if (e != hipSuccess) return (int)e;                                                                              \
-        hipLaunchKernelGGL(mlp_generic_bwd_kernel<MODE>, dim3(grid), dim3(64), lds, st, *ba);                            \
-        if (wa->dw[0]) /* (no gradient buffers: the caller wants dLoss/dx only) */                                       \
-            hipLaunchKernelGGL(mlp_generic_wgrad_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa); \
+        hipLaunchKernelGGL((mlp_generic_bwd_kernel<MODE, NWV>), dim3(grid), dim3(64 * NWV), lds, st, *ba);               \
     }
-    NFX_FOR_MODE(ba->f.f32, NFX_LAUNCH)
+    NFX_FOR_MODE_AND_NW(ba->f.f32, nw, NFX_LAUNCH)
 #undef NFX_LAUNCH
-    if (wa->dw[0]) hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
+    if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
+#define NFX_WGRAD(MODE, NWV) hipLaunchKernelGGL(mlp_generic_wgrad_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
+        NFX_FOR_MODE(ba->f.f32, 0, NFX_WGRAD)
+#undef NFX_WGRAD
+        hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
+    }
     return (int)hipGetLastError();
 }
 int nfx_launch_split_hilo(void* frags, long long n_frags, hipStream_t st) {
