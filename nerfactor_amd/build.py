@@ -61,6 +61,9 @@ def _compile(src, force, verbose):
     obj = os.path.join(OBJDIR, src + '.o')
     spath = os.path.join(CSRC, src)
     newest = max(os.path.getmtime(spath), _headers_mtime())
+    for line in open(spath):       # a translation unit that includes another .hip (mlp_generic_{x3,native}.hip) follows its changes
+        if line.startswith('#include "') and line.rstrip().endswith('.hip"'):
+            newest = max(newest, os.path.getmtime(os.path.join(CSRC, line.split('"')[1])))
     cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + ['-x', 'hip', '-c', spath, '-o', obj]
     stamp = obj + '.cmd'     # the command line is part of the staleness check (per-file flags, NFX_EXTRA_DEFS)
     same_cmd = os.path.exists(stamp) and open(stamp).read() == ' '.join(cmd)

@@ -45,6 +45,13 @@
 #include "mlp_generic.hpp"
 #include "tr16.hpp"
 
+// This file is compiled three times (build time: one translation unit per operand mode, in parallel): as itself
+// (NFX_GENERIC_TU = 0: the bf16 instantiations, the mode-independent kernels and the C launch entry points) and through
+// mlp_generic_x3.hip / mlp_generic_native.hip (NFX_GENERIC_TU = 1 | 2: the fp32-class / native-fp32 instantiations).
+#ifndef NFX_GENERIC_TU
+#define NFX_GENERIC_TU 0
+#endif
+
 namespace nfx {
 namespace generic {
 
@@ -72,10 +79,9 @@ struct P {
     static constexpr int kFrag = 32 * 16 * kElem;             // one k-step's A fragment (32 outputs x 16 inputs): 1 or 2 KiB
     static constexpr int kGroupBytes = kGroup * kFrag;
     static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
-    // ring depth in groups (round 5: the ring is SHARED by the NW waves of a workgroup, below): a slot is refilled one
-    // group after it was read, so the fetch runs kRingGroups - 1 groups ahead.  bf16: 4 slots of 4 KiB; fp32 modes: 3 of
-    // 8 KiB (a group is 12 (pairs) or 32 (native) MFMAs per output tile there: two groups ahead are > 700 matrix-pipe cycles)
-    static constexpr int kRingGroups = kF32 ? 3 : 4;
+    // ring depth in groups: 3 slots of 4 KiB (bf16) or 8 KiB (fp32 modes: a group is 12 (pairs) or 32 (native) MFMAs per
+    // output tile there, so two groups ahead are > 700 matrix-pipe cycles of cover for an L2 fetch)
+    static constexpr int kRingGroups = 3;
     static constexpr int kRingBytes = kRingGroups * kGroupBytes;
     static constexpr int kStep = 16 * kElem;                  // bytes of one k-step in a row: 32 or 64
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
@@ -90,7 +96,8 @@ static_assert(kGroup == 4, "a group = 4 fragments = 4 (bf16) or 8 (fp32 modes) 1
 // cannot rotate its buffers without waiting for the loads it just issued; an LDS slot is only an address.  The stream is
 // circular: behind its last group the ring already fetches the next row tile's first.
 //
-// Round 5: ONE ring per workgroup of NW waves (NW = 4, 2 or 1: what fits the LDS beside NW activation areas).  Round 4 gave
+// Round 5, fp32 modes: ONE ring per workgroup of NW waves (NW = 4, 2 or 1: what fits the LDS beside NW activation areas;
+// bf16 keeps NW = 1, see generic_waves).  Round 4 gave
 // every wave its own ring: each wave then issues every 1-KiB DMA piece of the network itself, 4 (bf16) or 8 (fp32 modes)
 // global_load_lds per 4 (12, 32) MFMAs, and at 60-180 cycles of issue per piece (MI355X_MICROARCH.md) the DMA issue, not
 // the matrix pipe, set the pace (bf16: 13 % matrix-pipe busy at 384 TFLOP/s).  The NW waves of a workgroup run the same
@@ -138,17 +145,23 @@ struct Ring {
         end = stream + (size_t)n_frags * P<M>::kFrag;
         slot = fill = 0;
 #pragma unroll
-        for (int i = 0; i < kR - 1; ++i) fetch();
+        for (int i = 0; i < (NW > 1 ? kR - 1 : kR); ++i) fetch();
     }
-    // group `slot` is ready for every wave of the workgroup; fetches one more group into the slot read before it
+    // group `slot` is ready.  NW > 1: for every wave of the workgroup, and one more group is fetched into the slot read
+    // before it (kR - 1 groups ahead).  NW = 1 (a private ring): the slot is refilled by release() as soon as this wave's own
+    // reads have returned (kR groups ahead, no barrier) — round 4's protocol.
     __device__ __forceinline__ void acquire() {
-        if constexpr (NW > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kR - 2) * kMine) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kR - 2) * kMine) : "memory");
-        fetch();
+        if constexpr (NW > 1) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kR - 2) * kMine) : "memory");
+            fetch();
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kR - 1) * kMine) : "memory");
+        }
     }
     __device__ __forceinline__ const lds_char* group() const { return lds_ptr + slot * P<M>::kGroupBytes + lane_off; }
     __device__ __forceinline__ void release() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (NW == 1) fetch();      // (fill == slot: the ring is full)
         slot = slot == kR - 1 ? 0 : slot + 1;
     }
 };
@@ -792,6 +805,7 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     }
 }
 
+#if NFX_GENERIC_TU == 0      // the shape- and mode-independent kernels live in the first translation unit only
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_reduce_kernel(WgradArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.slice) return;
@@ -884,26 +898,81 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
     for (int k = 0; k < 3; ++k) dv[row * 3 + k] = g[k];
 }
 
+#endif
+
 }  // namespace generic
 }  // namespace nfx
 
-// (one instantiation per operand mode, picked by Args::f32, and per workgroup size NW)
-#define NFX_FOR_MODE(mode, NWV, CALL)                                        \
-    switch (mode) {                                                          \
-        case nfx::generic::kBf16: CALL(nfx::generic::kBf16, NWV); break;     \
-        case nfx::generic::kX3: CALL(nfx::generic::kX3, NWV); break;         \
-        default: CALL(nfx::generic::kNative, NWV); break;                    \
+// ---- launch: one pair of functions per translation unit = per operand mode (NFX_GENERIC_TU), dispatched by the C entry
+// points of translation unit 0
+#define NFX_CAT_(a, b) a##b
+#define NFX_CAT(a, b) NFX_CAT_(a, b)
+extern "C" {
+int nfx_generic_fwd_m0(const nfx::generic::Args*, int, int, int, hipStream_t);
+int nfx_generic_fwd_m1(const nfx::generic::Args*, int, int, int, hipStream_t);
+int nfx_generic_fwd_m2(const nfx::generic::Args*, int, int, int, hipStream_t);
+int nfx_generic_bwd_m0(const nfx::generic::BwdArgs*, const nfx::generic::WgradArgs*, int, int, int, hipStream_t);
+int nfx_generic_bwd_m1(const nfx::generic::BwdArgs*, const nfx::generic::WgradArgs*, int, int, int, hipStream_t);
+int nfx_generic_bwd_m2(const nfx::generic::BwdArgs*, const nfx::generic::WgradArgs*, int, int, int, hipStream_t);
+}
+namespace {
+template <int M, int NW>
+int launch_fwd(const nfx::generic::Args* args, int grid, int lds, hipStream_t st) {
+    using namespace nfx::generic;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<M, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((mlp_generic_kernel<M, NW>), dim3(grid), dim3(64 * NW), lds, st, *args);
+    return 0;
+}
+template <int M, int NW>
+int launch_bwd(const nfx::generic::BwdArgs* ba, int grid, int lds, hipStream_t st) {
+    using namespace nfx::generic;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<M, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((mlp_generic_bwd_kernel<M, NW>), dim3(grid), dim3(64 * NW), lds, st, *ba);
+    return 0;
+}
+}  // namespace
+extern "C" {
+int NFX_CAT(nfx_generic_fwd_m, NFX_GENERIC_TU)(const nfx::generic::Args* args, int nw, int grid, int lds, hipStream_t st) {
+    constexpr int M = NFX_GENERIC_TU;
+#if NFX_GENERIC_TU != 0      // (bf16 keeps a private ring per wave: generic_waves)
+    if (nw == 4) return launch_fwd<M, 4>(args, grid, lds, st);
+    if (nw == 2) return launch_fwd<M, 2>(args, grid, lds, st);
+#endif
+    (void)nw;
+    return launch_fwd<M, 1>(args, grid, lds, st);
+}
+int NFX_CAT(nfx_generic_bwd_m, NFX_GENERIC_TU)(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int nw, int grid, int lds, hipStream_t st) {
+    using namespace nfx::generic;
+    constexpr int M = NFX_GENERIC_TU;
+    int rc;
+#if NFX_GENERIC_TU != 0
+    if (nw == 4) rc = launch_bwd<M, 4>(ba, grid, lds, st);
+    else if (nw == 2) rc = launch_bwd<M, 2>(ba, grid, lds, st);
+    else
+#endif
+        rc = launch_bwd<M, 1>(ba, grid, lds, st);
+    (void)nw;
+    if (rc) return rc;
+    if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
+        const long long waves = (long long)wa->n_jobs * wa->splits;
+        hipLaunchKernelGGL(mlp_generic_wgrad_kernel<M>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
     }
-#define NFX_FOR_MODE_AND_NW(mode, nw, CALL)            \
-    switch (nw) {                                      \
-        case 4: NFX_FOR_MODE(mode, 4, CALL) break;     \
-        case 2: NFX_FOR_MODE(mode, 2, CALL) break;     \
-        default: NFX_FOR_MODE(mode, 1, CALL) break;    \
-    }
+    return 0;
+}
+}
+
+#if NFX_GENERIC_TU == 0
+static_assert(nfx::generic::kBf16 == 0 && nfx::generic::kX3 == 1 && nfx::generic::kNative == 2, "NFX_GENERIC_TU = the operand mode");
 // waves per workgroup: as many (4, 2, 1) as fit the 160 KiB of LDS beside the shared ring
 static int generic_waves(const nfx::generic::Args& a, long long tiles) {
     using namespace nfx::generic;
     const int ring = a.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes, act = 32 * (a.x_pitch + a.h_pitch);
+    // bf16 keeps a private ring per wave: a group is only 4 MFMAs there, a workgroup barrier per group costs more than the
+    // DMA pieces it saves, and the backward's workspace stores sit in the same in-order vmcnt queue the shared ring has to
+    // drain to 2 (measured, r05 call K: 256 x 8 forward 380 against 384 TFLOP/s, 128 x 4 backward 126 against 173)
+    if (!a.f32) return 1;
     int nw = 4;
     while (nw > 1 && (ring + nw * act > 160 * 1024 || tiles < nw)) nw /= 2;
     return nw;
@@ -917,16 +986,9 @@ int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipSt
     const long long wgs = (tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
     const int grid = (int)(wgs < cap ? wgs : cap);
     const int lds = (args->f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (args->x_pitch + args->h_pitch);
-#define NFX_LAUNCH(MODE, NWV)                                                                                            \
-    {                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<MODE, NWV>),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-        if (e != hipSuccess) return (int)e;                                                                              \
-        hipLaunchKernelGGL((mlp_generic_kernel<MODE, NWV>), dim3(grid), dim3(64 * NWV), lds, st, *args);                 \
-    }
-    NFX_FOR_MODE_AND_NW(args->f32, nw, NFX_LAUNCH)
-#undef NFX_LAUNCH
-    return (int)hipGetLastError();
+    const int rc = args->f32 == kBf16 ? nfx_generic_fwd_m0(args, nw, grid, lds, st)
+                 : args->f32 == kX3 ? nfx_generic_fwd_m1(args, nw, grid, lds, st) : nfx_generic_fwd_m2(args, nw, grid, lds, st);
+    return rc ? rc : (int)hipGetLastError();
 }
 int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int max_blocks, hipStream_t st) {
     using namespace nfx::generic;
@@ -935,22 +997,10 @@ int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::gener
     const long long wgs = (ba->tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
     const int grid = (int)(wgs < cap ? wgs : cap);
     const int lds = (ba->f.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (ba->f.x_pitch + ba->f.h_pitch);
-    const long long waves = (long long)wa->n_jobs * wa->splits;
-#define NFX_LAUNCH(MODE, NWV)                                                                                            \
-    {                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<MODE, NWV>),             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-        if (e != hipSuccess) return (int)e;                                                                              \
-        hipLaunchKernelGGL((mlp_generic_bwd_kernel<MODE, NWV>), dim3(grid), dim3(64 * NWV), lds, st, *ba);               \
-    }
-    NFX_FOR_MODE_AND_NW(ba->f.f32, nw, NFX_LAUNCH)
-#undef NFX_LAUNCH
-    if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
-#define NFX_WGRAD(MODE, NWV) hipLaunchKernelGGL(mlp_generic_wgrad_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
-        NFX_FOR_MODE(ba->f.f32, 0, NFX_WGRAD)
-#undef NFX_WGRAD
-        hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
-    }
+    const int rc = ba->f.f32 == kBf16 ? nfx_generic_bwd_m0(ba, wa, nw, grid, lds, st)
+                 : ba->f.f32 == kX3 ? nfx_generic_bwd_m1(ba, wa, nw, grid, lds, st) : nfx_generic_bwd_m2(ba, wa, nw, grid, lds, st);
+    if (rc) return rc;
+    if (wa->dw[0]) hipLaunchKernelGGL(mlp_generic_wgrad_reduce_kernel, dim3((unsigned)((wa->slice + 255) / 256)), dim3(256), 0, st, *wa);
     return (int)hipGetLastError();
 }
 int nfx_launch_split_hilo(void* frags, long long n_frags, hipStream_t st) {
@@ -969,3 +1019,4 @@ int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 }
+#endif  // NFX_GENERIC_TU == 0
