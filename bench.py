@@ -308,7 +308,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision, refine=refine).cpu().numpy()
         want = ref[1]['rgb'].numpy()[keep]
         # r04: NO ray is excused.  Rays decided by the sign of a near-zero logit at the dist = 1e10 last sample are a
-        # discontinuity of the reference formula (DESIGN.md §4); the render evaluates that one sample fp32-class, so
+        # discontinuity of the reference formula (DESIGN.md §3.4); the render evaluates that one sample fp32-class, so
         # they are held to the tolerance like every other ray.  The band count stays, for information.
         sig = np.minimum(ref[2]['sigma_last_coarse'].numpy()[keep], ref[2]['sigma_last_fine'].numpy()[keep])
         err = np.abs(got - want).max(1)
@@ -330,7 +330,7 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, n=2048):
     """The same render on the NeRF weights FITTED to a scene (tests/golden/nerf_trained_fp16.npz, the networks of the
     reference fixtures; empty space sits at a robustly negative density): the glorot "opaque variant" weights of the
     timed frame put ~9 % of the rays on the reference formula's own discontinuity (alpha_last = [sigma_last > 0],
-    DESIGN.md §4), fitted weights < 2 % — max-abs is reported over ALL rays and outside the counted band."""
+    DESIGN.md §3.4), fitted weights < 2 % — max-abs is reported over ALL rays and outside the counted band."""
     from oracle import torch_ref
     from tests.golden import golden_inputs as gi
     nets = gi.trained_nerf_nets()
@@ -940,7 +940,7 @@ def olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
                      "avg_launch_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg, "traffic": o_traffic,
                      "traffic_unit": "GB per launch", "traffic_source": o_source,
                      # (static count of the kernel: 2348 VALU instructions, ~2000 executed per point and wave — the per-light GGX
-                     #  term, 512 of them per point: the kernel sits at its VALU issue rate, not at the HBM roof; DESIGN.md section 3)
+                     #  term, 512 of them per point: the kernel sits at its VALU issue rate, not at the HBM roof; DESIGN.md section 3.5)
                      "note": "VALU-bound by the per-light microfacet term: the HBM roofline is the bound by bytes, not the binding one",
                      "share_of_step": k_s * sh.n_views / (elapsed / args.steps)},
     }

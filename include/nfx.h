@@ -402,7 +402,7 @@ NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, co
 /* ------------------------------------------------------------------------ */
 
 /* D[32,32] = A[32,16] * B[16,32] through one v_mfma_f32_32x32x16_bf16 with the operand
- * lane maps documented in DESIGN.md; used by the GPU tests to pin the fragment layout. */
+ * lane maps documented in DESIGN.md section 3 / csrc/mlp_engine.hpp; used by the GPU tests to pin the fragment layout. */
 NFX_API int nfx_selftest_mfma_bf16(const float *dev_a, const float *dev_b, float *dev_d, void *stream);
 /* out[i] = (which ? cos : sin)(in[i]) with the kernel's own range reduction.  */
 /* ------------------------------------------------------------------------ */

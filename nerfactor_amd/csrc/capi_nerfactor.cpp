@@ -279,7 +279,7 @@ int nfx_brdf_spec_fwd(const float* xyz, const float* cam, const float* normal, c
     // 6 (default) = 5 with closed-form Rusinkiewicz angles.  Option brdf_ct of variants 5 / 6: 2 | 3 | 4 (default) column
     // tiles per wave, one wave per SIMD.  8 = 8 waves x 2 column tiles, two waves per SIMD, variant 6 only and NOT the
     // default: r03 shipped it (12 % faster), and its per-row-geometry sibling <2, 0, 8> then failed bit identity on a
-    // fresh MI355X for a reason that is still not established — a kernel form whose sibling's
+    // fresh MI355X for a reason that is still not established (profiles/HISTORY.md section 2c) — a kernel form whose sibling's
     // bits depend on the box is opt-in until the mechanism is known.
     int variant = nfx_option_int("brdf_variant", 6);
     if (variant >= 5) {

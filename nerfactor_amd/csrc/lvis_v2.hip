@@ -898,7 +898,7 @@ extern "C" int nfx_launch_brdf_spec_v3(const float* xyz, const float* cam, const
     const int tiles = ct == 8 ? 2 : ct;
     if (n_lights > 1024 || tiles * 32 - 1 + n_lights > nfx::lv2::kRing) return -1;   // (launch_compact checks its own ring)
     nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
-#ifdef NFX_EXPERIMENT_BUILD   // the per-row-geometry form with two waves per SIMD: NOT deterministic on MI355X, soak builds only
+#ifdef NFX_EXPERIMENT_BUILD   // the per-row-geometry form with two waves per SIMD: NOT deterministic on MI355X (profiles/HISTORY.md section 2c), soak builds only
     if (ct == 8 && !geo) return launch_compact<2, 0, 8>(a, max_blocks, st);
 #endif
     if (ct == 8) return geo ? launch_compact<2, 1, 8>(a, max_blocks, st) : launch_compact<2, 0, 4>(a, max_blocks, st);

@@ -4,7 +4,7 @@
 // Round 3's backward (mlp128_bwd.hip) stores every layer's input and pre-activation gradient — 1130 bf16 features per
 // row, 2.37 GB for the 1 048 576 light-visibility rows of a 1024-ray step — and a separate GEMM launch reads them back:
 // 4.7 GB of HBM traffic for a few MB of algorithmic input / output, both kernels at the 64-requests-per-CU ceiling
-// (DESIGN.md section 3b).  Here nothing but the weight gradients leaves the CU:
+// (profiles/HISTORY.md section 3b).  Here nothing but the weight gradients leaves the CU:
 //
 //   * one workgroup = 4 waves x 32 rows, persistent over its 128-row tiles; per tile it re-computes the forward and
 //     runs the dgrad chain exactly like mlp128_bwd_ring_kernel (same MFMA order, same operand registers);

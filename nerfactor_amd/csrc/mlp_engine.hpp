@@ -32,7 +32,7 @@ constexpr int kSlotBytes = kSlotFrags * kFragBytes;
 constexpr int kPieceThreads = 256;                // a "piece" = 256 lanes x 16 B = 4 KiB
 
 // --------------------------------------------------------------------------------------
-// MFMA operands written by packed 16-bit VALU instructions — a round-3 finding that is NOT a lever (DESIGN.md §2d,
+// MFMA operands written by packed 16-bit VALU instructions — a round-3 finding that is NOT a lever (profiles/HISTORY.md §2d,
 // profiles/r03/nerf_first_tile/).  In the cycle-stamp build of the NeRF kernel an MFMA that reads an A / B operand
 // register whose LAST WRITER was v_cvt_pk_bf16_f32 or v_pk_max_i16 — the two instructions every epilogue here ends
 // with — runs at about half rate the first time it reads that register: the "first tile of every layer takes two tile

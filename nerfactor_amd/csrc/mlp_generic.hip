@@ -481,7 +481,7 @@ template <int M, int NW>
 __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, g = lane >> 5, p = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (NW = 1: every LDS address keeps its compile-time base)
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
     lds_char* xb = ring + P<M>::kRingBytes + wave * 32 * (x_pitch + h_pitch);   // [32][x_pitch]  network input
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
     const int lane = threadIdx.x & 63, g = lane >> 5, p = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (NW = 1: every LDS address keeps its compile-time base)
     const int x_pitch = a.x_pitch, h_pitch = a.h_pitch;
     lds_char* ring = (lds_char*)smem;
     lds_char* xb = ring + P<M>::kRingBytes + wave * 32 * (x_pitch + h_pitch);

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_kernel(
 // tests/test_cpu_ring_protocol.py replays the stream).  Chunks the backward does not use (sigma_out, rgb_out[1] forward
 // tiles) are not fetched at all.  Same MFMA order and operands as the kernel above: bit-identical workspace and
 // gradients (scripts/grad_identity.py, tests/test_gpu_train.py::test_ring_backward_kernels_equal_the_register_staged_ones).
-// What the measurements of the round say bounds it: not the fetch distance but the 64 requests a CU's
+// What the measurements of the round say bounds it (profiles/HISTORY.md section 3b): not the fetch distance but the 64 requests a CU's
 // L1 keeps in flight towards L2 — hence non-temporal activation stores (feat_store.hpp: the weights stay in L2) and
 // 8 waves per weight fetch.
 namespace nring {

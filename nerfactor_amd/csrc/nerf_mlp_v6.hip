@@ -16,9 +16,9 @@
 //                        start of tile k, counted s_waitcnt vmcnt before the barrier — no staging VGPRs, no ds_write;
 //   DMA = 2  variant 8   register-staged with two staging sets (chunk k+3 fetched during tile k, stored a tile later).
 // The r01 experiment switches (second bias read group, A-prefetch depth, epilogue start offset, DMA fetch distance,
-// DMA pieces spread over the k-steps) were all measured and left at the values now hard-wired here — DESIGN.md
+// DMA pieces spread over the k-steps) were all measured and left at the values now hard-wired here — profiles/HISTORY.md
 // section 2 has the numbers.  The cycle-stamp build (NFX_V6_TIMING), its experiment masks (NFX_V6_XP, NFX_V6_FENCE)
-// and the ablation instantiations (NFX_ABLATION_BUILD) that produced the r01-r03 measurements of DESIGN.md sections
+// and the ablation instantiations (NFX_ABLATION_BUILD) that produced the r01-r03 measurements of profiles/HISTORY.md sections
 // 2 / 2d left this file in r04 (git history: fdbd16f holds them): the shipped translation unit is the product kernel.
 #include "mlp_engine.hpp"
 #include "lds_dma.hpp"

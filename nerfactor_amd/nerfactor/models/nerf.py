@@ -258,7 +258,7 @@ class Model(BaseModel):
         if pref == 'coarse_' and self.precision == 'bf16' and self.coarse_precision == 'fp32':
             # (render-time option, round 5: the COARSE pass with fp32-class operands — its weights place the fine samples,
             #  and on a fitted network's sharp density edge bf16 coarse weights move a silhouette ray's fine samples by up
-            #  to 1.5 coarse bins; 25 % of a frame's points at 3.7x)
+            #  to 1.5 coarse bins, DESIGN.md section 3.4 / profiles/HISTORY.md section 4; 25 % of a frame's points at 3.7x)
             return ops.nerf_mlp_fwd(rayo, rayd, z, self._packed(
                 pref + 'fp32', sum(self._nerf_params(pref), []), lambda k, b: ops.pack_nerf_weights(k, b, 'fp32')), 'fp32')
         rgbs = ops.nerf_mlp_fwd(rayo, rayd, z, self._nerf_blob(pref), self.precision)
@@ -364,7 +364,7 @@ class Model(BaseModel):
     def _refine_last_sigma(self, rayo, rayd, z, sigma_raw, pref):
         """geometry_from_nerf composites these densities with accumulate_sigma, where the LAST sample of a ray gets
         dist = 1e10 (nerf.py:186-191): alpha_last = [sigma_last > 0] exactly, the one bit of a ray a bf16 density can get
-        wrong by a whole ray.  As in the render (last_sample_precision, DESIGN.md section 4), precision = bf16 re-evaluates
+        wrong by a whole ray.  As in the render (last_sample_precision, DESIGN.md section 3.4), precision = bf16 re-evaluates
         that one sample with the fp32-class density kernel: 1 of 128 / 320 samples at ~3x the cost (round 5)."""
         if self.precision == 'bf16' and self.last_sample_precision == 'fp32' and z.shape[1] > 1 and z.shape[0] > 0:
             last = ops.nerf_sigma_fwd(rayo, rayd, z[:, -1:].contiguous(), self._nerf_geom_blob(pref, 'fp32'), 'fp32')

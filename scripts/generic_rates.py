@@ -1,5 +1,5 @@
 """Rates of the runtime-shaped MLP kernels (csrc/mlp_generic.hip) next to the tuned kernels on the SAME architectures:
-the generality tax of DESIGN.md §3c.  Prints one JSON object (ms per call, TFLOP/s of the MLP's 2 x MACs)."""
+the generality tax of DESIGN.md §3.6.  Prints one JSON object (ms per call, TFLOP/s of the MLP's 2 x MACs)."""
 import json
 import os
 import sys

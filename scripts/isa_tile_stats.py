@@ -4,7 +4,7 @@ assembly with the flags of the product build, cuts the main loop of nerf_mlp_bf1
 (one per tile) and counts, per segment, instructions, MFMAs, ds_reads, s_nop cycles, s_waitcnt, AccVGPR moves and
 epilogue VALU.  `--dump K [K ...]` prints the abbreviated instruction stream of those segments.
 
-Round-2 reading: the first tile of a layer — 2x the time of a steady tile by cycle stamps — has
+Round-2 reading (profiles/HISTORY.md section 2c): the first tile of a layer — 2x the time of a steady tile by cycle stamps — has
 the SAME instruction mix, the same waits and the same `s_nop 10` before the epilogue as a steady tile; what does differ
 between tiles is 16 extra v_accvgpr moves in the second to fourth tile of most layers (half of the activations live in
 AccVGPRs at 491 registers per lane).

@@ -1,7 +1,7 @@
 """How far is the bf16 kernel's density of a ray's LAST sample from the fp32-class kernel's — the quantity that decides
 alpha_last = [sigma_last > 0] (nerf.py:186-191)?  800 x 800 rays of the bench view, glorot "opaque" and fitted weights,
 coarse and fine network: max / quantiles of |sigma_bf16 - sigma_fp32|, how many rays change sign, how many sit within
-0.06 / 0.25 of zero.  Evidence for models/nerf.py `last_sample_precision` (DESIGN.md section 4)."""
+0.06 / 0.25 of zero.  Evidence for models/nerf.py `last_sample_precision` (DESIGN.md section 3.4)."""
 import json
 import os
 import sys

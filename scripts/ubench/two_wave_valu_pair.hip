@@ -1,4 +1,4 @@
-// two_wave_valu_pair.hip — round 5 follow-up of two_wave_hazard.hip.
+// two_wave_valu_pair.hip — round 5 follow-up of two_wave_hazard.hip (profiles/HISTORY.md section 2c).
 //
 // brdf_compact_kernel<2, 0, 8> (per-row reference geometry, two waves per SIMD) returns wrong rows in whole groups of 16
 // lanes; compiling the IEEE division sequences out removes 90 % of them.  Round 4's probe ran the suspect VALU sequences on

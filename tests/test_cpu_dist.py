@@ -212,7 +212,7 @@ def test_graphed_step_only_captures_static_single_process_batches():
 
 def test_train_step_hands_back_detached_visualisation_tensors():
     """optim._detached: what a training step returns for visualisation must not keep the step's autograd graph (and
-    with it the parameters' AccumulateGrad nodes) alive across steps — DESIGN.md §3b, the hipGraph capture."""
+    with it the parameters' AccumulateGrad nodes) alive across steps — profiles/HISTORY.md §3b, the hipGraph capture."""
     from nerfactor_amd import optim
     w = torch.ones(3, requires_grad=True)
     to_vis = {'id': ['a'], 'hw': torch.tensor([[2, 2]]), 'pred_rgb': w * 2., 'gt_rgb': torch.zeros(3)}

@@ -83,7 +83,7 @@ def _compare(name, runs, psnr_tol=0.3, loss_tol=0.02):
     scene of this file the fp32 run passes 40 dB after 500 steps while the bf16 run turns noisy around 38-39 dB (r05 call F:
     38.9 against 40.3 dB at step 600, equal within 0.2 dB up to step 300 = 37.3 dB).  Past the floor the test records the
     gap, requires the bf16 run to stay within 3 dB and above BF16_FLOOR_DB, and that is the documented limit of
-    `precision = bf16` training (DESIGN.md section 3b): the reference's own scenes end at 22-33 dB."""
+    `precision = bf16` training (DESIGN.md section 5.4): the reference's own scenes end at 22-33 dB."""
     a, b, c = runs['bf16'], runs['fp32'], runs['fp32_other_draws']
     early = [i for i, (_, p) in enumerate(b['vali_psnr_curve']) if p < BF16_FLOOR_DB]
     last = early[-1] if early else 0

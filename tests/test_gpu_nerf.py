@@ -286,7 +286,7 @@ def test_full_frame_properties(nfx_lib, cuda):
     for k in ('rgb_c', 'rgb_f', 'z_all'):
         assert torch.equal(out[k][sel], sub[k]), k
     # ... and those 4096 rays OF THE FULL-SIZE FRAME against the CPU oracle (torch-CPU fp32 port of the reference op
-    # sequence): PSNR >= 40 dB; max-abs <= 3e-2 on every ray (the last sample's density is fp32-class, DESIGN.md §4)
+    # sequence): PSNR >= 40 dB; max-abs <= 3e-2 on every ray (the last sample's density is fp32-class, DESIGN.md §3.4)
     import torch as _t
     from oracle import torch_ref
     tn = [torch_ref.to_torch_net(n) for n in nets]

@@ -275,7 +275,7 @@ def test_trained_nerf_1024_rays_vs_reference_outputs(nfx_lib, cuda, coarse_preci
     rgb / occupancy (4 % of the depth range on depth) for at least 98 % of the rays — silhouette rays, where a bf16-sized
     change of the density moves the accumulated opacity, are the counted exceptions — and PSNR >= 40 dB.
     coarse_precision = fp32 (ini key, r05): the coarse pass fp32-class — the rays above the tolerance are a coarse-pass
-    effect (bf16 coarse weights move a silhouette ray's fine samples across the fitted density edge, DESIGN.md section 4):
+    effect (bf16 coarse weights move a silhouette ray's fine samples across the fitted density edge, DESIGN.md section 3.4):
     with it EVERY ray's rgb is within 3e-2, no exclusion."""
     model = make('nerf', cuda, coarse_precision=coarse_precision)
     nets = gi.trained_nerf_nets()
