@@ -357,10 +357,10 @@ static_assert(kMaxHidden == 256, "NFX_FOR_TILE_COUNT covers 1 .. 8 tiles");
 __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
     for (int o = lane * 16; o < bytes; o += 64 * 16) *reinterpret_cast<lds_f32x4*>(p + o) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-// the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features; `wst`
-// (backward, fp32 modes only): also to the workspace tile, feature-major (the bf16 path transposes through store_blocked)
+// the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features; `ws`
+// (backward, fp32 only): also to the workspace, feature-major (the bf16 path transposes through store_blocked instead)
 template <int M>
-__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g, char* wst = nullptr, int p = 0) {
+__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g, float* ws_col = nullptr) {
     for (int c0 = 8 * g; c0 < feats; c0 += 16) {
         float f[8];
 #pragma unroll
@@ -370,18 +370,9 @@ __device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, 
         if constexpr (P<M>::kF32) {
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4) = f32x4{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4 + 16) = f32x4{f[4], f[5], f[6], f[7]};
-            if (wst) {      // the workspace tile's copy of the input, feature-major (store_ws16's layouts)
-                if constexpr (M == kX3) {
+            if (ws_col) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const __bf16 hi = (__bf16)f[j];
-                        *reinterpret_cast<__bf16*>(wst + (size_t)(c0 + j) * 128 + 2 * p) = hi;
-                        *reinterpret_cast<__bf16*>(wst + (size_t)(c0 + j) * 128 + 64 + 2 * p) = (__bf16)(f[j] - (float)hi);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) reinterpret_cast<float*>(wst)[(size_t)(c0 + j) * 32 + p] = f[j];
-                }
+                for (int j = 0; j < 8; ++j) ws_col[(size_t)(c0 + j) * 32] = f[j];
             }
         } else {
             bf16x8 v;
@@ -560,26 +551,11 @@ __device__ __forceinline__ void store_blocked(const lds_char* lds, int pitch, in
         *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64 + 32) = hi;
     }
 }
-// fp32 modes: the lane's 16 values of a tile straight from registers.  kNative: fp32, one coalesced 128-byte line per feature
-// and half.  kX3 (round 5): the same 128 bytes per feature row hold [hi: 32 rows of bf16 | lo: 32 rows] — every value is
-// split ONCE here, where round 5's first form split it in the weight-gradient kernel once per use (each workspace row feeds
-// 2-4 of that kernel's jobs: 96 VALU per 12 MFMAs there, as long as the MFMAs themselves)
-template <int M>
+// fp32: the lane's 16 values of a tile straight from registers, one coalesced 128-byte line per feature and half
 __device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int g, const float* v) {
-    if constexpr (M == kX3) {
-        char* dst = wst + (size_t)(frow_tile + 4 * g) * 128 + 2 * p;
+    float* dst = reinterpret_cast<float*>(wst) + (size_t)(frow_tile + 4 * g) * 32 + p;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const __bf16 hi = (__bf16)v[q];
-            char* d = dst + ((q & 3) + 8 * (q >> 2)) * 128;
-            *reinterpret_cast<__bf16*>(d) = hi;
-            *reinterpret_cast<__bf16*>(d + 64) = (__bf16)(v[q] - (float)hi);
-        }
-    } else {
-        float* dst = reinterpret_cast<float*>(wst) + (size_t)(frow_tile + 4 * g) * 32 + p;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * 32] = v[q];
-    }
+    for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * 32] = v[q];
 }
 
 // the backward kernel's forward of one layer: as forward_layer, plus the workspace copies (fp32: straight from the
@@ -611,7 +587,7 @@ __device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M
         }
         zero_pad16(v, t, g, L.n_out);
         store_row16<M>(hrow + P<M>::kTile * t, g, v);
-        if constexpr (P<M>::kF32) store_ws16<M>(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
+        if constexpr (P<M>::kF32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
     });
     zero_pad_tile<M, NT>(hrow, g);
 }
@@ -623,14 +599,7 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M, NW
     layer_mma<M, NW, NT, true>(w, kg_o, 0, hrow + g * (P<M>::kStep / 2), hrow, [&](int mt, const f32x16& acc) {
         // the previous layer's outputs at the lane's 16 features, back from the workspace (same wave, own cache lines)
         float d[16], y[16];
-        if constexpr (M == kX3) {      // [hi plane | lo plane] of the feature row (store_ws16)
-            const char* hy = wst + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 128 + 2 * p;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const char* e = hy + ((q & 3) + 8 * (q >> 2)) * 128;
-                y[q] = (float)*reinterpret_cast<const __bf16*>(e) + (float)*reinterpret_cast<const __bf16*>(e + 64);
-            }
-        } else if constexpr (M == kNative) {
+        if constexpr (P<M>::kF32) {
             const float* hy = reinterpret_cast<const float*>(wst) + (size_t)(ba.b[l - 1].h_row + 32 * mt + 4 * g) * 32 + p;
 #pragma unroll
             for (int q = 0; q < 16; ++q) y[q] = hy[((q & 3) + 8 * (q >> 2)) * 32];
@@ -643,7 +612,7 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M, NW
         for (int q = 0; q < 16; ++q) d[q] = acc[q];
         scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
         store_row16<M>(hrow + P<M>::kTile * mt, g, d);
-        if constexpr (P<M>::kF32) store_ws16<M>(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
+        if constexpr (P<M>::kF32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
     });
     zero_pad_tile<M, NT>(hrow, g);
 }
@@ -672,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
         const bool live = mine && row0 + p < a.n;
         const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
         char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<M>::kWsFeat;
-        load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, P<M>::kF32 ? wst : nullptr, p);
+        load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
         if constexpr (!P<M>::kF32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
@@ -743,12 +712,9 @@ template <> struct Frag<kBf16> {
     static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x16 mma_ones(const Frag& one, const Frag& b, f32x16 c) { return mma(one, b, c); }
 };
-template <> struct Frag<kX3> {      // 8 consecutive rows of one feature: 16 bytes of the hi plane, 16 of the lo plane (store_ws16)
+template <> struct Frag<kX3> {      // 8 consecutive fp32 rows of one feature, split in registers (both operands are activations)
     HiLo v;
-    __device__ __forceinline__ void load(const char* p) {
-        v.hi = *reinterpret_cast<const bf16x8*>(p);
-        v.lo = *reinterpret_cast<const bf16x8*>(p + 64);
-    }
+    __device__ __forceinline__ void load(const char* p) { v = split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 16)); }
     __device__ __forceinline__ void ones() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v.hi[j] = (__bf16)1.0f; v.lo[j] = (__bf16)0.0f; }
@@ -774,8 +740,7 @@ template <> struct Frag<kNative> {
 };
 template <int M>
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
-    constexpr int E = P<M>::kElem;                     // a feature row of a tile = 32 E bytes in every mode ...
-    constexpr int ER = M == kX3 ? 2 : E;               // ... of 32 rows of ER bytes (pairs: two planes of bf16, hi then lo)
+    constexpr int E = P<M>::kElem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, g = lane >> 5;
     const long long wid = (long long)blockIdx.x * 4 + wave;
     if (wid >= (long long)a.n_jobs * a.splits) return;
@@ -789,8 +754,8 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     const InTile ti[2] = {in_tile(a, l, 2 * ip), in_tile(a, l, two_i ? 2 * ip + 1 : 2 * ip)};
     const int fb[2] = {a.b[l].dz_row + 64 * op, a.b[l].dz_row + 64 * op + (two_o ? 32 : 0)};
     const long long t0 = a.tiles * sp / a.splits, t1 = a.tiles * (sp + 1) / a.splits;
-    const char* pa[2] = {a.ws + (size_t)(ti[0].frow + m) * 32 * E + 8 * g * ER, a.ws + (size_t)(ti[1].frow + m) * 32 * E + 8 * g * ER};
-    const char* pb[2] = {a.ws + (size_t)(fb[0] + m) * 32 * E + 8 * g * ER, a.ws + (size_t)(fb[1] + m) * 32 * E + 8 * g * ER};
+    const char* pa[2] = {a.ws + ((size_t)(ti[0].frow + m) * 32 + 8 * g) * E, a.ws + ((size_t)(ti[1].frow + m) * 32 + 8 * g) * E};
+    const char* pb[2] = {a.ws + ((size_t)(fb[0] + m) * 32 + 8 * g) * E, a.ws + ((size_t)(fb[1] + m) * 32 + 8 * g) * E};
     const size_t tile_bytes = (size_t)a.feat_rows * 32 * E;
     f32x16 acc[2][2], accb[2];
 #pragma unroll
@@ -803,7 +768,7 @@ __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     for (long long t = t0; t < t1; ++t) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const size_t off = t * tile_bytes + 16 * ER * kk;
+            const size_t off = t * tile_bytes + 16 * E * kk;
             Frag<M> a0, a1, b0, b1;
             a0.load(pa[0] + off); a1.load(pa[1] + off); b0.load(pb[0] + off); b1.load(pb[1] + off);
             acc[0][0] = Frag<M>::mma(a0, b0, acc[0][0]);
