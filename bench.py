@@ -269,7 +269,8 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is the
     # committed digest of the same workload at N = 1 (scripts/gpu_pmc.sh -> scripts/pmc_digest.py): FETCH_SIZE x 2
     # (gfx950 correction) + WRITE_SIZE, per launch pair of a whole 640 000-ray view.
-    variant = str(ops._capi.get_option("nerf_variant") or 7)
+    variant = ops._capi.get_option("nerf_variant")
+    variant = str(7 if variant is None else variant)
     # digest = average over the coarse and the fine dispatch; a launch pair = both
     fp32 = args.precision == 'fp32'
     traffic, traffic_source = (None, None)
@@ -480,6 +481,8 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     fg_per_call = n_fg_local / sh.n_views
     lvis_s = kt.mean_ms('lvis_fwd') * 1e-3
     lvis_tf = fg_per_call * N_LIGHTS * 2 * LVIS_MAC / lvis_s / 1e12
+    lvis_variant = ops._capi.get_option("lvis_variant")
+    lvis_variant = str(8 if lvis_variant is None else lvis_variant)
     # algorithmic bytes per foreground point: 512 visibilities written, the 1-KiB pre-activation row written by
     # lvis_pre and read once by the main kernel, the position read
     lv_traffic, lv_source = None, None
@@ -507,7 +510,7 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                                         if args.precision == 'fp32' else
                                         "lvis_pre_kernel + %s (light visibility, %%d x 512 rows)" % {
                 "8": "resident128_kernel<2, 0, 8>", "4": "resident128_kernel<4, 0, 4>"}.get(
-                    str(ops._capi.get_option("lvis_variant") or 8), "variant %s" % ops._capi.get_option("lvis_variant")))
+                    lvis_variant, "variant %s" % lvis_variant))
                                        % int(fg_per_call),
             "achieved": lvis_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": lvis_tf / PEAK_BF16_TFLOPS,
             "avg_launch_ms": lvis_s * 1e3, "flop_per_launch": fg_per_call * N_LIGHTS * 2 * LVIS_MAC,

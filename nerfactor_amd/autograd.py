@@ -225,6 +225,9 @@ class GenericMlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net_fn, *params):
         net = net_fn()
+        if x.dim() != 2 or x.shape[1] != net.d_in:      # a wider x would get a gradient of the wrong shape back
+            raise _capi.NfxError("GenericMlp: x must be [n, %d] (the network's input width), got %s"
+                                     % (net.d_in, tuple(x.shape)))
         ctx.save_for_backward(x)
         ctx.cfg = (net_fn, params)
         return ops.mlp_generic_fwd(x, net)

@@ -359,6 +359,15 @@ def generic_pack_fn(acts, skip_at, train, prec, descs, tag):
     return pack
 
 
+def _check_out(who, out, n, col0, width, device):
+    """An `out` / `col0` destination: CUDA fp32 [n, >= col0 + width] with unit column stride on `device`."""
+    if not isinstance(out, torch.Tensor) or not out.is_cuda or out.dtype != torch.float32 or out.dim() != 2 \
+            or out.shape[0] != n or out.stride(1) != 1 or out.device != device:
+        raise _capi.NfxError("%s: out must be a CUDA fp32 [%d, ld] matrix with unit column stride on %s" % (who, n, device))
+    if col0 < 0 or col0 + width > out.shape[1]:
+        raise _capi.NfxError("%s: columns [%d, %d) do not fit out's %d columns" % (who, col0, col0 + width, out.shape[1]))
+
+
 def mlp_generic_fwd(x, net, out=None, col0=0):
     """y[n, d_out] = net(x[n, >= d_in]) through the runtime-shaped fused kernel; `out` / `col0`: write into columns
     [col0, col0 + d_out) of an existing [n, ld] matrix (assembling a concatenation without a copy)."""
@@ -368,9 +377,8 @@ def mlp_generic_fwd(x, net, out=None, col0=0):
     if x.shape[1] < net.d_in:
         raise _capi.NfxError("mlp_generic_fwd: x has %d columns, the network reads %d" % (x.shape[1], net.d_in))
     if out is None:
-        out = torch.empty((n, net.d_out), dtype=torch.float32, device=x.device)
-    if out.dim() != 2 or out.shape[0] != n or out.stride(1) != 1 or not out.is_cuda or out.dtype != torch.float32:
-        raise _capi.NfxError("mlp_generic_fwd: bad output matrix")
+        out = torch.empty((n, col0 + net.d_out), dtype=torch.float32, device=x.device)
+    _check_out('mlp_generic_fwd', out, n, col0, net.d_out, x.device)
     check(lib.nfx_mlp_generic_fwd(_ptr(x), n, x.stride(0) if n else net.d_in, net.d_in, net.n_layers, net._w, net._a,
                                   net._s, _ptr(net.blob), net.prec, _ptr(out), out.stride(0) if n else out.shape[1],
                                   col0, _stream()), 'nfx_mlp_generic_fwd')
@@ -386,6 +394,8 @@ def mlp_generic_bwd(x, net, dy, dkernels, dbiases, want_dx=False):
     if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise _capi.NfxError("mlp_generic_bwd: x must be a CUDA fp32 matrix with unit column stride")
     n = x.shape[0]
+    if x.shape[1] < net.d_in:
+        raise _capi.NfxError("mlp_generic_bwd: x has %d columns, the network reads %d" % (x.shape[1], net.d_in))
     dy = _dev(dy, 'dy', (n, net.d_out))
     if dkernels is None and dbiases is None:          # input gradient of a frozen network
         if not want_dx:
@@ -441,7 +451,8 @@ def embed(n_freqs, incl_input=True, x=None, rayo=None, rayd=None, z=None, per_ra
         n = b.shape[0] * per_ray
     dev_ = (a if a is not None else b).device
     if out is None:
-        out = torch.empty((n, d_out), dtype=torch.float32, device=dev_)
+        out = torch.empty((n, col0 + d_out), dtype=torch.float32, device=dev_)
+    _check_out('embed', out, n, col0, d_out, dev_)
     check(lib.nfx_embed(_ptr(a), _ptr(b), _ptr(c), n, per_ray, mode, n_freqs, 1 if incl_input else 0, _ptr(out),
                         out.stride(0) if n else d_out, col0, _stream()), 'nfx_embed')
     return out

@@ -610,3 +610,33 @@ def test_accumulate_sigma_with_another_far_distance(nfx_lib, cuda):
         trans = np.cumprod(np.concatenate([np.ones((n, 1)), (1. - alpha + 1e-6)[:, :-1]], 1), 1)
         want = alpha * trans
         assert got.shape == (n, s) and np.abs(got - want).max() < 2e-5, (inf, np.abs(got - want).max())
+
+
+def test_destination_and_input_shapes_are_validated(nfx_lib, cuda):
+    """`out` / `col0` destinations and input widths that do not fit are refused before a launch (they would write or read
+    past a row: ops._check_out, autograd.GenericMlp.forward)."""
+    from nerfactor_amd import autograd, ops
+    rng = np.random.default_rng(4)
+    ks = [nerf_ref.glorot_uniform(rng, 20, 48), nerf_ref.glorot_uniform(rng, 48, 2)]
+    bs = [np.zeros(48, np.float32), np.zeros(2, np.float32)]
+    net = ops.GenericNet(ks, bs, ['relu', None], train=True).to(cuda)
+    x = dev(rng.normal(size=(64, 20)), cuda)
+    with pytest.raises(Exception, match='do not fit'):
+        ops.mlp_generic_fwd(x, net, out=torch.zeros(64, 5, device=cuda), col0=4)
+    with pytest.raises(Exception, match='out must be'):
+        ops.mlp_generic_fwd(x, net, out=torch.zeros(63, 5, device=cuda))
+    with pytest.raises(Exception, match='out must be'):
+        ops.mlp_generic_fwd(x, net, out=torch.zeros(64, 5))
+    with pytest.raises(Exception, match='do not fit'):
+        ops.embed(2, x=x[:, :3].contiguous(), out=torch.zeros(64, 15, device=cuda), col0=1)
+    with pytest.raises(Exception, match='out must be'):
+        ops.embed(2, x=x[:, :3].contiguous(), out=torch.zeros(64, 15, device=cuda, dtype=torch.float64))
+    got = ops.embed(2, x=x[:, :3].contiguous(), out=torch.zeros(64, 17, device=cuda), col0=2)
+    assert torch.equal(got[:, 2:], ops.embed(2, x=x[:, :3].contiguous())) and not got[:, :2].any()
+    dy = dev(rng.normal(size=(64, 2)), cuda)
+    with pytest.raises(Exception, match='the network reads'):
+        ops.mlp_generic_bwd(x[:, :19], net, dy, None, None, want_dx=True)
+    wide = dev(rng.normal(size=(64, 24)), cuda).requires_grad_()
+    with pytest.raises(Exception, match="the network's input width"):
+        autograd.GenericMlp.apply(wide, lambda: net)
+    assert torch.equal(ops.mlp_generic_fwd(wide.detach(), net), ops.mlp_generic_fwd(wide.detach()[:, :20].contiguous(), net))
