@@ -213,7 +213,8 @@ int bwd_plan(int d_in, int n_layers, const int* widths, const int* skip_input, c
 int wgrad_splits(long long tiles, int n_jobs) {
     long long s = (8192 + n_jobs - 1) / n_jobs;
     if (s > tiles / 4) s = tiles / 4;
-    if (s > 64) s = 64;
+    const int cap = nfx_option_int("wgrad_splits", 64);
+    if (s > cap) s = cap;
     return s < 1 ? 1 : (int)s;
 }
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -330,6 +331,7 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     wa.d_in = d_in;
     wa.splits = wgrad_splits(tiles, p.n_jobs);
     wa.n_jobs = p.n_jobs;
+    wa.map = nfx_option_int("wgrad_map", 1);
     wa.slice = p.slice;
     wa.dw_total = p.dw_total;
     wa.partial = reinterpret_cast<float*>(ba.ws + align256((size_t)(tiles + 1) * p.feat_rows * (wide(prec) ? 128 : 64)));

@@ -49,7 +49,10 @@ namespace bwd {
 namespace fused {
 
 constexpr int kNW = 4, kRows = kNW * 32;
-constexpr int kR = 5, kD = 4, kSlot = 8192;
+#ifndef NFX_FUSED_RING
+#define NFX_FUSED_RING 5
+#endif
+constexpr int kR = NFX_FUSED_RING, kD = kR - 1, kSlot = 8192;
 constexpr int kFwdSub = 21;   // sub-chunks per tile: forward 0-20, dgrad through `out` 21-22, W3 23-26, W2 27-30, W1 31-34
 // PART 0 (layers 3 and out) stops behind dZ3: 23 sub-chunks per tile; PART 1 (layers 2, 1, 0) runs the whole chain: 35
 constexpr int sub_n(int part) { return part == 0 ? 23 : 35; }

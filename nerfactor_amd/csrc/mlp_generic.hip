@@ -357,10 +357,9 @@ static_assert(kMaxHidden == 256, "NFX_FOR_TILE_COUNT covers 1 .. 8 tiles");
 __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
     for (int o = lane * 16; o < bytes; o += 64 * 16) *reinterpret_cast<lds_f32x4*>(p + o) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-// the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features; `ws`
-// (backward, fp32 only): also to the workspace, feature-major (the bf16 path transposes through store_blocked instead)
+// the lane's row of the network input -> LDS, zero padded to `feats`; lane half g takes every other 8 features
 template <int M>
-__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g, float* ws_col = nullptr) {
+__device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, int feats, lds_char* dst, int g) {
     for (int c0 = 8 * g; c0 < feats; c0 += 16) {
         float f[8];
 #pragma unroll
@@ -370,10 +369,6 @@ __device__ __forceinline__ void load_x(const float* __restrict__ src, int d_in, 
         if constexpr (P<M>::kF32) {
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4) = f32x4{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<lds_f32x4*>(dst + c0 * 4 + 16) = f32x4{f[4], f[5], f[6], f[7]};
-            if (ws_col) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ws_col[(size_t)(c0 + j) * 32] = f[j];
-            }
         } else {
             bf16x8 v;
 #pragma unroll
@@ -536,26 +531,40 @@ __device__ __forceinline__ void scale_by_act_grad_output16(float* d, const float
         for (int q = 0; q < 16; ++q) d[q] *= 1.f - expf(-y[q]);
     }
 }
-// bf16: [32 rows][F features] row-major in the wave's LDS -> feature rows [frow, frow + F) of the wave's workspace tile.
-// 16-lane group q takes rows 4 q .. 4 q + 3 (then + 16): lane i supplies row 4 q + (i >> 2), features f0 + 4 (i & 3) ..,
+// [32 rows][F features] row-major in the wave's LDS -> feature rows [frow, frow + F) of the wave's workspace tile.
+// bf16: 16-lane group q takes rows 4 q .. 4 q + 3 (then + 16): lane i supplies row 4 q + (i >> 2), features f0 + 4 (i & 3) ..,
 // receives feature f0 + i of the four rows = one 8-byte store.
+// fp32 (round 5; round 4 stored the 16 accumulators of a tile as 16 dwords straight from the registers — 1260 vector-memory
+// instructions per 32 rows of the light-visibility network, and at 60-180 cycles of issue each THEY set the kernel's pace,
+// not the matrix pipe: profiles/r05/README.md): lane takes feature f0 + (lane >> 3), rows 4 (lane & 7) .. + 3 — four
+// ds_read_b32 a pitch apart, ONE 16-byte store; a wave instruction = 8 whole feature rows, 1 KiB contiguous.
+template <int M>
 __device__ __forceinline__ void store_blocked(const lds_char* lds, int pitch, int F, char* wst, int frow, int lane) {
-    const int i = lane & 15, q = lane >> 4;
-    const lds_char* src = lds + (4 * q + (i >> 2)) * pitch + 8 * (i & 3);
-    char* dst = wst + ((size_t)(frow + i) * 32 + 4 * q) * 2;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int f0 = 0; f0 < F; f0 += 16) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + f0 * 2));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + 16 * pitch + f0 * 2));
-        *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64) = lo;
-        *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64 + 32) = hi;
+    if constexpr (P<M>::kF32) {
+        typedef __attribute__((address_space(3))) float lds_float;
+        const int fi = lane >> 3, r0 = 4 * (lane & 7);
+        const lds_char* s0 = lds + r0 * pitch + fi * 4;
+        const lds_char* s1 = s0 + pitch;
+        const lds_char* s2 = s1 + pitch;
+        const lds_char* s3 = s2 + pitch;
+        float* dst = reinterpret_cast<float*>(wst) + (size_t)(frow + fi) * 32 + r0;
+        for (int f0 = 0; f0 < F; f0 += 8) {
+            const f32x4 v = {*(const lds_float*)(s0 + f0 * 4), *(const lds_float*)(s1 + f0 * 4), *(const lds_float*)(s2 + f0 * 4),
+                             *(const lds_float*)(s3 + f0 * 4)};
+            *reinterpret_cast<f32x4*>(dst + (size_t)f0 * 32) = v;
+        }
+    } else {
+        const int i = lane & 15, q = lane >> 4;
+        const lds_char* src = lds + (4 * q + (i >> 2)) * pitch + 8 * (i & 3);
+        char* dst = wst + ((size_t)(frow + i) * 32 + 4 * q) * 2;
+        for (int f0 = 0; f0 < F; f0 += 16) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + f0 * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + 16 * pitch + f0 * 2));
+            *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64) = lo;
+            *reinterpret_cast<s16x4*>(dst + (size_t)f0 * 64 + 32) = hi;
+        }
     }
-}
-// fp32: the lane's 16 values of a tile straight from registers, one coalesced 128-byte line per feature and half
-__device__ __forceinline__ void store_ws16(char* wst, int frow_tile, int p, int g, const float* v) {
-    float* dst = reinterpret_cast<float*>(wst) + (size_t)(frow_tile + 4 * g) * 32 + p;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * 32] = v[q];
 }
 
 // the backward kernel's forward of one layer: as forward_layer, plus the workspace copies (fp32: straight from the
@@ -587,7 +596,6 @@ __device__ __forceinline__ void recompute_layer(const BwdArgs& ba, int l, Ring<M
         }
         zero_pad16(v, t, g, L.n_out);
         store_row16<M>(hrow + P<M>::kTile * t, g, v);
-        if constexpr (P<M>::kF32) store_ws16(wst, (last ? ba.b[l].dz_row : ba.b[l].h_row) + 32 * t, p, g, v);
     });
     zero_pad_tile<M, NT>(hrow, g);
 }
@@ -612,7 +620,6 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M, NW
         for (int q = 0; q < 16; ++q) d[q] = acc[q];
         scale_by_act_grad_output16(d, y, a.layer[l - 1].act);
         store_row16<M>(hrow + P<M>::kTile * mt, g, d);
-        if constexpr (P<M>::kF32) store_ws16(wst, ba.b[l - 1].dz_row + 32 * mt, p, g, d);
     });
     zero_pad_tile<M, NT>(hrow, g);
 }
@@ -641,17 +648,15 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
         const bool live = mine && row0 + p < a.n;
         const long long r = row0 + p < a.n ? row0 + p : a.n - 1;
         char* wst = ba.ws + (size_t)rt * ba.feat_rows * P<M>::kWsFeat;
-        load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g, reinterpret_cast<float*>(wst) + p);
-        if constexpr (!P<M>::kF32) store_blocked(xb, x_pitch, fx, wst, 0, lane);
+        load_x<M>(a.x + r * a.ld_x, a.d_in, fx, xb + p * x_pitch, g);
+        store_blocked<M>(xb, x_pitch, fx, wst, 0, lane);
         // ---- forward; the last layer turns dy into its own gradient
         const float* dyr = ba.dy + r * ba.ld_dy + ba.col0_dy;
         for (int l = 0; l < a.n_layers; ++l) {
 #define NFX_RECOMPUTE(NT) recompute_layer<M, NW, NT>(ba, l, w, hrow, xb + p * x_pitch, g, p, live, dyr, wst)
             NFX_FOR_TILE_COUNT(a.layer[l].n_tiles, NFX_RECOMPUTE)
 #undef NFX_RECOMPUTE
-            if constexpr (!P<M>::kF32) {
-                if (l + 1 < a.n_layers) store_blocked(hb, h_pitch, a.layer[l].n_tiles * 32, wst, ba.b[l].h_row, lane);
-            }
+            if (l + 1 < a.n_layers) store_blocked<M>(hb, h_pitch, a.layer[l].n_tiles * 32, wst, ba.b[l].h_row, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stored activations are read back below (same wave, own lines)
         // ---- backward: the hidden buffer holds dZ of layer l.  The transposed fragments follow the forward ones in the
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
         bool dx_written = false;
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const Layer L = a.layer[l];
-            if constexpr (!P<M>::kF32) store_blocked(hb, h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
+            store_blocked<M>(hb, h_pitch, L.n_tiles * 32, wst, ba.b[l].dz_row, lane);
             const int kg_o = pad_group(2 * L.n_tiles) / kGroup;
             const lds_char* zsrc = hrow + g * (P<M>::kStep / 2);
             if (L.ks_x > 0 && (ba.dx || l > 0)) {
@@ -742,9 +747,24 @@ template <int M>
 __global__ __launch_bounds__(256) void mlp_generic_wgrad_kernel(WgradArgs a) {
     constexpr int E = P<M>::kElem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, g = lane >> 5;
-    const long long wid = (long long)blockIdx.x * 4 + wave;
-    if (wid >= (long long)a.n_jobs * a.splits) return;
-    const int job = (int)(wid / a.splits), sp = (int)(wid % a.splits);
+    // Which (64 x 64 block of dW = job, row split) this wave takes.  The jobs of one layer re-read each other's operands
+    // (a 128 x 128 layer: 4 jobs, every workspace tile of the layer read by 2 of them; 2.6 reads per stored byte over the
+    // light-visibility network), so the order decides how much of that is HBM traffic:
+    //   map 0 (round 4): consecutive waves = consecutive SPLITS of one job — the re-readers of a tile sit `splits` waves
+    //     apart, in other workgroups;
+    //   map 1: the 4 waves of a workgroup = 4 consecutive JOBS of one split (same rows, in lock step), and the workgroups
+    //     of a split are those the dispatcher hands to ONE XCD (workgroup b -> XCD b mod 8): every re-read is an L2 hit.
+    // Same (job, split) sums either way: bit-identical results.
+    int job, sp;
+    if (a.map == 0) {
+        const long long wid = (long long)blockIdx.x * 4 + wave;
+        if (wid >= (long long)a.n_jobs * a.splits) return;
+        job = (int)(wid / a.splits), sp = (int)(wid % a.splits);
+    } else {
+        const int per_split = (a.n_jobs + 3) / 4, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        sp = (j / per_split) * 8 + xcd, job = (j % per_split) * 4 + wave;
+        if (sp >= a.splits || job >= a.n_jobs) return;
+    }
     int l = 0;
     while (l + 1 < a.n_layers && a.b[l + 1].job0 <= job) ++l;
     const Layer L = a.layer[l];
@@ -834,9 +854,15 @@ __global__ __launch_bounds__(256) void split_hilo_kernel(char* frags, long long 
     *reinterpret_cast<bf16x8*>(f + 1024) = r.lo;
 }
 
+// One thread per OUTPUT ELEMENT, columns fastest: a wave writes 64 consecutive floats of a row (round 4 gave every thread a
+// whole row — 27 or 63 stores a lane, each wave store scattered over 64 rows: 0.4 TB/s).  An element re-computes its
+// vector (and, mode 3, the normalisation) and takes one half of sincos_cw: the same values bit for bit.
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
-    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (row >= a.n) return;
+    const int d = (a.incl_input ? 3 : 0) + 6 * a.n_freqs;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n * d) return;
+    const long long row = e / d;
+    const int c = (int)(e - row * d);
     const long long src = row / a.per_ray;
     float v[3];
 #pragma unroll
@@ -851,23 +877,17 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] *= inv;
     }
-    float* o = a.out + row * a.ld_out + a.col0;
-    int c = 0;
-    if (a.incl_input) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[c++] = v[k];
+    const int cb = c - (a.incl_input ? 3 : 0);        // column inside the bands: [sin x3 | cos x3] per band
+    const int k = cb < 0 ? c : cb % 3;
+    const float vk = k == 0 ? v[0] : k == 1 ? v[1] : v[2];
+    float r = vk;
+    if (cb >= 0) {
+        const int f = cb / 6;
+        float sn, cs;
+        sincos_cw(vk * (float)(1 << f), sn, cs);      // 2^k x is exact in fp32, as in TensorFlow
+        r = (cb - 6 * f) < 3 ? sn : cs;
     }
-    for (int f = 0; f < a.n_freqs; ++f) {
-        const float s = (float)(1 << f);     // 2^k x is exact in fp32, as in TensorFlow
-        float sn[3], cs[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sincos_cw(v[k] * s, sn[k], cs[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[c + k] = sn[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[c + 3 + k] = cs[k];
-        c += 6;
-    }
+    a.out[row * a.ld_out + a.col0 + c] = r;
 }
 
 // d (embedding) / d v pulled back: dv = d[identity block] + sum over bands of 2^k (cos(2^k v) d[sin block] - sin(2^k v) d[cos block])
@@ -957,7 +977,9 @@ int NFX_CAT(nfx_generic_bwd_m, NFX_GENERIC_TU)(const nfx::generic::BwdArgs* ba, 
     if (rc) return rc;
     if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
         const long long waves = (long long)wa->n_jobs * wa->splits;
-        hipLaunchKernelGGL(mlp_generic_wgrad_kernel<M>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *wa);
+        const unsigned wgs = wa->map == 0 ? (unsigned)((waves + 3) / 4)
+                                          : (unsigned)((wa->splits + 7) / 8 * ((wa->n_jobs + 3) / 4) * 8);
+        hipLaunchKernelGGL(mlp_generic_wgrad_kernel<M>, dim3(wgs), dim3(256), 0, st, *wa);
     }
     return 0;
 }
@@ -1015,7 +1037,8 @@ int nfx_launch_embed_bwd(const nfx::generic::EmbedArgs* a, const float* d_out, f
 }
 int nfx_launch_embed(const nfx::generic::EmbedArgs* a, hipStream_t st) {
     if (a->n <= 0) return 0;
-    hipLaunchKernelGGL(nfx::generic::embed_kernel, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, st, *a);
+    const long long elems = a->n * ((a->incl_input ? 3 : 0) + 6 * a->n_freqs);
+    hipLaunchKernelGGL(nfx::generic::embed_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, *a);
     return (int)hipGetLastError();
 }
 }

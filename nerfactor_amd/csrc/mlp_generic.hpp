@@ -87,6 +87,7 @@ struct WgradArgs {
     const char* ws;
     long long tiles;
     int feat_rows, n_layers, d_in, splits, n_jobs;   // (the element type of ws is the kernel's template argument)
+    int map;                 // wave -> (job, split): 0 = splits fastest (round 4) | 1 = a split's jobs share workgroups, a split stays on one XCD
     long long slice;         // floats per partial slice: all kernel gradients, then all bias gradients
     long long dw_total;      // floats of kernel gradients in a slice
     float* partial;          // [splits][slice]

@@ -36,8 +36,14 @@ def net(d_in, widths, acts, skip_at, rng, prec='bf16'):
 
 
 def main():
+    """--only name[,name]: those cases only; --option key=value: a library option (A / B runs, e.g. wgrad_map=0)."""
     rng = np.random.default_rng(0)
     out = {}
+    only = sys.argv[sys.argv.index('--only') + 1].split(',') if '--only' in sys.argv else None
+    for i, a in enumerate(sys.argv):
+        if a == '--option':
+            k, v = sys.argv[i + 1].split('=')
+            ops._capi.set_option(k, int(v))
     for name, d_in, widths, acts, skip, n, prec in (
             ('nerf_enc_256x8', 63, [256] * 8, ['relu'] * 8, [4], 1 << 18, 'bf16'),
             ('surface_128x4_lvis', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 21, 'bf16'),
@@ -48,6 +54,8 @@ def main():
             ('brdf_prior_128x4_fp32', 18, [128] * 4 + [1], ['relu'] * 4 + ['softplus'], [2], 1 << 19, 'fp32'),
             ('nerf_enc_256x8_fp32_native', 63, [256] * 8, ['relu'] * 8, [4], 1 << 17, 'fp32_native'),
             ('surface_128x4_lvis_fp32_native', 90, [128] * 4 + [1], ['relu'] * 4 + ['sigmoid'], [2], 1 << 19, 'fp32_native')):
+        if only and name not in only:
+            continue
         g, ks, bs, macs = net(d_in, widths, acts, skip, rng, prec)
         x = torch.randn((n, d_in), device=cuda)
         dy = torch.randn((n, widths[-1]), device=cuda)

@@ -66,6 +66,41 @@ PYEOF
     sigma)    timeout 600 python scripts/sigma_last_error.py > $OUT/sigma_last_error.json 2>&1; cat $OUT/sigma_last_error.json ;;
     prof)     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs ${PROF_LEGS:-nerf,nerfactor_microfacet,nerfactor,olat} > $ROOT/$OUT/prof_run.log 2>&1); find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -25 ;;
     train-prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_train -o train -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs train > $ROOT/$OUT/prof_train_run.log 2>&1); find $OUT/prof_train -name "*kernel_stats*" | head -1 | xargs -r head -30 ;;
+    train-prof-fp32) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_train_fp32 -o t -- python $ROOT/scripts/bench_train.py --model ${FP32_MODEL:-nerfactor_microfacet} --precision fp32 --fp32-matrix pairs --steps 10 > $ROOT/$OUT/prof_train_fp32_run.log 2>&1); find $OUT/prof_train_fp32 -name "*kernel_stats*" | head -1 | xargs -r head -40 ;;
+    generic-ab) for mp in 1 0; do timeout 300 python scripts/generic_rates.py --only ${GENERIC_ONLY:-surface_128x4_lvis_fp32,surface_128x4_lvis,nerf_enc_256x8_fp32} --option wgrad_map=$mp > $OUT/generic_rates_map$mp.json 2> $OUT/generic_rates_map$mp.err; cat $OUT/generic_rates_map$mp.json; tail -2 $OUT/generic_rates_map$mp.err
+                 for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "fetch FETCH_SIZE" "write WRITE_SIZE" "tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+                   set -- $pass; name=$1; shift
+                   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_generic_map$mp/$name -o p -- python $ROOT/scripts/generic_rates.py --only surface_128x4_lvis_fp32 --option wgrad_map=$mp > $ROOT/$OUT/pmc_generic_map${mp}_$name.log 2>&1); echo "pmc pass $name rc=$?"
+                 done
+                 python scripts/pmc_digest.py $OUT/pmc_generic_map$mp > $OUT/pmc_generic_map${mp}_digest.json; python - <<PYEOF
+import json
+d=json.load(open("$OUT/pmc_generic_map${mp}_digest.json"))
+for k,v in d.items():
+    if 'generic' in k: print(k[:60], {a: (round(b,4) if isinstance(b,float) and b<10 else int(b)) for a,b in v.items()})
+PYEOF
+               done ;;
+    pmc-sq2) for pass in "sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM" "sq3 SQ_WAVE_CYCLES SQ_INST_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
+                 set -- $pass; name=$1; shift
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_sq2_train/$name -o p -- python $ROOT/bench.py --legs train --train-models nerfactor_microfacet --steps 1 --warmup 1 --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/pmc_sq2_train_$name.log 2>&1); echo "pmc pass $name rc=$?"
+                 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_sq2_generic/$name -o p -- python $ROOT/scripts/generic_rates.py --only surface_128x4_lvis_fp32,surface_128x4_lvis > $ROOT/$OUT/pmc_sq2_generic_$name.log 2>&1); echo "pmc pass $name rc=$?"
+               done
+               for w in train generic; do python scripts/pmc_digest.py $OUT/pmc_sq2_$w > $OUT/pmc_sq2_${w}_digest.json; python - <<PYEOF
+import json
+d=json.load(open("$OUT/pmc_sq2_${w}_digest.json"))
+for k,v in d.items():
+    if 'fused_kernel<1' in k or 'generic_bwd' in k or 'generic_wgrad_kernel' in k or 'generic_kernel' in k:
+        wc=v.get('SQ_WAVE_CYCLES',1)
+        print(k[:64], {a: round(b/wc,4) for a,b in v.items() if a.startswith('SQ_') and a!='SQ_WAVE_CYCLES'}, int(wc))
+PYEOF
+               done ;;
+    fused-ab) for lib in ${AB_LIBS:-libnfx libnfx_xp6 libnfx_xp7}; do NFX_LIB_PATH=$ROOT/nerfactor_amd/$lib.so timeout 300 python bench.py --legs train --train-models nerfactor_microfacet --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_train_$lib.json 2> $OUT/bench_train_$lib.err; python - <<PYEOF
+import json
+d=json.loads(open("$OUT/bench_train_$lib.json").read().strip().splitlines()[-1])
+t=d.get('train',d)
+print("$lib", json.dumps({k:v for k,v in (t.get('nerfactor_microfacet') or t).items() if not isinstance(v,(dict,list))})[:600])
+PYEOF
+               done ;;
+    splits-ab) for sp in 64 128 256; do timeout 300 python scripts/generic_rates.py --only ${GENERIC_ONLY:-surface_128x4_lvis_fp32,nerf_enc_256x8_fp32,surface_128x4_lvis_fp32_native,surface_128x4_lvis} --option wgrad_splits=$sp > $OUT/generic_rates_splits$sp.json 2> $OUT/generic_rates_splits$sp.err; echo "splits $sp"; cat $OUT/generic_rates_splits$sp.json; tail -2 $OUT/generic_rates_splits$sp.err; done ;;
     *) echo "unknown stage $st" ;;
   esac
 done
