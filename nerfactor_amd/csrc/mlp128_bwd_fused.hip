@@ -158,10 +158,16 @@ __device__ __forceinline__ void end(Ctx& cx) {
 template <int KS, int KSA>
 __device__ __forceinline__ void mma(const Ctx& cx, const bf16x8 (&b)[KSA][1], int f0, f32x16& acc) {
     const char* p = cx.smem + cx.cur * kSlot + f0 * kFragBytes + cx.lane * 16;
+    // fragment s + 2 is read before MFMA s ("read, wait, MFMA" per k-step exposed the LDS latency KS times: round 5)
+    constexpr int D = 2;
+    bf16x8 a[D + 1];
+#pragma unroll
+    for (int s = 0; s < D && s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][0], acc, 0, 0, 0);
+        if (s + D < KS) a[(s + D) % (D + 1)] = *reinterpret_cast<const bf16x8*>(p + (s + D) * kFragBytes);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % (D + 1)], b[s][0], acc, 0, 0, 0);
+        if (KS > D) __builtin_amdgcn_sched_barrier(0);
     }
 }
 // The same in two halves (round 5): the fragment reads of a sub-chunk are ISSUED first, the epilogue of the PREVIOUS tile
@@ -321,33 +327,50 @@ __device__ __forceinline__ void store_rows(char* row, int lx, const bf16x8 (&v)[
 // operand adds two rows per instruction: 4 VALU per k-step instead of a 16-register all-ones MFMA block.
 // `a`, `b`: the buffers' starts; A tiles i < NI at the lane's offsets alo[i] / ahi[i] (MINE: the wave's own tile), B at
 // blo / bhi; the 16 rows of k-step kk are an immediate offset (kk * 4 KiB: outside the swizzle).
+// Software-pipelined (round 5): the transposing reads of MFMA s + kWgradAhead are issued before MFMA s.  Round 4 read an
+// operand and used it at once — "ds_read_tr x2, s_waitcnt lgkmcnt(0), MFMA" 104 times a PART-1 tile, the LDS latency
+// exposed every time (142 full lgkmcnt drains per tile in the ISA, a quarter of the wave's time waiting on a counter).
+#ifndef NFX_FUSED_WGRAD_AHEAD
+#define NFX_FUSED_WGRAD_AHEAD 2
+#endif
+constexpr int kWgradAhead = NFX_FUSED_WGRAD_AHEAD;
 template <int NI, int A0, int NA, int NO>
 __device__ __forceinline__ void wgrad(const char* a, const int (&alo)[NO], const int (&ahi)[NO], const char* b, int blo, int bhi,
                                       f32x16 (&acc)[NA], float* bsum) {
     static_assert(NI <= NO, "offsets");
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     const b2 ones = {(__bf16)1.f, (__bf16)1.f};
+    constexpr int D = kWgradAhead, NSTEP = (kRows / 16) * NI;     // step s: k-step s / NI, A tile s % NI
+    constexpr int NB = (D + NI - 1) / NI + 1;                     // B operands alive at once
+    bf16x8 af[D + 1], bf[NB];
+    auto load_a = [&](int s) { return tr_frag2(a + alo[s % NI] + (s / NI) * 16 * kHPitch, a + ahi[s % NI] + (s / NI) * 16 * kHPitch); };
+    auto load_b = [&](int kk) { return tr_frag2(b + blo + kk * 16 * kHPitch, b + bhi + kk * 16 * kHPitch); };
 #pragma unroll
-    for (int kk = 0; kk < kRows / 16; ++kk) {
-        const bf16x8 bf = tr_frag2(b + blo + kk * 16 * kHPitch, b + bhi + kk * 16 * kHPitch);
+    for (int s = 0; s < D && s < NSTEP; ++s) {
+        if (s % NI == 0) bf[(s / NI) % NB] = load_b(s / NI);
+        af[s % (D + 1)] = load_a(s);
+    }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const bf16x8 af = tr_frag2(a + alo[i] + kk * 16 * kHPitch, a + ahi[i] + kk * 16 * kHPitch);
-            acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[A0 + i], 0, 0, 0);
+    for (int s = 0; s < NSTEP; ++s) {
+        const int kk = s / NI, i = s % NI;
+        if (s + D < NSTEP) {
+            if ((s + D) % NI == 0) bf[((s + D) / NI) % NB] = load_b((s + D) / NI);
+            af[(s + D) % (D + 1)] = load_a(s + D);
         }
-        if (bsum != nullptr) {
+        acc[A0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % (D + 1)], bf[kk % NB], acc[A0 + i], 0, 0, 0);
+        if (bsum != nullptr && i == NI - 1) {
             // (hipcc 7.2: four dot products of the dwords of a bit_cast u32x4 all read the FIRST dword — r04 call D, every
             //  dot2-summed bias gradient wrong; element pairs spelled out read the right registers)
             float t = *bsum;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const b2 pr = {bf[2 * q], bf[2 * q + 1]};
+                const b2 pr = {bf[kk % NB][2 * q], bf[kk % NB][2 * q + 1]};
                 t = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, t, false);
             }
             *bsum = t;
         }
-        __builtin_amdgcn_sched_barrier(0);   // one k-step's operands at a time: the scheduler otherwise hoists every read of the
-                                             // step (80 fragment registers) above the first MFMA and the accumulators spill
+        __builtin_amdgcn_sched_barrier(0);   // one MFMA's operands at a time: the scheduler otherwise hoists every read of a
+                                             // k-step (80 fragment registers) above the first MFMA and the accumulators spill
     }
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -81,7 +81,13 @@ struct P {
     static constexpr int kPieces = kGroupBytes / 1024;        // DMA pieces per group: 4 or 8
     // ring depth in groups: 3 slots of 4 KiB (bf16) or 8 KiB (fp32 modes: a group is 12 (pairs) or 32 (native) MFMAs per
     // output tile there, so two groups ahead are > 700 matrix-pipe cycles of cover for an L2 fetch)
-    static constexpr int kRingGroups = 3;
+#ifndef NFX_GENERIC_RING_F32
+#define NFX_GENERIC_RING_F32 3
+#endif
+#ifndef NFX_GENERIC_RING_BF16
+#define NFX_GENERIC_RING_BF16 3
+#endif
+    static constexpr int kRingGroups = kF32 ? NFX_GENERIC_RING_F32 : NFX_GENERIC_RING_BF16;
     static constexpr int kRingBytes = kRingGroups * kGroupBytes;
     static constexpr int kStep = 16 * kElem;                  // bytes of one k-step in a row: 32 or 64
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row

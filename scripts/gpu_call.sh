@@ -101,6 +101,12 @@ print("$lib", json.dumps({k:v for k,v in (t.get('nerfactor_microfacet') or t).it
 PYEOF
                done ;;
     splits-ab) for sp in 64 128 256; do timeout 300 python scripts/generic_rates.py --only ${GENERIC_ONLY:-surface_128x4_lvis_fp32,nerf_enc_256x8_fp32,surface_128x4_lvis_fp32_native,surface_128x4_lvis} --option wgrad_splits=$sp > $OUT/generic_rates_splits$sp.json 2> $OUT/generic_rates_splits$sp.err; echo "splits $sp"; cat $OUT/generic_rates_splits$sp.json; tail -2 $OUT/generic_rates_splits$sp.err; done ;;
+    ring-ab) for lib in ${RING_LIBS:-libnfx libnfx_xpA libnfx_xpB}; do NFX_LIB_PATH=$ROOT/nerfactor_amd/$lib.so timeout 300 python scripts/generic_rates.py > $OUT/generic_rates_$lib.json 2> $OUT/generic_rates_$lib.err; echo $lib; python - <<PYEOF
+import json
+d=json.load(open("$OUT/generic_rates_$lib.json"))
+for k,v in d.items(): print('  %-34s fwd %7.3f ms %6.1f TF   bwd %7.3f ms %6.1f TF' % (k, v['fwd_ms'], v['fwd_tflops'], v['bwd_ms'], v['bwd_tflops']))
+PYEOF
+               tail -1 $OUT/generic_rates_$lib.err; done ;;
     *) echo "unknown stage $st" ;;
   esac
 done
