@@ -97,9 +97,12 @@ struct Sub {
              : G::kFwdFrags + (k - kFwdSub) * 8;   // the 112 dgrad fragments are contiguous: 14 sub-chunks of 8
     }
     static constexpr int pieces(int k) { return frags(k) / kNW; }   // 1-KiB pieces per wave: 1 | 2
-    static constexpr int allow(int k) {   // pieces that may still be in flight when sub-chunk k + 1 must have landed
+    // pieces that may still be in flight at the barrier that ends sub-chunk k: those of k + 3 ... k + kD.  k + 1 AND k + 2 have
+    // landed for every wave behind it (round 5: the first fragments of sub-chunk k + 2 are read while k + 1 multiplies — see
+    // sub_mma; until then the barrier guaranteed k + 1 only and every sub-chunk began with "read, wait ~130 cycles, MFMA")
+    static constexpr int allow(int k) {
         int n = 0;
-        for (int j = 2; j <= kD; ++j) n += pieces((k + j) % NS);
+        for (int j = 3; j <= kD; ++j) n += pieces((k + j) % NS);
         return n;
     }
 };
@@ -149,42 +152,53 @@ __device__ __forceinline__ void begin(const Ctx& cx) {
     lds_dma_pieces<n>((unsigned)cx.lane * 16u, reinterpret_cast<const char*>(base) + (size_t)Sub<KSX, NS>::off(F) * 1024 + piece0 * 1024,
                       lds + (unsigned)slot * kSlot + (unsigned)piece0 * 1024u);
 }
-template <int KSX, int NS, int K>
+// LGKM: the LDS reads that may still be in flight across the barrier — the NEXT sub-chunk's carry fragments, issued last.
+// Everything older (this sub-chunk's own fragment reads: the compiler is free to sink their MFMAs below the barrier) has
+// returned before the wave arrives, so no wave's DMA into this slot (begin<K + 1>) can overtake a read of it.
+template <int KSX, int NS, int K, int LGKM>
 __device__ __forceinline__ void end(Ctx& cx) {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Sub<KSX, NS>::allow(K)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(Sub<KSX, NS>::allow(K)), "n"(LGKM) : "memory");
     cx.cur = cx.cur + 1 == kR ? 0 : cx.cur + 1;
 }
-// acc += A(current slot, fragments f0 .. f0 + KS - 1) x b[0 ...]
-template <int KS, int KSA>
-__device__ __forceinline__ void mma(const Ctx& cx, const bf16x8 (&b)[KSA][1], int f0, f32x16& acc) {
-    const char* p = cx.smem + cx.cur * kSlot + f0 * kFragBytes + cx.lane * 16;
-    // fragment s + 2 is read before MFMA s ("read, wait, MFMA" per k-step exposed the LDS latency KS times: round 5)
-    constexpr int D = 2;
-    bf16x8 a[D + 1];
+// Fragment reads and MFMAs of one sub-chunk, software-pipelined ACROSS sub-chunks (round 5).  With one wave per SIMD nothing
+// hides the ~130 cycles between a ds_read_b128 and its first use but the wave's own MFMAs, and the ring's barrier sits in
+// front of every sub-chunk: "barrier, 8 reads, wait, MFMAs" exposed that latency 35 times per 128-row tile (the ISA of r04 /
+// early r05: every sub-chunk "rrrrrrrr s_waitcnt lgkmcnt(0) MFMA").  Now the first kCarry fragments of a sub-chunk are read
+// into the CARRY registers while the previous sub-chunk's second half multiplies — its barrier has guaranteed them, see
+// Sub::allow — and the remaining ones at its own start, under its first-half MFMAs.  Fragment registers alive: 16 + 16, as
+// before.  The carry is dropped where a weight-gradient section sits between two sub-chunks (HAVE = false behind it).
+constexpr int kCarry = 4;
+struct Carry {
+    bf16x8 f[kCarry];
+};
+template <int N>
+__device__ __forceinline__ void read_frags(const Ctx& cx, int slot, int f0, bf16x8* dst) {
+    const char* p = cx.smem + slot * kSlot + f0 * kFragBytes + cx.lane * 16;
 #pragma unroll
-    for (int s = 0; s < D && s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        if (s + D < KS) a[(s + D) % (D + 1)] = *reinterpret_cast<const bf16x8*>(p + (s + D) * kFragBytes);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % (D + 1)], b[s][0], acc, 0, 0, 0);
-        if (KS > D) __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int s = 0; s < N; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
 }
-// The same in two halves (round 5): the fragment reads of a sub-chunk are ISSUED first, the epilogue of the PREVIOUS tile
-// (30-70 VALU instructions: conversions, ReLU masks, the parked-row stores) runs while they are in flight, then the MFMAs.
-// With one wave per SIMD nothing else hides the ~130 cycles between a ds_read_b128 and its first use, and the ring's
-// barrier sits in front of every sub-chunk's reads: 35 exposed LDS latencies per 128-row tile before.
-template <int KS>
-__device__ __forceinline__ void load_frags(const Ctx& cx, int f0, bf16x8 (&a)[KS]) {
-    const char* p = cx.smem + cx.cur * kSlot + f0 * kFragBytes + cx.lane * 16;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(p + s * kFragBytes);
+constexpr int kSchedAluOnly = 0x2 | 0x4;   // sched_barrier mask: VALU / SALU may cross, MFMA and LDS instructions may not
+// acc += A(sub-chunk K: KS fragments) x b[0 .. KS); `pre`: VALU work that runs under the reads (the previous tile's epilogue).
+// HAVE: the carry holds this sub-chunk's first fragments; NEXT: how many of the FOLLOWING sub-chunk's to read into it.
+template <int KSX, int NS, int K, int KS, bool HAVE, int NEXT, int KSA, class Pre>
+__device__ __forceinline__ void sub_mma(Ctx& cx, Carry& c, const bf16x8 (&b)[KSA][1], f32x16& acc, Pre pre) {
+    constexpr int H = KS < kCarry ? KS : kCarry, R = KS - H;
+    static_assert(NEXT <= kCarry && KS <= KSA, "fragments");
+    bf16x8 rest[R > 0 ? R : 1];
+    if constexpr (!HAVE) read_frags<H>(cx, cx.cur, 0, c.f);
+    if constexpr (R > 0) read_frags<R>(cx, cx.cur, H, rest);
     __builtin_amdgcn_sched_barrier(0);      // (the reads stay in front of what follows)
-}
-template <int KS, int KSA>
-__device__ __forceinline__ void mma_regs(const bf16x8 (&a)[KS], const bf16x8 (&b)[KSA][1], f32x16& acc) {
+    pre();
 #pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s][0], acc, 0, 0, 0);
+    for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.f[s], b[s][0], acc, 0, 0, 0);
+    if constexpr (NEXT > 0) {
+        __builtin_amdgcn_sched_barrier(kSchedAluOnly);
+        read_frags<NEXT>(cx, cx.cur + 1 == kR ? 0 : cx.cur + 1, 0, c.f);
+        __builtin_amdgcn_sched_barrier(kSchedAluOnly);
+    }
+#pragma unroll
+    for (int s = 0; s < R; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rest[s], b[H + s][0], acc, 0, 0, 0);
+    end<KSX, NS, K, NEXT>(cx);
 }
 // ---- packed 16-bit epilogues (the kernels are VALU-bound beside their MFMAs: r04 call C counted ~3300 VALU instructions
 // per 128-row tile and wave against 340 matrix instructions; the scalar forms — v_med3 + v_cvt per value, bf16 -> f32 +
@@ -233,9 +247,9 @@ __device__ __forceinline__ void relu_tile(const f32x16& acc, bf16x8& lo, bf16x8&
 }
 // one forward layer of 4 tiles whose chunk is ONE sub-chunk each (K0 = its first sub-chunk)
 // `park` (optional): the tile's two output k-steps go to this lane's parked row in LDS as soon as they exist
-template <int KSX, int NS, int K0, int KS, bool BITS, int KSA>
-__device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1], unsigned (&mk)[4],
-                                      char* park = nullptr, int lx = 0) {
+template <int KSX, int NS, int K0, int KS, bool BITS, bool HAVE, int NEXT, int KSA>
+__device__ __forceinline__ void layer(Ctx& cx, Carry& c, const float* bias, const bf16x8 (&b)[KSA][1], bf16x8 (&out)[8][1],
+                                      unsigned (&mk)[4], char* park = nullptr, int lx = 0) {
     f32x16 prev;      // tile t - 1's accumulators: its epilogue runs under tile t's fragment reads
     auto epilogue = [&](auto T) {
         constexpr int t = decltype(T)::value;
@@ -248,14 +262,11 @@ __device__ __forceinline__ void layer(Ctx& cx, const float* bias, const bf16x8 (
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
-        bf16x8 a[KS];
-        load_frags<KS>(cx, 0, a);
         f32x16 acc[1];
         bias_init<1>(bias + 32 * t, cx.lane >> 5, acc);      // (broadcast reads: in flight under the epilogue as well)
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (t > 0) epilogue(std::integral_constant<int, t - 1>{});
-        mma_regs<KS>(a, b, acc[0]);
-        end<KSX, NS, K0 + t>(cx);
+        sub_mma<KSX, NS, K0 + t, KS, (t > 0 || HAVE), (t < 3 ? (KS < kCarry ? KS : kCarry) : NEXT)>(cx, c, b, acc[0], [&]() {
+            if constexpr (t > 0) epilogue(std::integral_constant<int, t - 1>{});
+        });
         prev = acc[0];
     });
     epilogue(std::integral_constant<int, 3>{});
@@ -294,20 +305,18 @@ __device__ __forceinline__ void relu_mask(const f32x16& acc, const bf16x8 (&hact
     mfma_operand_fence(ohi);
 }
 // dgrad layer, one sub-chunk (8 fragments) per 32-feature tile: dH^T = W dZ^T, ReLU-masked by the activation
-template <int KSX, int NS, int K0, int MODE>
-__device__ __forceinline__ void dgrad(Ctx& cx, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
+template <int KSX, int NS, int K0, int MODE, bool HAVE>
+__device__ __forceinline__ void dgrad(Ctx& cx, Carry& c, const bf16x8 (&dz)[8][1], const bf16x8 (&hact)[8][1], const unsigned (&mk)[4],
                                       const char* park, int lx, bf16x8 (&dout)[8][1]) {
     f32x16 prev;
     static_for<0, 4>([&](auto T) {
         constexpr int t = decltype(T)::value;
         begin<KSX, NS, K0 + t>(cx);
-        bf16x8 a[8];
-        load_frags<8>(cx, 0, a);
-        if constexpr (t > 0) relu_mask<MODE>(prev, hact, mk, park, lx, t - 1, dout[2 * t - 2][0], dout[2 * t - 1][0]);
         f32x16 acc[1];
         zero_acc(acc[0]);
-        mma_regs<8>(a, dz, acc[0]);
-        end<KSX, NS, K0 + t>(cx);
+        sub_mma<KSX, NS, K0 + t, 8, (t > 0 || HAVE), (t < 3 ? kCarry : 0)>(cx, c, dz, acc[0], [&]() {   // (a weight-gradient section follows tile 3)
+            if constexpr (t > 0) relu_mask<MODE>(prev, hact, mk, park, lx, t - 1, dout[2 * t - 2][0], dout[2 * t - 1][0]);
+        });
         prev = acc[0];
     });
     relu_mask<MODE>(prev, hact, mk, park, lx, 3, dout[6][0], dout[7][0]);
@@ -497,25 +506,23 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         // PART 0 stops behind dZ3 and needs no mask below h3.
         unsigned m2[4], m3[4];
         constexpr bool kBits = PART == 1;
-        layer<KSX, NS, 0, KSX, false>(cx, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr, lx);
-        layer<KSX, NS, 4, 8, false>(cx, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr, lx);
-        layer<KSX, NS, 8, 8, kBits>(cx, bias_lds + 256, h1, h2, m2);
+        Carry cr;     // the next sub-chunk's first fragments (sub_mma)
+        constexpr int kXc = KSX < kCarry ? KSX : kCarry;
+        layer<KSX, NS, 0, KSX, false, false, kCarry>(cx, cr, bias_lds, xin, h0, m2, PART == 1 ? h0row : nullptr, lx);
+        layer<KSX, NS, 4, 8, false, true, kCarry>(cx, cr, bias_lds + 128, h0, h1, m2, PART == 1 ? hrow : nullptr, lx);
+        layer<KSX, NS, 8, 8, kBits, true, kCarry>(cx, cr, bias_lds + 256, h1, h2, m2);
         {
             f32x16 prev3;
             static_for<0, 4>([&](auto T) {   // layer 3: [h2 ; input], two sub-chunks per tile
                 constexpr int t = decltype(T)::value;
                 begin<KSX, NS, 12 + 2 * t>(cx);
-                bf16x8 af[8];
-                load_frags<8>(cx, 0, af);
                 f32x16 a3[1];
                 bias_init<1>(bias_lds + 384 + 32 * t, h, a3);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (t > 0) relu_tile<kBits>(prev3, h3[2 * t - 2][0], h3[2 * t - 1][0], m3[t - 1]);   // (under the reads)
-                mma_regs<8>(af, h2, a3[0]);
-                end<KSX, NS, 12 + 2 * t>(cx);
+                sub_mma<KSX, NS, 12 + 2 * t, 8, true, kXc>(cx, cr, h2, a3[0], [&]() {
+                    if constexpr (t > 0) relu_tile<kBits>(prev3, h3[2 * t - 2][0], h3[2 * t - 1][0], m3[t - 1]);   // (under the reads)
+                });
                 begin<KSX, NS, 13 + 2 * t>(cx);
-                mma<KSX>(cx, xin, 0, a3[0]);
-                end<KSX, NS, 13 + 2 * t>(cx);
+                sub_mma<KSX, NS, 13 + 2 * t, KSX, true, kCarry>(cx, cr, xin, a3[0], []() {});   // next: tile t + 1's h2 part, or `out`
                 prev3 = a3[0];
             });
             relu_tile<kBits>(prev3, h3[6][0], h3[7][0], m3[3]);
@@ -523,8 +530,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         f32x16 logit[1];
         begin<KSX, NS, 20>(cx);
         bias_init<1>(bias_lds + 512, h, logit);
-        mma<8>(cx, h3, 0, logit[0]);
-        end<KSX, NS, 20>(cx);
+        // (PART 0: the out layer's weight-gradient section sits between sub-chunks 20 and 21 — no carry across it)
+        sub_mma<KSX, NS, 20, 8, true, (PART == 1 ? 1 : 0)>(cx, cr, h3, logit[0], []() {});
         // ------------------------------------------------------------------ dZ_out
         bf16x8 dzo[1][1];
 #pragma unroll
@@ -542,15 +549,24 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
         // ------------------------------------------------------------------ dgrad chain + weight gradients
         bf16x8 dz3[8][1];
         {   // through the out layer: one k-step (16 padded output slots); tiles 0, 1 in sub-chunk 21, tiles 2, 3 in 22
-            static_for<0, 2>([&](auto U) {
+            static_for<0, 2>([&](auto U) {      // fragments 0 and 4 of the sub-chunk: 0 rides in the carry
                 constexpr int u = decltype(U)::value;
                 begin<KSX, NS, 21 + u>(cx);
                 f32x16 a0[1], a1[1];
                 zero_acc(a0[0]);
                 zero_acc(a1[0]);
-                mma<1>(cx, dzo, 0, a0[0]);
-                mma<1>(cx, dzo, 4, a1[0]);
-                end<KSX, NS, 21 + u>(cx);
+                bf16x8 f4[1];
+                if constexpr (u == 0 && PART == 0) read_frags<1>(cx, cx.cur, 0, cr.f);
+                read_frags<1>(cx, cx.cur, 4, f4);
+                __builtin_amdgcn_sched_barrier(0);
+                a0[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cr.f[0], dzo[0][0], a0[0], 0, 0, 0);
+                if constexpr (u == 0 || PART == 1) {      // next: sub-chunk 22 (fragment 0), or PART 1's dgrad through W3
+                    __builtin_amdgcn_sched_barrier(kSchedAluOnly);
+                    read_frags<(u == 0 ? 1 : kCarry)>(cx, cx.cur + 1 == kR ? 0 : cx.cur + 1, 0, cr.f);
+                    __builtin_amdgcn_sched_barrier(kSchedAluOnly);
+                }
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f4[0], dzo[0][0], a1[0], 0, 0, 0);
+                end<KSX, NS, 21 + u, (u == 0 ? 1 : PART == 1 ? kCarry : 0)>(cx);
                 relu_mask<kBits ? 1 : 0>(a0[0], h3, m3, nullptr, 0, 2 * u, dz3[4 * u][0], dz3[4 * u + 1][0]);
                 relu_mask<kBits ? 1 : 0>(a1[0], h3, m3, nullptr, 0, 2 * u + 1, dz3[4 * u + 2][0], dz3[4 * u + 3][0]);
             });
@@ -564,15 +580,15 @@ __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
             lds_barrier();   // the next tile's first statement rewrites the X rows
         } else {
             bf16x8 dz2[8][1], dz1[8][1], dz0[8][1];
-            dgrad<KSX, NS, 23, 1>(cx, dz3, h2, m2, nullptr, 0, dz2);   // W3[:128, :]
+            dgrad<KSX, NS, 23, 1, true>(cx, cr, dz3, h2, m2, nullptr, 0, dz2);   // W3[:128, :]
             store_rows<8>(zrow, lx, dz2);
             lds_barrier();
             wgrad<4, B::kW2>(ha, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, &bsum0);   // A = h1, parked in the H buffer by the forward
-            dgrad<KSX, NS, 27, 2>(cx, dz2, h1, m2, hrow, lx, dz1);     // W2; mask = this lane's parked h1 row
+            dgrad<KSX, NS, 27, 2, false>(cx, cr, dz2, h1, m2, hrow, lx, dz1);     // W2; mask = this lane's parked h1 row
             store_rows<8>(zrow, lx, dz1);
             lds_barrier();
             wgrad<4, B::kW1>(xa, tr.lo, tr.hi, za, tr.mylo[0], tr.myhi[0], acc, &bsum1);   // A = h0, parked in the X region
-            dgrad<KSX, NS, 31, 2>(cx, dz1, h0, m2, h0row, lx, dz0);    // W1; mask = the parked h0 row
+            dgrad<KSX, NS, 31, 2, false>(cx, cr, dz1, h0, m2, h0row, lx, dz0);    // W1; mask = the parked h0 row
             store_rows<KSX>(hrow, lx, xin);                            // the input rows take the H buffer (h1 is done with)
             store_rows<8>(zrow, lx, dz0);
             lds_barrier();
