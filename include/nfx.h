@@ -352,6 +352,18 @@ NFX_API float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t 
 NFX_API int nfx_amsgrad_step_dev(float *dev_p, const float *dev_g, float *dev_m, float *dev_v, float *dev_vhat,
                          int64_t n, const float *dev_lr_t, float beta1, float beta2, float eps, void *stream);
 
+/* tf.linalg.l2_normalize over the rows of x[n, d] (d <= 16; util/math.py:63-64 of the reference: x * rsqrt(max(sum x^2, eps)))
+ * and its pull-back dx = (d y / d x)^T dy — the predicted normals and BRDF codes of a NeRFactor training step
+ * (nerfactor.py:205-206, 266-270), one launch each way instead of 5 + 12 elementwise ones.                       */
+NFX_API int nfx_l2_normalize_rows(const float *dev_x, float *dev_y, int64_t n, int d, float eps, void *stream);
+NFX_API int nfx_l2_normalize_rows_bwd(const float *dev_x, const float *dev_dy, float *dev_dx, int64_t n, int d, float eps,
+                                      void *stream);
+/* The light probe's smoothness penalties (nerfactor.py:526-539): dev_loss[0] = tv_weight * sum((L - roll(L, 1, 1))^2 +
+ * (L - roll(L, 1, 0))^2) + achro_weight * sum((L - roll(L, 1, 2))^2) over dev_light[h, w, 3], and dev_grad[h, w, 3] =
+ * d loss / d L.  One block, fixed reduction order.                                                                */
+NFX_API int nfx_light_smoothness(const float *dev_light, int h, int w, float tv_weight, float achro_weight, float *dev_loss,
+                                 float *dev_grad, void *stream);
+
 /* The per-ray training losses of the surface models (nerfactor.py:463-541, shape.py:239-277 `compute_loss`) as one
  * launch: loss[ray] = sum_t w_t * mean_d f_t(A_t[ray, d] - B_t[ray, d]), f = square (keras MSE) or abs (MAE), A / B
  * optionally alpha-blended onto the background first (util/img.py:alpha_blend: x * alpha + bg * (1 - alpha)).

@@ -77,6 +77,9 @@ SIGNATURES = {
     'nfx_shade_bwd_workspace_bytes': (_sz, [_i]),
     'nfx_shade_bwd': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p,
                            _p, _p, _sz, _p]),
+    'nfx_l2_normalize_rows': (_i, [_p, _p, _i64, _i, _f, _p]),
+    'nfx_l2_normalize_rows_bwd': (_i, [_p, _p, _p, _i64, _i, _f, _p]),
+    'nfx_light_smoothness': (_i, [_p, _i, _i, _f, _f, _p, _p, _p]),
     'nfx_pair_loss_fwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
     'nfx_pair_loss_bwd': (_i, [_p, _i, _p, _f, _i64, _p, _p]),
     'nfx_pack_gather': (_i, [_p, _p, _i64, _p, _p]),

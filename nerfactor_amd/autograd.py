@@ -245,6 +245,49 @@ class GenericMlp(torch.autograd.Function):
         return (dx, None) + tuple(rks) + tuple(rbs)
 
 
+class L2NormalizeRows(torch.autograd.Function):
+    """tf.linalg.l2_normalize(x, axis=1, epsilon=eps) with its pull-back as ONE launch each (csrc/regularizers.hip) — under
+    autograd the torch formula (util/math.py:safe_l2_normalize) is 5 launches forward and 12 backward per call."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return ops.l2_normalize_rows(x, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.l2_normalize_rows_bwd(x, dy.contiguous(), ctx.eps), None
+
+
+def l2_normalize(v, eps=1e-6):
+    """safe_l2_normalize(v, axis=1) of v[n, d]: one libnfx launch, and one more for the pull-back while autograd is
+    recording; host tensors (and d > 16) take the torch formula."""
+    if not v.is_cuda or v.dtype != torch.float32 or v.dim() != 2 or v.shape[1] > 16:
+        return v * torch.rsqrt(torch.clamp(torch.sum(v * v, dim=1, keepdim=True), min=eps))
+    if torch.is_grad_enabled() and v.requires_grad:
+        return L2NormalizeRows.apply(v, eps)
+    return ops.l2_normalize_rows(v.contiguous(), eps)
+
+
+class LightSmoothness(torch.autograd.Function):
+    """The light probe's spatial and cross-channel TV penalties (nerfactor.py:526-539) as a 0-dim loss: one launch computes
+    the sum and its gradient, the backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, light, tv_weight, achro_weight):
+        loss, grad = ops.light_smoothness(light.contiguous(), tv_weight, achro_weight)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None, None
+
+
 class BrdfRowsGeom(torch.autograd.Function):
     """(rows, front) = the learned BRDF's explicit fp32 input rows [z | embed(rusink)] per (point, light) and the front-lit
     flags (nerfactor.py:413-436); differentiable w.r.t. the normal (local frame + Rusinkiewicz angles, the reference's

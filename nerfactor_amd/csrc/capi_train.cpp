@@ -561,6 +561,26 @@ int nfx_pair_loss_bwd(const nfx_loss_term* terms, int n_terms, const float* alph
                           "pair_loss_bwd");
 }
 
+int nfx_launch_l2_normalize_rows(int, const float*, const float*, float*, long long, int, float, hipStream_t);
+int nfx_launch_light_smoothness(const float*, int, int, float, float, float*, float*, hipStream_t);
+int nfx_l2_normalize_rows(const float* x, float* y, int64_t n, int d, float eps, void* stream) {
+    REQUIRE(n >= 0 && d >= 1 && d <= 16, "nfx_l2_normalize_rows: n >= 0 and 1 <= d <= 16");
+    REQUIRE(n == 0 || (x && y), "nfx_l2_normalize_rows: null pointer");
+    return nfx_hip_result(nfx_launch_l2_normalize_rows(0, x, nullptr, y, n, d, eps, (hipStream_t)stream), "l2_normalize_rows");
+}
+int nfx_l2_normalize_rows_bwd(const float* x, const float* dy, float* dx, int64_t n, int d, float eps, void* stream) {
+    REQUIRE(n >= 0 && d >= 1 && d <= 16, "nfx_l2_normalize_rows_bwd: n >= 0 and 1 <= d <= 16");
+    REQUIRE(n == 0 || (x && dy && dx), "nfx_l2_normalize_rows_bwd: null pointer");
+    return nfx_hip_result(nfx_launch_l2_normalize_rows(1, x, dy, dx, n, d, eps, (hipStream_t)stream), "l2_normalize_rows_bwd");
+}
+int nfx_light_smoothness(const float* light, int h, int w, float tv_weight, float achro_weight, float* loss, float* grad,
+                         void* stream) {
+    REQUIRE(h >= 1 && w >= 1 && (int64_t)h * w <= (1 << 20), "nfx_light_smoothness: bad probe size %d x %d", h, w);
+    REQUIRE(light && loss && grad, "nfx_light_smoothness: null pointer");
+    return nfx_hip_result(nfx_launch_light_smoothness(light, h, w, tv_weight, achro_weight, loss, grad, (hipStream_t)stream),
+                          "light_smoothness");
+}
+
 int nfx_amsgrad_step(float* p, const float* g, float* m, float* v, float* vhat, int64_t n, float lr, float beta1,
                      float beta2, float eps, int64_t step, void* stream) {
     REQUIRE(n >= 0 && step >= 1, "nfx_amsgrad_step: bad n/step");

@@ -190,12 +190,19 @@ class Model(ShapeModel):
             xyz_j = None
         # The clean and the jittered evaluation of a head share ONE kernel launch per direction (forward, backward,
         # weight gradients): the two point sets are concatenated and the result is split again.
+        # (the concatenations are built once for all four heads; torch.split's backward is one cat, two slices' is
+        # zeros + copy twice and an add)
+        xyz_both = torch.cat((xyz, xyz_j)) if jitter else None
+        doubled = {}
+
         def both(fn, **kw):
             if not jitter:
                 return fn(xyz, **kw), None
-            n = xyz.shape[0]
-            out = fn(torch.cat((xyz, xyz_j)), **{k: torch.cat((v, v)) for k, v in kw.items()})
-            return out[:n], out[n:]
+            for k, v in kw.items():
+                if k not in doubled:
+                    doubled[k] = torch.cat((v, v))
+            out = fn(xyz_both, **{k: doubled[k] for k in kw})
+            return torch.split(out, xyz.shape[0])
         # ------ normals
         if self.shape_mode == 'nerf':
             normal_pred, normal_jitter = normal, None
@@ -222,9 +229,9 @@ class Model(ShapeModel):
                                       "_get_default_brdf_at (nerfactor.py:256)")
         brdf_prop, brdf_prop_jitter = both(self._pred_brdf_at)
         if self.normalize_brdf_z:
-            brdf_prop = mathutil.safe_l2_normalize(brdf_prop, axis=1)
+            brdf_prop = self._normalize(brdf_prop)
             if brdf_prop_jitter is not None:
-                brdf_prop_jitter = mathutil.safe_l2_normalize(brdf_prop_jitter, axis=1)
+                brdf_prop_jitter = self._normalize(brdf_prop_jitter)
         if brdf_z_override is not None:
             zo = torch.as_tensor(brdf_z_override, dtype=torch.float32, device=xyz.device)
             brdf_prop = zo.reshape(1, self.z_dim).expand(brdf_prop.shape[0], -1).contiguous()
@@ -274,11 +281,8 @@ class Model(ShapeModel):
 
     @staticmethod
     def _normalize(v):
-        """safe_l2_normalize(v, axis=1): the HIP kernel, or the (differentiable) torch formula while
-        autograd is recording — 3 floats per ray, not a hot spot."""
-        if torch.is_grad_enabled() and v.requires_grad:
-            return mathutil.safe_l2_normalize(v, axis=1)
-        return ops.l2_normalize3(v, 1e-6)
+        """safe_l2_normalize(v, axis=1) (csrc/regularizers.hip: one launch, one more for the pull-back)."""
+        return nfx_grad.l2_normalize(v, 1e-6)
 
     # ------------------------------------------------------------------ heads
     def _pred_albedo_at(self, pts):
@@ -483,7 +487,9 @@ class Model(ShapeModel):
                 loss = loss + self.albedo_smooth_weight * smooth(pred['albedo'], albedo_jitter)
             if brdf_prop_jitter is not None:
                 loss = loss + self.brdf_smooth_weight * smooth(pred['brdf'], brdf_prop_jitter)
-        if mode == 'train':
+        if mode == 'train' and self.light.is_cuda and (light_tv_weight > 0 or light_achro_weight > 0):
+            loss = loss + nfx_grad.LightSmoothness.apply(self.light, max(light_tv_weight, 0.), max(light_achro_weight, 0.))
+        elif mode == 'train':
             light = self.light
             if light_tv_weight > 0:
                 dx = light - torch.roll(light, 1, 1)

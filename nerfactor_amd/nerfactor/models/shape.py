@@ -228,10 +228,10 @@ class Model(BaseModel):
         xyz_jitter_std = self.config.getfloat('DEFAULT', 'xyz_jitter_std')
         id_, hw, _, _, _, alpha, xyz, normal, lvis = batch
         xyz_noise = torch.randn_like(xyz) * xyz_jitter_std if xyz_jitter_std > 0 else None
-        normal_pred = mathutil.safe_l2_normalize(self._pred_normal_at(xyz), axis=1)
+        normal_pred = nfx_grad.l2_normalize(self._pred_normal_at(xyz))
         normal_jitter = None
         if xyz_noise is not None and self.normal_smooth_weight > 0:
-            normal_jitter = mathutil.safe_l2_normalize(self._pred_normal_at(xyz + xyz_noise), axis=1)
+            normal_jitter = nfx_grad.l2_normalize(self._pred_normal_at(xyz + xyz_noise))
         lvis_pred = self._pred_lvis_at(xyz)
         lvis_jitter = None
         if xyz_noise is not None and self.lvis_smooth_weight > 0:

@@ -187,6 +187,34 @@ def l2_normalize3(x, eps):
     return out
 
 
+def l2_normalize_rows(x, eps=1e-6):
+    """tf.linalg.l2_normalize(x, axis=1, epsilon=eps) of x[n, d], d <= 16 (one launch)."""
+    x = _dev(x, 'x', (None, None))
+    out = torch.empty_like(x)
+    check(lib.nfx_l2_normalize_rows(_ptr(x), _ptr(out), x.shape[0], x.shape[1], eps, _stream()), 'nfx_l2_normalize_rows')
+    return out
+
+
+def l2_normalize_rows_bwd(x, dy, eps=1e-6):
+    """dx of l2_normalize_rows(x) given dy = dLoss / d y (one launch)."""
+    x = _dev(x, 'x', (None, None))
+    dy = _dev(dy, 'dy', tuple(x.shape))
+    dx = torch.empty_like(x)
+    check(lib.nfx_l2_normalize_rows_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.shape[0], x.shape[1], eps, _stream()),
+          'nfx_l2_normalize_rows_bwd')
+    return dx
+
+
+def light_smoothness(light, tv_weight, achro_weight):
+    """(loss[1], grad[h, w, 3]) of the light probe's smoothness penalties (nerfactor.py:526-539), one launch."""
+    light = _dev(light, 'light', (None, None, 3))
+    loss = torch.empty((1,), dtype=torch.float32, device=light.device)
+    grad = torch.empty_like(light)
+    check(lib.nfx_light_smoothness(_ptr(light), light.shape[0], light.shape[1], float(tv_weight), float(achro_weight),
+                                   _ptr(loss), _ptr(grad), _stream()), 'nfx_light_smoothness')
+    return loss, grad
+
+
 def all_finite(x):
     """0-dim bool CUDA tensor: no Inf / NaN in the fp32 tensor `x` (one read of x; tf.debugging.check_numerics)."""
     x = _dev(x, 'x')
