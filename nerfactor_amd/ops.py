@@ -134,15 +134,48 @@ class DevicePacker:
         self._dev = {}
         self._checked = False
 
+    def _map_in_place(self, tensors):
+        """(base address, device map) when every parameter is a contiguous view of one storage: the map's indices into the
+        concatenation, translated to element offsets from the lowest parameter's address.  None otherwise."""
+        try:
+            store = tensors[0].untyped_storage().data_ptr()
+            if any(t.untyped_storage().data_ptr() != store or not t.is_contiguous() or t.dtype != torch.float32 for t in tensors):
+                return None
+        except Exception:
+            return None
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        key = (tensors[0].device, ptrs)
+        hit = self._dev.get(key)
+        if hit is None:
+            base = min(ptrs)
+            sizes = [int(np.prod(s)) for s in self.shapes]
+            offs = np.cumsum([0] + sizes)
+            where = np.concatenate([np.full(k, (p - base) // 4 - offs[i], np.int64) for i, (k, p) in enumerate(zip(sizes, ptrs))])
+            if max((p - base) // 4 + k for k, p in zip(sizes, ptrs)) >= 1 << 30:
+                return None
+            m = self.map_host.astype(np.int64)
+            idx = m & 0x3fffffff
+            moved = np.where(m >= 0, (idx + where[np.minimum(idx, where.size - 1)]) | (m & (1 << 30)), m)
+            hit = (base, torch.from_numpy(moved.astype(np.int32)).to(tensors[0].device))
+            self._dev[key] = hit
+        return hit
+
     def pack(self, tensors):
         """tensors: the network's parameters (CUDA fp32, kernels then biases) -> uint8 CUDA blob."""
         dev = tensors[0].device
-        if dev not in self._dev:
-            self._dev[dev] = torch.from_numpy(self.map_host).to(dev)
-        src = torch.cat([t.detach().reshape(-1) for t in tensors])
         blob = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-        check(lib.nfx_pack_gather(_ptr(src), _ptr(self._dev[dev]), self.n_words, _ptr(blob), _stream()),
-              'nfx_pack_gather')
+        in_place = self._map_in_place(tensors)
+        if in_place is not None:
+            # the parameters are views of ONE buffer (optim.AMSGrad's flat bucket): gather straight out of it — no
+            # concatenation (2 launches per blob and step, 16 of the 92 launches of a NeRFactor step)
+            base, dmap = in_place
+            check(lib.nfx_pack_gather(ctypes.c_void_p(base), _ptr(dmap), self.n_words, _ptr(blob), _stream()), 'nfx_pack_gather')
+        else:
+            if dev not in self._dev:
+                self._dev[dev] = torch.from_numpy(self.map_host).to(dev)
+            src = torch.cat([t.detach().reshape(-1) for t in tensors])
+            check(lib.nfx_pack_gather(_ptr(src), _ptr(self._dev[dev]), self.n_words, _ptr(blob), _stream()),
+                  'nfx_pack_gather')
         if self.post is not None:
             self.post(blob)
         if not self._checked:   # once per network: the device gather must reproduce the host packer bit for bit

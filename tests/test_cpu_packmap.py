@@ -139,3 +139,34 @@ def test_fp32_split_blob_of_the_density_gradient_kernel(nfx_lib):
     ks_lo = [k - (_bf16_bits(k).astype(np.uint32) << 16).view(np.float32).reshape(k.shape) for k in ks]
     assert np.array_equal(f32[nw:2 * nw], ops.pack_nerf_geom_weights(ks_lo, bs).numpy()[:nw])
     assert np.array_equal(f32[2 * nw:].view(np.float32)[-256:], ks[8][:, 0])
+
+
+@pytest.mark.parametrize('name', ['lvis', 'lvis_train', 'nerf', 'lvis_fp32'])
+def test_gather_map_translated_into_a_flat_parameter_buffer(nfx_lib, name):
+    """Parameters that are views of one buffer (optim.AMSGrad's flat bucket) are gathered in place: the map's indices
+    translated to offsets from the lowest parameter (ops.DevicePacker._map_in_place) reproduce the host-packed blob from
+    the buffer itself — whatever the order and the gaps of the views."""
+    from nerfactor_amd import ops
+    pack_fn, shapes_k = _cases(nfx_lib)[name]
+    shapes_b = [(s[1],) for s in shapes_k]
+    packer = ops.DevicePacker(pack_fn, shapes_k, shapes_b)
+    shapes = shapes_k + shapes_b
+    rng = np.random.default_rng(11)
+    order = rng.permutation(len(shapes))
+    sizes = [int(np.prod(s)) for s in shapes]
+    offs, at = {}, 5
+    for i in order:                      # shuffled, with gaps (other networks' parameters live in between)
+        offs[i] = at
+        at += sizes[i] + int(rng.integers(0, 40))
+    flat = torch.from_numpy(rng.normal(size=at + 3).astype(np.float32))
+    views = [flat[offs[i]:offs[i] + sizes[i]].view(shapes[i]) for i in range(len(shapes))]
+    base, dmap = packer._map_in_place(views)
+    assert base == min(v.data_ptr() for v in views)
+    first = (base - flat.data_ptr()) // 4
+    moved = ops.DevicePacker.__new__(ops.DevicePacker)
+    moved.map_host = dmap.numpy()
+    got = _emulate_gather(moved, [flat.numpy()[first:]])
+    want = pack_fn([v.numpy() for v in views[:len(shapes_k)]], [v.numpy() for v in views[len(shapes_k):]]).numpy()
+    assert np.array_equal(got, want)
+    assert packer._map_in_place(views)[1] is dmap                                  # cached per set of addresses
+    assert packer._map_in_place([v.clone() for v in views]) is None                # separate storages: the concatenation path
