@@ -71,7 +71,7 @@ NFX_API int nfx_last_error(char *buf, size_t len);
  * should affect (set / unset are atomic, but not ordered against calls in flight on other threads).  Keys:
  *   nerf_variant (7)  nerf_blocks (256)  m128_blocks (256)  lvis_variant (8)  brdf_variant (6)  brdf_ct (4)
  *   nerf_bwd (1)  nerf_bwd_nw (8)  m128_bwd (1)  wgrad_lds / wgrad_slabs / wgrad_narrow (by row count)
- *   wgrad_fused (1)  wgrad_map (1)  wgrad_splits (64)
+ *   wgrad_fused (1)  wgrad_map (1)  wgrad_splits (256)
  * (defaults in parentheses; every variant of a selector computes the same function, most of them bit-identically —
  * DESIGN.md).  An unknown key is NFX_EINVAL.  nfx_unset_option returns a key to its default. */
 NFX_API int nfx_set_option(const char *key, int value);

@@ -85,7 +85,7 @@ Option g_options[] = {
     {"wgrad_slabs", {0}, {0}},    // number of row slabs of a weight-gradient batch (default by row count)
     {"wgrad_narrow", {0}, {0}},   // 0 = width-128 networks through the wide kernel as well
     {"wgrad_fused", {0}, {0}},    // 0 = backward kernels store activations, separate weight-gradient GEMMs (identity reference)
-    {"wgrad_splits", {0}, {0}},   // runtime-shaped weight gradients: most row splits of the contraction (default 64)
+    {"wgrad_splits", {0}, {0}},   // runtime-shaped weight gradients: most row splits of the contraction (default 256)
     {"wgrad_map", {0}, {0}},      // runtime-shaped weight gradients: 1 (default) = a row split's jobs on one XCD | 0 = round-4 order
 };
 Option* find_option(const char* key) {

@@ -413,10 +413,17 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArg
     float* lxyz_s = sm;
     float* area_s = lxyz_s + 3 * L;
     float* light_s = area_s + L;
+    // d loss / d light of THIS workgroup's rays, fixed point as in the global buffer (round 5).  Round 4 sent every
+    // (ray, light, channel) term to HBM as its own 64-bit device-scope atomic — 1.6 M of them on 1536 addresses per
+    // 1024-ray step, which the memory side serialises: 130 us of a 1.3 ms training step for a 14-us forward.  The sums are
+    // integers: adding them here first (ds_add_u64) and once per workgroup to the global buffer gives the same bits.
+    unsigned long long* dl_s = reinterpret_cast<unsigned long long*>(sm + (7 * L + 1) / 2 * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 3 * L; i += blockDim.x) lxyz_s[i] = f.lxyz[i];
     for (int i = tid; i < L; i += blockDim.x) area_s[i] = f.lareas[i];
     for (int i = tid; i < 3 * L; i += blockDim.x) light_s[i] = f.lights[i];
+    if (a.d_light_fx)
+        for (int i = tid; i < 3 * L; i += blockDim.x) dl_s[i] = 0ull;
     __syncthreads();
     const float pi = 3.14159265358979323846f;
     for (long long pt = (long long)blockIdx.x * kShadeWaves + wave; pt < f.n;
@@ -463,8 +470,7 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArg
                 U += dS[c] * lg;
                 d_alb[c] += dS[c] * k * lg / pi;
                 if (a.d_light_fx)
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.d_light_fx + 3 * l + c),
-                              (unsigned long long)__double2ll_rn((double)(dS[c] * b * k) * kLightFxScale));
+                    atomicAdd(dl_s + 3 * l + c, (unsigned long long)__double2ll_rn((double)(dS[c] * b * k) * kLightFxScale));
             }
             if (a.d_lvis) a.d_lvis[pt * L + l] = front ? cosv * area * T : 0.0f;
             const float d_cos = front ? lvis * area * T : 0.0f;
@@ -502,6 +508,13 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_bwd_kernel(ShadeBwdArg
             }
         }
     }
+    if (a.d_light_fx) {
+        __syncthreads();
+        for (int i = tid; i < 3 * L; i += blockDim.x) {
+            const unsigned long long v = dl_s[i];
+            if (v != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(a.d_light_fx + i), v);
+        }
+    }
 }
 
 }  // namespace nfx
@@ -520,7 +533,7 @@ extern "C" int nfx_launch_shade_bwd(const float* xyz, const float* cam, const fl
     a.d_lvis = d_lvis;
     a.d_light_fx = d_light ? static_cast<long long*>(workspace) : nullptr;
     if (a.d_light_fx) nfx::launch_zero_words(workspace, 3ll * n_lights, st);   // (a kernel, not hipMemsetAsync: nfx_common.hpp)
-    const size_t lds = sizeof(float) * (size_t)7 * n_lights;
+    const size_t lds = sizeof(float) * (size_t)((7 * n_lights + 1) / 2 * 2) + (d_light ? sizeof(long long) * (size_t)3 * n_lights : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
