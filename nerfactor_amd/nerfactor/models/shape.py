@@ -270,7 +270,7 @@ class Model(BaseModel):
                 pts.detach(), (pts if dir_pts is None else dir_pts).detach(), self.lxyz.reshape(-1, 3).contiguous(),
                 self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1, prec='fp32'),
                 lambda: self._generic_net('lvis_mlp', 'lvis_out', 'sigmoid', train=True), self.xyz_scale,
-                (self.embedder['xyz'].n_freqs, self.embedder['ldir'].n_freqs), max(self.mlp_chunk, 1 << 18), *params)
+                (self.embedder['xyz'].n_freqs, self.embedder['ldir'].n_freqs), max(self.mlp_chunk, 1 << 20), *params)
             return self.check_numerics(lvis, "Light visibility")
         if not self._net_tuned('lvis_mlp') or self._fp32_grads(params):
             return self.check_numerics(self._pred_lvis_generic(pts, dir_pts), "Light visibility")
