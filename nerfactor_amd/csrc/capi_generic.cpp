@@ -159,7 +159,9 @@ int nfx_mlp_generic_fwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     a.n_frags = nf;
     a.f32 = prec;
     set_pitches(&a);
-    return nfx_hip_result(nfx_launch_mlp_generic(&a, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream), "mlp_generic_fwd");
+    rc = nfx_launch_mlp_generic(&a, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream);
+    if (rc < 0) return nfx_fail(NFX_ENOSUP, "nfx_mlp_generic_fwd: this shape needs %d bytes of LDS per wave (160 KiB per CU): narrower layers or a smaller input", -rc);
+    return nfx_hip_result(rc, "mlp_generic_fwd");
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
@@ -345,8 +347,9 @@ int nfx_mlp_generic_bwd(const float* x, int64_t n, int ld_x, int d_in, int n_lay
     }
     ba.f.f32 = prec;
     set_pitches(&ba.f);
-    return nfx_hip_result(nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
-                          "mlp_generic_bwd");
+    rc = nfx_launch_mlp_generic_bwd(&ba, &wa, 8 * nfx_option_int("nerf_blocks", 256), (hipStream_t)stream);
+    if (rc < 0) return nfx_fail(NFX_ENOSUP, "nfx_mlp_generic_bwd: this shape needs %d bytes of LDS per wave (160 KiB per CU): narrower layers or a smaller input", -rc);
+    return nfx_hip_result(rc, "mlp_generic_bwd");
 }
 
 int nfx_mlp_generic_split_hilo(void* blob, int d_in, int n_layers, const int* widths, const int* skip_input, int train, void* stream) {

@@ -15,7 +15,8 @@
 //     not from the previous tile's accumulators) as 1-KiB A fragments, ONE stream in consumption order that each wave
 //     pulls through its own LDS ring with the DMA path, three groups of four fragments ahead of its MFMAs;
 //   * the layer table (input widths, tiles, activation, fragment and bias offsets) is a kernel argument.
-// Limits: network input <= 320 features, hidden widths <= 256, <= 16 layers, output <= 256.
+// Limits: network input <= 576 features, hidden widths <= 512, <= 16 layers, output <= 512 (and the wave's two activation rows
+// beside the weight ring within the 160 KiB of LDS: checked per launch).
 // nfx_embed is the Embedder (embedder.py:23-47) as its own kernel, with the point generation o + d z folded in.
 //
 // Backward (mlp_generic_bwd_kernel + mlp_generic_wgrad_kernel + one ordered reduction; mlp_generic.hpp has the
@@ -93,8 +94,11 @@ struct P {
     static constexpr int kTile = 32 * kElem;                  // bytes of 32 features in a row
     static constexpr int kWsFeat = 32 * kElem;                // workspace bytes per (feature, row tile)
 };
+// (every shape the reference builds with widths <= 512 fits one wave's area beside the ring — a 512-wide NeRF's colour head reads
+//  539 features into 256 units; the host refuses the launch with the numbers when a layer table does not: nfx_launch_mlp_generic*)
 static_assert(P<kBf16>::kRingBytes + 32 * ((kMaxIn * 2 + 16) + (kMaxHidden * 2 + 16)) <= 160 * 1024, "LDS");
-static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn * 4 + 16) + (kMaxHidden / 2 * 4 + 16)) <= 160 * 1024, "LDS");
+static_assert(P<kNative>::kRingBytes + 32 * ((kMaxIn / 2 * 4 + 16) + (kMaxHidden * 4 + 16)) <= 160 * 1024, "LDS");
 static_assert(kGroup == 4, "a group = 4 fragments = 4 (bf16) or 8 (fp32 modes) 1-KiB DMA pieces");
 
 // The weight stream: the whole network's fragments in consumption order (mlp_generic.hpp: every tile padded to whole
@@ -340,12 +344,22 @@ __device__ __forceinline__ void layer_mma(Ring<M, NW>& w, int kg_h, int kg_x, co
         }                                  \
     }
             NFX_PICK(0) NFX_PICK(1) NFX_PICK(2) NFX_PICK(3) NFX_PICK(4) NFX_PICK(5) NFX_PICK(6) NFX_PICK(7)
+            NFX_PICK(8) NFX_PICK(9) NFX_PICK(10) NFX_PICK(11) NFX_PICK(12) NFX_PICK(13) NFX_PICK(14) NFX_PICK(15)
 #undef NFX_PICK
             tile_done(t, c);
         }
     }
 }
-// (1 <= n <= kMaxHidden / 32 output tiles: one instantiation each, chosen by a wave-uniform branch)
+// (1 <= n <= kMaxHidden / 32 output tiles: one instantiation each, chosen by a wave-uniform branch.  9 .. 16 tiles — widths
+//  288 .. 512, round 5: all 16 accumulator tiles = 256 registers of a one-wave-per-SIMD kernel — exist in the WIDE
+//  instantiations only (one wave per workgroup; nfx_launch_mlp_generic* picks them for a network with such a layer): the
+//  kernels of every narrower network keep their register counts — the bf16 backward 240, two waves per SIMD)
+#define NFX_WIDE_TILES(k, CALL) \
+    case k:                      \
+        if constexpr (WIDE) {    \
+            CALL(k);             \
+        }                        \
+        break;
 #define NFX_FOR_TILE_COUNT(n, CALL) \
     switch (n) {                     \
         case 1: CALL(1); break;      \
@@ -355,9 +369,12 @@ __device__ __forceinline__ void layer_mma(Ring<M, NW>& w, int kg_h, int kg_x, co
         case 5: CALL(5); break;      \
         case 6: CALL(6); break;      \
         case 7: CALL(7); break;      \
-        default: CALL(8); break;     \
+        case 8: CALL(8); break;      \
+        NFX_WIDE_TILES(9, CALL) NFX_WIDE_TILES(10, CALL) NFX_WIDE_TILES(11, CALL) NFX_WIDE_TILES(12, CALL) \
+        NFX_WIDE_TILES(13, CALL) NFX_WIDE_TILES(14, CALL) NFX_WIDE_TILES(15, CALL) NFX_WIDE_TILES(16, CALL) \
+        default: break;              \
     }
-static_assert(kMaxHidden == 256, "NFX_FOR_TILE_COUNT covers 1 .. 8 tiles");
+static_assert(kMaxHidden == 512, "NFX_FOR_TILE_COUNT covers 1 .. 16 tiles");
 
 // the wave's activation area starts as zeros: every feature a pad k-step can touch is a finite number
 __device__ __forceinline__ void zero_lds(lds_char* p, int bytes, int lane) {
@@ -447,7 +464,8 @@ __device__ __forceinline__ void zero_pad_tile(lds_char* hrow, int g) {
 template <int M, int NW, int NT>
 __device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, bool last, Ring<M, NW>& w, lds_char* hrow, const lds_char* xrow,
                                               int g, float* yrow) {
-    layer_mma<M, NW, NT, false>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
+    // (more than 8 tiles: the looped epilogue — sixteen unrolled ones beside 256 accumulator registers spill)
+    layer_mma<M, NW, NT, (NT > 8)>(w, L.ks_h / kGroup, L.ks_x / kGroup, hrow + g * (P<M>::kStep / 2), xrow + g * (P<M>::kStep / 2),
                               [&](int t, const f32x16& acc) {
         // D: lane = row p (+ half g), register q = output feature 32 t + (q&3) + 8 (q>>2) + 4 g
         float bias[16], v[16];
@@ -478,7 +496,7 @@ __device__ __forceinline__ void forward_layer(const Args& a, const Layer& L, boo
 // One workgroup = NW waves, each with its own 32-row tile and its own activation area in LDS, ONE weight ring (Ring above).
 // Every wave runs the same number of row-tile iterations (the ring's barriers are workgroup barriers): a wave whose tile
 // lies past the end re-computes the last tile and stores nothing.
-template <int M, int NW>
+template <int M, int NW, bool WIDE>
 __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, g = lane >> 5, p = lane & 31;
@@ -630,7 +648,7 @@ __device__ __forceinline__ void dgrad_layer(const BwdArgs& ba, int l, Ring<M, NW
     zero_pad_tile<M, NT>(hrow, g);
 }
 
-template <int M, int NW>
+template <int M, int NW, bool WIDE>
 __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Args& a = ba.f;
@@ -942,21 +960,26 @@ int nfx_generic_bwd_m1(const nfx::generic::BwdArgs*, const nfx::generic::WgradAr
 int nfx_generic_bwd_m2(const nfx::generic::BwdArgs*, const nfx::generic::WgradArgs*, int, int, int, hipStream_t);
 }
 namespace {
-template <int M, int NW>
+template <int M, int NW, bool WIDE = false>
 int launch_fwd(const nfx::generic::Args* args, int grid, int lds, hipStream_t st) {
     using namespace nfx::generic;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<M, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_kernel<M, NW, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((mlp_generic_kernel<M, NW>), dim3(grid), dim3(64 * NW), lds, st, *args);
+    hipLaunchKernelGGL((mlp_generic_kernel<M, NW, WIDE>), dim3(grid), dim3(64 * NW), lds, st, *args);
     return 0;
 }
-template <int M, int NW>
+template <int M, int NW, bool WIDE = false>
 int launch_bwd(const nfx::generic::BwdArgs* ba, int grid, int lds, hipStream_t st) {
     using namespace nfx::generic;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<M, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_generic_bwd_kernel<M, NW, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((mlp_generic_bwd_kernel<M, NW>), dim3(grid), dim3(64 * NW), lds, st, *ba);
+    hipLaunchKernelGGL((mlp_generic_bwd_kernel<M, NW, WIDE>), dim3(grid), dim3(64 * NW), lds, st, *ba);
     return 0;
+}
+bool wide_layers(const nfx::generic::Args& a) {      // a layer of more than 8 output tiles (width > 256)
+    for (int l = 0; l < a.n_layers; ++l)
+        if (a.layer[l].n_tiles > 8) return true;
+    return false;
 }
 }  // namespace
 extern "C" {
@@ -967,6 +990,7 @@ int NFX_CAT(nfx_generic_fwd_m, NFX_GENERIC_TU)(const nfx::generic::Args* args, i
     if (nw == 2) return launch_fwd<M, 2>(args, grid, lds, st);
 #endif
     (void)nw;
+    if (wide_layers(*args)) return launch_fwd<M, 1, true>(args, grid, lds, st);
     return launch_fwd<M, 1>(args, grid, lds, st);
 }
 int NFX_CAT(nfx_generic_bwd_m, NFX_GENERIC_TU)(const nfx::generic::BwdArgs* ba, const nfx::generic::WgradArgs* wa, int nw, int grid, int lds, hipStream_t st) {
@@ -978,7 +1002,8 @@ int NFX_CAT(nfx_generic_bwd_m, NFX_GENERIC_TU)(const nfx::generic::BwdArgs* ba, 
     else if (nw == 2) rc = launch_bwd<M, 2>(ba, grid, lds, st);
     else
 #endif
-        rc = launch_bwd<M, 1>(ba, grid, lds, st);
+        if (wide_layers(ba->f)) rc = launch_bwd<M, 1, true>(ba, grid, lds, st);
+    else rc = launch_bwd<M, 1>(ba, grid, lds, st);
     (void)nw;
     if (rc) return rc;
     if (wa->dw[0]) {     // (no gradient buffers: the caller wants dLoss/dx only)
@@ -1001,6 +1026,8 @@ static int generic_waves(const nfx::generic::Args& a, long long tiles) {
     // DMA pieces it saves, and the backward's workspace stores sit in the same in-order vmcnt queue the shared ring has to
     // drain to 2 (measured, r05 call K: 256 x 8 forward 380 against 384 TFLOP/s, 128 x 4 backward 126 against 173)
     if (!a.f32) return 1;
+    for (int l = 0; l < a.n_layers; ++l)
+        if (a.layer[l].n_tiles > 8) return 1;      // (more than 8 output tiles: instantiated for one wave per workgroup only)
     int nw = 4;
     while (nw > 1 && (ring + nw * act > 160 * 1024 || tiles < nw)) nw /= 2;
     return nw;
@@ -1014,6 +1041,7 @@ int nfx_launch_mlp_generic(const nfx::generic::Args* args, int max_blocks, hipSt
     const long long wgs = (tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
     const int grid = (int)(wgs < cap ? wgs : cap);
     const int lds = (args->f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (args->x_pitch + args->h_pitch);
+    if (lds > 160 * 1024) return -lds;      // (the C entry point turns this into NFX_ENOSUP with the numbers)
     const int rc = args->f32 == kBf16 ? nfx_generic_fwd_m0(args, nw, grid, lds, st)
                  : args->f32 == kX3 ? nfx_generic_fwd_m1(args, nw, grid, lds, st) : nfx_generic_fwd_m2(args, nw, grid, lds, st);
     return rc ? rc : (int)hipGetLastError();
@@ -1025,6 +1053,7 @@ int nfx_launch_mlp_generic_bwd(const nfx::generic::BwdArgs* ba, const nfx::gener
     const long long wgs = (ba->tiles + nw - 1) / nw, cap = max_blocks / nw > 0 ? max_blocks / nw : 1;
     const int grid = (int)(wgs < cap ? wgs : cap);
     const int lds = (ba->f.f32 ? P<kNative>::kRingBytes : P<kBf16>::kRingBytes) + nw * 32 * (ba->f.x_pitch + ba->f.h_pitch);
+    if (lds > 160 * 1024) return -lds;
     const int rc = ba->f.f32 == kBf16 ? nfx_generic_bwd_m0(ba, wa, nw, grid, lds, st)
                  : ba->f.f32 == kX3 ? nfx_generic_bwd_m1(ba, wa, nw, grid, lds, st) : nfx_generic_bwd_m2(ba, wa, nw, grid, lds, st);
     if (rc) return rc;

@@ -4,7 +4,7 @@
 namespace nfx {
 namespace generic {
 
-constexpr int kMaxLayers = 16, kMaxIn = 320, kMaxHidden = 256;   // kMaxIn: concat(256 features, embedded view) = 283
+constexpr int kMaxLayers = 16, kMaxIn = 576, kMaxHidden = 512;   // kMaxIn: concat(512 features, embedded view) = 539 (round 5: widths up to 512)
 // A wave pulls the network's fragments through its LDS ring kGroup at a time as ONE stream (mlp_generic.hip: Ring): both
 // operand sources of every tile are padded to whole groups with zero fragments; within a layer the groups run k-group
 // outer, output tile inner (the kernel reads a group's B operand once for all tiles); layers follow each other without

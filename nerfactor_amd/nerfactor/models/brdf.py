@@ -43,9 +43,9 @@ class Model(BaseModel):
         self.tuned = (width, depth, skip_at) == (128, 4, 2) and self.embedder['rusink'].n_freqs == 2
         if not self.tuned:
             # (a skip behind the body's last layer is an inner skip of the body + head network the kernels evaluate)
-            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth):
+            if not (1 <= width <= 512 and 2 <= depth <= 12 and 0 <= skip_at < depth):
                 raise NotImplementedError(
-                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
+                    "libnfx's runtime-shaped kernels take mlp_width <= 512, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
                     "mlp_depth (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
         head = mlp.Network([1], act=['softplus'])  # reflectance > 0

@@ -99,9 +99,9 @@ class Model(BaseModel):
                       self.embedder['xyz'].n_freqs == 10 and self.embedder['view'].n_freqs == 4)
         if self.tuned:
             return
-        if act not in (None, 'relu', 'sigmoid', 'softplus') or depth < 2 or depth > 12 or not 1 <= width <= 256:
+        if act not in (None, 'relu', 'sigmoid', 'softplus') or depth < 2 or depth > 12 or not 1 <= width <= 512:
             raise NotImplementedError(
-                "libnfx's runtime-shaped kernels take 2 <= enc_depth <= 12, mlp_width <= 256 and relu / sigmoid / softplus "
+                "libnfx's runtime-shaped kernels take 2 <= enc_depth <= 12, mlp_width <= 512 and relu / sigmoid / softplus "
                 "/ linear activations (got enc_depth = %d, mlp_width = %d, act = %s)" % (depth, width, act))
 
     # ------------------------------------------------------------------ weights -> device blob

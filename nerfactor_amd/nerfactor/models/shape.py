@@ -61,9 +61,9 @@ class Model(BaseModel):
             self.tuned = False
             # (a skip behind the body's LAST layer is an inner skip of the body + head network the kernels evaluate: the
             # head then reads concat(y, x), which is what body.build returns)
-            if not (1 <= width <= 256 and 2 <= depth <= 12 and 0 <= skip_at < depth):
+            if not (1 <= width <= 512 and 2 <= depth <= 12 and 0 <= skip_at < depth):
                 raise NotImplementedError(
-                    "libnfx's runtime-shaped kernels take mlp_width <= 256, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
+                    "libnfx's runtime-shaped kernels take mlp_width <= 512, 2 <= mlp_depth <= 12 and 0 <= mlp_skip_at < "
                     "mlp_depth (got mlp_width = %d, mlp_depth = %d, mlp_skip_at = %d)" % (width, depth, skip_at))
         body = mlp.Network([width] * depth, act=['relu'] * depth, skip_at=[skip_at])
         head = mlp.Network([out_dims], act=[out_act])

@@ -74,9 +74,9 @@ def test_generic_limits_are_reported(nfx_lib):
     from nerfactor_amd import ops
     z = lambda a, b: np.zeros((a, b), np.float32)
     with pytest.raises(nfx_lib.NfxError, match='units'):
-        ops.GenericNet([z(3, 300)], [np.zeros(300, np.float32)], [None])
+        ops.GenericNet([z(3, 600)], [np.zeros(600, np.float32)], [None])      # (widths up to 512 since round 5)
     with pytest.raises(nfx_lib.NfxError, match='network input'):
-        ops.GenericNet([z(400, 8)], [np.zeros(8, np.float32)], [None])
+        ops.GenericNet([z(600, 8)], [np.zeros(8, np.float32)], [None])        # (inputs up to 576)
     with pytest.raises(nfx_lib.NfxError, match='expected'):
         ops.GenericNet([z(3, 8), z(9, 4)], [np.zeros(8, np.float32), np.zeros(4, np.float32)], ['relu', None])
 

@@ -35,9 +35,9 @@ def test_surface_model_shapes_are_checked_per_network(ov):
 
 def test_limits_of_the_runtime_shaped_kernels_raise_with_the_numbers():
     with pytest.raises(NotImplementedError, match='mlp_width'):
-        build('nerf', mlp_width='512')
+        build('nerf', mlp_width='640')
     with pytest.raises(NotImplementedError, match='mlp_width'):
-        build('shape', mlp_width='300')
+        build('shape', mlp_width='600')
     assert not build('brdf', mlp_depth='4', mlp_skip_at='3').tuned      # (a skip behind the body's last layer: the head reads concat(y, x))
     with pytest.raises(NotImplementedError, match='skip'):
         build('brdf', mlp_depth='4', mlp_skip_at='4')

@@ -20,7 +20,9 @@ def dev(a, cuda):
     (3, [64, 64, 4], ['relu', 'relu', None], None, 77),
     (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 333),
     (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
-    (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200)])
+    (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200),
+    # round 5: widths up to 512 (9 .. 16 output tiles per layer: one wave per workgroup), a 512-wide NeRF's colour head
+    (63, [512, 512, 288, 512, 4], ['relu'] * 4 + [None], [1], 300), (539, [256, 3], ['relu', 'sigmoid'], None, 150)])
 @pytest.mark.parametrize("prec", ['bf16', 'fp32', 'fp32_native'])
 def test_generic_mlp_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n, prec):
     """bf16: same-rounding bound 4e-3, float64 bound 3e-2; prec = 'fp32_native' (fp32 operands, native fp32 matrix
@@ -82,7 +84,10 @@ def test_embed_kernel_is_the_embedder(nfx_lib, cuda):
     (dict(use_views='False'), dict(use_views=False, n_freqs_view=0)),
     (dict(pos_enc='False', mlp_width='128'), dict(width=128, n_freqs_xyz=0, n_freqs_view=0)),
     # enc_depth = 2: skip_at = [1] = the LAST encoder layer, every head reads concat(y, embed(x)) (nerf.py:53-71)
-    (dict(enc_depth='2', mlp_width='64'), dict(width=64, depth=2))])
+    (dict(enc_depth='2', mlp_width='64'), dict(width=64, depth=2)),
+    # round 5: mlp_width up to 512 (the colour head reads concat(512 bottleneck features, embedded view) = 539 inputs)
+    (dict(mlp_width='512', enc_depth='4'), dict(width=512, depth=4)),
+    (dict(mlp_width='384'), dict(width=384))])
 def test_nerf_plugin_renders_non_shipped_shapes(nfx_lib, cuda, overrides, kw):
     """Model.call(mode='test') of NeRF configurations outside config/nerf.ini's architecture against the oracle's render
     of the same weights: the stated tolerance (max-abs 3e-2 outside the alpha_last band, PSNR >= 40 dB)."""
@@ -197,7 +202,8 @@ def _oracle_grads(x, layers, acts, skip_at, dy, want_dx, quant=True):
     (90, [256] * 8 + [1], ['relu'] * 8 + ['sigmoid'], [4], 3333),
     (27, [40, 200, 33], ['relu', 'softplus', None], [0, 1], 64),
     (128, [256], ['relu'], None, 1), (283, [128, 3], ['relu', None], None, 200),
-    (39, [128, 128, 128, 1], ['relu'] * 3 + ['sigmoid'], [1], 20000)])
+    (39, [128, 128, 128, 1], ['relu'] * 3 + ['sigmoid'], [1], 20000),
+    (63, [512, 320, 512, 2], ['relu'] * 3 + [None], [1], 500), (539, [256, 3], ['relu', 'sigmoid'], None, 150)])
 @pytest.mark.parametrize("prec", ['bf16', 'fp32', 'fp32_native'])
 def test_generic_mlp_backward_vs_oracle(nfx_lib, cuda, d_in, widths, acts, skip_at, n, prec):
     """nfx_mlp_generic_bwd: weight, bias and input gradients of arbitrary mlp.Network shapes against torch.autograd of
