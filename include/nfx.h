@@ -262,6 +262,17 @@ NFX_API int nfx_mlp128_bwd(int in_kind, const float *dev_xyz, const float *dev_x
                    int out_dim, int out_act, float post_scale, const float *dev_dout,
                    void *dev_workspace, size_t workspace_bytes, float *const dev_dkernels[5],
                    float *const dev_dbiases[5], int prec, void *stream);
+/* The same for up to NFX_MLP128_MAX_HEADS networks over the SAME rows in ONE launch pair and reduction (round 5): the three xyz
+ * heads of a NeRFactor step (nerfactor.py:377-411: normal, albedo, BRDF code; 2048 rows each at 1024 rays) are 16 workgroups per
+ * launch on their own.  Head i: dev_blobs[i], out_dims[i], out_acts[i], post_scales[i], dev_douts[i]; gradients accumulated into
+ * dev_dkernels[5 i .. 5 i + 5) / dev_dbiases[5 i ..) — no buffer may belong to two heads.  Workspace: n_heads x
+ * nfx_mlp128_bwd_workspace_bytes().  Bit-identical to n_heads calls of nfx_mlp128_bwd.                                   */
+#define NFX_MLP128_MAX_HEADS 4
+NFX_API int nfx_mlp128_bwd_heads(int in_kind, const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
+                                 const float *dev_lxyz, int n_lights, int n_heads, const void *const *dev_blobs,
+                                 const int *out_dims, const int *out_acts, const float *post_scales,
+                                 const float *const *dev_douts, void *dev_workspace, size_t workspace_bytes,
+                                 float *const *dev_dkernels, float *const *dev_dbiases, int prec, void *stream);
 
 /* Backward of nfx_composite_fwd w.r.t. the raw network outputs (nerf.py:184-254): given dev_d_rgb [n_rays, 3] =
  * dLoss/d rgb (the composited, background-blended colour), writes dev_d_rgbs [n_rays, S, 4] = dLoss/d rgbs

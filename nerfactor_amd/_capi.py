@@ -62,6 +62,7 @@ SIGNATURES = {
     'nfx_mlp128_pack_train_weights': (_i, [_pp, _pp, _i, _i, _i, _p, _sz]),
     'nfx_mlp128_bwd_workspace_bytes': (_sz, [_i, _i64, _i]),
     'nfx_mlp128_bwd': (_i, [_i, _p, _p, _i64, _f, _p, _i, _p, _i, _i, _f, _p, _p, _sz, _pp, _pp, _i, _p]),
+    'nfx_mlp128_bwd_heads': (_i, [_i, _p, _p, _i64, _f, _p, _i, _i, _pp, _p, _p, _p, _pp, _p, _sz, _pp, _pp, _i, _p]),
     'nfx_composite_bwd': (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p]),
     'nfx_nerf_train_packed_bytes': (_sz, [_i]),
     'nfx_nerf_pack_train_weights': (_i, [_pp, _pp, _i, _p, _sz]),

@@ -36,6 +36,34 @@ def _targets(params):
     return bufs, rets
 
 
+# The backward of an xyz head (normal, albedo, BRDF code: 2048 rows of a 1024-ray step) is three launches of 16 workgroups
+# each — 35 us on 6 % of the chip, latency-bound by one 128-row tile per workgroup — and a NeRFactor step has three of them.
+# Nothing in the autograd graph waits for them (no input gradient; the parameter gradients are accumulated in place, _targets),
+# so a head's backward is only RECORDED here and all recorded heads over the same rows leave as ONE launch pair + reduction
+# (ops.mlp128_bwd_heads, blockIdx.y = head) when autograd's backward pass ends (an engine callback).  Bit-identical to one
+# launch per head; heads that share a gradient buffer (the same network evaluated twice) go to separate launches.
+BATCH_HEADS = True
+_heads = {'pending': [], 'armed': False}
+
+
+def _flush_heads():
+    pending, _heads['pending'], _heads['armed'] = _heads['pending'], [], False
+    while pending:
+        first = pending[0]
+        group, rest, bufs = [], [], set()
+        for h in pending:
+            same = h['xyz'] is first['xyz'] and h['xyz_scale'] == first['xyz_scale']
+            ptr = h['dks'][0].data_ptr()
+            if same and ptr not in bufs and len(group) < ops.MLP128_MAX_HEADS:
+                group.append(h)
+                bufs.add(ptr)
+            else:
+                rest.append(h)
+        ops.mlp128_bwd_heads(_capi.IN_XYZ, first['xyz'], [(h['dout'], h['blob'], h['dks'], h['dbs'], h['out_act'], h['post_scale'])
+                                                          for h in group], xyz_scale=first['xyz_scale'], prec=GRAD_PREC)
+        pending = rest
+
+
 class Mlp128Xyz(torch.autograd.Function):
     """out = post_scale * act(out(mlp(posenc10(xyz_scale * xyz)))) + post_bias."""
 
@@ -53,8 +81,15 @@ class Mlp128Xyz(torch.autograd.Function):
         train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, params = ctx.cfg
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
-        ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
-                       xyz_scale=xyz_scale, post_scale=post_scale, prec=GRAD_PREC)
+        if BATCH_HEADS and all(r is None for r in rks + rbs):      # (every gradient accumulated in place: nothing to hand back)
+            _heads['pending'].append(dict(xyz=xyz, dout=dout.contiguous(), blob=train_blob_fn(), dks=dks, dbs=dbs, out_act=out_act,
+                                          xyz_scale=xyz_scale, post_scale=post_scale))
+            if not _heads['armed']:
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_heads)
+                _heads['armed'] = True
+        else:
+            ops.mlp128_bwd(_capi.IN_XYZ, xyz, dout.contiguous(), train_blob_fn(), dks, dbs, out_act=out_act,
+                           xyz_scale=xyz_scale, post_scale=post_scale, prec=GRAD_PREC)
         return (None,) * 9 + tuple(rks) + tuple(rbs)
 
 

@@ -23,8 +23,9 @@ extern "C" int nfx_option_int(const char* name, int dflt);
 extern "C" {
 int nfx_launch_mlp128_bwd(int, const float*, const float*, long long, float, const float*, int, const void*, int,
                           int, float, const float*, void*, long long, int, hipStream_t);
-int nfx_launch_mlp128_bwd_fused(int, const float*, const float*, long long, float, const float*, int, const void*, int, int,
-                                float, const float*, float*, int, float* const*, float* const*, hipStream_t);
+int nfx_launch_mlp128_bwd_fused(int, const float*, const float*, long long, float, const float*, int, int, const void* const*,
+                                const int*, const int*, const float*, const float* const*, float*, int, float* const*,
+                                float* const*, hipStream_t);
 size_t nfx_mlp128_fused_partial_floats(int in_kind, int grid);
 int nfx_mlp128_fused_grid(int in_kind, long long n, int n_lights, int max_blocks);
 int nfx_mlp128_train_feats(int in_kind);
@@ -153,8 +154,8 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (fused_wgrad()) {
         const int grid = nfx_mlp128_fused_grid(in_kind, n, n_lights, nfx_option_int("m128_blocks", 256));
-        return nfx_hip_result(nfx_launch_mlp128_bwd_fused(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights,
-                                                          blob, out_dim, out_act, post_scale, dout,
+        return nfx_hip_result(nfx_launch_mlp128_bwd_fused(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights, 1,
+                                                          &blob, &out_dim, &out_act, &post_scale, &dout,
                                                           static_cast<float*>(workspace), grid, dkernels, dbiases, st),
                               "mlp128_bwd(fused)");
     }
@@ -182,6 +183,49 @@ int nfx_mlp128_bwd(int in_kind, const float* xyz, const float* xyz_dir, int64_t 
     };
     void* partial = static_cast<char*>(workspace) + mlp128_feat_bytes(in_kind, n, n_lights);
     return nfx_hip_result(nfx_launch_wgrad_batch(calls, 6, ld, rows16, partial, st), "wgrad");
+}
+
+// Up to NFX_MLP128_MAX_HEADS networks over the SAME rows in one launch pair (+ one reduction): the three xyz heads of a
+// NeRFactor step.  Head i: blob dev_blobs[i], dout dev_douts[i], gradients dev_dkernels[5 i .. 5 i + 5) / dev_dbiases[...].
+int nfx_mlp128_bwd_heads(int in_kind, const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale, const float* lxyz,
+                         int n_lights, int n_heads, const void* const* blobs, const int* out_dims, const int* out_acts,
+                         const float* post_scales, const float* const* douts, void* workspace, size_t workspace_bytes,
+                         float* const* dkernels, float* const* dbiases, int prec, void* stream) {
+    REQUIRE(n_heads >= 1 && n_heads <= NFX_MLP128_MAX_HEADS, "nfx_mlp128_bwd_heads: 1 .. %d heads", NFX_MLP128_MAX_HEADS);
+    REQUIRE(blobs && out_dims && out_acts && post_scales && douts && dkernels && dbiases, "nfx_mlp128_bwd_heads: null table");
+    const size_t per_head = nfx_mlp128_bwd_workspace_bytes(in_kind, n, n_lights);
+    if (n_heads == 1 || !fused_wgrad()) {        // (the unfused identity path has no multi-head form: head after head)
+        for (int i = 0; i < n_heads; ++i) {
+            const int rc = nfx_mlp128_bwd(in_kind, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blobs[i], out_dims[i], out_acts[i],
+                                          post_scales[i], douts[i], workspace, workspace_bytes, dkernels + 5 * i, dbiases + 5 * i,
+                                          prec, stream);
+            if (rc) return rc;
+        }
+        return NFX_OK;
+    }
+    REQUIRE(kind_ok(in_kind), "nfx_mlp128_bwd_heads: in_kind %d has no backward", in_kind);
+    REQUIRE(n >= 0, "nfx_mlp128_bwd_heads: n < 0");
+    if (prec != NFX_PREC_BF16) return nfx_fail(NFX_ENOSUP, "nfx_mlp128_bwd_heads: only bf16 is built");
+    if (in_kind == NFX_IN_XYZ_LDIR) REQUIRE(n_lights > 0 && lxyz, "nfx_mlp128_bwd_heads: light positions required for NFX_IN_XYZ_LDIR");
+    if (n == 0) return NFX_OK;
+    REQUIRE(xyz && workspace, "nfx_mlp128_bwd_heads: null pointer");
+    for (int i = 0; i < n_heads; ++i) {
+        REQUIRE(out_dims[i] >= 1 && out_dims[i] <= 8 && out_acts[i] >= 0 && out_acts[i] <= 3, "nfx_mlp128_bwd_heads: head %d: bad out_dim/act", i);
+        REQUIRE(blobs[i] && douts[i], "nfx_mlp128_bwd_heads: head %d: null pointer", i);
+        if (!ALIGNED(blobs[i], 16)) return nfx_fail(NFX_EALIGN, "nfx_mlp128_bwd_heads: blob %d must be 16-byte aligned", i);
+        for (int j = 0; j < 5; ++j) {
+            REQUIRE(dkernels[5 * i + j] && dbiases[5 * i + j], "nfx_mlp128_bwd_heads: head %d: gradient buffer %d null", i, j);
+            for (int k = 0; k < i; ++k)          // two heads adding into one buffer would race in the reduction
+                REQUIRE(dkernels[5 * k + j] != dkernels[5 * i + j], "nfx_mlp128_bwd_heads: heads %d and %d share a gradient buffer", k, i);
+        }
+    }
+    REQUIRE(workspace_bytes >= per_head * n_heads, "nfx_mlp128_bwd_heads: workspace too small (%zu < %zu)", workspace_bytes, per_head * n_heads);
+    if (!ALIGNED(workspace, 16)) return nfx_fail(NFX_EALIGN, "nfx_mlp128_bwd_heads: workspace must be 16-byte aligned");
+    const int grid = nfx_mlp128_fused_grid(in_kind, n, n_lights, nfx_option_int("m128_blocks", 256));
+    return nfx_hip_result(nfx_launch_mlp128_bwd_fused(in_kind, xyz, xyz_dir ? xyz_dir : xyz, n, xyz_scale, lxyz, n_lights, n_heads,
+                                                      blobs, out_dims, out_acts, post_scales, douts, static_cast<float*>(workspace),
+                                                      grid, dkernels, dbiases, (hipStream_t)stream),
+                          "mlp128_bwd_heads");
 }
 
 // ------------------------------------------------------------------------------------ NeRF MLP backward

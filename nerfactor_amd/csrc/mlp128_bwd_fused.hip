@@ -384,12 +384,28 @@ __device__ __forceinline__ void wgrad(const char* a, const int (&alo)[NO], const
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Up to kMaxHeads networks over the SAME input rows in one launch (blockIdx.y = head; round 5): the three xyz heads of a
+// NeRFactor step — normal, albedo, BRDF code, 2048 rows each — are 16 workgroups per launch on their own, three launches per
+// head back to back; as heads of one launch they fill 48 CUs for the time of one.
+constexpr int kMaxHeads = 4;
+struct HeadArgs {
+    const char* blob[kMaxHeads];
+    const float* dout[kMaxHeads];
+    float* partial[kMaxHeads];
+    int out_dim[kMaxHeads], out_act[kMaxHeads];
+    float post_scale[kMaxHeads];
+};
 // IN_KIND 0: posenc10(xyz_scale*xyz) ; 1: [posenc10(xyz_scale*xyz), posenc4(normalize(lxyz_l - xyz_dir))]
 template <int IN_KIND, int PART>
 __global__ __launch_bounds__(kNW * 64, 1) void mlp128_bwd_fused_kernel(
     const float* __restrict__ xyz, const float* __restrict__ xyz_dir, long long n, float xyz_scale,
-    const float* __restrict__ lxyz, int n_lights, const char* __restrict__ blob, int out_dim, int out_act,
-    float post_scale, const float* __restrict__ dout, float* __restrict__ partial) {
+    const float* __restrict__ lxyz, int n_lights, HeadArgs heads) {
+    const int hd = blockIdx.y;
+    const char* __restrict__ blob = heads.blob[hd];
+    const float* __restrict__ dout = heads.dout[hd];
+    float* __restrict__ partial = heads.partial[hd];
+    const int out_dim = heads.out_dim[hd], out_act = heads.out_act[hd];
+    const float post_scale = heads.post_scale[hd];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSX = IN_KIND == 0 ? 4 : 6;
     using G = Geo<KSX>;
@@ -635,11 +651,15 @@ struct ReduceArgs {
     float* dk[5];
     float* db[5];
 };
+struct ReduceHeads {
+    ReduceArgs h[kMaxHeads];     // blockIdx.y = head
+};
 // One WAVE-QUARTET per 64 accumulator elements (part, wave, block, register, lanes 0-63): wave q of a workgroup sums
 // the workgroups [q n/4, (q+1) n/4) of its 64 elements, the four partial sums are added in wave order through LDS
 // (fixed order: deterministic), and the total is added to the gradient element it stands for.
 template <int KSX>
-__global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceArgs a) {
+__global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceHeads heads) {
+    const ReduceArgs& a = heads.h[blockIdx.y];
     constexpr int N0 = Blocks<KSX, 0>::N, N1 = Blocks<KSX, 1>::N, NX = KSX / 2;
     using B0 = Blocks<KSX, 0>;
     using B1 = Blocks<KSX, 1>;
@@ -700,34 +720,44 @@ __global__ __launch_bounds__(256) void mlp128_wgrad_reduce_kernel(ReduceArgs a) 
 
 template <int IN_KIND>
 static int launch_fused(const float* xyz, const float* xyz_dir, long long n, float xyz_scale, const float* lxyz, int n_lights,
-                        const void* blob, int out_dim, int out_act, float post_scale, const float* dout, float* partial,
-                        int grid, float* const dk[5], float* const db[5], hipStream_t st) {
+                        int n_heads, const void* const* blobs, const int* out_dims, const int* out_acts, const float* post_scales,
+                        const float* const* douts, float* partial, int grid, float* const* dk, float* const* db, hipStream_t st) {
     using namespace nfx::bwd::fused;
     constexpr int KSX = IN_KIND == 0 ? 4 : 6;
     constexpr int lds = Lds<KSX>::kTotal;
-    float* part1 = partial + (size_t)grid * kNW * Blocks<KSX, 0>::N * 1024;
+    const size_t floats0 = (size_t)grid * kNW * Blocks<KSX, 0>::N * 1024, floats1 = (size_t)grid * kNW * Blocks<KSX, 1>::N * 1024;
     auto k0 = mlp128_bwd_fused_kernel<IN_KIND, 0>;
     auto k1 = mlp128_bwd_fused_kernel<IN_KIND, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k0, dim3(grid), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights,
-                       (const char*)blob, out_dim, out_act, post_scale, dout, partial);
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights,
-                       (const char*)blob, out_dim, out_act, post_scale, dout, part1);
-    ReduceArgs ra;
-    ra.part[0] = partial;
-    ra.part[1] = part1;
-    ra.n_wg = grid;
-    ra.out_dim = out_dim;
-    ra.in_dims = IN_KIND == 0 ? 63 : 90;
-    for (int i = 0; i < 5; ++i) {
-        ra.dk[i] = dk[i];
-        ra.db[i] = db[i];
+    HeadArgs h0 = {}, h1 = {};
+    ReduceHeads rh = {};
+    for (int i = 0; i < n_heads; ++i) {       // head i's slice of the workspace: [PART 0 partials | PART 1 partials]
+        float* p0 = partial + (size_t)i * (floats0 + floats1);
+        h0.blob[i] = h1.blob[i] = static_cast<const char*>(blobs[i]);
+        h0.dout[i] = h1.dout[i] = douts[i];
+        h0.out_dim[i] = h1.out_dim[i] = out_dims[i];
+        h0.out_act[i] = h1.out_act[i] = out_acts[i];
+        h0.post_scale[i] = h1.post_scale[i] = post_scales[i];
+        h0.partial[i] = p0;
+        h1.partial[i] = p0 + floats0;
+        ReduceArgs& ra = rh.h[i];
+        ra.part[0] = p0;
+        ra.part[1] = p0 + floats0;
+        ra.n_wg = grid;
+        ra.out_dim = out_dims[i];
+        ra.in_dims = IN_KIND == 0 ? 63 : 90;
+        for (int j = 0; j < 5; ++j) {
+            ra.dk[j] = dk[5 * i + j];
+            ra.db[j] = db[5 * i + j];
+        }
     }
+    hipLaunchKernelGGL(k0, dim3(grid, n_heads), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, h0);
+    hipLaunchKernelGGL(k1, dim3(grid, n_heads), dim3(kNW * 64), lds, st, xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, h1);
     const int elems = kNW * (Blocks<KSX, 0>::N + Blocks<KSX, 1>::N) * 1024;
-    hipLaunchKernelGGL(mlp128_wgrad_reduce_kernel<KSX>, dim3(elems / 64), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(mlp128_wgrad_reduce_kernel<KSX>, dim3(elems / 64, n_heads), dim3(256), 0, st, rh);
     return (int)hipGetLastError();
 }
 
@@ -744,16 +774,18 @@ int nfx_mlp128_fused_grid(int in_kind, long long n, int n_lights, int max_blocks
     return (int)(tiles < max_blocks ? tiles : max_blocks);
 }
 
-// Fused backward + weight gradients of one width-128 network call: two kernel launches (the layers split over them)
-// and one ordered reduction into dkernels / dbiases (accumulated into, like nfx_launch_wgrad_batch).
+// Fused backward + weight gradients of n_heads (<= kMaxHeads) width-128 networks over the same input rows: two kernel
+// launches (the layers split over them) and one ordered reduction into dkernels / dbiases (accumulated into, like
+// nfx_launch_wgrad_batch).  dk / db: 5 pointers per head; `partial`: n_heads x nfx_mlp128_fused_partial_floats floats.
 int nfx_launch_mlp128_bwd_fused(int in_kind, const float* xyz, const float* xyz_dir, long long n, float xyz_scale,
-                                const float* lxyz, int n_lights, const void* blob, int out_dim, int out_act,
-                                float post_scale, const float* dout, float* partial, int grid, float* const dk[5],
-                                float* const db[5], hipStream_t st) {
-    if (n <= 0) return 0;
-    return in_kind == 0 ? launch_fused<0>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blob, out_dim, out_act, post_scale, dout,
-                                          partial, grid, dk, db, st)
-                        : launch_fused<1>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blob, out_dim, out_act, post_scale, dout,
-                                          partial, grid, dk, db, st);
+                                const float* lxyz, int n_lights, int n_heads, const void* const* blobs, const int* out_dims,
+                                const int* out_acts, const float* post_scales, const float* const* douts, float* partial,
+                                int grid, float* const* dk, float* const* db, hipStream_t st) {
+    if (n <= 0 || n_heads <= 0) return 0;
+    if (n_heads > nfx::bwd::fused::kMaxHeads) return (int)hipErrorInvalidValue;
+    return in_kind == 0 ? launch_fused<0>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, n_heads, blobs, out_dims, out_acts,
+                                          post_scales, douts, partial, grid, dk, db, st)
+                        : launch_fused<1>(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, n_heads, blobs, out_dims, out_acts,
+                                          post_scales, douts, partial, grid, dk, db, st);
 }
 }

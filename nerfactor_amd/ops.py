@@ -706,6 +706,44 @@ def mlp128_bwd(in_kind, xyz, dout, blob, dkernels, dbiases, out_act=None, xyz_sc
 
 
 
+MLP128_MAX_HEADS = 4
+
+
+def mlp128_bwd_heads(in_kind, xyz, heads, xyz_scale=1., lxyz=None, xyz_dir=None, prec='bf16'):
+    """mlp128_bwd for up to MLP128_MAX_HEADS networks over the SAME rows in one launch pair (nfx_mlp128_bwd_heads).
+    heads: [(dout, train_blob, dkernels, dbiases, out_act, post_scale), ...]; bit-identical to one mlp128_bwd per head."""
+    if not 1 <= len(heads) <= MLP128_MAX_HEADS:
+        raise _capi.NfxError("mlp128_bwd_heads: 1 .. %d heads" % MLP128_MAX_HEADS)
+    xyz = _dev(xyz, 'xyz', (None, 3))
+    n = xyz.shape[0]
+    nl = 0
+    if in_kind == _capi.IN_XYZ_LDIR:
+        lxyz = _dev(lxyz, 'lxyz', (None, 3))
+        nl = lxyz.shape[0]
+    rows = n if in_kind == _capi.IN_XYZ else n * nl
+    xyz_dir = _dev(xyz_dir, 'xyz_dir', (n, 3))
+    douts, keep = [], []
+    for dout, blob, dks, dbs, _, _ in heads:
+        douts.append(_dev(dout.reshape(rows, -1), 'dout', (rows, None)))
+        for t in list(dks) + list(dbs):
+            _dev(t, 'gradient buffer')
+        if len(dks) != 5 or len(dbs) != 5:
+            raise _capi.NfxError("mlp128_bwd_heads: 5 kernel and 5 bias gradient buffers per head")
+    nh = len(heads)
+    ws_bytes = lib.nfx_mlp128_bwd_workspace_bytes(in_kind, n, nl) * nh
+    ws = torch.empty((max(ws_bytes, 16) // 2,), dtype=torch.bfloat16, device=xyz.device)
+    blobs = (ctypes.c_void_p * nh)(*[h[1].data_ptr() for h in heads])
+    darr = (ctypes.c_void_p * nh)(*[d.data_ptr() for d in douts])
+    dims = (ctypes.c_int * nh)(*[d.shape[1] for d in douts])
+    acts = (ctypes.c_int * nh)(*[_ACT[h[4]] for h in heads])
+    scales = (ctypes.c_float * nh)(*[float(h[5]) for h in heads])
+    karr = (ctypes.c_void_p * (5 * nh))(*[t.data_ptr() for h in heads for t in h[2]])
+    barr = (ctypes.c_void_p * (5 * nh))(*[t.data_ptr() for h in heads for t in h[3]])
+    check(lib.nfx_mlp128_bwd_heads(in_kind, _ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, nh, blobs, dims, acts, scales,
+                                   darr, _ptr(ws), ws.numel() * 2, karr, barr, _PREC[prec], _stream()), 'nfx_mlp128_bwd_heads')
+    return ws
+
+
 # ------------------------------------------------------------------------------ NeRF training ops
 def pack_nerf_train_weights(kernels, biases, prec='bf16'):
     """Train blob (forward + dgrad fragments) of one NeRF network, for nerf_mlp_bwd."""

@@ -137,6 +137,69 @@ def test_lvis_backward_vs_autograd(nfx_lib, cuda, nfx_opt, path, n):
         _check_grads(dbs, [b.grad for b in bs], 'dbias', tol)
 
 
+def test_heads_of_one_launch_equal_one_launch_per_head(nfx_lib, cuda, nfx_opt):
+    """nfx_mlp128_bwd_heads (round 5: the three xyz heads of a NeRFactor step in ONE launch pair + reduction, blockIdx.y =
+    head) against nfx_mlp128_bwd per head: the same bits in every gradient tensor, for a persistent grid smaller than the
+    tile count too; gradient buffers shared between heads are refused; autograd's deferred form (autograd.Mlp128Xyz records
+    the heads, an engine callback launches them together) gives the same parameter gradients as the immediate one."""
+    from nerfactor_amd import autograd, ops
+    rng, _, _, xyz, _, _ = scene(700, 96)
+    outs = [(3, None, 1.0), (3, 'sigmoid', 0.7), (1, 'softplus', 1.0), (3, 'sigmoid', 1.0)]
+    nets = []
+    for seed, (od, act, scale) in enumerate(outs):
+        layers, out = net128(40 + seed, 63, od)
+        ks = [k for k, _ in layers] + [out[0][0]]
+        bs = [b for _, b in layers] + [out[0][1]]
+        nets.append((ks, bs, ops.pack_mlp128_train_weights(ks, bs, nfx_lib.IN_XYZ, od).to(cuda),
+                     dev(rng.normal(size=(700, od)), cuda), act, scale))
+    x = dev(xyz, cuda)
+
+    def zeros(ks, bs):
+        return [torch.zeros(k.shape, device=cuda) for k in ks], [torch.zeros(b.shape, device=cuda) for b in bs]
+    for blocks in (None, 3):
+        if blocks:
+            nfx_opt.set("m128_blocks", blocks)
+        else:
+            nfx_opt.unset("m128_blocks")
+        want, heads, got = [], [], []
+        for ks, bs, blob, dout, act, scale in nets:
+            dks, dbs = zeros(ks, bs)
+            ops.mlp128_bwd(nfx_lib.IN_XYZ, x, dout, blob, dks, dbs, out_act=act, xyz_scale=0.9, post_scale=scale)
+            want.append(dks + dbs)
+            dks, dbs = zeros(ks, bs)
+            heads.append((dout, blob, dks, dbs, act, scale))
+            got.append(dks + dbs)
+        ops.mlp128_bwd_heads(nfx_lib.IN_XYZ, x, heads, xyz_scale=0.9)
+        for h, (g, w) in enumerate(zip(got, want)):
+            assert all(torch.equal(a, b) for a, b in zip(g, w)) and float(g[0].abs().sum()) > 0, (blocks, h)
+    nfx_opt.unset("m128_blocks")
+    with pytest.raises(Exception, match='share a gradient buffer'):
+        ops.mlp128_bwd_heads(nfx_lib.IN_XYZ, x, [heads[0], heads[0]], xyz_scale=0.9)
+    with pytest.raises(Exception, match='heads'):
+        ops.mlp128_bwd_heads(nfx_lib.IN_XYZ, x, heads + heads[:1], xyz_scale=0.9)
+
+    # autograd: parameters that own their gradient buffers (as under optim.AMSGrad) -> deferred, batched; else immediate
+    def grads(batch):
+        autograd.BATCH_HEADS = batch
+        try:
+            params, loss = [], 0.
+            for ks, bs, blob, dout, act, scale in nets[:3]:
+                P = [torch.nn.Parameter(dev(k, cuda)) for k in ks] + [torch.nn.Parameter(dev(b, cuda)) for b in bs]
+                for q in P:
+                    q.grad = torch.zeros_like(q)
+                fwd = ops.pack_mlp128_weights(ks, bs, nfx_lib.IN_XYZ, dout.shape[1]).to(cuda)
+                y = autograd.Mlp128Xyz.apply(x, fwd, lambda blob=blob: blob, 'bf16', dout.shape[1], act, 0.9, scale, 0., *P)
+                loss = loss + (y * dout).sum()
+                params.append(P)
+            loss.backward()
+            assert not autograd._heads['pending'] and not autograd._heads['armed']
+            return [q.grad.clone() for P in params for q in P]
+        finally:
+            autograd.BATCH_HEADS = True
+    a, b = grads(True), grads(False)
+    assert all(torch.equal(u, v) for u, v in zip(a, b)) and float(a[0].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("in_kind,n", [("xyz", 1500), ("lvis", 37)])
 def test_fused_weight_gradients_match_the_gemm_path(nfx_lib, cuda, nfx_opt, in_kind, n):
     """Same bf16 products, fp32 sums in a different order: the fused kernels (slot-permuted accumulators, two launches,
