@@ -42,7 +42,8 @@ def _targets(params):
 # so a head's backward is only RECORDED here and all recorded heads over the same rows leave as ONE launch pair + reduction
 # (ops.mlp128_bwd_heads, blockIdx.y = head) when autograd's backward pass ends (an engine callback).  Bit-identical to one
 # launch per head; heads that share a gradient buffer (the same network evaluated twice) go to separate launches.
-BATCH_HEADS = True
+import os as _os
+BATCH_HEADS = _os.environ.get('NFX_BATCH_HEADS', '1') != '0'      # (A / B switch of the plugin, not of libnfx)
 _heads = {'pending': [], 'armed': False}
 
 
