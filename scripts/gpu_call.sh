@@ -2,7 +2,10 @@
 # One GPU-box call (via gpurun): runs the stages named on the command line, everything worth keeping goes to gpurun_out/<tag>/.
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
 # stages: pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
-#         soak | soak-xp | soak-xp2 | sigma | fitted | generic | prof | train-prof | pmc | pmc-train | bench-legs (LEGS=..., LEGS_TAG=...)
+#         bench-train-fp32 | soak | sigma | fitted | generic | prof | train-prof | train-prof-fp32 | pmc | pmc-train | pmc-sq2 |
+#         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair
+#   A / B stages (experiment builds: NFX_EXTRA_DEFS=... python -m nerfactor_amd.build --out nerfactor_amd/libnfx_xpX.so):
+#         fused-ab (AB_LIBS=...) | ring-ab (RING_LIBS=...) | generic-ab | splits-ab | generic-prof | generic-pmc
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
