@@ -73,6 +73,10 @@ class Mlp128Xyz(torch.autograd.Function):
                 *params):
         ctx.save_for_backward(xyz)
         ctx.cfg = (train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, params)
+        if _heads['pending'] or _heads['armed']:
+            # heads recorded by a backward pass that never reached its end (an exception inside autograd: the engine runs no
+            # callback then) must not leak into the next one
+            _heads['pending'], _heads['armed'] = [], False
         return ops.mlp128_xyz_fwd(xyz, fwd_blob, out_dim, out_act=out_act, xyz_scale=xyz_scale,
                                   post_scale=post_scale, post_bias=post_bias, prec=prec)
 
