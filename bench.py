@@ -166,6 +166,7 @@ def nerf_cpu_reference(nets, rayo, rayd, budget_s, timed_run=True):
 
 
 _LIVE_TRAFFIC = {}     # legs -> digest of a counter run of THIS command (measure_traffic)
+MEASURE_TRAFFIC = False     # --measure-traffic: spawn the two rocprofv3 counter children (off by default: ~50 s of a driver-timed run)
 
 
 def measure_traffic(legs, extra=()):
@@ -182,6 +183,8 @@ def measure_traffic(legs, extra=()):
     if key in _LIVE_TRAFFIC:
         return _LIVE_TRAFFIC[key]
     _LIVE_TRAFFIC[key] = {}
+    if not MEASURE_TRAFFIC:
+        return {}
     if (os.environ.get('NFX_BENCH_CHILD') or os.environ.get('NFX_BENCH_NO_PMC') or not shutil.which('rocprofv3')
             or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)):
         return {}
@@ -317,6 +320,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
             "psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()),
             "max_abs_all_rays": float(err.max()), "rays_compared": int(len(sel)),
             "rays_excluded_from_max_abs": 0, "frac_rays_above_3e-2": float((err > 3e-2).mean()),
+            "rays_above_3e-2": int((err > 3e-2).sum()),
             "rays_with_abs_sigma_last_below_0.06": int((sig <= 0.06).sum()),
             "last_sample": "bf16 (no refine)" if refine is None else "fp32-class density (ops.nerf_refine_last_sample)",
             "reference": "oracle/torch_ref.py (fp32) on the same rays; tolerance PSNR >= 40 dB, max-abs <= 3e-2"}
@@ -642,8 +646,8 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     # ~170 launches and sits at the host's issue time (2.2-2.8 ms depending on the box's CPU), whatever its kernels
     # take: the replay is what shows the GPU time.  N > 1 ranks keep the eager step (the all-reduce is not captured).
     graph_dt, graph_note = None, None
-    if world == 1 and not args.no_hip_graph:      # (NeRF too since r05: torch's generator hands a replay the stratified draws of an eager step)
-        gstep = optim.GraphedTrainStep(model, opt, global_bs)
+    if (world == 1 or os.environ.get('NFX_GRAPH_COLLECTIVE') == '1') and not args.no_hip_graph:      # (NeRF too since r05: torch's generator hands a replay the stratified draws of an eager step)
+        gstep = optim.GraphedTrainStep(model, opt, global_bs, capture_collective=(True if world == 1 else None))
         glosses = []
 
         def gs(k):
@@ -718,15 +722,21 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
             m32.flush_numerics(block=True)
             return dt32 * 1e3
         default_mode = get_model_class(name).DEFAULT_FP32_MATRIX      # pairs for the surface models, native for NeRF
-        ms32 = {"pairs_eager": time_fp32('pairs', False), "native_eager": time_fp32('native', False)}
-        # (tests/test_gpu_convergence.py: the floor of bf16 training comes from the bf16 FORWARD; fp32-class forward kernels with
-        #  the bf16-operand backward kernels — precision = fp32, grad_precision = bf16 — recover most of it)
-        ms32["fp32_forward_bf16_grads_eager"] = time_fp32('pairs', False, grad_precision='bf16')
-        if not args.no_hip_graph:
+        graph32 = not args.no_hip_graph and default_mode == 'pairs'
+        ms32 = {}
+        if graph32:
             try:
                 ms32["pairs_hip_graph"] = time_fp32('pairs', True)
             except Exception as e:      # (a capture failure must not take the whole line down)
                 ms32["pairs_hip_graph_error"] = str(e)[:200]
+        if not any(isinstance(v, float) for v in ms32.values()):
+            ms32[default_mode + "_eager"] = time_fp32(default_mode, False)
+        if args.fp32_modes:             # every matrix mode beside the default one (--fp32-modes: ~8 s per model)
+            for mode in ('pairs', 'native'):
+                ms32.setdefault(mode + "_eager", time_fp32(mode, False))
+            # (tests/test_gpu_convergence.py: the floor of bf16 training comes from the bf16 FORWARD; fp32-class forward kernels with
+            #  the bf16-operand backward kernels — precision = fp32, grad_precision = bf16 — recover most of it)
+            ms32["fp32_forward_bf16_grads_eager"] = time_fp32('pairs', False, grad_precision='bf16')
         tag, rmodel, rlosses, rgrad1 = reference_steps.run(name, dev, 'fp32')
         p32 = reference_steps.metrics_fp32(tag, rmodel, rlosses, rgrad1)
         p32.pop('grads')
@@ -747,7 +757,8 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         "ms_per_step_eager": dt_eager * 1e3,
         "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
         "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
-            torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if world > 1 else "none (one rank)",
+            torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if (world > 1 or nfx_dist.run_collectives_on_one_rank())
+        else "none (one rank, no process group)",
         "roofline": {"bound": "mfma", "kernel": "whole step; largest backward call = ops.%s (fused backward + batched "
                                                 "weight-gradient launches)" % dom,
                      "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
@@ -872,23 +883,29 @@ def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm,
     t_dn = time.perf_counter() - t0
     g_occu, g_depth, g_normal = occu[idx].cpu().numpy(), depth[idx].cpu().numpy(), normal[idx].cpu().numpy()
     hit = r_occu > 0.5
-    cos = (g_normal[hit] * r_normal[hit]).sum(1) / np.maximum(np.linalg.norm(g_normal[hit], axis=1) * np.linalg.norm(r_normal[hit], axis=1), 1e-12)
+    # the tests' terms (tests/test_gpu_reference_golden.py): the normal error as a VECTOR (the expected normal sum_i w_i n_i of a
+    # fitted field is short, |n| 0.01-0.25, so a cosine between two such vectors says nothing), depth against the near-far range
+    err_n = np.abs(g_normal - r_normal).max(1)
+    z_range = 6. - 2.
     sp, sn = surf[:n_pts].cpu().numpy(), nrm[:n_pts].cpu().numpy()
     t0 = time.perf_counter()
     r_lvis = GR.compute_light_visibility(sp, sn, lxyz.reshape(-1, 3).astype(np.float32), nets[0], nets[1])
     t_lv = time.perf_counter() - t0
     g_lvis = lvis[:n_pts].cpu().numpy()
     pairs = int((r_lvis > 0).sum() + ((r_lvis == 0) & (g_lvis > 0)).sum())
+    depth_err = float(np.abs(g_depth - r_depth)[hit].max()) if hit.any() else None
     return {
         "cpu_baseline": {"kind": "port", "cores": host_cores(), "unit": "rays/s (depth + normal) | pairs/s (light visibility)",
                          "value": len(idx) / t_dn, "light_visibility_pairs_per_s": max(pairs, 1) / t_lv,
                          "sample": "oracle/geometry_ref.py on %d rays of the view (%.1f s) and %d surface points x 512 lights (%.1f s)" % (
                              len(idx), t_dn, n_pts, t_lv)},
         "parity": {"rays_compared": int(len(idx)), "occu_max_abs": float(np.abs(g_occu - r_occu).max()),
-                   "depth_max_abs_on_hits": float(np.abs(g_depth - r_depth)[hit].max()) if hit.any() else None,
-                   "normal_cos_min_on_hits": float(cos.min()) if hit.any() else None,
-                   "normal_cos_median_on_hits": float(np.median(cos)) if hit.any() else None,
+                   "depth_max_abs_on_hits": depth_err,
+                   "depth_rel_of_range": None if depth_err is None else depth_err / z_range,
+                   "normal_vec_max_abs": float(err_n.max()), "rays_above_8e-2": int((err_n > 8e-2).sum()),
                    "lvis_points_compared": int(n_pts), "lvis_max_abs": float(np.abs(g_lvis - r_lvis).max()),
+                   "tolerance": "occupancy 3e-2, depth 4 % of the near-far range, normal 8e-2 as a vector, visibility 4e-2 "
+                                "(tests/test_gpu_reference_golden.py)",
                    "reference": "oracle/geometry_ref.py (fp32 / float64 autograd) on the same rays and points"}}
 
 
@@ -1042,8 +1059,200 @@ def nerf_fp32_class_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the line
+LINE_MAX_BYTES = 6144          # the driver reads ONE line; r05's 20.7 KB line (with an `Infinity` in it) came back `parsed: null`
+DETAIL_NAME = 'bench_detail.json'
+
+
+def strict(x):
+    """`x` as strict JSON data: NumPy scalars / arrays -> Python, non-finite floats -> None (json.dumps(allow_nan=False)
+    would raise on them; `Infinity` / `NaN` are not JSON)."""
+    if isinstance(x, dict):
+        return {str(k): strict(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [strict(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return strict(x.tolist())
+    if isinstance(x, (np.bool_, bool)):
+        return bool(x)
+    if isinstance(x, (np.integer, int)):
+        return int(x)
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return x if np.isfinite(x) else None
+    if x is None or isinstance(x, str):
+        return x
+    return str(x)
+
+
+def _sig(x, n=6):
+    """Floats of the line rounded to n significant digits (the detail file keeps every digit)."""
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_sig(v, n) for v in x]
+    if isinstance(x, float) and x != 0:
+        return float('%.*g' % (n, x))
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _parity_block(p, tol_key, count_key, n_key):
+    """psnr / max-abs / how many were compared / how many are above the stated tolerance.  An identical frame has an
+    infinite PSNR: `psnr_db: null, identical: true`."""
+    if not isinstance(p, dict):
+        return None
+    out = {"psnr_db": p.get("psnr_db"), "max_abs": p.get("max_abs", p.get("max_abs_all_rays")),
+           n_key: p.get(n_key), tol_key: p.get(count_key)}
+    if "psnr_db" in p and (p["psnr_db"] is None or not np.isfinite(p["psnr_db"])):
+        out["psnr_db"], out["identical"] = None, True
+    return out
+
+
+def assemble(args_steps, args_warmup, scaling, precision, world, backend, rehearsal, legs):
+    """The full result object (-> bench_detail.json) from the legs' dictionaries.  `legs`: {'nerf': {...} | None,
+    'nerfactor': {name: {...}}, 'train': {name: {...}}, 'olat', 'relight', 'fp32_class', 'geometry', 'wall_s': {...}}."""
+    out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
+           "unit": "rays/s", "n_gpus": world, "steps": args_steps, "warmup": args_warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
+           "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "bf16x3 (fp32-class: hi/lo operand pairs)",
+           "data": "synthetic", "world_size": world, "collective_backend": backend}
+    if rehearsal:
+        out["rehearsal"] = "all ranks share GPU 0 over gloo: a functional check of the N > 1 path, not a measurement"
+    nerf = legs.get('nerf')
+    if nerf is not None:   # (profiling runs may time the NeRFactor legs alone: --legs nerfactor)
+        out.update(nerf)
+        if "parity" in nerf:
+            out["psnr_db"], out["max_abs"] = nerf["parity"]["psnr_db"], nerf["parity"]["max_abs"]
+    for k in ('nerfactor', 'train', 'olat', 'relight', 'fp32_class', 'geometry', 'wall_s'):
+        if legs.get(k):
+            out[k] = legs[k]
+    return strict(out)
+
+
+def compact(full):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, `parity` of the
+    headline leg, and one small object per further leg (step time, roofline fraction, worst error).  Everything else
+    is in bench_detail.json next to bench.py."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "world_size", "collective_backend", "rehearsal", "error")
+    line = _pick(full, *keys)
+    cfg = full.get("config")
+    if cfg:
+        line["config"] = _pick(cfg, "workload", "views_per_step", "rays_per_view", "rays_per_step_per_gpu",
+                               "n_samples_coarse", "n_samples_fine", "kernel_variant")
+        line["config"]["workload"] = "lego_3072-shaped NeRF coarse+fine MLP render, 800x800 rays/view, 64+128 samples (BASELINE.json configs[1])"
+    r = full.get("roofline")
+    if r:
+        line["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit",
+                                 "algorithmic_hbm_gb", "avg_launch_pair_ms", "flop_per_launch_pair")
+        src = r.get("traffic_source") or ""
+        line["roofline"]["traffic_source"] = ("measured by this run (rocprofv3 --pmc children)" if src.startswith("measured")
+                                              else src[:80] if src else None)
+    c = full.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind")
+        line["cpu_baseline"]["sample"] = (c.get("sample") or "").split(';')[0][:160]
+        if "gpu_over_cpu" in full:
+            line["gpu_over_cpu"] = full["gpu_over_cpu"]
+    if "parity" in full:
+        line["parity"] = _parity_block(full["parity"], "rays_above_tol", "rays_above_3e-2", "rays_compared")
+        line["parity"]["tolerance"] = "PSNR >= 40 dB, max-abs <= 3e-2 on every ray (BASELINE.md section 4)"
+        pf = full.get("parity_fitted_weights")
+        if pf:
+            line["parity"]["fitted_weights"] = _parity_block(pf, "rays_above_tol", "rays_above_3e-2", "rays_compared")
+    legs = {}
+    for name, leg in (full.get("nerfactor") or {}).items():
+        e = {"ms_per_step": leg.get("ms_per_step"), "frac": (leg.get("roofline") or {}).get("frac")}
+        if "parity" in leg:
+            e["max_abs"], e["points_above_tol"] = leg["parity"].get("max_abs"), leg["parity"].get("points_above_3e-2")
+        if "brdf_spec" in leg:
+            e["brdf_spec_ms"] = leg["brdf_spec"].get("avg_launch_ms")
+        if "cpu_baseline" in leg:
+            e["gpu_over_cpu"] = leg.get("gpu_over_cpu")
+        legs[name] = e
+    for name, leg in (full.get("train") or {}).items():
+        if "error" in leg:
+            legs["train_" + name] = {"error": str(leg["error"])[:120]}
+            continue
+        e = {"ms_per_step": leg.get("ms_per_step"), "ms_per_step_eager": leg.get("ms_per_step_eager"),
+             "frac": (leg.get("roofline") or {}).get("frac")}
+        if leg.get("parity"):
+            e["grad_rel_vs_bf16_oracle"] = leg["parity"].get("grad_rel_frobenius_vs_bf16_oracle_worst")
+            e["grad_rel_vs_reference"] = leg["parity"].get("grad_rel_frobenius_vs_reference_worst")
+        if leg.get("fp32"):
+            e["fp32_ms_per_step"] = leg["fp32"].get("ms_per_step")
+            e["fp32_grad_rel_vs_reference"] = (leg["fp32"].get("parity") or {}).get("grad_rel_frobenius_vs_reference_worst")
+        legs["train_" + name] = e
+    if full.get("olat"):
+        legs["olat"] = {"ms_per_step": full["olat"].get("ms_per_step"), "frac": (full["olat"].get("roofline") or {}).get("frac"),
+                        "bound": "hbm"}
+    if full.get("relight"):
+        legs["relight"] = _pick(full["relight"], "ms_per_step", "ms_per_view", "views_per_step", "probes")
+    if full.get("fp32_class"):
+        f = full["fp32_class"]
+        legs["fp32_class"] = {"ms_per_step": f.get("ms_per_step"), "frac": (f.get("roofline") or {}).get("frac"),
+                              "max_abs": (f.get("parity") or {}).get("max_abs_all_rays")}
+    if full.get("geometry"):
+        g = full["geometry"]
+        e = {"ms_per_view": (g.get("depth_normal") or {}).get("ms_per_view"),
+             "frac": ((g.get("depth_normal") or {}).get("roofline") or {}).get("frac"),
+             "lvis_frac": ((g.get("light_visibility") or {}).get("roofline") or {}).get("frac")}
+        e.update(_pick(g.get("parity") or {}, "normal_vec_max_abs", "rays_above_8e-2", "depth_rel_of_range", "lvis_max_abs"))
+        legs["geometry"] = e
+    if legs:
+        line["legs"] = legs
+    line["detail"] = DETAIL_NAME
+    return _sig(strict(line))
+
+
+def emit(full, stream=None, detail_dir=None):
+    """Write bench_detail.json (every leg, every digit) and print the compact line — strict JSON, one line, <= 6 KB."""
+    detail_dir = ROOT if detail_dir is None else detail_dir
+    try:
+        with open(os.path.join(detail_dir, DETAIL_NAME), 'w') as h:
+            json.dump(full, h, allow_nan=False, indent=1)
+    except OSError:                      # (a read-only tree must not take the line down)
+        pass
+    line = compact(full)
+    text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    if len(text) > LINE_MAX_BYTES:       # never silently: drop the per-leg objects before anything of the contract
+        line["legs"] = {"dropped": "line over %d bytes; see %s" % (LINE_MAX_BYTES, DETAIL_NAME)}
+        text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    print(text, file=stream or sys.stdout, flush=True)
+    return text
+
+
+# ------------------------------------------------------------------------------------------------ launching N ranks
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no torchrun around it (the reference's MirroredStrategy is one process that uses every
+    visible GPU, trainvali.py:263-266): re-execute this script as N ranks, one per GPU, under torch.distributed.run on
+    127.0.0.1; rank 0 prints the line.  Refuses — with a JSON error line and a non-zero exit — when the box has fewer GPUs."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    rehearsal = os.environ.get('NFX_BENCH_REHEARSAL') == '1' or os.environ.get('NFX_REHEARSAL') == '1'
+    if have < args.gpus and not (rehearsal and have >= 1):
+        print(json.dumps({"error": "--gpus %d but this box has %d GPU(s)" % (args.gpus, have), "n_gpus": args.gpus,
+                          "gpus_visible": have, "metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)",
+                          "value": None}, allow_nan=False), flush=True)
+        raise SystemExit(2)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 # ------------------------------------------------------------------------------------------------ main
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -1051,20 +1260,31 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat,relight,fp32_class,geometry')
     ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
-    ap.add_argument('--cpu-budget', type=float, default=20., help="seconds of CPU work for the NeRF baseline sample")
+    ap.add_argument('--cpu-budget', type=float, default=12., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true', help="train leg: time the eager step only")
     ap.add_argument('--no-last-sample-refine', action='store_true',
                     help="A/B: skip the fp32-class re-evaluation of every ray's last sample (the r03 render)")
     ap.add_argument('--precision', choices=('bf16', 'fp32'), default='bf16',
                     help="MLP operand type: bf16 (the headline) or fp32 = bf16 hi/lo pairs, 3 MFMAs per product")
-    args = ap.parse_args()
+    ap.add_argument('--measure-traffic', action='store_true',
+                    help="roofline.traffic from two rocprofv3 --pmc child runs of this command (default: the committed digest, labelled)")
+    ap.add_argument('--fp32-modes', action='store_true',
+                    help="train leg: time the precision = fp32 step in every matrix mode (default: the model's default mode only)")
+    ap.add_argument('--force-group', action='store_true',
+                    help="one rank: initialise the nccl (RCCL) process group anyway, so that the training legs' all-reduce runs on RCCL")
+    argv = sys.argv[1:] if argv is None else argv
+    args = ap.parse_args(argv)
+    global MEASURE_TRAFFIC
+    MEASURE_TRAFFIC = args.measure_traffic
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args, argv)          # does not return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnfx has no CPU path")
     # NFX_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo — exercises the whole N > 1 code path (sharding, barriers,
@@ -1076,7 +1296,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     from nerfactor_amd import dist as nfx_dist
-    nfx_dist.init_from_env(backend='gloo' if rehearsal else 'nccl', device=None if rehearsal else dev)
+    nfx_dist.init_from_env(backend='gloo' if rehearsal else 'nccl', device=None if rehearsal else dev,
+                           force=args.force_group)
     from nerfactor_amd import build
     build.build()
     from nerfactor_amd import ops
@@ -1089,47 +1310,36 @@ def main():
     def max_over_ranks(x):
         return nfx_dist.max_over_ranks(x, device=dev)
 
-    legs = [s for s in args.legs.split(',') if s]
-    nerf = nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'nerf' in legs else None
-    nerfactor = {name: nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
-                 for name in legs if name in ('nerfactor_microfacet', 'nerfactor')}
-    train = {}
-    if 'train' in legs and args.precision == 'bf16':
-        for name in (m for m in args.train_models.split(',') if m):
+    names = [s for s in args.legs.split(',') if s]
+    wall, legs = {}, {}
+
+    def run(key, fn, *a):
+        t0 = time.perf_counter()
+        res = fn(*a, args, ops, dev, rank, world, barrier, max_over_ranks)
+        wall[key] = round(time.perf_counter() - t0, 2)
+        return res
+
+    if 'nerf' in names:
+        legs['nerf'] = run('nerf', nerf_leg)
+    legs['nerfactor'] = {n: run(n, nerfactor_leg, n) for n in names if n in ('nerfactor_microfacet', 'nerfactor')}
+    legs['train'] = {}
+    if 'train' in names and args.precision == 'bf16':
+        for n in (m for m in args.train_models.split(',') if m):
             # (a check_numerics failure comes back as {"error": ...}, agreed on by all ranks inside the leg)
-            train[name] = train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks)
-    olat = olat_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'olat' in legs else None
-    relight = relight_sweep_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'relight' in legs else None
-    fp32c = nerf_fp32_class_leg(args, ops, dev, rank, world, barrier, max_over_ranks) \
-        if 'fp32_class' in legs and args.precision == 'bf16' else None
-    geometry = geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks) if 'geometry' in legs else None
+            legs['train'][n] = run('train_' + n, train_leg, n)
+    if 'olat' in names:
+        legs['olat'] = run('olat', olat_leg)
+    if 'relight' in names:
+        legs['relight'] = run('relight', relight_sweep_leg)
+    if 'fp32_class' in names and args.precision == 'bf16':
+        legs['fp32_class'] = run('fp32_class', nerf_fp32_class_leg)
+    if 'geometry' in names:
+        legs['geometry'] = run('geometry', geometry_leg)
+    legs['wall_s'] = wall
     if rank == 0:
-        out = {"metric": "rays/sec (NeRF coarse+fine render, 64+128 samples/ray)", "value": None,
-               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
-               "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-class: hi/lo operand pairs)",
-               "data": "synthetic", "world_size": world,
-               "collective_backend": (dist.get_backend() if dist.is_initialized() else "none (single process)")}
-        if rehearsal:
-            out["rehearsal"] = "all ranks share GPU 0 over gloo: a functional check of the N > 1 path, not a measurement"
-        if nerf is not None:   # (profiling runs may time the NeRFactor legs alone: --legs nerfactor)
-            out.update(nerf)
-            if "parity" in nerf:
-                out["psnr_db"], out["max_abs"] = nerf["parity"]["psnr_db"], nerf["parity"]["max_abs"]
-        if nerfactor:
-            out["nerfactor"] = nerfactor
-        if train:
-            out["train"] = train
-        if olat is not None:
-            out["olat"] = olat
-        if relight is not None:
-            out["relight"] = relight
-        if fp32c is not None:
-            out["fp32_class"] = fp32c
-        if geometry is not None:
-            out["geometry"] = geometry
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        backend = dist.get_backend() if dist.is_initialized() else "none (single process)"
+        emit(assemble(args.steps, args.warmup, args.scaling, args.precision, world, backend, rehearsal, legs))
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

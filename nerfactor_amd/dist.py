@@ -21,13 +21,22 @@ def rehearsal():
     return os.environ.get('NFX_REHEARSAL') == '1'
 
 
-def init_from_env(backend=None, device=None):
-    """Initialise the default process group from torchrun's environment; returns (rank, world)."""
+def init_from_env(backend=None, device=None, force=False):
+    """Initialise the default process group from torchrun's environment; returns (rank, world).  A single process gets no
+    group (and no collective) unless `force`: then a group of ONE rank is created — on a GPU that is RCCL with one rank,
+    and every collective of the training step (FlatBucket.all_reduce, broadcast_model) really goes through it."""
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:
+            if world > 1:
+                os.environ['MASTER_PORT'] = '29500'
+            else:                      # one forced rank: any free port will do
+                import socket
+                with socket.socket() as s:
+                    s.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(s.getsockname()[1])
         if rehearsal():
             backend, device = 'gloo', None
         if backend is None:
@@ -41,6 +50,14 @@ def init_from_env(backend=None, device=None):
 
 def world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
+def run_collectives_on_one_rank():
+    """A process group of ONE rank on the nccl (RCCL) backend exists only because somebody asked for it
+    (init_from_env(force=True), bench.py --force-group, the world_size-1 RCCL tests): then the step's collectives are
+    issued for real — a sum over one rank leaves the values unchanged — instead of being skipped.  gloo groups of one
+    rank (CPU tests of other things) keep the shortcut."""
+    return dist.is_initialized() and dist.get_world_size() == 1 and dist.get_backend() == 'nccl'
 
 
 def shard_range(n, rank=None, world_size=None):
@@ -95,7 +112,7 @@ class FlatBucket:
         the bucket, so whatever the caller enqueues on the current stream BETWEEN this call and its first read of the
         bucket overlaps the collective.  optim.train_step has nothing to put there (the collective follows the last
         backward kernel and the optimizer kernel needs its result), so it passes None."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized() and (dist.get_world_size() > 1 or run_collectives_on_one_rank()):
             if stream is None or not self.flat.is_cuda:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             else:
@@ -113,8 +130,8 @@ def broadcast_model(model, optimizer=None, src=0):
     the optimizer's flat parameter buffer and moments.  tf.distribute.MirroredStrategy creates every variable once
     and mirrors its initial value (trainvali.py:259-262); with one process per GPU each rank would otherwise keep
     its own random initialisation and the all-reduced gradient would be a sum of gradients taken at different
-    points.  No-op for a single process."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    points.  No-op for a single process (a forced one-rank RCCL group does run the broadcasts)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not run_collectives_on_one_rank()):
         return
     with torch.no_grad():
         if optimizer is not None:   # the trainable parameters are views of optimizer.flat: one call moves them all

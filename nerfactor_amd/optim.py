@@ -129,10 +129,22 @@ class GraphedTrainStep:
     goes to torch's current stream, workspaces come from torch's (graph-private) allocator, and the AMSGrad kernel
     reads its step size from device memory.  Per replay the host copies the batch into the static input tensors,
     writes the step size, launches the graph, advances `iterations` and bumps the parameters' version counters.
-    Batches that are not tagged foreground-only (dynamic shapes) and multi-process runs fall back to train_step."""
+    Batches that are not tagged foreground-only (dynamic shapes) fall back to train_step.
 
-    def __init__(self, model, optimizer, global_bs, warmup=2):
+    The collective: torch's ProcessGroupNCCL records an all-reduce issued under stream capture into the graph (RCCL
+    supports capture), so a step with the one all-reduce of the flat bucket in it replays like any other — exercised on
+    hardware with a ONE-rank RCCL group only (tests/test_gpu_rccl.py: bit-identical to the step without a group).  With
+    more than one rank the capture is therefore opt-in (`capture_collective=True`, ini key `hip_graph_collective`, or
+    NFX_GRAPH_COLLECTIVE=1) and the default stays the eager step; gloo groups are never captured."""
+
+    def __init__(self, model, optimizer, global_bs, warmup=2, capture_collective=None):
         self.model, self.opt, self.global_bs, self.warmup = model, optimizer, global_bs, warmup
+        if capture_collective is None:
+            import os
+            cfg = getattr(model, 'config', None)
+            capture_collective = os.environ.get('NFX_GRAPH_COLLECTIVE') == '1' or bool(
+                cfg is not None and cfg.getboolean('DEFAULT', 'hip_graph_collective', fallback=False))
+        self.capture_collective = capture_collective
         self.graphs = {}
         self.lr_t = torch.zeros(1, dtype=torch.float32, device=optimizer.flat.device)
         self.seen = {}
@@ -143,8 +155,10 @@ class GraphedTrainStep:
 
     def _capturable(self, batch):
         from .nerfactor.datasets.nerf_shape import known_all_foreground
-        if nfx_dist.world()[1] > 1:
-            return False
+        if nfx_dist.world()[1] > 1 or nfx_dist.run_collectives_on_one_rank():      # the step issues an all-reduce
+            import torch.distributed as dist
+            if not (self.capture_collective and dist.get_backend() == 'nccl'):
+                return False
         alpha = batch[5] if len(batch) > 5 else None       # NeRF batches (5 fields) have no compaction at all
         return alpha is None or known_all_foreground(alpha)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call (via gpurun): runs the stages named on the command line, everything worth keeping goes to gpurun_out/<tag>/.
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
-# stages: pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
+# stages: bench-driver | rccl | pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
 #         bench-train-fp32 | soak | sigma | fitted | generic | prof | train-prof | train-prof-fp32 | pmc | pmc-train | pmc-sq2 |
 #         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair
 #   A / B stages (experiment builds: NFX_EXTRA_DEFS=... python -m nerfactor_amd.build --out nerfactor_amd/libnfx_xpX.so):
@@ -21,6 +21,9 @@ for st in "$@"; do
     pytest)   timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -25 $OUT/pytest_gpu.log ;;
     pytest-x) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_x.log 2>&1; tail -8 $OUT/pytest_gpu_x.log ;;
     smoke)    timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -6 $OUT/smoke.log ;;
+    bench-driver) /usr/bin/time -f "driver-command wall %e s" timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err; cp bench_detail.json $OUT/ 2>/dev/null; wc -c $OUT/bench_line.json; cat $OUT/bench_line.json; tail -3 $OUT/bench_line.err; python -c "
+import json; d=json.load(open('$OUT/bench_detail.json')); print('wall_s', d.get('wall_s'))" ;;
+    rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
     ubench-pair) (cd scripts/ubench && timeout 600 ./two_wave_valu_pair.bin > $ROOT/$OUT/two_wave_valu_pair.jsonl 2>&1); cat $OUT/two_wave_valu_pair.jsonl ;;
