@@ -531,7 +531,7 @@ def nerfactor_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     if rank == 0 and not args.no_cpu_baseline:
         lights = torch.stack([model.light.detach().cpu().reshape(-1, 3)] +
                              [p.cpu().reshape(-1, 3) for p in model.novel_probes.values()])
-        base, n_s, ref = nerfactor_cpu_reference(model, variant, host_batches[0], lights, args.cpu_budget / 2,
+        base, n_s, ref = nerfactor_cpu_reference(model, variant, host_batches[0], lights, args.cpu_budget / 4,
                                                  timed_run=(world == 1))
         hi = min(n_s, sh.hi)
         if hi > 0 and sh.lo == 0:
@@ -870,7 +870,7 @@ def geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
     return out
 
 
-def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lvis, lxyz, n_rays=768, n_pts=12):
+def geometry_cpu_reference(nets, rayo_h, rayd_h, occu, depth, normal, surf, nrm, lvis, lxyz, n_rays=512, n_pts=8):
     """oracle/geometry_ref.py (NumPy / torch-CPU restatement of geometry_from_nerf.py:93-246) on a bounded sample: the CPU
     baseline of both stages and the parity of the timed outputs on those rays / points."""
     from oracle import geometry_ref as GR
@@ -1201,7 +1201,7 @@ def compact(full):
         e = {"ms_per_view": (g.get("depth_normal") or {}).get("ms_per_view"),
              "frac": ((g.get("depth_normal") or {}).get("roofline") or {}).get("frac"),
              "lvis_frac": ((g.get("light_visibility") or {}).get("roofline") or {}).get("frac")}
-        e.update(_pick(g.get("parity") or {}, "normal_vec_max_abs", "rays_above_8e-2", "depth_rel_of_range", "lvis_max_abs"))
+        e.update(_pick(g.get("parity") or {}, "normal_vec_max_abs", "rays_above_8e-2", "rays_compared", "depth_rel_of_range", "lvis_max_abs"))
         legs["geometry"] = e
     if legs:
         line["legs"] = legs
@@ -1260,7 +1260,7 @@ def main(argv=None):
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--legs', default='nerf,nerfactor_microfacet,nerfactor,train,olat,relight,fp32_class,geometry')
     ap.add_argument('--train-models', default='nerfactor_microfacet,nerfactor,nerf')
-    ap.add_argument('--cpu-budget', type=float, default=12., help="seconds of CPU work for the NeRF baseline sample")
+    ap.add_argument('--cpu-budget', type=float, default=10., help="seconds of CPU work for the NeRF baseline sample")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true', help="train leg: time the eager step only")
     ap.add_argument('--no-last-sample-refine', action='store_true',

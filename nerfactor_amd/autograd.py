@@ -49,6 +49,9 @@ _heads = {'pending': [], 'armed': False}
 
 def _flush_heads():
     pending, _heads['pending'], _heads['armed'] = _heads['pending'], [], False
+    for h in pending:       # the callback runs on the caller's stream: wait for the streams the recorded gradients were produced on
+        if h.get('event') is not None:
+            torch.cuda.current_stream(h['dout'].device).wait_event(h['event'])
     while pending:
         first = pending[0]
         group, rest, bufs = [], [], set()
@@ -73,9 +76,14 @@ class Mlp128Xyz(torch.autograd.Function):
                 *params):
         ctx.save_for_backward(xyz)
         ctx.cfg = (train_blob_fn, prec, out_dim, out_act, xyz_scale, post_scale, params)
-        if _heads['pending'] or _heads['armed']:
+        if (_heads['pending'] or _heads['armed']) and torch._C._current_graph_task_id() < 0:
             # heads recorded by a backward pass that never reached its end (an exception inside autograd: the engine runs no
-            # callback then) must not leak into the next one
+            # callback then) must not leak into the next one.  A forward that runs WHILE a backward pass is in flight
+            # (activation re-computation, a second model: the engine's graph-task id is >= 0 on this thread) leaves the
+            # recorded heads alone: their gradients are still owed.
+            import warnings
+            warnings.warn("nerfactor_amd.autograd: dropping %d width-128 head(s) recorded by a backward pass that did not "
+                          "finish" % len(_heads['pending']))
             _heads['pending'], _heads['armed'] = [], False
         return ops.mlp128_xyz_fwd(xyz, fwd_blob, out_dim, out_act=out_act, xyz_scale=xyz_scale,
                                   post_scale=post_scale, post_bias=post_bias, prec=prec)
@@ -87,8 +95,13 @@ class Mlp128Xyz(torch.autograd.Function):
         ks, bs = list(params[:5]), list(params[5:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
         if BATCH_HEADS and all(r is None for r in rks + rbs):      # (every gradient accumulated in place: nothing to hand back)
-            _heads['pending'].append(dict(xyz=xyz, dout=dout.contiguous(), blob=train_blob_fn(), dks=dks, dbs=dbs, out_act=out_act,
-                                          xyz_scale=xyz_scale, post_scale=post_scale))
+            dout = dout.contiguous()
+            event = None
+            if dout.is_cuda:    # (every gradient is returned as None: no AccumulateGrad makes the engine sync this node's stream)
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(dout.device))
+            _heads['pending'].append(dict(xyz=xyz, dout=dout, blob=train_blob_fn(), dks=dks, dbs=dbs, out_act=out_act,
+                                          xyz_scale=xyz_scale, post_scale=post_scale, event=event))
             if not _heads['armed']:
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_heads)
                 _heads['armed'] = True

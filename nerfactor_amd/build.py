@@ -43,8 +43,10 @@ VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 FAST_DIV = ['-fno-hip-fp32-correctly-rounded-divide-sqrt']
 PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
                   'nerf_geom.hip': VGPR_FORM, 'mlp128_bwd_fused.hip': VGPR_FORM, 'shade.hip': FAST_DIV}
-if os.environ.get('NFX_VGPR_FORM_FILES') is not None:
-    PER_FILE_FLAGS = {f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f}
+if os.environ.get('NFX_VGPR_FORM_FILES') is not None:      # A/B experiment libraries: only the VGPR-form entries are overridden —
+    # shade.hip keeps FAST_DIV, so an experiment build divides exactly like the shipped library
+    PER_FILE_FLAGS = dict({f: v for f, v in PER_FILE_FLAGS.items() if v is not VGPR_FORM},
+                          **{f: VGPR_FORM for f in os.environ['NFX_VGPR_FORM_FILES'].split(',') if f})
 
 
 def _sources():

