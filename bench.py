@@ -102,7 +102,23 @@ def timed(step, steps, warmup, barrier):
 
 
 # ------------------------------------------------------------------------------------------------ NeRF leg
-def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coarse_prec=None):
+COARSE_REFINE_GATE = 4e-3      # models/nerf.py `coarse_refine_gate` (ini default)
+
+
+def coarse_refine_decision(ops, view, blobs, refine, prec='bf16'):
+    """What the plugin's `coarse_precision = auto` decides for these weights (models/nerf.py:_coarse_refine_on): the measured
+    bf16 density error as an alpha error, and whether the selective fp32-class refinement of the coarse pass is on."""
+    if refine is None or prec != 'bf16':
+        return False, None
+    o, d_raw = view
+    d = ops.l2_normalize3(d_raw, 1e-12)
+    z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
+    raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
+    err = ops.nerf_coarse_alpha_error(o, d, z, raw, refine[0])
+    return err > COARSE_REFINE_GATE, err
+
+
+def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coarse_prec=None, refine_coarse=False):
     """views: [(rayo, rayd)] device tensors (this rank's shard of every view).  ev: per-view 4 events around the two
     MLP launches.  refine: the two fp32-class density blobs — the last sample of every ray is re-evaluated with them
     (what models/nerf.py does when rendering with precision = bf16: ops.nerf_refine_last_sample); inside the timed step,
@@ -119,6 +135,8 @@ def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coars
             e[1].record()
         if refine is not None and (coarse_prec or prec) == 'bf16':
             ops.nerf_refine_last_sample(o, d, z, raw, refine[0])
+            if refine_coarse:       # (the plugin's coarse_precision = auto / select: the deciding coarse samples fp32-class)
+                ops.nerf_refine_coarse(o, d, z, raw, refine[0])
         _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
         z_all = ops.sample_fine(z, w, N_FINE)
         if e is not None:
@@ -254,8 +272,10 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         host_views.append((rayo, rayd))
         views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in views] for _ in range(args.steps)]
+    # coarse_precision = auto: measured once per weight version, as the plugin does — outside the timed region
+    refine_coarse, alpha_err = coarse_refine_decision(ops, views[0], blobs, refine, args.precision)
     elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k], args.precision,
-                                                    refine),
+                                                    refine, refine_coarse=refine_coarse),
                          args.steps, args.warmup, barrier)
     elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(rgb).all()
@@ -291,7 +311,10 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
             "views_per_step": sh.n_views, "rays_per_view": H * W, "rays_per_step_per_gpu": sh.n_views * n_local,
             "partition": "each view's rays in contiguous ranges over the ranks",
             "n_samples_coarse": N_COARSE, "n_samples_fine": N_FINE, "weights": "glorot seed 0, opaque variant",
-            "kernel_variant": variant},
+            "kernel_variant": variant,
+            "coarse_precision": "auto: measured bf16 alpha error %s %s gate %.0e -> selective fp32-class coarse refinement %s" % (
+                "n/a" if alpha_err is None else "%.2e" % alpha_err, ">" if refine_coarse else "<=", COARSE_REFINE_GATE,
+                "ON" if refine_coarse else "off")},
         "roofline": {
             "bound": "mfma", "kernel": "%s (coarse + fine launches)" % (
                 "nerf_mlp_x3_kernel, 3 MFMAs per product: achieved counts the algorithmic FLOPs once" if fp32 else {
@@ -309,7 +332,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         sel = idx[(idx >= sh.lo) & (idx < sh.hi)]
         keep = np.isin(idx, sel)
         o, d = (torch.from_numpy(a[sel]).to(dev) for a in host_views[0])
-        got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision, refine=refine).cpu().numpy()
+        got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse).cpu().numpy()
         want = ref[1]['rgb'].numpy()[keep]
         # r04: NO ray is excused.  Rays decided by the sign of a near-zero logit at the dist = 1e10 last sample are a
         # discontinuity of the reference formula; the render evaluates that one sample fp32-class, so
@@ -327,11 +350,11 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         if base is not None:
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = out["value"] / base["value"]
-        out["parity_fitted_weights"] = nerf_fitted_parity(args, ops, dev, host_views[0], refine is not None)
+        out["parity_fitted_weights"] = nerf_fitted_parity(args, ops, dev, host_views[0], refine is not None, views[0] if world == 1 else None)
     return out
 
 
-def nerf_fitted_parity(args, ops, dev, host_view, refine_last, n=2048):
+def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n=2048):
     """The same render on the NeRF weights FITTED to a scene (tests/golden/nerf_trained_fp16.npz, the networks of the
     reference fixtures; empty space sits at a robustly negative density): the glorot "opaque variant" weights of the
     timed frame put ~9 % of the rays on the reference formula's own discontinuity (alpha_last = [sigma_last > 0],
@@ -348,8 +371,33 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, n=2048):
     with torch.no_grad():
         ref = torch_ref.render_rays(torch.from_numpy(o), torch.from_numpy(d), *[torch_ref.to_torch_net(x) for x in nets])
     view = [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))]
-    got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine).cpu().numpy()
+    refine_coarse, alpha_err = coarse_refine_decision(ops, full_view or view[0], blobs, refine, args.precision)
+    got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse).cpu().numpy()
     want = ref[1]['rgb'].numpy()
+    cost = None
+    if full_view is not None and refine_coarse:       # what the refinement costs on THIS scene: the whole 800 x 800 view both ways
+        def frame_ms(on, reps=3):
+            nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        o_f, d_f = full_view
+        d_n = ops.l2_normalize3(d_f, 1e-12)
+        z_f = ops.gen_z(2., 6., N_COARSE, o_f.shape[0], device=dev)
+        raw_f = ops.nerf_mlp_fwd(o_f, d_n, z_f, blobs[0], args.precision)
+        ops.nerf_refine_last_sample(o_f, d_n, z_f, raw_f, refine[0])
+        _, cnt = ops.nerf_refine_coarse(o_f, d_n, z_f, raw_f, refine[0], want_count=True)
+        t_off, t_on = frame_ms(False), frame_ms(True)
+        cost = {"frame_ms_bf16_coarse": t_off, "frame_ms_with_refinement": t_on, "extra_frame_time": t_on / t_off - 1.,
+                "coarse_samples_refined_frac": float(cnt.item()) / float(z_f.numel())}
+    no_refine = None
+    if refine_coarse:      # the same rays with coarse_precision = bf16 (the r05 default), for the record
+        g0 = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine).cpu().numpy()
+        e0 = np.abs(g0 - want).max(1)
+        no_refine = {"max_abs_all_rays": float(e0.max()), "rays_above_3e-2": int((e0 > 3e-2).sum())}
     sig = np.minimum(ref[2]['sigma_last_coarse'].numpy(), ref[2]['sigma_last_fine'].numpy())
     err = np.abs(got - want).max(1)
     coarse32 = None
@@ -360,6 +408,9 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, n=2048):
         coarse32 = {"psnr_db": psnr_uint8_luma(g32, want), "max_abs_all_rays": float(e32.max()),
                     "rays_above_3e-2": int((e32 > 3e-2).sum()), "what": "ini key coarse_precision = fp32: +67 % frame time (r04 call B)"}
     return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()), "coarse_precision_fp32": coarse32,
+            "coarse_precision": "auto: measured bf16 alpha error %s -> selective refinement %s" % (
+                "n/a" if alpha_err is None else "%.2e" % alpha_err, "ON" if refine_coarse else "off"),
+            "coarse_refinement_cost": cost, "coarse_precision_bf16": no_refine,
             "max_abs_all_rays": float(err.max()), "rays_compared": int(n),
             "rays_excluded_from_max_abs": 0, "rays_with_abs_sigma_last_below_0.06": int((sig <= 0.06).sum()),
             "frac_rays_above_3e-2": float((err > 3e-2).mean()), "rays_above_3e-2": int((err > 3e-2).sum()),
@@ -1164,6 +1215,12 @@ def compact(full):
         pf = full.get("parity_fitted_weights")
         if pf:
             line["parity"]["fitted_weights"] = _parity_block(pf, "rays_above_tol", "rays_above_3e-2", "rays_compared")
+            cost = pf.get("coarse_refinement_cost") or {}
+            if cost:       # what holding the tolerance on every ray of a FITTED scene costs there (the timed frame: glorot weights)
+                line["parity"]["fitted_weights"]["refine_extra_frame_time"] = cost.get("extra_frame_time")
+                line["parity"]["fitted_weights"]["coarse_samples_refined_frac"] = cost.get("coarse_samples_refined_frac")
+            if pf.get("coarse_precision_bf16"):
+                line["parity"]["fitted_weights"]["rays_above_tol_without_refinement"] = pf["coarse_precision_bf16"].get("rays_above_3e-2")
     legs = {}
     for name, leg in (full.get("nerfactor") or {}).items():
         e = {"ms_per_step": leg.get("ms_per_step"), "frac": (leg.get("roofline") or {}).get("frac")}

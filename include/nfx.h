@@ -420,6 +420,24 @@ NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, co
                         int n_samples, const void *dev_geom_blob, int prec, float *dev_normal_sigma,
                         void *stream);
 
+/* Selective fp32-class refinement of the COARSE densities of a bf16 render (round 6; nerf.py:138-147 with
+ * util/math.py:71-94: the coarse weights place the fine samples, and on a fitted network's silhouette rays a bf16
+ * density error of 0.1-0.3 moves them across the edge).  Two launches, no host round trip:
+ *   nfx_nerf_refine_select  lists the samples that decide (same scan as nfx_composite_fwd): visible (T_i > t_min) and
+ *                           either not saturated (a_lo < alpha_i < a_hi) or undecided (|sigma_i| < sigma_margin: the side
+ *                           of the relu is within the bf16 error), grown by `dilate` neighbours either way, never the last
+ *                           sample of a ray; dev_list[n_rays * S] int32 receives flat indices ray * S + s in arbitrary
+ *                           order, dev_count[1] their number (zeroed by this call);
+ *   nfx_nerf_sigma_refine   overwrites rgbs[i, 3] (the density channel of rgbs[n_rays, S, 4]) of every listed sample i
+ *                           with the fp32-class density (NFX_PREC_FP32 blob of nfx_nerf_pack_geom_weights), bit-identical
+ *                           to nfx_nerf_sigma_fwd(prec = NFX_PREC_FP32) at those samples; reads the count on the device. */
+NFX_API int nfx_nerf_refine_select(const float *dev_rgbs, const float *dev_z, const float *dev_rayd, int64_t n_rays,
+                           int n_samples, float t_min, float a_lo, float a_hi, float sigma_margin, int dilate,
+                           int *dev_list, int *dev_count, void *stream);
+NFX_API int nfx_nerf_sigma_refine(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+                          int n_samples, const void *dev_geom_blob_fp32, const int *dev_list, const int *dev_count,
+                          float *dev_rgbs, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Diagnostics.                                                              */
 /* ------------------------------------------------------------------------ */

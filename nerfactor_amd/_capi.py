@@ -88,6 +88,8 @@ SIGNATURES = {
     'nfx_amsgrad_step_size': (_f, [_f, _f, _f, _i64]),
     'nfx_amsgrad_step_dev': (_i, [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _p]),
     'nfx_nerf_sigma_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_nerf_refine_select': (_i, [_p, _p, _p, _i64, _i, _f, _f, _f, _f, _i, _p, _p, _p]),
+    'nfx_nerf_sigma_refine': (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
     'nfx_nerf_geom_packed_bytes': (_sz, [_i]),
     'nfx_nerf_pack_geom_weights': (_i, [_pp, _pp, _i, _p, _sz]),
     'nfx_nerf_sigma_grad': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
@@ -132,7 +134,7 @@ def check(rc, what):
 
 # ------------------------------------------------------------------------------- options
 OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
-               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused')
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify')
 
 
 def set_option(key, value):

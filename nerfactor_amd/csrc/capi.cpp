@@ -76,6 +76,8 @@ Option g_options[] = {
     {"nerf_blocks", {0}, {0}},    // persistent grid of the NeRF kernels (default 256)
     {"m128_blocks", {0}, {0}},    // persistent grid of the width-128 kernels (default 256)
     {"lvis_variant", {0}, {0}},   // light visibility: 8 (default) | 2 | 3 | 4 | 0 — all bit-identical
+    {"lvis_verify", {0}, {0}},    // k > 0: the HOST side (ops.lvis_fwd) re-runs ~1 % of the points of every k-th launch on the one-wave-per-SIMD
+                                  //        kernel (variant 4) and raises on any differing bit; 0 / unset = off.  The library only stores it.
     {"brdf_variant", {0}, {0}},   // learned BRDF: 6 (default) | 5 | 2 | 3 | 4 | 0
     {"brdf_ct", {0}, {0}},        // column tiles of brdf variants 5 / 6: 4 (default) | 2 | 3; 8 = two waves per SIMD (variant 6 only)
     {"nerf_bwd", {0}, {0}},       // 1 (default) = LDS-DMA ring backward, 0 = register-staged identity reference

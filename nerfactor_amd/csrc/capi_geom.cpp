@@ -24,6 +24,10 @@ int nfx_launch_nerf_sigma_geo(const float*, const float*, const float*, long lon
                               hipStream_t);
 int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long long, int, const void*, float*, int,
                                hipStream_t);
+int nfx_launch_refine_select(const float*, const float*, const float*, long long, int, float, float, float, float, int, int*, int*,
+                             hipStream_t);
+int nfx_launch_nerf_sigma_x3_list(const float*, const float*, const float*, long long, int, const void*, float*, const int*,
+                                  const int*, int, hipStream_t);
 int nfx_launch_nerf_sigma_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
                              hipStream_t);   // nerf_geom_x3.hip
 int nfx_launch_nerf_sigma_grad_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
@@ -142,6 +146,31 @@ int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int
     return nfx_hip_result(nfx_launch_nerf_sigma_geo(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
                                                     sigma, nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                           "nerf_sigma_fwd");
+}
+
+int nfx_nerf_refine_select(const float* rgbs, const float* z, const float* rayd, int64_t n_rays, int n_samples,
+                           float t_min, float a_lo, float a_hi, float sigma_margin, int dilate, int* list, int* count,
+                           void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 512, "nfx_nerf_refine_select: bad shape (1 <= S <= 512, got %d)", n_samples);
+    REQUIRE(n_rays * (int64_t)n_samples < (int64_t)1 << 31, "nfx_nerf_refine_select: %lld samples do not fit int32 indices",
+            (long long)(n_rays * n_samples));
+    REQUIRE(dilate >= 0 && dilate <= 8, "nfx_nerf_refine_select: dilate = %d (0 .. 8)", dilate);
+    REQUIRE(count, "nfx_nerf_refine_select: null count");
+    if (n_rays > 0) REQUIRE(rgbs && z && rayd && list, "nfx_nerf_refine_select: null pointer");
+    if (n_rays > 0 && !ALIGNED(rgbs, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_refine_select: rgbs must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_refine_select(rgbs, z, rayd, (long long)n_rays, n_samples, t_min, a_lo, a_hi, sigma_margin, dilate,
+                                                   list, count, (hipStream_t)stream), "nerf_refine_select");
+}
+
+int nfx_nerf_sigma_refine(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                          const void* blob, const int* list, const int* count, float* rgbs, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_refine: bad shape");
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && blob && list && count && rgbs, "nfx_nerf_sigma_refine: null pointer");
+    if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_refine: blob must be 16-byte aligned");
+    return nfx_hip_result(nfx_launch_nerf_sigma_x3_list(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob, rgbs,
+                                                        list, count, nfx_option_int("nerf_blocks", 256),
+                                                        (hipStream_t)stream), "nerf_sigma_refine");
 }
 
 int nfx_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,

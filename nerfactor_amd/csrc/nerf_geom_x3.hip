@@ -69,9 +69,17 @@ __device__ __forceinline__ void input_grad(x3::Stream& st, int tid, const float*
 template <bool GRAD>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
-    int n_samples, const char* __restrict__ blob, float* __restrict__ out) {
+    int n_samples, const char* __restrict__ blob, float* __restrict__ out, const int* __restrict__ list,
+    const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
+    // LIST mode (density only, round 6: the selective coarse refinement of the bf16 render): the points are the flat sample
+    // indices list[0 .. *count) (both in device memory: the number of selected samples never visits the host), and the
+    // density of point i goes to out[4 i + 3] — the sigma channel of rgbs[N, S, 4].  A workgroup with no tile leaves at once.
+    if (list != nullptr) {
+        n_pts = *count;
+        if ((long long)blockIdx.x * kRows >= n_pts) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
     float* fl = reinterpret_cast<float*>(smem + 2 * x3::kSlot);
     {
@@ -92,7 +100,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row = tile * kRows + wave * 32 + p;
         const bool valid = row < n_pts;
-        const long long mm = valid ? row : n_pts - 1;
+        long long mm = valid ? row : n_pts - 1;
+        if (list != nullptr) mm = list[mm];
         float x[3];
         {
             const long long ray = mm / n_samples;
@@ -120,7 +129,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
             sigma = acc[0];  // row 0 of the tile, on the h = 0 lanes
         }
         if constexpr (!GRAD) {
-            if (valid && h == 0) out[row] = sigma;
+            if (valid && h == 0) {
+                if (list != nullptr) out[4 * mm + 3] = sigma;
+                else out[row] = sigma;
+            }
         } else {
             // -------------------------------------------------------------- reverse sweep
             // dZ7 = mask7 . W_sigma (the same vector for every point: no MFMA)
@@ -175,14 +187,16 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
 
 template <bool GRAD>
 static int launch(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
-                  const void* blob, float* out, int max_blocks, hipStream_t st) {
+                  const void* blob, float* out, int max_blocks, hipStream_t st, const int* list = nullptr,
+                  const int* count = nullptr) {
     if (n_pts <= 0) return 0;
     const long long tiles = (n_pts + kRows - 1) / kRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     auto k = nerf_sigma_x3_kernel<GRAD>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kNW * 64), kLds, st, rayo, rayd, z, n_pts, n_samples, (const char*)blob, out);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kNW * 64), kLds, st, rayo, rayd, z, n_pts, n_samples, (const char*)blob, out,
+                       list, count);
     return (int)hipGetLastError();
 }
 
@@ -197,4 +211,10 @@ extern "C" int nfx_launch_nerf_sigma_grad_x3(const float* rayo, const float* ray
 extern "C" int nfx_launch_nerf_sigma_x3(const float* rayo, const float* rayd, const float* z, long long n_pts,
                                         int n_samples, const void* blob, float* out, int max_blocks, hipStream_t st) {
     return nfx::geo3::launch<false>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, st);
+}
+// density at the listed samples (n_pts = the list's capacity: sizes the grid; the kernel reads the real count on the device)
+extern "C" int nfx_launch_nerf_sigma_x3_list(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                             int n_samples, const void* blob, float* rgbs, const int* list,
+                                             const int* count, int max_blocks, hipStream_t st) {
+    return nfx::geo3::launch<false>(rayo, rayd, z, n_pts, n_samples, blob, rgbs, max_blocks, st, list, count);
 }

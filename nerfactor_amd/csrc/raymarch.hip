@@ -114,6 +114,76 @@ __global__ __launch_bounds__(256) void composite_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// refine_select: which COARSE samples decide where the inverse-CDF sampler puts the fine samples (round 6).  One wave
+// per ray, the same scan as composite_kernel (alpha_i, exclusive transmittance T_i).  A sample is listed when it is
+// VISIBLE (T_i > t_min) and either NOT SATURATED (a_lo < alpha_i < a_hi) — a density error there moves the weights of the
+// ray — or UNDECIDED (|sigma_i| < sigma_margin: the bf16 kernel cannot tell which side of the relu the sample is on; on a
+// near-miss ray, whose weights sum to almost nothing, one such sample IS the pdf of the inverse-CDF sampler),
+// or is the neighbour (`dilate` samples either way) of such a sample: at a density edge the bf16 kernel may say
+// sigma < 0 (alpha = 0 exactly) where the fp32 value is positive.  The last sample (dist = 1e10) is never listed: the
+// render re-evaluates it anyway (nfx_nerf_sigma_fwd on z[:, -1]).  list[] receives the flat sample indices ray * S + s
+// in arbitrary order (one atomicAdd per wave), *count their number.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_select_kernel(
+    const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rayd, long long n_rays, int S,
+    float t_min, float a_lo, float a_hi, float sigma_margin, int dilate, int* __restrict__ list, int* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;  // wave-uniform
+    const float dx = rayd[3 * ray], dy = rayd[3 * ray + 1], dz = rayd[3 * ray + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const long long base = ray * S;
+    float carry = 1.0f;
+    constexpr int kMaxChunks = 8;                     // S <= 512 (checked by nfx_nerf_refine_select)
+    unsigned long long bits[kMaxChunks + 2];          // bits[c + 1] = marks of chunk c; zero guards at both ends
+#pragma unroll
+    for (int c = 0; c < kMaxChunks + 2; ++c) bits[c] = 0ull;
+    const int n_chunks = (S + 63) / 64;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int s = c * 64 + lane;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const float sg = rgbs[base + sc].w;
+        const float zc = z[base + sc];
+        const float zn = (sc < S - 1) ? z[base + sc + 1] : 0.f;
+        const float dist = ((sc < S - 1) ? (zn - zc) : 1e10f) * dnorm;
+        const float alpha = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);
+        const float t = valid ? (1.0f - alpha + 1e-6f) : 1.0f;
+        float incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63, 64);
+        const bool m = valid && T > t_min && ((alpha > a_lo && alpha < a_hi) || fabsf(sg) < sigma_margin);
+        const unsigned long long b = __ballot(m);
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k)
+            if (k == c) bits[k + 1] = b;
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+        unsigned long long own = 0ull, before = 0ull, after = 0ull;
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k)
+            if (k == c) { before = bits[k]; own = bits[k + 1]; after = bits[k + 2]; }
+        unsigned long long grown = own;
+        for (int k = 1; k <= dilate; ++k) grown |= (own << k) | (own >> k) | (before >> (64 - k)) | (after << (64 - k));
+        const int s = c * 64 + lane;
+        const bool m = s < S - 1 && ((grown >> lane) & 1ull);      // never the last sample of the ray
+        const unsigned long long sel = __ballot(m);
+        const int n_sel = __popcll(sel);
+        int at = 0;
+        if (lane == 0 && n_sel) at = atomicAdd(count, n_sel);
+        at = __shfl(at, 0, 64);
+        if (m) list[at + __popcll(sel & ((1ull << lane) - 1ull))] = (int)(base + s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // composite_bwd: gradient of the composited colour (nerf.py:184-254) w.r.t. the raw network outputs.
 // One wave per ray.  Pass 1 re-runs the forward scan (weights w_i and transmittances T_i parked in LDS, sums R_c, O);
 // pass 2 walks the samples backwards with a suffix sum:
@@ -352,6 +422,15 @@ int nfx_launch_composite(const float* rgbs, const float* z, const float* rayd, c
     hipLaunchKernelGGL(nfx::composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st,
                        (const float4*)rgbs, z, rayd, noise, n_rays, S, white_bg ? 1.0f : 0.0f, rgb,
                        occu, depth, disp, w);
+    return (int)hipGetLastError();
+}
+int nfx_launch_refine_select(const float* rgbs, const float* z, const float* rayd, long long n_rays, int S, float t_min,
+                             float a_lo, float a_hi, float sigma_margin, int dilate, int* list, int* count, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(nfx::refine_select_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st,
+                       (const float4*)rgbs, z, rayd, n_rays, S, t_min, a_lo, a_hi, sigma_margin, dilate, list, count);
     return (int)hipGetLastError();
 }
 int nfx_launch_sample_fine(const float* z, const float* w, long long n_rays, int nc, int nf,

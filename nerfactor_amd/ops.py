@@ -569,7 +569,45 @@ def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., xyz_dir=None, prec='bf16'):
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=xyz.device)
     check(lib.nfx_lvis_fwd(_ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
                            ws.numel() * 4, _ptr(out), _stream()), 'nfx_lvis_fwd')
+    _lvis_verify(out, xyz, xyz_dir, xyz_scale, lxyz, blob, prec)
     return out
+
+
+_lvis_launches = [0]
+
+
+def _lvis_verify(out, xyz, xyz_dir, xyz_scale, lxyz, blob, prec, every=100, max_points=8192):
+    """nfx_set_option("lvis_verify", k): every k-th launch of the DEFAULT light-visibility kernel (resident128_kernel<2, 0, 8>:
+    two waves per SIMD — the regime in which a sibling kernel, brdf_compact_kernel<2, 0, 8>, returns wrong rows for a reason
+    three rounds of probes have not found) is checked against the one-wave-per-SIMD kernel (variant 4)
+    on every `every`-th point: the two are the same sums in the same order, so ANY differing bit raises NfxError.  Costs
+    ~1 % of the launch plus one host read; skipped while a hipGraph is being captured (nothing may wait there)."""
+    k = _capi.get_option("lvis_verify")
+    if not k or k <= 0 or prec != 'bf16' or out.shape[0] == 0:
+        return
+    variant = _capi.get_option("lvis_variant")
+    if variant not in (None, 8) or torch.cuda.is_current_stream_capturing():
+        return
+    _lvis_launches[0] += 1
+    if _lvis_launches[0] % k:
+        return
+    n = out.shape[0]
+    step = max(1, min(every, n), -(-n // max_points))
+    pick = torch.arange(0, n, step, device=out.device)
+    x, xd = xyz[pick].contiguous(), (xyz if xyz_dir is None else xyz_dir)[pick].contiguous()
+    nl = lxyz.shape[0]
+    ref = torch.empty((x.shape[0], nl), dtype=torch.float32, device=out.device)
+    ws = torch.empty((max(lib.nfx_lvis_workspace_bytes(x.shape[0]), 16) // 4,), dtype=torch.float32, device=out.device)
+    with _capi.option("lvis_variant", 4):
+        check(lib.nfx_lvis_fwd(_ptr(x), _ptr(xd), x.shape[0], xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
+                               ws.numel() * 4, _ptr(ref), _stream()), 'nfx_lvis_fwd(verify)')
+    got = out[pick]
+    if not torch.equal(got, ref):
+        bad = (got != ref)
+        rows = torch.nonzero(bad.any(1))[:, 0]
+        raise _capi.NfxError("lvis_verify: resident128_kernel<2, 0, 8> differs from the one-wave-per-SIMD kernel on %d of %d checked "
+                             "points (%d elements, first point %d, max |diff| %.3e) — set lvis_variant = 4" % (
+                                 rows.numel(), x.shape[0], int(bad.sum()), int(pick[rows[0]]), float((got - ref).abs().max())))
 
 
 def brdf_spec_fwd(xyz, cam, normal, z, lxyz, blob, prec='bf16'):
@@ -838,6 +876,52 @@ def nerf_refine_last_sample(rayo, rayd, z, rgbs, geom_blob_fp32):
     sig = nerf_sigma_fwd(rayo, rayd, z[:, -1:].contiguous(), geom_blob_fp32, 'fp32')
     rgbs[:, -1, 3] = sig[:, 0]
     return rgbs
+
+
+# the selection of nfx_nerf_refine_select as the render uses it (calibrated on a fitted NeRF, scripts/coarse_refine_probe*.py:
+# 0 of 131 072 rays of a fitted view above 3e-2 against 509 without; T > 1e-3 or no dilation leave 5-13 rays)
+REFINE_T_MIN, REFINE_A_LO, REFINE_A_HI, REFINE_DILATE = 1e-4, 1e-4, 0.9999, 1
+
+
+def nerf_refine_coarse(rayo, rayd, z, rgbs, geom_blob_fp32, t_min=REFINE_T_MIN, a_lo=REFINE_A_LO, a_hi=REFINE_A_HI,
+                       dilate=REFINE_DILATE, sigma_margin=0., want_count=False):
+    """Overwrites, in place, the density in rgbs[N,S,4] of the coarse samples that decide where the inverse-CDF sampler
+    (util/math.py:71-94) puts the fine samples with the fp32-class density kernel's value: samples that are visible
+    (T_i > t_min) and not saturated (a_lo < alpha_i < a_hi), and `dilate` neighbours either way.  Two launches
+    (nfx_nerf_refine_select, nfx_nerf_sigma_refine); the list and its length stay on the device.  Returns rgbs (and the
+    1-element int32 count tensor if `want_count`)."""
+    rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, geom_blob_fp32)
+    if not (isinstance(rgbs, torch.Tensor) and rgbs.is_contiguous()):
+        raise _capi.NfxError("nerf_refine_coarse: rgbs is updated in place and must be contiguous")
+    rgbs = _dev(rgbs, 'rgbs', (n, s, 4))
+    count = torch.empty(1, dtype=torch.int32, device=z.device)
+    if n == 0 or s < 2:
+        count.zero_()
+        return (rgbs, count) if want_count else rgbs
+    lst = torch.empty(n * s, dtype=torch.int32, device=z.device)
+    check(lib.nfx_nerf_refine_select(_ptr(rgbs), _ptr(z), _ptr(rayd), n, s, t_min, a_lo, a_hi, sigma_margin, dilate, _ptr(lst), _ptr(count),
+                                     _stream()), 'nfx_nerf_refine_select')
+    check(lib.nfx_nerf_sigma_refine(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(geom_blob_fp32), _ptr(lst), _ptr(count),
+                                    _ptr(rgbs), _stream()), 'nfx_nerf_sigma_refine')
+    return (rgbs, count) if want_count else rgbs
+
+
+def nerf_coarse_alpha_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.999):
+    """How far the bf16 kernel's density error can move a coarse sample's alpha for THESE weights: the q-quantile of
+    |sigma_bf16 - sigma_fp32class| over the samples of up to `max_rays` rays of the batch, times the mean sample spacing.
+    The render's `coarse_precision = auto` measures this once per weight version (one host read) and switches the selective
+    refinement on when it exceeds `coarse_refine_gate` (measured: glorot "opaque" weights of the bench 1.5e-3, a NeRF fitted
+    to a scene 1.0e-2)."""
+    n = min(int(z.shape[0]), max_rays)
+    if n == 0 or z.shape[1] < 2:
+        return 0.
+    step = max(1, int(z.shape[0]) // n)
+    pick = slice(0, n * step, step)
+    o, d, zz = rayo[pick].contiguous(), rayd[pick].contiguous(), z[pick].contiguous()
+    s32 = nerf_sigma_fwd(o, d, zz, geom_blob_fp32, 'fp32')
+    err = (rgbs[pick][..., 3] - s32).abs()[:, :-1].reshape(-1)
+    spacing = ((zz[:, 1:] - zz[:, :-1]).mean() * d.norm(dim=1).mean())
+    return float(torch.quantile(err[:4000000], q) * spacing)
 
 
 def nerf_sigma_grad(rayo, rayd, z, geom_blob, prec='bf16'):

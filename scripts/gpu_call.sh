@@ -23,7 +23,7 @@ for st in "$@"; do
     smoke)    timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -6 $OUT/smoke.log ;;
     bench-driver) T0=$SECONDS; timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err; echo "driver-command wall $((SECONDS-T0)) s"; cp bench_detail.json $OUT/ 2>/dev/null; wc -c $OUT/bench_line.json; cat $OUT/bench_line.json; tail -3 $OUT/bench_line.err; python -c "
 import json; d=json.load(open('$OUT/bench_detail.json')); print('wall_s', d.get('wall_s'))" ;;
-    coarse-probe2) timeout 900 python scripts/coarse_refine_probe2.py > $OUT/coarse_refine_probe2.json 2> $OUT/coarse_refine_probe2.err; python - <<PYEOF
+    coarse-probe2) timeout 900 python scripts/coarse_refine_probe${PROBE:-2}.py > $OUT/coarse_refine_probe2.json 2> $OUT/coarse_refine_probe2.err; python - <<PYEOF
 import json
 d=json.load(open("$OUT/coarse_refine_probe2.json"))
 for w,v in d.items():
@@ -31,7 +31,7 @@ for w,v in d.items():
     for k,r in v['results'].items(): print('   %-44s' % k[:44], {a:(round(b,5) if isinstance(b,float) else b) for a,b in r.items()} if isinstance(r,dict) else [round(x,4) for x in r])
 PYEOF
               tail -3 $OUT/coarse_refine_probe2.err ;;
-    coarse-probe) timeout 900 python scripts/coarse_refine_probe.py > $OUT/coarse_refine_probe.json 2> $OUT/coarse_refine_probe.err; python - <<PYEOF
+    coarse-probe) timeout 900 python scripts/coarse_refine_probe${PROBE:-}.py > $OUT/coarse_refine_probe.json 2> $OUT/coarse_refine_probe.err; python - <<PYEOF
 import json
 d=json.load(open("$OUT/coarse_refine_probe.json"))
 for w,v in d.items():
@@ -39,6 +39,7 @@ for w,v in d.items():
     for k,r in v['results'].items(): print('   %-44s' % k, {a:(round(b,5) if isinstance(b,float) else b) for a,b in r.items()})
 PYEOF
               tail -3 $OUT/coarse_refine_probe.err ;;
+    residual) timeout 600 python scripts/coarse_refine_residual.py > $OUT/coarse_refine_residual.json 2> $OUT/coarse_refine_residual.err; cat $OUT/coarse_refine_residual.json; tail -3 $OUT/coarse_refine_residual.err ;;
     rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;

@@ -143,7 +143,7 @@ def test_sample_fine_vs_oracle(nfx_lib, cuda, nc, nf):
         np.testing.assert_allclose(got, want, atol=1e-5)
 
 
-def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16', refine=True):
+def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16', refine=True, refine_coarse=False):
     """The render of models/nerf.py:_render_rays spelled out in ops calls; with precision = bf16 every ray's last sample
     gets its density from the fp32-class kernel (ops.nerf_refine_last_sample; `refine=False` = the r03 render)."""
     from nerfactor_amd import ops
@@ -155,6 +155,8 @@ def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16', refine=True)
     raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
     if gblobs:
         ops.nerf_refine_last_sample(o, d, z, raw, gblobs[0])
+        if refine_coarse:      # models/nerf.py coarse_precision = select (auto: when the measured bf16 error says so)
+            ops.nerf_refine_coarse(o, d, z, raw, gblobs[0])
     rgb_c, occu_c, depth_c, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
     z_all = ops.sample_fine(z, w, n_fine)
     raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1], prec)
@@ -305,13 +307,18 @@ def test_full_frame_properties(nfx_lib, cuda):
 
 def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
     """800 x 800 x (64 + 128) through the TRAINED networks (no discontinuity band): a 4096-ray subset of the full-size
-    frame against the CPU oracle with a max-abs bound on at least 98 % of the rays (silhouette rays counted)."""
+    frame against the CPU oracle, max-abs 3e-2 on EVERY ray (round 6).  Until round 5 the bound held on >= 98 % of the rays:
+    on a fitted network the inverse-CDF sampler is chaotic on silhouette rays — bf16 density errors of 0.1-0.3 move their fine
+    samples across the density edge (0.4 % of the rays of a view, up to 0.23 off).  The render now re-evaluates the coarse
+    samples that decide (visible, not saturated, +-1) with the fp32-class density kernel (ops.nerf_refine_coarse; plugin:
+    coarse_precision = auto); without it the same frame must show the outliers."""
     import torch as _t
     from oracle import torch_ref
     from tests.golden import golden_inputs as gi
     nets = gi.trained_nerf_nets()
     rayo, rayd = common.camera_rays(800, 800, cam_loc=(1.9, -2.8, 2.1))
-    out = _render_device(rayo, rayd, nets, cuda)
+    out = _render_device(rayo, rayd, nets, cuda, refine_coarse=True)
+    plain = _render_device(rayo, rayd, nets, cuda)
     idx = np.random.default_rng(7).choice(rayo.shape[0], 4096, replace=False)
     tn = [torch_ref.to_torch_net(n) for n in nets]
     with _t.no_grad():
@@ -321,10 +328,133 @@ def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
     got = out['rgb_f'][_t.from_numpy(idx).to(cuda)].cpu().numpy()
     err = np.abs(got - want).max(1)
     bad = int((err > 3e-2).sum())
-    print("trained full frame: %d of 4096 rays above 3e-2 (max %.3e), PSNR %.1f dB" % (
-        bad, err.max(), nerf_ref.psnr_uint8_luma(got, want)))
-    assert bad <= 0.02 * 4096 and nerf_ref.psnr_uint8_luma(got, want) >= 40.
+    err0 = np.abs(plain['rgb_f'][_t.from_numpy(idx).to(cuda)].cpu().numpy() - want).max(1)
+    print("trained full frame: %d of 4096 rays above 3e-2 (max %.3e), PSNR %.1f dB; coarse_precision = bf16: %d rays (max %.3e)" % (
+        bad, err.max(), nerf_ref.psnr_uint8_luma(got, want), int((err0 > 3e-2).sum()), err0.max()))
+    assert bad == 0 and nerf_ref.psnr_uint8_luma(got, want) >= 40.
+    assert int((err0 > 3e-2).sum()) >= 1            # (the plain bf16 coarse pass does have such rays: the test proves something)
     assert 0.05 < float(out['occu_f'].mean()) < 0.6
+    # the whole frame against the fp32-class render of the same rays (7e-4 from the fp32 oracle): every one of the 640 000 rays
+    ref32 = _render_device(rayo, rayd, nets, cuda, prec='fp32')['rgb_f']
+    e_all = (out['rgb_f'] - ref32).abs().max(1)[0]
+    e_plain = (plain['rgb_f'] - ref32).abs().max(1)[0]
+    print("all 640 000 rays vs the fp32-class render: %d above 3e-2 (max %.3e); coarse_precision = bf16: %d (max %.3e)" % (
+        int((e_all > 3e-2).sum()), float(e_all.max()), int((e_plain > 3e-2).sum()), float(e_plain.max())))
+    # (measured: 27 rays — 0.004 % — against 2195 without the refinement.  The sampler's chaos does not end at any precision:
+    #  these rays also move between the fp32-class and a bit-different fp32 render; the oracle subset above is the bound
+    #  that is asserted on every ray, this one on all but 1e-4 of the frame and on the factor gained)
+    assert int((e_all > 3e-2).sum()) <= 64 and int((e_all > 3e-2).sum()) * 20 <= int((e_plain > 3e-2).sum())
+
+
+def test_refine_select_lists_the_deciding_samples(nfx_lib, cuda):
+    """nfx_nerf_refine_select against its definition in torch: visible (T > t_min), not saturated (a_lo < alpha < a_hi), grown
+    by `dilate` neighbours, never the last sample; ragged sample counts (S = 7, 64, 70: more than one 64-lane chunk)."""
+    from nerfactor_amd import _capi, ops
+    rng = np.random.default_rng(3)
+    for n, S, dilate, margin in ((513, 64, 1, 0.), (37, 7, 0, 0.), (130, 70, 2, 0.3), (9, 64, 0, 5.), (257, 64, 1, 0.5)):
+        z = dev(np.sort(rng.uniform(2, 6, size=(n, S)), -1), cuda)
+        rayd = dev(rng.normal(size=(n, 3)), cuda)
+        raw = dev(rng.normal(size=(n, S, 4)) * np.exp(rng.uniform(-2, 5, size=(n, 1, 1))), cuda)
+        raw[::5, :, 3] = -1.                                # empty rays: nothing is listed
+        lst = torch.full((n * S,), -7, dtype=torch.int32, device=cuda)
+        cnt = torch.full((1,), 99, dtype=torch.int32, device=cuda)
+        _capi.check(_capi.lib.nfx_nerf_refine_select(raw.data_ptr(), z.data_ptr(), rayd.data_ptr(), n, S, 1e-4, 1e-4, 0.9999, margin, dilate,
+                                                     lst.data_ptr(), cnt.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                    'nfx_nerf_refine_select')
+        k = int(cnt.item())
+        got = np.sort(lst[:k].cpu().numpy())
+        dist = torch.cat((z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)), 1) * rayd.norm(dim=1, keepdim=True)
+        alpha = 1 - torch.exp(-torch.relu(raw[..., 3]) * dist)
+        T = torch.cumprod(torch.cat((torch.ones_like(alpha[:, :1]), 1 - alpha[:, :-1] + 1e-6), 1), 1)
+        # a sample within 1e-3 (relative) of a threshold may legitimately fall on either side (expf vs torch.exp, the order of
+        # the transmittance product): the kernel's list must contain the samples that qualify with a margin and be contained
+        # in the samples that qualify with slack
+        def grow(m):
+            g = m.clone()
+            for j in range(1, dilate + 1):
+                g[:, j:] |= m[:, :-j]
+                g[:, :-j] |= m[:, j:]
+            g[:, -1] = False
+            return set(torch.nonzero(g.reshape(-1))[:, 0].cpu().numpy().tolist())
+        e = 1e-3
+        sg = raw[..., 3].abs()
+        sure = grow((T > 1e-4 * (1 + e)) & (((alpha > 1e-4 * (1 + e)) & (alpha < 0.9999 - 1e-6)) | (sg < margin * (1 - e))))
+        maybe = grow((T > 1e-4 * (1 - e)) & (((alpha > 1e-4 * (1 - e)) & (alpha < 0.9999 + 1e-6)) | (sg < margin * (1 + e))))
+        listed = set(got.tolist())
+        assert len(listed) == k and bool((lst[k:] == -7).all())          # no duplicates, nothing written past the count
+        assert sure <= listed <= maybe, (n, S, dilate, k, len(sure), len(maybe), sorted(sure - listed)[:5], sorted(listed - maybe)[:5])
+        assert len(maybe) - len(sure) <= 0.01 * max(len(sure), 100)
+        if n == 513:
+            assert len(sure) > 2000
+
+
+@pytest.mark.determinism
+def test_sigma_refine_writes_the_fp32_class_density_of_the_listed_samples(nfx_lib, cuda):
+    """ops.nerf_refine_coarse: the listed samples' density channel becomes BIT-identical to nfx_nerf_sigma_fwd(fp32) there,
+    everything else in rgbs stays untouched; an empty list (all-empty rays) changes nothing; run twice = same bits."""
+    from nerfactor_amd import ops
+    from tests.golden import golden_inputs as gi
+    net = gi.trained_nerf_nets()[0]
+    blob = ops.pack_nerf_weights(*common.nerf_layers(net)).to(cuda)
+    gblob = ops.pack_nerf_geom_weights(*common.nerf_layers(net), prec='fp32').to(cuda)
+    rayo, rayd = common.camera_rays(96, 96, cam_loc=(1.9, -2.8, 2.1))
+    o, d = dev(rayo, cuda), ops.l2_normalize3(dev(rayd, cuda), 1e-12)
+    z = ops.gen_z(2., 6., 64, o.shape[0], device=cuda)
+    raw0 = ops.nerf_mlp_fwd(o, d, z, blob)
+    s32 = ops.nerf_sigma_fwd(o, d, z, gblob, 'fp32')
+    outs = []
+    for _ in range(2):
+        raw = raw0.clone()
+        _, cnt = ops.nerf_refine_coarse(o, d, z, raw, gblob, want_count=True)
+        outs.append(raw)
+    k = int(cnt.item())
+    assert 0.01 * z.numel() < k < 0.5 * z.numel(), k
+    assert torch.equal(outs[0], outs[1])
+    changed = outs[0][..., 3] != raw0[..., 3]
+    assert torch.equal(outs[0][..., :3], raw0[..., :3])
+    assert torch.equal(outs[0][..., 3][changed], s32[changed])
+    # every listed sample carries the fp32-class value (a listed sample whose two values coincide does not show up in `changed`)
+    assert int(changed.sum()) <= k and int(changed.sum()) >= 0.9 * k
+    empty = raw0.clone()
+    empty[..., 3] = -5.
+    _, cnt = ops.nerf_refine_coarse(o, d, z, empty, gblob, want_count=True)
+    assert int(cnt.item()) == 0 and bool((empty[..., 3] == -5.).all())
+
+
+def test_plugin_coarse_precision_auto_follows_the_measured_error(nfx_lib, cuda):
+    """models/nerf.py: coarse_precision = auto measures the bf16 density error of the weights at hand once per weight version —
+    the fitted networks switch the selective refinement on, freshly initialised (glorot) ones do not — and `select` / `bf16`
+    force it either way; the auto render of the fitted networks equals the `select` render bit for bit."""
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    from tests.golden import golden_inputs as gi
+    rayo, rayd = common.camera_rays(64, 64, cam_loc=(1.9, -2.8, 2.1))
+    batch = (None, None, dev(rayo, cuda), dev(rayd, cuda), dev(np.zeros_like(rayo), cuda))
+
+    def model_with(nets, **kw):
+        torch.manual_seed(0)
+        model = get_model_class('nerf')(make_config('nerf', **kw))
+        if nets is not None:
+            with torch.no_grad():
+                for pref, net in zip(('coarse_', 'fine_'), nets):
+                    for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+                        for layer, (k, b) in zip(model.net[pref + part].layers, net[part]):
+                            layer.kernel.copy_(torch.from_numpy(np.asarray(k, np.float32)))
+                            layer.bias.copy_(torch.from_numpy(np.asarray(b, np.float32)))
+        return model.to(cuda)
+    fitted = gi.trained_nerf_nets()
+    auto = model_with(fitted)
+    assert auto.coarse_precision == 'auto'
+    with torch.no_grad():
+        p_auto = auto(batch, mode='test')[0]['fine']
+        p_sel = model_with(fitted, coarse_precision='select')(batch, mode='test')[0]['fine']
+        p_off = model_with(fitted, coarse_precision='bf16')(batch, mode='test')[0]['fine']
+        fresh = model_with(None)
+        fresh(batch, mode='test')
+    assert auto._coarse_gate[1] is True and auto._coarse_gate[2] > auto.coarse_refine_gate
+    assert fresh._coarse_gate[1] is False and fresh._coarse_gate[2] < fresh.coarse_refine_gate
+    print("measured bf16 alpha error: fitted %.2e, fresh glorot %.2e (gate %.0e)" % (auto._coarse_gate[2], fresh._coarse_gate[2], auto.coarse_refine_gate))
+    assert torch.equal(p_auto, p_sel) and not torch.equal(p_auto, p_off)
 
 
 @pytest.mark.determinism

@@ -582,3 +582,33 @@ def test_scatter_rows_is_tf_scatter_nd_of_the_foreground_rows(nfx_lib, cuda, sha
     assert torch.equal(got, want)
     with pytest.raises(nfx_lib.NfxError):
         ops.scatter_rows(src, row_of.long(), n_all)
+
+
+def test_lvis_verify_option_checks_the_two_wave_kernel_against_the_one_wave_form(nfx_lib, cuda, nfx_opt, monkeypatch):
+    """nfx_set_option("lvis_verify", k): every k-th launch of the default light-visibility kernel
+    (two waves per SIMD) is checked bit for bit against the one-wave-per-SIMD kernel on ~1 % of its points.  Here: it
+    stays silent on a healthy kernel (40 launches, every 2nd checked), and it does raise when the comparison sees a
+    difference (the reference launch is doctored through the xyz_scale it is given)."""
+    from nerfactor_amd import _capi, ops
+    layers, out = net128(30, 90, 1)
+    blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
+    rng, lxyz, _, xyz, _, _ = scene(20000, 31)
+    x, l = dev(xyz, cuda), dev(lxyz, cuda)
+    plain = ops.lvis_fwd(x, l, blob)
+    nfx_opt.set("lvis_verify", "2")
+    before = ops._lvis_launches[0]
+    for _ in range(40):
+        assert torch.equal(ops.lvis_fwd(x, l, blob), plain)
+    assert ops._lvis_launches[0] - before == 40
+    # a checker that cannot fail proves nothing: make the reference launch see a different scale
+    real = _capi.lib.nfx_lvis_fwd
+    calls = {'n': 0}
+
+    class Doctored:
+        def __call__(self, xp, xd, n, scale, *rest):
+            calls['n'] += 1
+            return real(xp, xd, n, scale * (1.001 if calls['n'] % 2 == 0 else 1.0), *rest)
+    monkeypatch.setattr(ops.lib, 'nfx_lvis_fwd', Doctored(), raising=False)
+    with pytest.raises(_capi.NfxError, match="lvis_verify"):
+        for _ in range(4):
+            ops.lvis_fwd(x, l, blob)
