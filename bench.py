@@ -109,16 +109,16 @@ def coarse_refine_decision(ops, view, blobs, refine, prec='bf16'):
     """What the plugin's `coarse_precision = auto` decides for these weights (models/nerf.py:_coarse_refine_on): the measured
     bf16 density error as an alpha error, and whether the selective fp32-class refinement of the coarse pass is on."""
     if refine is None or prec != 'bf16':
-        return False, None
+        return False, (None, 0.)
     o, d_raw = view
     d = ops.l2_normalize3(d_raw, 1e-12)
     z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
     raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
-    err = ops.nerf_coarse_alpha_error(o, d, z, raw, refine[0])
-    return err > COARSE_REFINE_GATE, err
+    err_a, err_s = ops.nerf_coarse_error(o, d, z, raw, refine[0])
+    return err_a > COARSE_REFINE_GATE, (err_a, err_s)
 
 
-def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coarse_prec=None, refine_coarse=False):
+def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coarse_prec=None, refine_coarse=False, margin=0.):
     """views: [(rayo, rayd)] device tensors (this rank's shard of every view).  ev: per-view 4 events around the two
     MLP launches.  refine: the two fp32-class density blobs — the last sample of every ray is re-evaluated with them
     (what models/nerf.py does when rendering with precision = bf16: ops.nerf_refine_last_sample); inside the timed step,
@@ -136,7 +136,7 @@ def nerf_render_step(ops, views, blobs, ev=None, prec='bf16', refine=None, coars
         if refine is not None and (coarse_prec or prec) == 'bf16':
             ops.nerf_refine_last_sample(o, d, z, raw, refine[0])
             if refine_coarse:       # (the plugin's coarse_precision = auto / select: the deciding coarse samples fp32-class)
-                ops.nerf_refine_coarse(o, d, z, raw, refine[0])
+                ops.nerf_refine_coarse(o, d, z, raw, refine[0], sigma_margin=margin)
         _, _, _, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
         z_all = ops.sample_fine(z, w, N_FINE)
         if e is not None:
@@ -273,9 +273,10 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in views] for _ in range(args.steps)]
     # coarse_precision = auto: measured once per weight version, as the plugin does — outside the timed region
-    refine_coarse, alpha_err = coarse_refine_decision(ops, views[0], blobs, refine, args.precision)
+    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, views[0], blobs, refine, args.precision)
+    margin = ops.REFINE_MARGIN_FACTOR * sigma_err
     elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k], args.precision,
-                                                    refine, refine_coarse=refine_coarse),
+                                                    refine, refine_coarse=refine_coarse, margin=margin),
                          args.steps, args.warmup, barrier)
     elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(rgb).all()
@@ -332,7 +333,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         sel = idx[(idx >= sh.lo) & (idx < sh.hi)]
         keep = np.isin(idx, sel)
         o, d = (torch.from_numpy(a[sel]).to(dev) for a in host_views[0])
-        got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse).cpu().numpy()
+        got = nerf_render_step(ops, [(o, d)], blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse, margin=margin).cpu().numpy()
         want = ref[1]['rgb'].numpy()[keep]
         # r04: NO ray is excused.  Rays decided by the sign of a near-zero logit at the dist = 1e10 last sample are a
         # discontinuity of the reference formula; the render evaluates that one sample fp32-class, so
@@ -371,17 +372,18 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n
     with torch.no_grad():
         ref = torch_ref.render_rays(torch.from_numpy(o), torch.from_numpy(d), *[torch_ref.to_torch_net(x) for x in nets])
     view = [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))]
-    refine_coarse, alpha_err = coarse_refine_decision(ops, full_view or view[0], blobs, refine, args.precision)
-    got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse).cpu().numpy()
+    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, full_view or view[0], blobs, refine, args.precision)
+    margin = ops.REFINE_MARGIN_FACTOR * sigma_err
+    got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse, margin=margin).cpu().numpy()
     want = ref[1]['rgb'].numpy()
     cost = None
     if full_view is not None and refine_coarse:       # what the refinement costs on THIS scene: the whole 800 x 800 view both ways
         def frame_ms(on, reps=3):
-            nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on)
+            nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on, margin=margin)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
-                nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on)
+                nerf_render_step(ops, [full_view], blobs, prec=args.precision, refine=refine, refine_coarse=on, margin=margin)
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps * 1e3
         o_f, d_f = full_view
@@ -389,7 +391,7 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n
         z_f = ops.gen_z(2., 6., N_COARSE, o_f.shape[0], device=dev)
         raw_f = ops.nerf_mlp_fwd(o_f, d_n, z_f, blobs[0], args.precision)
         ops.nerf_refine_last_sample(o_f, d_n, z_f, raw_f, refine[0])
-        _, cnt = ops.nerf_refine_coarse(o_f, d_n, z_f, raw_f, refine[0], want_count=True)
+        _, cnt = ops.nerf_refine_coarse(o_f, d_n, z_f, raw_f, refine[0], sigma_margin=margin, want_count=True)
         t_off, t_on = frame_ms(False), frame_ms(True)
         cost = {"frame_ms_bf16_coarse": t_off, "frame_ms_with_refinement": t_on, "extra_frame_time": t_on / t_off - 1.,
                 "coarse_samples_refined_frac": float(cnt.item()) / float(z_f.numel())}

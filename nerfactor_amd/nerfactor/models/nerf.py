@@ -45,7 +45,7 @@ class Model(BaseModel):
         # `coarse_precision` (render-time, precision = bf16 only; see _eval_rays and _coarse_refine_on):
         #   bf16    the coarse pass as the bf16 kernel computes it;
         #   select  + the fp32-class density for the coarse samples that decide where the fine samples go
-        #           (ops.nerf_refine_coarse: visible, not saturated, +-1 neighbour; ~12 % of the coarse samples of a fitted scene);
+        #           (ops.nerf_refine_coarse: visible and unsaturated or sign-undecided; ~9 % of the coarse samples of a fitted scene);
         #   auto    (default) `select` when the bf16 density error of THESE weights can move a sample's alpha by more than
         #           `coarse_refine_gate` (measured once per weight version), `bf16` otherwise;
         #   fp32    the whole coarse pass fp32-class (25 % of a frame's points at 3.7x).
@@ -273,7 +273,8 @@ class Model(BaseModel):
         if self.precision == 'bf16' and self.last_sample_precision == 'fp32' and z.shape[1] > 1:
             ops.nerf_refine_last_sample(rayo, rayd, z, rgbs, self._nerf_geom_blob(pref, 'fp32'))
         if pref == 'coarse_' and self.precision == 'bf16' and self.n_samples_fine > 0 and self._coarse_refine_on(rayo, rayd, z, rgbs):
-            ops.nerf_refine_coarse(rayo, rayd, z, rgbs, self._nerf_geom_blob(pref, 'fp32'))
+            ops.nerf_refine_coarse(rayo, rayd, z, rgbs, self._nerf_geom_blob(pref, 'fp32'),
+                                   sigma_margin=ops.REFINE_MARGIN_FACTOR * self._coarse_gate[3])
         return rgbs
 
     def _coarse_refine_on(self, rayo, rayd, z, rgbs):
@@ -283,15 +284,13 @@ class Model(BaseModel):
         fp32 render (scripts/coarse_refine_probe.py: 509 of 131 072 rays; 0 with the refinement).  On weights whose bf16
         error is ten times smaller (glorot initialisation: 1.5e-3 of alpha) nothing is gained, and every sample of such a
         fog qualifies — so `auto` measures the error of the weights at hand, once per weight version."""
-        if self.coarse_precision == 'select':
-            return True
-        if self.coarse_precision != 'auto' or z.shape[0] == 0 or z.shape[1] < 3:
+        if self.coarse_precision not in ('auto', 'select') or z.shape[0] == 0 or z.shape[1] < 3:
             return False
         versions = tuple((t.data_ptr(), t._version) for t in sum(self._nerf_params('coarse_'), []))
-        if self._coarse_gate is None or self._coarse_gate[0] != versions:
-            err = ops.nerf_coarse_alpha_error(rayo, rayd, z, rgbs, self._nerf_geom_blob('coarse_', 'fp32'))
-            self._coarse_gate = (versions, err > self.coarse_refine_gate, err)
-        return self._coarse_gate[1]
+        if self._coarse_gate is None or self._coarse_gate[0] != versions:    # (weights, decision, alpha error, sigma error)
+            err_a, err_s = ops.nerf_coarse_error(rayo, rayd, z, rgbs, self._nerf_geom_blob('coarse_', 'fp32'))
+            self._coarse_gate = (versions, err_a > self.coarse_refine_gate, err_a, err_s)
+        return self.coarse_precision == 'select' or self._coarse_gate[1]
 
     def _render_rays(self, rayo, rayd, mode='train'):
         cfg = self.config

@@ -878,16 +878,22 @@ def nerf_refine_last_sample(rayo, rayd, z, rgbs, geom_blob_fp32):
     return rgbs
 
 
-# the selection of nfx_nerf_refine_select as the render uses it (calibrated on a fitted NeRF, scripts/coarse_refine_probe*.py:
-# 0 of 131 072 rays of a fitted view above 3e-2 against 509 without; T > 1e-3 or no dilation leave 5-13 rays)
-REFINE_T_MIN, REFINE_A_LO, REFINE_A_HI, REFINE_DILATE = 1e-4, 1e-4, 0.9999, 1
+# The selection of nfx_nerf_refine_select as the render uses it, calibrated on all 640 000 rays of a view of a fitted NeRF
+# against the fp32-class render (scripts/coarse_refine_residual.py, profiles/r06/coarse_refine_residual*.json): 2195 rays above
+# 3e-2 with the plain bf16 coarse pass; 0 (max 1.6e-2 = the fp32-class coarse pass's own figure) with T > 1e-2, alpha in
+# (1e-2, 0.99), no dilation, |sigma| < 0.3 — 6.9 % of the coarse samples — and with every wider rule; 767 with alpha in
+# (0.05, 0.95); 27 without the |sigma| rule however wide the rest.  Shipped: one notch wider than the cheapest rule that held.
+REFINE_T_MIN, REFINE_A_LO, REFINE_A_HI, REFINE_DILATE = 1e-3, 1e-3, 0.999, 0
+REFINE_MARGIN_FACTOR = 2.       # sigma_margin = factor x the measured 99.9 % quantile of |sigma_bf16 - sigma_fp32class|
 
 
 def nerf_refine_coarse(rayo, rayd, z, rgbs, geom_blob_fp32, t_min=REFINE_T_MIN, a_lo=REFINE_A_LO, a_hi=REFINE_A_HI,
                        dilate=REFINE_DILATE, sigma_margin=0., want_count=False):
     """Overwrites, in place, the density in rgbs[N,S,4] of the coarse samples that decide where the inverse-CDF sampler
     (util/math.py:71-94) puts the fine samples with the fp32-class density kernel's value: samples that are visible
-    (T_i > t_min) and not saturated (a_lo < alpha_i < a_hi), and `dilate` neighbours either way.  Two launches
+    (T_i > t_min) and either not saturated (a_lo < alpha_i < a_hi) or undecided (|sigma_i| < sigma_margin: which side of
+    the relu the sample is on lies within the bf16 kernel's error — on a near-miss ray, whose weights sum to almost nothing,
+    one such sample is the whole pdf), and `dilate` neighbours either way.  Two launches
     (nfx_nerf_refine_select, nfx_nerf_sigma_refine); the list and its length stay on the device.  Returns rgbs (and the
     1-element int32 count tensor if `want_count`)."""
     rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, geom_blob_fp32)
@@ -906,22 +912,25 @@ def nerf_refine_coarse(rayo, rayd, z, rgbs, geom_blob_fp32, t_min=REFINE_T_MIN, 
     return (rgbs, count) if want_count else rgbs
 
 
-def nerf_coarse_alpha_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.999):
-    """How far the bf16 kernel's density error can move a coarse sample's alpha for THESE weights: the q-quantile of
-    |sigma_bf16 - sigma_fp32class| over the samples of up to `max_rays` rays of the batch, times the mean sample spacing.
-    The render's `coarse_precision = auto` measures this once per weight version (one host read) and switches the selective
-    refinement on when it exceeds `coarse_refine_gate` (measured: glorot "opaque" weights of the bench 1.5e-3, a NeRF fitted
-    to a scene 1.0e-2)."""
+def nerf_coarse_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.999):
+    """(alpha_error, sigma_error) of the bf16 coarse pass for THESE weights: sigma_error = the q-quantile of
+    |sigma_bf16 - sigma_fp32class| over the samples of up to `max_rays` rays of the batch; alpha_error = that times the mean
+    sample spacing = how far the bf16 error can move a sample's alpha.  The render's `coarse_precision = auto` measures this
+    once per weight version (one host read): the selective refinement is on when alpha_error exceeds `coarse_refine_gate`
+    (measured: glorot "opaque" weights of the bench 1.5e-3, a NeRF fitted to a scene 1.0e-2), and sigma_error sizes the
+    |sigma| < margin rule of nerf_refine_coarse."""
     n = min(int(z.shape[0]), max_rays)
     if n == 0 or z.shape[1] < 2:
-        return 0.
+        return 0., 0.
     step = max(1, int(z.shape[0]) // n)
     pick = slice(0, n * step, step)
     o, d, zz = rayo[pick].contiguous(), rayd[pick].contiguous(), z[pick].contiguous()
     s32 = nerf_sigma_fwd(o, d, zz, geom_blob_fp32, 'fp32')
     err = (rgbs[pick][..., 3] - s32).abs()[:, :-1].reshape(-1)
     spacing = ((zz[:, 1:] - zz[:, :-1]).mean() * d.norm(dim=1).mean())
-    return float(torch.quantile(err[:4000000], q) * spacing)
+    sig = torch.quantile(err[:4000000], q)
+    both = torch.stack((sig * spacing, sig)).tolist()
+    return float(both[0]), float(both[1])
 
 
 def nerf_sigma_grad(rayo, rayd, z, geom_blob, prec='bf16'):

@@ -156,7 +156,8 @@ def _render_device(rayo, rayd, nets, cuda, n_fine=128, prec='bf16', refine=True,
     if gblobs:
         ops.nerf_refine_last_sample(o, d, z, raw, gblobs[0])
         if refine_coarse:      # models/nerf.py coarse_precision = select (auto: when the measured bf16 error says so)
-            ops.nerf_refine_coarse(o, d, z, raw, gblobs[0])
+            ops.nerf_refine_coarse(o, d, z, raw, gblobs[0],
+                                   sigma_margin=ops.REFINE_MARGIN_FACTOR * ops.nerf_coarse_error(o, d, z, raw, gblobs[0])[1])
     rgb_c, occu_c, depth_c, _, w = ops.composite_fwd(raw, z, d, white_bg=True)
     z_all = ops.sample_fine(z, w, n_fine)
     raw = ops.nerf_mlp_fwd(o, d, z_all, blobs[1], prec)
@@ -310,7 +311,7 @@ def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
     frame against the CPU oracle, max-abs 3e-2 on EVERY ray (round 6).  Until round 5 the bound held on >= 98 % of the rays:
     on a fitted network the inverse-CDF sampler is chaotic on silhouette rays — bf16 density errors of 0.1-0.3 move their fine
     samples across the density edge (0.4 % of the rays of a view, up to 0.23 off).  The render now re-evaluates the coarse
-    samples that decide (visible, not saturated, +-1) with the fp32-class density kernel (ops.nerf_refine_coarse; plugin:
+    samples that decide (visible and unsaturated or sign-undecided) with the fp32-class density kernel (ops.nerf_refine_coarse; plugin:
     coarse_precision = auto); without it the same frame must show the outliers."""
     import torch as _t
     from oracle import torch_ref
@@ -340,10 +341,10 @@ def test_full_frame_of_the_trained_nerf_vs_oracle(nfx_lib, cuda):
     e_plain = (plain['rgb_f'] - ref32).abs().max(1)[0]
     print("all 640 000 rays vs the fp32-class render: %d above 3e-2 (max %.3e); coarse_precision = bf16: %d (max %.3e)" % (
         int((e_all > 3e-2).sum()), float(e_all.max()), int((e_plain > 3e-2).sum()), float(e_plain.max())))
-    # (measured: 27 rays — 0.004 % — against 2195 without the refinement.  The sampler's chaos does not end at any precision:
-    #  these rays also move between the fp32-class and a bit-different fp32 render; the oracle subset above is the bound
-    #  that is asserted on every ray, this one on all but 1e-4 of the frame and on the factor gained)
-    assert int((e_all > 3e-2).sum()) <= 64 and int((e_all > 3e-2).sum()) * 20 <= int((e_plain > 3e-2).sum())
+    # (measured: 0 rays, max 1.6e-2 = what a whole fp32-class coarse pass gives, against 2195 rays / 0.25 without the refinement;
+    #  without the |sigma| < margin rule 27 rays stayed, each a near-miss ray whose pdf is one sample the bf16 kernel put on
+    #  the wrong side of the relu)
+    assert int((e_all > 3e-2).sum()) == 0 and int((e_plain > 3e-2).sum()) >= 100
 
 
 def test_refine_select_lists_the_deciding_samples(nfx_lib, cuda):
@@ -408,7 +409,7 @@ def test_sigma_refine_writes_the_fp32_class_density_of_the_listed_samples(nfx_li
         _, cnt = ops.nerf_refine_coarse(o, d, z, raw, gblob, want_count=True)
         outs.append(raw)
     k = int(cnt.item())
-    assert 0.01 * z.numel() < k < 0.5 * z.numel(), k
+    assert 0.005 * z.numel() < k < 0.5 * z.numel(), k
     assert torch.equal(outs[0], outs[1])
     changed = outs[0][..., 3] != raw0[..., 3]
     assert torch.equal(outs[0][..., :3], raw0[..., :3])
@@ -451,7 +452,7 @@ def test_plugin_coarse_precision_auto_follows_the_measured_error(nfx_lib, cuda):
         p_off = model_with(fitted, coarse_precision='bf16')(batch, mode='test')[0]['fine']
         fresh = model_with(None)
         fresh(batch, mode='test')
-    assert auto._coarse_gate[1] is True and auto._coarse_gate[2] > auto.coarse_refine_gate
+    assert auto._coarse_gate[1] is True and auto._coarse_gate[2] > auto.coarse_refine_gate and auto._coarse_gate[3] > 0.05
     assert fresh._coarse_gate[1] is False and fresh._coarse_gate[2] < fresh.coarse_refine_gate
     print("measured bf16 alpha error: fitted %.2e, fresh glorot %.2e (gate %.0e)" % (auto._coarse_gate[2], fresh._coarse_gate[2], auto.coarse_refine_gate))
     assert torch.equal(p_auto, p_sel) and not torch.equal(p_auto, p_off)
