@@ -348,11 +348,37 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
             "rays_with_abs_sigma_last_below_0.06": int((sig <= 0.06).sum()),
             "last_sample": "bf16 (no refine)" if refine is None else "fp32-class density (ops.nerf_refine_last_sample)",
             "reference": "oracle/torch_ref.py (fp32) on the same rays; tolerance PSNR >= 40 dB, max-abs <= 3e-2"}
+        if args.precision == 'bf16':
+            out["parity_vs_reference"] = reference_fixture_parity(
+                ops, dev, host_views[0], 'glorot', lambda oo, dd: nerf_render_step(
+                    ops, [(oo, dd)], blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse, margin=margin))
         if base is not None:
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = out["value"] / base["value"]
         out["parity_fitted_weights"] = nerf_fitted_parity(args, ops, dev, host_views[0], refine is not None, views[0] if world == 1 else None)
     return out
+
+
+REFERENCE_LARGE = os.path.join(ROOT, 'tests', 'golden', 'reference_large.npz')
+
+
+def reference_fixture_parity(ops, dev, host_view, tag, render):
+    """The timed view's 8192 fixture rays against the outputs of the REFERENCE'S OWN Python (tests/golden/reference_large.npz:
+    nerfactor/models/nerf.py Model.call on the NumPy TensorFlow stand-in, make_reference_large_golden.py; weights `tag` =
+    glorot | fitted).  `render(o, d)` -> rgb of the fine level.  None when the fixture is not there."""
+    if not os.path.exists(REFERENCE_LARGE):
+        return None
+    gold = np.load(REFERENCE_LARGE)
+    idx = gold['nerfbig_ray_index'].astype(np.int64)
+    o, d = host_view[0][idx], host_view[1][idx]
+    if not np.allclose([o.astype(np.float64).sum(), d.astype(np.float64).sum()], gold['nerfbig_ray_checksum'], rtol=1e-6):
+        return {"error": "the bench view is not the view of the fixture"}
+    got = render(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)).cpu().numpy()
+    want = gold['nerfbig_%s_fine_rgb' % tag]
+    err = np.abs(got - want).max(1)
+    return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()), "rays_compared": int(len(idx)),
+            "rays_above_3e-2": int((err > 3e-2).sum()), "median_abs": float(np.median(err)),
+            "reference": "tests/golden/reference_large.npz: the reference's own nerf.py Model.call on these rays of the timed view"}
 
 
 def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n=2048):
@@ -409,7 +435,10 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n
         e32 = np.abs(g32 - want).max(1)
         coarse32 = {"psnr_db": psnr_uint8_luma(g32, want), "max_abs_all_rays": float(e32.max()),
                     "rays_above_3e-2": int((e32 > 3e-2).sum()), "what": "ini key coarse_precision = fp32: +67 % frame time (r04 call B)"}
+    vs_ref = reference_fixture_parity(ops, dev, host_view, 'fitted', lambda oo, dd: nerf_render_step(
+        ops, [(oo, dd)], blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse, margin=margin)) if args.precision == 'bf16' else None
     return {"psnr_db": psnr_uint8_luma(got, want), "max_abs": float(err.max()), "coarse_precision_fp32": coarse32,
+            "vs_reference": vs_ref,
             "coarse_precision": "auto: measured bf16 alpha error %s -> selective refinement %s" % (
                 "n/a" if alpha_err is None else "%.2e" % alpha_err, "ON" if refine_coarse else "off"),
             "coarse_refinement_cost": cost, "coarse_precision_bf16": no_refine,
@@ -1213,10 +1242,17 @@ def compact(full):
             line["gpu_over_cpu"] = full["gpu_over_cpu"]
     if "parity" in full:
         line["parity"] = _parity_block(full["parity"], "rays_above_tol", "rays_above_3e-2", "rays_compared")
+        line["parity"]["against"] = "CPU port (oracle/torch_ref.py, fp32) on rays of the timed frame"
         line["parity"]["tolerance"] = "PSNR >= 40 dB, max-abs <= 3e-2 on every ray (BASELINE.md section 4)"
+        pr = full.get("parity_vs_reference")
+        if isinstance(pr, dict) and "error" not in pr:     # the same frame against outputs of the reference's own Python
+            line["parity"]["vs_reference_python"] = _parity_block(pr, "rays_above_tol", "rays_above_3e-2", "rays_compared")
         pf = full.get("parity_fitted_weights")
         if pf:
             line["parity"]["fitted_weights"] = _parity_block(pf, "rays_above_tol", "rays_above_3e-2", "rays_compared")
+            if isinstance(pf.get("vs_reference"), dict) and "error" not in pf["vs_reference"]:
+                line["parity"]["fitted_weights"]["vs_reference_python"] = _parity_block(
+                    pf["vs_reference"], "rays_above_tol", "rays_above_3e-2", "rays_compared")
             cost = pf.get("coarse_refinement_cost") or {}
             if cost:       # what holding the tolerance on every ray of a FITTED scene costs there (the timed frame: glorot weights)
                 line["parity"]["fitted_weights"]["refine_extra_frame_time"] = cost.get("extra_frame_time")

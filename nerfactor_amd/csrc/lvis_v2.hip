@@ -589,8 +589,13 @@ __device__ __forceinline__ void brdf_row_angles(const float (&x)[3], const float
 // rows).  Through ds_bpermute (NFX_BRDF_SWAP=1, the default: the LDS crossbar, counted by lgkmcnt) the 8-wave kernel is
 // bit-identical to the 4-wave one on every call (scripts/brdf_nw8_soak.py).  One wave per SIMD never showed the fault
 // (10^10 rows in round 2), but the shipped form does not depend on those wait states any more.
+#ifdef NFX_XP_VGPR_CAP      // round-6 experiment: the two-waves-per-SIMD forms may not touch the top of their half of the register file
+#define NFX_XP_CAP_ATTR __attribute__((amdgpu_num_vgpr(NFX_XP_VGPR_CAP)))      // (an integer constant: every instantiation; the one-wave reference forms spill, slower but the same sums)
+#else
+#define NFX_XP_CAP_ATTR
+#endif
 template <int CT, int GEO, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
+__global__ __launch_bounds__(NW * 64, NW / 4) NFX_XP_CAP_ATTR void brdf_compact_kernel(Args a) {
     constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
@@ -644,6 +649,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 nr[k] = a.normal[pt * 3 + k];
             }
             world2local(nr, rot);
+#ifdef NFX_XP_LDS_INPUTS
+            // round-6 experiment: the GEO = 0 pass takes its per-point inputs from the wave's LDS table instead of per-lane
+            // global loads (x, cam, normal, z: raw values, the per-row op sequence unchanged) — no vector-memory LOAD inside a pass
+            if constexpr (!kPark) {
+                float cmx[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cmx[k] = a.cam[pt * 3 + k];
+                const float* zp = a.z + pt * a.z_dim;
+                float zv[17];
+#pragma unroll
+                for (int i = 0; i < 17; ++i) zv[i] = i < a.z_dim ? zp[i] : 0.0f;
+                if (lane == 0) {
+                    f32x4* ps = reinterpret_cast<f32x4*>(ptab + (int)(kfill & (kSlots - 1)) * 32);
+                    ps[0] = f32x4{x[0], x[1], x[2], cmx[0]};
+                    ps[1] = f32x4{cmx[1], cmx[2], nr[0], nr[1]};
+                    ps[2] = f32x4{nr[2], zv[0], zv[1], zv[2]};
+                    ps[3] = f32x4{zv[3], zv[4], zv[5], zv[6]};
+                    ps[4] = f32x4{zv[7], zv[8], zv[9], zv[10]};
+                    ps[5] = f32x4{zv[11], zv[12], zv[13], zv[14]};
+                    ps[6] = f32x4{zv[15], zv[16], 0.f, 0.f};
+                }
+            }
+#endif
             if constexpr (kPark) {
                 float cm[3], prot[9], pvl[3];
 #pragma unroll
@@ -756,7 +784,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 for (int cc = 0; cc < 2; ++cc) {
                     // the latent code of the row's point: z_0 (slot 7 of half 1) and this half's z_{1 + 2j + h}
                     const f32x4* pz = reinterpret_cast<const f32x4*>(ptab + rslot[k2 + cc] * 32);
-#ifdef NFX_XP_FORCE_SCRATCH
+#ifdef NFX_XP_USE_V255
+                    // round-6 experiment: the healthy <2, 1, 8> made to keep a live value in v255 (its allocation stops at v246)
+                    int hs;
+                    asm volatile("v_mov_b32 v255, %1\n\ts_nop 4\n\tv_mov_b32 %0, v255" : "=v"(hs) : "v"(h) : "v255");
+#elif defined(NFX_XP_FORCE_SCRATCH)
                     const int hs = xp_slot[0];          // h, re-loaded from scratch memory
                     xp_slot[2] = xp_slot[2] + cc;       // and a slot that is re-stored in the loop, like the spilled constant pair
 #else
@@ -783,6 +815,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 const long long pt = rpt[c];
                 const int l = rl[c];
                 float x[3], lp[3], cm[3], nr[3];
+#ifdef NFX_XP_LDS_INPUTS
+                const float* row = ptab + rslot[c] * 32;
+                const float* zsrc = row + 9;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    x[k] = row[k];
+                    lp[k] = lx[l * 3 + k];
+                    cm[k] = row[3 + k];
+                    nr[k] = row[6 + k];
+                }
+#else
+                const float* zsrc = a.z + pt * a.z_dim;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     x[k] = a.xyz[pt * 3 + k];
@@ -790,15 +834,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                     cm[k] = a.cam[pt * 3 + k];
                     nr[k] = a.normal[pt * 3 + k];
                 }
+#endif
                 float v[16];
 #ifdef NFX_XP_NOSCRATCH
                 // round-6 experiment: <2, 0, 8> without its scratch spill — the lane half is re-derived where it is used
                 // (a volatile asm is neither hoisted nor kept live across the pass), so nothing has to be spilled for it
                 int hx;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshrrev_b32 %0, 5, %0" : "=v"(hx));
-                brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, hx, v);
+                brdf_row_inputs<GEO>(x, lp, cm, nr, zsrc, a.z_dim, hx, v);
 #else
-                brdf_row_inputs<GEO>(x, lp, cm, nr, a.z + pt * a.z_dim, a.z_dim, h, v);
+                brdf_row_inputs<GEO>(x, lp, cm, nr, zsrc, a.z_dim, h, v);
 #endif
 #pragma unroll
                 for (int sidx = 0; sidx < 2; ++sidx) {
@@ -808,6 +853,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 }
             }
         }
+#ifdef NFX_XP_CLOBBER_TOP     // round-6 experiment: nothing of this wave lives in v248 .. v255 across this point
+        asm volatile("" ::: "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+#endif
         bf16x8 ha[8][CT], hb[8][CT];
         Acc<CT> accs[2];
         Pre pre;
@@ -829,6 +877,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
         NFX_LV3_TILE(5, 8, 0, ha, pl, NFX_LV3_EPI(4, hb, 0), NFX_LV3_BIAS(128 + 64));
         NFX_LV3_TILE(6, 8, 0, ha, pl, NFX_LV3_EPI(5, hb, 1), NFX_LV3_BIAS(128 + 96));
         NFX_LV3_TILE(7, 8, 0, ha, pl, NFX_LV3_EPI(6, hb, 2), NFX_LV3_BIAS(256));
+#ifdef NFX_XP_CLOBBER_TOP     // round-6 experiment: nothing of this wave lives in v248 .. v255 across this point
+        asm volatile("" ::: "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+#endif
         NFX_LV3_TILE(8, 8, 0, hb, pl, NFX_LV3_EPI(7, hb, 3), NFX_LV3_BIAS(256 + 32));
         NFX_LV3_TILE(9, 8, 0, hb, pl, NFX_LV3_EPI(8, ha, 0), NFX_LV3_BIAS(256 + 64));
         NFX_LV3_TILE(10, 8, 0, hb, pl, NFX_LV3_EPI(9, ha, 1), NFX_LV3_BIAS(256 + 96));
@@ -850,6 +901,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void brdf_compact_kernel(Args a) {
                 if (orow[c] >= 0) a.out[orow[c]] = softplusf(accs[0].v[c][0]);   // brdf.py:65
 #endif
         }
+#ifdef NFX_XP_CLOBBER_TOP     // round-6 experiment: nothing of this wave lives in v248 .. v255 across this point
+        asm volatile("" ::: "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+#endif
         head = ring_wrap(head + rows, kCap);
         cnt -= rows;
         if (cnt > 0) {

@@ -1,10 +1,11 @@
-"""Static guard on the built code objects (no GPU): the kernels that run TWO waves per SIMD by construction — 512-thread
-workgroups of kernels that need more than half of a SIMD's registers... i.e. `__launch_bounds__(512, 2)` — must not use
-scratch memory.  Round 6: the one kernel of lvis_v2.hip that fails bit identity with a partner wave on
-its SIMD, brdf_compact_kernel<2, 0, 8>, is also the only one whose register allocation spills to scratch (20 bytes per lane:
-the lane half h and a constant pair, re-loaded in every pass); the default light-visibility kernel resident128_kernel<2, 0, 8>
-and the opt-in brdf_compact_kernel<2, 1, 8> have none, and a change of compiler or source that makes them spill fails here
-instead of on a customer's frame."""
+"""Static guard on the built code objects (no GPU): the kernels of lvis_v2.hip that run TWO waves per SIMD by construction
+(`__launch_bounds__(512, 2)`: 512-thread workgroups, at most 256 registers) must not use scratch memory.  Round 6 (DESIGN.md
+section 3.3): the one kernel of that file that fails bit identity with a partner wave on its SIMD, brdf_compact_kernel<2, 0, 8>
+(an experiment build, not part of the product), is also the only one whose register allocation spills to scratch memory — and
+the bisection showed scratch traffic to be an AMPLIFIER of its failure, not the cause (20 B per lane: 57 000 wrong elements
+per 3e9 rows; none: 1 800; 32 B: 200 000), while the healthy two-wave kernels stay bit-identical even with scratch forced into
+them.  The default light-visibility kernel resident128_kernel<2, 0, 8> and the opt-in brdf_compact_kernel<2, 1, 8> have no
+scratch today; a change of compiler or source that makes them spill to memory fails here instead of on a customer's frame."""
 import os
 import sys
 
