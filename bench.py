@@ -245,7 +245,7 @@ def committed_traffic(kernel_substr, scale=1):
     scripts/pmc_digest.py: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the kernel's dispatches of
     this very command at N = 1).  rocprofv3 counter passes cannot run inside this process, so the figure is a committed
     constant and the line says so."""
-    for rnd, name in (('r05', 'pmc_digest.json'), ('r05', 'pmc_train_digest.json'), ('r04', 'pmc_digest.json'), ('r04', 'pmc_train_digest.json'), ('r03', 'pmc_digest.json'),
+    for rnd, name in (('r06', 'pmc_digest.json'), ('r06', 'pmc_train_digest.json'), ('r05', 'pmc_digest.json'), ('r05', 'pmc_train_digest.json'), ('r04', 'pmc_digest.json'), ('r04', 'pmc_train_digest.json'), ('r03', 'pmc_digest.json'),
                       ('r02', 'pmc_digest.json'), ('r01', 'pmc_variant7_digest.json'), ('r01', 'pmc_nerfactor_digest.json')):
         dig = os.path.join(ROOT, 'profiles', rnd, name)
         if not os.path.exists(dig):

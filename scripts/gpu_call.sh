@@ -41,6 +41,9 @@ PYEOF
               tail -3 $OUT/coarse_refine_probe.err ;;
     residual) timeout 600 python scripts/coarse_refine_residual.py > $OUT/coarse_refine_residual.json 2> $OUT/coarse_refine_residual.err; cat $OUT/coarse_refine_residual.json; tail -3 $OUT/coarse_refine_residual.err ;;
     soak-libs) for lib in ${SOAK_LIBS:-libnfx_xp libnfx_xpN libnfx_xpS}; do echo "--- $lib"; NFX_LIB_PATH=$ROOT/nerfactor_amd/$lib.so REPS=${REPS:-30} timeout 500 python scripts/soak_8wave.py --geo0 > $OUT/soak_$lib.log 2>&1; grep -v "^  launch" $OUT/soak_$lib.log | tail -${SOAK_TAIL:-14}; done ;;
+    time-refine) timeout 600 python scripts/time_refine.py > $OUT/time_refine.json 2> $OUT/time_refine.err; cat $OUT/time_refine.json; tail -3 $OUT/time_refine.err ;;
+    bench-traffic) timeout 1200 python bench.py --gpus 1 --steps 10 --warmup 3 --measure-traffic --legs nerf,nerfactor_microfacet,olat > $OUT/bench_line_measured_traffic.json 2> $OUT/bench_traffic.err; cp bench_detail.json $OUT/bench_detail_measured_traffic.json; python -c "
+import json; d=json.load(open('$OUT/bench_detail_measured_traffic.json')); print('nerf', d['roofline']['traffic'], d['roofline']['traffic_source'][:60]); print('lvis', d['nerfactor']['nerfactor_microfacet']['roofline']['traffic'], d['nerfactor']['nerfactor_microfacet']['roofline']['traffic_source'][:40]); print('olat', d['olat']['roofline']['traffic'], d['olat']['roofline']['traffic_source'][:40])" ;;
     rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
