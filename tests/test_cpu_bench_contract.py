@@ -157,6 +157,11 @@ def test_committed_r06_evidence():
     line = parse_strict(text)
     check_line(line, 20, 5)
     assert line['parity']['rays_above_tol'] == 0
+    # the same frame against outputs of the reference's own Python (tests/golden/reference_large.npz), glorot and fitted weights
+    for block in (line['parity']['vs_reference_python'], line['parity']['fitted_weights']['vs_reference_python']):
+        assert block['rays_compared'] == 8192 and block['rays_above_tol'] == 0 and block['max_abs'] <= 3e-2 and block['psnr_db'] >= 40
+    assert line['parity']['fitted_weights']['rays_above_tol'] == 0                 # DEFAULT ini: coarse_precision = auto
+    assert line['parity']['fitted_weights']['refine_extra_frame_time'] <= 0.15
     legs = line['legs']
     assert legs['train_nerfactor_microfacet']['ms_per_step'] <= 1.35 and legs['train_nerfactor_microfacet']['frac'] >= 0.13
     assert legs['nerfactor_microfacet']['max_abs'] <= 3e-2 and legs['nerfactor']['max_abs'] <= 3e-2
