@@ -244,3 +244,32 @@ def test_rank0_gather_of_uint8_rows_is_point_to_point_and_ragged():
     ranks with ragged shards; only the destination rank assembles the view."""
     from tests.mp_util import run_workers
     run_workers(_gather_cat_worker, world=3)
+
+
+def _forced_group_worker(rank, world, q):
+    from nerfactor_amd import dist as nfx_dist
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        os.environ.pop(k, None)
+    nfx_dist.init_from_env(backend='gloo', force=True)
+    ok = dist.is_initialized() and dist.get_world_size() == 1 and dist.get_backend() == 'gloo'
+    # a gloo group of one rank keeps the shortcut: only an nccl (RCCL) group of one rank runs the collectives for real
+    shortcut = not nfx_dist.run_collectives_on_one_rank()
+    params = [torch.arange(6, dtype=torch.float32).reshape(2, 3), torch.ones(4)]
+    bucket = nfx_dist.FlatBucket(params)
+    bucket.pack([p * 2 for p in params], 0.5)
+    before = bucket.flat.clone()
+    views, total = bucket.all_reduce()
+    q.put((ok, shortcut, bool(torch.equal(bucket.flat, before)), float(total), nfx_dist.max_over_ranks(3.5)))
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_initialises_and_keeps_values():
+    """dist.init_from_env(force=True) (bench.py --force-group, the RCCL tests): a single process gets a process group of one
+    rank on a free port; on gloo the step's collectives keep their one-rank shortcut, the bucket is unchanged either way."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_group_worker, args=(0, 1, q))
+    p.start()
+    ok, shortcut, same, total, mx = q.get(timeout=120)
+    p.join(60)
+    assert ok and shortcut and same and total == 0.5 and mx == 3.5
