@@ -105,16 +105,19 @@ def timed(step, steps, warmup, barrier):
 COARSE_REFINE_GATE = 4e-3      # models/nerf.py `coarse_refine_gate` (ini default)
 
 
-def coarse_refine_decision(ops, view, blobs, refine, prec='bf16'):
+def coarse_refine_decision(ops, view, nets, refine, prec='bf16'):
     """What the plugin's `coarse_precision = auto` decides for these weights (models/nerf.py:_coarse_refine_on): the measured
-    bf16 density error as an alpha error, and whether the selective fp32-class refinement of the coarse pass is on."""
+    bf16 density error as an alpha error, and whether the selective fp32-class refinement of the coarse pass is on.  4096 rays of
+    the view through the bf16 and the fp32-class DENSITY kernels (the bf16 one is bit-identical to the MLP kernel's sigma): the
+    headline kernel is not launched here, so its coarse and fine launches stay 1 : 1 in every profile of this command."""
     if refine is None or prec != 'bf16':
         return False, (None, 0.)
+    from nerfactor_amd import synth
     o, d_raw = view
     d = ops.l2_normalize3(d_raw, 1e-12)
     z = ops.gen_z(2., 6., N_COARSE, o.shape[0], device=o.device)
-    raw = ops.nerf_mlp_fwd(o, d, z, blobs[0], prec)
-    err_a, err_s = ops.nerf_coarse_error(o, d, z, raw, refine[0])
+    g16 = ops.pack_nerf_geom_weights(*synth.nerf_layers(nets[0]), prec='bf16').to(o.device)
+    err_a, err_s = ops.nerf_coarse_error(o, d, z, None, refine[0], geom_blob_bf16=g16)
     return err_a > COARSE_REFINE_GATE, (err_a, err_s)
 
 
@@ -273,7 +276,7 @@ def nerf_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         views.append((torch.from_numpy(rayo[sh.lo:sh.hi]).to(dev), torch.from_numpy(rayd[sh.lo:sh.hi]).to(dev)))
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in views] for _ in range(args.steps)]
     # coarse_precision = auto: measured once per weight version, as the plugin does — outside the timed region
-    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, views[0], blobs, refine, args.precision)
+    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, views[0], nets, refine, args.precision)
     margin = ops.REFINE_MARGIN_FACTOR * sigma_err
     elapsed, rgb = timed(lambda k: nerf_render_step(ops, views, blobs, None if k is None else evs[k], args.precision,
                                                     refine, refine_coarse=refine_coarse, margin=margin),
@@ -398,7 +401,7 @@ def nerf_fitted_parity(args, ops, dev, host_view, refine_last, full_view=None, n
     with torch.no_grad():
         ref = torch_ref.render_rays(torch.from_numpy(o), torch.from_numpy(d), *[torch_ref.to_torch_net(x) for x in nets])
     view = [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))]
-    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, full_view or view[0], blobs, refine, args.precision)
+    refine_coarse, (alpha_err, sigma_err) = coarse_refine_decision(ops, full_view or view[0], nets, refine, args.precision)
     margin = ops.REFINE_MARGIN_FACTOR * sigma_err
     got = nerf_render_step(ops, view, blobs, prec=args.precision, refine=refine, refine_coarse=refine_coarse, margin=margin).cpu().numpy()
     want = ref[1]['rgb'].numpy()

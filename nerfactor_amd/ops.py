@@ -912,13 +912,14 @@ def nerf_refine_coarse(rayo, rayd, z, rgbs, geom_blob_fp32, t_min=REFINE_T_MIN, 
     return (rgbs, count) if want_count else rgbs
 
 
-def nerf_coarse_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.999):
+def nerf_coarse_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.999, geom_blob_bf16=None):
     """(alpha_error, sigma_error) of the bf16 coarse pass for THESE weights: sigma_error = the q-quantile of
     |sigma_bf16 - sigma_fp32class| over the samples of up to `max_rays` rays of the batch; alpha_error = that times the mean
     sample spacing = how far the bf16 error can move a sample's alpha.  The render's `coarse_precision = auto` measures this
     once per weight version (one host read): the selective refinement is on when alpha_error exceeds `coarse_refine_gate`
     (measured: glorot "opaque" weights of the bench 1.5e-3, a NeRF fitted to a scene 1.0e-2), and sigma_error sizes the
-    |sigma| < margin rule of nerf_refine_coarse."""
+    |sigma| < margin rule of nerf_refine_coarse.  `rgbs` = the bf16 pass's output for these rays, or None: then the bf16
+    densities of the picked rays come from the bf16 density kernel (`geom_blob_bf16`; bit-identical to the MLP kernel's sigma)."""
     n = min(int(z.shape[0]), max_rays)
     if n == 0 or z.shape[1] < 2:
         return 0., 0.
@@ -926,7 +927,8 @@ def nerf_coarse_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.99
     pick = slice(0, n * step, step)
     o, d, zz = rayo[pick].contiguous(), rayd[pick].contiguous(), z[pick].contiguous()
     s32 = nerf_sigma_fwd(o, d, zz, geom_blob_fp32, 'fp32')
-    err = (rgbs[pick][..., 3] - s32).abs()[:, :-1].reshape(-1)
+    s16 = rgbs[pick][..., 3] if rgbs is not None else nerf_sigma_fwd(o, d, zz, geom_blob_bf16, 'bf16')
+    err = (s16 - s32).abs()[:, :-1].reshape(-1)
     spacing = ((zz[:, 1:] - zz[:, :-1]).mean() * d.norm(dim=1).mean())
     sig = torch.quantile(err[:4000000], q)
     both = torch.stack((sig * spacing, sig)).tolist()
