@@ -183,6 +183,17 @@ NFX_API int nfx_mlp128_xyz_fwd(const float *dev_xyz, int64_t n, float xyz_scale,
 /* The posenc(xyz) rows of layers 0 and 3 are evaluated once per point into a caller-provided
  * workspace of nfx_lvis_workspace_bytes(n) bytes (16-byte aligned); n_lights % 32 == 0.      */
 NFX_API size_t nfx_lvis_workspace_bytes(int64_t n);
+/* nfx_lvis_fwd_rows (round 6) = nfx_lvis_fwd with the tf.scatter_nd of shape.py:171-176 and the tf.debugging.check_numerics
+ * of shape.py:222-232 done by the kernel's own stores: dev_out_row [n] int32 (or NULL) = the row of point i in dev_lvis,
+ * which is then the caller's FULL [n_all, n_lights] buffer (background rows: nfx_zero_rows); dev_nan_flag (or NULL) = an int32
+ * the caller zeroed, 1 is OR-ed into it when a visibility is NaN.  bf16 kernels with the network resident in LDS only
+ * (lvis_variant 8 | 2 | 3 | 4): NFX_ENOSUP otherwise.  nfx_zero_rows: dev_dst[i, :] = 0 where dev_row_of[i] < 0
+ * (dev_row_of [n_all] int32 as for nfx_scatter_rows; d % 4 == 0, 16-byte aligned); other rows are left alone.       */
+NFX_API int nfx_lvis_fwd_rows(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
+                      const float *dev_lxyz, int n_lights, const void *dev_blob, int prec, void *dev_workspace,
+                      size_t workspace_bytes, const int32_t *dev_out_row, float *dev_lvis, int *dev_nan_flag,
+                      void *stream);
+NFX_API int nfx_zero_rows(float *dev_dst, const int32_t *dev_row_of, int64_t n_all, int d, void *stream);
 NFX_API int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t n, float xyz_scale,
                  const float *dev_lxyz, int n_lights, const void *dev_blob, int prec,
                  void *dev_workspace, size_t workspace_bytes, float *dev_lvis, void *stream);
@@ -200,6 +211,18 @@ NFX_API int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t
  * out rgb [n, n_probes, 3].                                                  */
 /* Dynamic LDS the shading kernels need for a given sphere / probe count (must be <= 160 KiB). */
 NFX_API size_t nfx_shade_lds_bytes(int n_lights, int n_probes);
+/* nfx_shade_fwd_rows / nfx_shade_olat_fwd_rows (round 6): dev_lvis_row [n] int32 (or NULL) = the row of point i in
+ * dev_lvis — the visibilities may live in the full [n_all, n_lights] buffer nfx_lvis_fwd_rows wrote.               */
+NFX_API int nfx_shade_fwd_rows(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                       const float *dev_albedo, const float *dev_rough, const float *dev_spec, float spec_scale,
+                       float f0, const float *dev_lvis, const int32_t *dev_lvis_row, const float *dev_lxyz,
+                       const float *dev_lareas, const float *dev_lights, int64_t n, int n_lights, int n_probes,
+                       int linear2srgb, float *dev_rgb, void *stream);
+NFX_API int nfx_shade_olat_fwd_rows(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                            const float *dev_albedo, const float *dev_rough, const float *dev_spec,
+                            float spec_scale, float f0, const float *dev_lvis, const int32_t *dev_lvis_row,
+                            const float *dev_lxyz, const float *dev_lareas, float olat_inten, float ambient,
+                            int64_t n, int n_lights, int linear2srgb, float *dev_rgb_olat, void *stream);
 NFX_API int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,

@@ -88,6 +88,10 @@ SIGNATURES = {
     'nfx_amsgrad_step_size': (_f, [_f, _f, _f, _i64]),
     'nfx_amsgrad_step_dev': (_i, [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _p]),
     'nfx_nerf_sigma_fwd': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_lvis_fwd_rows': (_i, [_p, _p, _i64, _f, _p, _i, _p, _i, _p, _sz, _p, _p, _p, _p]),
+    'nfx_zero_rows': (_i, [_p, _p, _i64, _i, _p]),
+    'nfx_shade_fwd_rows': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
+    'nfx_shade_olat_fwd_rows': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _f, _f, _i64, _i, _i, _p, _p]),
     'nfx_nerf_refine_select': (_i, [_p, _p, _p, _i64, _i, _f, _f, _f, _f, _i, _p, _p, _p]),
     'nfx_nerf_sigma_refine': (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
     'nfx_nerf_geom_packed_bytes': (_sz, [_i]),

@@ -32,17 +32,18 @@ int nfx_launch_brdf_spec_v2(const float*, const float*, const float*, const floa
 int nfx_launch_brdf_spec_v3(const float*, const float*, const float*, const float*, int, const float*, int,
                             const void*, long long, float*, int, int, int, hipStream_t);
 int nfx_launch_lvis_v2(const float*, long long, const float*, int, const float*, const void*, float*, int, int,
-                       hipStream_t);
+                       hipStream_t, const int*, int*);
+int nfx_launch_zero_rows(float*, const int*, long long, int, hipStream_t);
 int nfx_launch_lvis(const float*, long long, const float*, int, const float*, const void*, float*, int,
                     hipStream_t);
 int nfx_launch_brdf_spec(const float*, const float*, const float*, const float*, int, const float*, int,
                          const void*, long long, float*, int, hipStream_t);
 int nfx_launch_shade(const float*, const float*, const float*, const float*, const float*, const float*, float,
                      float, const float*, const float*, const float*, const float*, long long, int, int, int,
-                     float*, hipStream_t);
+                     float*, hipStream_t, const int*);
 int nfx_launch_shade_olat(const float*, const float*, const float*, const float*, const float*, const float*,
                           float, float, const float*, const float*, const float*, float, float, long long, int,
-                          int, float*, hipStream_t);
+                          int, float*, hipStream_t, const int*);
 int nfx_launch_dir2rusink(const float*, const float*, long long, float*, hipStream_t);
 size_t nfx_shade_olat_lds_bytes(int n_lights);
 int nfx_mlp128_x3_weight_bytes(int in_kind);   // mlp128_x3.hip
@@ -220,12 +221,32 @@ size_t nfx_lvis_workspace_bytes(int64_t n) { return n > 0 ? (size_t)n * 256 * si
 int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale, const float* lxyz,
                  int n_lights, const void* blob, int prec, void* workspace, size_t workspace_bytes,
                  float* lvis, void* stream) {
+    return nfx_lvis_fwd_rows(xyz, xyz_dir, n, xyz_scale, lxyz, n_lights, blob, prec, workspace, workspace_bytes, nullptr,
+                             lvis, nullptr, stream);
+}
+
+int nfx_zero_rows(float* dst, const int32_t* row_of, int64_t n_all, int d, void* stream) {
+    REQUIRE(n_all >= 0 && d >= 1, "nfx_zero_rows: bad shape");
+    if (n_all == 0) return NFX_OK;
+    REQUIRE(dst && row_of, "nfx_zero_rows: null pointer");
+    REQUIRE(d % 4 == 0 && ALIGNED(dst, 16), "nfx_zero_rows: rows of a multiple of 4 floats, 16-byte aligned (d = %d)", d);
+    return nfx_hip_result(nfx_launch_zero_rows(dst, row_of, (long long)n_all, d, (hipStream_t)stream), "zero_rows");
+}
+
+int nfx_lvis_fwd_rows(const float* xyz, const float* xyz_dir, int64_t n, float xyz_scale, const float* lxyz,
+                      int n_lights, const void* blob, int prec, void* workspace, size_t workspace_bytes,
+                      const int32_t* out_row, float* lvis, int* nan_flag, void* stream) {
     using namespace nfx::m128;
     REQUIRE(n >= 0, "nfx_lvis_fwd: n < 0");
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_lvis_fwd: n_lights (%d) must be a positive multiple of 32",
             n_lights);
     REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_lvis_fwd: bad prec %d", prec);
     if (n == 0) return NFX_OK;
+    const int variant = nfx_option_int("lvis_variant", 8);   // 8 (default) = 8 waves (two per SIMD) x 2 column tiles
+    REQUIRE(out_row || !nan_flag, "nfx_lvis_fwd_rows: the NaN flag comes with output rows (pass the identity for a compact output)");
+    if (out_row && (prec != NFX_PREC_BF16 || !((variant >= 2 && variant <= 4) || variant == 8)))
+        return nfx_fail(NFX_ENOSUP, "nfx_lvis_fwd_rows: output rows / NaN flag exist for the bf16 kernels with the network resident "
+                                    "in LDS (lvis_variant 8 | 2 | 3 | 4), not for prec %d / variant %d", prec, variant);
     if (prec == NFX_PREC_FP32) {   // no per-point fold, no workspace
         REQUIRE(xyz && lxyz && blob && lvis, "nfx_lvis_fwd: null pointer");
         if (!ALIGNED(blob, 16)) return nfx_fail(NFX_EALIGN, "nfx_lvis_fwd: blob must be 16-byte aligned");
@@ -246,10 +267,9 @@ int nfx_lvis_fwd(const float* xyz, const float* xyz_dir, int64_t n, float xyz_sc
     if (rc) return rc;
     // option lvis_variant: 0 = 8 waves x 32 rows with streamed weights (mlp128.hip); 2 | 3 | 4 = network resident in LDS,
     // one wave per SIMD with that many 32-row column tiles (lvis_v2.hip)
-    const int variant = nfx_option_int("lvis_variant", 8);   // 8 (default) = 8 waves (two per SIMD) x 2 column tiles
     if ((variant >= 2 && variant <= 4) || variant == 8)
         return nfx_hip_result(nfx_launch_lvis_v2(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis,
-                                                 variant, blocks, (hipStream_t)stream),
+                                                 variant, blocks, (hipStream_t)stream, out_row, nan_flag),
                               "lvis_fwd(v2)");
     return nfx_hip_result(
         nfx_launch_lvis(xyz_dir ? xyz_dir : xyz, n, lxyz, n_lights, pre, b + kPreBytes, lvis, blocks,
@@ -319,6 +339,13 @@ int nfx_shade_fwd(const float* xyz, const float* cam, const float* normal, const
                   const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
                   const float* lxyz, const float* lareas, const float* lights, int64_t n, int n_lights,
                   int n_probes, int linear2srgb, float* rgb, void* stream) {
+    return nfx_shade_fwd_rows(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, nullptr, lxyz, lareas, lights, n,
+                              n_lights, n_probes, linear2srgb, rgb, stream);
+}
+int nfx_shade_fwd_rows(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                       const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
+                       const int32_t* lvis_row, const float* lxyz, const float* lareas, const float* lights, int64_t n,
+                       int n_lights, int n_probes, int linear2srgb, float* rgb, void* stream) {
     int rc = check_shade("nfx_shade_fwd", xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, n_lights);
     if (rc) return rc;
     REQUIRE(n_probes >= 1, "nfx_shade_fwd: n_probes must be >= 1");
@@ -329,7 +356,7 @@ int nfx_shade_fwd(const float* xyz, const float* cam, const float* normal, const
     REQUIRE(lights && rgb, "nfx_shade_fwd: null pointer");
     return nfx_hip_result(nfx_launch_shade(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
                                            lareas, lights, n, n_lights, n_probes, linear2srgb, rgb,
-                                           (hipStream_t)stream),
+                                           (hipStream_t)stream, lvis_row),
                           "shade_fwd");
 }
 
@@ -337,6 +364,13 @@ int nfx_shade_olat_fwd(const float* xyz, const float* cam, const float* normal, 
                        const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
                        const float* lxyz, const float* lareas, float olat_inten, float ambient, int64_t n,
                        int n_lights, int linear2srgb, float* rgb_olat, void* stream) {
+    return nfx_shade_olat_fwd_rows(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, nullptr, lxyz, lareas,
+                                   olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat, stream);
+}
+int nfx_shade_olat_fwd_rows(const float* xyz, const float* cam, const float* normal, const float* albedo,
+                            const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
+                            const int32_t* lvis_row, const float* lxyz, const float* lareas, float olat_inten,
+                            float ambient, int64_t n, int n_lights, int linear2srgb, float* rgb_olat, void* stream) {
     int rc =
         check_shade("nfx_shade_olat_fwd", xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, n_lights);
     if (rc) return rc;
@@ -346,7 +380,7 @@ int nfx_shade_olat_fwd(const float* xyz, const float* cam, const float* normal, 
     REQUIRE(rgb_olat, "nfx_shade_olat_fwd: null output");
     return nfx_hip_result(nfx_launch_shade_olat(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
                                                 lareas, olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat,
-                                                (hipStream_t)stream),
+                                                (hipStream_t)stream, lvis_row),
                           "shade_olat_fwd");
 }
 

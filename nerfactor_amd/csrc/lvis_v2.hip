@@ -166,13 +166,20 @@ struct Args {
     int n_lights;
     const char* blob;
     float* out;            // [n,L]
+    // MODE 0, round 6 (both optional): row of point i in the caller's FULL [n_all, L] buffer (the tf.scatter_nd of
+    // shape.py:171-176 done by the store itself: the compact [n, L] tensor is never written and never re-read), and the
+    // tf.debugging.check_numerics flag: 1 is OR-ed into it when a visibility is NaN
+    const int* out_row;
+    int* nan_flag;
 };
 
 // NW = 4: one wave per SIMD with up to 512 registers (CT = 3 | 4).  NW = 8 (CT = 2): two waves per SIMD with 256
 // registers each share the LDS copy of the network — a wave's stalls (epilogue bursts, the slow first tile of a
 // layer, encoder VALU at the start of a point tile) are covered by its partner's MFMAs; an A fragment feeds 2 MFMAs,
 // 64 B/clk of LDS reads per CU at full MFMA rate, a quarter of the ds_read_b128 peak.
-template <int CT, int MODE, int NW>
+// ROWS (MODE 0, round 6): the stores go to the rows Args::out_row names and NaNs raise Args::nan_flag.  A separate instantiation:
+// the plain kernel keeps the exact code that 5e11 rows of soak have seen (255 registers, no scratch).
+template <int CT, int MODE, int NW, bool ROWS = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
     constexpr int kNW = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,21 +224,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
     // point position and light position of this lane's row in column tile c of point tile t, fetched one point tile
     // ahead: the first touch of a point's xyz is an HBM miss (~2-3 k cycles) that the first MFMA of the tile waited for
     float xq[CT][3], lq[CT][3];
+    // ROWS: where column tile c of the NEXT point tile stores — out_row[point] * L + first light — as two wave-uniform words
+    // (readfirstlane: SGPRs; the point index is computed here anyway, a division at the store would cost the registers the
+    // kernel does not have)
+    unsigned obq_lo[CT], obq_hi[CT];
     auto fetch_inputs = [&](long long t) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const long long m = t * kTileRows + (wave * CT + c) * 32;
             const long long mc = m < n_rows ? m : 0;
             const long long pt = div_l(mc);
-            const int l = mod_l(mc) + p;
+            const int l0 = mod_l(mc);
+            const int l = l0 + p;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 xq[c][k] = a.xyz[pt * 3 + k];
                 lq[c][k] = a.lxyz[l * 3 + k];
             }
+            if constexpr (ROWS) {
+                const long long ob = (long long)a.out_row[pt] * n_lights + l0;
+                obq_lo[c] = __builtin_amdgcn_readfirstlane((unsigned)ob);
+                obq_hi[c] = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ob >> 32));
+            }
         }
     };
     fetch_inputs(blockIdx.x);
+    unsigned long long bad = 0ull;      // lanes that saw a NaN: a ballot, wave-uniform — SGPRs, not one more VGPR (the kernel sits at 255)
     for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         bf16x8 pl[2][CT];
         const float* pre_pt[CT];
@@ -240,13 +258,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
         long long m0[CT];
         bool front[CT];
         float xc[CT][3], lc[CT][3];
+        unsigned ob_lo[CT], ob_hi[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 xc[c][k] = xq[c][k];
                 lc[c][k] = lq[c][k];
             }
+            if constexpr (ROWS) {
+                ob_lo[c] = obq_lo[c];
+                ob_hi[c] = obq_hi[c];
+            }
+        }
         fetch_inputs(tnext);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -352,10 +376,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
             for (int c = 0; c < CT; ++c)
                 if (m0[c] < n_rows) {
                     const float o = accs[0].v[c][0];
-                    if constexpr (MODE == 0) a.out[m0[c] + p] = sigmoidf(o);             // shape.py:93 sigmoid out
-                    else a.out[m0[c] + p] = front[c] ? softplusf(o) : 0.0f;             // brdf.py:65, back-lit rows 0
+                    if constexpr (MODE == 0) {
+                        const float v = sigmoidf(o);                                    // shape.py:93 sigmoid out
+                        if constexpr (ROWS) {
+                            const long long at = (long long)(((unsigned long long)ob_hi[c] << 32) | ob_lo[c]);
+                            a.out[at + p] = v;
+                            bad |= __ballot(!(v == v));
+                        } else {
+                            a.out[m0[c] + p] = v;
+                        }
+                    } else {
+                        a.out[m0[c] + p] = front[c] ? softplusf(o) : 0.0f;              // brdf.py:65, back-lit rows 0
+                    }
                 }
         }
+    }
+    if constexpr (ROWS) {
+        if (a.nan_flag != nullptr && bad != 0ull && lane == 0) atomicOr(a.nan_flag, 1);
     }
 }
 
@@ -918,7 +955,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) NFX_XP_CAP_ATTR void brdf_compact_
 }  // namespace lv2
 }  // namespace nfx
 
-template <int CT, int MODE, int NW = 4>
+template <int CT, int MODE, int NW = 4, bool ROWS = false>
 static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     using namespace nfx;
     const long long rows = a.n * a.n_lights, tile_rows = NW * CT * 32;
@@ -926,7 +963,7 @@ static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     constexpr int lds = lv2::kLdsNet + NW * CT * 1024;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto k = lv2::resident128_kernel<CT, MODE, NW>;
+    auto k = lv2::resident128_kernel<CT, MODE, NW, ROWS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, a);
@@ -934,9 +971,14 @@ static int launch_res(const nfx::lv2::Args& a, int max_blocks, hipStream_t st) {
 }
 
 extern "C" int nfx_launch_lvis_v2(const float* xyz, long long n, const float* lxyz, int n_lights, const float* pre,
-                                  const void* blob_main, float* lvis, int ct, int max_blocks, hipStream_t st) {
+                                  const void* blob_main, float* lvis, int ct, int max_blocks, hipStream_t st,
+                                  const int* out_row, int* nan_flag) {
     if (n <= 0) return 0;
-    nfx::lv2::Args a{xyz, lxyz, pre, nullptr, nullptr, nullptr, 0, n, n_lights, (const char*)blob_main, lvis};
+    nfx::lv2::Args a{xyz, lxyz, pre, nullptr, nullptr, nullptr, 0, n, n_lights, (const char*)blob_main, lvis, out_row, nan_flag};
+    if (out_row != nullptr) {     // (a NaN flag alone: the caller passes the identity rows — capi_nerfactor.cpp refuses it)
+        if (ct == 8) return launch_res<2, 0, 8, true>(a, max_blocks, st);
+        return launch_res<4, 0, 4, true>(a, max_blocks, st);     // variants 2 | 3 | 4: the one-wave-per-SIMD reference form
+    }
     if (ct == 8) return launch_res<2, 0, 8>(a, max_blocks, st);   // variant 8: 8 waves x 2 column tiles
     if (ct == 2) return launch_res<2, 0>(a, max_blocks, st);
     if (ct == 3) return launch_res<3, 0>(a, max_blocks, st);
@@ -947,7 +989,7 @@ extern "C" int nfx_launch_brdf_spec_v2(const float* xyz, const float* cam, const
                                        int z_dim, const float* lxyz, int n_lights, const void* blob, long long n,
                                        float* spec, int ct, int max_blocks, hipStream_t st) {
     if (n <= 0) return 0;
-    nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec};
+    nfx::lv2::Args a{xyz, lxyz, nullptr, cam, normal, z, z_dim, n, n_lights, (const char*)blob, spec, nullptr, nullptr};
     if (ct == 2) return launch_res<2, 1>(a, max_blocks, st);
     if (ct == 3) return launch_res<3, 1>(a, max_blocks, st);
     return launch_res<4, 1>(a, max_blocks, st);

@@ -512,6 +512,14 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const unsigned* __restri
 // output row is written exactly once — its compact row or zeros.  torch.zeros + index_put_ wrote the [n, 512]
 // visibilities twice and read the compact copy once (0.4 + 1.3 ms per 800 x 800 NeRFactor view, the 5th-largest kernel
 // of the render legs in round 2).  row_of[i] = compact row of full row i, or -1.  V = 4: rows of d4 float4 each.
+// Zero-fill of the BACKGROUND rows only (round 6): the rows of the foreground points are written, once, by the kernel that
+// computes them (nfx_lvis_fwd_rows stores every visibility at its final row); row_of[i] < 0 marks a background row.
+__global__ __launch_bounds__(256) void zero_rows_kernel(float4* __restrict__ dst, const int* __restrict__ row_of, unsigned n_elems,
+                                                        unsigned per_row) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_elems; i += gridDim.x * 256u)
+        if (row_of[i / per_row] < 0) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__ src, const int* __restrict__ row_of,
                                                            unsigned n_elems, unsigned per_row, T* __restrict__ dst) {
@@ -540,6 +548,22 @@ extern "C" int nfx_launch_scatter_rows(const float* src, const int* row_of, long
     else
         hipLaunchKernelGGL(nfx::scatter_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, src, row_of,
                            (unsigned)n_elems, (unsigned)per_row, dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nfx_launch_zero_rows(float* dst, const int* row_of, long long n_all, int d, hipStream_t st) {
+    if (n_all <= 0 || d <= 0) return 0;
+    const long long per_row = d / 4;            // (the C-ABI wrapper checks d % 4 == 0 and the alignment)
+    // rows in slices of < 2^31 elements: the kernel's index is 32 bits
+    const long long rows_per_call = ((1ll << 31) - 1) / per_row;
+    for (long long r0 = 0; r0 < n_all; r0 += rows_per_call) {
+        const long long rows = n_all - r0 < rows_per_call ? n_all - r0 : rows_per_call;
+        const long long n_elems = rows * per_row;
+        long long blocks = (n_elems + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(nfx::zero_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<float4*>(dst) + r0 * per_row, row_of + r0, (unsigned)n_elems, (unsigned)per_row);
+    }
     return (int)hipGetLastError();
 }
 

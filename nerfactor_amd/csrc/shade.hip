@@ -16,6 +16,7 @@ struct ShadeArgs {
     int n_lights, n_probes, to_srgb;
     float olat_inten, ambient;
     float* out;
+    const int* lvis_row;   // optional (round 6): row of point i in `lvis` — the visibilities live in the caller's FULL [n_all, L] buffer
 };
 
 struct PointCtx {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void light_transport_v(const ShadeArgs& a, const Poin
 }
 __device__ __forceinline__ void light_transport(const ShadeArgs& a, const PointCtx& pc, long long pt, int l,
                                                 const float* lxyz_s, const float* area_s, float (&T)[3]) {
-    light_transport_v(a, pc, l, a.lvis[pt * a.n_lights + l], a.spec ? a.spec[pt * a.n_lights + l] : 0.0f, lxyz_s,
+    light_transport_v(a, pc, l, a.lvis[(a.lvis_row ? (long long)a.lvis_row[pt] : pt) * a.n_lights + l], a.spec ? a.spec[pt * a.n_lights + l] : 0.0f, lxyz_s,
                       area_s, T);
 }
 
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_kernel(ShadeArgs a) {
         for (int k = 0; k < kLightsPerPass; ++k) {
             const int l = k * 64 + lane;
             const bool ok = pt < a.n && l < L;
-            lvn[k] = ok ? a.lvis[pt * L + l] : 0.0f;
+            lvn[k] = ok ? a.lvis[(a.lvis_row ? (long long)a.lvis_row[pt] : pt) * L + l] : 0.0f;
             spn[k] = ok && a.spec ? a.spec[pt * L + l] : 0.0f;
         }
     };
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_olat_kernel(ShadeArgs 
         for (int k = 0; k < kLightsPerPass; ++k) {
             const int l = k * 64 + lane;
             const bool ok = pt < a.n && l < L;
-            lvn[k] = ok ? a.lvis[pt * L + l] : 0.0f;
+            lvn[k] = ok ? a.lvis[(a.lvis_row ? (long long)a.lvis_row[pt] : pt) * L + l] : 0.0f;
             spn[k] = ok && a.spec ? a.spec[pt * L + l] : 0.0f;
         }
     };
@@ -261,8 +262,9 @@ static nfx::ShadeArgs make_args(const float* xyz, const float* cam, const float*
                                 const float* rough, const float* spec, float spec_scale, float f0,
                                 const float* lvis, const float* lxyz, const float* lareas,
                                 const float* lights, long long n, int n_lights, int n_probes, int to_srgb,
-                                float olat_inten, float ambient, float* out) {
+                                float olat_inten, float ambient, float* out, const int* lvis_row = nullptr) {
     nfx::ShadeArgs a;
+    a.lvis_row = lvis_row;
     a.xyz = xyz; a.cam = cam; a.normal = normal; a.albedo = albedo; a.rough = rough; a.spec = spec;
     a.lvis = lvis; a.lxyz = lxyz; a.lareas = lareas; a.lights = lights;
     a.spec_scale = spec_scale; a.f0 = f0; a.n = n; a.n_lights = n_lights; a.n_probes = n_probes;
@@ -277,7 +279,7 @@ size_t nfx_shade_olat_lds_bytes(int n_lights) { return sizeof(float) * (size_t)4
 int nfx_launch_shade(const float* xyz, const float* cam, const float* normal, const float* albedo,
                      const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
                      const float* lxyz, const float* lareas, const float* lights, long long n, int n_lights,
-                     int n_probes, int to_srgb, float* out, hipStream_t st) {
+                     int n_probes, int to_srgb, float* out, hipStream_t st, const int* lvis_row) {
     if (n <= 0) return 0;
     const size_t lds = nfx_shade_lds_bytes(n_lights, n_probes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_kernel),
@@ -287,13 +289,14 @@ int nfx_launch_shade(const float* xyz, const float* cam, const float* normal, co
     if (blocks > 512) blocks = 512;   // two resident workgroups per CU, each stages the lights once and loops over points
     hipLaunchKernelGGL(nfx::shade_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
                        make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
-                                 lights, n, n_lights, n_probes, to_srgb, 0.f, 0.f, out));
+                                 lights, n, n_lights, n_probes, to_srgb, 0.f, 0.f, out, lvis_row));
     return (int)hipGetLastError();
 }
 int nfx_launch_shade_olat(const float* xyz, const float* cam, const float* normal, const float* albedo,
                           const float* rough, const float* spec, float spec_scale, float f0,
                           const float* lvis, const float* lxyz, const float* lareas, float olat_inten,
-                          float ambient, long long n, int n_lights, int to_srgb, float* out, hipStream_t st) {
+                          float ambient, long long n, int n_lights, int to_srgb, float* out, hipStream_t st,
+                          const int* lvis_row) {
     if (n <= 0) return 0;
     const size_t lds = nfx_shade_olat_lds_bytes(n_lights);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_olat_kernel),
@@ -303,7 +306,7 @@ int nfx_launch_shade_olat(const float* xyz, const float* cam, const float* norma
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(nfx::shade_olat_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
                        make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
-                                 nullptr, n, n_lights, 0, to_srgb, olat_inten, ambient, out));
+                                 nullptr, n, n_lights, 0, to_srgb, olat_inten, ambient, out, lvis_row));
     return (int)hipGetLastError();
 }
 int nfx_launch_dir2rusink(const float* a, const float* b, long long n, float* out, hipStream_t st) {

@@ -134,11 +134,17 @@ class Model(torch.nn.Module):
             ok = ops.all_finite(tensor.detach())      # one pass, no full-size temporaries
         else:
             ok = torch.isfinite(tensor).all()
+        self.check_flag(ok, message)
+        return tensor
+
+    def check_flag(self, ok, message):
+        """`ok`: a 0-dim / 1-element bool tensor a kernel's own epilogue produced (round 6: nfx_lvis_fwd_rows ORs a NaN flag
+        while it stores) — the verdict of check_numerics without the extra pass over the tensor."""
+        ok = ok.reshape(())
         if torch.is_grad_enabled():
             self.__dict__.setdefault('_pending_numerics', []).append((message, ok))
         elif not bool(ok):
             raise FloatingPointError(message)
-        return tensor
 
     def flush_numerics(self, block=False):
         """Ships the verdicts recorded since the last call to pinned host memory (asynchronous copy + event) and raises

@@ -212,8 +212,25 @@ class Model(ShapeModel):
         if normal_jitter is not None:
             normal_jitter = self._normalize(normal_jitter)
         # ------ light visibility (the jittered points keep the light directions of the clean ones, shape.py:160-163)
+        row_of = []   # [n_all] int32: compact row of every ray, -1 for the background (built on first use)
+
+        def rows():
+            if not row_of:
+                r = torch.full((n_all,), -1, dtype=torch.int32, device=xyz.device)
+                r[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=xyz.device)
+                row_of.append(r)
+            return row_of[0]
+        lvis_row = lvis_full = None
         if self.shape_mode == 'nerf':
             lvis_pred, lvis_jitter = torch.clamp(lvis, 1e-8, 1.), None
+        elif not all_fg and not jitter and xyz.shape[0] > 0 and self._lvis_rows_ok():
+            # a render with background rays (round 6): the kernel stores every visibility at its FINAL row of pred['lvis'] and
+            # raises the NaN flag itself — no compact [n, 512] tensor, no scatter pass over it (0.7 ms per 800 x 800 view), no
+            # check_numerics pass (0.13 ms); the shading kernels read the rows through the same index
+            lvis_row = idx.to(torch.int32)
+            lvis_full = torch.empty((n_all, self.lxyz.reshape(-1, 3).shape[0]), dtype=torch.float32, device=xyz.device)
+            ops.zero_rows(lvis_full, rows())
+            lvis_pred, lvis_jitter = self._pred_lvis_rows(xyz, lvis_full, lvis_row, dir_pts=xyz), None
         else:
             lvis_pred, lvis_jitter = both(self._pred_lvis_at, dir_pts=xyz)
         # ------ albedo
@@ -238,20 +255,14 @@ class Model(ShapeModel):
         # ------ rendering equation
         rgb_pred, rgb_olat, rgb_probes = self._render(
             xyz, rayo, normal_pred, albedo, brdf_prop, lvis_pred, relight_olat=relight_olat,
-            relight_probes=relight_probes)
-
-        row_of = []   # [n_all] int32: compact row of every ray, -1 for the background (built on first use)
+            relight_probes=relight_probes, lvis_row=lvis_row)
 
         def full(v):  # zero-filled scatter back to all rays (tf.scatter_nd)
-            if v is None or all_fg:
+            if v is None or all_fg or v is lvis_full:       # (lvis_full: already at its final rows)
                 return v
             if v.is_cuda and v.dtype == torch.float32 and not (torch.is_grad_enabled() and v.requires_grad):
                 # one pass that writes every output row once (nfx_scatter_rows) instead of zeros + index_put_
-                if not row_of:
-                    r = torch.full((n_all,), -1, dtype=torch.int32, device=v.device)
-                    r[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=v.device)
-                    row_of.append(r)
-                return ops.scatter_rows(v.contiguous(), row_of[0], n_all)
+                return ops.scatter_rows(v.contiguous(), rows(), n_all)
             out = torch.zeros((n_all,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
             out[idx] = v
             return out
@@ -332,7 +343,9 @@ class Model(ShapeModel):
         return albedo[:, None, :] / np.pi + spec.reshape(n, nl, 1).expand(n, nl, 3) * scale
 
     def _render(self, xyz, cam, normal, albedo, brdf_prop, light_vis, relight_olat=False,
-                relight_probes=False, white_light_override=False, white_lvis_override=False):
+                relight_probes=False, white_light_override=False, white_lvis_override=False, lvis_row=None):
+        """`lvis_row` (round 6, inference only): light_vis is a full-size [n_all, L] buffer and row lvis_row[i] of it belongs
+        to point i (ops.lvis_fwd(out=, out_row=))."""
         to_srgb = self.config.getboolean('DEFAULT', 'linear2srgb')
         light = torch.ones_like(self.light) if white_light_override else self.light
         if white_lvis_override:
@@ -347,6 +360,7 @@ class Model(ShapeModel):
         if relight_probes:
             lights += [p.to(light.device).reshape(-1, 3) for p in self.novel_probes.values()]
         common = (xyz, cam, normal, albedo, light_vis, self.lxyz.reshape(-1, 3), self.lareas)
+        terms = dict(terms, lvis_row=lvis_row)
         out = ops.shade_fwd(*common, torch.stack(lights).detach(), linear2srgb=to_srgb, **terms)
         rgb = out[:, 0]
         rgb_probes = out[:, 1:] if relight_probes else None

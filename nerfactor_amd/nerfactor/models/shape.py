@@ -287,6 +287,23 @@ class Model(BaseModel):
                                 prec=self.precision)
         return self.check_numerics(lvis, "Light visibility")
 
+    def _lvis_rows_ok(self):
+        """May a render store its visibilities straight into the rows of a full-size buffer (round 6: ops.lvis_fwd(out=,
+        out_row=) — the zero-filled scatter and the check_numerics pass of the [n, 512] tensor done by the kernel's own
+        stores)?  The shipped network, bf16 operands, nothing being differentiated."""
+        if torch.is_grad_enabled() or not self._net_tuned('lvis_mlp'):
+            return False
+        return ops.lvis_rows_supported(self.precision)
+
+    def _pred_lvis_rows(self, pts, out, out_row, dir_pts=None):
+        """_pred_lvis_at whose result for point i lands in out[out_row[i]] (out: [n_all, L], the other rows are the caller's)."""
+        blob = self._blob128('lvis_mlp', 'lvis_out', _capi.IN_XYZ_LDIR, 1)
+        flag = torch.zeros(1, dtype=torch.int32, device=pts.device)
+        ops.lvis_fwd(pts, self.lxyz.reshape(-1, 3), blob, xyz_scale=self.xyz_scale, xyz_dir=dir_pts, prec=self.precision,
+                     out=out, out_row=out_row, nan_flag=flag)
+        self.check_flag(flag == 0, "Light visibility")
+        return out
+
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):
         cfg = self.config

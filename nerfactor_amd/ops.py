@@ -557,16 +557,43 @@ def mlp128_xyz_fwd(xyz, blob, out_dim, out_act=None, xyz_scale=1., post_scale=1.
     return out
 
 
-def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., xyz_dir=None, prec='bf16'):
+def lvis_rows_supported(prec='bf16'):
+    """Can lvis_fwd write straight into the rows of a full-size buffer (nfx_lvis_fwd_rows)?  bf16 kernels with the network
+    resident in LDS: the default and lvis_variant 2 | 3 | 4."""
+    return prec == 'bf16' and _capi.get_option("lvis_variant") in (None, 8, 2, 3, 4)
+
+
+def zero_rows(dst, row_of):
+    """dst[i, :] = 0 where row_of[i] < 0 (the background rows of a tf.scatter_nd whose foreground rows a kernel writes itself)."""
+    dst = _dev(dst, 'dst', (row_of.shape[0], None))
+    if not row_of.is_cuda or row_of.dtype != torch.int32 or not row_of.is_contiguous():
+        raise _capi.NfxError("zero_rows: row_of must be a contiguous CUDA int32 tensor")
+    check(lib.nfx_zero_rows(_ptr(dst), ctypes.c_void_p(row_of.data_ptr()), dst.shape[0], dst.shape[1], _stream()), 'nfx_zero_rows')
+    return dst
+
+
+def lvis_fwd(xyz, lxyz, blob, xyz_scale=1., xyz_dir=None, prec='bf16', out=None, out_row=None, nan_flag=None):
     """lvis[n, L]: the light-visibility MLP for every (surface point, light) pair.  `xyz_dir`
-    (default xyz) are the points the light directions are taken from."""
+    (default xyz) are the points the light directions are taken from.
+    Round 6: with `out` [n_all, L] and `out_row` [n] int32 the visibilities of point i are stored at out[out_row[i]] — the
+    zero-filled scatter of shape.py:171-176 without its pass (the caller zeroes the other rows: zero_rows) — and `nan_flag`
+    (int32[1], zeroed by the caller) receives a 1 if any of them is NaN (tf.debugging.check_numerics without its pass)."""
     xyz = _dev(xyz, 'xyz', (None, 3))
     xyz_dir = _dev(xyz_dir, 'xyz_dir', (xyz.shape[0], 3))
     lxyz = _dev(lxyz, 'lxyz', (None, 3))
     n, nl = xyz.shape[0], lxyz.shape[0]
-    out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
     ws_bytes = 0 if prec == 'fp32' else lib.nfx_lvis_workspace_bytes(n)   # (the fp32-class kernel has no per-point fold)
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=xyz.device)
+    if out_row is not None:
+        if out is None or not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 2 or out.shape[1] != nl:
+            raise _capi.NfxError("lvis_fwd: `out` must be a contiguous CUDA float32 [n_all, %d] tensor" % nl)
+        if not out_row.is_cuda or out_row.dtype != torch.int32 or not out_row.is_contiguous() or out_row.shape != (n,):
+            raise _capi.NfxError("lvis_fwd: `out_row` must be a contiguous CUDA int32 [%d] tensor" % n)
+        check(lib.nfx_lvis_fwd_rows(_ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
+                                    ws.numel() * 4, ctypes.c_void_p(out_row.data_ptr()), _ptr(out),
+                                    None if nan_flag is None else ctypes.c_void_p(nan_flag.data_ptr()), _stream()), 'nfx_lvis_fwd_rows')
+        return out
+    out = torch.empty((n, nl), dtype=torch.float32, device=xyz.device)
     check(lib.nfx_lvis_fwd(_ptr(xyz), _ptr(xyz_dir), n, xyz_scale, _ptr(lxyz), nl, _ptr(blob), _PREC[prec], _ptr(ws),
                            ws.numel() * 4, _ptr(out), _stream()), 'nfx_lvis_fwd')
     _lvis_verify(out, xyz, xyz_dir, xyz_scale, lxyz, blob, prec)
@@ -625,23 +652,28 @@ def brdf_spec_fwd(xyz, cam, normal, z, lxyz, blob, prec='bf16'):
     return out
 
 
-def _shade_common(xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas):
+def _shade_common(xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, lvis_row=None):
     xyz = _dev(xyz, 'xyz', (None, 3))
     n = xyz.shape[0]
     lxyz = _dev(lxyz, 'lxyz', (None, 3))
     nl = lxyz.shape[0]
     if rough is not None and rough.dim() == 2:
         rough = rough.reshape(-1)
+    if lvis_row is not None and (not lvis_row.is_cuda or lvis_row.dtype != torch.int32 or not lvis_row.is_contiguous()
+                                 or lvis_row.shape != (n,)):
+        raise _capi.NfxError("shade: `lvis_row` must be a contiguous CUDA int32 [%d] tensor" % n)
     return (xyz, _dev(cam, 'cam', (n, 3)), _dev(normal, 'normal', (n, 3)),
             _dev(albedo, 'albedo', (n, 3)), _dev(rough, 'rough', (n,)), _dev(spec, 'spec', (n, nl)),
-            _dev(lvis, 'lvis', (n, nl)), lxyz, _dev(lareas.reshape(-1), 'lareas', (nl,)), n, nl)
+            _dev(lvis, 'lvis', (n if lvis_row is None else None, nl)), lxyz, _dev(lareas.reshape(-1), 'lareas', (nl,)), n, nl)
 
 
 def shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, lights, rough=None, spec=None,
-              spec_scale=1., f0=0.04, linear2srgb=True):
-    """rgb[n, P, 3] for P lights [P, L, 3] (microfacet BRDF if `rough`, else albedo/pi + spec)."""
+              spec_scale=1., f0=0.04, linear2srgb=True, lvis_row=None):
+    """rgb[n, P, 3] for P lights [P, L, 3] (microfacet BRDF if `rough`, else albedo/pi + spec).  `lvis_row` [n] int32: the
+    visibilities of point i are row lvis_row[i] of `lvis` (a full-size buffer written by lvis_fwd(out=, out_row=))."""
     xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
-        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
+        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, lvis_row)
+    row_p = None if lvis_row is None else ctypes.c_void_p(lvis_row.data_ptr())
     lights = _dev(lights, 'lights', (None, nl, 3))
     p_total = lights.shape[0]
     out = torch.empty((n, p_total, 3), dtype=torch.float32, device=xyz.device)
@@ -653,23 +685,24 @@ def shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, lights, rough=None, 
         chunk = lights[p0:p0 + p_max].contiguous()
         dst = out if p_max == p_total else torch.empty((n, chunk.shape[0], 3), dtype=torch.float32,
                                                       device=xyz.device)
-        check(lib.nfx_shade_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
-                                spec_scale, f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), _ptr(chunk), n, nl,
-                                chunk.shape[0], int(linear2srgb), _ptr(dst), _stream()), 'nfx_shade_fwd')
+        check(lib.nfx_shade_fwd_rows(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
+                                     spec_scale, f0, _ptr(lvis), row_p, _ptr(lxyz), _ptr(lareas), _ptr(chunk), n, nl,
+                                     chunk.shape[0], int(linear2srgb), _ptr(dst), _stream()), 'nfx_shade_fwd')
         if dst is not out:
             out[:, p0:p0 + chunk.shape[0]] = dst
     return out
 
 
 def shade_olat_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, olat_inten, ambient, rough=None,
-                   spec=None, spec_scale=1., f0=0.04, linear2srgb=True):
-    """rgb_olat[n, L, 3]: one-light-at-a-time relighting."""
+                   spec=None, spec_scale=1., f0=0.04, linear2srgb=True, lvis_row=None):
+    """rgb_olat[n, L, 3]: one-light-at-a-time relighting (`lvis_row`: as in shade_fwd)."""
     xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
-        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas)
+        xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, lvis_row)
     out = torch.empty((n, nl, 3), dtype=torch.float32, device=xyz.device)
-    check(lib.nfx_shade_olat_fwd(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
-                                 spec_scale, f0, _ptr(lvis), _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
-                                 n, nl, int(linear2srgb), _ptr(out), _stream()), 'nfx_shade_olat_fwd')
+    check(lib.nfx_shade_olat_fwd_rows(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
+                                      spec_scale, f0, _ptr(lvis), None if lvis_row is None else ctypes.c_void_p(lvis_row.data_ptr()),
+                                      _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
+                                      n, nl, int(linear2srgb), _ptr(out), _stream()), 'nfx_shade_olat_fwd')
     return out
 
 

@@ -81,6 +81,12 @@ for n in sizes:
     lblob = pack(layers, out, _capi.IN_XYZ_LDIR, 1, cuda)
     largs = (dev(xyz, cuda), dev(lxyz, cuda), lblob)
     soak('resident128_kernel<2,0,8> (lvis, default)', lambda: ops.lvis_fwd(*largs), {'lvis_variant': 4}, {'lvis_variant': 8}, n)
+    # round 6: the same kernel storing at final rows (what a render with background rays launches): a 60 % subset of a 5/3 n buffer
+    n_all = n * 5 // 3
+    out_row = torch.from_numpy(np.sort(np.random.default_rng(7).choice(n_all, n, replace=False)).astype(np.int32)).to(cuda)
+    full = torch.zeros((n_all, lxyz.shape[0]), device=cuda)
+    soak('resident128_kernel<2,0,8,true> (lvis at final rows)', lambda: ops.lvis_fwd(*largs, out=full, out_row=out_row).clone(),
+         {'lvis_variant': 4}, {'lvis_variant': 8}, n)
     layers, out = net128(40 + zd, zd + 15, 1)
     bblob = pack(layers, out, _capi.IN_Z_RUSINK, 1, cuda, z_dim=zd)
     bargs = (dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(z, cuda), dev(lxyz, cuda), bblob)

@@ -32,7 +32,8 @@ def test_every_kernel_has_metadata(rows):
 def test_two_wave_kernels_of_the_resident_networks_use_no_scratch(rows):
     two_wave = [r for r in rows if 'lv2::' in r['name'] and r['max_flat_workgroup_size'] == 512]
     names = sorted(r['name'].split('(')[0] for r in two_wave)
-    assert any('resident128_kernel<2, 0, 8>' in n for n in names), names          # the default light-visibility kernel
+    assert any('resident128_kernel<2, 0, 8, false>' in n for n in names), names   # the default light-visibility kernel
+    assert any('resident128_kernel<2, 0, 8, true>' in n for n in names), names    # ... and its form that stores at final rows (round 6)
     assert any('brdf_compact_kernel<2, 1, 8>' in n for n in names), names         # the opt-in learned-BRDF kernel
     assert not any('brdf_compact_kernel<2, 0, 8>' in n for n in names), "the failing form is not part of the product"
     for r in two_wave:

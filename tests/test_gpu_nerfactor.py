@@ -612,3 +612,100 @@ def test_lvis_verify_option_checks_the_two_wave_kernel_against_the_one_wave_form
     with pytest.raises(_capi.NfxError, match="lvis_verify"):
         for _ in range(4):
             ops.lvis_fwd(x, l, blob)
+
+
+@pytest.mark.determinism
+@pytest.mark.parametrize("variant", ["8", "4"])
+def test_lvis_rows_mode_stores_at_final_rows_and_flags_nans(nfx_lib, cuda, nfx_opt, variant):
+    """nfx_lvis_fwd_rows (round 6): the visibilities of compact point i land in row out_row[i] of a full-size buffer, bit-identical
+    to the compact launch; rows that are not named stay what they were (nfx_zero_rows zeroes exactly the background rows); a NaN
+    input raises the flag; the shading kernels read the same rows through `lvis_row`."""
+    from nerfactor_amd import ops
+    nfx_opt.set("lvis_variant", variant)
+    layers, out = net128(30, 90, 1)
+    blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
+    n_all, n = 3000, 1777
+    rng, lxyz, lareas, xyz, cam, normal = scene(n, 31)
+    rows = np.sort(rng.choice(n_all, n, replace=False)).astype(np.int32)
+    x, l = dev(xyz, cuda), dev(lxyz, cuda)
+    compact = ops.lvis_fwd(x, l, blob)
+    full = torch.full((n_all, l.shape[0]), -7., device=cuda)
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda)
+    out_row = torch.from_numpy(rows).to(cuda)
+    assert ops.lvis_rows_supported()
+    got = ops.lvis_fwd(x, l, blob, out=full, out_row=out_row, nan_flag=flag)
+    assert got is full and int(flag.item()) == 0
+    assert torch.equal(full[out_row.long()], compact)
+    others = torch.ones(n_all, dtype=torch.bool, device=cuda)
+    others[out_row.long()] = False
+    assert bool((full[others] == -7.).all())
+    row_of = torch.full((n_all,), -1, dtype=torch.int32, device=cuda)
+    row_of[out_row.long()] = torch.arange(n, dtype=torch.int32, device=cuda)
+    ops.zero_rows(full, row_of)
+    assert torch.equal(full, ops.scatter_rows(compact, row_of, n_all))            # = the zero-filled scatter of the compact tensor
+    # shading through the row index = shading of the compact tensor
+    albedo = dev(rng.uniform(0.1, 0.9, size=(n, 3)), cuda)
+    rough = dev(rng.uniform(0.1, 0.9, size=(n,)), cuda)
+    lights = dev(rng.uniform(0, 2, size=(3, l.shape[0], 3)), cuda)
+    args = (x, dev(cam, cuda), dev(normal, cuda), albedo)
+    a = ops.shade_fwd(*args, compact, l, dev(lareas, cuda), lights, rough=rough)
+    b = ops.shade_fwd(*args, full, l, dev(lareas, cuda), lights, rough=rough, lvis_row=out_row)
+    assert torch.equal(a, b)
+    a = ops.shade_olat_fwd(*args, compact, l, dev(lareas, cuda), 200., 0.1, rough=rough)
+    b = ops.shade_olat_fwd(*args, full, l, dev(lareas, cuda), 200., 0.1, rough=rough, lvis_row=out_row)
+    assert torch.equal(a, b)
+    # a NaN position: the kernel's own epilogue reports it
+    xb = x.clone()
+    xb[5, 1] = float('nan')
+    flag.zero_()
+    ops.lvis_fwd(xb, l, blob, out=full, out_row=out_row, nan_flag=flag)
+    assert int(flag.item()) == 1
+    # unsupported forms say so
+    nfx_opt.set("lvis_variant", "0")
+    assert not ops.lvis_rows_supported()
+    with pytest.raises(nfx_lib.NfxError):
+        ops.lvis_fwd(x, l, blob, out=full, out_row=out_row)
+
+
+@pytest.mark.determinism
+@pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor"])
+def test_render_with_background_rays_is_the_same_through_the_final_row_stores(nfx_lib, cuda, nfx_opt, name):
+    """Model.call(mode='test', relight_probes, relight_olat) on a batch with background rays: the round-6 path (visibilities stored
+    at their final rows by the kernel, shading through the row index, NaN flag from the kernel) against the round-5 path
+    (compact tensor + nfx_scatter_rows + nfx_any_nonfinite; forced here by an lvis variant without row stores, whose
+    visibilities are bit-identical): every output tensor bit for bit; and a NaN point raises as check_numerics would."""
+    from nerfactor_amd import synth
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    torch.manual_seed(5)
+    cfg = make_config(name, shape_mode='finetune', shape_model_ckpt='none', brdf_model_ckpt='none', test_envmap_dir='', xyz_jitter_std='0')
+    model = get_model_class(name)(cfg).to(cuda)
+    for i, p in enumerate(synth.probes(2, seed=20)):
+        model.add_probe('p%d' % i, p)
+    hb = synth.surface_batch(5000, seed=3, n_lights=512)
+    batch = tuple(None if a is None else torch.from_numpy(a).to(cuda) for a in hb)
+
+    def run():
+        with torch.no_grad():
+            pred, gt, _, _ = model(batch, mode='test', relight_probes=True, relight_olat=True)
+        return {k: v.clone() for k, v in pred.items()}, {k: v.clone() for k, v in gt.items()}
+    assert model._lvis_rows_ok()
+    new, gt_new = run()
+    nfx_opt.set("lvis_variant", "0")
+    assert not model._lvis_rows_ok()
+    old, gt_old = run()
+    nfx_opt.unset("lvis_variant")
+    assert set(new) == set(old) and {'rgb', 'lvis', 'rgb_probes', 'rgb_olat'} <= set(new)
+    for k in new:
+        assert torch.equal(new[k], old[k]), k
+    for k in gt_new:
+        assert torch.equal(gt_new[k], gt_old[k]), k
+    bg = batch[5][:, 0] == 0
+    assert 0.3 * bg.numel() < int(bg.sum()) < 0.5 * bg.numel() and not bool(new['lvis'][bg].any())
+    bad = list(batch)
+    bad[6] = batch[6].clone()
+    fg_row = int(torch.nonzero(~bg)[7])
+    bad[6][fg_row, 0] = float('nan')
+    with pytest.raises(FloatingPointError, match="Light visibility|Albedo|numerics|Normal"):
+        with torch.no_grad():
+            model(tuple(bad), mode='test')
