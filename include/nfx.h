@@ -212,7 +212,10 @@ NFX_API int nfx_lvis_fwd(const float *dev_xyz, const float *dev_xyz_dir, int64_t
 /* Dynamic LDS the shading kernels need for a given sphere / probe count (must be <= 160 KiB). */
 NFX_API size_t nfx_shade_lds_bytes(int n_lights, int n_probes);
 /* nfx_shade_fwd_rows / nfx_shade_olat_fwd_rows (round 6): dev_lvis_row [n] int32 (or NULL) = the row of point i in
- * dev_lvis — the visibilities may live in the full [n_all, n_lights] buffer nfx_lvis_fwd_rows wrote.               */
+ * dev_lvis — the visibilities may live in the full [n_all, n_lights] buffer nfx_lvis_fwd_rows wrote.  The OLAT form also
+ * takes dev_out_row [n] int32 (or NULL) = the row of point i in dev_rgb_olat, then the caller's full [n_all, n_lights, 3]
+ * buffer (background rows: nfx_zero_rows with d = 3 n_lights), and dev_nan_flag (or NULL): 1 is OR-ed into the int32 when a
+ * radiance is NaN before the clip to [0, 1] (tf.debugging.check_numerics of nerfactor.py:363 without its pass).        */
 NFX_API int nfx_shade_fwd_rows(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                        const float *dev_albedo, const float *dev_rough, const float *dev_spec, float spec_scale,
                        float f0, const float *dev_lvis, const int32_t *dev_lvis_row, const float *dev_lxyz,
@@ -222,7 +225,8 @@ NFX_API int nfx_shade_olat_fwd_rows(const float *dev_xyz, const float *dev_cam, 
                             const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                             float spec_scale, float f0, const float *dev_lvis, const int32_t *dev_lvis_row,
                             const float *dev_lxyz, const float *dev_lareas, float olat_inten, float ambient,
-                            int64_t n, int n_lights, int linear2srgb, float *dev_rgb_olat, void *stream);
+                            int64_t n, int n_lights, int linear2srgb, const int32_t *dev_out_row,
+                            float *dev_rgb_olat, int *dev_nan_flag, void *stream);
 NFX_API int nfx_shade_fwd(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
                   const float *dev_albedo, const float *dev_rough, const float *dev_spec,
                   float spec_scale, float f0, const float *dev_lvis, const float *dev_lxyz,

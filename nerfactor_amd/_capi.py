@@ -91,7 +91,7 @@ SIGNATURES = {
     'nfx_lvis_fwd_rows': (_i, [_p, _p, _i64, _f, _p, _i, _p, _i, _p, _sz, _p, _p, _p, _p]),
     'nfx_zero_rows': (_i, [_p, _p, _i64, _i, _p]),
     'nfx_shade_fwd_rows': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
-    'nfx_shade_olat_fwd_rows': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _f, _f, _i64, _i, _i, _p, _p]),
+    'nfx_shade_olat_fwd_rows': (_i, [_p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _f, _f, _i64, _i, _i, _p, _p, _p, _p]),
     'nfx_nerf_refine_select': (_i, [_p, _p, _p, _i64, _i, _f, _f, _f, _f, _i, _p, _p, _p]),
     'nfx_nerf_sigma_refine': (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
     'nfx_nerf_geom_packed_bytes': (_sz, [_i]),
@@ -138,7 +138,7 @@ def check(rc, what):
 
 # ------------------------------------------------------------------------------- options
 OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
-               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify')
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows')
 
 
 def set_option(key, value):

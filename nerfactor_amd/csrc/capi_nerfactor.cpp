@@ -43,7 +43,7 @@ int nfx_launch_shade(const float*, const float*, const float*, const float*, con
                      float*, hipStream_t, const int*);
 int nfx_launch_shade_olat(const float*, const float*, const float*, const float*, const float*, const float*,
                           float, float, const float*, const float*, const float*, float, float, long long, int,
-                          int, float*, hipStream_t, const int*);
+                          int, float*, hipStream_t, const int*, const int*, int*);
 int nfx_launch_dir2rusink(const float*, const float*, long long, float*, hipStream_t);
 size_t nfx_shade_olat_lds_bytes(int n_lights);
 int nfx_mlp128_x3_weight_bytes(int in_kind);   // mlp128_x3.hip
@@ -365,12 +365,13 @@ int nfx_shade_olat_fwd(const float* xyz, const float* cam, const float* normal, 
                        const float* lxyz, const float* lareas, float olat_inten, float ambient, int64_t n,
                        int n_lights, int linear2srgb, float* rgb_olat, void* stream) {
     return nfx_shade_olat_fwd_rows(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, nullptr, lxyz, lareas,
-                                   olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat, stream);
+                                   olat_inten, ambient, n, n_lights, linear2srgb, nullptr, rgb_olat, nullptr, stream);
 }
 int nfx_shade_olat_fwd_rows(const float* xyz, const float* cam, const float* normal, const float* albedo,
                             const float* rough, const float* spec, float spec_scale, float f0, const float* lvis,
                             const int32_t* lvis_row, const float* lxyz, const float* lareas, float olat_inten,
-                            float ambient, int64_t n, int n_lights, int linear2srgb, float* rgb_olat, void* stream) {
+                            float ambient, int64_t n, int n_lights, int linear2srgb, const int32_t* out_row,
+                            float* rgb_olat, int* nan_flag, void* stream) {
     int rc =
         check_shade("nfx_shade_olat_fwd", xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, n_lights);
     if (rc) return rc;
@@ -380,7 +381,7 @@ int nfx_shade_olat_fwd_rows(const float* xyz, const float* cam, const float* nor
     REQUIRE(rgb_olat, "nfx_shade_olat_fwd: null output");
     return nfx_hip_result(nfx_launch_shade_olat(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz,
                                                 lareas, olat_inten, ambient, n, n_lights, linear2srgb, rgb_olat,
-                                                (hipStream_t)stream, lvis_row),
+                                                (hipStream_t)stream, lvis_row, out_row, nan_flag),
                           "shade_olat_fwd");
 }
 

@@ -17,6 +17,9 @@ struct ShadeArgs {
     float olat_inten, ambient;
     float* out;
     const int* lvis_row;   // optional (round 6): row of point i in `lvis` — the visibilities live in the caller's FULL [n_all, L] buffer
+    const int* out_row;    // optional (round 6, OLAT kernel): row of point i in `out` — the caller's FULL [n_all, L, 3] buffer
+    int* nan_flag;         // optional (round 6, OLAT kernel): 1 is OR-ed into it when a radiance is NaN BEFORE the clip to [0, 1]
+                           // (tf.clip_by_value keeps a NaN, fminf / fmaxf do not: the check_numerics of nerfactor.py:363 has to look here)
 };
 
 struct PointCtx {
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_olat_kernel(ShadeArgs 
     };
     long long pt = (long long)blockIdx.x * kShadeWaves + wave;
     fetch(pt);
+    bool bad = false;
     for (; pt < a.n; pt += stride) {
         PointCtx pc;
         load_point(a, pt, pc);
@@ -218,28 +222,34 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_olat_kernel(ShadeArgs 
         } else {
             tot[0] = tot[1] = tot[2] = 0.0f;
         }
-        float* o = a.out + pt * L * 3;
+        float* o = a.out + (a.out_row ? (long long)a.out_row[pt] : pt) * L * 3;
 #pragma unroll
         for (int k = 0; k < kLightsPerPass; ++k) {
             const int l = k * 64 + lane;
             if (l < L) {
+                const float r0 = a.olat_inten * T0[k][0] + tot[0], r1 = a.olat_inten * T0[k][1] + tot[1],
+                            r2 = a.olat_inten * T0[k][2] + tot[2];
+                bad = bad || !(r0 + r1 + r2 == r0 + r1 + r2);      // (a NaN in any channel; Inf - Inf cannot arise: all terms >= 0)
                 f32x3_t v;
-                v.x = tonemap_fast(a.olat_inten * T0[k][0] + tot[0], a.to_srgb);
-                v.y = tonemap_fast(a.olat_inten * T0[k][1] + tot[1], a.to_srgb);
-                v.z = tonemap_fast(a.olat_inten * T0[k][2] + tot[2], a.to_srgb);
+                v.x = tonemap_fast(r0, a.to_srgb);
+                v.y = tonemap_fast(r1, a.to_srgb);
+                v.z = tonemap_fast(r2, a.to_srgb);
                 *reinterpret_cast<f32x3_t*>(o + 3 * l) = v;
             }
         }
         for (int l = 64 * kLightsPerPass + lane; l < L; l += 64) {
             float T[3];
             light_transport(a, pc, pt, l, lxyz_s, area_s, T);
+            const float r0 = a.olat_inten * T[0] + tot[0], r1 = a.olat_inten * T[1] + tot[1], r2 = a.olat_inten * T[2] + tot[2];
+            bad = bad || !(r0 + r1 + r2 == r0 + r1 + r2);
             f32x3_t v;
-            v.x = tonemap_fast(a.olat_inten * T[0] + tot[0], a.to_srgb);
-            v.y = tonemap_fast(a.olat_inten * T[1] + tot[1], a.to_srgb);
-            v.z = tonemap_fast(a.olat_inten * T[2] + tot[2], a.to_srgb);
+            v.x = tonemap_fast(r0, a.to_srgb);
+            v.y = tonemap_fast(r1, a.to_srgb);
+            v.z = tonemap_fast(r2, a.to_srgb);
             *reinterpret_cast<f32x3_t*>(o + 3 * l) = v;
         }
     }
+    if (a.nan_flag != nullptr && __ballot(bad) != 0ull && lane == 0) atomicOr(a.nan_flag, 1);
 }
 
 __global__ void dir2rusink_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
@@ -262,9 +272,12 @@ static nfx::ShadeArgs make_args(const float* xyz, const float* cam, const float*
                                 const float* rough, const float* spec, float spec_scale, float f0,
                                 const float* lvis, const float* lxyz, const float* lareas,
                                 const float* lights, long long n, int n_lights, int n_probes, int to_srgb,
-                                float olat_inten, float ambient, float* out, const int* lvis_row = nullptr) {
+                                float olat_inten, float ambient, float* out, const int* lvis_row = nullptr,
+                                const int* out_row = nullptr, int* nan_flag = nullptr) {
     nfx::ShadeArgs a;
     a.lvis_row = lvis_row;
+    a.out_row = out_row;
+    a.nan_flag = nan_flag;
     a.xyz = xyz; a.cam = cam; a.normal = normal; a.albedo = albedo; a.rough = rough; a.spec = spec;
     a.lvis = lvis; a.lxyz = lxyz; a.lareas = lareas; a.lights = lights;
     a.spec_scale = spec_scale; a.f0 = f0; a.n = n; a.n_lights = n_lights; a.n_probes = n_probes;
@@ -296,7 +309,7 @@ int nfx_launch_shade_olat(const float* xyz, const float* cam, const float* norma
                           const float* rough, const float* spec, float spec_scale, float f0,
                           const float* lvis, const float* lxyz, const float* lareas, float olat_inten,
                           float ambient, long long n, int n_lights, int to_srgb, float* out, hipStream_t st,
-                          const int* lvis_row) {
+                          const int* lvis_row, const int* out_row, int* nan_flag) {
     if (n <= 0) return 0;
     const size_t lds = nfx_shade_olat_lds_bytes(n_lights);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::shade_olat_kernel),
@@ -306,7 +319,7 @@ int nfx_launch_shade_olat(const float* xyz, const float* cam, const float* norma
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(nfx::shade_olat_kernel, dim3((unsigned)blocks), dim3(nfx::kShadeWaves * 64), lds, st,
                        make_args(xyz, cam, normal, albedo, rough, spec, spec_scale, f0, lvis, lxyz, lareas,
-                                 nullptr, n, n_lights, 0, to_srgb, olat_inten, ambient, out, lvis_row));
+                                 nullptr, n, n_lights, 0, to_srgb, olat_inten, ambient, out, lvis_row, out_row, nan_flag));
     return (int)hipGetLastError();
 }
 int nfx_launch_dir2rusink(const float* a, const float* b, long long n, float* out, hipStream_t st) {

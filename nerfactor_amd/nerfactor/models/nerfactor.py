@@ -255,11 +255,11 @@ class Model(ShapeModel):
         # ------ rendering equation
         rgb_pred, rgb_olat, rgb_probes = self._render(
             xyz, rayo, normal_pred, albedo, brdf_prop, lvis_pred, relight_olat=relight_olat,
-            relight_probes=relight_probes, lvis_row=lvis_row)
+            relight_probes=relight_probes, lvis_row=lvis_row, row_of=rows() if lvis_row is not None else None)
 
         def full(v):  # zero-filled scatter back to all rays (tf.scatter_nd)
-            if v is None or all_fg or v is lvis_full:       # (lvis_full: already at its final rows)
-                return v
+            if v is None or all_fg or v.shape[0] == n_all:   # (n_all rows while some rays are background: the kernel stored
+                return v                                     #  the foreground rows at their final place — lvis, rgb_olat)
             if v.is_cuda and v.dtype == torch.float32 and not (torch.is_grad_enabled() and v.requires_grad):
                 # one pass that writes every output row once (nfx_scatter_rows) instead of zeros + index_put_
                 return ops.scatter_rows(v.contiguous(), rows(), n_all)
@@ -343,9 +343,10 @@ class Model(ShapeModel):
         return albedo[:, None, :] / np.pi + spec.reshape(n, nl, 1).expand(n, nl, 3) * scale
 
     def _render(self, xyz, cam, normal, albedo, brdf_prop, light_vis, relight_olat=False,
-                relight_probes=False, white_light_override=False, white_lvis_override=False, lvis_row=None):
+                relight_probes=False, white_light_override=False, white_lvis_override=False, lvis_row=None, row_of=None):
         """`lvis_row` (round 6, inference only): light_vis is a full-size [n_all, L] buffer and row lvis_row[i] of it belongs
-        to point i (ops.lvis_fwd(out=, out_row=))."""
+        to point i (ops.lvis_fwd(out=, out_row=)); `row_of` [n_all] int32 is its inverse (-1: background).  The OLAT renders
+        — [n, 512, 3], the largest tensor of the model — are then stored at their final rows as well and come back full-size."""
         to_srgb = self.config.getboolean('DEFAULT', 'linear2srgb')
         light = torch.ones_like(self.light) if white_light_override else self.light
         if white_lvis_override:
@@ -366,14 +367,25 @@ class Model(ShapeModel):
         rgb_probes = out[:, 1:] if relight_probes else None
         rgb_olat = None
         if relight_olat:
-            rgb_olat = ops.shade_olat_fwd(*common, self.olat_inten, self.olat_ambient,
-                                          linear2srgb=to_srgb, **terms)
-            if len(self.novel_olat) != rgb_olat.shape[1]:  # debug mode keeps the 2x2 corner only
-                keep = [i * self.light_res[1] + j for (i, j) in self.novel_olat.values()]
-                rgb_olat = rgb_olat[:, keep]
-        for name, v in (("OLAT Renders", rgb_olat), ("Light Probe Renders", rgb_probes)):
-            if v is not None:
-                self.check_numerics(v, name)
+            n_l = self.lxyz.reshape(-1, 3).shape[0]
+            if lvis_row is not None and row_of is not None and len(self.novel_olat) == n_l:
+                # stored at the final rows by the kernel, NaN flag from its epilogue (before the clip, where tf.clip_by_value
+                # would still show it): no [n, 512, 3] scatter (6.3 GB of traffic per 800 x 800 view), no check_numerics pass
+                rgb_olat = torch.empty((row_of.shape[0], n_l, 3), dtype=torch.float32, device=xyz.device)
+                ops.zero_rows(rgb_olat.view(row_of.shape[0], n_l * 3), row_of)
+                flag = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+                ops.shade_olat_fwd(*common, self.olat_inten, self.olat_ambient, linear2srgb=to_srgb, out=rgb_olat,
+                                   out_row=lvis_row, nan_flag=flag, **terms)
+                self.check_flag(flag == 0, "OLAT Renders")
+            else:
+                rgb_olat = ops.shade_olat_fwd(*common, self.olat_inten, self.olat_ambient,
+                                              linear2srgb=to_srgb, **terms)
+                if len(self.novel_olat) != rgb_olat.shape[1]:  # debug mode keeps the 2x2 corner only
+                    keep = [i * self.light_res[1] + j for (i, j) in self.novel_olat.values()]
+                    rgb_olat = rgb_olat[:, keep]
+                self.check_numerics(rgb_olat, "OLAT Renders")
+        if rgb_probes is not None:
+            self.check_numerics(rgb_probes, "Light Probe Renders")
         return rgb, rgb_olat, rgb_probes
 
     def _render_train(self, xyz, cam, normal, albedo, brdf_prop, light_vis, light, to_srgb):

@@ -560,7 +560,7 @@ def mlp128_xyz_fwd(xyz, blob, out_dim, out_act=None, xyz_scale=1., post_scale=1.
 def lvis_rows_supported(prec='bf16'):
     """Can lvis_fwd write straight into the rows of a full-size buffer (nfx_lvis_fwd_rows)?  bf16 kernels with the network
     resident in LDS: the default and lvis_variant 2 | 3 | 4."""
-    return prec == 'bf16' and _capi.get_option("lvis_variant") in (None, 8, 2, 3, 4)
+    return prec == 'bf16' and _capi.get_option("lvis_variant") in (None, 8, 2, 3, 4) and _capi.get_option("lvis_rows") != 0
 
 
 def zero_rows(dst, row_of):
@@ -694,15 +694,24 @@ def shade_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, lights, rough=None, 
 
 
 def shade_olat_fwd(xyz, cam, normal, albedo, lvis, lxyz, lareas, olat_inten, ambient, rough=None,
-                   spec=None, spec_scale=1., f0=0.04, linear2srgb=True, lvis_row=None):
-    """rgb_olat[n, L, 3]: one-light-at-a-time relighting (`lvis_row`: as in shade_fwd)."""
+                   spec=None, spec_scale=1., f0=0.04, linear2srgb=True, lvis_row=None, out=None, out_row=None, nan_flag=None):
+    """rgb_olat[n, L, 3]: one-light-at-a-time relighting (`lvis_row`: as in shade_fwd).  `out` [n_all, L, 3] + `out_row` [n]
+    int32: the renders of point i go to out[out_row[i]] (the caller zeroes the other rows); `nan_flag` int32[1]: raised when a
+    radiance is NaN before the clip."""
     xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, n, nl = _shade_common(
         xyz, cam, normal, albedo, rough, spec, lvis, lxyz, lareas, lvis_row)
-    out = torch.empty((n, nl, 3), dtype=torch.float32, device=xyz.device)
+    if out_row is not None:
+        if out is None or not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape[1:]) != (nl, 3):
+            raise _capi.NfxError("shade_olat_fwd: `out` must be a contiguous CUDA float32 [n_all, %d, 3] tensor" % nl)
+        if not out_row.is_cuda or out_row.dtype != torch.int32 or not out_row.is_contiguous() or out_row.shape != (n,):
+            raise _capi.NfxError("shade_olat_fwd: `out_row` must be a contiguous CUDA int32 [%d] tensor" % n)
+    else:
+        out = torch.empty((n, nl, 3), dtype=torch.float32, device=xyz.device)
+    as_p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     check(lib.nfx_shade_olat_fwd_rows(_ptr(xyz), _ptr(cam), _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(spec),
-                                      spec_scale, f0, _ptr(lvis), None if lvis_row is None else ctypes.c_void_p(lvis_row.data_ptr()),
-                                      _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
-                                      n, nl, int(linear2srgb), _ptr(out), _stream()), 'nfx_shade_olat_fwd')
+                                      spec_scale, f0, _ptr(lvis), as_p(lvis_row), _ptr(lxyz), _ptr(lareas), olat_inten, ambient,
+                                      n, nl, int(linear2srgb), as_p(out_row), _ptr(out), as_p(nan_flag), _stream()),
+          'nfx_shade_olat_fwd')
     return out
 
 

@@ -44,6 +44,8 @@ PYEOF
     time-refine) timeout 600 python scripts/time_refine.py > $OUT/time_refine.json 2> $OUT/time_refine.err; cat $OUT/time_refine.json; tail -3 $OUT/time_refine.err ;;
     bench-traffic) timeout 1200 python bench.py --gpus 1 --steps 10 --warmup 3 --measure-traffic --legs nerf,nerfactor_microfacet,olat > $OUT/bench_line_measured_traffic.json 2> $OUT/bench_traffic.err; cp bench_detail.json $OUT/bench_detail_measured_traffic.json; python -c "
 import json; d=json.load(open('$OUT/bench_detail_measured_traffic.json')); print('nerf', d['roofline']['traffic'], d['roofline']['traffic_source'][:60]); print('lvis', d['nerfactor']['nerfactor_microfacet']['roofline']['traffic'], d['nerfactor']['nerfactor_microfacet']['roofline']['traffic_source'][:40]); print('olat', d['olat']['roofline']['traffic'], d['olat']['roofline']['traffic_source'][:40])" ;;
+    bench-nerfactor-ab) for r in 1 0 1 0; do NFX_LVIS_ROWS=$r timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --legs nerfactor_microfacet,nerfactor,olat --no-cpu-baseline > $OUT/bench_nerfactor_rows$r.json 2> $OUT/bench_nerfactor_rows$r.err; python -c "
+import json; l=json.load(open('$OUT/bench_nerfactor_rows$r.json')); print('lvis_rows=$r', {k: round(v['ms_per_step'], 3) for k, v in l['legs'].items()})"; done ;;
     bench-nerfactor) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --legs nerfactor_microfacet,nerfactor,olat,relight --no-cpu-baseline > $OUT/bench_nerfactor_line.json 2> $OUT/bench_nerfactor.err; python -c "
 import json; l=json.load(open('$OUT/bench_nerfactor_line.json')); print(l['legs'])"; tail -3 $OUT/bench_nerfactor.err ;;
     rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;

@@ -654,12 +654,15 @@ def test_lvis_rows_mode_stores_at_final_rows_and_flags_nans(nfx_lib, cuda, nfx_o
     a = ops.shade_olat_fwd(*args, compact, l, dev(lareas, cuda), 200., 0.1, rough=rough)
     b = ops.shade_olat_fwd(*args, full, l, dev(lareas, cuda), 200., 0.1, rough=rough, lvis_row=out_row)
     assert torch.equal(a, b)
-    # a NaN position: the kernel's own epilogue reports it
-    xb = x.clone()
-    xb[5, 1] = float('nan')
+    # a NaN visibility: the kernel's own epilogue reports it.  (A NaN INPUT does not make one — v_med3 / fmaxf drop NaNs at the
+    # first ReLU and in the direction's normalisation, for the compact launch and check_numerics alike; NaN WEIGHTS, what a
+    # diverged training leaves behind, do: here the output layer's bias)
+    out_nan = [(out[0][0], np.full_like(out[0][1], np.nan))]
+    blob_nan = pack(layers, out_nan, nfx_lib.IN_XYZ_LDIR, 1, cuda)
     flag.zero_()
-    ops.lvis_fwd(xb, l, blob, out=full, out_row=out_row, nan_flag=flag)
-    assert int(flag.item()) == 1
+    ops.lvis_fwd(x, l, blob_nan, out=full, out_row=out_row, nan_flag=flag)
+    assert int(flag.item()) == 1 and bool(torch.isnan(full[out_row.long()]).all())
+    assert bool(torch.isnan(ops.lvis_fwd(x, l, blob_nan)).all())
     # unsupported forms say so
     nfx_opt.set("lvis_variant", "0")
     assert not ops.lvis_rows_supported()
@@ -672,8 +675,8 @@ def test_lvis_rows_mode_stores_at_final_rows_and_flags_nans(nfx_lib, cuda, nfx_o
 def test_render_with_background_rays_is_the_same_through_the_final_row_stores(nfx_lib, cuda, nfx_opt, name):
     """Model.call(mode='test', relight_probes, relight_olat) on a batch with background rays: the round-6 path (visibilities stored
     at their final rows by the kernel, shading through the row index, NaN flag from the kernel) against the round-5 path
-    (compact tensor + nfx_scatter_rows + nfx_any_nonfinite; forced here by an lvis variant without row stores, whose
-    visibilities are bit-identical): every output tensor bit for bit; and a NaN point raises as check_numerics would."""
+    (compact tensor + nfx_scatter_rows + nfx_any_nonfinite: option lvis_rows = 0): every output tensor bit for bit; and NaN
+    weights raise as check_numerics would."""
     from nerfactor_amd import synth
     from nerfactor_amd.nerfactor.config import make_config
     from nerfactor_amd.nerfactor.models import get_model_class
@@ -689,12 +692,14 @@ def test_render_with_background_rays_is_the_same_through_the_final_row_stores(nf
         with torch.no_grad():
             pred, gt, _, _ = model(batch, mode='test', relight_probes=True, relight_olat=True)
         return {k: v.clone() for k, v in pred.items()}, {k: v.clone() for k, v in gt.items()}
-    assert model._lvis_rows_ok()
+    with torch.no_grad():
+        assert model._lvis_rows_ok()
     new, gt_new = run()
-    nfx_opt.set("lvis_variant", "0")
-    assert not model._lvis_rows_ok()
+    nfx_opt.set("lvis_rows", "0")             # the round-5 path: compact tensor, nfx_scatter_rows, nfx_any_nonfinite
+    with torch.no_grad():
+        assert not model._lvis_rows_ok()
     old, gt_old = run()
-    nfx_opt.unset("lvis_variant")
+    nfx_opt.unset("lvis_rows")
     assert set(new) == set(old) and {'rgb', 'lvis', 'rgb_probes', 'rgb_olat'} <= set(new)
     for k in new:
         assert torch.equal(new[k], old[k]), k
@@ -702,10 +707,11 @@ def test_render_with_background_rays_is_the_same_through_the_final_row_stores(nf
         assert torch.equal(gt_new[k], gt_old[k]), k
     bg = batch[5][:, 0] == 0
     assert 0.3 * bg.numel() < int(bg.sum()) < 0.5 * bg.numel() and not bool(new['lvis'][bg].any())
-    bad = list(batch)
-    bad[6] = batch[6].clone()
-    fg_row = int(torch.nonzero(~bg)[7])
-    bad[6][fg_row, 0] = float('nan')
-    with pytest.raises(FloatingPointError, match="Light visibility|Albedo|numerics|Normal"):
-        with torch.no_grad():
-            model(tuple(bad), mode='test')
+    # NaN weights (a diverged training): the kernel's flag raises what check_numerics raised
+    with torch.no_grad():
+        model.net['lvis_out'].layers[0].bias.fill_(float('nan'))
+    for rows_on in ("1", "0"):
+        nfx_opt.set("lvis_rows", rows_on)
+        with pytest.raises(FloatingPointError, match="Light visibility"):
+            with torch.no_grad():
+                model(batch, mode='test')
