@@ -78,8 +78,9 @@ Option g_options[] = {
     {"lvis_variant", {0}, {0}},   // light visibility: 8 (default) | 2 | 3 | 4 | 0 — all bit-identical
     {"lvis_verify", {0}, {0}},    // k > 0: the HOST side (ops.lvis_fwd) re-runs ~1 % of the points of every k-th launch on the one-wave-per-SIMD
                                   //        kernel (variant 4) and raises on any differing bit; 0 / unset = off.  The library only stores it.
-    {"lvis_rows", {0}, {0}},      // 0: the HOST side renders through the round-5 path (compact visibilities + nfx_scatter_rows + nfx_any_nonfinite)
-                                  //    instead of nfx_lvis_fwd_rows / nfx_shade_olat_fwd_rows; 1 / unset = final-row stores.  A/B and identity tests.
+    {"lvis_rows", {0}, {0}},      // 1: the HOST side renders through nfx_lvis_fwd_rows / nfx_shade_olat_fwd_rows (visibilities and OLAT renders stored at
+                                  //    their final rows, NaN flags from the kernels); 0 / unset = compact tensors + nfx_scatter_rows + nfx_any_nonfinite.
+                                  //    Opt-in: measured equal within the noise (profiles/r06/render_rows_ab.txt).
     {"brdf_variant", {0}, {0}},   // learned BRDF: 6 (default) | 5 | 2 | 3 | 4 | 0
     {"brdf_ct", {0}, {0}},        // column tiles of brdf variants 5 / 6: 4 (default) | 2 | 3; 8 = two waves per SIMD (variant 6 only)
     {"nerf_bwd", {0}, {0}},       // 1 (default) = LDS-DMA ring backward, 0 = register-staged identity reference

@@ -242,9 +242,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
                 lq[c][k] = a.lxyz[l * 3 + k];
             }
             if constexpr (ROWS) {
-                const long long ob = (long long)a.out_row[pt] * n_lights + l0;
-                obq_lo[c] = __builtin_amdgcn_readfirstlane((unsigned)ob);
-                obq_hi[c] = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ob >> 32));
+                // everything scalar: the point index is wave-uniform, so its row comes by s_load (no vector-memory wait in
+                // front of the prefetch — a readfirstlane of a vector LOAD made every tile wait for the loads it had just issued)
+                const unsigned long long ptu = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pt >> 32)) << 32) |
+                                               __builtin_amdgcn_readfirstlane((unsigned)pt);
+                const long long ob = (long long)a.out_row[ptu] * n_lights + __builtin_amdgcn_readfirstlane(l0);
+                obq_lo[c] = (unsigned)ob;
+                obq_hi[c] = (unsigned)((unsigned long long)ob >> 32);
             }
         }
     };

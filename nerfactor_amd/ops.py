@@ -558,9 +558,13 @@ def mlp128_xyz_fwd(xyz, blob, out_dim, out_act=None, xyz_scale=1., post_scale=1.
 
 
 def lvis_rows_supported(prec='bf16'):
-    """Can lvis_fwd write straight into the rows of a full-size buffer (nfx_lvis_fwd_rows)?  bf16 kernels with the network
-    resident in LDS: the default and lvis_variant 2 | 3 | 4."""
-    return prec == 'bf16' and _capi.get_option("lvis_variant") in (None, 8, 2, 3, 4) and _capi.get_option("lvis_rows") != 0
+    """Does a render store its visibilities (and OLAT renders) straight into the rows of the full-size buffers
+    (nfx_lvis_fwd_rows / nfx_shade_olat_fwd_rows)?  OPT-IN: nfx_set_option("lvis_rows", 1) — measured on one box, 20 steps
+    each, A/B/A/B (profiles/r06/render_rows_ab.txt): NeRFactor-microfacet render 21.48 / 21.31 ms with, 22.10 / 21.15 without;
+    learned BRDF 31.26 / 30.94 against 30.72 / 30.48; OLAT view 22.57 / 22.41 against 22.79 / 22.81 — the scatter and
+    check_numerics passes it removes (~0.8 ms of traffic) are paid back by a 1 % slower kernel and the zero-fill: no gain worth
+    a second two-waves-per-SIMD kernel form as the default.  bf16 kernels with the network resident in LDS only."""
+    return prec == 'bf16' and _capi.get_option("lvis_variant") in (None, 8, 2, 3, 4) and _capi.get_option("lvis_rows") == 1
 
 
 def zero_rows(dst, row_of):

@@ -82,6 +82,7 @@ for n in sizes:
     largs = (dev(xyz, cuda), dev(lxyz, cuda), lblob)
     soak('resident128_kernel<2,0,8> (lvis, default)', lambda: ops.lvis_fwd(*largs), {'lvis_variant': 4}, {'lvis_variant': 8}, n)
     # round 6: the same kernel storing at final rows (what a render with background rays launches): a 60 % subset of a 5/3 n buffer
+    _capi.set_option('lvis_rows', 1)
     n_all = n * 5 // 3
     out_row = torch.from_numpy(np.sort(np.random.default_rng(7).choice(n_all, n, replace=False)).astype(np.int32)).to(cuda)
     full = torch.zeros((n_all, lxyz.shape[0]), device=cuda)

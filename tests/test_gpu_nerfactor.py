@@ -622,6 +622,7 @@ def test_lvis_rows_mode_stores_at_final_rows_and_flags_nans(nfx_lib, cuda, nfx_o
     input raises the flag; the shading kernels read the same rows through `lvis_row`."""
     from nerfactor_amd import ops
     nfx_opt.set("lvis_variant", variant)
+    nfx_opt.set("lvis_rows", "1")
     layers, out = net128(30, 90, 1)
     blob = pack(layers, out, nfx_lib.IN_XYZ_LDIR, 1, cuda)
     n_all, n = 3000, 1777
@@ -692,14 +693,14 @@ def test_render_with_background_rays_is_the_same_through_the_final_row_stores(nf
         with torch.no_grad():
             pred, gt, _, _ = model(batch, mode='test', relight_probes=True, relight_olat=True)
         return {k: v.clone() for k, v in pred.items()}, {k: v.clone() for k, v in gt.items()}
+    nfx_opt.set("lvis_rows", "1")             # opt-in: final-row stores
     with torch.no_grad():
         assert model._lvis_rows_ok()
     new, gt_new = run()
-    nfx_opt.set("lvis_rows", "0")             # the round-5 path: compact tensor, nfx_scatter_rows, nfx_any_nonfinite
+    nfx_opt.set("lvis_rows", "0")             # the default path: compact tensor, nfx_scatter_rows, nfx_any_nonfinite
     with torch.no_grad():
         assert not model._lvis_rows_ok()
     old, gt_old = run()
-    nfx_opt.unset("lvis_rows")
     assert set(new) == set(old) and {'rgb', 'lvis', 'rgb_probes', 'rgb_olat'} <= set(new)
     for k in new:
         assert torch.equal(new[k], old[k]), k
