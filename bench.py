@@ -779,7 +779,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         if all(p[0] is not None for p in parts):
             traffic, traffic_source = sum(p[0] for p in parts), parts[0][1]
     parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (one process only: these are training steps of their own — with a process group their all-reduce would wait for ranks
+        #  that are not here; found by the full-leg two-rank rehearsal of round 6)
         # the reference's own ten steps (tests/golden/reference_grads.npz) through the same train path: step-1
         # gradients, loss trajectory, parameters after the steps (tests/reference_steps.py; CPU oracle outside the timing)
         from tests import reference_steps

@@ -82,16 +82,20 @@ def test_bench_gpus_2_on_a_one_gpu_box_is_a_json_error(nfx_lib, cuda):
 
 def test_bench_launches_its_own_ranks(nfx_lib, cuda, tmp_path):
     """`python bench.py --gpus 2` with no torchrun around it and NFX_BENCH_REHEARSAL=1 (both ranks on GPU 0, gloo):
-    bench.py re-executes itself as two ranks and rank 0 prints the one line with world_size 2."""
-    res = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--legs', 'nerf,train', '--train-models', 'nerfactor_microfacet',
-                  '--no-cpu-baseline'], NFX_BENCH_REHEARSAL='1')
+    bench.py re-executes itself as two ranks and rank 0 prints the one line with world_size 2.  WITH the CPU baselines and
+    parity blocks that only rank 0 runs: none of them may contain a collective (round 6: the training legs' reference-step parity
+    did — ten training steps of its own, whose all-reduce waited for ranks that were not there; it is one-process-only now)."""
+    res = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--legs', 'nerf,train,nerfactor_microfacet', '--train-models',
+                  'nerfactor_microfacet', '--cpu-budget', '1'], NFX_BENCH_REHEARSAL='1')
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]
     line = json.loads(lines[0])
     assert line['world_size'] == 2 and line['n_gpus'] == 2 and line['collective_backend'] == 'gloo' and 'rehearsal' in line
     assert line['config']['views_per_step'] == 2 and line['value'] > 0
-    assert line['legs']['train_nerfactor_microfacet']['ms_per_step'] > 0
+    assert line['legs']['train_nerfactor_microfacet']['ms_per_step'] > 0 and line['legs']['nerfactor_microfacet']['ms_per_step'] > 0
+    assert line['parity']['rays_above_tol'] == 0 and line['parity']['vs_reference_python']['rays_above_tol'] == 0
+    assert 'cpu_baseline' not in line                  # (timed at N = 1 only)
 
 
 def test_bench_force_group_runs_the_training_leg_on_rccl(nfx_lib, cuda):
