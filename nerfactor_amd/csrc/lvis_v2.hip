@@ -14,6 +14,13 @@
 #include "mlp_engine.hpp"
 
 
+#ifdef NFX_XP_TRANS_LOAD
+#ifdef NFX_XP_LOAD_PLAIN_VALU     // control: full-rate VALU instructions of the same total issue time instead of transcendental ones
+#define NFX_XP_LOAD_INSN "v_mul_f32 %0, 1.0, %0\n\tv_mul_f32 %0, 1.0, %0\n\tv_mul_f32 %0, 1.0, %0\n\tv_mul_f32 %0, 1.0, %0"
+#else
+#define NFX_XP_LOAD_INSN "v_sin_f32 %0, %0"
+#endif
+#endif
 namespace nfx {
 namespace lv2 {
 
@@ -297,6 +304,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void resident128_kernel(Args a) {
                 const float inv = 1.0f / sqrtf(fmaxf(sq, 1e-6f));
 #pragma unroll
                 for (int k = 0; k < 3; ++k) d[k] *= inv;
+#ifdef NFX_XP_TRANS_LOAD
+                {
+                    float tl = d[0];
+#pragma unroll
+                    for (int i = 0; i < NFX_XP_TRANS_LOAD; ++i) asm volatile(NFX_XP_LOAD_INSN : "+v"(tl));
+                    asm volatile("" ::"v"(tl));
+                }
+#endif
                 posenc<4, CT>(d, h, c, pl);
                 pre_pt[c] = a.pre + pt * 256;
                 front[c] = true;
@@ -796,6 +811,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) NFX_XP_CAP_ATTR void brdf_compact_
                 const float x[3] = {q0[0], q0[1], q0[2]}, vl[3] = {q0[3], q1[0], q1[1]};
                 const float rot[9] = {q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2]};
                 const float lp[3] = {lx[l * 3], lx[l * 3 + 1], lx[l * 3 + 2]};
+#ifdef NFX_XP_TRANS_LOAD      // round-6 experiment: the healthy two-wave kernels under a partner that issues MANY quarter-rate
+                              // transcendental instructions (what the failing <2, 0, 8> has five times more of): dead work, same outputs
+                {
+                    float tl = lp[0];
+#pragma unroll
+                    for (int i = 0; i < NFX_XP_TRANS_LOAD; ++i) asm volatile(NFX_XP_LOAD_INSN : "+v"(tl));
+                    asm volatile("" ::"v"(tl));
+                }
+#endif
                 float S[8], C[8];
                 brdf_row_angles(x, lp, rot, vl, S, C);
                 float v[2][16];
