@@ -49,6 +49,10 @@ import json; l=json.load(open('$OUT/bench_nerfactor_rows$r.json')); print('lvis_
     bench-nerfactor) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --legs nerfactor_microfacet,nerfactor,olat,relight --no-cpu-baseline > $OUT/bench_nerfactor_line.json 2> $OUT/bench_nerfactor.err; python -c "
 import json; l=json.load(open('$OUT/bench_nerfactor_line.json')); print(l['legs'])"; tail -3 $OUT/bench_nerfactor.err ;;
     rehearsal) NFX_BENCH_REHEARSAL=1 timeout 1500 python bench.py --gpus ${REH_GPUS:-2} --steps 2 --warmup 1 > $OUT/bench_rehearsal_line.json 2> $OUT/bench_rehearsal.err; echo rc=$?; cp bench_detail.json $OUT/bench_rehearsal_detail.json; head -c 1500 $OUT/bench_rehearsal_line.json; echo; tail -5 $OUT/bench_rehearsal.err ;;
+    grad-modes) timeout 900 python scripts/grad_modes.py > $OUT/grad_modes.json 2> $OUT/grad_modes.err; python -c "
+import json; d=json.load(open('$OUT/grad_modes.json'))
+for m,v in d.items():
+    for k,r in v.items(): print('%-22s %-32s worst %.4f median %.4f  loss1 %.1e' % (m,k,r['grad_rel_frobenius_vs_reference_worst'],r['grad_rel_frobenius_median_tensor'],r['loss_step1_rel_err']))"; tail -3 $OUT/grad_modes.err ;;
     rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
