@@ -53,6 +53,8 @@ import json; l=json.load(open('$OUT/bench_nerfactor_line.json')); print(l['legs'
 import json; d=json.load(open('$OUT/grad_modes.json'))
 for m,v in d.items():
     for k,r in v.items(): print('%-22s %-32s worst %.4f median %.4f  loss1 %.1e' % (m,k,r['grad_rel_frobenius_vs_reference_worst'],r['grad_rel_frobenius_median_tensor'],r['loss_step1_rel_err']))"; tail -3 $OUT/grad_modes.err ;;
+    bench-force-group) timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 --force-group > $OUT/bench_force_group_line.json 2> $OUT/bench_force_group.err; echo rc=$?; python -c "
+import json; l=json.loads([x for x in open('$OUT/bench_force_group_line.json') if x.startswith('{')][-1]); print(l['collective_backend'], l['value'], {k: v.get('ms_per_step') for k, v in l['legs'].items()})"; tail -3 $OUT/bench_force_group.err ;;
     rccl)     timeout 1200 python -m pytest tests/test_gpu_rccl.py -q -x > $OUT/pytest_rccl.log 2>&1; tail -30 $OUT/pytest_rccl.log ;;
     bench)    timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench-legs) timeout 1200 python bench.py --steps ${STEPS:-5} --warmup 2 --legs ${LEGS:-geometry} ${BENCH_FLAGS:-} > $OUT/bench_${LEGS_TAG:-legs}.json 2> $OUT/bench_${LEGS_TAG:-legs}.err; tail -c ${TAILC:-3000} $OUT/bench_${LEGS_TAG:-legs}.json; tail -3 $OUT/bench_${LEGS_TAG:-legs}.err ;;
