@@ -145,7 +145,7 @@ d=json.load(open("$OUT/generic_rates_$lib.json"))
 for k,v in d.items(): print('  %-34s fwd %7.3f ms %6.1f TF   bwd %7.3f ms %6.1f TF' % (k, v['fwd_ms'], v['fwd_tflops'], v['bwd_ms'], v['bwd_tflops']))
 PYEOF
                tail -1 $OUT/generic_rates_$lib.err; done ;;
-    step-trace) (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/step_trace -o t -- python $ROOT/bench.py --legs train --train-models ${TRACE_MODEL:-nerfactor_microfacet} --steps 3 --warmup 1 --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/step_trace_run.log 2>&1); python scripts/step_trace.py $(find $OUT/step_trace -name "*kernel_trace.csv" | head -1) 1000 | tail -45 ;;
+    step-trace) (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/step_trace -o t -- python $ROOT/bench.py --legs train --train-models ${TRACE_MODEL:-nerfactor_microfacet} --steps 3 --warmup 1 --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/step_trace_run.log 2>&1); python scripts/step_trace.py $(find $OUT/step_trace -name "*kernel_trace.csv" | head -1) ${TRACE_MIN_US:-1000} > $OUT/step_trace_${TRACE_MODEL:-nerfactor_microfacet}.txt; tail -${TRACE_TAIL:-45} $OUT/step_trace_${TRACE_MODEL:-nerfactor_microfacet}.txt ;;
     *) echo "unknown stage $st" ;;
   esac
 done
