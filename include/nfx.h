@@ -337,6 +337,18 @@ NFX_API int nfx_brdf_spec_bwd(const float *dev_xyz, const float *dev_cam, const 
                       const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
                       float *dev_d_z, float *dev_d_normal, void *dev_workspace, size_t workspace_bytes,
                       void *stream);
+/* nfx_brdf_spec_bwd_rows (round 6) = nfx_brdf_spec_bwd over the rows with dev_dspec != 0 ONLY: a row whose upstream gradient
+ * is zero contributes exactly nothing, and the shading backward (nfx_shade_bwd) zeroes d spec of every back-facing light — the
+ * half of the (point, light) rows the forward never evaluates either (nerfactor.py:429-434).  dev_list_workspace:
+ * nfx_brdf_spec_bwd_list_bytes(n, n_lights) bytes, 16-byte aligned (the row list and its length stay on the device; 0 = more
+ * than 2^31 rows: use the dense call), or NULL = the dense call.  Both forms sum in fixed point from the first addition on and
+ * return the same bits.                                                                                                     */
+NFX_API size_t nfx_brdf_spec_bwd_list_bytes(int64_t n, int n_lights);
+NFX_API int nfx_brdf_spec_bwd_rows(const float *dev_xyz, const float *dev_cam, const float *dev_normal,
+                           const float *dev_z, int z_dim, const float *dev_lxyz, int n_lights,
+                           const void *dev_blob, int prec, int64_t n, const float *dev_dspec,
+                           float *dev_d_z, float *dev_d_normal, void *dev_workspace, size_t workspace_bytes,
+                           void *dev_list_workspace, size_t list_workspace_bytes, void *stream);
 
 /* The BRDF prior on EXPLICIT rows — evaluation and one training step's backward of models/brdf.py
  * (reference nerfactor/models/brdf.py:57-66 `_eval_brdf_at`, :87-136 `call`/`compute_loss`, trained by

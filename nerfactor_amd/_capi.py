@@ -72,6 +72,8 @@ SIGNATURES = {
     'nfx_brdf_pack_train_weights': (_i, [_pp, _pp, _i, _i, _p, _sz]),
     'nfx_brdf_spec_bwd_workspace_bytes': (_sz, [_i, _i64]),
     'nfx_brdf_spec_bwd': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _sz, _p]),
+    'nfx_brdf_spec_bwd_list_bytes': (_sz, [_i64, _i]),
+    'nfx_brdf_spec_bwd_rows': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     'nfx_brdf_rows_fwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p]),
     'nfx_brdf_rows_bwd_workspace_bytes': (_sz, [_i, _i64, _i]),
     'nfx_brdf_rows_bwd': (_i, [_p, _i, _p, _i64, _i, _p, _i, _p, _p, _sz, _p, _pp, _pp, _p]),
@@ -138,7 +140,7 @@ def check(rc, what):
 
 # ------------------------------------------------------------------------------- options
 OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
-               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows')
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows', 'brdf_bwd_rows')
 
 
 def set_option(key, value):

@@ -69,14 +69,26 @@ __global__ void brdf_fx_finish_kernel(const long long* __restrict__ fx, long lon
     else d_normal[pt * 3 + (c - z_dim)] += v;
 }
 
+// LIST (round 6): the rows are the flat (point, light) indices list[0 .. *count) — the rows whose upstream gradient is not zero
+// (select_nonzero_kernel; a row with d spec = 0 contributes exactly nothing: its d logit is 0 and every product behind it).  The
+// shading backward zeroes d spec of every back-facing light, so about half of the rows — the back-lit half the FORWARD kernel
+// never evaluates either (nerfactor.py:429-434) — are not re-computed and not differentiated: 313 -> ~170 us per 1024-ray step.
+// Rows of a wave may then belong to different points: the per-point sums are segmented (below).
+template <bool LIST>
 __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ cam, const float* __restrict__ normal,
     const float* __restrict__ z, int z_dim, const float* __restrict__ lxyz, int n_lights,
-    const char* __restrict__ blob, long long n, const float* __restrict__ dspec, long long* __restrict__ fx) {
+    const char* __restrict__ blob, long long n, const float* __restrict__ dspec, long long* __restrict__ fx,
+    const int* __restrict__ list, const int* __restrict__ count) {
     // fx: [n, z_dim + 3] fixed-point (2^40) sums of d z and d normal over the point's lights — integer atomics, so the
-    // 16 waves that share a point may arrive in any order (float atomics made the step's gradients run-dependent)
+    // waves that share a point may arrive in any order (float atomics made the step's gradients run-dependent)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace m128;
+    long long n_rows = n * n_lights;
+    if constexpr (LIST) {
+        n_rows = *count;
+        if ((long long)blockIdx.x * kRows >= n_rows) return;      // (before the first barrier: the whole workgroup leaves)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
     {
@@ -89,14 +101,27 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
     ws.gnext = ws.gbase;
     ws.ring = smem;
     stream_prologue<1, kNW>(ws, tid);
-    const long long n_rows = n * n_lights;
     const long long n_tiles = (n_rows + kRows - 1) / kRows;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long m0 = tile * kRows + wave * 32;  // wave-uniform: 32 lights of one point
-        const bool valid = m0 < n_rows;
-        const long long mc = valid ? m0 : 0;
-        const long long pt = mc / n_lights;
-        const int l = (int)(mc % n_lights) + p;
+        const long long m0 = tile * kRows + wave * 32;  // dense: wave-uniform, 32 lights of one point
+        bool valid;
+        long long pt, mrow;
+        int l;
+        if constexpr (LIST) {
+            const long long r = m0 + p;
+            valid = r < n_rows;
+            const unsigned mu = (unsigned)list[valid ? r : n_rows - 1];      // n * n_lights < 2^31 (checked by the launcher)
+            const unsigned pu = mu / (unsigned)n_lights;
+            pt = pu;
+            l = (int)(mu - pu * (unsigned)n_lights);
+            mrow = mu;
+        } else {
+            valid = m0 < n_rows;
+            const long long mc = valid ? m0 : 0;
+            pt = mc / n_lights;
+            l = (int)(mc % n_lights) + p;
+            mrow = m0 + p;
+        }
         float x[3], c[3], nr[3], lp[3], ldir[3], vdir[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -139,7 +164,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
         tile_raw<8, 0, 1, kNW>(ws, tid, bias_lds + 512, h3, bin, logit);
         // ---- d logit (row 0 of the out tile lives in reg 0 of the half-0 lanes)
         float g = 0.f;
-        if (valid && front && h == 0) g = dspec[m0 + p] * sigmoidf(logit[0][0]);  // softplus' = sigmoid
+        if (valid && front && h == 0) g = dspec[mrow] * sigmoidf(logit[0][0]);  // softplus' = sigmoid
         bf16x8 dzo[1][1];
 #pragma unroll
         for (int j = 0; j < 8; ++j) dzo[0][0][j] = (__bf16)0.f;
@@ -197,25 +222,81 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_spec_bwd_kernel(
             if (1 + 2 * j < m128::kMaxZDim && h == 0) dzv[1 + 2 * j] = dx[0][8 + j];
             if (2 + 2 * j < m128::kMaxZDim && h == 1) dzv[2 + 2 * j] = dx[0][8 + j];
         }
-        // reduce over the 32 rows (lanes of one half), halves hold disjoint z indices / identical dn
+        // Sum over the rows of the wave that belong to ONE point (dense: all 32 of the half; LIST: usually 1-2 points per wave),
+        // in FIXED POINT from the first addition on (round 6): integer sums do not depend on how rows are grouped into waves, so
+        // the dense and the list form — and any order of the list — give the same bits.  Halves hold disjoint z indices /
+        // identical dn; an invalid row contributes 0.
+        long long sn[3], sz[m128::kMaxZDim];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int a = 0; a < 3; ++a) sn[a] = valid ? (long long)to_fx(dn[a]) : 0ll;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) dn[a] += __shfl_xor(dn[a], o, 64);
+        for (int i = 0; i < m128::kMaxZDim; ++i) sz[i] = valid ? (long long)to_fx(dzv[i]) : 0ll;
+        auto shfl_xor_ll = [](long long v, int o) {
+            const int lo = __shfl_xor((int)(unsigned)v, o, 64), hi = __shfl_xor((int)((unsigned long long)v >> 32), o, 64);
+            return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        };
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull) {                                             // wave-uniform loop over the distinct points
+            const int leader = __builtin_ctzll(todo);
+            const long long pt_u = (long long)__shfl((int)pt, leader, 64); // (pt < 2^31 in both forms)
+            const bool mine = valid && pt == pt_u;
+            long long tn[3], tz[m128::kMaxZDim];
 #pragma unroll
-            for (int i = 0; i < m128::kMaxZDim; ++i) dzv[i] += __shfl_xor(dzv[i], o, 64);
-        }
-        if (valid && p == 0) {
-            unsigned long long* row = reinterpret_cast<unsigned long long*>(fx + pt * (z_dim + 3));
-            if (h == 0) {
+            for (int a = 0; a < 3; ++a) tn[a] = mine ? sn[a] : 0ll;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) atomicAdd(row + z_dim + a, to_fx(dn[a]));
+            for (int i = 0; i < m128::kMaxZDim; ++i) tz[i] = mine ? sz[i] : 0ll;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) tn[a] += shfl_xor_ll(tn[a], o);
+#pragma unroll
+                for (int i = 0; i < m128::kMaxZDim; ++i) tz[i] += shfl_xor_ll(tz[i], o);
             }
+            if (p == 0) {
+                unsigned long long* row = reinterpret_cast<unsigned long long*>(fx + pt_u * (z_dim + 3));
+                if (h == 0) {
 #pragma unroll
-            for (int i = 0; i < m128::kMaxZDim; ++i)
-                if (i < z_dim && ((i == 0) ? h == 1 : ((i - 1) & 1) == h)) atomicAdd(row + i, to_fx(dzv[i]));
+                    for (int a = 0; a < 3; ++a) atomicAdd(row + z_dim + a, (unsigned long long)tn[a]);
+                }
+#pragma unroll
+                for (int i = 0; i < m128::kMaxZDim; ++i)
+                    if (i < z_dim && ((i == 0) ? h == 1 : ((i - 1) & 1) == h)) atomicAdd(row + i, (unsigned long long)tz[i]);
+            }
+            todo &= ~__ballot(mine);
         }
     }
+}
+
+// list[] <- the indices i < n_elems with x[i] != 0, *count <- their number (zeroed by the launcher).  One atomic per workgroup of
+// 1024 elements; the order of the list is whatever the workgroups' arrival makes it (the consumer's sums are integers).
+__global__ __launch_bounds__(256) void select_nonzero_kernel(const float* __restrict__ x, unsigned n_elems, int* __restrict__ list,
+                                                             int* __restrict__ count) {
+    __shared__ int s_cnt[4][4], s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned i0 = blockIdx.x * 1024u + wave * 256u;
+    unsigned long long masks[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = i0 + k * 64u + lane;
+        masks[k] = __ballot(i < n_elems && x[i] != 0.0f);
+        if (lane == 0) s_cnt[wave][k] = __popcll(masks[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < 4; ++k) {
+                const int c = s_cnt[w][k];
+                s_cnt[w][k] = sum;
+                sum += c;
+            }
+        s_base = sum ? atomicAdd(count, sum) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((masks[k] >> lane) & 1ull)
+            list[s_base + s_cnt[wave][k] + __popcll(masks[k] & ((1ull << lane) - 1ull))] = (int)(i0 + k * 64u + lane);
 }
 
 
@@ -367,21 +448,35 @@ __global__ __launch_bounds__(kNW * 64, 1) void brdf_rows_kernel(
 
 extern "C" {
 int nfx_brdf_train_blob_bytes(void) { return nfx::brdfbwd::kBlobBytes; }
+// list_ws: NULL = the dense form (every row); else 4 (n n_lights + 4) bytes: [count | pad | list] — the rows with d spec != 0 only
 int nfx_launch_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
                              const float* lxyz, int n_lights, const void* blob, long long n, const float* dspec,
-                             float* d_z, float* d_normal, void* workspace, int max_blocks, hipStream_t st) {
+                             float* d_z, float* d_normal, void* workspace, int max_blocks, hipStream_t st, void* list_ws) {
     using namespace nfx;
     if (n <= 0) return 0;
     const long long tiles = (n * n_lights + brdfbwd::kRows - 1) / brdfbwd::kRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
     const int lds = 2 * kSlotBytes + m128::kMainBiasFloats * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(brdfbwd::brdf_spec_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
     const long long words = n * (z_dim + 3);
     launch_zero_words(workspace, words, st);   // (a kernel, not hipMemsetAsync: nfx_common.hpp)
-    hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
-                       z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, static_cast<long long*>(workspace));
+    if (list_ws != nullptr && n * n_lights < (1ll << 31)) {
+        int* count = static_cast<int*>(list_ws);
+        int* list = count + 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(brdfbwd::brdf_spec_bwd_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        launch_zero_words(count, 2, st);        // (a kernel node, not a memset node: nfx_common.hpp — the step is captured in a hipGraph)
+        const unsigned n_elems = (unsigned)(n * n_lights);
+        hipLaunchKernelGGL(brdfbwd::select_nonzero_kernel, dim3((n_elems + 1023u) / 1024u), dim3(256), 0, st, dspec, n_elems, list, count);
+        hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel<true>, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
+                           z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, static_cast<long long*>(workspace), list, count);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(brdfbwd::brdf_spec_bwd_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(brdfbwd::brdf_spec_bwd_kernel<false>, dim3(grid), dim3(brdfbwd::kNW * 64), lds, st, xyz, cam, normal,
+                           z, z_dim, lxyz, n_lights, (const char*)blob, n, dspec, static_cast<long long*>(workspace), nullptr, nullptr);
+    }
     hipLaunchKernelGGL(brdfbwd::brdf_fx_finish_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                        static_cast<const long long*>(workspace), n, z_dim, d_z, d_normal);
     return (int)hipGetLastError();

@@ -81,6 +81,8 @@ Option g_options[] = {
     {"lvis_rows", {0}, {0}},      // 1: the HOST side renders through nfx_lvis_fwd_rows / nfx_shade_olat_fwd_rows (visibilities and OLAT renders stored at
                                   //    their final rows, NaN flags from the kernels); 0 / unset = compact tensors + nfx_scatter_rows + nfx_any_nonfinite.
                                   //    Opt-in: measured equal within the noise (profiles/r06/render_rows_ab.txt).
+    {"brdf_bwd_rows", {0}, {0}},  // 0: the HOST side differentiates the learned BRDF over every (point, light) row (nfx_brdf_spec_bwd);
+                                  //    1 / unset = over the rows with a non-zero upstream gradient only (nfx_brdf_spec_bwd_rows; same bits)
     {"brdf_variant", {0}, {0}},   // learned BRDF: 6 (default) | 5 | 2 | 3 | 4 | 0
     {"brdf_ct", {0}, {0}},        // column tiles of brdf variants 5 / 6: 4 (default) | 2 | 3; 8 = two waves per SIMD (variant 6 only)
     {"nerf_bwd", {0}, {0}},       // 1 (default) = LDS-DMA ring backward, 0 = register-staged identity reference

@@ -371,7 +371,7 @@ int nfx_pack_gather(const float* src, const int32_t* map, int64_t n_words, void*
 
 int nfx_brdf_train_blob_bytes(void);
 int nfx_launch_brdf_spec_bwd(const float*, const float*, const float*, const float*, int, const float*, int,
-                             const void*, long long, const float*, float*, float*, void*, int, hipStream_t);
+                             const void*, long long, const float*, float*, float*, void*, int, hipStream_t, void*);
 
 size_t nfx_brdf_train_packed_bytes(void) { return (size_t)nfx_brdf_train_blob_bytes(); }
 
@@ -455,9 +455,21 @@ size_t nfx_brdf_spec_bwd_workspace_bytes(int z_dim, int64_t n) {
     return n > 0 && z_dim >= 1 ? sizeof(long long) * (size_t)n * (z_dim + 3) : 0;
 }
 
+size_t nfx_brdf_spec_bwd_list_bytes(int64_t n, int n_lights) {
+    return n > 0 && n_lights > 0 && n * (int64_t)n_lights < ((int64_t)1 << 31) ? sizeof(int) * ((size_t)n * n_lights + 4) : 0;
+}
+
 int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
                       const float* lxyz, int n_lights, const void* blob, int prec, int64_t n, const float* dspec,
                       float* d_z, float* d_normal, void* workspace, size_t workspace_bytes, void* stream) {
+    return nfx_brdf_spec_bwd_rows(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, prec, n, dspec, d_z, d_normal, workspace,
+                                  workspace_bytes, nullptr, 0, stream);
+}
+
+int nfx_brdf_spec_bwd_rows(const float* xyz, const float* cam, const float* normal, const float* z, int z_dim,
+                           const float* lxyz, int n_lights, const void* blob, int prec, int64_t n, const float* dspec,
+                           float* d_z, float* d_normal, void* workspace, size_t workspace_bytes, void* list_workspace,
+                           size_t list_bytes, void* stream) {
     REQUIRE(n >= 0, "nfx_brdf_spec_bwd: n < 0");
     REQUIRE(z_dim >= 1 && z_dim <= nfx::m128::kMaxZDim, "nfx_brdf_spec_bwd: z_dim %d unsupported", z_dim);
     REQUIRE(n_lights > 0 && n_lights % 32 == 0, "nfx_brdf_spec_bwd: n_lights (%d) must be a multiple of 32", n_lights);
@@ -468,9 +480,14 @@ int nfx_brdf_spec_bwd(const float* xyz, const float* cam, const float* normal, c
             "nfx_brdf_spec_bwd: workspace of nfx_brdf_spec_bwd_workspace_bytes(z_dim, n) bytes required");
     if (!ALIGNED(blob, 16) || !ALIGNED(workspace, 8))
         return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd: blob must be 16-byte, workspace 8-byte aligned");
+    if (list_workspace != nullptr) {
+        REQUIRE(nfx_brdf_spec_bwd_list_bytes(n, n_lights) > 0 && list_bytes >= nfx_brdf_spec_bwd_list_bytes(n, n_lights),
+                "nfx_brdf_spec_bwd_rows: list workspace of nfx_brdf_spec_bwd_list_bytes(n, n_lights) bytes required (n n_lights < 2^31)");
+        if (!ALIGNED(list_workspace, 16)) return nfx_fail(NFX_EALIGN, "nfx_brdf_spec_bwd_rows: list workspace must be 16-byte aligned");
+    }
     return nfx_hip_result(nfx_launch_brdf_spec_bwd(xyz, cam, normal, z, z_dim, lxyz, n_lights, blob, n, dspec, d_z,
                                                    d_normal, workspace, nfx_option_int("m128_blocks", 256),
-                                                   (hipStream_t)stream),
+                                                   (hipStream_t)stream, list_workspace),
                           "brdf_spec_bwd");
 }
 

@@ -1051,9 +1051,15 @@ def brdf_spec_bwd(xyz, cam, normal, z, lxyz, blob, dspec, prec='bf16'):
     d_normal = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device)
     ws = torch.empty((max(lib.nfx_brdf_spec_bwd_workspace_bytes(z.shape[1], n), 8) // 8,), dtype=torch.int64,
                      device=xyz.device)
-    check(lib.nfx_brdf_spec_bwd(_ptr(xyz), _ptr(_dev(cam, 'cam', (n, 3))), _ptr(_dev(normal, 'normal', (n, 3))),
-                                _ptr(z), z.shape[1], _ptr(lxyz), nl, _ptr(blob), _PREC[prec], n, _ptr(dspec),
-                                _ptr(d_z), _ptr(d_normal), _ptr(ws), ws.numel() * 8, _stream()), 'nfx_brdf_spec_bwd')
+    # round 6: only the rows with a non-zero upstream gradient are re-computed and differentiated (the shading backward zeroes
+    # d spec of every back-facing light: half of the rows); option brdf_bwd_rows = 0 keeps every row (same bits)
+    list_bytes = lib.nfx_brdf_spec_bwd_list_bytes(n, nl) if _capi.get_option("brdf_bwd_rows") != 0 else 0
+    lws = torch.empty((list_bytes // 4,), dtype=torch.int32, device=xyz.device) if list_bytes else None
+    check(lib.nfx_brdf_spec_bwd_rows(_ptr(xyz), _ptr(_dev(cam, 'cam', (n, 3))), _ptr(_dev(normal, 'normal', (n, 3))),
+                                     _ptr(z), z.shape[1], _ptr(lxyz), nl, _ptr(blob), _PREC[prec], n, _ptr(dspec),
+                                     _ptr(d_z), _ptr(d_normal), _ptr(ws), ws.numel() * 8,
+                                     None if lws is None else ctypes.c_void_p(lws.data_ptr()), list_bytes, _stream()),
+          'nfx_brdf_spec_bwd')
     return d_z, d_normal
 
 

@@ -517,6 +517,37 @@ def test_brdf_spec_backward_vs_autograd(nfx_lib, cuda, zd):
             assert err < tol, (name, quant, err)
 
 
+@pytest.mark.determinism
+@pytest.mark.parametrize("zd,n,zero_frac", [(3, 700, 0.5), (1, 33, 0.5), (3, 257, 0.97), (3, 64, 0.0)])
+def test_brdf_spec_backward_over_the_rows_with_a_gradient_equals_every_row(nfx_lib, cuda, nfx_opt, zd, n, zero_frac):
+    """nfx_brdf_spec_bwd_rows (round 6): the learned BRDF differentiated over the (point, light) rows with d spec != 0 only
+    — the shading backward zeroes the back-facing half — against the same call over EVERY row (option brdf_bwd_rows = 0):
+    both sum in fixed point from the first addition on, so d z and d normal are the same bits whatever the grouping of rows
+    into waves and whatever order the row list came out in (run three times).  All-zero and no-zero gradients included."""
+    from nerfactor_amd import ops
+    layers, out = net128(110 + zd, zd + 15, 1)
+    blob = ops.pack_brdf_train_weights([k for k, _ in layers] + [out[0][0]], [b for _, b in layers] + [out[0][1]], zd).to(cuda)
+    rng, lxyz, _, xyz, cam, normal = scene(n, 211)
+    zl = rng.normal(size=(n, zd)).astype(np.float32)
+    dspec = rng.normal(size=(n, 512)).astype(np.float32)
+    dspec[rng.uniform(size=dspec.shape) < zero_frac] = 0.
+    if n == 33:
+        dspec[5] = 0.           # a whole point without gradient
+    args = (dev(xyz, cuda), dev(cam, cuda), dev(normal, cuda), dev(zl, cuda), dev(lxyz, cuda), blob, dev(dspec, cuda))
+    nfx_opt.set("brdf_bwd_rows", "0")
+    dz_all, dn_all = ops.brdf_spec_bwd(*args)
+    nfx_opt.set("brdf_bwd_rows", "1")
+    for _ in range(3):
+        dz, dn = ops.brdf_spec_bwd(*args)
+        assert torch.equal(dz, dz_all) and torch.equal(dn, dn_all)
+    assert bool(torch.isfinite(dz_all).all()) and (zero_frac == 0.97 or float(dn_all.abs().max()) > 0)
+    if n == 33:
+        assert not bool(dz_all[5].any()) and not bool(dn_all[5].any())
+    zero = torch.zeros_like(args[-1])
+    dz0, dn0 = ops.brdf_spec_bwd(*args[:-1], zero)
+    assert not bool(dz0.any()) and not bool(dn0.any())
+
+
 def test_nerfactor_learned_brdf_train_step_runs_and_descends(nfx_lib, cuda):
     """The flagship model (frozen learned BRDF) trains end to end through libnfx: a few steps on a fixed
     batch must decrease the loss, and every trainable tensor must receive a finite, non-zero gradient."""
