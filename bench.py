@@ -753,10 +753,25 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
     if graph_dt is not None and graph_dt > dt_eager:      # (a GPU-bound step — NeRF: ~60 launches — gains nothing from the replay)
         graph_dt, graph_note = None, "the hipGraph replay was not faster: %.3f ms" % (graph_dt * 1e3)
     dt = graph_dt if graph_dt is not None else dt_eager
+    grad_frac = None
     if name == 'nerf':
-        # per ray 64 coarse + 192 fine points; forward + re-computed forward + dgrad + wgrad = 4 x the forward MACs
-        flops = 4 * n * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT
-        what = "64+128 samples per ray, perturb on; FLOPs = 4 x forward (forward, re-computed forward, dgrad, wgrad)"
+        # per ray 64 coarse + 192 fine points; forward + re-computed forward + dgrad + wgrad = 4 x the forward MACs — the last
+        # three only for the points with a gradient (nfx_nerf_mlp_bwd skips a point whose d_rgbs is four zeros: a sample the
+        # composite gave no weight; the reference's gradient of it is zero too).  Their share: one untimed step, counted by
+        # the library's own device-side list
+        ops.NERF_BWD_STATS = []
+        try:
+            optim.train_step(model, batch, opt, global_bs)
+            torch.cuda.synchronize()
+            stats = [(int(c.item()), m) for c, m in ops.NERF_BWD_STATS]
+        finally:
+            ops.NERF_BWD_STATS = None
+        listed = ops._capi.get_option('nerf_bwd_rows') != 0
+        grad_frac = sum(c for c, _ in stats) / max(1, sum(m for _, m in stats)) if listed and stats else 1.
+        pts = n * (N_COARSE + N_COARSE + N_FINE)
+        flops = pts * FLOP_PER_POINT * (1 + 3 * grad_frac)
+        what = ("64+128 samples per ray, perturb on; FLOPs = forward over every point + 3 x forward (re-computed forward, dgrad, "
+                "wgrad) over the %.1f %% of the points with a gradient" % (100 * grad_frac))
         dom, per_step = 'nerf_mlp_bwd', 2
     else:
         rows = n * N_LIGHTS * 2                                # clean + jittered visibility rows
@@ -843,6 +858,7 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                  else "eager optim.train_step" + (" (%s)" % graph_note if graph_note else "")),
         "ms_per_step_eager": dt_eager * 1e3,
         "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
+        "points_with_gradient_frac": grad_frac,
         "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
             torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if (world > 1 or nfx_dist.run_collectives_on_one_rank())
         else "none (one rank, no process group)",
@@ -1280,6 +1296,8 @@ def compact(full):
             continue
         e = {"ms_per_step": leg.get("ms_per_step"), "ms_per_step_eager": leg.get("ms_per_step_eager"),
              "frac": (leg.get("roofline") or {}).get("frac")}
+        if leg.get("points_with_gradient_frac") is not None:
+            e["points_with_gradient_frac"] = leg["points_with_gradient_frac"]
         if leg.get("parity"):
             e["grad_rel_vs_bf16_oracle"] = leg["parity"].get("grad_rel_frobenius_vs_bf16_oracle_worst")
             e["grad_rel_vs_reference"] = leg["parity"].get("grad_rel_frobenius_vs_reference_worst")

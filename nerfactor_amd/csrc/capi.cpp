@@ -83,6 +83,8 @@ Option g_options[] = {
                                   //    Opt-in: measured equal within the noise (profiles/r06/render_rows_ab.txt).
     {"brdf_bwd_rows", {0}, {0}},  // 0: the HOST side differentiates the learned BRDF over every (point, light) row (nfx_brdf_spec_bwd);
                                   //    1 / unset = over the rows with a non-zero upstream gradient only (nfx_brdf_spec_bwd_rows; same bits)
+    {"nerf_bwd_rows", {0}, {0}},  // 0: nfx_nerf_mlp_bwd differentiates every point; 1 / unset = only the points whose upstream gradient is not
+                                  //    all zeros (device-side ordered row list; same sums, another fp32 summation order)
     {"brdf_variant", {0}, {0}},   // learned BRDF: 6 (default) | 5 | 2 | 3 | 4 | 0
     {"brdf_ct", {0}, {0}},        // column tiles of brdf variants 5 / 6: 4 (default) | 2 | 3; 8 = two waves per SIMD (variant 6 only)
     {"nerf_bwd", {0}, {0}},       // 1 (default) = LDS-DMA ring backward, 0 = register-staged identity reference
@@ -90,6 +92,8 @@ Option g_options[] = {
     {"m128_bwd", {0}, {0}},       // as nerf_bwd for the width-128 networks
     {"wgrad_lds", {0}, {0}},      // force the LDS-staged weight-gradient GEMM on (1) / off (0); default by row count
     {"wgrad_slabs", {0}, {0}},    // number of row slabs of a weight-gradient batch (default by row count)
+    {"wgrad_rounds", {0}, {0}},   // wide weight-gradient kernel: slabs x blocks = this many workgroups per CU (default 1); 0 = the
+                                  //    row-count rule of rounds 3-5 (64 ... 256 slabs)
     {"wgrad_narrow", {0}, {0}},   // 0 = width-128 networks through the wide kernel as well
     {"wgrad_fused", {0}, {0}},    // 0 = backward kernels store activations, separate weight-gradient GEMMs (identity reference)
     {"wgrad_splits", {0}, {0}},   // runtime-shaped weight gradients: most row splits of the contraction (default 256)

@@ -40,6 +40,9 @@ struct nfx_wgrad_call {   // one weight-gradient GEMM of a batched launch (train
 size_t nfx_wgrad_partial_bytes(const nfx_wgrad_call* calls, int n_calls, long long rows);
 int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
                            hipStream_t st);
+int nfx_launch_wgrad_batch_counted(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
+                                   const int* count, hipStream_t st);
+int nfx_wgrad_counted_ok(long long rows);
 int nfx_launch_amsgrad(float*, const float*, float*, float*, float*, long long, float, float, float, float,
                        hipStream_t);
 float nfx_amsgrad_step_size(float lr, float beta1, float beta2, int64_t step);
@@ -230,7 +233,8 @@ int nfx_mlp128_bwd_heads(int in_kind, const float* xyz, const float* xyz_dir, in
 
 // ------------------------------------------------------------------------------------ NeRF MLP backward
 int nfx_launch_nerf_bwd(const float*, const float*, const float*, long long, int, const void*, const float*, void*,
-                        long long, int, hipStream_t);
+                        long long, int, hipStream_t, void*);
+size_t nfx_nerf_bwd_list_bytes(long long n_pts);
 int nfx_launch_composite_bwd(const float*, const float*, const float*, const float*, long long, int, int,
                              const float*, float*, hipStream_t);
 
@@ -301,7 +305,13 @@ size_t nfx_nerf_bwd_workspace_bytes(int64_t n_rays, int n_samples) {
     nfx_wgrad_call calls[14];
     for (int i = 0; i < 14; ++i) calls[i] = nfx_wgrad_call{nullptr, nullptr, kNerfWgradDims[i][0], kNerfWgradDims[i][1], nullptr, nullptr};
     const long long n_pts = (long long)n_rays * n_samples;
-    return nerf_feat_bytes(n_pts) + nfx_wgrad_partial_bytes(calls, 14, (n_pts + 15) / 16 * 16);
+    const size_t partial = (nfx_wgrad_partial_bytes(calls, 14, (n_pts + 15) / 16 * 16) + 15) / 16 * 16;
+    return nerf_feat_bytes(n_pts) + partial + nfx_nerf_bwd_list_bytes(n_pts);   // (the list: option nerf_bwd_rows)
+}
+// the list of the points with a gradient sits behind the partial sums
+static void* nerf_list_ws(void* workspace, int64_t n_rays, int n_samples) {
+    return static_cast<char*>(workspace) + nfx_nerf_bwd_workspace_bytes(n_rays, n_samples) -
+           nfx_nerf_bwd_list_bytes((long long)n_rays * n_samples);
 }
 
 int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
@@ -320,11 +330,17 @@ int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64
     const long long n_pts = (long long)n_rays * n_samples, ld = nerf_ld(n_pts);
     // feat_store.hpp: a lane's 32-bit offset inside a feature-pair row reaches row * 4 + 4 * ld2 = up to 12 * ld
     REQUIRE(12 * ld < (1ll << 32), "nfx_nerf_mlp_bwd: at most %lld points per call (got %lld)", (1ll << 32) / 12 - 256, n_pts);
+    const long long rows16 = (n_pts + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in every dZ
+    // default: only the points whose upstream gradient is not all zeros are differentiated (nerf_bwd.hip, rowsel: a
+    // sample the composite gave no weight has four exact zeros).  They sit in rows [0, count) of the workspace, count
+    // stays on the device, the weight-gradient batch reads it.  Option nerf_bwd_rows = 0: every point.
+    const bool listed = nfx_option_int("nerf_bwd_rows", 1) != 0 && nfx_option_int("nerf_bwd", 1) != 0 &&
+                        nfx_wgrad_counted_ok(rows16) != 0;
+    void* list_ws = listed ? nerf_list_ws(workspace, n_rays, n_samples) : nullptr;
     int rc = nfx_hip_result(nfx_launch_nerf_bwd(rayo, rayd, z, n_pts, n_samples, blob, d_rgbs, workspace, ld,
-                                                nfx_option_int("nerf_blocks", 256), st),
+                                                nfx_option_int("nerf_blocks", 256), st, list_ws),
                             "nerf_bwd");
     if (rc) return rc;
-    const long long rows16 = (n_pts + 15) / 16 * 16;  // pad rows of the last tile hold exact zeros in every dZ
     const char* ws = static_cast<const char*>(workspace);
     auto feat = [&](int f) { return ws + (size_t)f * ld * 2; };
     std::vector<nfx_wgrad_call> calls;
@@ -341,7 +357,9 @@ int nfx_nerf_mlp_bwd(const float* rayo, const float* rayd, const float* z, int64
         if (calls[i].k_in != kNerfWgradDims[i][0] || calls[i].n_out != kNerfWgradDims[i][1])
             return nfx_fail(NFX_EINVAL, "nfx_nerf_mlp_bwd: weight-gradient table out of sync");
     void* partial = static_cast<char*>(workspace) + nerf_feat_bytes(n_pts);
-    return nfx_hip_result(nfx_launch_wgrad_batch(calls.data(), (int)calls.size(), ld, rows16, partial, st), "wgrad");
+    return nfx_hip_result(nfx_launch_wgrad_batch_counted(calls.data(), (int)calls.size(), ld, rows16, partial,
+                                                         static_cast<const int*>(list_ws), st),
+                          "wgrad");
 }
 
 int nfx_composite_bwd(const float* rgbs, const float* z, const float* rayd, const float* noise, int64_t n_rays,

@@ -69,7 +69,7 @@ __device__ __forceinline__ void dgrad_layer(WStream& ws, int tid, const bf16x8 (
 __global__ __launch_bounds__(kNerfNW * 64, 1) void nerf_bwd_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, const float4* __restrict__ d_rgbs, __bf16* __restrict__ wsp,
-    long long ld) {
+    long long ld, const int* /*list*/, const int* /*count*/) {   // (the ring kernels' signature; every point)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
     constexpr int NW = kNerfNW;
@@ -321,11 +321,14 @@ __device__ __forceinline__ void dgrad_layer(const Ctx& cx, const bf16x8 (&dz)[KS
 }
 }  // namespace nring
 
-template <int NW>
+// LIST: the kernel's rows are the points list[0 .. *count) (ascending; rowsel below: the points whose upstream gradient
+// is not all zeros), row c of the feature workspace is point list[c].  A point with a zero upstream gradient has zeros
+// in every dZ, so it adds nothing to any weight gradient: the sums over the listed rows are the sums over all rows.
+template <int NW, bool LIST>
 __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
     int n_samples, const char* __restrict__ blob, const float4* __restrict__ d_rgbs, __bf16* __restrict__ wsp,
-    long long ld) {
+    long long ld, const int* __restrict__ list, const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
     constexpr int kRows = NW * 32;
@@ -341,7 +344,9 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
     typedef __attribute__((address_space(3))) char lds_char;
     nring::Ctx cx{smem, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)smem), blob, lane, wave, 0u};
     cx.bias_addr = (unsigned)(uintptr_t)(lds_char*)smem + (unsigned)(nring::kR * RC::kSlot) + 16u * (unsigned)h;
-    const long long n_tiles = (n_pts + kRows - 1) / kRows;
+    long long n_act = n_pts;
+    if constexpr (LIST) n_act = *count;
+    const long long n_tiles = (n_act + kRows - 1) / kRows;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row = tile * kRows + wave * 32 + p;  // < ld (ld is a multiple of 256)
         FeatStore fs;
@@ -352,8 +357,11 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
             fs.ld2 = ld2;
             fs.roff = (unsigned)(row * 4);
         }
-        const bool valid = row < n_pts;
-        const long long mm = valid ? row : n_pts - 1;
+        const bool valid = row < n_act;
+        long long mm = valid ? row : n_pts - 1;
+        if constexpr (LIST) {
+            if (valid) mm = list[row];
+        }
         bf16x8 pe[4][1], pv[2][1];
         bf16x8 dzo[1][1], dsg[1][1];
         // every load of the tile and every store that is not a chunk epilogue happens HERE, before the ring is primed:
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
             const long long ray = mm / n_samples;
             const float zz = zbuf[mm];
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && h == 0) g = d_rgbs[row];
+            if (valid && h == 0) g = d_rgbs[LIST ? mm : row];
             float x[3], d[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -427,14 +435,93 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
     }
 }
 
+// ------------------------------------------------------------ the rows with a gradient, in ascending order
+// d_rgbs of a point the composite gave no weight (alpha = 0: raw density <= 0) is four exact zeros — half the samples of a
+// freshly initialised network, most of a fitted scene's.  Three small launches (no host sync, no memset node: the whole
+// step stays one hipGraph): per 1024 rows a count, one workgroup's exclusive scan of the counts (+ the total), then
+// every row's rank = its block's offset + the rows before it inside the block.  Ascending order makes the weight
+// gradients' summation order a function of d_rgbs alone: the same bits run to run.
+namespace rowsel {
+constexpr int kBlockRows = 1024;
+__device__ __forceinline__ bool has_gradient(const float4* __restrict__ g, long long r, long long n) {
+    if (r >= n) return false;
+    const uint4 v = *reinterpret_cast<const uint4*>(g + r);
+    return ((v.x | v.y | v.z | v.w) & 0x7fffffffu) != 0u;   // -0 is zero; a NaN is a gradient (and reaches the weights)
+}
+__global__ __launch_bounds__(256) void count_kernel(const float4* __restrict__ g, long long n, int* __restrict__ block_count) {
+    __shared__ int s[4];
+    const int tid = threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        c += __popcll(__ballot(has_gradient(g, (long long)blockIdx.x * kBlockRows + r * 256 + tid, n)));
+    if ((tid & 63) == 0) s[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) block_count[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ __launch_bounds__(1024) void scan_kernel(int* __restrict__ block_count, int n_blocks, int* __restrict__ count) {
+    __shared__ int s[1024];
+    const int tid = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n_blocks ? block_count[i] : 0;
+        s[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int t = tid >= d ? s[tid - d] : 0;
+            __syncthreads();
+            s[tid] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_count[i] = carry + s[tid] - v;
+        carry += s[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *count = carry;
+}
+__global__ __launch_bounds__(256) void write_kernel(const float4* __restrict__ g, long long n,
+                                                    const int* __restrict__ block_offset, int* __restrict__ list) {
+    __shared__ int s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool f[4];
+    unsigned long long m[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        f[r] = has_gradient(g, (long long)blockIdx.x * kBlockRows + r * 256 + tid, n);
+        m[r] = __ballot(f[r]);
+        if (lane == 0) s[r * 4 + wave] = __popcll(m[r]);
+    }
+    __syncthreads();
+    int before = block_offset[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k == wave && f[r])
+                list[before + __popcll(m[r] & ((1ull << lane) - 1ull))] = (int)((long long)blockIdx.x * kBlockRows + r * 256 + tid);
+            before += s[r * 4 + k];
+        }
+    }
+}
+}  // namespace rowsel
 }  // namespace bwd
 }  // namespace nfx
 
 extern "C" int nfx_option_int(const char* name, int dflt);   // capi.cpp
 
+// the row-list workspace of nfx_launch_nerf_bwd: [count, 3 pad][one count per 1024 points, padded to 4][n_pts indices]
+static long long rowsel_blocks(long long n_pts) {
+    return (n_pts + nfx::bwd::rowsel::kBlockRows - 1) / nfx::bwd::rowsel::kBlockRows;
+}
+extern "C" size_t nfx_nerf_bwd_list_bytes(long long n_pts) {
+    if (n_pts <= 0) return 0;
+    return (size_t)(4 + (rowsel_blocks(n_pts) + 3) / 4 * 4 + (n_pts + 3) / 4 * 4) * sizeof(int);
+}
+
 extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                                    const void* blob, const float* d_rgbs, void* wsp, long long ld, int max_blocks,
-                                   hipStream_t st) {
+                                   hipStream_t st, void* list_ws) {
     using namespace nfx;
     if (n_pts <= 0) return 0;
     const long long tiles = (n_pts + bwd::kNerfRows - 1) / bwd::kNerfRows;
@@ -442,7 +529,23 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     // r03 default: weights through the LDS-DMA ring; NFX_NERF_BWD=0 keeps the register-staged kernel (identity reference)
     const bool use_ring = nfx_option_int("nerf_bwd", 1) != 0;            // (per call, like every knob: INTEGRATION.md)
     const int ring_nw = nfx_option_int("nerf_bwd_nw", 8) == 4 ? 4 : 8;
-    auto k = !use_ring ? bwd::nerf_bwd_kernel : ring_nw == 8 ? bwd::nerf_bwd_ring_kernel<8> : bwd::nerf_bwd_ring_kernel<4>;
+    // list_ws not null: only the points with a gradient (in list_ws: nfx_nerf_bwd_list_bytes), count = (int*)list_ws
+    if (list_ws && !use_ring) return (int)hipErrorInvalidValue;
+    int *count = static_cast<int*>(list_ws), *list = nullptr;
+    if (list_ws) {
+        const long long nb = rowsel_blocks(n_pts);
+        int* block_count = count + 4;
+        list = block_count + (nb + 3) / 4 * 4;
+        hipLaunchKernelGGL(bwd::rowsel::count_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)d_rgbs, n_pts, block_count);
+        hipLaunchKernelGGL(bwd::rowsel::scan_kernel, dim3(1), dim3(1024), 0, st, block_count, (int)nb, count);
+        hipLaunchKernelGGL(bwd::rowsel::write_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)d_rgbs, n_pts,
+                           (const int*)block_count, list);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    auto k = !use_ring ? bwd::nerf_bwd_kernel
+             : ring_nw == 8 ? (list ? bwd::nerf_bwd_ring_kernel<8, true> : bwd::nerf_bwd_ring_kernel<8, false>)
+                            : (list ? bwd::nerf_bwd_ring_kernel<4, true> : bwd::nerf_bwd_ring_kernel<4, false>);
     const int nw = use_ring ? ring_nw : bwd::kNerfNW;
     const int lds = !use_ring ? bwd::kNerfBwdLds : ring_nw == 8 ? bwd::nring::Cfg<8>::kLds : bwd::nring::Cfg<4>::kLds;
     const long long tiles_nw = (n_pts + nw * 32 - 1) / (nw * 32);
@@ -450,6 +553,6 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid_nw), dim3(nw * 64), lds, st, rayo, rayd, z, n_pts, n_samples,
-                       (const char*)blob, (const float4*)d_rgbs, (__bf16*)wsp, ld);
+                       (const char*)blob, (const float4*)d_rgbs, (__bf16*)wsp, ld, (const int*)list, (const int*)count);
     return (int)hipGetLastError();
 }

@@ -33,6 +33,8 @@ struct WgBatch {
     int n_calls, n_slabs;
     int wide_only;      // NFX_WGRAD_NARROW=0: the 256 x 256 block form also for narrow GEMMs (A/B)
     long long ld, rows, slab;
+    const int* count;   // not null (wgrad_lds_kernel only): the batch's rows are [0, *count) — a number only the device knows
+                        // (nerf_bwd.hip, the rows with a gradient); the n_slabs blocks split THOSE rows evenly
 };
 // the two features of a 16-byte piece (4 rows x [even, odd]) as 8 bytes each: rows r .. r+3 of one feature
 __device__ __forceinline__ void wg_split(const u32x4& v, unsigned (&even)[2], unsigned (&odd)[2]) {
@@ -396,9 +398,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(WgBatch bt) {
     const int k_in = c.k_in, n_out = c.n_out;
     const int kb = (lb / c.gz) * 256, nb = (lb % c.gz) * 256;
     const int wk = wave >> 1, wn = wave & 1;
-    const long long r0 = (long long)blockIdx.x * bt.slab;
-    long long r1 = r0 + bt.slab;
-    if (r1 > bt.rows) r1 = bt.rows;
+    long long rows = bt.rows, slab = bt.slab;
+    if (bt.count) {   // a slab past the counted rows: zero chunks, and its block of partial sums is written as zeros
+        rows = ((long long)*bt.count + 15) & ~15ll;
+        slab = ((rows + gridDim.x - 1) / gridDim.x + kWlRows - 1) / kWlRows * kWlRows;
+        if (slab < 256) slab = 256;
+    }
+    const long long r0 = (long long)blockIdx.x * slab;
+    long long r1 = r0 + slab;
+    if (r1 > rows) r1 = rows;
+    if (r1 < r0) r1 = r0;
     const int n_chunks = (int)((r1 - r0 + kWlRows - 1) / kWlRows);
     f32x16 acc[4][4];
 #pragma unroll
@@ -522,7 +531,18 @@ struct nfx_wgrad_call {
 
 int nfx_option_int(const char* key, int dflt);   // capi.cpp
 
-static void wgrad_plan(long long rows, bool* use_lds, long long* slab, int* n_slabs) {
+// blocks of 256 x 256 outputs the batch has when it takes the wide LDS form (wgrad_lds_kernel); 0: every GEMM is narrow
+static int wg_wide_blocks(const nfx_wgrad_call* calls, int n_calls) {
+    bool all_narrow = nfx_option_int("wgrad_narrow", 1) != 0;
+    int blocks = 0;
+    for (int i = 0; i < n_calls; ++i) {
+        all_narrow = all_narrow && calls[i].k_in <= 128 && calls[i].n_out <= 128;
+        blocks += ((calls[i].k_in + 255) / 256) * ((calls[i].n_out + 255) / 256);
+    }
+    return all_narrow ? 0 : blocks;
+}
+
+static void wgrad_plan(long long rows, int wide_blocks, bool* use_lds, long long* slab, int* n_slabs) {
     const int force_lds = nfx_option_int("wgrad_lds", -1);
     *use_lds = force_lds >= 0 ? force_lds != 0 : rows >= 16384;
     const int n_forced = nfx_option_int("wgrad_slabs", 0);
@@ -531,6 +551,13 @@ static void wgrad_plan(long long rows, bool* use_lds, long long* slab, int* n_sl
         // fewer, longer slabs = fewer partial blocks to write and sum; at least 64 slabs, at most one per CU
         if (n_forced > 0) {
             sl = rows / n_forced;
+        } else if (wide_blocks > 0 && nfx_option_int("wgrad_rounds", 1) > 0) {
+            // the wide form is one workgroup per CU and HBM-bound on the stored activations: what the slab count buys is
+            // only partial sums to write and read back (3.7 MB per slab for the NeRF batch).  One workgroup per CU in
+            // all — slabs x blocks <= 256 — measured best (profiles/r06/wgrad_slabs_sweep.txt: 18 / 36 slabs are the
+            // minima for the NeRF batch's 14 blocks, 18 the lower)
+            const int per_round = 256 / wide_blocks > 0 ? 256 / wide_blocks : 1;
+            sl = (rows + (long long)per_round * nfx_option_int("wgrad_rounds", 1) - 1) / ((long long)per_round * nfx_option_int("wgrad_rounds", 1));
         } else {
             sl = rows / 256 > 2048 ? rows / 256 : 2048;
             const long long cap = rows / 64 > 256 ? rows / 64 : 256;
@@ -555,7 +582,7 @@ size_t nfx_wgrad_partial_bytes(const nfx_wgrad_call* calls, int n_calls, long lo
     bool lds;
     long long slab;
     int n_slabs;
-    wgrad_plan(rows, &lds, &slab, &n_slabs);
+    wgrad_plan(rows, wg_wide_blocks(calls, n_calls), &lds, &slab, &n_slabs);
     const int bs = lds ? 256 : 128;
     size_t total = 0;
     for (int i = 0; i < n_calls; ++i) {
@@ -565,13 +592,16 @@ size_t nfx_wgrad_partial_bytes(const nfx_wgrad_call* calls, int n_calls, long lo
     return total;
 }
 
-int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
-                           hipStream_t st) {
+// `count` not null: rows = the most rows the batch can hold (the plan and the partial-sum workspace are sized for it), the
+// rows that count are [0, *count), read by the kernel.  Only the wide LDS form reads it: hipErrorInvalidValue otherwise.
+int nfx_launch_wgrad_batch_counted(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
+                                   const int* count, hipStream_t st) {
     if (rows <= 0 || n_calls <= 0) return 0;
     if (n_calls > nfx::kWgMaxCalls) return (int)hipErrorInvalidValue;
     bool lds;
     nfx::WgBatch bt;
-    wgrad_plan(rows, &lds, &bt.slab, &bt.n_slabs);
+    wgrad_plan(rows, wg_wide_blocks(calls, n_calls), &lds, &bt.slab, &bt.n_slabs);
+    bt.count = count;
     bt.n_calls = n_calls;
     bt.ld = ld;
     bt.rows = rows;
@@ -603,6 +633,7 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
     }
     bool all_narrow = !bt.wide_only;
     for (int i = 0; i < n_calls; ++i) all_narrow = all_narrow && calls[i].k_in <= 128 && calls[i].n_out <= 128;
+    if (count && (!lds || all_narrow)) return (int)hipErrorInvalidValue;
     if (lds && all_narrow) {   // width-128 networks: 128-row chunks, the four waves split the rows (wgrad_lds_narrow)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nfx::wgrad_lds_narrow_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, nfx::kWlLds);
@@ -621,5 +652,17 @@ int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long l
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nfx::wgrad_reduce_kernel, dim3((unsigned)((max_elems + 63) / 64), (unsigned)n_calls), dim3(256), 0, st, bt);
     return (int)hipGetLastError();
+}
+int nfx_launch_wgrad_batch(const nfx_wgrad_call* calls, int n_calls, long long ld, long long rows, void* partial,
+                           hipStream_t st) {
+    return nfx_launch_wgrad_batch_counted(calls, n_calls, ld, rows, partial, nullptr, st);
+}
+// whether a batch of `rows` rows takes the wide LDS form (the one that can read its row count from the device)
+int nfx_wgrad_counted_ok(long long rows) {
+    bool lds;
+    long long slab;
+    int n_slabs;
+    wgrad_plan(rows, 0, &lds, &slab, &n_slabs);
+    return lds ? 1 : 0;
 }
 }

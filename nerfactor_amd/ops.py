@@ -857,9 +857,21 @@ def composite_bwd(rgbs, z, rayd, d_rgb, white_bg=True, noise=None):
 NERF_BWD_MAX_POINTS = 1 << 19   # ~5 GB of feature-major workspace per call; more rays are processed in slices
 
 
+NERF_BWD_STATS = None   # a list: nerf_mlp_bwd appends (points with a gradient [device int32 copy], points) per call (bench.py)
+
+
+def nerf_bwd_list_words(n_pts):
+    """Word offsets of (count, per-1024-point counts, indices) and the total of the row list at the END of the workspace
+    of nfx_nerf_mlp_bwd (nerf_bwd.hip:nfx_nerf_bwd_list_bytes)."""
+    nb = (n_pts + 1023) // 1024
+    b0 = 4 + (nb + 3) // 4 * 4
+    return 0, 4, b0, b0 + (n_pts + 3) // 4 * 4
+
+
 def nerf_mlp_bwd(rayo, rayd, z, d_rgbs, blob, dkernels, dbiases, prec='bf16'):
     """Accumulate the weight gradients of one nerf_mlp_fwd call into `dkernels` / `dbiases` (lists of 12 fp32
-    CUDA tensors, Keras layout) given d_rgbs[N,S,4]."""
+    CUDA tensors, Keras layout) given d_rgbs[N,S,4].  Only the points whose d_rgbs is not four zeros are differentiated
+    (the library builds their list on the device; option nerf_bwd_rows = 0: every point)."""
     rayo = _dev(rayo, 'rayo', (None, 3))
     n = rayo.shape[0]
     rayd = _dev(rayd, 'rayd', (n, 3))
@@ -880,6 +892,9 @@ def nerf_mlp_bwd(rayo, rayd, z, d_rgbs, blob, dkernels, dbiases, prec='bf16'):
         check(lib.nfx_nerf_mlp_bwd(_ptr(rayo[lo:hi]), _ptr(rayd[lo:hi]), _ptr(z[lo:hi]), hi - lo, s, _ptr(blob),
                                    _PREC[prec], _ptr(d_rgbs[lo:hi]), _ptr(ws), ws.numel() * 2, karr, barr,
                                    _stream()), 'nfx_nerf_mlp_bwd')
+        if NERF_BWD_STATS is not None:
+            first = ws_bytes // 4 - nerf_bwd_list_words((hi - lo) * s)[3]
+            NERF_BWD_STATS.append((ws.view(torch.int32)[first:first + 1].clone(), (hi - lo) * s))
     return ws
 
 

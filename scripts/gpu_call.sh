@@ -3,7 +3,7 @@
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
 # stages: bench-driver | rccl | pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
 #         bench-train-fp32 | soak | sigma | fitted | generic | prof | train-prof | train-prof-fp32 | pmc | pmc-train | pmc-sq2 |
-#         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair
+#         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair | bench-train-nerf-ab | prof-train-nerf
 #   A / B stages (experiment builds: NFX_EXTRA_DEFS=... python -m nerfactor_amd.build --out nerfactor_amd/libnfx_xpX.so):
 #         fused-ab (AB_LIBS=...) | ring-ab (RING_LIBS=...) | generic-ab | splits-ab | generic-prof | generic-pmc
 set -u
@@ -85,6 +85,27 @@ PYEOF
     fitted)   timeout 600 python scripts/fitted_outliers.py > $OUT/fitted_outliers.json 2>&1; cat $OUT/fitted_outliers.json ;;
     pytest-k) timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_FLAGS:-} -k "$PYTEST_K" > $OUT/pytest_gpu_k.log 2>&1; tail -${TAILN:-30} $OUT/pytest_gpu_k.log ;;
     bench-train) timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; tail -c 2500 $OUT/bench_train.json; tail -3 $OUT/bench_train.err ;;
+    bench-train-nerf-ab) for i in 1 2; do for r in 0 1; do NFX_NERF_BWD_ROWS=$r timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --train-models nerf --no-cpu-baseline > $OUT/bench_train_nerf_rows$r.json 2> $OUT/bench_train_nerf_rows$r.err; python - <<PYEOF
+import json
+d = json.load(open("bench_detail.json"))["train"]["nerf"]
+print("nerf_bwd_rows=$r", {k: d.get(k) for k in ("ms_per_step", "ms_per_step_eager", "points_with_gradient_frac")}, {k: d["roofline"].get(k) for k in ("frac", "largest_backward_call_ms", "backward_calls_ms_per_step")})
+PYEOF
+      tail -2 $OUT/bench_train_nerf_rows$r.err; done; done ;;
+    prof-train-nerf) for r in 0 1; do mkdir -p $ROOT/$OUT/prof_train_nerf$r; (cd /tmp && export TMPDIR=/tmp && NFX_NERF_BWD_ROWS=$r timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_train_nerf$r -o t -- python $ROOT/bench.py --steps 3 --warmup 1 --legs train --train-models nerf --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/prof_train_nerf$r.log 2>&1); f=$(find $OUT/prof_train_nerf$r -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/train_nerf_rows${r}_kernel_stats.csv; rm -rf $OUT/prof_train_nerf$r; head -16 $OUT/train_nerf_rows${r}_kernel_stats.csv | cut -c1-150,250-330; done ;;
+    prof-nerf-bwd-rows) for r in 0 1; do mkdir -p $ROOT/$OUT/prof_nbr$r; (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_nbr$r -o t -- python $ROOT/scripts/nerf_bwd_rows.py ${NBR_KIND:-fitted} $r > $ROOT/$OUT/prof_nbr$r.log 2>&1); f=$(find $OUT/prof_nbr$r -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/nerf_${NBR_KIND:-fitted}_rows${r}_kernel_stats.csv; rm -rf $OUT/prof_nbr$r; head -12 $OUT/nerf_${NBR_KIND:-fitted}_rows${r}_kernel_stats.csv | cut -c1-100,200-330; done ;;
+    wgrad-slabs-sweep) for sl in ${SLABS:-0 27 36 54 72 96 128}; do NFX_WGRAD_SLABS=$sl timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --train-models nerf --no-cpu-baseline > $OUT/bench_train_nerf_slabs$sl.json 2> $OUT/bench_train_nerf_slabs$sl.err; python - <<PYEOF
+import json
+d = json.load(open("bench_detail.json"))["train"]["nerf"]
+print("wgrad_slabs=$sl", {k: d.get(k) for k in ("ms_per_step", "ms_per_step_eager", "points_with_gradient_frac")}, {k: d["roofline"].get(k) for k in ("largest_backward_call_ms", "backward_calls_ms_per_step")})
+PYEOF
+      done ;;
+    wgrad-rounds-ab) for i in 1 2; do for r in 0 1 2; do NFX_WGRAD_ROUNDS=$r timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --train-models nerf --no-cpu-baseline > $OUT/bench_train_nerf_rounds$r.json 2> $OUT/bench_train_nerf_rounds$r.err; python - <<PYEOF
+import json
+d = json.load(open("bench_detail.json"))["train"]["nerf"]
+print("wgrad_rounds=$r", {k: d.get(k) for k in ("ms_per_step", "ms_per_step_eager", "points_with_gradient_frac")}, {k: d["roofline"].get(k) for k in ("frac", "largest_backward_call_ms", "backward_calls_ms_per_step")})
+PYEOF
+      done; done ;;
+    nerf-bwd-rows) timeout 600 python scripts/nerf_bwd_rows.py > $OUT/nerf_bwd_rows.json 2> $OUT/nerf_bwd_rows.err; cat $OUT/nerf_bwd_rows.json; tail -3 $OUT/nerf_bwd_rows.err ;;
     bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do for fm in "pairs" "pairs --graph" "native"; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --fp32-matrix $fm --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
     soak-xp)  NFX_LIB_PATH=$ROOT/nerfactor_amd/libnfx_xp.so timeout 600 python scripts/soak_8wave.py --geo0 > $OUT/soak_experiment_build.log 2>&1; tail -16 $OUT/soak_experiment_build.log ;;

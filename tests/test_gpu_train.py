@@ -663,6 +663,68 @@ def test_nerf_mlp_backward_vs_autograd(nfx_lib, cuda, n_rays, s, nfx_opt, wgrad_
     assert torch.equal(inf[:nfrag], blob[:nfrag].cpu()) and torch.equal(inf[nfrag:], blob[-(inf.numel() - nfrag):].cpu())
 
 
+@pytest.mark.parametrize("n_rays,s,keep", [(150, 192, 0.4), (700, 64, 0.03), (129, 130, 1.0), (90, 192, 0.)])
+def test_nerf_mlp_backward_over_the_points_with_a_gradient(nfx_lib, cuda, nfx_opt, n_rays, s, keep):
+    """nfx_nerf_mlp_bwd differentiates only the points whose d_rgbs is not four zeros (default; capi_train.cpp).  The
+    reference's gradient of such a point is zero as well (nerf.py:236-239: alpha = 1 - exp(-relu(sigma) dist) gives a
+    sample with sigma <= 0 no weight, tf.nn.relu no slope), so the sums are the sums over every point:
+      * the device-side list is exactly np.nonzero of the upstream gradient, ascending, -0 counted as zero, NaN not;
+      * the weight gradients equal the every-point call's (option nerf_bwd_rows = 0) to fp32 summation order;
+      * two calls return the same bits; no point with a gradient: the gradients stay as they were."""
+    from nerfactor_amd import ops
+    from tests import common
+    ks_np, bs_np = common.nerf_layers(common.nerf_nets(seed=5, opaque=False)[0])
+    rng = np.random.default_rng(900 + s)
+    rayo = rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32)
+    rayd = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    rayd /= np.linalg.norm(rayd, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(0.5, 3., size=(n_rays, s)).astype(np.float32), 1)
+    n_pts = n_rays * s
+    d_rgbs = rng.normal(size=(n_pts, 4)).astype(np.float32)
+    on = rng.uniform(size=n_pts) < keep
+    on[2048:5120] = False                      # whole 1024-point blocks without a gradient
+    if keep > 0:
+        on[7000:7300] = True
+    d_rgbs[~on] = 0.
+    d_rgbs[~on & (rng.uniform(size=n_pts) < 0.3)] = -0.     # signed zeros are zeros
+    one = np.flatnonzero(on)[::7]
+    d_rgbs[one, :3] = 0.                        # a gradient in one component is a gradient
+    want_list = np.flatnonzero((d_rgbs != 0).any(1))
+    blob = ops.pack_nerf_train_weights(ks_np, bs_np).to(cuda)
+    args = (dev(rayo, cuda), dev(rayd, cuda), dev(z, cuda), dev(d_rgbs.reshape(n_rays, s, 4), cuda), blob)
+
+    def run(rows):
+        nfx_opt.set('nerf_bwd_rows', rows)
+        dks = [torch.zeros(k.shape, device=cuda) for k in ks_np]
+        dbs = [torch.zeros(b.shape, device=cuda) for b in bs_np]
+        ws = ops.nerf_mlp_bwd(*args, dks, dbs)
+        torch.cuda.synchronize()
+        return torch.cat([t.reshape(-1) for t in dks + dbs]), ws
+
+    dense, _ = run(0)
+    listed, ws = run(1)
+    words = ws.view(torch.int32)
+    total = nfx_lib.lib.nfx_nerf_bwd_workspace_bytes(n_rays, s) // 4
+    _, _, i0, n_words = ops.nerf_bwd_list_words(n_pts)    # [count, 3 pad][a count per 1024 points][indices], at the end
+    tail = words[total - n_words:total].cpu().numpy()
+    assert int(tail[0]) == want_list.size
+    assert np.array_equal(tail[i0:i0 + want_list.size], want_list)
+    assert torch.isfinite(listed).all()
+    scale = float(dense.abs().max())
+    if keep == 0.:
+        assert scale == 0. and float(listed.abs().max()) == 0.
+    else:
+        assert scale > 0 and float((listed - dense).abs().max()) <= 2e-5 * scale
+    assert torch.equal(run(1)[0], listed)
+    # a NaN upstream is a gradient: it reaches the weights instead of being dropped with the zeros
+    if keep == 1.0:
+        bad = d_rgbs.copy()
+        bad[:] = 0.
+        bad[4321, 3] = np.nan
+        args = args[:3] + (dev(bad.reshape(n_rays, s, 4), cuda), blob)
+        assert not torch.isfinite(run(1)[0]).all()
+
+
 def test_nerf_train_step_descends(nfx_lib, cuda):
     """models.nerf through optim.train_step: every one of the 48 parameter tensors gets a finite gradient and the
     coarse + fine L2 loss (nerf.py:292-300) goes down on a fixed batch."""
@@ -1067,6 +1129,7 @@ def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, nfx
                  torch.nn.functional.normalize(t(rng.normal(size=(n, 3))), dim=1), t(rng.uniform(size=(n, 512))))
 
     nfx_opt.set('wgrad_fused', 0)   # the stored-activation path: the kernels this test compares (the fused kernels have their own)
+    nfx_opt.set('nerf_bwd_rows', 0)  # every point, as the register-staged kernel has them (the row list: its own test below)
 
     def grads(**env):
         for k in ('nerf_bwd', 'nerf_bwd_nw', 'm128_bwd'):
@@ -1084,6 +1147,10 @@ def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, nfx
     assert torch.equal(grads(), ref)                                     # the defaults: rings, NeRF with 8 waves
     if name == 'nerf':
         assert torch.equal(grads(nerf_bwd_nw=4), ref)
+        if n >= 1024:   # over the rows with a gradient (another summation order than `ref`): 8 waves == 4 waves, run == run
+            listed = grads(nerf_bwd_rows=1)
+            assert torch.equal(grads(nerf_bwd_rows=1, nerf_bwd_nw=4), listed) and torch.equal(grads(nerf_bwd_rows=1), listed)
+            assert float((listed - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor", "nerf", "shape"])
