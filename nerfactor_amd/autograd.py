@@ -2,6 +2,8 @@
 backward kernel.  Gradients exist for what the reference trains (trainvali.py:278-285): the MLP
 kernels/biases, the light, and — between kernels — normals, albedo, roughness and visibility.
 Points, cameras and light geometry are data (no gradient)."""
+import os
+
 import torch
 
 from . import _capi, ops
@@ -251,11 +253,34 @@ class ShadeSpec(torch.autograd.Function):
         return (None,) * 6 + (d_normal, d_albedo, d_spec, d_lvis, d_light.reshape(light.shape))
 
 
+# 'capture' (default): the two NeRF networks' backward chains fork onto side streams while the step is being captured into a
+# hipGraph (optim.GraphedTrainStep: two parallel branches of the graph; measured -2.5 ... -3 % of the replayed step when the
+# chains' tile counts leave a partly filled round, profiles/r06/nerf_train_ab.txt) and stay on the caller's stream in an eager
+# step (whose host side the stream switches only lengthen).  True / NFX_NERF_BWD_SIDE_STREAMS=1: always; False / =0: never.
+NERF_BWD_SIDE_STREAMS = {'0': False, '1': True}.get(os.environ.get('NFX_NERF_BWD_SIDE_STREAMS', ''), 'capture')
+_nerf_side = {'pending': [], 'armed': False, 'streams': {}}
+
+
+def _side_stream(dev, k):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), k % 2)
+    if key not in _nerf_side['streams']:
+        _nerf_side['streams'][key] = torch.cuda.Stream(device=dev)
+    return _nerf_side['streams'][key]
+
+
+def _join_side_streams():
+    pending, _nerf_side['pending'], _nerf_side['armed'] = _nerf_side['pending'], [], False
+    for event, dev, _keep in pending:
+        torch.cuda.current_stream(dev).wait_event(event)
+
+
 class NerfMlp(torch.autograd.Function):
     """rgbs[N,S,4] = NeRF MLP at rayo + rayd z (nerf.py:256-290); gradients for the 12 kernels / biases only."""
 
     @staticmethod
     def forward(ctx, rayo, rayd, z, fwd_blob, train_blob_fn, prec, *params):
+        if _nerf_side['pending'] and torch._C._current_graph_task_id() < 0:
+            _join_side_streams()      # (a backward pass that raised never reached its callback)
         ctx.save_for_backward(rayo, rayd, z)
         ctx.cfg = (train_blob_fn, prec, params)
         return ops.nerf_mlp_fwd(rayo, rayd, z, fwd_blob, prec)
@@ -266,7 +291,32 @@ class NerfMlp(torch.autograd.Function):
         train_blob_fn, prec, params = ctx.cfg
         ks, bs = list(params[:12]), list(params[12:])
         (dks, rks), (dbs, rbs) = _targets(ks), _targets(bs)
-        ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs.contiguous(), train_blob_fn(), dks, dbs, GRAD_PREC)
+        d_rgbs = d_rgbs.contiguous()
+        in_place = all(r is None for r in rks) and all(r is None for r in rbs)
+        forked = NERF_BWD_SIDE_STREAMS is True or (NERF_BWD_SIDE_STREAMS == 'capture' and d_rgbs.is_cuda and
+                                                   torch.cuda.is_current_stream_capturing())
+        if forked and in_place and d_rgbs.is_cuda and torch._C._current_graph_task_id() >= 0:
+            # The coarse and the fine network's backward are independent chains (nerf.py:292-300: two L2 terms, the fine
+            # samples are drawn from stop-gradient weights) of kernels that each take whole CUs: a chain alone leaves the
+            # CUs of its last, partly filled round idle (fine: 2.2 rounds of 256-row tiles).  Each chain goes to a side
+            # stream forked from the caller's; the caller's stream joins them when the backward pass ends (the engine's
+            # callback), so whoever reads .grad after loss.backward() sees finished gradients.  Only when every gradient
+            # is accumulated in place: a buffer handed back to autograd would be read on the caller's stream at once.
+            dev = d_rgbs.device
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev, len(_nerf_side['pending']))
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ws = ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs, train_blob_fn(), dks, dbs, GRAD_PREC)
+                event = side.record_event()
+            # (the tensors stay referenced until the join: nothing of them is handed back to the allocator of the
+            #  caller's stream while the side stream still reads it)
+            _nerf_side['pending'].append((event, dev, (d_rgbs, rayo, rayd, z, ws)))
+            if not _nerf_side['armed']:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                _nerf_side['armed'] = True
+        else:
+            ops.nerf_mlp_bwd(rayo, rayd, z, d_rgbs, train_blob_fn(), dks, dbs, GRAD_PREC)
         return (None,) * 6 + tuple(rks) + tuple(rbs)
 
 

@@ -1153,6 +1153,48 @@ def test_ring_backward_kernels_equal_the_register_staged_ones(nfx_lib, cuda, nfx
             assert float((listed - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.determinism
+def test_nerf_backward_chains_on_side_streams_equal_the_serial_ones(nfx_lib, cuda):
+    """autograd.NerfMlp.backward puts the coarse and the fine network's backward (independent chains) on two side streams that
+    the caller's stream joins when the backward pass ends: the gradients read right after loss.backward() — and after a
+    hipGraph replay of the whole step — are bit for bit those of the two chains run one after the other."""
+    from nerfactor_amd import autograd, optim
+    from nerfactor_amd.nerfactor.config import make_config
+    from nerfactor_amd.nerfactor.models import get_model_class
+    n = 1024
+    rng = np.random.default_rng(21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    cam = t(np.broadcast_to([2.2, -2.4, 1.7], (n, 3)))
+    batch = (None, None, cam, t(rng.uniform(-1, 1, size=(n, 3))) - cam, t(rng.uniform(size=(n, 3))))
+
+    def run(side, graphed):
+        torch.manual_seed(3)
+        model = get_model_class('nerf')(make_config('nerf')).to(cuda)
+        opt = optim.make_optimizer(model, model.config)
+        prev, autograd.NERF_BWD_SIDE_STREAMS = autograd.NERF_BWD_SIDE_STREAMS, side
+        try:
+            torch.manual_seed(4)
+            if graphed:
+                step = optim.GraphedTrainStep(model, opt, n)
+                for _ in range(4):
+                    loss, _ = step(batch)
+            else:
+                for _ in range(4):
+                    loss, _ = optim.train_step(model, batch, opt, n)
+            torch.cuda.synchronize()
+        finally:
+            autograd.NERF_BWD_SIDE_STREAMS = prev
+        assert not autograd._nerf_side['pending']
+        return float(loss), opt.bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+    serial = run(False, False)
+    assert float(serial[1].abs().max()) > 0
+    assert autograd.NERF_BWD_SIDE_STREAMS == 'capture'      # the default: forked inside a capture only
+    for side, graphed in ((True, False), (True, True), ('capture', True), (False, True)):
+        got = run(side, graphed)
+        assert got[0] == serial[0] and torch.equal(got[1], serial[1]) and torch.equal(got[2], serial[2]), (side, graphed)
+
+
 @pytest.mark.parametrize("name", ["nerfactor_microfacet", "nerfactor", "nerf", "shape"])
 def test_precision_fp32_trains(nfx_lib, cuda, name):
     """`precision = fp32` (the reference computes in fp32, trainvali.py:110-127): the forward runs the fp32-class kernels
