@@ -10,6 +10,7 @@ import torch
 
 from nerfactor_amd import autograd, autograd as nfx_grad, ops
 
+from .. import losses
 from ..networks import mlp
 from ..networks.embedder import Embedder
 from .base import Model as BaseModel
@@ -413,6 +414,14 @@ class Model(BaseModel):
     # ------------------------------------------------------------------ loss
     def compute_loss(self, pred, gt, **kwargs):
         coarse, fine = pred['coarse'], pred['fine']
+        if (gt.is_cuda and fine is not None and kwargs.get('keep_batch') and kwargs.get('weights') is None
+                and gt.ndim == 2 and all(isinstance(fn, losses.L2) for _, fn in self.wloss)):
+            # nerf.py:292-300 per ray — sum over the loss terms of w (mse(gt, coarse) + mse(gt, fine)) — as one forward and one
+            # backward launch (autograd.PairLoss, the surface models' loss kernel) instead of ~20 elementwise ones
+            spec = []
+            for weight, _ in self.wloss:
+                spec += [(0, 1, float(weight), 'mse', False, False), (0, 2, float(weight), 'mse', False, False)]
+            return nfx_grad.PairLoss.apply(None, 0., tuple(spec), gt, coarse, fine)
         loss = 0
         for weight, fn in self.wloss:
             loss = loss + weight * fn(gt, coarse, **kwargs)
