@@ -920,7 +920,23 @@ def geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         fwd_ms, grad_ms = kt.all_ms('nerf_sigma_fwd'), kt.all_ms('nerf_sigma_grad')
     kernel_ms = (sum(fwd_ms) + sum(grad_ms)) / steps
     n_local = sh.hi - sh.lo
-    flop_dn = n_local * (n_c + 2 * (n_c + n_f)) * 2 * GEO_MAC
+    # executed FLOPs: the coarse density, the fine density of every sample, and forward + reverse sweep of the samples with a
+    # positive density only (ops.nerf_sigma_grad -> nfx_nerf_sigma_grad_rows: every other sample's gradient is zero); their
+    # count comes from the library's device-side list on one untimed march
+    listed_frac = 1.
+    if ops._capi.get_option("sigma_grad_rows") != 0:
+        ops.SIGMA_GRAD_STATS = []
+        try:
+            with torch.no_grad():
+                G.compute_depth_and_normal(model, rayo, rayd, cfg)
+            torch.cuda.synchronize()
+            st = [(int(c.item()), m) for c, m in ops.SIGMA_GRAD_STATS]
+        finally:
+            ops.SIGMA_GRAD_STATS = None
+        listed_frac = sum(c for c, _ in st) / max(1, sum(m for _, m in st)) if st else 1.
+        flop_dn = n_local * (n_c + (n_c + n_f) * (1 + 2 * listed_frac)) * 2 * GEO_MAC
+    else:
+        flop_dn = n_local * (n_c + 2 * (n_c + n_f)) * 2 * GEO_MAC
     # ---- shadow rays: a bounded sample of this rank's surface points (foreground: occupancy > 0.5) x 512 lights
     fg = torch.nonzero(occu > 0.5)[:, 0]
     n_pts = min(GEO_LVIS_POINTS // world, int(fg.numel()))
@@ -951,9 +967,10 @@ def geometry_leg(args, ops, dev, rank, world, barrier, max_over_ranks):
         "precision": args.precision, "steps": steps, "finite": finite,
         "depth_normal": {
             "ms_per_view": elapsed / steps * 1e3, "rays_per_s": H * W * steps / elapsed,
-            "foreground_rays_this_rank": int(fg.numel()),
-            "roofline": {"bound": "mfma", "kernel": "nerf_sigma_geo_kernel (coarse density) + nerf_sigma_grad_kernel (fine density "
-                                                    "and its gradient: forward + reverse sweep), all launches of a view",
+            "foreground_rays_this_rank": int(fg.numel()), "samples_with_density_frac": listed_frac,
+            "roofline": {"bound": "mfma", "kernel": "nerf_sigma_geo_kernel (coarse density; fine density of every sample) + "
+                                                    "nerf_sigma_grad_kernel (forward + reverse sweep of the samples with a density), "
+                                                    "all launches of a view; FLOPs as executed",
                          "achieved": flop_dn / (kernel_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop_dn / (kernel_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
                          "flop_per_view_per_gpu": flop_dn, "kernels_ms_per_view": kernel_ms,
@@ -1319,6 +1336,8 @@ def compact(full):
         e = {"ms_per_view": (g.get("depth_normal") or {}).get("ms_per_view"),
              "frac": ((g.get("depth_normal") or {}).get("roofline") or {}).get("frac"),
              "lvis_frac": ((g.get("light_visibility") or {}).get("roofline") or {}).get("frac")}
+        if (g.get("depth_normal") or {}).get("samples_with_density_frac") is not None:
+            e["samples_with_density_frac"] = g["depth_normal"]["samples_with_density_frac"]
         e.update(_pick(g.get("parity") or {}, "normal_vec_max_abs", "rays_above_8e-2", "rays_compared", "depth_rel_of_range", "lvis_max_abs"))
         legs["geometry"] = e
     if legs:

@@ -459,6 +459,17 @@ NFX_API int nfx_nerf_sigma_grad(const float *dev_rayo, const float *dev_rayd, co
                         int n_samples, const void *dev_geom_blob, int prec, float *dev_normal_sigma,
                         void *stream);
 
+/* The same output with the reverse sweep run only where it is not zero (round 6): d relu(sigma_raw)/dx of a sample with
+ * sigma_raw <= 0 — empty space, most samples of a fitted scene — is zero; its normal is written as (-0, -0, -0) (the
+ * every-sample kernel writes zeros with the sign of g * 0 there), every other sample gets the same bits.  Three
+ * steps on the stream, nothing visits the host: the forward-only density of every sample (nfx_nerf_sigma_fwd's kernel), the
+ * ascending list of the samples with a density (every other sample's output row is written by that pass), the gradient
+ * kernel over the list.  `workspace`: nfx_nerf_sigma_grad_workspace_bytes bytes, 16-byte aligned; n_rays * S < 2^31.   */
+NFX_API size_t nfx_nerf_sigma_grad_workspace_bytes(int64_t n_rays, int n_samples);
+NFX_API int nfx_nerf_sigma_grad_rows(const float *dev_rayo, const float *dev_rayd, const float *dev_z, int64_t n_rays,
+                             int n_samples, const void *dev_geom_blob, int prec, float *dev_normal_sigma,
+                             void *dev_workspace, size_t workspace_bytes, void *stream);
+
 /* Selective fp32-class refinement of the COARSE densities of a bf16 render (round 6; nerf.py:138-147 with
  * util/math.py:71-94: the coarse weights place the fine samples, and on a fitted network's silhouette rays a bf16
  * density error of 0.1-0.3 moves them across the edge).  Two launches, no host round trip:

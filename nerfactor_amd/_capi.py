@@ -99,6 +99,8 @@ SIGNATURES = {
     'nfx_nerf_geom_packed_bytes': (_sz, [_i]),
     'nfx_nerf_pack_geom_weights': (_i, [_pp, _pp, _i, _p, _sz]),
     'nfx_nerf_sigma_grad': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p]),
+    'nfx_nerf_sigma_grad_workspace_bytes': (_sz, [_i64, _i]),
+    'nfx_nerf_sigma_grad_rows': (_i, [_p, _p, _p, _i64, _i, _p, _i, _p, _p, _sz, _p]),
     'nfx_selftest_mfma_bf16': (_i, [_p, _p, _p, _p]),
     'nfx_selftest_sincos': (_i, [_p, _i64, _i, _p, _p]),
     'nfx_selftest_tr16': (_i, [_p, _p, _p, _i, _p]),
@@ -140,7 +142,7 @@ def check(rc, what):
 
 # ------------------------------------------------------------------------------- options
 OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
-               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_rounds', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows', 'brdf_bwd_rows', 'nerf_bwd_rows')
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_rounds', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows', 'brdf_bwd_rows', 'nerf_bwd_rows', 'sigma_grad_rows')
 
 
 def set_option(key, value):

@@ -402,10 +402,13 @@ class BrdfRowsGeom(torch.autograd.Function):
         ctx.cfg = (n_freqs, z.shape[1])
         rows, front = ops.brdf_rows_geom_fwd(xyz, cam, normal, z, lxyz, n_freqs)
         ctx.mark_non_differentiable(front)
+        ctx.set_materialize_grads(False)   # (no zero tensor per backward for the gradient of `front` that nobody reads)
         return rows, front
 
     @staticmethod
     def backward(ctx, d_rows, _unused):
+        if d_rows is None:
+            return (None,) * 6
         xyz, cam, lxyz, normal = ctx.saved_tensors
         n_freqs, z_dim = ctx.cfg
         d_normal, d_z = ops.brdf_rows_geom_bwd(xyz, cam, normal, z_dim, lxyz, n_freqs, d_rows.contiguous())
@@ -442,10 +445,15 @@ class Composite(torch.autograd.Function):
         if w is None:
             w = rgb.new_empty(0)
         ctx.mark_non_differentiable(w)
+        # (otherwise autograd hands the backward a zero-filled tensor for each of the four detached outputs: 8 of the 9
+        #  fill launches of a NeRF training step)
+        ctx.set_materialize_grads(False)
         return rgb, occu, depth, disp, w
 
     @staticmethod
     def backward(ctx, d_rgb, *unused):
+        if d_rgb is None:
+            return (None,) * 6
         rgbs, z, rayd, noise = ctx.saved_tensors
         d_rgbs = ops.composite_bwd(rgbs, z, rayd, d_rgb.contiguous(), white_bg=ctx.white_bg, noise=noise)
         return d_rgbs, None, None, None, None, None

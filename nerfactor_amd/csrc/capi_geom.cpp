@@ -26,6 +26,12 @@ int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long lo
                                hipStream_t);
 int nfx_launch_refine_select(const float*, const float*, const float*, long long, int, float, float, float, float, int, int*, int*,
                              hipStream_t);
+int nfx_launch_nerf_sigma_grad_list(const float*, const float*, const float*, long long, int, const void*, float*, const int*,
+                                    const int*, int, hipStream_t);
+int nfx_launch_nerf_sigma_grad_x3_list(const float*, const float*, const float*, long long, int, const void*, float*,
+                                       const int*, const int*, int, hipStream_t);
+int nfx_launch_select_density(const float*, long long, float*, void*, hipStream_t);
+size_t nfx_nerf_bwd_list_bytes(long long n_pts);   // nerf_bwd.hip: bytes of a rowsel list over n_pts rows
 int nfx_launch_nerf_sigma_x3_list(const float*, const float*, const float*, long long, int, const void*, float*, const int*,
                                   const int*, int, hipStream_t);
 int nfx_launch_nerf_sigma_x3(const float*, const float*, const float*, long long, int, const void*, float*, int,
@@ -190,5 +196,49 @@ int nfx_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, in
                                                      geom_blob, normal_sigma, nfx_option_int("nerf_blocks", 256),
                                                      (hipStream_t)stream),
                           "nerf_sigma_grad");
+}
+
+// the density of every sample [n_pts floats, padded to 16 bytes], then the row list (rowsel.hpp)
+static size_t sigma_grad_sigma_bytes(long long n_pts) { return ((size_t)n_pts * 4 + 15) / 16 * 16; }
+size_t nfx_nerf_sigma_grad_workspace_bytes(int64_t n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    const long long n_pts = (long long)n_rays * n_samples;
+    return sigma_grad_sigma_bytes(n_pts) + nfx_nerf_bwd_list_bytes(n_pts);
+}
+
+int nfx_nerf_sigma_grad_rows(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
+                             const void* geom_blob, int prec, float* normal_sigma, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_grad_rows: bad shape");
+    REQUIRE(prec == NFX_PREC_BF16 || prec == NFX_PREC_FP32, "nfx_nerf_sigma_grad_rows: bad prec %d", prec);
+    if (n_rays == 0) return NFX_OK;
+    REQUIRE(rayo && rayd && z && geom_blob && normal_sigma && workspace, "nfx_nerf_sigma_grad_rows: null pointer");
+    const long long n_pts = (long long)n_rays * n_samples;
+    REQUIRE(n_pts < (1ll << 31), "nfx_nerf_sigma_grad_rows: %lld samples do not fit int32 indices", n_pts);
+    REQUIRE(workspace_bytes >= nfx_nerf_sigma_grad_workspace_bytes(n_rays, n_samples), "nfx_nerf_sigma_grad_rows: workspace too small");
+    if (!ALIGNED(geom_blob, 16) || !ALIGNED(normal_sigma, 16) || !ALIGNED(workspace, 16))
+        return nfx_fail(NFX_EALIGN, "nfx_nerf_sigma_grad_rows: blob, output and workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = nfx_option_int("nerf_blocks", 256);
+    float* sigma = static_cast<float*>(workspace);
+    void* list_ws = static_cast<char*>(workspace) + sigma_grad_sigma_bytes(n_pts);
+    const int* count = static_cast<const int*>(list_ws);
+    const int* list = reinterpret_cast<const int*>(static_cast<char*>(list_ws) + nfx_nerf_bwd_list_bytes(n_pts)) - (n_pts + 3) / 4 * 4;
+    // 1. the density of every sample (the forward-only kernel: bit-identical to the gradient kernel's own density)
+    int rc = nfx_hip_result(prec == NFX_PREC_FP32
+                                ? nfx_launch_nerf_sigma_x3(rayo, rayd, z, n_pts, n_samples, geom_blob, sigma, blocks, st)
+                                : nfx_launch_nerf_sigma_geo(rayo, rayd, z, n_pts, n_samples, geom_blob, sigma, blocks, st),
+                            "nerf_sigma_grad_rows(density)");
+    if (rc) return rc;
+    // 2. the samples with a density, ascending; every other sample's output row is final after this pass
+    rc = nfx_hip_result(nfx_launch_select_density(sigma, n_pts, normal_sigma, list_ws, st), "nerf_sigma_grad_rows(select)");
+    if (rc) return rc;
+    // 3. forward + reverse sweep over the listed samples only
+    return nfx_hip_result(prec == NFX_PREC_FP32
+                              ? nfx_launch_nerf_sigma_grad_x3_list(rayo, rayd, z, n_pts, n_samples, geom_blob, normal_sigma,
+                                                                   list, count, blocks, st)
+                              : nfx_launch_nerf_sigma_grad_list(rayo, rayd, z, n_pts, n_samples, geom_blob, normal_sigma,
+                                                                list, count, blocks, st),
+                          "nerf_sigma_grad_rows(gradient)");
 }
 }  // extern "C"

@@ -10,6 +10,7 @@
 // Sample positions carry no gradient (z_fine is under stop_gradient, nerf.py:145; rays are data).
 #include <cstdlib>
 #include "feat_store.hpp"
+#include "rowsel.hpp"
 #include "lds_dma.hpp"
 #include "nerf_train_layout.hpp"
 
@@ -435,30 +436,20 @@ __global__ __launch_bounds__(NW * 64, 1) void nerf_bwd_ring_kernel(
     }
 }
 
-// ------------------------------------------------------------ the rows with a gradient, in ascending order
+// ------------------------------------------------------------ the rows with a gradient, in ascending order (rowsel.hpp)
 // d_rgbs of a point the composite gave no weight (alpha = 0: raw density <= 0) is four exact zeros — half the samples of a
-// freshly initialised network, most of a fitted scene's.  Three small launches (no host sync, no memset node: the whole
-// step stays one hipGraph): per 1024 rows a count, one workgroup's exclusive scan of the counts (+ the total), then
-// every row's rank = its block's offset + the rows before it inside the block.  Ascending order makes the weight
-// gradients' summation order a function of d_rgbs alone: the same bits run to run.
+// freshly initialised network, most of a fitted scene's.
+struct HasGradient {
+    const float4* g;
+    __device__ bool operator()(long long r) const {
+        const uint4 v = *reinterpret_cast<const uint4*>(g + r);
+        return ((v.x | v.y | v.z | v.w) & 0x7fffffffu) != 0u;   // -0 is zero; a NaN is a gradient (and reaches the weights)
+    }
+    __device__ void visit(long long, bool) const {}
+};
+}  // namespace bwd
+
 namespace rowsel {
-constexpr int kBlockRows = 1024;
-__device__ __forceinline__ bool has_gradient(const float4* __restrict__ g, long long r, long long n) {
-    if (r >= n) return false;
-    const uint4 v = *reinterpret_cast<const uint4*>(g + r);
-    return ((v.x | v.y | v.z | v.w) & 0x7fffffffu) != 0u;   // -0 is zero; a NaN is a gradient (and reaches the weights)
-}
-__global__ __launch_bounds__(256) void count_kernel(const float4* __restrict__ g, long long n, int* __restrict__ block_count) {
-    __shared__ int s[4];
-    const int tid = threadIdx.x;
-    int c = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        c += __popcll(__ballot(has_gradient(g, (long long)blockIdx.x * kBlockRows + r * 256 + tid, n)));
-    if ((tid & 63) == 0) s[tid >> 6] = c;
-    __syncthreads();
-    if (tid == 0) block_count[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
-}
 __global__ __launch_bounds__(1024) void scan_kernel(int* __restrict__ block_count, int n_blocks, int* __restrict__ count) {
     __shared__ int s[1024];
     const int tid = threadIdx.x;
@@ -480,44 +471,17 @@ __global__ __launch_bounds__(1024) void scan_kernel(int* __restrict__ block_coun
     }
     if (tid == 0) *count = carry;
 }
-__global__ __launch_bounds__(256) void write_kernel(const float4* __restrict__ g, long long n,
-                                                    const int* __restrict__ block_offset, int* __restrict__ list) {
-    __shared__ int s[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    bool f[4];
-    unsigned long long m[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        f[r] = has_gradient(g, (long long)blockIdx.x * kBlockRows + r * 256 + tid, n);
-        m[r] = __ballot(f[r]);
-        if (lane == 0) s[r * 4 + wave] = __popcll(m[r]);
-    }
-    __syncthreads();
-    int before = block_offset[blockIdx.x];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k == wave && f[r])
-                list[before + __popcll(m[r] & ((1ull << lane) - 1ull))] = (int)((long long)blockIdx.x * kBlockRows + r * 256 + tid);
-            before += s[r * 4 + k];
-        }
-    }
+int launch_scan(int* block_count, int n_blocks, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, block_count, n_blocks, count);
+    return (int)hipGetLastError();
 }
 }  // namespace rowsel
-}  // namespace bwd
 }  // namespace nfx
 
 extern "C" int nfx_option_int(const char* name, int dflt);   // capi.cpp
 
-// the row-list workspace of nfx_launch_nerf_bwd: [count, 3 pad][one count per 1024 points, padded to 4][n_pts indices]
-static long long rowsel_blocks(long long n_pts) {
-    return (n_pts + nfx::bwd::rowsel::kBlockRows - 1) / nfx::bwd::rowsel::kBlockRows;
-}
-extern "C" size_t nfx_nerf_bwd_list_bytes(long long n_pts) {
-    if (n_pts <= 0) return 0;
-    return (size_t)(4 + (rowsel_blocks(n_pts) + 3) / 4 * 4 + (n_pts + 3) / 4 * 4) * sizeof(int);
-}
+// the row-list workspace of nfx_launch_nerf_bwd (rowsel.hpp: count, block counts, n_pts indices)
+extern "C" size_t nfx_nerf_bwd_list_bytes(long long n_pts) { return nfx::rowsel::workspace_bytes(n_pts); }
 
 extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                                    const void* blob, const float* d_rgbs, void* wsp, long long ld, int max_blocks,
@@ -533,15 +497,9 @@ extern "C" int nfx_launch_nerf_bwd(const float* rayo, const float* rayd, const f
     if (list_ws && !use_ring) return (int)hipErrorInvalidValue;
     int *count = static_cast<int*>(list_ws), *list = nullptr;
     if (list_ws) {
-        const long long nb = rowsel_blocks(n_pts);
-        int* block_count = count + 4;
-        list = block_count + (nb + 3) / 4 * 4;
-        hipLaunchKernelGGL(bwd::rowsel::count_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)d_rgbs, n_pts, block_count);
-        hipLaunchKernelGGL(bwd::rowsel::scan_kernel, dim3(1), dim3(1024), 0, st, block_count, (int)nb, count);
-        hipLaunchKernelGGL(bwd::rowsel::write_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)d_rgbs, n_pts,
-                           (const int*)block_count, list);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+        list = rowsel::list_of(list_ws, n_pts);
+        const int rc = rowsel::build(bwd::HasGradient{(const float4*)d_rgbs}, n_pts, list_ws, st);
+        if (rc) return rc;
     }
     auto k = !use_ring ? bwd::nerf_bwd_kernel
              : ring_nw == 8 ? (list ? bwd::nerf_bwd_ring_kernel<8, true> : bwd::nerf_bwd_ring_kernel<8, false>)

@@ -4,6 +4,7 @@
 // 8x256 encoder keeping 1-bit ReLU masks, reverse sweep with the transposed weights in the same register-resident
 // MFMA dataflow, input-gradient tiles landing in the positional-encoding SLOT layout, analytic posenc Jacobian.
 #include "feat_store.hpp"
+#include "rowsel.hpp"
 #include "nerf_geom_layout.hpp"
 
 namespace nfx {
@@ -54,11 +55,20 @@ __device__ __forceinline__ void input_grad(WStream& ws, int tid, const bf16x8 (&
     });
 }
 
+// LIST (round 6): the points are the flat sample indices list[0 .. *count) — the samples whose density is positive
+// (nfx_nerf_sigma_grad_rows: d relu(sigma) / dx of every other sample is zero, its output row is written by the selecting pass)
+// — and point list[c]'s result goes to out[list[c]].  A workgroup with no tile leaves before it touches the weight stream.
+template <bool LIST>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_grad_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
-    int n_samples, const char* __restrict__ blob, float4* __restrict__ out) {
+    int n_samples, const char* __restrict__ blob, float4* __restrict__ out, const int* __restrict__ list,
+    const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
+    if constexpr (LIST) {
+        n_pts = *count;
+        if ((long long)blockIdx.x * kRows >= n_pts) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
     float* fl = reinterpret_cast<float*>(smem + 2 * kSlotBytes);
     {
@@ -75,7 +85,8 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_grad_kernel(
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row = tile * kRows + wave * 32 + p;
         const bool valid = row < n_pts;
-        const long long mm = valid ? row : n_pts - 1;
+        long long mm = valid ? row : n_pts - 1;
+        if constexpr (LIST) mm = list[mm];
         float x[3];
         {
             const long long ray = mm / n_samples;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_grad_kernel(
             const float on = sigma > 0.f ? 1.f : 0.f;           // gradient of relu(sigma_raw)
             const float gx = g[0] * on, gy = g[1] * on, gz = g[2] * on;
             const float inv = -1.0f / sqrtf(fmaxf(gx * gx + gy * gy + gz * gz, 1e-12f));  // -l2_normalize(., eps 1e-12)
-            out[row] = make_float4(gx * inv, gy * inv, gz * inv, sigma);
+            out[LIST ? mm : row] = make_float4(gx * inv, gy * inv, gz * inv, sigma);
         }
     }
 }
@@ -209,19 +220,46 @@ __global__ __launch_bounds__(512, 2) void nerf_sigma_geo_kernel(
 }  // namespace geo
 }  // namespace nfx
 
-extern "C" int nfx_launch_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, long long n_pts,
-                                          int n_samples, const void* blob, float* out, int max_blocks, hipStream_t st) {
+// list / count null: every point; else n_pts = the list's capacity (sizes the grid), the kernel reads the count on the device
+extern "C" int nfx_launch_nerf_sigma_grad_list(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                               int n_samples, const void* blob, float* out, const int* list,
+                                               const int* count, int max_blocks, hipStream_t st) {
     using namespace nfx;
     if (n_pts <= 0) return 0;
     const long long tiles = (n_pts + geo::kRows - 1) / geo::kRows;
     const int grid = (int)(tiles < max_blocks ? tiles : max_blocks);
-    auto k = geo::nerf_sigma_grad_kernel;
+    auto k = list ? geo::nerf_sigma_grad_kernel<true> : geo::nerf_sigma_grad_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        geo::kLds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(geo::kNW * 64), geo::kLds, st, rayo, rayd, z, n_pts, n_samples,
-                       (const char*)blob, (float4*)out);
+                       (const char*)blob, (float4*)out, list, count);
     return (int)hipGetLastError();
+}
+extern "C" int nfx_launch_nerf_sigma_grad(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                          int n_samples, const void* blob, float* out, int max_blocks, hipStream_t st) {
+    return nfx_launch_nerf_sigma_grad_list(rayo, rayd, z, n_pts, n_samples, blob, out, nullptr, nullptr, max_blocks, st);
+}
+
+// The samples with a positive density, ascending (rowsel.hpp), for the LIST form of the gradient kernels; the same pass
+// writes the output row of every sample without density: relu has no slope there, the gradient is zero and
+// -l2_normalize(0) = 0 * (-1 / sqrt(1e-12)) = (-0, -0, -0) (the every-sample kernel forms g * 0 and so keeps g's signs on
+// its zeros: equal as numbers); the density channel keeps the raw value.
+// (A NaN density is listed: the gradient kernel then writes what it always wrote for it.)
+namespace nfx {
+namespace geo {
+struct HasDensity {
+    const float* sigma;
+    float4* out;
+    __device__ bool operator()(long long r) const { return !(sigma[r] <= 0.f); }
+    __device__ void visit(long long r, bool on) const {
+        if (!on) out[r] = make_float4(-0.f, -0.f, -0.f, sigma[r]);
+    }
+};
+}  // namespace geo
+}  // namespace nfx
+extern "C" int nfx_launch_select_density(const float* sigma, long long n_pts, float* out, void* list_ws, hipStream_t st) {
+    return nfx::rowsel::build(nfx::geo::HasDensity{sigma, (float4*)out}, n_pts, list_ws, st);
 }
 
 extern "C" int nfx_launch_nerf_sigma_geo(const float* rayo, const float* rayd, const float* z, long long n_pts,

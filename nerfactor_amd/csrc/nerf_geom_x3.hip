@@ -73,9 +73,10 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
     const int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace nerf;
-    // LIST mode (density only, round 6: the selective coarse refinement of the bf16 render): the points are the flat sample
-    // indices list[0 .. *count) (both in device memory: the number of selected samples never visits the host), and the
-    // density of point i goes to out[4 i + 3] — the sigma channel of rgbs[N, S, 4].  A workgroup with no tile leaves at once.
+    // LIST mode (round 6): the points are the flat sample indices list[0 .. *count) (both in device memory: the number of
+    // selected samples never visits the host).  Density only (the selective coarse refinement of the bf16 render): the
+    // density of point i goes to out[4 i + 3] — the sigma channel of rgbs[N, S, 4]; GRAD (nfx_nerf_sigma_grad_rows: the
+    // samples with a positive density): (normal, sigma) of point i to row i of out[n][4].  A workgroup with no tile leaves at once.
     if (list != nullptr) {
         n_pts = *count;
         if ((long long)blockIdx.x * kRows >= n_pts) return;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_sigma_x3_kernel(
                 const float on = sigma > 0.f ? 1.f : 0.f;           // gradient of relu(sigma_raw)
                 const float gx = g[0] * on, gy = g[1] * on, gz = g[2] * on;
                 const float inv = -1.0f / sqrtf(fmaxf(gx * gx + gy * gy + gz * gz, 1e-12f));  // -l2_normalize(., 1e-12)
-                reinterpret_cast<float4*>(out)[row] = make_float4(gx * inv, gy * inv, gz * inv, sigma);
+                reinterpret_cast<float4*>(out)[list != nullptr ? mm : row] = make_float4(gx * inv, gy * inv, gz * inv, sigma);
             }
         }
     }
@@ -211,6 +212,12 @@ extern "C" int nfx_launch_nerf_sigma_grad_x3(const float* rayo, const float* ray
 extern "C" int nfx_launch_nerf_sigma_x3(const float* rayo, const float* rayd, const float* z, long long n_pts,
                                         int n_samples, const void* blob, float* out, int max_blocks, hipStream_t st) {
     return nfx::geo3::launch<false>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, st);
+}
+// density gradient at the listed samples, each written to its own row of out[n_pts][4] (nfx_nerf_sigma_grad_rows)
+extern "C" int nfx_launch_nerf_sigma_grad_x3_list(const float* rayo, const float* rayd, const float* z, long long n_pts,
+                                                  int n_samples, const void* blob, float* out, const int* list,
+                                                  const int* count, int max_blocks, hipStream_t st) {
+    return nfx::geo3::launch<true>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, st, list, count);
 }
 // density at the listed samples (n_pts = the list's capacity: sizes the grid; the kernel reads the real count on the device)
 extern "C" int nfx_launch_nerf_sigma_x3_list(const float* rayo, const float* rayd, const float* z, long long n_pts,

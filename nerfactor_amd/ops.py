@@ -996,12 +996,26 @@ def nerf_coarse_error(rayo, rayd, z, rgbs, geom_blob_fp32, max_rays=4096, q=0.99
     return float(both[0]), float(both[1])
 
 
+SIGMA_GRAD_STATS = None   # a list: nerf_sigma_grad appends (samples with a density [device int32 copy], samples) per call (bench.py)
+
+
 def nerf_sigma_grad(rayo, rayd, z, geom_blob, prec='bf16'):
     """(normal[N,S,3], sigma_raw[N,S]) with normal = -l2_normalize(d relu(sigma)/dx)."""
     rayo, rayd, z, n, s = _ray_args(rayo, rayd, z, geom_blob)
     out = torch.empty((n, s, 4), dtype=torch.float32, device=z.device)
-    check(lib.nfx_nerf_sigma_grad(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(geom_blob), _PREC[prec], _ptr(out),
-                                  _stream()), 'nfx_nerf_sigma_grad')
+    if _capi.get_option("sigma_grad_rows") != 0 and n * s < 2 ** 31:
+        # the reverse sweep only over the samples with a positive density (every other sample's normal is zero: relu has no
+        # slope there) — the same values, and most samples of a fitted scene are empty space
+        ws_bytes = lib.nfx_nerf_sigma_grad_workspace_bytes(n, s)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=z.device)
+        check(lib.nfx_nerf_sigma_grad_rows(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(geom_blob), _PREC[prec], _ptr(out),
+                                           _ptr(ws), ws.numel(), _stream()), 'nfx_nerf_sigma_grad_rows')
+        if SIGMA_GRAD_STATS is not None:
+            first = (n * s * 4 + 15) // 16 * 4
+            SIGMA_GRAD_STATS.append((ws.view(torch.int32)[first:first + 1].clone(), n * s))
+    else:
+        check(lib.nfx_nerf_sigma_grad(_ptr(rayo), _ptr(rayd), _ptr(z), n, s, _ptr(geom_blob), _PREC[prec], _ptr(out),
+                                      _stream()), 'nfx_nerf_sigma_grad')
     return out[..., :3], out[..., 3]
 
 def amsgrad_step(p, g, m, v, vhat, lr, step, beta1=0.9, beta2=0.999, eps=1e-7):

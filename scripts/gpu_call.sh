@@ -111,6 +111,12 @@ d = json.load(open("bench_detail.json"))["train"]["nerf"]
 print("side_streams=$r", {k: d.get(k) for k in ("ms_per_step", "ms_per_step_eager", "points_with_gradient_frac", "step")}, {k: d["roofline"].get(k) for k in ("frac", "largest_backward_call_ms", "backward_calls_ms_per_step")})
 PYEOF
       tail -2 $OUT/bench_train_nerf_streams$r.err; done; done ;;
+    geometry-ab) for i in 1 2; do for r in 0 1; do NFX_SIGMA_GRAD_ROWS=$r timeout 600 python bench.py --steps 3 --warmup 1 --legs geometry --no-cpu-baseline > $OUT/bench_geometry_rows$r.json 2> $OUT/bench_geometry_rows$r.err; python - <<PYEOF
+import json
+d = json.load(open("bench_detail.json"))["geometry"]["depth_normal"]
+print("sigma_grad_rows=$r", {k: d.get(k) for k in ("ms_per_view", "rays_per_s", "samples_with_density_frac")}, {k: d["roofline"].get(k) for k in ("frac", "kernels_ms_per_view", "share_of_stage")})
+PYEOF
+      tail -2 $OUT/bench_geometry_rows$r.err; done; done ;;
     nerf-bwd-rows) timeout 600 python scripts/nerf_bwd_rows.py > $OUT/nerf_bwd_rows.json 2> $OUT/nerf_bwd_rows.err; cat $OUT/nerf_bwd_rows.json; tail -3 $OUT/nerf_bwd_rows.err ;;
     bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do for fm in "pairs" "pairs --graph" "native"; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --fp32-matrix $fm --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;

@@ -499,6 +499,49 @@ def test_sigma_only_kernel_is_the_full_kernel_s_density(nfx_lib, cuda):
     assert torch.equal(sig, full[..., 3])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("weights,n_rays,s", [("fitted", 900, 70), ("glorot", 301, 9), ("fitted", 40, 320)])
+def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_lib, cuda, nfx_opt, prec, weights, n_rays, s):
+    """ops.nerf_sigma_grad runs the reverse sweep only over the samples with a positive raw density (nfx_nerf_sigma_grad_rows:
+    forward-only density of every sample, device-side ascending list, gradient kernel over the list; d relu(sigma)/dx of every
+    other sample is zero — geometry_from_nerf.py:289-297 differentiates relu(sigma)) and returns what the every-sample kernel
+    returns (option sigma_grad_rows = 0): the same bits on the listed samples, zeros elsewhere (there the every-sample kernel
+    writes g * 0 with g's sign, the list form -0); the list is exactly the samples with sigma_raw > 0."""
+    from nerfactor_amd import ops
+    from tests.golden import golden_inputs as gi
+    net = gi.trained_nerf_nets()[1] if weights == "fitted" else common.nerf_nets(seed=8)[1]
+    ks, bs = common.nerf_layers(net)
+    gblob = ops.pack_nerf_geom_weights(ks, bs, prec).to(cuda)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
+    if weights == "fitted":      # rays of a view of the fitted scene: empty space in front of and behind the object
+        side = int(np.ceil(np.sqrt(n_rays)))
+        rayo, rayd = common.camera_rays(side, side, cam_loc=(1.9, -2.8, 2.1))
+        rayo, rayd = rayo[:n_rays], rayd[:n_rays]
+        rayd = rayd / np.linalg.norm(rayd, axis=1, keepdims=True)
+        z = np.sort(np.random.default_rng(5).uniform(2., 6., size=(n_rays, s)).astype(np.float32), 1)
+    else:
+        rayo, rayd, z = _geom_inputs(n_rays, s, 2)
+    args = (t(rayo), t(rayd), t(z), gblob, prec)
+    nfx_opt.set("sigma_grad_rows", 0)
+    n0, s0 = ops.nerf_sigma_grad(*args)
+    nfx_opt.set("sigma_grad_rows", 1)
+    ops.SIGMA_GRAD_STATS = []
+    try:
+        n1, s1 = ops.nerf_sigma_grad(*args)
+        (count, total), = ops.SIGMA_GRAD_STATS
+    finally:
+        ops.SIGMA_GRAD_STATS = None
+    assert total == n_rays * s and int(count.item()) == int((s0 > 0).sum().item())
+    if weights == "fitted" and s > 9:
+        assert 0 < int(count.item()) < 0.6 * total      # most of the samples are empty space
+    assert torch.equal(s1, s0)
+    assert torch.equal(n1, n0)                          # (as numbers: the every-sample kernel's zeros carry the sign of g * 0)
+    listed = (s0 > 0)[..., None].expand_as(n0)
+    assert torch.equal(n1[listed].view(torch.int32), n0[listed].view(torch.int32))
+    assert float(n1[~listed].abs().max() if (~listed).any() else 0.) == 0.
+    assert torch.isfinite(n1).all() and int(count.item()) > 0 and float(n1.abs().max()) > 0.5
+
+
 def test_sigma_gradient_normals_vs_autograd(nfx_lib, cuda):
     """n = -normalize(d relu(sigma)/dx) (geometry_from_nerf.py:289-297) against torch autograd through the network
     evaluated with the kernel's bf16 operand rounding (straight-through), and loosely against plain fp64."""
