@@ -778,6 +778,9 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
         flops = 3 * 2 * (rows * LVIS_MAC + 2 * 3 * n * 65664)   # 2 (jitter) x 3 (fwd + dgrad + wgrad) x forward
         what = "512 lights, xyz jitter on; FLOPs = 2 (clean + jittered) x 3 (forward, dgrad, wgrad) x the four trainable MLPs' forward"
         dom, per_step = 'mlp128_bwd', 4
+    fitted = None
+    if name == 'nerf' and world == 1 and args.precision == 'bf16' and not args.no_hip_graph:
+        fitted = nerf_fitted_train_step(ops, dev, n, optim, get_model_class, make_config)
     calls = np.asarray(kt.all_ms(dom))
     if calls.size != steps * per_step:
         per_step = max(1, calls.size // steps)
@@ -858,7 +861,7 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                  else "eager optim.train_step" + (" (%s)" % graph_note if graph_note else "")),
         "ms_per_step_eager": dt_eager * 1e3,
         "first_loss": float(losses[0]), "final_loss": float(losses[-1]),
-        "points_with_gradient_frac": grad_frac,
+        "points_with_gradient_frac": grad_frac, "fitted_scene": fitted,
         "collective": ("%s all_reduce of one flat fp32 bucket (%d floats) per step over %d ranks" % (
             torch.distributed.get_backend(), opt.bucket.flat.numel(), world)) if (world > 1 or nfx_dist.run_collectives_on_one_rank())
         else "none (one rank, no process group)",
@@ -871,6 +874,59 @@ def train_leg(name, args, ops, dev, rank, world, barrier, max_over_ranks):
                      "largest_backward_call_ms": float(big.mean()),
                      "backward_calls_ms_per_step": float(calls.sum(1).mean())},
     }
+
+
+def nerf_fitted_train_step(ops, dev, n, optim, get_model_class, make_config, steps=40):
+    """The NeRF training step on networks FITTED to a scene (tests/golden/nerf_trained_fp16.npz) — what a training run spends most
+    of its steps on: empty space has a negative raw density there, so most points carry no gradient and nfx_nerf_mlp_bwd skips
+    them.  `n` rays of the view the render legs time, targets = the networks' own render (the densities stay
+    where they are), one hipGraph replay per step; one process only."""
+    from nerfactor_amd import synth
+    from tests.golden import golden_inputs as gi
+    torch.manual_seed(0)
+    model = get_model_class('nerf')(make_config('nerf'))
+    with torch.no_grad():
+        for pref, net in zip(('coarse_', 'fine_'), gi.trained_nerf_nets()):
+            for part in ('enc', 'sigma_out', 'bottleneck', 'rgb_out'):
+                for layer, (k, b) in zip(model.net[pref + part].layers, net[part]):
+                    layer.kernel.copy_(torch.from_numpy(np.asarray(k, np.float32)))
+                    layer.bias.copy_(torch.from_numpy(np.asarray(b, np.float32)))
+    model = model.to(dev)
+    opt = optim.make_optimizer(model, model.config)
+    rayo, rayd = synth.camera_rays(800, 800, cam_loc=(4 * 0.8, -0.1, 4 * 0.6))
+    idx = np.random.default_rng(7).choice(rayo.shape[0], n, replace=False)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    o, d = t(rayo[idx]), t(rayd[idx])
+    with torch.no_grad():
+        rgb = model((None, None, o, d, torch.zeros_like(o)), mode='test')[0]['fine'].clamp(0, 1)
+    batch = (None, None, o, d, rgb)
+
+    def count():
+        ops.NERF_BWD_STATS = []
+        try:
+            optim.train_step(model, batch, opt, n)
+            torch.cuda.synchronize()
+            return [(int(c.item()), m) for c, m in ops.NERF_BWD_STATS]
+        finally:
+            ops.NERF_BWD_STATS = None
+    listed = ops._capi.get_option('nerf_bwd_rows') != 0
+    before = count()
+    step = optim.GraphedTrainStep(model, opt, n)
+    for _ in range(6):
+        step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = step(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    after = count()
+    frac = lambda st: (sum(c for c, _ in st) / max(1, sum(m for _, m in st))) if listed and st else 1.
+    model.flush_numerics(block=True)
+    return {"what": "the same step on the networks fitted to a scene, %d rays of the rendered view, targets = their own render, "
+                    "one hipGraph replay per step" % n,
+            "ms_per_step": ms, "steps": steps, "loss": float(loss),
+            "points_with_gradient_frac": frac(before), "points_with_gradient_frac_after_the_steps": frac(after)}
 
 
 # ------------------------------------------------------------------------------------------------ geometry leg (SURVEY §8f-2)
@@ -1315,6 +1371,9 @@ def compact(full):
              "frac": (leg.get("roofline") or {}).get("frac")}
         if leg.get("points_with_gradient_frac") is not None:
             e["points_with_gradient_frac"] = leg["points_with_gradient_frac"]
+        if leg.get("fitted_scene"):
+            e["fitted_scene_ms_per_step"] = leg["fitted_scene"].get("ms_per_step")
+            e["fitted_scene_points_with_gradient_frac"] = leg["fitted_scene"].get("points_with_gradient_frac")
         if leg.get("parity"):
             e["grad_rel_vs_bf16_oracle"] = leg["parity"].get("grad_rel_frobenius_vs_bf16_oracle_worst")
             e["grad_rel_vs_reference"] = leg["parity"].get("grad_rel_frobenius_vs_reference_worst")
