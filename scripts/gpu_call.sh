@@ -71,7 +71,7 @@ for k,v in d.items():
     if 'mfma_util' in v and v.get('mfma_util',0)>0.05 or 'shade' in k: print(k[:60], {a: (round(b,4) if isinstance(b,float) and b<10 else int(b)) for a,b in v.items() if a in ('dispatches','mfma_util','hbm_read_bytes_corrected','hbm_write_bytes')})" ;;
     pmc-train) for pass in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_LDS" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
                  set -- $pass; name=$1; shift
-                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_train/$name -o p -- python $ROOT/bench.py --legs train --train-models ${PMC_MODELS:-nerfactor_microfacet,nerf} --steps 1 --warmup 1 --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/pmc_train_$name.log 2>&1); echo "pmc pass $name rc=$?"
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/pmc_train/$name -o p -- python $ROOT/bench.py --legs train --train-models ${PMC_MODELS:-nerfactor_microfacet,nerf} --steps ${PMC_STEPS:-1} --warmup 1 --no-cpu-baseline --no-hip-graph > $ROOT/$OUT/pmc_train_$name.log 2>&1); echo "pmc pass $name rc=$?"
                done
                python scripts/pmc_digest.py $OUT/pmc_train > $OUT/pmc_train_digest.json; python - <<PYEOF
 import json
