@@ -142,7 +142,7 @@ def check(rc, what):
 
 # ------------------------------------------------------------------------------- options
 OPTION_KEYS = ('nerf_variant', 'nerf_blocks', 'm128_blocks', 'lvis_variant', 'brdf_variant', 'brdf_ct', 'nerf_bwd',
-               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_rounds', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows', 'brdf_bwd_rows', 'nerf_bwd_rows', 'sigma_grad_rows')
+               'nerf_bwd_nw', 'm128_bwd', 'wgrad_lds', 'wgrad_slabs', 'wgrad_rounds', 'wgrad_narrow', 'wgrad_fused', 'lvis_verify', 'lvis_rows', 'brdf_bwd_rows', 'nerf_bwd_rows', 'sigma_grad_rows', 'sigma_variant')
 
 
 def set_option(key, value):

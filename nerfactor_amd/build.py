@@ -41,7 +41,7 @@ VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 # The 2.5-ulp forms (v_rcp_f32 + one Newton step) leave the render inside its 3e-4 of the fp32 oracle
 # (tests/test_gpu_nerfactor.py::test_shade_microfacet_vs_oracle): 4364 -> 3263 and 3070 -> 2348 instructions.
 FAST_DIV = ['-fno-hip-fp32-correctly-rounded-divide-sqrt']
-PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM,
+PER_FILE_FLAGS = {'lvis_v2.hip': VGPR_FORM, 'nerf_mlp_v6.hip': VGPR_FORM, 'nerf_sigma_v6.hip': VGPR_FORM,
                   'nerf_geom.hip': VGPR_FORM, 'mlp128_bwd_fused.hip': VGPR_FORM, 'shade.hip': FAST_DIV}
 if os.environ.get('NFX_VGPR_FORM_FILES') is not None:      # A/B experiment libraries: only the VGPR-form entries are overridden —
     # shade.hip keeps FAST_DIV, so an experiment build divides exactly like the shipped library

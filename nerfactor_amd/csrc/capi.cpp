@@ -83,6 +83,7 @@ Option g_options[] = {
                                   //    Opt-in: measured equal within the noise (profiles/r06/render_rows_ab.txt).
     {"brdf_bwd_rows", {0}, {0}},  // 0: the HOST side differentiates the learned BRDF over every (point, light) row (nfx_brdf_spec_bwd);
                                   //    1 / unset = over the rows with a non-zero upstream gradient only (nfx_brdf_spec_bwd_rows; same bits)
+    {"sigma_variant", {0}, {0}},    // bf16 density-only kernel: 1 / unset = the render kernel's dataflow (nerf_sigma_v6.hip), 0 = nerf_sigma_geo_kernel
     {"sigma_grad_rows", {0}, {0}},  // 0: the HOST side calls nfx_nerf_sigma_grad (reverse sweep for every sample); 1 / unset =
                                     //    nfx_nerf_sigma_grad_rows (only the samples with a positive density; same values)
     {"nerf_bwd_rows", {0}, {0}},  // 0: nfx_nerf_mlp_bwd differentiates every point; 1 / unset = only the points whose upstream gradient is not

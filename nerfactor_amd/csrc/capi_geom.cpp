@@ -26,6 +26,7 @@ int nfx_launch_nerf_sigma_grad(const float*, const float*, const float*, long lo
                                hipStream_t);
 int nfx_launch_refine_select(const float*, const float*, const float*, long long, int, float, float, float, float, int, int*, int*,
                              hipStream_t);
+int nfx_launch_nerf_sigma_v6(const float*, const float*, const float*, long long, int, const void*, float*, int, hipStream_t);
 int nfx_launch_nerf_sigma_grad_list(const float*, const float*, const float*, long long, int, const void*, float*, const int*,
                                     const int*, int, hipStream_t);
 int nfx_launch_nerf_sigma_grad_x3_list(const float*, const float*, const float*, long long, int, const void*, float*,
@@ -138,6 +139,16 @@ int nfx_nerf_pack_geom_weights(const float* const kernels[12], const float* cons
     return pack_geom_half(lo_ptr, biases, w0 + nerf::kGeoWeightBytes, sink.data());
 }
 
+// bf16 density of every sample: the render kernel's dataflow over the GEOM blob (nerf_sigma_v6.hip, round 6; default) or the
+// round-2 kernel (option sigma_variant = 0) — the same MFMAs on the same operands, bit-identical
+static int launch_sigma_bf16(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
+                             const void* blob, float* sigma, hipStream_t st) {
+    const int blocks = nfx_option_int("nerf_blocks", 256);
+    if (nfx_option_int("sigma_variant", 1) != 0)
+        return nfx_launch_nerf_sigma_v6(rayo, rayd, z, n_pts, n_samples, blob, sigma, blocks, st);
+    return nfx_launch_nerf_sigma_geo(rayo, rayd, z, n_pts, n_samples, blob, sigma, blocks, st);
+}
+
 int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int64_t n_rays, int n_samples,
                        const void* blob, int prec, float* sigma, void* stream) {
     REQUIRE(n_rays >= 0 && n_samples >= 1, "nfx_nerf_sigma_fwd: bad shape");
@@ -149,8 +160,8 @@ int nfx_nerf_sigma_fwd(const float* rayo, const float* rayd, const float* z, int
         return nfx_hip_result(nfx_launch_nerf_sigma_x3(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
                                                        sigma, nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
                               "nerf_sigma_fwd(fp32)");
-    return nfx_hip_result(nfx_launch_nerf_sigma_geo(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob,
-                                                    sigma, nfx_option_int("nerf_blocks", 256), (hipStream_t)stream),
+    return nfx_hip_result(launch_sigma_bf16(rayo, rayd, z, (long long)n_rays * n_samples, n_samples, blob, sigma,
+                                            (hipStream_t)stream),
                           "nerf_sigma_fwd");
 }
 
@@ -227,7 +238,7 @@ int nfx_nerf_sigma_grad_rows(const float* rayo, const float* rayd, const float* 
     // 1. the density of every sample (the forward-only kernel: bit-identical to the gradient kernel's own density)
     int rc = nfx_hip_result(prec == NFX_PREC_FP32
                                 ? nfx_launch_nerf_sigma_x3(rayo, rayd, z, n_pts, n_samples, geom_blob, sigma, blocks, st)
-                                : nfx_launch_nerf_sigma_geo(rayo, rayd, z, n_pts, n_samples, geom_blob, sigma, blocks, st),
+                                : launch_sigma_bf16(rayo, rayd, z, n_pts, n_samples, geom_blob, sigma, st),
                             "nerf_sigma_grad_rows(density)");
     if (rc) return rc;
     // 2. the samples with a density, ascending; every other sample's output row is final after this pass

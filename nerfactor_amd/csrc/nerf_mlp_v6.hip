@@ -25,8 +25,18 @@
 #include "nerf_layout.hpp"
 
 
+// NFX_V6_SIGMA (nerf_sigma_v6.hip includes this file with it defined): the DENSITY-ONLY form of the same dataflow over the
+// GEOM blob (nerf_geom_layout.hpp: chunks 0..63 = the encoder exactly as here, chunk 64 = the sigma tile, chunk 65 = the
+// first reverse-sweep chunk, fetched and not multiplied: the weight sequence must be a multiple of the 6-slot ring) — the
+// tile / layer machinery below is shared, the kernel and the chunk count differ.
+#ifdef NFX_V6_SIGMA
+#define NFX_V6_NS v6s
+#else
+#define NFX_V6_NS v6
+#endif
+
 namespace nfx {
-namespace v6 {
+namespace NFX_V6_NS {
 
 constexpr int kNW = 4, kCT = 2;
 // ring size / fetch distance: register-staged 3 slots, chunk K+2 fetched during tile K; LDS-DMA 6 slots (78 = 6 x 13),
@@ -39,7 +49,12 @@ template <int DMA> constexpr int ring_of = DMA == 1 ? 6 : 3;
 constexpr int kDmaDist = 3;   // LDS-DMA fetch distance in tiles (4 measured the same; the 6-slot ring holds either)
 template <int DMA> constexpr int dist_of = DMA == 1 ? kDmaDist : DMA ? 3 : 2;
 template <int DMA> constexpr int lds_of = ring_of<DMA> * kSlotBytes + nerf::kBiasFloats * 4;
+#ifdef NFX_V6_SIGMA
+constexpr int kNChunks = 66;              // 64 encoder chunks + the sigma tile + one idle chunk = 6 x 11
+#else
 constexpr int kNChunks = nerf::kNChunks;  // 78
+#endif
+static_assert(kNChunks % 6 == 0, "the chunk sequence wraps on the 6-slot (and the 3-slot) ring");
 
 constexpr int kPreA = 3;   // A fragments in flight ahead of their MFMAs (2 / 3 / 4 measured: 1373 / 1372 / 1363 TFLOP/s)
 
@@ -266,6 +281,7 @@ __device__ __forceinline__ void layer(const Ctx& cx, Regs& rg, const float* bias
     });
 }
 
+#ifndef NFX_V6_SIGMA
 template <int AB, int DMA>
 __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     const float* __restrict__ rayo, const float* __restrict__ rayd, const float* __restrict__ zbuf, long long n_pts,
@@ -368,9 +384,11 @@ __global__ __launch_bounds__(kNW * 64, 1) void nerf_mlp_bf16_v6_kernel(
     }
 }
 
-}  // namespace v6
+#endif   // !NFX_V6_SIGMA
+}  // namespace NFX_V6_NS
 }  // namespace nfx
 
+#ifndef NFX_V6_SIGMA
 template <int AB, int DMA>
 static int launch_v6(const float* rayo, const float* rayd, const float* z, long long n_pts, int n_samples,
                      const void* blob, float* out, int max_blocks, hipStream_t stream) {
@@ -395,4 +413,4 @@ extern "C" int nfx_launch_nerf_mlp_bf16_v6(const float* rayo, const float* rayd,
     if (dma_mode == 2) return launch_v6<0, 2>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);   // variant 8
     return launch_v6<0, 0>(rayo, rayd, z, n_pts, n_samples, blob, out, max_blocks, stream);                      // variant 6
 }
-
+#endif   // !NFX_V6_SIGMA

@@ -118,6 +118,13 @@ print("sigma_grad_rows=$r", {k: d.get(k) for k in ("ms_per_view", "rays_per_s", 
 PYEOF
       tail -2 $OUT/bench_geometry_rows$r.err; done; done ;;
     soak-nerf-bwd) timeout ${SOAK_TIMEOUT:-900} python scripts/soak_nerf_bwd.py --launches ${SOAK_LAUNCHES:-3000} > $OUT/soak_nerf_bwd.log 2>&1; tail -5 $OUT/soak_nerf_bwd.log ;;
+    sigma-variant-ab) for i in 1 2; do for r in 0 1; do NFX_SIGMA_VARIANT=$r timeout 600 python bench.py --steps 3 --warmup 1 --legs geometry --no-cpu-baseline > $OUT/bench_geometry_sv$r.json 2> $OUT/bench_geometry_sv$r.err; python - <<PYEOF
+import json
+g = json.load(open("bench_detail.json"))["geometry"]
+d, l = g["depth_normal"], g["light_visibility"]
+print("sigma_variant=$r", {k: d.get(k) for k in ("ms_per_view", "rays_per_s")}, {k: d["roofline"].get(k) for k in ("frac", "kernels_ms_per_view")}, "| shadow rays", {k: l.get(k) for k in ("ms", "pairs_per_s", "full_view_estimate_s")}, {k: l["roofline"].get(k) for k in ("frac", "kernels_ms")})
+PYEOF
+      tail -2 $OUT/bench_geometry_sv$r.err; done; done ;;
     nerf-bwd-rows) timeout 600 python scripts/nerf_bwd_rows.py > $OUT/nerf_bwd_rows.json 2> $OUT/nerf_bwd_rows.err; cat $OUT/nerf_bwd_rows.json; tail -3 $OUT/nerf_bwd_rows.err ;;
     bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do for fm in "pairs" "pairs --graph" "native"; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --fp32-matrix $fm --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;

@@ -542,6 +542,30 @@ def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_
     assert torch.isfinite(n1).all() and int(count.item()) > 0 and float(n1.abs().max()) > 0.5
 
 
+@pytest.mark.determinism
+@pytest.mark.parametrize("n_rays,s", [(1, 1), (301, 5), (1000, 320), (4099, 64)])
+def test_density_kernel_in_the_render_dataflow_equals_the_round_2_one(nfx_lib, cuda, nfx_opt, n_rays, s):
+    """nfx_nerf_sigma_fwd (bf16) runs the render kernel's dataflow over the GEOM blob (csrc/nerf_sigma_v6.hip: LDS-DMA weight ring,
+    66-chunk sequence = encoder + sigma tile + one idle chunk); option sigma_variant = 0 keeps nerf_sigma_geo_kernel.  Same
+    MFMAs on the same operands: the same bits, for one point, a ragged last tile and several passes of the persistent loop —
+    and the density channel of the full MLP kernel."""
+    from nerfactor_amd import ops
+    from tests.golden import golden_inputs as gi
+    for net in (common.nerf_nets(seed=7)[1], gi.trained_nerf_nets()[1]):
+        ks, bs = common.nerf_layers(net)
+        gblob = ops.pack_nerf_geom_weights(ks, bs).to(cuda)
+        rayo, rayd, z = _geom_inputs(n_rays, s, 3)
+        t = lambda a: torch.from_numpy(a).to(cuda)
+        nfx_opt.set("sigma_variant", 0)
+        old = ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), gblob)
+        nfx_opt.set("sigma_variant", 1)
+        new = ops.nerf_sigma_fwd(t(rayo), t(rayd), t(z), gblob)
+        assert torch.equal(new, old) and torch.isfinite(new).all() and float(new.abs().max()) > 0
+        if n_rays * s < 200000:
+            full = ops.nerf_mlp_fwd(t(rayo), t(rayd), t(z), ops.pack_nerf_weights(ks, bs).to(cuda))
+            assert torch.equal(new, full[..., 3])
+
+
 def test_sigma_gradient_normals_vs_autograd(nfx_lib, cuda):
     """n = -normalize(d relu(sigma)/dx) (geometry_from_nerf.py:289-297) against torch autograd through the network
     evaluated with the kernel's bf16 operand rounding (straight-through), and loosely against plain fp64."""
