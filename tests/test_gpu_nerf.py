@@ -500,7 +500,7 @@ def test_sigma_only_kernel_is_the_full_kernel_s_density(nfx_lib, cuda):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
-@pytest.mark.parametrize("weights,n_rays,s", [("fitted", 900, 70), ("glorot", 301, 9), ("fitted", 40, 320)])
+@pytest.mark.parametrize("weights,n_rays,s", [("fitted", 900, 70), ("glorot", 301, 9), ("fitted", 40, 320), ("fitted-outside", 77, 33)])
 def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_lib, cuda, nfx_opt, prec, weights, n_rays, s):
     """ops.nerf_sigma_grad runs the reverse sweep only over the samples with a positive raw density (nfx_nerf_sigma_grad_rows:
     forward-only density of every sample, device-side ascending list, gradient kernel over the list; d relu(sigma)/dx of every
@@ -509,7 +509,7 @@ def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_
     writes g * 0 with g's sign, the list form -0); the list is exactly the samples with sigma_raw > 0."""
     from nerfactor_amd import ops
     from tests.golden import golden_inputs as gi
-    net = gi.trained_nerf_nets()[1] if weights == "fitted" else common.nerf_nets(seed=8)[1]
+    net = gi.trained_nerf_nets()[1] if weights.startswith("fitted") else common.nerf_nets(seed=8)[1]
     ks, bs = common.nerf_layers(net)
     gblob = ops.pack_nerf_geom_weights(ks, bs, prec).to(cuda)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda)
@@ -519,6 +519,11 @@ def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_
         rayo, rayd = rayo[:n_rays], rayd[:n_rays]
         rayd = rayd / np.linalg.norm(rayd, axis=1, keepdims=True)
         z = np.sort(np.random.default_rng(5).uniform(2., 6., size=(n_rays, s)).astype(np.float32), 1)
+    elif weights == "fitted-outside":      # samples in front of the scene only: (almost) nothing has a density — the list may be empty
+        rayo, rayd = common.camera_rays(9, 9, cam_loc=(1.9, -2.8, 2.1))
+        rayo, rayd = rayo[:n_rays], rayd[:n_rays]
+        rayd = rayd / np.linalg.norm(rayd, axis=1, keepdims=True)
+        z = np.sort(np.random.default_rng(6).uniform(0.05, 1.5, size=(n_rays, s)).astype(np.float32), 1)
     else:
         rayo, rayd, z = _geom_inputs(n_rays, s, 2)
     args = (t(rayo), t(rayd), t(z), gblob, prec)
@@ -539,7 +544,11 @@ def test_sigma_gradient_over_the_samples_with_a_density_equals_every_sample(nfx_
     listed = (s0 > 0)[..., None].expand_as(n0)
     assert torch.equal(n1[listed].view(torch.int32), n0[listed].view(torch.int32))
     assert float(n1[~listed].abs().max() if (~listed).any() else 0.) == 0.
-    assert torch.isfinite(n1).all() and int(count.item()) > 0 and float(n1.abs().max()) > 0.5
+    assert torch.isfinite(n1).all()
+    if weights != "fitted-outside":
+        assert int(count.item()) > 0 and float(n1.abs().max()) > 0.5
+    else:
+        print("samples with a density in front of the scene: %d of %d" % (int(count.item()), total))
 
 
 @pytest.mark.determinism
