@@ -125,6 +125,7 @@ d, l = g["depth_normal"], g["light_visibility"]
 print("sigma_variant=$r", {k: d.get(k) for k in ("ms_per_view", "rays_per_s")}, {k: d["roofline"].get(k) for k in ("frac", "kernels_ms_per_view")}, "| shadow rays", {k: l.get(k) for k in ("ms", "pairs_per_s", "full_view_estimate_s")}, {k: l["roofline"].get(k) for k in ("frac", "kernels_ms")})
 PYEOF
       tail -2 $OUT/bench_geometry_sv$r.err; done; done ;;
+    soak-sigma-v6) timeout ${SOAK_TIMEOUT:-900} python scripts/soak_sigma_v6.py --launches ${SOAK_LAUNCHES:-2000} > $OUT/soak_sigma_v6.log 2>&1; tail -4 $OUT/soak_sigma_v6.log ;;
     nerf-bwd-rows) timeout 600 python scripts/nerf_bwd_rows.py > $OUT/nerf_bwd_rows.json 2> $OUT/nerf_bwd_rows.err; cat $OUT/nerf_bwd_rows.json; tail -3 $OUT/nerf_bwd_rows.err ;;
     bench-train-fp32) for m in nerfactor_microfacet nerfactor nerf shape; do for fm in "pairs" "pairs --graph" "native"; do timeout 300 python scripts/bench_train.py --model $m --precision fp32 --fp32-matrix $fm --steps 10 >> $OUT/bench_train_fp32.jsonl 2>> $OUT/bench_train_fp32.err; done; done; cat $OUT/bench_train_fp32.jsonl; tail -3 $OUT/bench_train_fp32.err ;;
     bench-train-unfused) NFX_WGRAD_FUSED=0 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --legs train --no-cpu-baseline --train-models nerfactor_microfacet > $OUT/bench_train_unfused.json 2> $OUT/bench_train_unfused.err; tail -c 1500 $OUT/bench_train_unfused.json ;;
