@@ -313,7 +313,11 @@ NFX_API int nfx_composite_bwd(const float *dev_rgbs, const float *dev_z, const f
  * ACCUMULATES the gradients of the 12 Keras kernels / biases (order of nfx_nerf_pack_weights) into
  * dev_dkernels[i] ([in, out] fp32) / dev_dbiases[i].  The forward is re-computed inside; `blob` is the TRAIN
  * blob (forward + dgrad fragments).  Workspace: nfx_nerf_bwd_workspace_bytes() bytes (feature-major bf16
- * activations and pre-activation gradients, ~10 KB per sample point), 16-byte aligned.  No input gradients. */
+ * activations and pre-activation gradients, ~10 KB per sample point), 16-byte aligned.  No input gradients.
+ * Round 6: a point whose dev_d_rgbs row is four zeros (a sample the composite gave no weight: nerf.py:236-239) adds nothing
+ * to any gradient and is skipped — the library lists the other points on the device, in ascending order, and works on
+ * those (calls of >= 16384 points; option nerf_bwd_rows = 0: every point).  The sums are the same, their fp32 order
+ * differs from the every-point form's; run-to-run the bits are identical.                                        */
 NFX_API size_t nfx_nerf_train_packed_bytes(int prec);
 NFX_API int nfx_nerf_pack_train_weights(const float *const kernels[12], const float *const biases[12],
                                 int prec, void *blob, size_t blob_bytes);
