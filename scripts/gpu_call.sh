@@ -3,7 +3,11 @@
 #   bash scripts/gpu_call.sh <tag> stage [stage ...]
 # stages: bench-driver | rccl | pytest | pytest-x | pytest-k (PYTEST_K=expr) | smoke | bench | bench-norefine | bench-train | bench-train-unfused |
 #         bench-train-fp32 | soak | sigma | fitted | generic | prof | train-prof | train-prof-fp32 | pmc | pmc-train | pmc-sq2 |
-#         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair | bench-train-nerf-ab | prof-train-nerf
+#         bench-legs (LEGS=..., LEGS_TAG=...) | step-trace (TRACE_MODEL=...) | ubench-pair
+#   round 6, second half (one option A / B'd per stage on one box: NFX_<OPTION>=0 / 1 through the binding):
+#         bench-train-nerf-ab (nerf_bwd_rows) | wgrad-slabs-sweep (SLABS=...) | wgrad-rounds-ab | nerf-streams-ab | nerf-bwd-rows |
+#         prof-train-nerf | prof-nerf-bwd-rows (NBR_KIND=fitted|glorot) | geometry-ab (sigma_grad_rows) | sigma-variant-ab |
+#         soak-nerf-bwd | soak-sigma-v6 (SOAK_LAUNCHES=...)
 #   A / B stages (experiment builds: NFX_EXTRA_DEFS=... python -m nerfactor_amd.build --out nerfactor_amd/libnfx_xpX.so):
 #         fused-ab (AB_LIBS=...) | ring-ab (RING_LIBS=...) | generic-ab | splits-ab | generic-prof | generic-pmc
 set -u
