@@ -40,8 +40,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this driver stack shares memory through dmabuf only: without it RCCL's start-up fails with
+# "hipIpcGetMemHandle: invalid argument".  Read by the runtime when it starts — so before torch is imported; the ranks
+# bench.py launches for --gpus N inherit it.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
