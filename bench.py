@@ -916,7 +916,7 @@ def nerf_fitted_train_step(ops, dev, n, optim, get_model_class, make_config, ste
             ops.NERF_BWD_STATS = None
     listed = ops._capi.get_option('nerf_bwd_rows') != 0
     before = count()
-    step = optim.GraphedTrainStep(model, opt, n)
+    step = optim.GraphedTrainStep(model, opt, n, capture_collective=True)      # (one process; --force-group: the all-reduce is captured too)
     for _ in range(6):
         step(batch)
     torch.cuda.synchronize()
