@@ -44,8 +44,27 @@ def init_from_env(backend=None, device=None, force=False):
         kwargs = {}
         if backend == 'nccl' and device is not None:
             kwargs['device_id'] = device
-        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+        with _stdout_to_stderr():      # (gloo announces its connections on the C-level stdout: a bench line must stay the only line there)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world
+
+
+class _stdout_to_stderr:
+    """File descriptor 1 points at descriptor 2 inside the block (what native libraries print, not only sys.stdout)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def world():
